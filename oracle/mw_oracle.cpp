@@ -1,0 +1,1515 @@
+// =====================================================================================================
+// mw_oracle.cpp -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// A plain, serial, loop-nest-per-kernel restatement of the miniWeatherML hot path
+// (Dynamics_Euler_Stratified_WenoFV::time_step, Microphysics_Kessler::time_step, the ponni 5->10->4 MLP)
+// used ONLY as the checker in tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+// The product (miniweatherml_amd/, include/) never includes, links, imports or executes this file.
+//
+// PINNING STATUS
+//   * The reference itself is UNBUILDABLE in this image: its three git submodules (external/YAKL,
+//     external/ponni, external/yaml-cpp; /root/reference/.gitmodules:1-9) are empty, it needs
+//     Fortran + (P)NetCDF, and the build rules forbid writing stand-ins for absent headers.  There is
+//     therefore no oracle/_ref.
+//   * The reference ships no tests, golden vectors or fixtures.
+//   * Dycore + init + perturb_temperature: pinned against the reference-run known answers the survey
+//     recorded in BASELINE.md section 2 (32x32x16 supercell + bubble, 3 dycore steps: wvel max/min,
+//     temp max, sum(density_dry) before/after, all 18 significant digits) and the WenoLimiter<5> facts in
+//     SURVEY.md section 4 (convexified ideal weights, degree<=2 exactness, step-stencil behaviour).
+//     See tests/test_oracle_known_answers.py.
+//   * Kessler: PARITY UNPINNED (no reference output of the isolated module is recorded anywhere).
+//   * MLP (ponni source absent): PARITY UNPINNED; restated from the call sites and Keras Dense semantics.
+//
+// Every function cites the reference file:line it follows (paths relative to /root/reference/).
+// All arithmetic is IEEE fp64 in the reference's operation order; compile with -O2 -ffp-contract=off
+// (x86-64 baseline emits no FMA) so the result is the serial-backend result of the reference code.
+// Literals written `x_fp` in the reference go through `long double` first (model/main_header.h:61-63);
+// FP(x) below reproduces that double rounding.
+// =====================================================================================================
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <cstdio>
+#include <random>
+#include <algorithm>
+
+#define FP(x) ((double)(x##L))
+
+typedef double real;
+
+static const int hs  = 2;   // dynamics_euler_stratified_wenofv.h:29  (ord = 5)
+static const int ord = 5;   // :25
+static const int num_state = 5;          // :31
+enum { idR = 0, idU = 1, idV = 2, idW = 3, idT = 4 };       // :34-38
+enum { DATA_THERMAL = 0, DATA_SUPERCELL = 1, DATA_CITY = 2, DATA_BUILDING = 3 };  // :41-44
+enum { BC_PERIODIC = 0, BC_OPEN = 1, BC_WALL = 2 };          // :46-48
+
+extern "C" {
+
+// Exchange callback: kind 0 = halo (hs cells deep), kind 1 = edge (1 value deep).
+// send/recv buffers are laid out exactly as the reference's MPI buffers
+// (dynamics_euler_stratified_wenofv.h:603-639 and :861-895).  nWE / nSN = element counts.
+typedef void (*mwo_xchg_fn)(void *ctx, int kind,
+                            const double *sendW, const double *sendE, const double *sendS, const double *sendN,
+                            double *recvW, double *recvE, double *recvS, double *recvN,
+                            long long nWE, long long nSN);
+
+typedef struct {
+  int nz, ny, nx, nens, num_tracers;           // local sizes
+  long long nx_glob, ny_glob, i_beg, j_beg;    // coupler.h:147-153
+  double xlen, ylen, zlen;
+  int px, py, nproc_x, nproc_y;
+  int bc_x, bc_y, bc_z;
+  int use_immersed, enable_gravity;
+  int idWV;
+  double R_d, R_v, cp_d, cp_v, p0, grav, gamma_d, kappa_d, C0, earthrot, latitude;
+} mwo_params;
+
+typedef struct {
+  mwo_params p;
+  int  *tracer_positive, *tracer_adds_mass;
+  double *hy_dens_cells, *hy_dens_theta_cells;   // (nz  ,nens)
+  double *hy_dens_edges, *hy_dens_theta_edges;   // (nz+1,nens)
+  double *immersed_proportion;                   // (nz,ny,nx,nens)
+  double *state_flux_x, *state_flux_y, *state_flux_z;       // (5,nz[+1],ny[+1],nx[+1],nens)
+  double *tracers_flux_x, *tracers_flux_y, *tracers_flux_z; // (T,...)
+  double etime;
+  mwo_xchg_fn xchg; void *xchg_ctx;
+} mwo_dycore;
+
+} // extern "C"
+
+// -----------------------------------------------------------------------------------------------------
+// WENO limiter, ord = 5.   helpers/WenoLimiter.h:53-93 and helpers/WenoLimiter_recon.h
+// -----------------------------------------------------------------------------------------------------
+static inline void convexify4(real &w1, real &w2, real &w3, real &w4) {  // WenoLimiter_recon.h:12-15
+  real tot = w1 + w2 + w3 + w4;
+  if (tot > 1.e-20) { w1 /= tot;   w2 /= tot;   w3 /= tot;   w4 /= tot; }
+}
+static inline real TV3(const real *a) {   // WenoLimiter_recon.h:37-42
+  return FP(1.0000000000000000000000000000000000000)*(a[1]*a[1])+FP(4.3333333333333333333333333333333333333)*(a[2]*a[2]);
+}
+static inline real TV5(const real *a) {   // WenoLimiter_recon.h:51-56
+  return FP(1.0000000000000000000000000000000000000)*(a[1]*a[1])+FP(4.3333333333333333333333333333333333333)*(a[2]*a[2])
+        +FP(0.50000000000000000000000000000000000000)*a[1]*a[3]+FP(39.112500000000000000000000000000000000)*(a[3]*a[3])
+        +FP(4.2000000000000000000000000000000000000)*a[2]*a[4]+FP(625.83571428571428571428571428571428571)*(a[4]*a[4]);
+}
+static inline void coefs3_shift1(real *c, real v0, real v1, real v2) {  // WenoLimiter_recon.h:84-89
+  c[0]=-FP(0.041666666666666666666666666666666666667)*v0+FP(0.083333333333333333333333333333333333333)*v1+FP(0.95833333333333333333333333333333333333)*v2;
+  c[1]=FP(0.50000000000000000000000000000000000000)*v0-FP(2.0000000000000000000000000000000000000)*v1+FP(1.5000000000000000000000000000000000000)*v2;
+  c[2]=FP(0.50000000000000000000000000000000000000)*v0-FP(1.0000000000000000000000000000000000000)*v1+FP(0.50000000000000000000000000000000000000)*v2;
+}
+static inline void coefs3_shift2(real *c, real v0, real v1, real v2) {  // WenoLimiter_recon.h:91-96
+  c[0]=-FP(0.041666666666666666666666666666666666667)*v0+FP(1.0833333333333333333333333333333333333)*v1-FP(0.041666666666666666666666666666666666667)*v2;
+  c[1]=-FP(0.50000000000000000000000000000000000000)*v0+FP(0.50000000000000000000000000000000000000)*v2;
+  c[2]=FP(0.50000000000000000000000000000000000000)*v0-FP(1.0000000000000000000000000000000000000)*v1+FP(0.50000000000000000000000000000000000000)*v2;
+}
+static inline void coefs3_shift3(real *c, real v0, real v1, real v2) {  // WenoLimiter_recon.h:98-103
+  c[0]=FP(0.95833333333333333333333333333333333333)*v0+FP(0.083333333333333333333333333333333333333)*v1-FP(0.041666666666666666666666666666666666667)*v2;
+  c[1]=-FP(1.5000000000000000000000000000000000000)*v0+FP(2.0000000000000000000000000000000000000)*v1-FP(0.50000000000000000000000000000000000000)*v2;
+  c[2]=FP(0.50000000000000000000000000000000000000)*v0-FP(1.0000000000000000000000000000000000000)*v1+FP(0.50000000000000000000000000000000000000)*v2;
+}
+static inline void coefs5_shift3(real *c, real v0, real v1, real v2, real v3, real v4) {  // WenoLimiter_recon.h:155-162
+  c[0]=FP(0.0046875000000000000000000000000000000000)*v0-FP(0.060416666666666666666666666666666666667)*v1+FP(1.1114583333333333333333333333333333333)*v2-FP(0.060416666666666666666666666666666666667)*v3+FP(0.0046875000000000000000000000000000000000)*v4;
+  c[1]=FP(0.10416666666666666666666666666666666667)*v0-FP(0.70833333333333333333333333333333333333)*v1+FP(0.70833333333333333333333333333333333333)*v3-FP(0.10416666666666666666666666666666666667)*v4;
+  c[2]=-FP(0.062500000000000000000000000000000000000)*v0+FP(0.75000000000000000000000000000000000000)*v1-FP(1.3750000000000000000000000000000000000)*v2+FP(0.75000000000000000000000000000000000000)*v3-FP(0.062500000000000000000000000000000000000)*v4;
+  c[3]=-FP(0.083333333333333333333333333333333333333)*v0+FP(0.16666666666666666666666666666666666667)*v1-FP(0.16666666666666666666666666666666666667)*v3+FP(0.083333333333333333333333333333333333333)*v4;
+  c[4]=FP(0.041666666666666666666666666666666666667)*v0-FP(0.16666666666666666666666666666666666667)*v1+FP(0.25000000000000000000000000000000000000)*v2-FP(0.16666666666666666666666666666666666667)*v3+FP(0.041666666666666666666666666666666666667)*v4;
+}
+
+struct Weno5 {   // WenoLimiter.h:53-66: default ctor arguments cutoff 0, idl 1,2,1,1e3, convexified
+  real cutoff, idl_L, idl_C, idl_R, idl_H;
+  Weno5() { cutoff = 0; idl_L = 1; idl_C = 2; idl_R = 1; idl_H = 1.e3; convexify4(idl_L, idl_C, idl_R, idl_H); }
+  void compute_limited_coefs(const real *s, real *coefs_H) const {   // WenoLimiter.h:68-93
+    real coefs_L[3], coefs_C[3], coefs_R[3];
+    coefs3_shift1( coefs_L , s[0] , s[1] , s[2] );
+    coefs3_shift2( coefs_C , s[1] , s[2] , s[3] );
+    coefs3_shift3( coefs_R , s[2] , s[3] , s[4] );
+    coefs5_shift3( coefs_H , s[0] , s[1] , s[2] , s[3] , s[4] );
+    real w_L = TV3( coefs_L );
+    real w_C = TV3( coefs_C );
+    real w_R = TV3( coefs_R );
+    real w_H = TV5( coefs_H );
+    convexify4( w_L , w_C , w_R , w_H );
+    w_L = idl_L / (w_L*w_L + 1.e-20);
+    w_C = idl_C / (w_C*w_C + 1.e-20);
+    w_R = idl_R / (w_R*w_R + 1.e-20);
+    w_H = idl_H / (w_H*w_H + 1.e-20);
+    convexify4( w_L , w_C , w_R , w_H );
+    if (w_L <= cutoff) w_L = 0;
+    if (w_C <= cutoff) w_C = 0;
+    if (w_R <= cutoff) w_R = 0;
+    convexify4( w_L , w_C , w_R , w_H );
+    coefs_H[0] = coefs_H[0]*w_H + coefs_L[0]*w_L + coefs_C[0]*w_C + coefs_R[0]*w_R;
+    coefs_H[1] = coefs_H[1]*w_H + coefs_L[1]*w_L + coefs_C[1]*w_C + coefs_R[1]*w_R;
+    coefs_H[2] = coefs_H[2]*w_H + coefs_L[2]*w_L + coefs_C[2]*w_C + coefs_R[2]*w_R;
+    coefs_H[3] = coefs_H[3]*w_H;
+    coefs_H[4] = coefs_H[4]*w_H;
+  }
+};
+
+// TransformMatrices.h:1132-1144  coefs_to_gll_lower(SArray<FP,2,5,2>)  (c2g[s][ii])
+static const real coefs_to_gll[5][2] = { {1,1}, {-0.5,0.5}, {0.25,0.25}, {-0.125,0.125}, {0.0625,0.0625} };
+// TransformMatrices.h:650-665  get_gll_points / get_gll_weights (SArray<FP,1,5>) -- plain double literals
+static const real gll_pts[5] = { -0.50000000000000000000000000000000000000, -0.32732683535398857189914622812342917778,
+                                  0.00000000000000000000000000000000000000,  0.32732683535398857189914622812342917778,
+                                  0.50000000000000000000000000000000000000 };
+static const real gll_wts[5] = { 0.050000000000000000000000000000000000000, 0.27222222222222222222222222222222222222,
+                                 0.35555555555555555555555555555555555556, 0.27222222222222222222222222222222222222,
+                                 0.050000000000000000000000000000000000000 };
+// TransformMatrices.h:4113-4137  9-point GLL rule (city / building init)
+static const real gll_pts9[9] = { -0.50000000000000000000000000000000000000, -0.44987899770573007865617262220916897903,
+  -0.33859313975536887672294271354567122536, -0.18155873191308907935537603435432960651, 0.00000000000000000000000000000000000000,
+   0.18155873191308907935537603435432960651,  0.33859313975536887672294271354567122536, 0.44987899770573007865617262220916897903,
+   0.50000000000000000000000000000000000000 };
+static const real gll_wts9[9] = { 0.013888888888888888888888888888888888889, 0.082747680780402762523169860014604152919,
+   0.13726935625008086764035280928968636297, 0.17321425548652317255756576606985914397, 0.18575963718820861678004535147392290249,
+   0.17321425548652317255756576606985914397, 0.13726935625008086764035280928968636297, 0.082747680780402762523169860014604152919,
+   0.013888888888888888888888888888888888889 };
+
+// dynamics_euler_stratified_wenofv.h:556-571
+static inline void reconstruct_gll_values(const real *stencil, real *gll, const Weno5 &limiter) {
+  real wenoCoefs[5];
+  limiter.compute_limited_coefs( stencil , wenoCoefs );
+  for (int ii=0; ii<2; ii++) {
+    real tmp = 0;
+    for (int s=0; s < ord; s++) { tmp += coefs_to_gll[s][ii] * wenoCoefs[s]; }
+    gll[ii] = tmp;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Array index helpers (C row-major, last index fastest)
+// -----------------------------------------------------------------------------------------------------
+struct Dims {
+  int nz, ny, nx, nens, nt;
+  size_t sz, sy, sx;          // strides of halo'd (.,nz+2hs,ny+2hs,nx+2hs,nens) arrays
+  size_t svar;
+  explicit Dims(const mwo_params &p) : nz(p.nz), ny(p.ny), nx(p.nx), nens(p.nens), nt(p.num_tracers) {
+    sx = nens; sy = (size_t)(nx+2*hs)*sx; sz = (size_t)(ny+2*hs)*sy; svar = (size_t)(nz+2*hs)*sz;
+  }
+  inline size_t H(int l, int k, int j, int i, int e) const { return l*svar + k*sz + j*sy + i*sx + e; }       // halo'd
+  inline size_t C(int k, int j, int i, int e) const { return (((size_t)k*ny + j)*nx + i)*nens + e; }          // (nz,ny,nx,nens)
+  inline size_t T(int l, int k, int j, int i, int e) const { return ((((size_t)l*nz + k)*ny + j)*nx + i)*nens + e; } // tend
+  // limits (l,2,nz+dz,ny+dy,nx+dx,nens)
+  inline size_t LX(int l,int s,int k,int j,int i,int e) const { return (((((size_t)l*2+s)*nz    +k)*ny    +j)*(nx+1)+i)*nens+e; }
+  inline size_t LY(int l,int s,int k,int j,int i,int e) const { return (((((size_t)l*2+s)*nz    +k)*(ny+1)+j)*nx    +i)*nens+e; }
+  inline size_t LZ(int l,int s,int k,int j,int i,int e) const { return (((((size_t)l*2+s)*(nz+1)+k)*ny    +j)*nx    +i)*nens+e; }
+  // fluxes (l,nz+dz,ny+dy,nx+dx,nens)
+  inline size_t FX(int l,int k,int j,int i,int e) const { return ((((size_t)l*nz    +k)*ny    +j)*(nx+1)+i)*nens+e; }
+  inline size_t FY(int l,int k,int j,int i,int e) const { return ((((size_t)l*nz    +k)*(ny+1)+j)*nx    +i)*nens+e; }
+  inline size_t FZ(int l,int k,int j,int i,int e) const { return ((((size_t)l*(nz+1)+k)*ny    +j)*nx    +i)*nens+e; }
+  size_t n_halo(int nv) const { return (size_t)nv*svar; }
+  size_t n_cells() const { return (size_t)nz*ny*nx*nens; }
+};
+
+static inline real get_dx(const mwo_params &p) { return p.xlen / p.nx_glob; }   // coupler.h:262
+static inline real get_dy(const mwo_params &p) { return p.ylen / p.ny_glob; }   // coupler.h:265
+static inline real get_dz(const mwo_params &p) { return p.zlen / p.nz; }        // coupler.h:268
+static inline bool is_sim2d(const mwo_params &p) { return p.ny_glob == 1; }     // coupler.h:236
+
+// Default exchange: one rank, periodic wrap == send to self (coupler.h:169-179 makes every neighbour "me").
+// What I send West arrives as my neighbour's East receive, and that neighbour is me.
+static void self_xchg(void *, int, const double *sW, const double *sE, const double *sS, const double *sN,
+                      double *rW, double *rE, double *rS, double *rN, long long nWE, long long nSN) {
+  memcpy(rE, sW, sizeof(double)*nWE);
+  memcpy(rW, sE, sizeof(double)*nWE);
+  if (nSN > 0) { memcpy(rN, sS, sizeof(double)*nSN); memcpy(rS, sN, sizeof(double)*nSN); }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// halo_exchange    dynamics_euler_stratified_wenofv.h:574-827
+// -----------------------------------------------------------------------------------------------------
+static void halo_exchange(const mwo_dycore *d, real *state, real *tracers) {
+  const mwo_params &p = d->p;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens, num_tracers=p.num_tracers;
+  bool sim2d = is_sim2d(p);
+  int npack = num_state + num_tracers;
+  size_t nWE = (size_t)npack*nz*ny*hs*nens, nSN = (size_t)npack*nz*hs*nx*nens;
+  real *sW=(real*)malloc(8*nWE), *sE=(real*)malloc(8*nWE), *rW=(real*)malloc(8*nWE), *rE=(real*)malloc(8*nWE);
+  real *sS=(real*)malloc(8*nSN), *sN=(real*)malloc(8*nSN), *rS=(real*)malloc(8*nSN), *rN=(real*)malloc(8*nSN);
+  #define BWE(v,k,j,ii,e) (((((size_t)(v)*nz+(k))*ny+(j))*hs+(ii))*nens+(e))
+  #define BSN(v,k,jj,i,e) (((((size_t)(v)*nz+(k))*hs+(jj))*nx+(i))*nens+(e))
+  // :606-615
+  for (int v=0; v<npack; v++) for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int ii=0;ii<hs;ii++) for (int e=0;e<nens;e++) {
+    if (v < num_state) {
+      sW[BWE(v,k,j,ii,e)] = state  [D.H(v          ,hs+k,hs+j,hs+ii,e)];
+      sE[BWE(v,k,j,ii,e)] = state  [D.H(v          ,hs+k,hs+j,nx+ii,e)];
+    } else {
+      sW[BWE(v,k,j,ii,e)] = tracers[D.H(v-num_state,hs+k,hs+j,hs+ii,e)];
+      sE[BWE(v,k,j,ii,e)] = tracers[D.H(v-num_state,hs+k,hs+j,nx+ii,e)];
+    }
+  }
+  // :620-631
+  if (!sim2d) {
+    for (int v=0; v<npack; v++) for (int k=0;k<nz;k++) for (int jj=0;jj<hs;jj++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+      if (v < num_state) {
+        sS[BSN(v,k,jj,i,e)] = state  [D.H(v          ,hs+k,hs+jj,hs+i,e)];
+        sN[BSN(v,k,jj,i,e)] = state  [D.H(v          ,hs+k,ny+jj,hs+i,e)];
+      } else {
+        sS[BSN(v,k,jj,i,e)] = tracers[D.H(v-num_state,hs+k,hs+jj,hs+i,e)];
+        sN[BSN(v,k,jj,i,e)] = tracers[D.H(v-num_state,hs+k,ny+jj,hs+i,e)];
+      }
+    }
+  }
+  // :641-723  MPI Irecv/Isend with the four face neighbours (no corners)
+  d->xchg(d->xchg_ctx, 0, sW, sE, sS, sN, rW, rE, rS, rN, (long long)nWE, sim2d ? 0 : (long long)nSN);
+  // :725-734
+  for (int v=0; v<npack; v++) for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int ii=0;ii<hs;ii++) for (int e=0;e<nens;e++) {
+    if (v < num_state) {
+      state  [D.H(v          ,hs+k,hs+j,      ii,e)] = rW[BWE(v,k,j,ii,e)];
+      state  [D.H(v          ,hs+k,hs+j,nx+hs+ii,e)] = rE[BWE(v,k,j,ii,e)];
+    } else {
+      tracers[D.H(v-num_state,hs+k,hs+j,      ii,e)] = rW[BWE(v,k,j,ii,e)];
+      tracers[D.H(v-num_state,hs+k,hs+j,nx+hs+ii,e)] = rE[BWE(v,k,j,ii,e)];
+    }
+  }
+  // :736-747
+  if (!sim2d) {
+    for (int v=0; v<npack; v++) for (int k=0;k<nz;k++) for (int jj=0;jj<hs;jj++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+      if (v < num_state) {
+        state  [D.H(v          ,hs+k,      jj,hs+i,e)] = rS[BSN(v,k,jj,i,e)];
+        state  [D.H(v          ,hs+k,ny+hs+jj,hs+i,e)] = rN[BSN(v,k,jj,i,e)];
+      } else {
+        tracers[D.H(v-num_state,hs+k,      jj,hs+i,e)] = rS[BSN(v,k,jj,i,e)];
+        tracers[D.H(v-num_state,hs+k,ny+hs+jj,hs+i,e)] = rN[BSN(v,k,jj,i,e)];
+      }
+    }
+  }
+  #undef BWE
+  #undef BSN
+  free(sW); free(sE); free(rW); free(rE); free(sS); free(sN); free(rS); free(rN);
+  int bc_x=p.bc_x, bc_y=p.bc_y, bc_z=p.bc_z, px=p.px, py=p.py, nproc_x=p.nproc_x, nproc_y=p.nproc_y;
+  // :752-781
+  if (bc_z == BC_PERIODIC) {
+    for (int kk=0;kk<hs;kk++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+      for (int l=0; l < num_state; l++) {
+        state[D.H(l,      kk,hs+j,hs+i,e)] = state[D.H(l,      kk+nz,hs+j,hs+i,e)];
+        state[D.H(l,hs+nz+kk,hs+j,hs+i,e)] = state[D.H(l,hs+nz+kk-nz,hs+j,hs+i,e)];
+      }
+      for (int l=0; l < num_tracers; l++) {
+        tracers[D.H(l,      kk,hs+j,hs+i,e)] = tracers[D.H(l,      kk+nz,hs+j,hs+i,e)];
+        tracers[D.H(l,hs+nz+kk,hs+j,hs+i,e)] = tracers[D.H(l,hs+nz+kk-nz,hs+j,hs+i,e)];
+      }
+    }
+  } else if (bc_z == BC_WALL || bc_z == BC_OPEN) {
+    for (int kk=0;kk<hs;kk++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+      for (int l=0; l < num_state; l++) {
+        if (l == idW && bc_z == BC_WALL) {
+          state[D.H(l,      kk,hs+j,hs+i,e)] = 0;
+          state[D.H(l,hs+nz+kk,hs+j,hs+i,e)] = 0;
+        } else {
+          state[D.H(l,      kk,hs+j,hs+i,e)] = state[D.H(l,hs+0   ,hs+j,hs+i,e)];
+          state[D.H(l,hs+nz+kk,hs+j,hs+i,e)] = state[D.H(l,hs+nz-1,hs+j,hs+i,e)];
+        }
+      }
+      for (int l=0; l < num_tracers; l++) {
+        tracers[D.H(l,      kk,hs+j,hs+i,e)] = tracers[D.H(l,hs+0   ,hs+j,hs+i,e)];
+        tracers[D.H(l,hs+nz+kk,hs+j,hs+i,e)] = tracers[D.H(l,hs+nz-1,hs+j,hs+i,e)];
+      }
+    }
+  }
+  // :782-803
+  if (bc_x == BC_WALL || bc_x == BC_OPEN) {
+    if (px == 0) {
+      for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int ii=0;ii<hs;ii++) for (int e=0;e<nens;e++) {
+        for (int l=0; l < num_state; l++) {
+          if (l == idU && bc_x == BC_WALL) { state[D.H(l,hs+k,hs+j,ii,e)] = 0; }
+          else                             { state[D.H(l,hs+k,hs+j,ii,e)] = state[D.H(l,hs+k,hs+j,hs+0,e)]; }
+        }
+        for (int l=0; l < num_tracers; l++) { tracers[D.H(l,hs+k,hs+j,ii,e)] = tracers[D.H(l,hs+k,hs+j,hs+0,e)]; }
+      }
+    }
+    if (px == nproc_x-1) {
+      for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int ii=0;ii<hs;ii++) for (int e=0;e<nens;e++) {
+        for (int l=0; l < num_state; l++) {
+          if (l == idU && bc_x == BC_WALL) { state[D.H(l,hs+k,hs+j,hs+nx+ii,e)] = 0; }
+          else                             { state[D.H(l,hs+k,hs+j,hs+nx+ii,e)] = state[D.H(l,hs+k,hs+j,hs+nx-1,e)]; }
+        }
+        for (int l=0; l < num_tracers; l++) { tracers[D.H(l,hs+k,hs+j,hs+nx+ii,e)] = tracers[D.H(l,hs+k,hs+j,hs+nx-1,e)]; }
+      }
+    }
+  }
+  // :804-825
+  if (bc_y == BC_WALL || bc_y == BC_OPEN) {
+    if (py == 0) {
+      for (int k=0;k<nz;k++) for (int jj=0;jj<hs;jj++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+        for (int l=0; l < num_state; l++) {
+          if (l == idV && bc_y == BC_WALL) { state[D.H(l,hs+k,jj,hs+i,e)] = 0; }
+          else                             { state[D.H(l,hs+k,jj,hs+i,e)] = state[D.H(l,hs+k,hs+0,hs+i,e)]; }
+        }
+        for (int l=0; l < num_tracers; l++) { tracers[D.H(l,hs+k,jj,hs+i,e)] = tracers[D.H(l,hs+k,hs+0,hs+i,e)]; }
+      }
+    }
+    if (py == nproc_y-1) {
+      for (int k=0;k<nz;k++) for (int jj=0;jj<hs;jj++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+        for (int l=0; l < num_state; l++) {
+          if (l == idV && bc_y == BC_WALL) { state[D.H(l,hs+k,hs+ny+jj,hs+i,e)] = 0; }
+          else                             { state[D.H(l,hs+k,hs+ny+jj,hs+i,e)] = state[D.H(l,hs+k,hs+ny-1,hs+i,e)]; }
+        }
+        for (int l=0; l < num_tracers; l++) { tracers[D.H(l,hs+k,hs+ny+jj,hs+i,e)] = tracers[D.H(l,hs+k,hs+ny-1,hs+i,e)]; }
+      }
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// edge_exchange    dynamics_euler_stratified_wenofv.h:830-1082
+// -----------------------------------------------------------------------------------------------------
+static void edge_exchange(const mwo_dycore *d, real *slx, real *tlx, real *sly, real *tly, real *slz, real *tlz) {
+  const mwo_params &p = d->p;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens, num_tracers=p.num_tracers;
+  bool sim2d = is_sim2d(p);
+  int npack = num_state + num_tracers;
+  size_t nWE = (size_t)npack*nz*ny*nens, nSN = (size_t)npack*nz*nx*nens;
+  real *sW=(real*)malloc(8*nWE), *sE=(real*)malloc(8*nWE), *rW=(real*)malloc(8*nWE), *rE=(real*)malloc(8*nWE);
+  real *sS=(real*)malloc(8*nSN), *sN=(real*)malloc(8*nSN), *rS=(real*)malloc(8*nSN), *rN=(real*)malloc(8*nSN);
+  #define BWE(v,k,j,e) ((((size_t)(v)*nz+(k))*ny+(j))*nens+(e))
+  #define BSN(v,k,i,e) ((((size_t)(v)*nz+(k))*nx+(i))*nens+(e))
+  // :864-872
+  for (int v=0; v<npack; v++) for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int e=0;e<nens;e++) {
+    if (v < num_state) {
+      sW[BWE(v,k,j,e)] = slx[D.LX(v          ,1,k,j,0 ,e)];
+      sE[BWE(v,k,j,e)] = slx[D.LX(v          ,0,k,j,nx,e)];
+    } else {
+      sW[BWE(v,k,j,e)] = tlx[D.LX(v-num_state,1,k,j,0 ,e)];
+      sE[BWE(v,k,j,e)] = tlx[D.LX(v-num_state,0,k,j,nx,e)];
+    }
+  }
+  // :877-887
+  if (!sim2d) {
+    for (int v=0; v<npack; v++) for (int k=0;k<nz;k++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+      if (v < num_state) {
+        sS[BSN(v,k,i,e)] = sly[D.LY(v          ,1,k,0 ,i,e)];
+        sN[BSN(v,k,i,e)] = sly[D.LY(v          ,0,k,ny,i,e)];
+      } else {
+        sS[BSN(v,k,i,e)] = tly[D.LY(v-num_state,1,k,0 ,i,e)];
+        sN[BSN(v,k,i,e)] = tly[D.LY(v-num_state,0,k,ny,i,e)];
+      }
+    }
+  }
+  // :897-979
+  d->xchg(d->xchg_ctx, 1, sW, sE, sS, sN, rW, rE, rS, rN, (long long)nWE, sim2d ? 0 : (long long)nSN);
+  // :981-990
+  for (int v=0; v<npack; v++) for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int e=0;e<nens;e++) {
+    if (v < num_state) {
+      slx[D.LX(v          ,0,k,j,0 ,e)] = rW[BWE(v,k,j,e)];
+      slx[D.LX(v          ,1,k,j,nx,e)] = rE[BWE(v,k,j,e)];
+    } else {
+      tlx[D.LX(v-num_state,0,k,j,0 ,e)] = rW[BWE(v,k,j,e)];
+      tlx[D.LX(v-num_state,1,k,j,nx,e)] = rE[BWE(v,k,j,e)];
+    }
+  }
+  // :992-1003
+  if (!sim2d) {
+    for (int v=0; v<npack; v++) for (int k=0;k<nz;k++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+      if (v < num_state) {
+        sly[D.LY(v          ,0,k,0 ,i,e)] = rS[BSN(v,k,i,e)];
+        sly[D.LY(v          ,1,k,ny,i,e)] = rN[BSN(v,k,i,e)];
+      } else {
+        tly[D.LY(v-num_state,0,k,0 ,i,e)] = rS[BSN(v,k,i,e)];
+        tly[D.LY(v-num_state,1,k,ny,i,e)] = rN[BSN(v,k,i,e)];
+      }
+    }
+  }
+  #undef BWE
+  #undef BSN
+  free(sW); free(sE); free(rW); free(rE); free(sS); free(sN); free(rS); free(rN);
+  int bc_x=p.bc_x, bc_y=p.bc_y, bc_z=p.bc_z, px=p.px, py=p.py, nproc_x=p.nproc_x, nproc_y=p.nproc_y;
+  // :1008-1039
+  if (bc_z == BC_PERIODIC) {
+    for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+      for (int l=0; l < num_state; l++) {
+        slz[D.LZ(l,0,0 ,j,i,e)] = slz[D.LZ(l,0,nz,j,i,e)];
+        slz[D.LZ(l,1,nz,j,i,e)] = slz[D.LZ(l,1,0 ,j,i,e)];
+      }
+      for (int l=0; l < num_tracers; l++) {
+        tlz[D.LZ(l,0,0 ,j,i,e)] = tlz[D.LZ(l,0,nz,j,i,e)];
+        tlz[D.LZ(l,1,nz,j,i,e)] = tlz[D.LZ(l,1,0 ,j,i,e)];
+      }
+    }
+  } else if (bc_z == BC_WALL || bc_z == BC_OPEN) {
+    for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+      for (int l=0; l < num_state; l++) {
+        if (l == idW && bc_z == BC_WALL) {
+          slz[D.LZ(l,0,0 ,j,i,e)] = 0;
+          slz[D.LZ(l,1,0 ,j,i,e)] = 0;
+          slz[D.LZ(l,0,nz,j,i,e)] = 0;
+          slz[D.LZ(l,1,nz,j,i,e)] = 0;
+        } else {
+          slz[D.LZ(l,0,0 ,j,i,e)] = slz[D.LZ(l,1,0 ,j,i,e)];
+          slz[D.LZ(l,1,nz,j,i,e)] = slz[D.LZ(l,0,nz,j,i,e)];
+        }
+      }
+      for (int l=0; l < num_tracers; l++) {
+        tlz[D.LZ(l,0,0 ,j,i,e)] = tlz[D.LZ(l,1,0 ,j,i,e)];
+        tlz[D.LZ(l,1,nz,j,i,e)] = tlz[D.LZ(l,0,nz,j,i,e)];
+      }
+    }
+  }
+  // :1040-1060   NOTE the `else if` (quirk 1 of SURVEY 8(a)): with nproc_x == 1 only the low side is applied
+  if (bc_x == BC_WALL || bc_x == BC_OPEN) {
+    if (px == 0) {
+      for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int e=0;e<nens;e++) {
+        for (int l=0; l < num_state; l++) {
+          if (l == idU && bc_x == BC_WALL) { slx[D.LX(l,0,k,j,0,e)] = 0; slx[D.LX(l,1,k,j,0,e)] = 0; }
+          else                             { slx[D.LX(l,0,k,j,0,e)] = slx[D.LX(l,1,k,j,0,e)]; }
+        }
+        for (int l=0; l < num_tracers; l++) { tlx[D.LX(l,0,k,j,0,e)] = tlx[D.LX(l,1,k,j,0,e)]; }
+      }
+    } else if (px == nproc_x-1) {
+      for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int e=0;e<nens;e++) {
+        for (int l=0; l < num_state; l++) {
+          if (l == idU && bc_x == BC_WALL) { slx[D.LX(l,0,k,j,nx,e)] = 0; slx[D.LX(l,1,k,j,nx,e)] = 0; }
+          else                             { slx[D.LX(l,1,k,j,nx,e)] = slx[D.LX(l,0,k,j,nx,e)]; }
+        }
+        for (int l=0; l < num_tracers; l++) { tlx[D.LX(l,1,k,j,nx,e)] = tlx[D.LX(l,0,k,j,nx,e)]; }
+      }
+    }
+  }
+  // :1061-1081
+  if (bc_y == BC_WALL || bc_y == BC_OPEN) {
+    if (py == 0) {
+      for (int k=0;k<nz;k++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+        for (int l=0; l < num_state; l++) {
+          if (l == idV && bc_y == BC_WALL) { sly[D.LY(l,0,k,0,i,e)] = 0; sly[D.LY(l,1,k,0,i,e)] = 0; }
+          else                             { sly[D.LY(l,0,k,0,i,e)] = sly[D.LY(l,1,k,0,i,e)]; }
+        }
+        for (int l=0; l < num_tracers; l++) { tly[D.LY(l,0,k,0,i,e)] = tly[D.LY(l,1,k,0,i,e)]; }
+      }
+    } else if (py == nproc_y-1) {
+      for (int k=0;k<nz;k++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+        for (int l=0; l < num_state; l++) {
+          if (l == idV && bc_y == BC_WALL) { sly[D.LY(l,0,k,ny,i,e)] = 0; sly[D.LY(l,1,k,ny,i,e)] = 0; }
+          else                             { sly[D.LY(l,1,k,ny,i,e)] = sly[D.LY(l,0,k,ny,i,e)]; }
+        }
+        for (int l=0; l < num_tracers; l++) { tly[D.LY(l,1,k,ny,i,e)] = tly[D.LY(l,0,k,ny,i,e)]; }
+      }
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// compute_tendencies    dynamics_euler_stratified_wenofv.h:204-552
+// -----------------------------------------------------------------------------------------------------
+static void compute_tendencies(const mwo_dycore *d, real *state, real *state_tend, real *tracers, real *tracers_tend, real dt) {
+  const mwo_params &p = d->p;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens, num_tracers=p.num_tracers;
+  bool use_immersed_boundaries = p.use_immersed != 0;
+  real earthrot = p.earthrot;
+  real fcor = 2*earthrot*sin(p.latitude);                  // :213
+  real dx = get_dx(p), dy = get_dy(p), dz = get_dz(p);
+  bool sim2d = is_sim2d(p);
+  real C0 = p.C0, gamma = p.gamma_d, grav = p.grav;
+  bool enable_gravity = p.enable_gravity != 0;
+  real *state_flux_x = d->state_flux_x, *state_flux_y = d->state_flux_y, *state_flux_z = d->state_flux_z;
+  real *tracers_flux_x = d->tracers_flux_x, *tracers_flux_y = d->tracers_flux_y, *tracers_flux_z = d->tracers_flux_z;
+  const real *immersed_proportion = d->immersed_proportion;
+  const real *hy_dens_cells = d->hy_dens_cells, *hy_dens_theta_cells = d->hy_dens_theta_cells;
+  const real *hy_dens_edges = d->hy_dens_edges, *hy_dens_theta_edges = d->hy_dens_theta_edges;
+  const int *tracer_positive = d->tracer_positive;
+  #define HYC(k,e)  hy_dens_cells[(size_t)(k)*nens+(e)]
+  #define HYTC(k,e) hy_dens_theta_cells[(size_t)(k)*nens+(e)]
+  #define HYE(k,e)  hy_dens_edges[(size_t)(k)*nens+(e)]
+  #define HYTE(k,e) hy_dens_theta_edges[(size_t)(k)*nens+(e)]
+
+  // :248-255  [D2]
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int e=0;e<nens;e++) {
+    state[D.H(idU,hs+k,hs+j,hs+i,e)] /= ( state[D.H(idR,hs+k,hs+j,hs+i,e)] + HYC(k,e) );
+    state[D.H(idV,hs+k,hs+j,hs+i,e)] /= ( state[D.H(idR,hs+k,hs+j,hs+i,e)] + HYC(k,e) );
+    state[D.H(idW,hs+k,hs+j,hs+i,e)] /= ( state[D.H(idR,hs+k,hs+j,hs+i,e)] + HYC(k,e) );
+    for (int tr=0; tr < num_tracers; tr++) {
+      tracers[D.H(tr,hs+k,hs+j,hs+i,e)] /= ( state[D.H(idR,hs+k,hs+j,hs+i,e)] + HYC(k,e) );
+    }
+  }
+
+  halo_exchange( d , state , tracers );    // :257
+
+  // :260-265
+  size_t nlx = (size_t)2*nz*ny*(nx+1)*nens, nly = (size_t)2*nz*(ny+1)*nx*nens, nlz = (size_t)2*(nz+1)*ny*nx*nens;
+  real *state_limits_x   = (real*)malloc(8*nlx*num_state);
+  real *state_limits_y   = (real*)malloc(8*nly*num_state);
+  real *state_limits_z   = (real*)malloc(8*nlz*num_state);
+  real *tracers_limits_x = (real*)malloc(8*nlx*(num_tracers>0?num_tracers:1));
+  real *tracers_limits_y = (real*)malloc(8*nly*(num_tracers>0?num_tracers:1));
+  real *tracers_limits_z = (real*)malloc(8*nlz*(num_tracers>0?num_tracers:1));
+
+  Weno5 limiter;    // :267
+
+  // :271-388  [D6]
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    // X-direction  :276-305
+    for (int l=0; l < num_state; l++) {
+      real stencil[5], gll[2];
+      for (int s=0; s < ord; s++) { stencil[s] = state[D.H(l,hs+k,hs+j,i+s,iens)]; }
+      reconstruct_gll_values(stencil,gll,limiter);
+      state_limits_x[D.LX(l,1,k,j,i  ,iens)] = gll[0];
+      state_limits_x[D.LX(l,0,k,j,i+1,iens)] = gll[1];
+    }
+    state_limits_x[D.LX(idR,1,k,j,i  ,iens)] += HYC(k,iens);
+    state_limits_x[D.LX(idR,0,k,j,i+1,iens)] += HYC(k,iens);
+    state_limits_x[D.LX(idU,1,k,j,i  ,iens)] *= state_limits_x[D.LX(idR,1,k,j,i  ,iens)];
+    state_limits_x[D.LX(idU,0,k,j,i+1,iens)] *= state_limits_x[D.LX(idR,0,k,j,i+1,iens)];
+    state_limits_x[D.LX(idV,1,k,j,i  ,iens)] *= state_limits_x[D.LX(idR,1,k,j,i  ,iens)];
+    state_limits_x[D.LX(idV,0,k,j,i+1,iens)] *= state_limits_x[D.LX(idR,0,k,j,i+1,iens)];
+    state_limits_x[D.LX(idW,1,k,j,i  ,iens)] *= state_limits_x[D.LX(idR,1,k,j,i  ,iens)];
+    state_limits_x[D.LX(idW,0,k,j,i+1,iens)] *= state_limits_x[D.LX(idR,0,k,j,i+1,iens)];
+    state_limits_x[D.LX(idT,1,k,j,i  ,iens)] += HYTC(k,iens);
+    state_limits_x[D.LX(idT,0,k,j,i+1,iens)] += HYTC(k,iens);
+    for (int l=0; l < num_tracers; l++) {
+      real stencil[5], gll[2];
+      for (int s=0; s < ord; s++) { stencil[s] = tracers[D.H(l,hs+k,hs+j,i+s,iens)]; }
+      reconstruct_gll_values(stencil,gll,limiter);
+      tracers_limits_x[D.LX(l,1,k,j,i  ,iens)] = gll[0] * state_limits_x[D.LX(idR,1,k,j,i  ,iens)];
+      tracers_limits_x[D.LX(l,0,k,j,i+1,iens)] = gll[1] * state_limits_x[D.LX(idR,0,k,j,i+1,iens)];
+    }
+    // Y-direction  :311-352
+    if (!sim2d) {
+      for (int l=0; l < num_state; l++) {
+        real stencil[5], gll[2];
+        for (int s=0; s < ord; s++) { stencil[s] = state[D.H(l,hs+k,j+s,hs+i,iens)]; }
+        reconstruct_gll_values(stencil,gll,limiter);
+        state_limits_y[D.LY(l,1,k,j  ,i,iens)] = gll[0];
+        state_limits_y[D.LY(l,0,k,j+1,i,iens)] = gll[1];
+      }
+      state_limits_y[D.LY(idR,1,k,j  ,i,iens)] += HYC(k,iens);
+      state_limits_y[D.LY(idR,0,k,j+1,i,iens)] += HYC(k,iens);
+      state_limits_y[D.LY(idU,1,k,j  ,i,iens)] *= state_limits_y[D.LY(idR,1,k,j  ,i,iens)];
+      state_limits_y[D.LY(idU,0,k,j+1,i,iens)] *= state_limits_y[D.LY(idR,0,k,j+1,i,iens)];
+      state_limits_y[D.LY(idV,1,k,j  ,i,iens)] *= state_limits_y[D.LY(idR,1,k,j  ,i,iens)];
+      state_limits_y[D.LY(idV,0,k,j+1,i,iens)] *= state_limits_y[D.LY(idR,0,k,j+1,i,iens)];
+      state_limits_y[D.LY(idW,1,k,j  ,i,iens)] *= state_limits_y[D.LY(idR,1,k,j  ,i,iens)];
+      state_limits_y[D.LY(idW,0,k,j+1,i,iens)] *= state_limits_y[D.LY(idR,0,k,j+1,i,iens)];
+      state_limits_y[D.LY(idT,1,k,j  ,i,iens)] += HYTC(k,iens);
+      state_limits_y[D.LY(idT,0,k,j+1,i,iens)] += HYTC(k,iens);
+      for (int l=0; l < num_tracers; l++) {
+        real stencil[5], gll[2];
+        for (int s=0; s < ord; s++) { stencil[s] = tracers[D.H(l,hs+k,j+s,hs+i,iens)]; }
+        reconstruct_gll_values(stencil,gll,limiter);
+        tracers_limits_y[D.LY(l,1,k,j  ,i,iens)] = gll[0] * state_limits_y[D.LY(idR,1,k,j  ,i,iens)];
+        tracers_limits_y[D.LY(l,0,k,j+1,i,iens)] = gll[1] * state_limits_y[D.LY(idR,0,k,j+1,i,iens)];
+      }
+    } else {
+      for (int l=0; l < num_state; l++) {
+        state_limits_y[D.LY(l,1,k,j  ,i,iens)] = 0;
+        state_limits_y[D.LY(l,0,k,j+1,i,iens)] = 0;
+      }
+      for (int l=0; l < num_tracers; l++) {
+        tracers_limits_y[D.LY(l,1,k,j  ,i,iens)] = 0;
+        tracers_limits_y[D.LY(l,0,k,j+1,i,iens)] = 0;
+      }
+    }
+    // Z-direction  :358-387
+    for (int l=0; l < num_state; l++) {
+      real stencil[5], gll[2];
+      for (int s=0; s < ord; s++) { stencil[s] = state[D.H(l,k+s,hs+j,hs+i,iens)]; }
+      reconstruct_gll_values(stencil,gll,limiter);
+      state_limits_z[D.LZ(l,1,k  ,j,i,iens)] = gll[0];
+      state_limits_z[D.LZ(l,0,k+1,j,i,iens)] = gll[1];
+    }
+    state_limits_z[D.LZ(idR,1,k  ,j,i,iens)] += HYE(k  ,iens);
+    state_limits_z[D.LZ(idR,0,k+1,j,i,iens)] += HYE(k+1,iens);
+    state_limits_z[D.LZ(idU,1,k  ,j,i,iens)] *= state_limits_z[D.LZ(idR,1,k  ,j,i,iens)];
+    state_limits_z[D.LZ(idU,0,k+1,j,i,iens)] *= state_limits_z[D.LZ(idR,0,k+1,j,i,iens)];
+    state_limits_z[D.LZ(idV,1,k  ,j,i,iens)] *= state_limits_z[D.LZ(idR,1,k  ,j,i,iens)];
+    state_limits_z[D.LZ(idV,0,k+1,j,i,iens)] *= state_limits_z[D.LZ(idR,0,k+1,j,i,iens)];
+    state_limits_z[D.LZ(idW,1,k  ,j,i,iens)] *= state_limits_z[D.LZ(idR,1,k  ,j,i,iens)];
+    state_limits_z[D.LZ(idW,0,k+1,j,i,iens)] *= state_limits_z[D.LZ(idR,0,k+1,j,i,iens)];
+    state_limits_z[D.LZ(idT,1,k  ,j,i,iens)] += HYTE(k  ,iens);
+    state_limits_z[D.LZ(idT,0,k+1,j,i,iens)] += HYTE(k+1,iens);
+    for (int l=0; l < num_tracers; l++) {
+      real stencil[5], gll[2];
+      for (int s=0; s < ord; s++) { stencil[s] = tracers[D.H(l,k+s,hs+j,hs+i,iens)]; }
+      reconstruct_gll_values(stencil,gll,limiter);
+      tracers_limits_z[D.LZ(l,1,k  ,j,i,iens)] = gll[0] * state_limits_z[D.LZ(idR,1,k  ,j,i,iens)];
+      tracers_limits_z[D.LZ(l,0,k+1,j,i,iens)] = gll[1] * state_limits_z[D.LZ(idR,0,k+1,j,i,iens)];
+    }
+  }
+
+  // :390-392
+  edge_exchange( d , state_limits_x , tracers_limits_x , state_limits_y , tracers_limits_y , state_limits_z , tracers_limits_z );
+
+  // :395-485  [D9]
+  for (int k=0;k<nz+1;k++) for (int j=0;j<ny+1;j++) for (int i=0;i<nx+1;i++) for (int iens=0;iens<nens;iens++) {
+    if (j < ny && k < nz) {   // X  :397-418
+      real ru_L = state_limits_x[D.LX(idU,0,k,j,i,iens)];   real ru_R = state_limits_x[D.LX(idU,1,k,j,i,iens)];
+      real rt_L = state_limits_x[D.LX(idT,0,k,j,i,iens)];   real rt_R = state_limits_x[D.LX(idT,1,k,j,i,iens)];
+      real p_L  = C0*std::pow(rt_L,gamma)                ;   real p_R  = C0*std::pow(rt_R,gamma)                ;
+      const real cs = 350;
+      real w1 = FP(0.5) * (p_R-cs*ru_R);
+      real w2 = FP(0.5) * (p_L+cs*ru_L);
+      real p_upw  = w1 + w2;
+      real ru_upw = (w2-w1)/cs;
+      int ind = ru_L+ru_R > 0 ? 0 : 1;
+      real r_upw = state_limits_x[D.LX(idR,ind,k,j,i,iens)];
+      state_flux_x[D.FX(idR,k,j,i,iens)] = ru_upw;
+      state_flux_x[D.FX(idU,k,j,i,iens)] = ru_upw*state_limits_x[D.LX(idU,ind,k,j,i,iens)]/r_upw + p_upw;
+      state_flux_x[D.FX(idV,k,j,i,iens)] = ru_upw*state_limits_x[D.LX(idV,ind,k,j,i,iens)]/r_upw;
+      state_flux_x[D.FX(idW,k,j,i,iens)] = ru_upw*state_limits_x[D.LX(idW,ind,k,j,i,iens)]/r_upw;
+      state_flux_x[D.FX(idT,k,j,i,iens)] = ru_upw*state_limits_x[D.LX(idT,ind,k,j,i,iens)]/r_upw;
+      for (int tr=0; tr < num_tracers; tr++) {
+        tracers_flux_x[D.FX(tr,k,j,i,iens)] = ru_upw*tracers_limits_x[D.LX(tr,ind,k,j,i,iens)]/r_upw;
+      }
+    }
+    if ( (! sim2d) && i < nx && k < nz) {   // Y  :422-442
+      real rv_L = state_limits_y[D.LY(idV,0,k,j,i,iens)];   real rv_R = state_limits_y[D.LY(idV,1,k,j,i,iens)];
+      real rt_L = state_limits_y[D.LY(idT,0,k,j,i,iens)];   real rt_R = state_limits_y[D.LY(idT,1,k,j,i,iens)];
+      real p_L  = C0*std::pow(rt_L,gamma)                ;   real p_R  = C0*std::pow(rt_R,gamma)                ;
+      const real cs = 350;
+      real w1 = FP(0.5) * (p_R-cs*rv_R);
+      real w2 = FP(0.5) * (p_L+cs*rv_L);
+      real p_upw  = w1 + w2;
+      real rv_upw = (w2-w1)/cs;
+      int ind = rv_L+rv_R > 0 ? 0 : 1;
+      real r_upw = state_limits_y[D.LY(idR,ind,k,j,i,iens)];
+      state_flux_y[D.FY(idR,k,j,i,iens)] = rv_upw;
+      state_flux_y[D.FY(idU,k,j,i,iens)] = rv_upw*state_limits_y[D.LY(idU,ind,k,j,i,iens)]/r_upw;
+      state_flux_y[D.FY(idV,k,j,i,iens)] = rv_upw*state_limits_y[D.LY(idV,ind,k,j,i,iens)]/r_upw + p_upw;
+      state_flux_y[D.FY(idW,k,j,i,iens)] = rv_upw*state_limits_y[D.LY(idW,ind,k,j,i,iens)]/r_upw;
+      state_flux_y[D.FY(idT,k,j,i,iens)] = rv_upw*state_limits_y[D.LY(idT,ind,k,j,i,iens)]/r_upw;
+      for (int tr=0; tr < num_tracers; tr++) {
+        tracers_flux_y[D.FY(tr,k,j,i,iens)] = rv_upw*tracers_limits_y[D.LY(tr,ind,k,j,i,iens)]/r_upw;
+      }
+    } else if (i < nx && k < nz) {   // :443-450
+      state_flux_y[D.FY(idR,k,j,i,iens)] = 0;
+      state_flux_y[D.FY(idU,k,j,i,iens)] = 0;
+      state_flux_y[D.FY(idV,k,j,i,iens)] = 0;
+      state_flux_y[D.FY(idW,k,j,i,iens)] = 0;
+      state_flux_y[D.FY(idT,k,j,i,iens)] = 0;
+      for (int tr=0; tr < num_tracers; tr++) { tracers_flux_y[D.FY(tr,k,j,i,iens)] = 0; }
+    }
+    if (i < nx && j < ny) {   // Z  :453-474
+      real rw_L = state_limits_z[D.LZ(idW,0,k,j,i,iens)];   real rw_R = state_limits_z[D.LZ(idW,1,k,j,i,iens)];
+      real rt_L = state_limits_z[D.LZ(idT,0,k,j,i,iens)];   real rt_R = state_limits_z[D.LZ(idT,1,k,j,i,iens)];
+      real p_L  = C0*std::pow(rt_L,gamma)                ;   real p_R  = C0*std::pow(rt_R,gamma)                ;
+      const real cs = 350;
+      real w1 = FP(0.5) * (p_R-cs*rw_R);
+      real w2 = FP(0.5) * (p_L+cs*rw_L);
+      real p_upw  = w1 + w2;
+      real rw_upw = (w2-w1)/cs;
+      int ind = rw_L+rw_R > 0 ? 0 : 1;
+      real r_upw = state_limits_z[D.LZ(idR,ind,k,j,i,iens)];
+      state_flux_z[D.FZ(idR,k,j,i,iens)] = rw_upw;
+      state_flux_z[D.FZ(idU,k,j,i,iens)] = rw_upw*state_limits_z[D.LZ(idU,ind,k,j,i,iens)]/r_upw;
+      state_flux_z[D.FZ(idV,k,j,i,iens)] = rw_upw*state_limits_z[D.LZ(idV,ind,k,j,i,iens)]/r_upw;
+      state_flux_z[D.FZ(idW,k,j,i,iens)] = rw_upw*state_limits_z[D.LZ(idW,ind,k,j,i,iens)]/r_upw + p_upw;
+      state_flux_z[D.FZ(idT,k,j,i,iens)] = rw_upw*state_limits_z[D.LZ(idT,ind,k,j,i,iens)]/r_upw;
+      for (int tr=0; tr < num_tracers; tr++) {
+        tracers_flux_z[D.FZ(tr,k,j,i,iens)] = rw_upw*tracers_limits_z[D.LZ(tr,ind,k,j,i,iens)]/r_upw;
+      }
+    }
+    if (i < nx && j < ny && k < nz) {   // :477-484  multiply density back
+      state[D.H(idU,hs+k,hs+j,hs+i,iens)] *= ( state[D.H(idR,hs+k,hs+j,hs+i,iens)] + HYC(k,iens) );
+      state[D.H(idV,hs+k,hs+j,hs+i,iens)] *= ( state[D.H(idR,hs+k,hs+j,hs+i,iens)] + HYC(k,iens) );
+      state[D.H(idW,hs+k,hs+j,hs+i,iens)] *= ( state[D.H(idR,hs+k,hs+j,hs+i,iens)] + HYC(k,iens) );
+      for (int tr=0; tr < num_tracers; tr++) {
+        tracers[D.H(tr,hs+k,hs+j,hs+i,iens)] *= ( state[D.H(idR,hs+k,hs+j,hs+i,iens)] + HYC(k,iens) );
+      }
+    }
+  }
+
+  free(state_limits_x); free(state_limits_y); free(state_limits_z);       // :488-493
+  free(tracers_limits_x); free(tracers_limits_y); free(tracers_limits_z);
+
+  // :498-516  [D10]  FCT.  Serial order (tr,k,j,i,iens); race-free by the reference's sign argument (:495-497).
+  for (int tr=0; tr<num_tracers; tr++) for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    if (tracer_positive[tr]) {
+      real mass_available = std::max(tracers[D.H(tr,hs+k,hs+j,hs+i,iens)],FP(0.)) * dx * dy * dz;
+      real flux_out_x = ( std::max(tracers_flux_x[D.FX(tr,k,j,i+1,iens)],FP(0.)) - std::min(tracers_flux_x[D.FX(tr,k,j,i,iens)],FP(0.)) ) / dx;
+      real flux_out_y = ( std::max(tracers_flux_y[D.FY(tr,k,j+1,i,iens)],FP(0.)) - std::min(tracers_flux_y[D.FY(tr,k,j,i,iens)],FP(0.)) ) / dy;
+      real flux_out_z = ( std::max(tracers_flux_z[D.FZ(tr,k+1,j,i,iens)],FP(0.)) - std::min(tracers_flux_z[D.FZ(tr,k,j,i,iens)],FP(0.)) ) / dz;
+      real mass_out = (flux_out_x + flux_out_y + flux_out_z) * dt * dx * dy * dz;
+      if (mass_out > mass_available) {
+        real mult = mass_available / mass_out;
+        if (tracers_flux_x[D.FX(tr,k,j,i+1,iens)] > 0) tracers_flux_x[D.FX(tr,k,j,i+1,iens)] *= mult;
+        if (tracers_flux_x[D.FX(tr,k,j,i  ,iens)] < 0) tracers_flux_x[D.FX(tr,k,j,i  ,iens)] *= mult;
+        if (tracers_flux_y[D.FY(tr,k,j+1,i,iens)] > 0) tracers_flux_y[D.FY(tr,k,j+1,i,iens)] *= mult;
+        if (tracers_flux_y[D.FY(tr,k,j  ,i,iens)] < 0) tracers_flux_y[D.FY(tr,k,j  ,i,iens)] *= mult;
+        if (tracers_flux_z[D.FZ(tr,k+1,j,i,iens)] > 0) tracers_flux_z[D.FZ(tr,k+1,j,i,iens)] *= mult;
+        if (tracers_flux_z[D.FZ(tr,k  ,j,i,iens)] < 0) tracers_flux_z[D.FZ(tr,k  ,j,i,iens)] *= mult;
+      }
+    }
+  }
+
+  // :519-551  [D11]
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    for (int l = 0; l < num_state; l++) {
+      state_tend[D.T(l,k,j,i,iens)] = -( state_flux_x[D.FX(l,k  ,j  ,i+1,iens)] - state_flux_x[D.FX(l,k,j,i,iens)] ) / dx
+                                      -( state_flux_y[D.FY(l,k  ,j+1,i  ,iens)] - state_flux_y[D.FY(l,k,j,i,iens)] ) / dy
+                                      -( state_flux_z[D.FZ(l,k+1,j  ,i  ,iens)] - state_flux_z[D.FZ(l,k,j,i,iens)] ) / dz;
+      if (l == idW && enable_gravity) state_tend[D.T(l,k,j,i,iens)] += -grav * ( state[D.H(idR,hs+k,hs+j,hs+i,iens)] + HYC(k,iens) );
+      if (l == idU) state_tend[D.T(l,k,j,i,iens)] += fcor*state[D.H(idV,hs+k,hs+j,hs+i,iens)];
+      if (l == idV) state_tend[D.T(l,k,j,i,iens)] -= fcor*state[D.H(idU,hs+k,hs+j,hs+i,iens)];
+      if (l == idV && sim2d) state_tend[D.T(l,k,j,i,iens)] = 0;
+    }
+    for (int l = 0; l < num_tracers; l++) {
+      tracers_tend[D.T(l,k,j,i,iens)] = -( tracers_flux_x[D.FX(l,k  ,j  ,i+1,iens)] - tracers_flux_x[D.FX(l,k,j,i,iens)] ) / dx
+                                        -( tracers_flux_y[D.FY(l,k  ,j+1,i  ,iens)] - tracers_flux_y[D.FY(l,k,j,i,iens)] ) / dy
+                                        -( tracers_flux_z[D.FZ(l,k+1,j  ,i  ,iens)] - tracers_flux_z[D.FZ(l,k,j,i,iens)] ) / dz;
+    }
+    if (use_immersed_boundaries) {
+      real tau = 1.e3*dt;
+      real imm_tend_idR = -std::min(FP(1.),dt/tau)*state[D.H(idR,hs+k,hs+j,hs+i,iens)]/dt;
+      real imm_tend_idU = -std::min(FP(1.),dt/tau)*state[D.H(idU,hs+k,hs+j,hs+i,iens)]/dt;
+      real imm_tend_idV = -std::min(FP(1.),dt/tau)*state[D.H(idV,hs+k,hs+j,hs+i,iens)]/dt;
+      real imm_tend_idW = -std::min(FP(1.),dt/tau)*state[D.H(idW,hs+k,hs+j,hs+i,iens)]/dt;
+      real imm_tend_idT = -std::min(FP(1.),dt/tau)*state[D.H(idT,hs+k,hs+j,hs+i,iens)]/dt;
+      real prop = immersed_proportion[D.C(k,j,i,iens)];
+      state_tend[D.T(idR,k,j,i,iens)] = prop*imm_tend_idR + (1-prop)*state_tend[D.T(idR,k,j,i,iens)];
+      state_tend[D.T(idU,k,j,i,iens)] = prop*imm_tend_idU + (1-prop)*state_tend[D.T(idU,k,j,i,iens)];
+      state_tend[D.T(idV,k,j,i,iens)] = prop*imm_tend_idV + (1-prop)*state_tend[D.T(idV,k,j,i,iens)];
+      state_tend[D.T(idW,k,j,i,iens)] = prop*imm_tend_idW + (1-prop)*state_tend[D.T(idW,k,j,i,iens)];
+      state_tend[D.T(idT,k,j,i,iens)] = prop*imm_tend_idT + (1-prop)*state_tend[D.T(idT,k,j,i,iens)];
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// convert_coupler_to_dynamics  :1955-2015 [D1]   /   convert_dynamics_to_coupler  :1891-1951 [D13]
+// -----------------------------------------------------------------------------------------------------
+static void convert_coupler_to_dynamics(const mwo_dycore *d, const real *dm_rho_d, const real *dm_uvel, const real *dm_vvel,
+                                        const real *dm_wvel, const real *dm_temp, real *const *dm_tracers,
+                                        real *state, real *tracers) {
+  const mwo_params &p = d->p;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens, num_tracers=p.num_tracers, idWV=p.idWV;
+  real R_d=p.R_d, R_v=p.R_v, gamma=p.gamma_d, C0=p.C0;
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    size_t c = D.C(k,j,i,iens);
+    real rho_d = dm_rho_d[c];
+    real u     = dm_uvel [c];
+    real v     = dm_vvel [c];
+    real w     = dm_wvel [c];
+    real temp  = dm_temp [c];
+    real rho_v = dm_tracers[idWV][c];
+    real press = rho_d * R_d * temp + rho_v * R_v * temp;
+    real rho = rho_d;
+    for (int tr=0; tr < num_tracers; tr++) { if (d->tracer_adds_mass[tr]) rho += dm_tracers[tr][c]; }
+    real theta = pow( press/C0 , FP(1.) / gamma ) / rho;
+    state[D.H(idR,hs+k,hs+j,hs+i,iens)] = rho - d->hy_dens_cells[(size_t)k*nens+iens];
+    state[D.H(idU,hs+k,hs+j,hs+i,iens)] = rho * u;
+    state[D.H(idV,hs+k,hs+j,hs+i,iens)] = rho * v;
+    state[D.H(idW,hs+k,hs+j,hs+i,iens)] = rho * w;
+    state[D.H(idT,hs+k,hs+j,hs+i,iens)] = rho * theta - d->hy_dens_theta_cells[(size_t)k*nens+iens];
+    for (int tr=0; tr < num_tracers; tr++) { tracers[D.H(tr,hs+k,hs+j,hs+i,iens)] = dm_tracers[tr][c]; }
+  }
+}
+
+static void convert_dynamics_to_coupler(const mwo_dycore *d, const real *state, const real *tracers,
+                                        real *dm_rho_d, real *dm_uvel, real *dm_vvel, real *dm_wvel, real *dm_temp,
+                                        real *const *dm_tracers) {
+  const mwo_params &p = d->p;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens, num_tracers=p.num_tracers, idWV=p.idWV;
+  real R_d=p.R_d, R_v=p.R_v, gamma=p.gamma_d, C0=p.C0;
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    size_t c = D.C(k,j,i,iens);
+    real rho   = state[D.H(idR,hs+k,hs+j,hs+i,iens)] + d->hy_dens_cells[(size_t)k*nens+iens];
+    real u     = state[D.H(idU,hs+k,hs+j,hs+i,iens)] / rho;
+    real v     = state[D.H(idV,hs+k,hs+j,hs+i,iens)] / rho;
+    real w     = state[D.H(idW,hs+k,hs+j,hs+i,iens)] / rho;
+    real theta = ( state[D.H(idT,hs+k,hs+j,hs+i,iens)] + d->hy_dens_theta_cells[(size_t)k*nens+iens] ) / rho;
+    real press = C0 * pow( rho*theta , gamma );
+    real rho_v = tracers[D.H(idWV,hs+k,hs+j,hs+i,iens)];
+    real rho_d = rho;
+    for (int tr=0; tr < num_tracers; tr++) { if (d->tracer_adds_mass[tr]) rho_d -= tracers[D.H(tr,hs+k,hs+j,hs+i,iens)]; }
+    real temp = press / ( rho_d * R_d + rho_v * R_v );
+    dm_rho_d[c] = rho_d;
+    dm_uvel [c] = u;
+    dm_vvel [c] = v;
+    dm_wvel [c] = w;
+    dm_temp [c] = temp;
+    for (int tr=0; tr < num_tracers; tr++) { dm_tracers[tr][c] = tracers[D.H(tr,hs+k,hs+j,hs+i,iens)]; }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Initial-data helpers   dynamics_euler_stratified_wenofv.h:1086-1193
+// -----------------------------------------------------------------------------------------------------
+static void hydro_const_theta(real z, real grav, real C0, real cp, real p0, real gamma, real rd, real &r, real &t) { // :1108-1117
+  const real theta0 = 300.;
+  const real exner0 = 1.;
+  t = theta0;
+  real exner = exner0 - grav * z / (cp * theta0);
+  real p = p0 * std::pow(exner,(cp/rd));
+  real rt = std::pow((p / C0),(FP(1.) / gamma));
+  r = rt / t;
+}
+static real sample_ellipse_cosine(real amp, real x, real y, real z, real x0, real y0, real z0, real xrad, real yrad, real zrad) { // :1121-1134
+  real dist = sqrt( ((x-x0)/xrad)*((x-x0)/xrad) + ((y-y0)/yrad)*((y-y0)/yrad) + ((z-z0)/zrad)*((z-z0)/zrad) ) * M_PI / 2.;
+  if (dist <= M_PI / 2.) { return amp * std::pow(cos(dist),FP(2.)); } else { return 0.; }
+}
+static real saturation_vapor_pressure(real temp) {  // :1137-1140
+  real tc = temp - 273.15;
+  return 610.94 * std::exp( 17.625*tc / (243.04+tc) );
+}
+static void thermal(real x, real y, real z, real xlen, real ylen, real grav, real C0, real gamma, real cp, real p0, real R_d, real R_v,
+                    real &rho, real &u, real &v, real &w, real &theta, real &rho_v, real &hr, real &ht) {  // :1086-1103
+  hydro_const_theta(z,grav,C0,cp,p0,gamma,R_d,hr,ht);
+  real rho_d   = hr;
+  u = 0.; v = 0.; w = 0.;
+  real theta_d = ht + sample_ellipse_cosine(FP(2.)  ,  x,y,z  ,  xlen/2,ylen/2,2000.  ,  2000.,2000.,2000.);
+  real p_d     = C0 * pow( rho_d*theta_d , gamma );
+  real temp    = p_d / rho_d / R_d;
+  real sat_pv  = saturation_vapor_pressure(temp);
+  real sat_rv  = sat_pv / R_v / temp;
+  rho_v        = sample_ellipse_cosine(FP(0.8)  ,  x,y,z  ,  xlen/2,ylen/2,2000.  ,  2000.,2000.,2000.) * sat_rv;
+  real p       = rho_d * R_d * temp + rho_v * R_v * temp;
+  rho          = rho_d + rho_v;
+  theta        = std::pow( p / C0 , FP(1.) / gamma ) / rho;
+}
+static real init_supercell_temperature(real z, real z_0, real z_trop, real z_top, real T_0, real T_trop, real T_top) { // :1144-1153
+  if (z <= z_trop) {
+    real lapse = - (T_trop - T_0) / (z_trop - z_0);
+    return T_0 - lapse * (z - z_0);
+  } else {
+    real lapse = - (T_top - T_trop) / (z_top - z_trop);
+    return T_trop - lapse * (z - z_trop);
+  }
+}
+static real init_supercell_pressure_dry(real z, real z_0, real z_trop, real z_top, real T_0, real T_trop, real T_top,
+                                        real p_0, real R_d, real grav) {  // :1157-1177
+  if (z <= z_trop) {
+    real lapse = - (T_trop - T_0) / (z_trop - z_0);
+    real T = init_supercell_temperature(z, z_0, z_trop, z_top, T_0, T_trop, T_top);
+    return p_0 * pow( T / T_0 , grav/(R_d*lapse) );
+  } else {
+    real lapse = - (T_trop - T_0) / (z_trop - z_0);
+    real p_trop = p_0 * pow( T_trop / T_0 , grav/(R_d*lapse) );
+    lapse = - (T_top - T_trop) / (z_top - z_trop);
+    if (lapse != 0) {
+      real T = init_supercell_temperature(z, z_0, z_trop, z_top, T_0, T_trop, T_top);
+      return p_trop * pow( T / T_trop , grav/(R_d*lapse) );
+    } else {
+      return p_trop * exp(-grav*(z-z_trop)/(R_d*T_trop));
+    }
+  }
+}
+static real init_supercell_relhum(real z, real z_0, real z_trop) {  // :1181-1187
+  if (z <= z_trop) { return FP(1.) - FP(0.75) * pow(z / z_trop , FP(1.25) ); } else { return FP(0.25); }
+}
+static real init_supercell_sat_mix_dry(real press, real T) {   // :1191-1193
+  return 380/(press) * exp( FP(17.27) * (T-273)/(T-36) );
+}
+
+// init_supercell    :1687-1887
+static void init_supercell(mwo_dycore *d, real *state, real *tracers) {
+  const mwo_params &p = d->p;  Dims D(p);
+  const real z_0 = 0, z_trop = 12000, T_0 = 300, T_trop = 213, T_top = 213, p_0 = 100000;
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens, num_tracers=p.num_tracers, idWV=p.idWV;
+  real dx=get_dx(p), dy=get_dy(p), dz=get_dz(p), ylen=p.ylen;
+  bool sim2d = is_sim2d(p);
+  real R_d=p.R_d, R_v=p.R_v, grav=p.grav, gamma=p.gamma_d, C0=p.C0;
+  long long i_beg=p.i_beg, j_beg=p.j_beg;
+  real *quad_temp      = (real*)malloc(8*(size_t)nz*(ord-1)*ord);
+  real *hyDensGLL      = (real*)malloc(8*(size_t)nz*ord);
+  real *hyDensThetaGLL = (real*)malloc(8*(size_t)nz*ord);
+  real *hyDensVapGLL   = (real*)malloc(8*(size_t)nz*ord);
+  real *hyPressureGLL  = (real*)malloc(8*(size_t)nz*ord);
+  #define QT(k,kk,kkk) quad_temp[((size_t)(k)*(ord-1)+(kk))*ord+(kkk)]
+  #define G2(a,k,kk) a[(size_t)(k)*ord+(kk)]
+  real ztop = p.zlen;
+  // :1736-1756
+  for (int k=0;k<nz;k++) for (int kk=0;kk<ord-1;kk++) for (int kkk=0;kkk<ord;kkk++) {
+    real cellmid   = (k+FP(0.5)) * dz;
+    real ord_b    = cellmid + gll_pts[kk  ]*dz;
+    real ord_t    = cellmid + gll_pts[kk+1]*dz;
+    real ord_m    = FP(0.5) * (ord_b + ord_t);
+    real ord_dz   = dz * ( gll_pts[kk+1] - gll_pts[kk] );
+    real zloc      = ord_m + ord_dz * gll_pts[kkk];
+    real temp      = init_supercell_temperature (zloc, z_0, z_trop, ztop, T_0, T_trop, T_top);
+    real press_dry = init_supercell_pressure_dry(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top, p_0, R_d, grav);
+    real qvs       = init_supercell_sat_mix_dry(press_dry, temp);
+    real relhum    = init_supercell_relhum(zloc, z_0, z_trop);
+    if (relhum * qvs > FP(0.014)) relhum = FP(0.014) / qvs;
+    real qv        = std::min( FP(0.014) , qvs*relhum );
+    QT(k,kk,kkk) = -(1+qv)*grav/(R_d+qv*R_v)/temp;
+  }
+  // :1759-1774
+  G2(hyPressureGLL,0,0) = p_0;
+  for (int k=0; k < nz; k++) {
+    for (int kk=0; kk < ord-1; kk++) {
+      real tot = 0;
+      for (int kkk=0; kkk < ord; kkk++) { tot += QT(k,kk,kkk) * gll_wts[kkk]; }
+      tot *= dz * ( gll_pts[kk+1] - gll_pts[kk] );
+      G2(hyPressureGLL,k,kk+1) = G2(hyPressureGLL,k,kk) * exp( tot );
+      if (kk == ord-2 && k < nz-1) { G2(hyPressureGLL,k+1,0) = G2(hyPressureGLL,k,ord-1); }
+    }
+  }
+  // :1777-1805
+  for (int k=0;k<nz;k++) for (int kk=0;kk<ord;kk++) {
+    real zloc = (k+FP(0.5))*dz + gll_pts[kk]*dz;
+    real temp       = init_supercell_temperature (zloc, z_0, z_trop, ztop, T_0, T_trop, T_top);
+    real press_tmp  = init_supercell_pressure_dry(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top, p_0, R_d, grav);
+    real qvs        = init_supercell_sat_mix_dry(press_tmp, temp);
+    real relhum     = init_supercell_relhum(zloc, z_0, z_trop);
+    if (relhum * qvs > FP(0.014)) relhum = FP(0.014) / qvs;
+    real qv         = std::min( FP(0.014) , qvs*relhum );
+    real press      = G2(hyPressureGLL,k,kk);
+    real dens_dry   = press / (R_d+qv*R_v) / temp;
+    real dens_vap   = qv * dens_dry;
+    real dens       = dens_dry + dens_vap;
+    real dens_theta = pow( press / C0 , FP(1.) / gamma );
+    G2(hyDensGLL     ,k,kk) = dens;
+    G2(hyDensThetaGLL,k,kk) = dens_theta;
+    G2(hyDensVapGLL  ,k,kk) = dens_vap;
+    if (kk == 0) {
+      for (int iens=0; iens < nens; iens++) {
+        d->hy_dens_edges      [(size_t)k*nens+iens] = dens;
+        d->hy_dens_theta_edges[(size_t)k*nens+iens] = dens_theta;
+      }
+    }
+    if (k == nz-1 && kk == ord-1) {
+      for (int iens=0; iens < nens; iens++) {
+        d->hy_dens_edges      [(size_t)(k+1)*nens+iens] = dens;
+        d->hy_dens_theta_edges[(size_t)(k+1)*nens+iens] = dens_theta;
+      }
+    }
+  }
+  // :1808-1840
+  for (int k=0;k<nz;k++) {
+    real dens_tot = 0, dens_theta_tot = 0;
+    real press_tot = 0, dens_vap_tot = 0;
+    for (int kk=0; kk < ord; kk++) {
+      press_tot      += G2(hyPressureGLL ,k,kk) * gll_wts[kk];
+      dens_tot       += G2(hyDensGLL     ,k,kk) * gll_wts[kk];
+      dens_vap_tot   += G2(hyDensVapGLL  ,k,kk) * gll_wts[kk];
+      dens_theta_tot += G2(hyDensThetaGLL,k,kk) * gll_wts[kk];
+    }
+    (void)press_tot; (void)dens_vap_tot;   // only feed the unused tdew diagnostic (:1819-1834)
+    for (int iens=0; iens < nens; iens++) {
+      d->hy_dens_cells      [(size_t)k*nens+iens] = dens_tot;
+      d->hy_dens_theta_cells[(size_t)k*nens+iens] = dens_theta_tot;
+    }
+  }
+  // :1843-1886
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    state[D.H(idR,hs+k,hs+j,hs+i,iens)] = 0;
+    state[D.H(idU,hs+k,hs+j,hs+i,iens)] = 0;
+    state[D.H(idV,hs+k,hs+j,hs+i,iens)] = 0;
+    state[D.H(idW,hs+k,hs+j,hs+i,iens)] = 0;
+    state[D.H(idT,hs+k,hs+j,hs+i,iens)] = 0;
+    for (int tr=0; tr < num_tracers; tr++) { tracers[D.H(tr,hs+k,hs+j,hs+i,iens)] = 0; }
+    for (int kk=0; kk < ord; kk++) {
+      for (int jj=0; jj < ord; jj++) {
+        for (int ii=0; ii < ord; ii++) {
+          real xloc = (i+i_beg+FP(0.5))*dx + gll_pts[ii]*dx;
+          real yloc = (j+j_beg+FP(0.5))*dy + gll_pts[jj]*dy;
+          real zloc = (k      +FP(0.5))*dz + gll_pts[kk]*dz;
+          if (sim2d) yloc = ylen/2;
+          (void)xloc; (void)yloc;
+          real dens = G2(hyDensGLL,k,kk);
+          real uvel;
+          const real zs = 5000, us = 30, uc = 15;
+          if (zloc < zs) { uvel = us * (zloc / zs) - uc; } else { uvel = us - uc; }
+          real vvel       = 0;
+          real wvel       = 0;
+          real dens_vap   = G2(hyDensVapGLL  ,k,kk);
+          real dens_theta = G2(hyDensThetaGLL,k,kk);
+          real factor = gll_wts[ii] * gll_wts[jj] * gll_wts[kk];
+          state  [D.H(idR ,hs+k,hs+j,hs+i,iens)] += (dens - G2(hyDensGLL,k,kk))            * factor;
+          state  [D.H(idU ,hs+k,hs+j,hs+i,iens)] += dens * uvel                            * factor;
+          state  [D.H(idV ,hs+k,hs+j,hs+i,iens)] += dens * vvel                            * factor;
+          state  [D.H(idW ,hs+k,hs+j,hs+i,iens)] += dens * wvel                            * factor;
+          state  [D.H(idT ,hs+k,hs+j,hs+i,iens)] += (dens_theta - G2(hyDensThetaGLL,k,kk)) * factor;
+          tracers[D.H(idWV,hs+k,hs+j,hs+i,iens)] += dens_vap                               * factor;
+        }
+      }
+    }
+  }
+  #undef QT
+  #undef G2
+  free(quad_temp); free(hyDensGLL); free(hyDensThetaGLL); free(hyDensVapGLL); free(hyPressureGLL);
+}
+
+// Shared body of the thermal / city / building quadrature init   :1361-1392, :1463-1515, :1566-1618
+static void hydro_background(mwo_dycore *d, int nq, const real *qpoints, const real *qweights, bool gll_centered) {
+  // thermal: (qpoints(kk)-0.5)*dz with Gauss-Legendre points on [0,1]  (:1399-1400)
+  // city/building: the same expression (qpoints(kk)-0.5)*dz is used with GLL points on [-0.5,0.5] (:1522, :1626)
+  (void)gll_centered;
+  const mwo_params &p = d->p;
+  int nz=p.nz, nens=p.nens;
+  real dz=get_dz(p);
+  for (int k=0;k<nz;k++) for (int iens=0;iens<nens;iens++) {
+    d->hy_dens_cells      [(size_t)k*nens+iens] = 0.;
+    d->hy_dens_theta_cells[(size_t)k*nens+iens] = 0.;
+    for (int kk=0; kk<nq; kk++) {
+      real z = (k+0.5)*dz + (qpoints[kk]-0.5)*dz;
+      real hr, ht;
+      hydro_const_theta(z,p.grav,p.C0,p.cp_d,p.p0,p.gamma_d,p.R_d,hr,ht);
+      d->hy_dens_cells      [(size_t)k*nens+iens] += hr    * qweights[kk];
+      d->hy_dens_theta_cells[(size_t)k*nens+iens] += hr*ht * qweights[kk];
+    }
+  }
+  for (int k=0;k<nz+1;k++) for (int iens=0;iens<nens;iens++) {
+    real z = k*dz;
+    real hr, ht;
+    hydro_const_theta(z,p.grav,p.C0,p.cp_d,p.p0,p.gamma_d,p.R_d,hr,ht);
+    d->hy_dens_edges      [(size_t)k*nens+iens] = hr   ;
+    d->hy_dens_theta_edges[(size_t)k*nens+iens] = hr*ht;
+  }
+}
+
+static void init_quadrature_case(mwo_dycore *d, int init_data_int, real *state, real *tracers, const real *building_heights,
+                                 int nbuildings_x) {
+  const mwo_params &p = d->p;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens, num_tracers=p.num_tracers, idWV=p.idWV;
+  real dx=get_dx(p), dy=get_dy(p), dz=get_dz(p), xlen=p.xlen, ylen=p.ylen;
+  bool sim2d = is_sim2d(p);
+  bool enable_gravity = p.enable_gravity != 0;
+  size_t i_beg = (size_t)p.i_beg, j_beg = (size_t)p.j_beg;
+  // :1345-1355 (thermal, 3-point Gauss-Legendre on [0,1])
+  static const real qp3[3] = { 0.112701665379258311482073460022, 0.500000000000000000000000000000, 0.887298334620741688517926539980 };
+  static const real qw3[3] = { 0.277777777777777777777777777779, 0.444444444444444444444444444444, 0.277777777777777777777777777779 };
+  int nq; const real *qpoints, *qweights;
+  if (init_data_int == DATA_THERMAL) { nq = 3; qpoints = qp3; qweights = qw3; }
+  else                               { nq = 9; qpoints = gll_pts9; qweights = gll_wts9; }   // :1455-1460, :1558-1563
+  // city geometry  :1432-1438
+  int building_length = 30;
+  int cells_per_building = (int) std::round(building_length / dx);
+  int buildings_pad = 20;
+  int nblocks_x = (static_cast<int>(xlen)/building_length - 2*buildings_pad)/3;
+  int nblocks_y = (static_cast<int>(ylen)/building_length - 2*buildings_pad)/9;
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    for (int l=0; l < num_state  ; l++) { state  [D.H(l,hs+k,hs+j,hs+i,iens)] = 0.; }
+    for (int l=0; l < num_tracers; l++) { tracers[D.H(l,hs+k,hs+j,hs+i,iens)] = 0.; }
+    for (int kk=0; kk<nq; kk++) {
+      for (int jj=0; jj<nq; jj++) {
+        for (int ii=0; ii<nq; ii++) {
+          real x = (i+i_beg+0.5)*dx + (qpoints[ii]-0.5)*dx;
+          real y = (j+j_beg+0.5)*dy + (qpoints[jj]-0.5)*dy;   if (sim2d) y = ylen/2;
+          real z = (k      +0.5)*dz + (qpoints[kk]-0.5)*dz;
+          real rho, u, v, w, theta, rho_v, hr, ht;
+          if (init_data_int == DATA_THERMAL) {
+            thermal(x,y,z,xlen,ylen,p.grav,p.C0,p.gamma_d,p.cp_d,p.p0,p.R_d,p.R_v,rho,u,v,w,theta,rho_v,hr,ht);
+          } else {   // :1475-1487, :1579-1591
+            if (enable_gravity) { hydro_const_theta(z,p.grav,p.C0,p.cp_d,p.p0,p.gamma_d,p.R_d,hr,ht); }
+            else                { hr = 1.15; ht = 300; }
+            rho = hr; u = 20; v = 0; w = 0; theta = ht; rho_v = 0;
+          }
+          if (sim2d) v = 0;
+          real wt = qweights[ii]*qweights[jj]*qweights[kk];
+          state[D.H(idR,hs+k,hs+j,hs+i,iens)] += ( rho - hr )          * wt;
+          state[D.H(idU,hs+k,hs+j,hs+i,iens)] += rho*u                 * wt;
+          state[D.H(idV,hs+k,hs+j,hs+i,iens)] += rho*v                 * wt;
+          state[D.H(idW,hs+k,hs+j,hs+i,iens)] += rho*w                 * wt;
+          state[D.H(idT,hs+k,hs+j,hs+i,iens)] += ( rho*theta - hr*ht ) * wt;
+          for (int tr=0; tr < num_tracers; tr++) {
+            if (tr == idWV) { tracers[D.H(tr,hs+k,hs+j,hs+i,iens)] += rho_v * wt; }
+            else            { tracers[D.H(tr,hs+k,hs+j,hs+i,iens)] += 0     * wt; }
+          }
+        }
+      }
+    }
+    if (init_data_int == DATA_CITY) {    // :1504-1514
+      int inorm = (static_cast<int>(i_beg)+i)/cells_per_building - buildings_pad;
+      int jnorm = (static_cast<int>(j_beg)+j)/cells_per_building - buildings_pad;
+      if ( ( inorm >= 0 && inorm < nblocks_x*3 && inorm%3 < 2 ) &&
+           ( jnorm >= 0 && jnorm < nblocks_y*9 && jnorm%9 < 8 ) ) {
+        if ( k <= std::ceil( building_heights[(size_t)jnorm*nbuildings_x+inorm] / dz ) ) {
+          d->immersed_proportion[D.C(k,j,i,iens)] = 1;
+        }
+      }
+    } else if (init_data_int == DATA_BUILDING) {   // :1608-1617
+      real x0 = 0.3*p.nx_glob;
+      real y0 = 0.5*p.ny_glob;
+      real xr = 0.05*p.ny_glob;
+      real yr = 0.05*p.ny_glob;
+      if ( std::abs((real)(i_beg+i)-x0) <= xr && std::abs((real)(j_beg+j)-y0) <= yr && k <= 0.2*nz ) {
+        d->immersed_proportion[D.C(k,j,i,iens)] = 1;
+      }
+    }
+  }
+  // hydrostatic background  :1396-1419, :1516-1547, :1620-1651
+  if (init_data_int == DATA_THERMAL || enable_gravity) {
+    hydro_background(d, nq, qpoints, qweights, init_data_int != DATA_THERMAL);
+  } else {
+    for (size_t n=0; n<(size_t)nz*nens; n++)     { d->hy_dens_cells[n] = 1.15; d->hy_dens_theta_cells[n] = 1.15*300; }
+    for (size_t n=0; n<(size_t)(nz+1)*nens; n++) { d->hy_dens_edges[n] = 1.15; d->hy_dens_theta_edges[n] = 1.15*300; }
+  }
+}
+
+extern "C" {
+
+// ---- WENO unit entry (tests) -------------------------------------------------------------------------
+void mwo_weno5(const double *stencil, double *limited_coefs, double *gll) {
+  Weno5 lim;
+  lim.compute_limited_coefs(stencil, limited_coefs);
+  reconstruct_gll_values(stencil, gll, lim);
+}
+void mwo_weno5_ideal_weights(double *w4) { Weno5 l; w4[0]=l.idl_L; w4[1]=l.idl_C; w4[2]=l.idl_R; w4[3]=l.idl_H; }
+
+// C0 as dycore.init computes it   :1247
+double mwo_compute_C0(double R_d, double p0, double kappa, double gamma) { return pow( R_d * pow( p0 , -kappa ) , gamma ); }
+
+// compute_time_step   :70-77
+double mwo_compute_time_step(const mwo_params *p) {
+  real dx = get_dx(*p), dy = get_dy(*p), dz = get_dz(*p);
+  const real maxwave = 350 + 80;
+  real cfl = 0.6;
+  return cfl * std::min( std::min( dx , dy ) , dz ) / maxwave;
+}
+
+// coupler.h:127-179: 2-D decomposition of `nranks` ranks; neigh is [3][3] as [y][x]
+void mwo_decompose(int nranks, int myrank, long long nx_glob, long long ny_glob,
+                   int *nproc_x, int *nproc_y, int *px, int *py,
+                   long long *i_beg, long long *i_end, long long *j_beg, long long *j_end, int *neigh) {
+  bool sim2d = ny_glob == 1;
+  if (sim2d) { *nproc_x = nranks; *nproc_y = 1; }
+  else {
+    *nproc_y = (int) std::ceil( std::sqrt((double) nranks) );
+    while (*nproc_y >= 1) { if (nranks % *nproc_y == 0) { break; } (*nproc_y)--; }
+    *nproc_x = nranks / *nproc_y;
+  }
+  *py = myrank / *nproc_x;
+  *px = myrank % *nproc_x;
+  double nper;
+  nper = ((double) nx_glob)/(*nproc_x);
+  *i_beg = static_cast<size_t>( round( nper* (*px)    )   );
+  *i_end = static_cast<size_t>( round( nper*((*px)+1) )-1 );
+  nper = ((double) ny_glob)/(*nproc_y);
+  *j_beg = static_cast<size_t>( round( nper* (*py)    )   );
+  *j_end = static_cast<size_t>( round( nper*((*py)+1) )-1 );
+  for (int j = 0; j < 3; j++) {
+    for (int i = 0; i < 3; i++) {
+      int pxloc = *px+i-1;
+      while (pxloc < 0           ) { pxloc = pxloc + *nproc_x; }
+      while (pxloc > *nproc_x-1  ) { pxloc = pxloc - *nproc_x; }
+      int pyloc = *py+j-1;
+      while (pyloc < 0           ) { pyloc = pyloc + *nproc_y; }
+      while (pyloc > *nproc_y-1  ) { pyloc = pyloc - *nproc_y; }
+      neigh[j*3+i] = pyloc * (*nproc_x) + pxloc;
+    }
+  }
+}
+
+mwo_dycore *mwo_create(const mwo_params *p, const int *tracer_positive, const int *tracer_adds_mass) {
+  mwo_dycore *d = (mwo_dycore*)calloc(1,sizeof(mwo_dycore));
+  d->p = *p;
+  int nz=p->nz, ny=p->ny, nx=p->nx, nens=p->nens, nt=p->num_tracers;
+  d->tracer_positive  = (int*)malloc(sizeof(int)*(nt>0?nt:1));
+  d->tracer_adds_mass = (int*)malloc(sizeof(int)*(nt>0?nt:1));
+  for (int t=0;t<nt;t++) { d->tracer_positive[t] = tracer_positive[t]; d->tracer_adds_mass[t] = tracer_adds_mass[t]; }
+  d->hy_dens_cells       = (double*)calloc((size_t)nz*nens,8);
+  d->hy_dens_theta_cells = (double*)calloc((size_t)nz*nens,8);
+  d->hy_dens_edges       = (double*)calloc((size_t)(nz+1)*nens,8);
+  d->hy_dens_theta_edges = (double*)calloc((size_t)(nz+1)*nens,8);
+  d->immersed_proportion = (double*)calloc((size_t)nz*ny*nx*nens,8);
+  size_t nfx=(size_t)nz*ny*(nx+1)*nens, nfy=(size_t)nz*(ny+1)*nx*nens, nfz=(size_t)(nz+1)*ny*nx*nens;
+  d->state_flux_x = (double*)calloc(nfx*num_state,8); d->tracers_flux_x = (double*)calloc(nfx*(nt>0?nt:1),8);   // :1671-1682 (init to 0)
+  d->state_flux_y = (double*)calloc(nfy*num_state,8); d->tracers_flux_y = (double*)calloc(nfy*(nt>0?nt:1),8);
+  d->state_flux_z = (double*)calloc(nfz*num_state,8); d->tracers_flux_z = (double*)calloc(nfz*(nt>0?nt:1),8);
+  d->etime = 0;
+  d->xchg = self_xchg; d->xchg_ctx = NULL;
+  return d;
+}
+void mwo_destroy(mwo_dycore *d) {
+  if (!d) return;
+  free(d->tracer_positive); free(d->tracer_adds_mass);
+  free(d->hy_dens_cells); free(d->hy_dens_theta_cells); free(d->hy_dens_edges); free(d->hy_dens_theta_edges);
+  free(d->immersed_proportion);
+  free(d->state_flux_x); free(d->state_flux_y); free(d->state_flux_z);
+  free(d->tracers_flux_x); free(d->tracers_flux_y); free(d->tracers_flux_z);
+  free(d);
+}
+void mwo_set_exchange(mwo_dycore *d, mwo_xchg_fn fn, void *ctx) { d->xchg = fn ? fn : self_xchg; d->xchg_ctx = ctx; }
+mwo_params *mwo_params_ptr(mwo_dycore *d) { return &d->p; }
+double *mwo_hy_dens_cells(mwo_dycore *d)       { return d->hy_dens_cells; }
+double *mwo_hy_dens_theta_cells(mwo_dycore *d) { return d->hy_dens_theta_cells; }
+double *mwo_hy_dens_edges(mwo_dycore *d)       { return d->hy_dens_edges; }
+double *mwo_hy_dens_theta_edges(mwo_dycore *d) { return d->hy_dens_theta_edges; }
+double *mwo_immersed_proportion(mwo_dycore *d) { return d->immersed_proportion; }
+double *mwo_flux(mwo_dycore *d, int which) {   // 0..2 state x,y,z ; 3..5 tracers x,y,z
+  switch (which) { case 0: return d->state_flux_x; case 1: return d->state_flux_y; case 2: return d->state_flux_z;
+                   case 3: return d->tracers_flux_x; case 4: return d->tracers_flux_y; default: return d->tracers_flux_z; }
+}
+
+// City building heights: std::mt19937{17} + std::normal_distribution<>{60,10} in (j,i) order   :1440-1448
+// (libstdc++-specific sequence).  Returns nbuildings_y, nbuildings_x through pointers.
+void mwo_city_dims(const mwo_params *p, int *nbuildings_y, int *nbuildings_x) {
+  int building_length = 30, buildings_pad = 20;
+  int nblocks_x = (static_cast<int>(p->xlen)/building_length - 2*buildings_pad)/3;
+  int nblocks_y = (static_cast<int>(p->ylen)/building_length - 2*buildings_pad)/9;
+  *nbuildings_x = nblocks_x * 3;  *nbuildings_y = nblocks_y * 9;
+}
+void mwo_city_building_heights(int nbuildings_y, int nbuildings_x, double *heights) {
+  real height_mean = 60, height_std = 10;
+  std::mt19937 gen{17};
+  std::normal_distribution<> dd{height_mean, height_std};
+  for (int j=0; j < nbuildings_y; j++) for (int i=0; i < nbuildings_x; i++) heights[(size_t)j*nbuildings_x+i] = dd(gen);
+}
+
+// dycore.init    :1197-1683  (output() excluded: file I/O, out of scope).
+// The caller supplies the physical constants in params (as the Kessler module's init sets them first in
+// every driver, microphysics_kessler.h:86-95) and gets bc_x/bc_y/bc_z, use_immersed and latitude set here.
+void mwo_init(mwo_dycore *d, int init_data_int, double *dm_rho_d, double *dm_uvel, double *dm_vvel, double *dm_wvel,
+              double *dm_temp, double *const *dm_tracers) {
+  mwo_params &p = d->p;  Dims D(p);
+  p.latitude = 0;                                         // :1249
+  p.bc_x = BC_PERIODIC; p.bc_y = BC_PERIODIC; p.bc_z = BC_WALL;     // :1332-1334 etc. (same for all four cases)
+  p.use_immersed = 0;                                     // :1312
+  memset(d->immersed_proportion, 0, 8*D.n_cells());       // :1315
+  d->etime = 0;
+  real *state   = (real*)calloc(D.n_halo(num_state),8);
+  real *tracers = (real*)calloc(D.n_halo(p.num_tracers>0?p.num_tracers:1),8);
+  if (init_data_int == DATA_SUPERCELL) {
+    init_supercell(d, state, tracers);
+  } else if (init_data_int == DATA_THERMAL) {
+    init_quadrature_case(d, init_data_int, state, tracers, NULL, 0);
+  } else if (init_data_int == DATA_CITY) {
+    p.use_immersed = 1;                                   // :1426
+    int nby, nbx; mwo_city_dims(&p, &nby, &nbx);
+    real *bh = (real*)malloc(8*(size_t)(nby*nbx>0?nby*nbx:1));
+    mwo_city_building_heights(nby, nbx, bh);
+    init_quadrature_case(d, init_data_int, state, tracers, bh, nbx);
+    free(bh);
+  } else if (init_data_int == DATA_BUILDING) {
+    p.use_immersed = 1;                                   // :1554
+    init_quadrature_case(d, init_data_int, state, tracers, NULL, 0);
+  }
+  convert_dynamics_to_coupler(d, state, tracers, dm_rho_d, dm_uvel, dm_vvel, dm_wvel, dm_temp, dm_tracers);   // :1656
+  free(state); free(tracers);
+}
+
+// perturb_temperature(coupler, thermal=true, random=false)    perturb_temperature.h:41-66
+void mwo_perturb_temperature(const mwo_params *pp, double *temp) {
+  const mwo_params &p = *pp;  Dims D(p);
+  real dx=get_dx(p), dy=get_dy(p), dz=get_dz(p), xlen=p.xlen, ylen=p.ylen;
+  size_t i_beg=(size_t)p.i_beg, j_beg=(size_t)p.j_beg;
+  for (int k=0;k<p.nz;k++) for (int j=0;j<p.ny;j++) for (int i=0;i<p.nx;i++) for (int iens=0;iens<p.nens;iens++) {
+    real xloc = (i+i_beg+FP(0.5))*dx;
+    real yloc = (j+j_beg+FP(0.5))*dy;
+    real zloc = (k      +FP(0.5))*dz;
+    real x0 = xlen / 2;
+    real y0 = ylen / 2;
+    real z0 = 1500;
+    real radx = 10000;
+    real rady = 10000;
+    real radz = 1500;
+    real amp  = 5;
+    real xn = (xloc - x0) / radx;
+    real yn = (yloc - y0) / rady;
+    real zn = (zloc - z0) / radz;
+    real rad = sqrt( xn*xn + yn*yn + zn*zn );
+    if (rad < 1) { temp[D.C(k,j,i,iens)] += amp * pow( cos(M_PI*rad/2) , FP(2.) ); }
+  }
+}
+
+// One stage-level entry for unit tests: runs convert_coupler_to_dynamics + ONE compute_tendencies(dt) and
+// returns the tendencies (the six flux arrays are readable through mwo_flux).
+void mwo_stage_tendencies(mwo_dycore *d, const double *dm_rho_d, const double *dm_uvel, const double *dm_vvel,
+                          const double *dm_wvel, const double *dm_temp, double *const *dm_tracers, double dt,
+                          double *state_tend, double *tracers_tend) {
+  Dims D(d->p);
+  real *state   = (real*)calloc(D.n_halo(num_state),8);
+  real *tracers = (real*)calloc(D.n_halo(d->p.num_tracers>0?d->p.num_tracers:1),8);
+  convert_coupler_to_dynamics(d, dm_rho_d, dm_uvel, dm_vvel, dm_wvel, dm_temp, dm_tracers, state, tracers);
+  compute_tendencies(d, state, state_tend, tracers, tracers_tend, dt);
+  free(state); free(tracers);
+}
+
+// Dynamics_Euler_Stratified_WenoFV::time_step    :81-198   (output / maxw print :183-197 excluded: I/O)
+void mwo_time_step(mwo_dycore *d, double *dm_rho_d, double *dm_uvel, double *dm_vvel, double *dm_wvel, double *dm_temp,
+                   double *const *dm_tracers, double dt_phys) {
+  const mwo_params &p = d->p;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens, num_tracers=p.num_tracers;
+  const int *tracer_positive = d->tracer_positive;
+  int ntr = num_tracers>0?num_tracers:1;
+  real *state   = (real*)calloc(D.n_halo(num_state),8);     // :97-98
+  real *tracers = (real*)calloc(D.n_halo(ntr),8);
+  convert_coupler_to_dynamics(d, dm_rho_d, dm_uvel, dm_vvel, dm_wvel, dm_temp, dm_tracers, state, tracers);   // :101
+  real dt_dyn = mwo_compute_time_step(&p);                 // :104
+  int ncycles = (int) std::ceil( dt_phys / dt_dyn );       // :107
+  dt_dyn = dt_phys / ncycles;                              // :108
+  for (int icycle = 0; icycle < ncycles; icycle++) {
+    real *state_tmp    = (real*)calloc(D.n_halo(num_state),8);            // :112-115
+    real *state_tend   = (real*)calloc((size_t)num_state*D.n_cells(),8);
+    real *tracers_tmp  = (real*)calloc(D.n_halo(ntr),8);
+    real *tracers_tend = (real*)calloc((size_t)ntr*D.n_cells(),8);
+    // Stage 1  :119-132
+    compute_tendencies( d , state     , state_tend , tracers     , tracers_tend , dt_dyn );
+    for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+      for (int l = 0; l < num_state  ; l++) {
+        state_tmp  [D.H(l,hs+k,hs+j,hs+i,iens)] = state  [D.H(l,hs+k,hs+j,hs+i,iens)] + dt_dyn * state_tend  [D.T(l,k,j,i,iens)];
+      }
+      for (int l = 0; l < num_tracers; l++) {
+        tracers_tmp[D.H(l,hs+k,hs+j,hs+i,iens)] = tracers[D.H(l,hs+k,hs+j,hs+i,iens)] + dt_dyn * tracers_tend[D.T(l,k,j,i,iens)];
+        if (tracer_positive[l]) {
+          tracers_tmp[D.H(l,hs+k,hs+j,hs+i,iens)] = std::max( FP(0.) , tracers_tmp[D.H(l,hs+k,hs+j,hs+i,iens)] );
+        }
+      }
+    }
+    // Stage 2  :136-153
+    compute_tendencies( d , state_tmp , state_tend , tracers_tmp , tracers_tend , (FP(1.)/FP(4.)) * dt_dyn );
+    for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+      for (int l = 0; l < num_state  ; l++) {
+        state_tmp  [D.H(l,hs+k,hs+j,hs+i,iens)] = (FP(3.)/FP(4.)) * state      [D.H(l,hs+k,hs+j,hs+i,iens)] +
+                                                  (FP(1.)/FP(4.)) * state_tmp  [D.H(l,hs+k,hs+j,hs+i,iens)] +
+                                                  (FP(1.)/FP(4.)) * dt_dyn * state_tend  [D.T(l,k,j,i,iens)];
+      }
+      for (int l = 0; l < num_tracers; l++) {
+        tracers_tmp[D.H(l,hs+k,hs+j,hs+i,iens)] = (FP(3.)/FP(4.)) * tracers    [D.H(l,hs+k,hs+j,hs+i,iens)] +
+                                                  (FP(1.)/FP(4.)) * tracers_tmp[D.H(l,hs+k,hs+j,hs+i,iens)] +
+                                                  (FP(1.)/FP(4.)) * dt_dyn * tracers_tend[D.T(l,k,j,i,iens)];
+        if (tracer_positive[l]) {
+          tracers_tmp[D.H(l,hs+k,hs+j,hs+i,iens)] = std::max( FP(0.) , tracers_tmp[D.H(l,hs+k,hs+j,hs+i,iens)] );
+        }
+      }
+    }
+    // Stage 3  :157-174
+    compute_tendencies( d , state_tmp , state_tend , tracers_tmp , tracers_tend , (FP(2.)/FP(3.)) * dt_dyn );
+    for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+      for (int l = 0; l < num_state  ; l++) {
+        state      [D.H(l,hs+k,hs+j,hs+i,iens)] = (FP(1.)/FP(3.)) * state      [D.H(l,hs+k,hs+j,hs+i,iens)] +
+                                                  (FP(2.)/FP(3.)) * state_tmp  [D.H(l,hs+k,hs+j,hs+i,iens)] +
+                                                  (FP(2.)/FP(3.)) * dt_dyn * state_tend  [D.T(l,k,j,i,iens)];
+      }
+      for (int l = 0; l < num_tracers; l++) {
+        tracers    [D.H(l,hs+k,hs+j,hs+i,iens)] = (FP(1.)/FP(3.)) * tracers    [D.H(l,hs+k,hs+j,hs+i,iens)] +
+                                                  (FP(2.)/FP(3.)) * tracers_tmp[D.H(l,hs+k,hs+j,hs+i,iens)] +
+                                                  (FP(2.)/FP(3.)) * dt_dyn * tracers_tend[D.T(l,k,j,i,iens)];
+        if (tracer_positive[l]) {
+          tracers    [D.H(l,hs+k,hs+j,hs+i,iens)] = std::max( FP(0.) , tracers    [D.H(l,hs+k,hs+j,hs+i,iens)] );
+        }
+      }
+    }
+    free(state_tmp); free(state_tend); free(tracers_tmp); free(tracers_tend);
+  }
+  convert_dynamics_to_coupler(d, state, tracers, dm_rho_d, dm_uvel, dm_vvel, dm_wvel, dm_temp, dm_tracers);   // :178
+  d->etime += dt_phys;                                                                                        // :181
+  free(state); free(tracers);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Microphysics_Kessler::time_step + kessler()     microphysics_kessler.h:99-162, :234-339
+// Arrays are (nz,ncol) views of the (nz,ny,nx,nens) coupler fields (get_lev_col); precl is (ncol).
+// Constants from the module's constructor (:29-41).  Returns rainsplit (for tests).
+// -----------------------------------------------------------------------------------------------------
+int mwo_kessler_time_step(int nz, long long ncol_ll, double dz, double dt,
+                          double *rho_v, double *rho_c, double *rho_r, const double *rho_dry, double *temp, double *precl) {
+  size_t ncol = (size_t)ncol_ll;
+  real R_d = 287., cp_d = 1003., R_v = 461., p0 = 1.e5;
+  size_t n = (size_t)nz*ncol;
+  real *qv=(real*)malloc(8*n), *qc=(real*)malloc(8*n), *qr=(real*)malloc(8*n), *pressure=(real*)malloc(8*n),
+       *theta=(real*)malloc(8*n), *exner=(real*)malloc(8*n), *zmid=(real*)malloc(8*n);
+  #define A(a,k,i) a[(size_t)(k)*ncol+(i)]
+  // :136-144 [K1]
+  for (int k=0;k<nz;k++) for (size_t i=0;i<ncol;i++) {
+    A(zmid    ,k,i) = (k+FP(0.5)) * dz;
+    A(qv      ,k,i) = A(rho_v,k,i) / A(rho_dry,k,i);
+    A(qc      ,k,i) = A(rho_c,k,i) / A(rho_dry,k,i);
+    A(qr      ,k,i) = A(rho_r,k,i) / A(rho_dry,k,i);
+    A(pressure,k,i) = R_d * A(rho_dry,k,i) * A(temp,k,i) + R_v * A(rho_v,k,i) * A(temp,k,i);
+    A(exner   ,k,i) = pow( A(pressure,k,i) / p0 , R_d / cp_d );
+    A(theta   ,k,i) = A(temp,k,i) / A(exner,k,i);
+  }
+  // kessler(theta, qv, qc, qr, rho_dry, precl, zmid, exner, dt, R_d, cp_d, p0)   :151 -> :234
+  const real *rho = rho_dry, *z = zmid, *pk = exner;
+  real Rd = R_d, cp = cp_d;
+  real psl    = p0 / 100;
+  real rhoqr  = FP(1000.);
+  real lv     = FP(2.5e6);
+  real *r=(real*)malloc(8*n), *rhalf=(real*)malloc(8*n), *pc=(real*)malloc(8*n), *velqr=(real*)malloc(8*n),
+       *dt2d=(real*)malloc(8*(size_t)(nz>1?nz-1:1)*ncol), *sed=(real*)malloc(8*n);
+  // :255-273 [K2]
+  for (int k=0;k<nz;k++) for (size_t i=0;i<ncol;i++) {
+    A(r    ,k,i) = FP(0.001) * A(rho,k,i);
+    A(rhalf,k,i) = sqrt( A(rho,0,i) / A(rho,k,i) );
+    A(pc   ,k,i) = FP(3.8) / ( pow( A(pk,k,i) , cp/Rd ) * psl );
+    A(velqr,k,i) = FP(36.34) * pow( A(qr,k,i)*A(r,k,i) , FP(0.1364) ) * A(rhalf,k,i);
+    if (k < nz-1) {
+      if (A(velqr,k,i) > FP(1.e-10)) { A(dt2d,k,i) = FP(0.8) * (A(z,k+1,i)-A(z,k,i))/A(velqr,k,i); }
+      else                           { A(dt2d,k,i) = dt; }
+    }
+    if (k == 0) { precl[i] = 0; }
+  }
+  // :276 [K3]
+  real dt_max = A(dt2d,0,0);
+  for (size_t m=0; m<(size_t)(nz-1)*ncol; m++) dt_max = std::min(dt_max, dt2d[m]);
+  int rainsplit = ceil(dt / dt_max);                 // :279
+  real dt0 = dt / static_cast<real>(rainsplit);      // :280
+  for (int nt=0; nt < rainsplit; nt++) {             // :285
+    // :288-299
+    for (int k=0;k<nz;k++) for (size_t i=0;i<ncol;i++) {
+      if (k == 0) { precl[i] = precl[i] + A(rho,0,i) * A(qr,0,i) * A(velqr,0,i) / rhoqr; }
+      if (k == nz-1) {
+        A(sed,nz-1,i) = -dt0*A(qr,nz-1,i)*A(velqr,nz-1,i)/(FP(0.5) * (A(z,nz-1,i)-A(z,nz-2,i)));
+      } else {
+        A(sed,k,i) = dt0 * ( A(r,k+1,i)*A(qr,k+1,i)*A(velqr,k+1,i) -
+                             A(r,k  ,i)*A(qr,k  ,i)*A(velqr,k  ,i) ) / ( A(r,k,i)*(A(z,k+1,i)-A(z,k,i)) );
+      }
+    }
+    // :302-335
+    for (int k=0;k<nz;k++) for (size_t i=0;i<ncol;i++) {
+      real qrprod = A(qc,k,i) - ( A(qc,k,i)-dt0*std::max( FP(0.001) * (A(qc,k,i)-FP(0.001)) , FP(0.) ) ) /
+                                ( 1 + dt0 * FP(2.2) * pow( A(qr,k,i) , FP(0.875) ) );
+      A(qc,k,i) = std::max( A(qc,k,i)-qrprod , FP(0.) );
+      A(qr,k,i) = std::max( A(qr,k,i)+qrprod+A(sed,k,i) , FP(0.) );
+      real tmp = A(pk,k,i)*A(theta,k,i)-FP(36.);
+      real qvs = A(pc,k,i)*exp( FP(17.27) * (A(pk,k,i)*A(theta,k,i)-FP(273.)) / tmp );
+      real prod = (A(qv,k,i)-qvs) / (FP(1.) + qvs*(FP(4093.) * lv/cp)/(tmp*tmp));
+      real tmp1 = dt0*( ( ( FP(1.6) + FP(124.9) * pow( A(r,k,i)*A(qr,k,i) , FP(0.2046) ) ) *
+                          pow( A(r,k,i)*A(qr,k,i) , FP(0.525) ) ) /
+                        ( FP(2550000.) * A(pc,k,i) / (FP(3.8) * qvs)+FP(540000.)) ) *
+                      ( std::max(qvs-A(qv,k,i),FP(0.)) / (A(r,k,i)*qvs) );
+      real tmp2 = std::max( -prod-A(qc,k,i) , FP(0.) );
+      real tmp3 = A(qr,k,i);
+      real ern = std::min( tmp1 , std::min( tmp2 , tmp3 ) );
+      A(theta,k,i)= A(theta,k,i) + lv / (cp*A(pk,k,i)) * ( std::max( prod , -A(qc,k,i) ) - ern );
+      A(qv,k,i) = std::max( A(qv,k,i) - std::max( prod , -A(qc,k,i) ) + ern , FP(0.) );
+      A(qc,k,i) = A(qc,k,i) + std::max( prod , -A(qc,k,i) );
+      A(qr,k,i) = A(qr,k,i) - ern;
+      A(velqr,k,i)  = FP(36.34) * pow( A(qr,k,i)*A(r,k,i) , FP(0.1364) ) * A(rhalf,k,i);
+      if (k == 0 && nt == rainsplit-1) { precl[i] = precl[i] / static_cast<real>(rainsplit); }
+    }
+  }
+  // :154-161 [K5]
+  for (int k=0;k<nz;k++) for (size_t i=0;i<ncol;i++) {
+    A(rho_v,k,i) = A(qv,k,i)*A(rho_dry,k,i);
+    A(rho_c,k,i) = A(qc,k,i)*A(rho_dry,k,i);
+    A(rho_r,k,i) = A(qr,k,i)*A(rho_dry,k,i);
+    A(temp ,k,i) = A(theta,k,i) * A(exner,k,i);
+  }
+  #undef A
+  free(qv); free(qc); free(qr); free(pressure); free(theta); free(exner); free(zmid);
+  free(r); free(rhalf); free(pc); free(velqr); free(dt2d); free(sed);
+  return rainsplit;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Surrogate NN block   experiments/supercell_kessler_surrogate/custom_modules/microphysics_kessler_ponni.h:176-202
+// ponni source is absent (empty submodule): layers restated from the call sites :103-110 and Keras Dense
+// semantics (kernel stored (in,out); y = x.W + b; LeakyReLU alpha = 0.1), fp32, accumulation in index order
+// with the bias added after the matvec (Matvec layer then Bias layer).   PARITY UNPINNED.
+// W1 (5,10) row-major, b1 (10), W2 (10,4) row-major, b2 (4); scl_in (5,2), scl_out (4,2) as [min,max] rows.
+// -----------------------------------------------------------------------------------------------------
+void mwo_mlp_forward(long long ncells, const double *temp, const double *rho_d, const double *rho_v, const double *rho_c,
+                     const double *rho_r, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const double *scl_in, const double *scl_out,
+                     double *temp_out, double *rho_v_out, double *rho_c_out, double *rho_r_out) {
+  for (long long c = 0; c < ncells; c++) {
+    float x[5];
+    x[0] = (float)( ( temp [c] - scl_in[0*2+0] ) / ( scl_in[0*2+1] - scl_in[0*2+0] ) );   // :182-186 (fp64 math, stored to float)
+    x[1] = (float)( ( rho_d[c] - scl_in[1*2+0] ) / ( scl_in[1*2+1] - scl_in[1*2+0] ) );
+    x[2] = (float)( ( rho_v[c] - scl_in[2*2+0] ) / ( scl_in[2*2+1] - scl_in[2*2+0] ) );
+    x[3] = (float)( ( rho_c[c] - scl_in[3*2+0] ) / ( scl_in[3*2+1] - scl_in[3*2+0] ) );
+    x[4] = (float)( ( rho_r[c] - scl_in[4*2+0] ) / ( scl_in[4*2+1] - scl_in[4*2+0] ) );
+    float h[10];
+    for (int o = 0; o < 10; o++) {
+      float acc = 0.f;
+      for (int i = 0; i < 5; i++) acc += x[i] * W1[i*10+o];
+      acc = acc + b1[o];
+      h[o] = acc > 0.f ? acc : 0.1f * acc;
+    }
+    float y[4];
+    for (int o = 0; o < 4; o++) {
+      float acc = 0.f;
+      for (int i = 0; i < 10; i++) acc += h[i] * W2[i*4+o];
+      y[o] = acc + b2[o];
+    }
+    temp_out [c] =                      y[0] * (scl_out[0*2+1] - scl_out[0*2+0]) + scl_out[0*2+0]  ;   // :198-201
+    rho_v_out[c] = std::max( FP(0.) , y[1] * (scl_out[1*2+1] - scl_out[1*2+0]) + scl_out[1*2+0] );
+    rho_c_out[c] = std::max( FP(0.) , y[2] * (scl_out[2*2+1] - scl_out[2*2+0]) + scl_out[2*2+0] );
+    rho_r_out[c] = std::max( FP(0.) , y[3] * (scl_out[3*2+1] - scl_out[3*2+0]) + scl_out[3*2+0] );
+  }
+}
+
+} // extern "C"
