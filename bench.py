@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native dycore.
+
+    python bench.py --gpus N --steps K --warmup W
+
+metric  : cell-updates/s (whole job) of Dynamics_Euler_Stratified_WenoFV::time_step on the supercell grid.
+          One cell-update = one (k,j,i,iens) cell advanced through one dycore sub-cycle (3 SSPRK stages, all
+          V = 8 prognostic variables) -- SURVEY.md 8(d).  A "step" = one time_step(coupler, dt_CFL) call.
+workload: BASELINE.json configs[1]: supercell 400x400x100, nens 1, fp64, 3 Kessler tracers advected, dycore only,
+          dx = dy = 500 m, dz = 200 m, out_freq = -1, dt_phys = CFL step (community_benchmark/driver.cpp:66-82 timed
+          region).  N > 1: weak scaling, every GPU keeps a 400x400x100 block of a (400*nproc_x) x (400*nproc_y) x 100
+          grid (2-D x/y decomposition of coupler.h:127-179), 3-cell halos exchanged over RCCL once per RK stage.
+timing  : W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(); max over ranks.
+roofline: dominant kernel k_flux (WENO reconstruction + Riemann, one launch per RK stage): algorithmic bytes
+          32*V B/cell (read V, write 3V fluxes) / average launch duration from hipEvents recorded on the kernel's
+          stream inside the timed region (mw_dycore_profile); peak 8 TB/s HBM3E spec.
+cpu_baseline: the CPU oracle (a port: the reference itself is unbuildable here) timed on one host core
+          on BASELINE.json configs[0] (supercell 200x200x50), rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nx", type=int, default=400, help="local block, x")
+    ap.add_argument("--ny", type=int, default=400, help="local block, y")
+    ap.add_argument("--nz", type=int, default=100)
+    ap.add_argument("--nens", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=str, default="200x200x50", help="oracle sample grid nx x ny x nz")
+    ap.add_argument("--strict", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(sample):
+    """Oracle (port of the reference's serial path) on a bounded sample of the same workload, one host core."""
+    from oracle import mw_oracle as O
+    nx, ny, nz = [int(v) for v in sample.split("x")]
+    dyc, f = O.supercell_setup(nx, ny, nz, 1, 500.0 * nx, 500.0 * ny, 20000.0)
+    dt = dyc.compute_time_step()
+    t0 = time.perf_counter()
+    dyc.time_step(f, dt)
+    el = time.perf_counter() - t0
+    return {"value": nx * ny * nz / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": "1 dycore time_step (3 RK stages) of supercell %dx%dx%d nens=1, 3 tracers, CPU oracle "
+                      "(oracle/mw_oracle.cpp, -O2 -ffp-contract=off), %.1f s on 1 of %d host cores" % (nx, ny, nz, el, os.cpu_count())}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0 and world != 1:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+
+    from miniweatherml_amd import capi, modules
+    import ctypes as C
+    L = capi.lib()
+
+    # global grid: every rank keeps an (nx, ny, nz) block (weak scaling)
+    g0 = capi.Grid()
+    capi.check(L.mw_decompose(world, rank, a.nx * world, a.ny * world if a.ny > 1 else 1, C.byref(g0)))   # only to learn nproc_x/y
+    npx, npy = g0.nproc_x, g0.nproc_y
+    nx_glob, ny_glob = a.nx * npx, (a.ny * npy if a.ny > 1 else 1)
+    xlen, ylen, zlen = 500.0 * nx_glob, 500.0 * max(ny_glob, 1) if ny_glob > 1 else 500.0 * a.ny, 20000.0
+    coupler, dycore, micro = modules.make_supercell(nx_glob, ny_glob, a.nz, a.nens, xlen, ylen, zlen, "supercell", device,
+                                                    nranks=world, myrank=rank)
+    assert coupler.get_nx() == a.nx and (coupler.get_ny() == a.ny or ny_glob == 1)
+    dycore.set_strict(a.strict)
+    if world > 1:
+        ident = torch.zeros(128, dtype=torch.uint8, device=device)
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            capi.check(L.mw_rccl_unique_id(buf))
+            ident.copy_(torch.tensor(list(buf.raw), dtype=torch.uint8))
+        dist.broadcast(ident, 0)
+        capi.check(L.mw_dycore_use_rccl(dycore.h, bytes(ident.cpu().tolist()), world, rank))
+
+    dt = dycore.compute_time_step(coupler)
+    V = 5 + coupler.get_num_tracers()
+    ncells_local = a.nx * coupler.get_ny() * a.nz * a.nens
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        dycore.time_step(coupler, dt)
+    sync()
+    dycore.profile(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        dycore.time_step(coupler, dt)
+    sync()
+    el = time.perf_counter() - t0
+    prof = {n: dycore.profile_get(i) for i, n in enumerate(["flux", "fct", "update", "halo", "convert"])}
+    dycore.profile(0)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # sanity: the run must still be physical (no NaN) -- a blown-up run would be an invalid measurement
+    wmax = float(coupler.get_data_manager_readonly().get("wvel", True).abs().max())
+    assert wmax == wmax and wmax < 100.0, "unphysical state after the timed region (max|w| = %r)" % wmax
+
+    if rank == 0:
+        ncycles = 1
+        total_updates = float(ncells_local) * world * ncycles * a.steps
+        value = total_updates / el
+        flux_ms, flux_n = prof["flux"]
+        avg_flux_s = flux_ms / 1e3 / max(1, flux_n)
+        alg_bytes = 32.0 * V * ncells_local                      # per launch: read V, write 3V doubles per cell
+        achieved = alg_bytes / avg_flux_s / 1e9 if flux_n else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_flux_latest.json")
+        if os.path.exists(pmc):
+            try:
+                pj = json.load(open(pmc))
+                if pj.get("workload") == "%dx%dx%dx%d" % (a.nx, a.ny, a.nz, a.nens):
+                    traffic = pj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "cell-updates/s", "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "supercell %dx%dx%d nens=%d per GPU (global %dx%dx%d), WENO-FV dycore only, 3 tracers, "
+                                   "CFL dt" % (a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz),
+                       "parallelism": "%dx%d slab" % (npx, npy), "V": V, "strict": a.strict,
+                       "alg_bytes_per_cell_update": 64 * V,
+                       "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world},
+            "roofline": {"bound": "hbm", "kernel": "k_flux", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
+                         "avg_launch_ms": avg_flux_s * 1e3, "launches": flux_n,
+                         "alg_bytes_per_launch": alg_bytes,
+                         "fp64_nominal_tflops": (4.4e3 * ncells_local / avg_flux_s / 1e12) if flux_n else None},
+            "kernel_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

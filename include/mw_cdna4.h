@@ -1,0 +1,158 @@
+/* =====================================================================================================
+ * mw_cdna4.h -- C ABI of the MI355X-native (gfx950 / CDNA4) miniWeatherML hot path.
+ *
+ * One shared library, libmw_cdna4.so (miniweatherml_amd/csrc), exports exactly the symbols declared
+ * here.  Plain pointers and sizes only; no C++ or torch types.  All field pointers are DEVICE pointers
+ * (hipMalloc'd / torch.cuda tensors) unless a parameter is documented as "host".  All arithmetic is IEEE
+ * fp64 except the MLP (fp32 inside, fp64 at the boundary).  Array layout everywhere: C row-major, last
+ * index fastest, coupler fields (nz,ny,nx,nens)  -- reference: model/core/coupler.h:323-330.
+ *
+ * Every entry point returns 0 on success, non-zero on failure; mw_last_error() then returns the message
+ * (replaces the reference's endrun()/yakl_throw abort, model/main_header.h:66-68).  A missing GPU, a
+ * failed kernel launch or an unsupported option is an ERROR -- there is no CPU fallback in this library.
+ *
+ * Each function cites the reference interface it replaces (paths relative to the reference repo root).
+ * ===================================================================================================== */
+#ifndef MW_CDNA4_H
+#define MW_CDNA4_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MW_NUM_STATE 5          /* dynamics_euler_stratified_wenofv.h:31 */
+#define MW_MAX_TRACERS 16
+
+/* test cases, dynamics_euler_stratified_wenofv.h:41-44 */
+enum { MW_DATA_THERMAL = 0, MW_DATA_SUPERCELL = 1, MW_DATA_CITY = 2, MW_DATA_BUILDING = 3 };
+/* boundary conditions, dynamics_euler_stratified_wenofv.h:46-48 */
+enum { MW_BC_PERIODIC = 0, MW_BC_OPEN = 1, MW_BC_WALL = 2 };
+
+/* Everything the dycore pulls out of core::Coupler getters and options
+ * (coupler.h:219-278 geometry getters; options set/read at dynamics_euler_stratified_wenofv.h:211-226,
+ * 1227-1249,1300,1312,1332-1335). */
+typedef struct {
+  int nz, ny, nx, nens, num_tracers;          /* local sizes: coupler.get_nz/ny/nx/nens/num_tracers            */
+  long long nx_glob, ny_glob, i_beg, j_beg;   /* coupler.get_nx_glob/ny_glob/i_beg/j_beg                       */
+  double xlen, ylen, zlen;                    /* coupler.get_xlen/ylen/zlen ; dx = xlen/nx_glob etc.           */
+  int px, py, nproc_x, nproc_y;               /* coupler.get_px/py/nproc_x/nproc_y                             */
+  int neigh[9];                               /* coupler.get_neighbor_rankid_matrix(), [y][x] row-major 3x3    */
+  int bc_x, bc_y, bc_z;                       /* options "bc_x","bc_y","bc_z"                                  */
+  int use_immersed, enable_gravity;           /* options "use_immersed_boundaries","enable_gravity"            */
+  int idWV;                                   /* option "idWV": index of the tracer named water_vapor          */
+  double R_d, R_v, cp_d, cp_v, p0, grav, gamma_d, kappa_d, C0, earthrot, latitude;   /* real options           */
+} mw_grid_t;
+
+typedef struct mw_dycore_s *mw_dycore_t;      /* opaque: module-private persistent state (hy_dens_*, flags,     */
+                                              /* etime, workspace) -- the reference keeps it in the module      */
+                                              /* object, dynamics_euler_stratified_wenofv.h:51-66               */
+
+const char *mw_last_error(void);
+int  mw_device_count(void);                   /* >0 iff a HIP device is usable                                  */
+
+/* ---- decomposition + constants (host only) -------------------------------------------------------- */
+/* core::Coupler::distribute_mpi_and_allocate_coupled_state, coupler.h:110-214 (factorisation :133-140,
+ * index ranges :147-153, neighbour matrix :169-179).  Fills nx,ny,nx_glob,ny_glob,i_beg,j_beg,px,py,
+ * nproc_x,nproc_y,neigh of *g; leaves the rest untouched. */
+int  mw_decompose(int nranks, int myrank, long long nx_glob, long long ny_glob, mw_grid_t *g);
+/* Physical constants exactly as Microphysics_Kessler::init then Dynamics::init leave them in the coupler
+ * options: microphysics_kessler.h:29-41,86-95 ; dynamics_euler_stratified_wenofv.h:1227-1249. */
+int  mw_default_constants(mw_grid_t *g);
+/* Dynamics_Euler_Stratified_WenoFV::compute_time_step, dynamics_euler_stratified_wenofv.h:70-77 */
+double mw_dycore_compute_time_step(const mw_grid_t *g);
+
+/* ---- dycore --------------------------------------------------------------------------------------- */
+/* Allocates the device workspace (two halo'd prognostic slabs + six flux arrays, reused across calls --
+ * the reference re-allocates them every call/cycle/stage, :97-98,:112-115,:260-265).  `stream` is a
+ * hipStream_t (NULL = default stream); all work of this handle is ordered on it.
+ * tracer_positive / tracer_adds_mass: host arrays [num_tracers], Coupler::get_tracer_info (:1285-1293). */
+int  mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tracer_positive,
+                      const unsigned char *tracer_adds_mass, void *stream);
+void mw_dycore_destroy(mw_dycore_t h);
+
+/* Dynamics_Euler_Stratified_WenoFV::init, :1197-1683 (file output :1659 excluded).  Builds the hydrostatic
+ * background + immersed_proportion for `init_data` (MW_DATA_*), sets bc_x/bc_y/bc_z/use_immersed/latitude as
+ * the reference does, and writes the initial COUPLER fields (density_dry,uvel,vvel,wvel,temp,tracers[T]). */
+int  mw_dycore_init(mw_dycore_t h, int init_data, double *density_dry, double *uvel, double *vvel, double *wvel,
+                    double *temp, double *const *tracers /* host array of T device ptrs */);
+/* For callers that build their own initial state: set the persistent background directly.
+ * hy_*: HOST arrays (nz,nens) / (nz+1,nens); immersed_proportion: DEVICE (nz,ny,nx,nens) or NULL (= zeros). */
+int  mw_dycore_set_background(mw_dycore_t h, const double *hy_dens_cells, const double *hy_dens_theta_cells,
+                              const double *hy_dens_edges, const double *hy_dens_theta_edges,
+                              const double *immersed_proportion);
+/* Copies the background to HOST arrays (any may be NULL).  Registered in the coupler by the reference at
+ * :1663-1668 (cells) ; edges are module members :53-54. */
+int  mw_dycore_get_background(mw_dycore_t h, double *hy_dens_cells, double *hy_dens_theta_cells,
+                              double *hy_dens_edges, double *hy_dens_theta_edges);
+/* DEVICE pointer of immersed_proportion (nz,ny,nx,nens), registered by the reference at :1313. */
+double *mw_dycore_immersed_proportion(mw_dycore_t h);
+/* Current grid/options of the handle (bc_*, use_immersed, latitude may have been set by mw_dycore_init). */
+int  mw_dycore_get_grid(mw_dycore_t h, mw_grid_t *g);
+/* coupler options "bc_x","bc_y","bc_z" (read at :588-590, :846-848); mw_dycore_init sets them like :1332-1334. */
+int  mw_dycore_set_bc(mw_dycore_t h, int bc_x, int bc_y, int bc_z);
+/* strict = 1: flux stencil in the reference's exact operation order with FMA contraction off (diagnostic /
+ * parity proof; also selected by env MW_STRICT=1 at create).  strict = 0 (default): re-associated fast path. */
+int  mw_dycore_set_strict(mw_dycore_t h, int strict);
+
+/* Dynamics_Euler_Stratified_WenoFV::time_step(coupler, dt_phys), :81-198: convert-in, ncycles x SSPRK3,
+ * convert-out, etime += dt_phys.  Fields are updated in place.  Asynchronous on the handle's stream. */
+int  mw_dycore_time_step(mw_dycore_t h, double *density_dry, double *uvel, double *vvel, double *wvel, double *temp,
+                         double *const *tracers /* host array of T device ptrs */, double dt_phys);
+/* One compute_tendencies(state(coupler fields), dt) as the first RK stage sees it, :204-552: fills the six
+ * public flux arrays and writes state_tend (5,nz,ny,nx,nens) / tracers_tend (T,nz,ny,nx,nens) (DEVICE, may be
+ * NULL).  Test/diagnostic entry; the fields are not modified. */
+int  mw_dycore_compute_tendencies(mw_dycore_t h, const double *density_dry, const double *uvel, const double *vvel,
+                                  const double *wvel, const double *temp, double *const *tracers, double dt,
+                                  double *state_tend, double *tracers_tend);
+/* The six persistent flux arrays the reference registers "so the user has access", :1671-1676:
+ * out[0..2] = state_flux_x,y,z (5,nz[+1],ny[+1],nx[+1],nens); out[3..5] = tracers_flux_x,y,z (T,...). DEVICE. */
+int  mw_dycore_get_fluxes(mw_dycore_t h, double **out6);
+double mw_dycore_get_etime(mw_dycore_t h);   /* member etime, :55 */
+/* Name + total time (ms) of this handle's kernels measured with hipEvents on the handle's stream since the
+ * last reset (enabled by mw_dycore_profile(h,1)); which: 0 flux stencil, 1 fct, 2 update, 3 halo, 4 convert. */
+int  mw_dycore_profile(mw_dycore_t h, int enable);
+int  mw_dycore_profile_get(mw_dycore_t h, int which, double *total_ms, long long *launches);
+
+/* modules::perturb_temperature(coupler, thermal=true, random=false), perturb_temperature.h:41-66 */
+int  mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream);
+
+/* ---- multi-GPU halo exchange ---------------------------------------------------------------------- */
+/* halo_exchange, :574-747 (MPI_Isend/Irecv W/E/S/N, tags 0-3).  The native design ships a 3-cell halo once
+ * per RK stage and reconstructs the neighbour's edge values locally, which makes edge_exchange (:830-1003)
+ * unnecessary (bitwise identical: reconstruction is a pure function of the 5-cell stencil).
+ * The callback receives DEVICE buffers packed as (V,nz,ny,3,nens) [W/E] and (V,nz,3,nx,nens) [S/N] and must
+ * deliver sendW to the west neighbour's recvE etc., ordered on `stream`.  NULL => single-rank periodic wrap. */
+typedef int (*mw_exchange_fn)(void *ctx, const double *sendW, const double *sendE, const double *sendS,
+                              const double *sendN, double *recvW, double *recvE, double *recvS, double *recvN,
+                              long long nWE, long long nSN, void *stream);
+int  mw_dycore_set_exchange(mw_dycore_t h, mw_exchange_fn fn, void *ctx);
+/* Built-in exchange over RCCL point-to-point (ncclSend/ncclRecv in one group on a side stream).
+ * unique_id: the 128-byte ncclUniqueId created on rank 0 (mw_rccl_unique_id) and broadcast by the host. */
+int  mw_rccl_unique_id(unsigned char *id128);
+int  mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, int myrank);
+
+/* ---- Kessler microphysics ------------------------------------------------------------------------- */
+/* Microphysics_Kessler::time_step(coupler, dt), microphysics_kessler.h:99-162 + kessler() :234-339.
+ * (nz,ncol) views of water_vapor, cloud_liquid, precip_liquid, density_dry(const), temp; precl (ncol).
+ * rainsplit is taken from THIS rank's minval exactly like the reference (:276-279).  workspace: DEVICE scratch
+ * of mw_kessler_workspace_bytes(nz,ncol) bytes.  rainsplit_out: optional HOST int (forces a stream sync). */
+long long mw_kessler_workspace_bytes(int nz, long long ncol);
+int  mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *rho_v, double *rho_c, double *rho_r,
+                          const double *rho_d, double *temp, double *precl, void *workspace, int *rainsplit_out,
+                          void *stream);
+
+/* ---- ponni surrogate MLP -------------------------------------------------------------------------- */
+/* NN block of custom_modules::Microphysics_Kessler::time_step,
+ * experiments/supercell_kessler_surrogate/custom_modules/microphysics_kessler_ponni.h:176-202
+ * (ponni::Matvec,Bias,Relu(0.1),Matvec,Bias ; model.forward_batch_parallel :189), fused with the min-max
+ * input scaling :182-186 and output un-scaling + clip :198-201.  W1 (5,10), b1 (10), W2 (10,4), b2 (4):
+ * HOST fp32, Keras (in,out) layout; scl_in (5,2), scl_out (4,2): HOST fp64 [min,max] rows. */
+int  mw_mlp_forward(long long ncells, const double *temp, const double *rho_d, const double *rho_v,
+                    const double *rho_c, const double *rho_r, const float *W1, const float *b1, const float *W2,
+                    const float *b2, const double *scl_in, const double *scl_out, double *temp_out,
+                    double *rho_v_out, double *rho_c_out, double *rho_r_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MW_CDNA4_H */

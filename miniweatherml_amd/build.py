@@ -1,0 +1,50 @@
+"""Builds libmw_cdna4.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m miniweatherml_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the built .so travels to the GPU box with the repo snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmw_cdna4.so")
+SOURCES = ["mw_host.cpp", "mw_dycore.hip", "mw_kessler.hip", "mw_mlp.hip", "mw_rccl.cpp"]
+HEADERS = ["mw_common.h", "mw_weno.h", os.path.join("..", "..", "include", "mw_cdna4.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable", "-ffp-contract=on", "-I/opt/rocm/include"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=True):
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for s in srcs:
+        o = os.path.splitext(s)[0] + ".o"
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if s.endswith(".hip") else []) + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + \
+              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

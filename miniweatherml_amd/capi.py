@@ -1,0 +1,102 @@
+"""ctypes binding of libmw_cdna4.so -- the C ABI declared in include/mw_cdna4.h.
+
+This is the only way Python reaches the hot path.  If the shared library is missing or cannot be loaded
+the import of the symbols FAILS LOUDLY (no CPU fallback, no oracle).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmw_cdna4.so")
+
+MW_MAX_TRACERS = 16
+DATA_THERMAL, DATA_SUPERCELL, DATA_CITY, DATA_BUILDING = 0, 1, 2, 3
+BC_PERIODIC, BC_OPEN, BC_WALL = 0, 1, 2
+INIT_IDS = {"thermal": DATA_THERMAL, "supercell": DATA_SUPERCELL, "city": DATA_CITY, "building": DATA_BUILDING}
+
+
+class Grid(C.Structure):
+    """mw_grid_t"""
+    _fields_ = [
+        ("nz", C.c_int), ("ny", C.c_int), ("nx", C.c_int), ("nens", C.c_int), ("num_tracers", C.c_int),
+        ("nx_glob", C.c_longlong), ("ny_glob", C.c_longlong), ("i_beg", C.c_longlong), ("j_beg", C.c_longlong),
+        ("xlen", C.c_double), ("ylen", C.c_double), ("zlen", C.c_double),
+        ("px", C.c_int), ("py", C.c_int), ("nproc_x", C.c_int), ("nproc_y", C.c_int),
+        ("neigh", C.c_int * 9),
+        ("bc_x", C.c_int), ("bc_y", C.c_int), ("bc_z", C.c_int),
+        ("use_immersed", C.c_int), ("enable_gravity", C.c_int),
+        ("idWV", C.c_int),
+        ("R_d", C.c_double), ("R_v", C.c_double), ("cp_d", C.c_double), ("cp_v", C.c_double), ("p0", C.c_double),
+        ("grav", C.c_double), ("gamma_d", C.c_double), ("kappa_d", C.c_double), ("C0", C.c_double),
+        ("earthrot", C.c_double), ("latitude", C.c_double),
+    ]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p)
+
+# every symbol include/mw_cdna4.h declares (checked by tests/test_capi_symbols.py against the header text)
+SYMBOLS = {
+    "mw_last_error": (C.c_char_p, []),
+    "mw_device_count": (C.c_int, []),
+    "mw_decompose": (C.c_int, [C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.POINTER(Grid)]),
+    "mw_default_constants": (C.c_int, [C.POINTER(Grid)]),
+    "mw_dycore_compute_time_step": (C.c_double, [C.POINTER(Grid)]),
+    "mw_dycore_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Grid), C.c_char_p, C.c_char_p, C.c_void_p]),
+    "mw_dycore_destroy": (None, [C.c_void_p]),
+    "mw_dycore_init": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.POINTER(C.c_void_p)]),
+    "mw_dycore_set_background": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.c_void_p]),
+    "mw_dycore_get_background": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_double)] * 4),
+    "mw_dycore_immersed_proportion": (C.c_void_p, [C.c_void_p]),
+    "mw_dycore_get_grid": (C.c_int, [C.c_void_p, C.POINTER(Grid)]),
+    "mw_dycore_set_bc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mw_dycore_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
+    "mw_dycore_time_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_double]),
+    "mw_dycore_compute_tendencies": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_double,
+                                                                               C.c_void_p, C.c_void_p]),
+    "mw_dycore_get_fluxes": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mw_dycore_get_etime": (C.c_double, [C.c_void_p]),
+    "mw_dycore_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "mw_dycore_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "mw_perturb_temperature": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p]),
+    "mw_dycore_set_exchange": (C.c_int, [C.c_void_p, EXCHANGE_FN, C.c_void_p]),
+    "mw_rccl_unique_id": (C.c_int, [C.c_char_p]),
+    "mw_dycore_use_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "mw_kessler_workspace_bytes": (C.c_longlong, [C.c_int, C.c_longlong]),
+    "mw_kessler_time_step": (C.c_int, [C.c_int, C.c_longlong, C.c_double, C.c_double] + [C.c_void_p] * 7 +
+                             [C.POINTER(C.c_int), C.c_void_p]),
+    "mw_mlp_forward": (C.c_int, [C.c_longlong] + [C.c_void_p] * 5 + [C.POINTER(C.c_float)] * 4 +
+                       [C.POINTER(C.c_double)] * 2 + [C.c_void_p] * 4 + [C.c_void_p]),
+}
+
+_lib = None
+
+
+class MWError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libmw_cdna4.so (built by miniweatherml_amd.build).  Raises if it is absent: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch bundles its own ROCm runtime (libamdhip64.so.7 / libhsa-runtime64 / librccl).  It must be loaded
+    # BEFORE libmw_cdna4.so so that both share ONE HIP/HSA runtime in the process (loading /opt/rocm's copy first
+    # leaves torch with "No HIP GPUs are available").  Pure C/C++ hosts simply use /opt/rocm's runtime.
+    import torch  # noqa: F401
+    if not os.path.exists(LIB_PATH):
+        raise MWError("libmw_cdna4.so not found at %s -- run `python -m miniweatherml_amd.build` "
+                      "(there is no CPU fallback for the hot path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise MWError(lib().mw_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,1195 @@
+// =====================================================================================================
+// mw_dycore.hip -- MI355X (gfx950) implementation of Dynamics_Euler_Stratified_WenoFV::time_step
+// (reference: model/modules/dynamics_euler_stratified_wenofv.h:81-552,1891-2015) behind include/mw_cdna4.h.
+//
+// Data layout in HBM:
+//   * two prognostic slabs S0 (q^n) and S1 (q*), each (V, nz+2*HZ, ny+2*HY, (nx+2*HX)*nens) fp64, x(+ens) fastest,
+//     V = 5 + T, HX = HY = 3 (HY = 0 in 2-D), HZ = 2.  They hold the *reconstruction variables*
+//     (rho', u, v, w, (rho theta)', q_t) -- i.e. the reference's `state`/`tracers` AFTER its in-place divide by
+//     density (:248-255); the conserved value is recovered as u*rho exactly like the reference's re-multiply
+//     (:477-484), so no information or rounding step is lost or added.
+//   * six face-flux arrays in the reference's public layout (:1671-1676), state and tracer parts contiguous.
+//   * no `limits` arrays (6*V*N doubles in the reference, :260-265): edge values live in registers only.
+//
+// Per RK stage:   halo fill (3-cell, replaces halo_exchange+edge_exchange)  ->  k_flux (D6+D9 fused)
+//                 ->  k_fct (D10)  ->  k_update (D11 + D12 + the next stage's D2, or D13 on the last stage)
+// =====================================================================================================
+#include "../../include/mw_cdna4.h"
+#include "mw_common.h"
+#include "mw_weno.h"
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <algorithm>
+
+namespace mw {
+
+enum { idR = 0, idU = 1, idV = 2, idW = 3, idT = 4 };
+static constexpr int HXc = 3;     // x/y halo: 2 for the stencil + 1 so that the neighbour's edge value is rebuilt locally
+static constexpr int HZc = 2;     // z halo: z faces at the domain boundary use the edge-value BC rule, not ghost cells
+
+struct DyP {                      // kernel parameter block (by value)
+  int nz, ny, nx, nens, nt, V;
+  int HX, HY, HZ;
+  int NXE;                        // (nx+2HX)*nens
+  long long sJ, sK, sV;           // strides of the prognostic slabs
+  long long nC;                   // nz*ny*nx*nens
+  long long fxJ, fxK, fxV, fyJ, fyK, fyV, fzJ, fzK, fzV;   // flux strides
+  int sim2d, bc_x, bc_y, bc_z, px, py, nproc_x, nproc_y;
+  int enable_gravity, use_immersed, idWV;
+  unsigned pos_mask, mass_mask;
+  double dx, dy, dz, C0, gamma, grav, fcor, R_d, R_v;
+  const double *hyc, *hytc, *hye, *hyte;       // device (nz,nens) / (nz+1,nens)
+  const double *imm;                           // device (nz,ny,nx,nens)
+};
+
+struct CouplerPtrs {
+  double *rho_d, *u, *v, *w, *temp;
+  double *tr[MW_MAX_TRACERS];
+};
+
+// -----------------------------------------------------------------------------------------------------
+// pow(x, gamma): strict = device libm pow; fast = same for now (kept separate so it can be specialised)
+// -----------------------------------------------------------------------------------------------------
+template <bool STRICT> __device__ __forceinline__ double pow_gamma(double x, double g) { return pow(x, g); }
+
+// -----------------------------------------------------------------------------------------------------
+// D1  convert_coupler_to_dynamics (:1955-2015) fused with the stage-1 divide D2 (:248-255)
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_coupler_to_state(DyP p, CouplerPtrs c, double *__restrict__ S) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y;
+  int NXI = p.nx * p.nens;
+  if (t >= (long long)p.ny * NXI) return;
+  int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  int e = ie % p.nens;
+  long long ci = ((long long)k * p.ny + j) * NXI + ie;
+  double rho_d = c.rho_d[ci], u = c.u[ci], v = c.v[ci], w = c.w[ci], temp = c.temp[ci];
+  double rho_v = c.tr[p.idWV][ci];
+  double press = rho_d * p.R_d * temp + rho_v * p.R_v * temp;
+  double rho = rho_d;
+  for (int tr = 0; tr < p.nt; tr++) if ((p.mass_mask >> tr) & 1u) rho += c.tr[tr][ci];
+  double theta = pow(press / p.C0, 1.0 / p.gamma) / rho;
+  double hyc = p.hyc[k * p.nens + e], hytc = p.hytc[k * p.nens + e];
+  double *s = S + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
+  double rp = rho - hyc;                                  // state(idR)
+  double den = rp + hyc;                                  // what D2 divides by (:249)
+  s[idR * p.sV] = rp;
+  s[idU * p.sV] = (rho * u) / den;
+  s[idV * p.sV] = (rho * v) / den;
+  s[idW * p.sV] = (rho * w) / den;
+  s[idT * p.sV] = rho * theta - hytc;
+  for (int tr = 0; tr < p.nt; tr++) s[(5 + tr) * p.sV] = c.tr[tr][ci] / den;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Halo fill, single rank in a direction == periodic wrap onto itself (coupler.h:169-179 self neighbour),
+// plus the boundary conditions of halo_exchange (:752-825).  One thread per halo cell and variable.
+// Regions: 0 = x halos (k,j interior), 1 = y halos (k,i interior), 2 = z halos (j,i interior); corners are
+// never read.  `do_x`/`do_y` = 0 when that direction's halos come from a neighbour.
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_halo_x(DyP p, double *__restrict__ S) {
+  // threads: (v, k, j, h in [0,2HX), e)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int H2 = 2 * p.HX;
+  long long n = (long long)p.V * p.nz * p.ny * H2 * p.nens;
+  if (t >= n) return;
+  int e = (int)(t % p.nens); t /= p.nens;
+  int h = (int)(t % H2); t /= H2;
+  int j = (int)(t % p.ny); t /= p.ny;
+  int k = (int)(t % p.nz); int v = (int)(t / p.nz);
+  double *row = S + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + e;
+  int lo = h < p.HX;
+  int ih = lo ? h : p.nx + h;                       // halo cell index in [0,HX) or [nx+HX, nx+2HX)
+  double val;
+  if (p.bc_x == MW_BC_PERIODIC) {
+    int src = lo ? ih + p.nx : ih - p.nx;
+    val = row[(long long)src * p.nens];
+  } else {                                          // :782-803 (both sides, two independent ifs)
+    if (v == idU && p.bc_x == MW_BC_WALL) val = 0;
+    else val = row[(long long)(lo ? p.HX : p.HX + p.nx - 1) * p.nens];
+  }
+  row[(long long)ih * p.nens] = val;
+}
+__global__ __launch_bounds__(256) void k_halo_y(DyP p, double *__restrict__ S) {
+  // threads: (v, k, h in [0,2HY), ie interior)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int H2 = 2 * p.HY, NXI = p.nx * p.nens;
+  long long n = (long long)p.V * p.nz * H2 * NXI;
+  if (t >= n) return;
+  int ie = (int)(t % NXI); t /= NXI;
+  int h = (int)(t % H2); t /= H2;
+  int k = (int)(t % p.nz); int v = (int)(t / p.nz);
+  double *col = S + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;
+  int lo = h < p.HY;
+  int jh = lo ? h : p.ny + h;
+  double val;
+  if (p.bc_y == MW_BC_PERIODIC) {
+    int src = lo ? jh + p.ny : jh - p.ny;
+    val = col[(long long)src * p.sJ];
+  } else {                                          // :804-825
+    if (v == idV && p.bc_y == MW_BC_WALL) val = 0;
+    else val = col[(long long)(lo ? p.HY : p.HY + p.ny - 1) * p.sJ];
+  }
+  col[(long long)jh * p.sJ] = val;
+}
+__global__ __launch_bounds__(256) void k_halo_z(DyP p, double *__restrict__ S) {
+  // threads: (v, h in [0,2HZ), j, ie interior)   :752-781
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int H2 = 2 * p.HZ, NXI = p.nx * p.nens;
+  long long n = (long long)p.V * H2 * p.ny * NXI;
+  if (t >= n) return;
+  int ie = (int)(t % NXI); t /= NXI;
+  int j = (int)(t % p.ny); t /= p.ny;
+  int h = (int)(t % H2); int v = (int)(t / H2);
+  double *col = S + (long long)v * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
+  int lo = h < p.HZ;
+  int kh = lo ? h : p.nz + h;
+  double val;
+  if (v == idW && p.bc_z == MW_BC_WALL) val = 0;
+  else val = col[(long long)(lo ? p.HZ : p.HZ + p.nz - 1) * p.sK];
+  col[(long long)kh * p.sK] = val;
+}
+
+// Pack / unpack for a neighbour exchange (3-cell halos of all V variables; interior rows only, like :606-631,:725-747)
+// W/E buffers (V,nz,ny,HX,nens), S/N buffers (V,nz,HY,nx,nens).
+__global__ __launch_bounds__(256) void k_pack_x(DyP p, const double *__restrict__ S, double *__restrict__ bW, double *__restrict__ bE) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long n = (long long)p.V * p.nz * p.ny * p.HX * p.nens;
+  if (t >= n) return;
+  long long r = t;
+  int e = (int)(r % p.nens); r /= p.nens;
+  int h = (int)(r % p.HX); r /= p.HX;
+  int j = (int)(r % p.ny); r /= p.ny;
+  int k = (int)(r % p.nz); int v = (int)(r / p.nz);
+  const double *row = S + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + e;
+  bW[t] = row[(long long)(p.HX + h) * p.nens];              // my first HX interior cells -> west neighbour's east halo
+  bE[t] = row[(long long)(p.nx + h) * p.nens];              // my last  HX interior cells -> east neighbour's west halo
+}
+__global__ __launch_bounds__(256) void k_unpack_x(DyP p, double *__restrict__ S, const double *__restrict__ bW, const double *__restrict__ bE) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long n = (long long)p.V * p.nz * p.ny * p.HX * p.nens;
+  if (t >= n) return;
+  long long r = t;
+  int e = (int)(r % p.nens); r /= p.nens;
+  int h = (int)(r % p.HX); r /= p.HX;
+  int j = (int)(r % p.ny); r /= p.ny;
+  int k = (int)(r % p.nz); int v = (int)(r / p.nz);
+  double *row = S + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + e;
+  row[(long long)h * p.nens]                 = bW[t];       // received from west
+  row[(long long)(p.nx + p.HX + h) * p.nens] = bE[t];       // received from east
+}
+__global__ __launch_bounds__(256) void k_pack_y(DyP p, const double *__restrict__ S, double *__restrict__ bS, double *__restrict__ bN) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int NXI = p.nx * p.nens;
+  long long n = (long long)p.V * p.nz * p.HY * NXI;
+  if (t >= n) return;
+  long long r = t;
+  int ie = (int)(r % NXI); r /= NXI;
+  int h = (int)(r % p.HY); r /= p.HY;
+  int k = (int)(r % p.nz); int v = (int)(r / p.nz);
+  const double *col = S + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;
+  bS[t] = col[(long long)(p.HY + h) * p.sJ];
+  bN[t] = col[(long long)(p.ny + h) * p.sJ];
+}
+__global__ __launch_bounds__(256) void k_unpack_y(DyP p, double *__restrict__ S, const double *__restrict__ bS, const double *__restrict__ bN) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int NXI = p.nx * p.nens;
+  long long n = (long long)p.V * p.nz * p.HY * NXI;
+  if (t >= n) return;
+  long long r = t;
+  int ie = (int)(r % NXI); r /= NXI;
+  int h = (int)(r % p.HY); r /= p.HY;
+  int k = (int)(r % p.nz); int v = (int)(r / p.nz);
+  double *col = S + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;
+  col[(long long)h * p.sJ]                 = bS[t];
+  col[(long long)(p.ny + p.HY + h) * p.sJ] = bN[t];
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Flux stencil: WENO reconstruction (D6, :271-388) + edge BCs (D8, :1008-1081) + Riemann solver (D9, :395-474)
+// fused; one thread per face triple (x-, y-, z- lower faces of cell (k,j,i,e), plus the top/north/east rim).
+// The two sides of a face are described by (source cell, which edge); passive variables (transverse momenta,
+// tracers) are reconstructed on the upwind side only.
+// -----------------------------------------------------------------------------------------------------
+template <bool STRICT>
+__device__ __forceinline__ double edge_value(const double *__restrict__ q, long long st, int right) {
+  double l, r;
+  if (STRICT) weno5_edges_strict(q[-2 * st], q[-st], q[0], q[st], q[2 * st], l, r);
+  else        weno5_edges_fast  (q[-2 * st], q[-st], q[0], q[st], q[2 * st], l, r);
+  return right ? r : l;
+}
+
+template <bool STRICT>
+__device__ __forceinline__ void face_flux(const DyP &p, const double *__restrict__ cL, int eL, const double *__restrict__ cR,
+                                          int eR, long long st, int nrm, double hyr, double hyt, bool zero_nrm,
+                                          double *__restrict__ f, long long fV) {
+  const double cs = 350;
+  double rL = edge_value<STRICT>(cL + idR * p.sV, st, eL) + hyr;
+  double rR = edge_value<STRICT>(cR + idR * p.sV, st, eR) + hyr;
+  double uL = edge_value<STRICT>(cL + nrm * p.sV, st, eL);
+  double uR = edge_value<STRICT>(cR + nrm * p.sV, st, eR);
+  double tL = edge_value<STRICT>(cL + idT * p.sV, st, eL) + hyt;
+  double tR = edge_value<STRICT>(cR + idT * p.sV, st, eR) + hyt;
+  if (STRICT) {
+#pragma clang fp contract(off)
+    double mL = zero_nrm ? 0.0 : uL * rL;
+    double mR = zero_nrm ? 0.0 : uR * rR;
+    double p_L = p.C0 * pow_gamma<true>(tL, p.gamma), p_R = p.C0 * pow_gamma<true>(tR, p.gamma);
+    double w1 = 0.5 * (p_R - cs * mR);
+    double w2 = 0.5 * (p_L + cs * mL);
+    double p_upw = w1 + w2;
+    double m_upw = (w2 - w1) / cs;
+    int ind = (mL + mR > 0) ? 0 : 1;
+    double r_upw = ind ? rR : rL;
+    const double *cU = ind ? cR : cL;  int eU = ind ? eR : eL;
+    f[idR * fV] = m_upw;
+    f[nrm * fV] = m_upw * (ind ? mR : mL) / r_upw + p_upw;
+    f[idT * fV] = m_upw * (ind ? tR : tL) / r_upw;
+    for (int l = idU; l < p.V; l++) {
+      if (l == nrm || l == idT) continue;
+      double val = edge_value<true>(cU + l * p.sV, st, eU) * r_upw;
+      f[l * fV] = m_upw * val / r_upw;
+    }
+  } else {
+#pragma clang fp contract(fast)
+    double mL = zero_nrm ? 0.0 : uL * rL;
+    double mR = zero_nrm ? 0.0 : uR * rR;
+    double p_L = p.C0 * pow_gamma<false>(tL, p.gamma), p_R = p.C0 * pow_gamma<false>(tR, p.gamma);
+    double w1 = 0.5 * (p_R - cs * mR);
+    double w2 = 0.5 * (p_L + cs * mL);
+    double p_upw = w1 + w2;
+    double m_upw = (w2 - w1) * (1.0 / 350.0);
+    int ind = (mL + mR > 0) ? 0 : 1;
+    double r_upw = ind ? rR : rL;
+    const double *cU = ind ? cR : cL;  int eU = ind ? eR : eL;
+    double u_upw = zero_nrm ? 0.0 : (ind ? uR : uL);
+    f[idR * fV] = m_upw;
+    f[nrm * fV] = m_upw * u_upw + p_upw;
+    f[idT * fV] = m_upw * (ind ? tR : tL) / r_upw;
+    for (int l = idU; l < p.V; l++) {
+      if (l == nrm || l == idT) continue;
+      f[l * fV] = m_upw * edge_value<false>(cU + l * p.sV, st, eU);
+    }
+  }
+}
+
+template <bool STRICT>
+__global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ S, double *__restrict__ FX,
+                                              double *__restrict__ FY, double *__restrict__ FZ) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y;
+  int NXF = (p.nx + 1) * p.nens;
+  int nyf = p.sim2d ? p.ny : p.ny + 1;                       // 2-D: no y faces beyond row 0 needed
+  if (t >= (long long)nyf * NXF) return;
+  int j = (int)(t / NXF), ie = (int)(t - (long long)j * NXF);
+  int i = ie / p.nens, e = ie - i * p.nens;
+  const double *c = S + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)(i + p.HX) * p.nens + e;
+  // ---------------- X face i-1/2 : left state = right edge of cell i-1, right state = left edge of cell i
+  if (j < p.ny && k < p.nz) {
+    const double *cL = c - p.nens, *cR = c;  int eL = 1, eR = 0;  bool zero = false;
+    if (p.bc_x != MW_BC_PERIODIC) {                          // :1040-1060 (note the else-if: quirk 1)
+      if (p.px == 0) {
+        if (i == 0) { cL = cR; eL = eR; zero = (p.bc_x == MW_BC_WALL); }
+        else if (i == p.nx && p.nproc_x == 1) { cR = c - (long long)p.nx * p.nens; eR = 0; }   // slot 1 at nx keeps what the periodic self-exchange delivered: left edge of cell 0 (:985)
+      } else if (p.px == p.nproc_x - 1) {
+        if (i == p.nx) { cR = cL; eR = eL; zero = (p.bc_x == MW_BC_WALL); }
+      }
+    }
+    double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
+    face_flux<STRICT>(p, cL, eL, cR, eR, p.nens, idU, hyr, hyt, zero,
+                      FX + (long long)k * p.fxK + (long long)j * p.fxJ + ie, p.fxV);
+  }
+  // ---------------- Y face j-1/2
+  if (!p.sim2d && i < p.nx && k < p.nz) {
+    const double *cL = c - p.sJ, *cR = c;  int eL = 1, eR = 0;  bool zero = false;
+    if (p.bc_y != MW_BC_PERIODIC) {                          // :1061-1081
+      if (p.py == 0) {
+        if (j == 0) { cL = cR; eL = eR; zero = (p.bc_y == MW_BC_WALL); }
+        else if (j == p.ny && p.nproc_y == 1) { cR = c - (long long)p.ny * p.sJ; eR = 0; }
+      } else if (p.py == p.nproc_y - 1) {
+        if (j == p.ny) { cR = cL; eR = eL; zero = (p.bc_y == MW_BC_WALL); }
+      }
+    }
+    double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
+    face_flux<STRICT>(p, cL, eL, cR, eR, p.sJ, idV, hyr, hyt, zero,
+                      FY + (long long)k * p.fyK + (long long)j * p.fyJ + ie, p.fyV);
+  }
+  // ---------------- Z face k-1/2 : wall / open edge-value rule at k = 0 and k = nz  (:1020-1038)
+  if (i < p.nx && j < p.ny) {
+    const double *cL = c - p.sK, *cR = c;  int eL = 1, eR = 0;  bool zero = false;
+    if (k == 0)    { cL = cR; eL = eR; zero = (p.bc_z == MW_BC_WALL); }
+    if (k == p.nz) { cR = cL; eR = eL; zero = (p.bc_z == MW_BC_WALL); }
+    double hyr = p.hye[k * p.nens + e], hyt = p.hyte[k * p.nens + e];      // edges for z (:368-377)
+    face_flux<STRICT>(p, cL, eL, cR, eR, p.sK, idW, hyr, hyt, zero,
+                      FZ + (long long)k * p.fzK + (long long)j * p.fzJ + (long long)i * p.nens + e, p.fzV);
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// D10  FCT positivity (:498-516).  In-place scaling of outgoing tracer fluxes; race-free by the reference's
+// sign argument (:495-497): a face is only ever rescaled by the cell it leaves.
+// -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fct(DyP p, const double *__restrict__ S, double *__restrict__ FX,
+                                             double *__restrict__ FY, double *__restrict__ FZ, double dt) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y, tr = blockIdx.z;
+  if (!((p.pos_mask >> tr) & 1u)) return;
+  int NXI = p.nx * p.nens;
+  if (t >= (long long)p.ny * NXI) return;
+  int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  int e = ie % p.nens;
+  const double *s = S + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
+  double rho = s[idR * p.sV] + p.hyc[k * p.nens + e];
+  double tracer = s[(5 + tr) * p.sV] * rho;                 // the re-multiplied value (:482) that FCT reads
+  double dx = p.dx, dy = p.dy, dz = p.dz;
+  double *fx = FX + (long long)(5 + tr) * p.fxV + (long long)k * p.fxK + (long long)j * p.fxJ + ie;
+  double *fy = FY + (long long)(5 + tr) * p.fyV + (long long)k * p.fyK + (long long)j * p.fyJ + ie;
+  double *fz = FZ + (long long)(5 + tr) * p.fzV + (long long)k * p.fzK + (long long)j * p.fzJ + ie;
+  double fxm = fx[0], fxp = fx[p.nens], fym = fy[0], fyp = fy[p.fyJ], fzm = fz[0], fzp = fz[p.fzK];
+  double mass_available = fmax(tracer, 0.0) * dx * dy * dz;
+  double flux_out_x = (fmax(fxp, 0.0) - fmin(fxm, 0.0)) / dx;
+  double flux_out_y = (fmax(fyp, 0.0) - fmin(fym, 0.0)) / dy;
+  double flux_out_z = (fmax(fzp, 0.0) - fmin(fzm, 0.0)) / dz;
+  double mass_out = (flux_out_x + flux_out_y + flux_out_z) * dt * dx * dy * dz;
+  if (mass_out > mass_available) {
+    double mult = mass_available / mass_out;
+    if (fxp > 0) fx[p.nens] = fxp * mult;
+    if (fxm < 0) fx[0]      = fxm * mult;
+    if (fyp > 0) fy[p.fyJ]  = fyp * mult;
+    if (fym < 0) fy[0]      = fym * mult;
+    if (fzp > 0) fz[p.fzK]  = fzp * mult;
+    if (fzm < 0) fz[0]      = fzm * mult;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// D11 tendencies (:519-551) + D12 SSPRK3 combine (:121-174) + storage divide (next stage's D2, :248-255)
+//   MODE 0: write the new slab (stored form)            STAGE 1: q* = q^n + dt L(q^n)
+//   MODE 1: last stage of the last cycle: write the     STAGE 2: q* = 3/4 q^n + 1/4 q* + 1/4 dt L(q*)
+//           COUPLER fields directly (D13, :1927-1950)    STAGE 3: q  = 1/3 q^n + 2/3 q* + 2/3 dt L(q*)
+//   MODE 2: write tendencies only (mw_dycore_compute_tendencies)
+// Sstar = slab the fluxes were computed from; Sn = q^n slab (== Sstar in stage 1).
+// -----------------------------------------------------------------------------------------------------
+template <int STAGE, int MODE>
+__global__ __launch_bounds__(256) void k_update(DyP p, const double *Sstar, const double *Sn,   // may alias Sout (in-place stages)
+                                                double *Sout, const double *__restrict__ FX,
+                                                const double *__restrict__ FY, const double *__restrict__ FZ,
+                                                double dt_stage, double dt_dyn, CouplerPtrs c,
+                                                double *__restrict__ state_tend, double *__restrict__ tracers_tend) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y;
+  int NXI = p.nx * p.nens;
+  if (t >= (long long)p.ny * NXI) return;
+  int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  int e = ie % p.nens;
+  long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
+  long long ci = ((long long)k * p.ny + j) * NXI + ie;
+  const double *fx = FX + (long long)k * p.fxK + (long long)j * p.fxJ + ie;
+  const double *fy = FY + (long long)k * p.fyK + (long long)j * p.fyJ + ie;
+  const double *fz = FZ + (long long)k * p.fzK + (long long)j * p.fzJ + ie;
+  const double hyc = p.hyc[k * p.nens + e], hytc = p.hytc[k * p.nens + e];
+  const double dx = p.dx, dy = p.dy, dz = p.dz;
+  const double rho_s = Sstar[so + idR * p.sV] + hyc;                 // density of the stage input
+  const double rho_n = (STAGE == 1) ? rho_s : Sn[so + idR * p.sV] + hyc;
+  // immersed-boundary relaxation coefficients (:534-550)
+  double prop = 0, imm_coef = 0;
+  if (p.use_immersed) {
+    double tau = 1.e3 * dt_stage;
+    imm_coef = -fmin(1.0, dt_stage / tau);
+    prop = p.imm[ci];
+  }
+  const double ru_s = Sstar[so + idU * p.sV] * rho_s;                // re-multiplied momenta (:478-480)
+  const double rv_s = Sstar[so + idV * p.sV] * rho_s;
+  double newR = 0, rho_new = 0;                                      // filled at l == idR (first iteration)
+  double rho_dry_acc = 0, rho_v_new = 0, press_arg = 0, unew = 0, vnew = 0, wnew = 0;
+  for (int l = 0; l < p.V; l++) {
+    // conserved value of the stage input and of q^n
+    double raw_s = Sstar[so + l * p.sV];
+    double q_s = (l == idR || l == idT) ? raw_s : raw_s * rho_s;
+    double q_n;
+    if (STAGE == 1) q_n = q_s;
+    else { double raw_n = Sn[so + l * p.sV]; q_n = (l == idR || l == idT) ? raw_n : raw_n * rho_n; }
+    double tend = -(fx[l * p.fxV + p.nens] - fx[l * p.fxV]) / dx
+                  -(fy[l * p.fyV + p.fyJ ] - fy[l * p.fyV]) / dy
+                  -(fz[l * p.fzV + p.fzK ] - fz[l * p.fzV]) / dz;
+    if (l == idW && p.enable_gravity) tend += -p.grav * rho_s;
+    if (l == idU) tend += p.fcor * rv_s;
+    if (l == idV) tend -= p.fcor * ru_s;
+    if (l == idV && p.sim2d) tend = 0;
+    if (p.use_immersed && l < 5) {
+      double imm_tend = imm_coef * q_s / dt_stage;
+      tend = prop * imm_tend + (1 - prop) * tend;
+    }
+    if (MODE == 2) {
+      if (l < 5) state_tend[(long long)l * p.nC + ci] = tend;
+      else       tracers_tend[(long long)(l - 5) * p.nC + ci] = tend;
+      continue;
+    }
+    double qnew;
+    if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
+    else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
+    else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
+    if (l >= 5 && ((p.pos_mask >> (l - 5)) & 1u)) qnew = fmax(0.0, qnew);
+    if (l == idR) { newR = qnew; rho_new = newR + hyc; rho_dry_acc = rho_new; }
+    if (MODE == 0) {
+      Sout[so + l * p.sV] = (l == idR || l == idT) ? qnew : qnew / rho_new;
+    } else {  // MODE 1: convert_dynamics_to_coupler (:1927-1950)
+      if (l == idU) unew = qnew / rho_new;
+      if (l == idV) vnew = qnew / rho_new;
+      if (l == idW) wnew = qnew / rho_new;
+      if (l == idT) { double theta = (qnew + hytc) / rho_new; press_arg = rho_new * theta; }
+      if (l >= 5) {
+        c.tr[l - 5][ci] = qnew;
+        if (l - 5 == p.idWV) rho_v_new = qnew;
+        if ((p.mass_mask >> (l - 5)) & 1u) rho_dry_acc -= qnew;
+      }
+    }
+  }
+  if (MODE == 1) {
+    double press = p.C0 * pow(press_arg, p.gamma);
+    double temp = press / (rho_dry_acc * p.R_d + rho_v_new * p.R_v);
+    c.rho_d[ci] = rho_dry_acc;  c.u[ci] = unew;  c.v[ci] = vnew;  c.w[ci] = wnew;  c.temp[ci] = temp;
+  }
+}
+
+// stored slab -> coupler fields (used when ncycles == 0 cannot happen; used by init + tests): D13 on a slab
+__global__ __launch_bounds__(256) void k_state_to_coupler(DyP p, const double *__restrict__ S, CouplerPtrs c) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y;
+  int NXI = p.nx * p.nens;
+  if (t >= (long long)p.ny * NXI) return;
+  int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  int e = ie % p.nens;
+  long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
+  long long ci = ((long long)k * p.ny + j) * NXI + ie;
+  double hyc = p.hyc[k * p.nens + e], hytc = p.hytc[k * p.nens + e];
+  double rho = S[so + idR * p.sV] + hyc;
+  double u = (S[so + idU * p.sV] * rho) / rho, v = (S[so + idV * p.sV] * rho) / rho, w = (S[so + idW * p.sV] * rho) / rho;
+  double theta = (S[so + idT * p.sV] + hytc) / rho;
+  double press = p.C0 * pow(rho * theta, p.gamma);
+  double rho_d = rho, rho_v = 0;
+  for (int tr = 0; tr < p.nt; tr++) {
+    double q = S[so + (5 + tr) * p.sV] * rho;
+    c.tr[tr][ci] = q;
+    if (tr == p.idWV) rho_v = q;
+    if ((p.mass_mask >> tr) & 1u) rho_d -= q;
+  }
+  c.rho_d[ci] = rho_d; c.u[ci] = u; c.v[ci] = v; c.w[ci] = w;
+  c.temp[ci] = press / (rho_d * p.R_d + rho_v * p.R_v);
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Initial data (input construction, :1197-1683, :1687-1887).  Column profiles are built on the host
+// (mw_init.cpp part below); the per-cell quadrature + convert_dynamics_to_coupler (:1656) runs here.
+// -----------------------------------------------------------------------------------------------------
+struct InitP {
+  int init_data;
+  long long i_beg, j_beg;
+  double xlen, ylen, cp_d, p0;
+  const double *hyDensGLL, *hyDensThetaGLL, *hyDensVapGLL;     // supercell: (nz,5) device
+  const double *bheights; int nbx, nby, cells_per_building, buildings_pad, nblocks_x, nblocks_y;   // city
+  long long nx_glob, ny_glob;
+};
+
+__device__ __forceinline__ void d_hydro_const_theta(double z, double grav, double C0, double cp, double p0, double gamma,
+                                                    double rd, double &r, double &t) {     // :1108-1117
+#pragma clang fp contract(off)
+  const double theta0 = 300., exner0 = 1.;
+  t = theta0;
+  double exner = exner0 - grav * z / (cp * theta0);
+  double pr = p0 * pow(exner, (cp / rd));
+  double rt = pow((pr / C0), (1.0 / gamma));
+  r = rt / t;
+}
+__device__ __forceinline__ double d_sample_ellipse_cosine(double amp, double x, double y, double z, double x0, double y0,
+                                                          double z0, double xrad, double yrad, double zrad) {   // :1121-1134
+#pragma clang fp contract(off)
+  double dist = sqrt(((x - x0) / xrad) * ((x - x0) / xrad) + ((y - y0) / yrad) * ((y - y0) / yrad) +
+                     ((z - z0) / zrad) * ((z - z0) / zrad)) * M_PI / 2.;
+  if (dist <= M_PI / 2.) return amp * pow(cos(dist), 2.0);
+  return 0.;
+}
+
+__constant__ double c_gll5_pts[5] = {-0.50000000000000000000000000000000000000, -0.32732683535398857189914622812342917778,
+                                     0.00000000000000000000000000000000000000, 0.32732683535398857189914622812342917778,
+                                     0.50000000000000000000000000000000000000};      // TransformMatrices.h:650-656
+__constant__ double c_gll5_wts[5] = {0.050000000000000000000000000000000000000, 0.27222222222222222222222222222222222222,
+                                     0.35555555555555555555555555555555555556, 0.27222222222222222222222222222222222222,
+                                     0.050000000000000000000000000000000000000};     // :659-665
+__constant__ double c_gll9_pts[9] = {-0.50000000000000000000000000000000000000, -0.44987899770573007865617262220916897903,
+                                     -0.33859313975536887672294271354567122536, -0.18155873191308907935537603435432960651,
+                                     0.00000000000000000000000000000000000000, 0.18155873191308907935537603435432960651,
+                                     0.33859313975536887672294271354567122536, 0.44987899770573007865617262220916897903,
+                                     0.50000000000000000000000000000000000000};      // :4113-4124
+__constant__ double c_gll9_wts[9] = {0.013888888888888888888888888888888888889, 0.082747680780402762523169860014604152919,
+                                     0.13726935625008086764035280928968636297, 0.17321425548652317255756576606985914397,
+                                     0.18575963718820861678004535147392290249, 0.17321425548652317255756576606985914397,
+                                     0.13726935625008086764035280928968636297, 0.082747680780402762523169860014604152919,
+                                     0.013888888888888888888888888888888888889};     // :4126-4137
+__constant__ double c_gl3_pts[3] = {0.112701665379258311482073460022, 0.500000000000000000000000000000,
+                                    0.887298334620741688517926539980};                // :1349-1351
+__constant__ double c_gl3_wts[3] = {0.277777777777777777777777777779, 0.444444444444444444444444444444,
+                                    0.277777777777777777777777777779};                // :1353-1355
+
+__global__ __launch_bounds__(256) void k_init_cells(DyP p, InitP q, CouplerPtrs c, double *__restrict__ imm) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y;
+  int NXI = p.nx * p.nens;
+  if (t >= (long long)p.ny * NXI) return;
+  int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  int i = ie / p.nens, e = ie - i * p.nens;
+  long long ci = ((long long)k * p.ny + j) * NXI + ie;
+  double sR = 0, sU = 0, sV = 0, sW = 0, sT = 0, sWV = 0;
+  const double dx = p.dx, dy = p.dy, dz = p.dz;
+  if (q.init_data == MW_DATA_SUPERCELL) {                     // :1843-1886
+    for (int kk = 0; kk < 5; kk++) for (int jj = 0; jj < 5; jj++) for (int ii = 0; ii < 5; ii++) {
+      double zloc = (k + 0.5) * dz + c_gll5_pts[kk] * dz;
+      double dens = q.hyDensGLL[k * 5 + kk];
+      double uvel;
+      const double zs = 5000, us = 30, uc = 15;
+      if (zloc < zs) uvel = us * (zloc / zs) - uc; else uvel = us - uc;
+      double vvel = 0, wvel = 0;
+      double dens_vap = q.hyDensVapGLL[k * 5 + kk], dens_theta = q.hyDensThetaGLL[k * 5 + kk];
+      double factor = c_gll5_wts[ii] * c_gll5_wts[jj] * c_gll5_wts[kk];
+      sR += (dens - q.hyDensGLL[k * 5 + kk]) * factor;
+      sU += dens * uvel * factor;
+      sV += dens * vvel * factor;
+      sW += dens * wvel * factor;
+      sT += (dens_theta - q.hyDensThetaGLL[k * 5 + kk]) * factor;
+      sWV += dens_vap * factor;
+    }
+  } else {                                                     // thermal :1361-1392 ; city :1463-1503 ; building :1566-1607
+    const int nq = (q.init_data == MW_DATA_THERMAL) ? 3 : 9;
+    const double *qp = (q.init_data == MW_DATA_THERMAL) ? c_gl3_pts : c_gll9_pts;
+    const double *qw = (q.init_data == MW_DATA_THERMAL) ? c_gl3_wts : c_gll9_wts;
+    for (int kk = 0; kk < nq; kk++) for (int jj = 0; jj < nq; jj++) for (int ii = 0; ii < nq; ii++) {
+      double x = (i + q.i_beg + 0.5) * dx + (qp[ii] - 0.5) * dx;
+      double y = (j + q.j_beg + 0.5) * dy + (qp[jj] - 0.5) * dy;   if (p.sim2d) y = q.ylen / 2;
+      double z = (k + 0.5) * dz + (qp[kk] - 0.5) * dz;
+      double rho, u, v, w, theta, rho_v, hr, ht;
+      if (q.init_data == MW_DATA_THERMAL) {                    // thermal(), :1086-1103
+        d_hydro_const_theta(z, p.grav, p.C0, q.cp_d, q.p0, p.gamma, p.R_d, hr, ht);
+        double rho_d = hr;
+        u = 0.; v = 0.; w = 0.;
+        double theta_d = ht + d_sample_ellipse_cosine(2.0, x, y, z, q.xlen / 2, q.ylen / 2, 2000., 2000., 2000., 2000.);
+        double p_d = p.C0 * pow(rho_d * theta_d, p.gamma);
+        double temp = p_d / rho_d / p.R_d;
+        double tc = temp - 273.15;                             // saturation_vapor_pressure, :1137-1140
+        double sat_pv = 610.94 * exp(17.625 * tc / (243.04 + tc));
+        double sat_rv = sat_pv / p.R_v / temp;
+        rho_v = d_sample_ellipse_cosine(0.8, x, y, z, q.xlen / 2, q.ylen / 2, 2000., 2000., 2000., 2000.) * sat_rv;
+        double pr = rho_d * p.R_d * temp + rho_v * p.R_v * temp;
+        rho = rho_d + rho_v;
+        theta = pow(pr / p.C0, 1.0 / p.gamma) / rho;
+      } else {
+        if (p.enable_gravity) d_hydro_const_theta(z, p.grav, p.C0, q.cp_d, q.p0, p.gamma, p.R_d, hr, ht);
+        else { hr = 1.15; ht = 300; }
+        rho = hr; u = 20; v = 0; w = 0; theta = ht; rho_v = 0;
+      }
+      if (p.sim2d) v = 0;
+      double wt = qw[ii] * qw[jj] * qw[kk];
+      sR += (rho - hr) * wt;
+      sU += rho * u * wt;
+      sV += rho * v * wt;
+      sW += rho * w * wt;
+      sT += (rho * theta - hr * ht) * wt;
+      sWV += rho_v * wt;
+    }
+    if (q.init_data == MW_DATA_CITY) {                         // :1504-1514
+      int inorm = ((int)q.i_beg + i) / q.cells_per_building - q.buildings_pad;
+      int jnorm = ((int)q.j_beg + j) / q.cells_per_building - q.buildings_pad;
+      if ((inorm >= 0 && inorm < q.nblocks_x * 3 && inorm % 3 < 2) && (jnorm >= 0 && jnorm < q.nblocks_y * 9 && jnorm % 9 < 8)) {
+        if (k <= ceil(q.bheights[(long long)jnorm * q.nbx + inorm] / dz)) imm[ci] = 1;
+      }
+    } else if (q.init_data == MW_DATA_BUILDING) {              // :1608-1617
+      double x0 = 0.3 * q.nx_glob, y0 = 0.5 * q.ny_glob, xr = 0.05 * q.ny_glob, yr = 0.05 * q.ny_glob;
+      if (fabs((double)(q.i_beg + i) - x0) <= xr && fabs((double)(q.j_beg + j) - y0) <= yr && k <= 0.2 * p.nz) imm[ci] = 1;
+    }
+  }
+  // convert_dynamics_to_coupler (:1927-1950); all tracers other than water vapour start at zero
+  double hyc = p.hyc[k * p.nens + e], hytc = p.hytc[k * p.nens + e];
+  double rho = sR + hyc;
+  double u = sU / rho, v = sV / rho, w = sW / rho;
+  double theta = (sT + hytc) / rho;
+  double press = p.C0 * pow(rho * theta, p.gamma);
+  double rho_d = rho;
+  for (int tr = 0; tr < p.nt; tr++) {
+    double val = (tr == p.idWV) ? sWV : 0.0;
+    if ((p.mass_mask >> tr) & 1u) rho_d -= val;
+    c.tr[tr][ci] = val;
+  }
+  double temp = press / (rho_d * p.R_d + sWV * p.R_v);
+  c.rho_d[ci] = rho_d; c.u[ci] = u; c.v[ci] = v; c.w[ci] = w; c.temp[ci] = temp;
+}
+
+// modules::perturb_temperature(thermal=true)   perturb_temperature.h:41-66
+__global__ __launch_bounds__(256) void k_perturb_temperature(int nz, int ny, int nx, int nens, long long i_beg, long long j_beg,
+                                                             double dx, double dy, double dz, double xlen, double ylen,
+                                                             double *__restrict__ temp) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long n = (long long)nz * ny * nx * nens;
+  if (t >= n) return;
+  long long r = t / nens;
+  int i = (int)(r % nx); r /= nx;
+  int j = (int)(r % ny); int k = (int)(r / ny);
+  double xloc = (i + i_beg + 0.5) * dx, yloc = (j + j_beg + 0.5) * dy, zloc = (k + 0.5) * dz;
+  double x0 = xlen / 2, y0 = ylen / 2, z0 = 1500, radx = 10000, rady = 10000, radz = 1500, amp = 5;
+  double xn = (xloc - x0) / radx, yn = (yloc - y0) / rady, zn = (zloc - z0) / radz;
+  double rad = sqrt(xn * xn + yn * yn + zn * zn);
+  if (rad < 1) temp[t] += amp * pow(cos(M_PI * rad / 2), 2.0);
+}
+
+} // namespace mw
+
+// =====================================================================================================
+// Host side
+// =====================================================================================================
+using namespace mw;
+
+struct mw_dycore_s {
+  mw_grid_t g;
+  unsigned char pos[MW_MAX_TRACERS], adds[MW_MAX_TRACERS];
+  hipStream_t stream;
+  DyP p;
+  double *S0 = nullptr, *S1 = nullptr;
+  double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
+  double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte
+  double *imm = nullptr;
+  std::vector<double> hy_host;               // same packing
+  double etime = 0;
+  int strict = 0;
+  // halo exchange
+  mw_exchange_fn xchg = nullptr; void *xchg_ctx = nullptr;
+  double *bufs[8] = {nullptr};               // sW sE sS sN rW rE rS rN
+  long long nWE = 0, nSN = 0;
+  // profiling
+  int prof = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
+  size_t ev_used[5] = {0, 0, 0, 0, 0};
+  void *rccl = nullptr;                      // mw_rccl.cpp state
+};
+
+static inline dim3 plane_grid(long long per_plane, int nk, int nzdim = 1) {
+  return dim3((unsigned)((per_plane + 255) / 256), (unsigned)nk, (unsigned)nzdim);
+}
+
+static void fill_params(mw_dycore_s *d) {
+  const mw_grid_t &g = d->g;  DyP &p = d->p;
+  p.nz = g.nz; p.ny = g.ny; p.nx = g.nx; p.nens = g.nens; p.nt = g.num_tracers; p.V = 5 + g.num_tracers;
+  p.sim2d = (g.ny_glob == 1);
+  p.HX = HXc; p.HY = p.sim2d ? 0 : HXc; p.HZ = HZc;
+  p.NXE = (g.nx + 2 * p.HX) * g.nens;
+  p.sJ = p.NXE; p.sK = (long long)(g.ny + 2 * p.HY) * p.sJ; p.sV = (long long)(g.nz + 2 * p.HZ) * p.sK;
+  p.nC = (long long)g.nz * g.ny * g.nx * g.nens;
+  p.fxJ = (long long)(g.nx + 1) * g.nens; p.fxK = (long long)g.ny * p.fxJ;       p.fxV = (long long)g.nz * p.fxK;
+  p.fyJ = (long long)g.nx * g.nens;       p.fyK = (long long)(g.ny + 1) * p.fyJ; p.fyV = (long long)g.nz * p.fyK;
+  p.fzJ = (long long)g.nx * g.nens;       p.fzK = (long long)g.ny * p.fzJ;       p.fzV = (long long)(g.nz + 1) * p.fzK;
+  p.bc_x = g.bc_x; p.bc_y = g.bc_y; p.bc_z = g.bc_z; p.px = g.px; p.py = g.py; p.nproc_x = g.nproc_x; p.nproc_y = g.nproc_y;
+  p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
+  p.pos_mask = 0; p.mass_mask = 0;
+  for (int t = 0; t < g.num_tracers; t++) { if (d->pos[t]) p.pos_mask |= 1u << t; if (d->adds[t]) p.mass_mask |= 1u << t; }
+  p.dx = g.xlen / g.nx_glob; p.dy = g.ylen / g.ny_glob; p.dz = g.zlen / g.nz;        // coupler.h:262-268
+  p.C0 = g.C0; p.gamma = g.gamma_d; p.grav = g.grav; p.R_d = g.R_d; p.R_v = g.R_v;
+  p.fcor = 2 * g.earthrot * sin(g.latitude);                                           // :213
+  size_t nzc = (size_t)g.nz * g.nens, nze = (size_t)(g.nz + 1) * g.nens;
+  p.hyc = d->hy_dev; p.hytc = d->hy_dev + nzc; p.hye = d->hy_dev + 2 * nzc; p.hyte = d->hy_dev + 2 * nzc + nze;
+  p.imm = d->imm;
+}
+
+static int upload_background(mw_dycore_s *d) {
+  MW_HIP(hipMemcpyAsync(d->hy_dev, d->hy_host.data(), d->hy_host.size() * sizeof(double), hipMemcpyHostToDevice, d->stream));
+  MW_HIP(hipStreamSynchronize(d->stream));
+  return 0;
+}
+
+struct ProfScope {
+  mw_dycore_s *d; int which; size_t idx; bool on;
+  ProfScope(mw_dycore_s *d_, int w) : d(d_), which(w), idx(0), on(d_->prof != 0) {
+    if (!on) return;
+    if (d->ev_used[which] == d->ev[which].size()) {
+      hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); d->ev[which].push_back({a, b});
+    }
+    idx = d->ev_used[which]++;
+    (void)hipEventRecord(d->ev[which][idx].first, d->stream);
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(d->ev[which][idx].second, d->stream); }
+};
+
+// halo fill of one slab: neighbour exchange (or self wrap) in x/y, then BCs -- replaces halo_exchange (:574-827)
+static int halo_fill(mw_dycore_s *d, double *S) {
+  ProfScope ps(d, 3);
+  const DyP &p = d->p;
+  bool ex_x = d->xchg && (p.nproc_x > 1), ex_y = d->xchg && (p.nproc_y > 1) && !p.sim2d;
+  if (ex_x || ex_y) {
+    // a rank grid with more than one rank in a direction: ship 3-cell strips to the face neighbours.
+    // Directions with a single rank still wrap locally below.
+    if (ex_x) { hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((d->nWE + 255) / 256)), dim3(256), 0, d->stream, p, S, d->bufs[0], d->bufs[1]); MW_LAUNCH_CHECK(); }
+    if (ex_y) { hipLaunchKernelGGL(k_pack_y, dim3((unsigned)((d->nSN + 255) / 256)), dim3(256), 0, d->stream, p, S, d->bufs[2], d->bufs[3]); MW_LAUNCH_CHECK(); }
+    int rc = d->xchg(d->xchg_ctx, ex_x ? d->bufs[0] : nullptr, ex_x ? d->bufs[1] : nullptr, ex_y ? d->bufs[2] : nullptr,
+                     ex_y ? d->bufs[3] : nullptr, ex_x ? d->bufs[4] : nullptr, ex_x ? d->bufs[5] : nullptr,
+                     ex_y ? d->bufs[6] : nullptr, ex_y ? d->bufs[7] : nullptr, ex_x ? d->nWE : 0, ex_y ? d->nSN : 0, d->stream);
+    if (rc) MW_FAIL("halo exchange callback failed");
+    if (ex_x) { hipLaunchKernelGGL(k_unpack_x, dim3((unsigned)((d->nWE + 255) / 256)), dim3(256), 0, d->stream, p, S, d->bufs[4], d->bufs[5]); MW_LAUNCH_CHECK(); }
+    if (ex_y) { hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((d->nSN + 255) / 256)), dim3(256), 0, d->stream, p, S, d->bufs[6], d->bufs[7]); MW_LAUNCH_CHECK(); }
+  }
+  // local wrap / BC:  x when this direction has one rank (periodic self-wrap) or a non-periodic BC on an edge rank
+  {
+    DyP q = p;
+    bool local_x = !ex_x;
+    if (local_x) {
+      long long n = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens;
+      hipLaunchKernelGGL(k_halo_x, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, q, S); MW_LAUNCH_CHECK();
+    } else if (p.bc_x != MW_BC_PERIODIC) MW_FAIL("wall/open bc_x with nproc_x > 1 is not implemented");
+    bool local_y = !ex_y && !p.sim2d;
+    if (local_y) {
+      long long n = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
+      hipLaunchKernelGGL(k_halo_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, q, S); MW_LAUNCH_CHECK();
+    } else if (!p.sim2d && p.bc_y != MW_BC_PERIODIC) MW_FAIL("wall/open bc_y with nproc_y > 1 is not implemented");
+    long long n = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
+    hipLaunchKernelGGL(k_halo_z, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, q, S); MW_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+static int launch_flux(mw_dycore_s *d, const double *S) {
+  ProfScope ps(d, 0);
+  const DyP &p = d->p;
+  long long per_plane = (long long)(p.sim2d ? p.ny : p.ny + 1) * (p.nx + 1) * p.nens;
+  dim3 grid = plane_grid(per_plane, p.nz + 1);
+  if (d->strict) hipLaunchKernelGGL(k_flux<true>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+  else           hipLaunchKernelGGL(k_flux<false>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+static int launch_fct(mw_dycore_s *d, const double *S, double dt) {
+  const DyP &p = d->p;
+  if (p.nt == 0 || p.pos_mask == 0) return 0;
+  ProfScope ps(d, 1);
+  dim3 grid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz, p.nt);
+  hipLaunchKernelGGL(k_fct, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ, dt);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int STAGE, int MODE>
+static int launch_update(mw_dycore_s *d, const double *Sstar, const double *Sn, double *Sout, double dt_stage, double dt_dyn,
+                         const CouplerPtrs &c, double *st, double *tt) {
+  ProfScope ps(d, 2);
+  const DyP &p = d->p;
+  dim3 grid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
+  hipLaunchKernelGGL((k_update<STAGE, MODE>), grid, dim3(256), 0, d->stream, p, Sstar, Sn, Sout, d->FX, d->FY, d->FZ, dt_stage,
+                     dt_dyn, c, st, tt);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+static int make_coupler_ptrs(mw_dycore_s *d, const double *rho_d, const double *u, const double *v, const double *w,
+                             const double *temp, double *const *tracers, CouplerPtrs &c) {
+  if (!rho_d || !u || !v || !w || !temp || (d->g.num_tracers > 0 && !tracers)) MW_FAIL("null field pointer");
+  c.rho_d = (double *)rho_d; c.u = (double *)u; c.v = (double *)v; c.w = (double *)w; c.temp = (double *)temp;
+  for (int t = 0; t < MW_MAX_TRACERS; t++) c.tr[t] = (t < d->g.num_tracers) ? tracers[t] : nullptr;
+  for (int t = 0; t < d->g.num_tracers; t++) if (!c.tr[t]) MW_FAIL("null tracer pointer");
+  return 0;
+}
+
+static int validate_grid(const mw_grid_t *g) {
+  if (!g) MW_FAIL("null grid");
+  if (g->nz < 3 || g->nx < 3 || g->ny < 1 || g->nens < 1) MW_FAIL("grid too small (need nz,nx >= 3, ny >= 1, nens >= 1)");
+  if (g->ny_glob != 1 && g->ny < 3) MW_FAIL("3-D runs need ny >= 3 per rank");
+  if (g->num_tracers < 1 || g->num_tracers > MW_MAX_TRACERS) MW_FAIL("num_tracers must be in [1, MW_MAX_TRACERS] (a water_vapor tracer is required, SURVEY 8(a) quirk 6)");
+  if (g->idWV < 0 || g->idWV >= g->num_tracers) MW_FAIL("idWV out of range");
+  if (g->bc_z == MW_BC_PERIODIC) MW_FAIL("bc_z = periodic is not implemented (no reference test case uses it)");
+  return 0;
+}
+
+extern "C" {
+
+int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tracer_positive,
+                     const unsigned char *tracer_adds_mass, void *stream) {
+  if (!h) MW_FAIL("null handle pointer");
+  if (validate_grid(g)) return 1;
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  mw_dycore_s *d = new mw_dycore_s();
+  d->g = *g;
+  for (int t = 0; t < MW_MAX_TRACERS; t++) { d->pos[t] = (t < g->num_tracers && tracer_positive) ? tracer_positive[t] : 0;
+                                             d->adds[t] = (t < g->num_tracers && tracer_adds_mass) ? tracer_adds_mass[t] : 0; }
+  d->stream = (hipStream_t)stream;
+  const char *s = getenv("MW_STRICT");
+  d->strict = (s && s[0] == '1');
+  size_t nzc = (size_t)g->nz * g->nens, nze = (size_t)(g->nz + 1) * g->nens;
+  d->hy_host.assign(2 * nzc + 2 * nze, 0.0);
+  auto fail = [&](void) { mw_dycore_destroy(d); return 1; };
+  if (hipMalloc(&d->hy_dev, d->hy_host.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(hy) failed"); return fail(); }
+  fill_params(d);
+  const DyP &p = d->p;
+  size_t slab = (size_t)p.V * p.sV * sizeof(double);
+  size_t fxb = (size_t)p.V * p.fxV * sizeof(double), fyb = (size_t)p.V * p.fyV * sizeof(double), fzb = (size_t)p.V * p.fzV * sizeof(double);
+  if (hipMalloc(&d->S0, slab) != hipSuccess || hipMalloc(&d->S1, slab) != hipSuccess || hipMalloc(&d->FX, fxb) != hipSuccess ||
+      hipMalloc(&d->FY, fyb) != hipSuccess || hipMalloc(&d->FZ, fzb) != hipSuccess ||
+      hipMalloc(&d->imm, (size_t)p.nC * sizeof(double)) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return fail(); }
+  // zero everything once: halo corners are never written and the flux arrays start at 0 (:1677-1682)
+  (void)hipMemsetAsync(d->S0, 0, slab, d->stream); (void)hipMemsetAsync(d->S1, 0, slab, d->stream);
+  (void)hipMemsetAsync(d->FX, 0, fxb, d->stream); (void)hipMemsetAsync(d->FY, 0, fyb, d->stream); (void)hipMemsetAsync(d->FZ, 0, fzb, d->stream);
+  (void)hipMemsetAsync(d->imm, 0, (size_t)p.nC * sizeof(double), d->stream);
+  d->nWE = (long long)p.V * p.nz * p.ny * p.HX * p.nens;
+  d->nSN = (long long)p.V * p.nz * p.HY * p.nx * p.nens;
+  fill_params(d);
+  if (hipStreamSynchronize(d->stream) != hipSuccess) { set_error("stream sync failed in create"); return fail(); }
+  *h = d;
+  return 0;
+}
+
+void mw_dycore_destroy(mw_dycore_t d) {
+  if (!d) return;
+  (void)hipStreamSynchronize(d->stream);
+  for (double *ptr : {d->S0, d->S1, d->FX, d->FY, d->FZ, d->hy_dev, d->imm}) if (ptr) (void)hipFree(ptr);
+  for (int b = 0; b < 8; b++) if (d->bufs[b]) (void)hipFree(d->bufs[b]);
+  for (int w = 0; w < 5; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  delete d;
+}
+
+int mw_dycore_get_grid(mw_dycore_t d, mw_grid_t *g) { if (!d || !g) MW_FAIL("null argument"); *g = d->g; return 0; }
+double mw_dycore_get_etime(mw_dycore_t d) { return d ? d->etime : -1.0; }
+double *mw_dycore_immersed_proportion(mw_dycore_t d) { return d ? d->imm : nullptr; }
+
+int mw_dycore_set_bc(mw_dycore_t d, int bc_x, int bc_y, int bc_z) {
+  if (!d) MW_FAIL("null handle");
+  if (bc_z == MW_BC_PERIODIC) MW_FAIL("bc_z = periodic is not implemented");
+  d->g.bc_x = bc_x; d->g.bc_y = bc_y; d->g.bc_z = bc_z;
+  fill_params(d);
+  return 0;
+}
+int mw_dycore_set_strict(mw_dycore_t d, int strict) { if (!d) MW_FAIL("null handle"); d->strict = strict; return 0; }
+
+int mw_dycore_set_background(mw_dycore_t d, const double *hyc, const double *hytc, const double *hye, const double *hyte,
+                             const double *immersed_proportion) {
+  if (!d || !hyc || !hytc || !hye || !hyte) MW_FAIL("null argument");
+  size_t nzc = (size_t)d->g.nz * d->g.nens, nze = (size_t)(d->g.nz + 1) * d->g.nens;
+  memcpy(d->hy_host.data(), hyc, nzc * 8); memcpy(d->hy_host.data() + nzc, hytc, nzc * 8);
+  memcpy(d->hy_host.data() + 2 * nzc, hye, nze * 8); memcpy(d->hy_host.data() + 2 * nzc + nze, hyte, nze * 8);
+  if (upload_background(d)) return 1;
+  if (immersed_proportion) MW_HIP(hipMemcpyAsync(d->imm, immersed_proportion, (size_t)d->p.nC * 8, hipMemcpyDeviceToDevice, d->stream));
+  else MW_HIP(hipMemsetAsync(d->imm, 0, (size_t)d->p.nC * 8, d->stream));
+  return 0;
+}
+
+int mw_dycore_get_background(mw_dycore_t d, double *hyc, double *hytc, double *hye, double *hyte) {
+  if (!d) MW_FAIL("null handle");
+  size_t nzc = (size_t)d->g.nz * d->g.nens, nze = (size_t)(d->g.nz + 1) * d->g.nens;
+  if (hyc) memcpy(hyc, d->hy_host.data(), nzc * 8);
+  if (hytc) memcpy(hytc, d->hy_host.data() + nzc, nzc * 8);
+  if (hye) memcpy(hye, d->hy_host.data() + 2 * nzc, nze * 8);
+  if (hyte) memcpy(hyte, d->hy_host.data() + 2 * nzc + nze, nze * 8);
+  return 0;
+}
+
+int mw_dycore_get_fluxes(mw_dycore_t d, double **out6) {
+  if (!d || !out6) MW_FAIL("null argument");
+  out6[0] = d->FX; out6[1] = d->FY; out6[2] = d->FZ;
+  out6[3] = d->FX + 5 * d->p.fxV; out6[4] = d->FY + 5 * d->p.fyV; out6[5] = d->FZ + 5 * d->p.fzV;
+  return 0;
+}
+
+int mw_dycore_set_exchange(mw_dycore_t d, mw_exchange_fn fn, void *ctx) {
+  if (!d) MW_FAIL("null handle");
+  d->xchg = fn; d->xchg_ctx = ctx;
+  if (fn) {
+    for (int b = 0; b < 8; b++) {
+      if (d->bufs[b]) continue;
+      long long n = (b % 4 < 2) ? d->nWE : d->nSN;
+      if (n == 0) n = 1;
+      MW_HIP(hipMalloc(&d->bufs[b], (size_t)n * sizeof(double)));
+    }
+  }
+  return 0;
+}
+
+int mw_dycore_profile(mw_dycore_t d, int enable) {
+  if (!d) MW_FAIL("null handle");
+  MW_HIP(hipStreamSynchronize(d->stream));
+  d->prof = enable;
+  for (int w = 0; w < 5; w++) d->ev_used[w] = 0;
+  return 0;
+}
+int mw_dycore_profile_get(mw_dycore_t d, int which, double *total_ms, long long *launches) {
+  if (!d || which < 0 || which > 4) MW_FAIL("bad argument");
+  MW_HIP(hipStreamSynchronize(d->stream));
+  double tot = 0;
+  for (size_t i = 0; i < d->ev_used[which]; i++) { float ms = 0; MW_HIP(hipEventElapsedTime(&ms, d->ev[which][i].first, d->ev[which][i].second)); tot += ms; }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (long long)d->ev_used[which];
+  return 0;
+}
+
+// ---- time_step (:81-198) -------------------------------------------------------------------------------
+int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, double *w, double *temp, double *const *tracers,
+                        double dt_phys) {
+  if (!d) MW_FAIL("null handle");
+  if (!(dt_phys > 0)) MW_FAIL("dt_phys must be > 0");
+  CouplerPtrs c;
+  if (make_coupler_ptrs(d, rho_d, u, v, w, temp, tracers, c)) return 1;
+  fill_params(d);
+  const DyP &p = d->p;
+  dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
+  { ProfScope ps(d, 4);
+    hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK(); }       // :101 (+ D2)
+  double dt_dyn = mw_dycore_compute_time_step(&d->g);                     // :104
+  int ncycles = (int)std::ceil(dt_phys / dt_dyn);                         // :107
+  dt_dyn = dt_phys / ncycles;                                             // :108
+  for (int icycle = 0; icycle < ncycles; icycle++) {
+    bool last = (icycle == ncycles - 1);
+    // stage 1 (:119-132)
+    if (halo_fill(d, d->S0)) return 1;
+    if (launch_flux(d, d->S0)) return 1;
+    if (launch_fct(d, d->S0, dt_dyn)) return 1;
+    if (launch_update<1, 0>(d, d->S0, d->S0, d->S1, dt_dyn, dt_dyn, c, nullptr, nullptr)) return 1;
+    // stage 2 (:136-153)
+    double dt2 = (1.0 / 4.0) * dt_dyn;
+    if (halo_fill(d, d->S1)) return 1;
+    if (launch_flux(d, d->S1)) return 1;
+    if (launch_fct(d, d->S1, dt2)) return 1;
+    if (launch_update<2, 0>(d, d->S1, d->S0, d->S1, dt2, dt_dyn, c, nullptr, nullptr)) return 1;
+    // stage 3 (:157-174)
+    double dt3 = (2.0 / 3.0) * dt_dyn;
+    if (halo_fill(d, d->S1)) return 1;
+    if (launch_flux(d, d->S1)) return 1;
+    if (launch_fct(d, d->S1, dt3)) return 1;
+    if (last) { if (launch_update<3, 1>(d, d->S1, d->S0, d->S0, dt3, dt_dyn, c, nullptr, nullptr)) return 1; }     // + :178
+    else      { if (launch_update<3, 0>(d, d->S1, d->S0, d->S0, dt3, dt_dyn, c, nullptr, nullptr)) return 1; }
+  }
+  d->etime += dt_phys;                                                    // :181
+  return 0;
+}
+
+int mw_dycore_compute_tendencies(mw_dycore_t d, const double *rho_d, const double *u, const double *v, const double *w,
+                                 const double *temp, double *const *tracers, double dt, double *state_tend, double *tracers_tend) {
+  if (!d) MW_FAIL("null handle");
+  CouplerPtrs c;
+  if (make_coupler_ptrs(d, rho_d, u, v, w, temp, tracers, c)) return 1;
+  fill_params(d);
+  const DyP &p = d->p;
+  dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
+  hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK();
+  if (halo_fill(d, d->S0)) return 1;
+  if (launch_flux(d, d->S0)) return 1;
+  if (launch_fct(d, d->S0, dt)) return 1;
+  if (state_tend && tracers_tend) { if (launch_update<1, 2>(d, d->S0, d->S0, nullptr, dt, dt, c, state_tend, tracers_tend)) return 1; }
+  return 0;
+}
+
+int mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream) {
+  if (!g || !temp) MW_FAIL("null argument");
+  long long n = (long long)g->nz * g->ny * g->nx * g->nens;
+  hipLaunchKernelGGL(k_perturb_temperature, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g->nz, g->ny, g->nx,
+                     g->nens, g->i_beg, g->j_beg, g->xlen / g->nx_glob, g->ylen / g->ny_glob, g->zlen / g->nz, g->xlen, g->ylen, temp);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+} // extern "C"
+
+// ---- init (:1197-1683): host column profiles + device quadrature --------------------------------------
+namespace {
+
+double h_supercell_temperature(double z, double z_0, double z_trop, double z_top, double T_0, double T_trop, double T_top) {  // :1144-1153
+  if (z <= z_trop) { double lapse = -(T_trop - T_0) / (z_trop - z_0); return T_0 - lapse * (z - z_0); }
+  double lapse = -(T_top - T_trop) / (z_top - z_trop);
+  return T_trop - lapse * (z - z_trop);
+}
+double h_supercell_pressure_dry(double z, double z_0, double z_trop, double z_top, double T_0, double T_trop, double T_top,
+                                double p_0, double R_d, double grav) {          // :1157-1177
+  if (z <= z_trop) {
+    double lapse = -(T_trop - T_0) / (z_trop - z_0);
+    double T = h_supercell_temperature(z, z_0, z_trop, z_top, T_0, T_trop, T_top);
+    return p_0 * pow(T / T_0, grav / (R_d * lapse));
+  }
+  double lapse = -(T_trop - T_0) / (z_trop - z_0);
+  double p_trop = p_0 * pow(T_trop / T_0, grav / (R_d * lapse));
+  lapse = -(T_top - T_trop) / (z_top - z_trop);
+  if (lapse != 0) {
+    double T = h_supercell_temperature(z, z_0, z_trop, z_top, T_0, T_trop, T_top);
+    return p_trop * pow(T / T_trop, grav / (R_d * lapse));
+  }
+  return p_trop * exp(-grav * (z - z_trop) / (R_d * T_trop));
+}
+double h_supercell_relhum(double z, double, double z_trop) {                    // :1181-1187
+  if (z <= z_trop) return 1.0 - 0.75 * pow(z / z_trop, 1.25);
+  return 0.25;
+}
+double h_supercell_sat_mix_dry(double press, double T) { return 380 / (press)*exp(17.27 * (T - 273) / (T - 36)); }   // :1191-1193
+
+void h_hydro_const_theta(double z, double grav, double C0, double cp, double p0, double gamma, double rd, double &r, double &t) {   // :1108-1117
+  const double theta0 = 300., exner0 = 1.;
+  t = theta0;
+  double exner = exner0 - grav * z / (cp * theta0);
+  double p = p0 * std::pow(exner, (cp / rd));
+  double rt = std::pow((p / C0), (1.0 / gamma));
+  r = rt / t;
+}
+
+const double h_gll5_pts[5] = {-0.50000000000000000000000000000000000000, -0.32732683535398857189914622812342917778,
+                              0.00000000000000000000000000000000000000, 0.32732683535398857189914622812342917778,
+                              0.50000000000000000000000000000000000000};
+const double h_gll5_wts[5] = {0.050000000000000000000000000000000000000, 0.27222222222222222222222222222222222222,
+                              0.35555555555555555555555555555555555556, 0.27222222222222222222222222222222222222,
+                              0.050000000000000000000000000000000000000};
+const double h_gll9_pts[9] = {-0.50000000000000000000000000000000000000, -0.44987899770573007865617262220916897903,
+                              -0.33859313975536887672294271354567122536, -0.18155873191308907935537603435432960651,
+                              0.00000000000000000000000000000000000000, 0.18155873191308907935537603435432960651,
+                              0.33859313975536887672294271354567122536, 0.44987899770573007865617262220916897903,
+                              0.50000000000000000000000000000000000000};
+const double h_gll9_wts[9] = {0.013888888888888888888888888888888888889, 0.082747680780402762523169860014604152919,
+                              0.13726935625008086764035280928968636297, 0.17321425548652317255756576606985914397,
+                              0.18575963718820861678004535147392290249, 0.17321425548652317255756576606985914397,
+                              0.13726935625008086764035280928968636297, 0.082747680780402762523169860014604152919,
+                              0.013888888888888888888888888888888888889};
+const double h_gl3_pts[3] = {0.112701665379258311482073460022, 0.500000000000000000000000000000, 0.887298334620741688517926539980};
+const double h_gl3_wts[3] = {0.277777777777777777777777777779, 0.444444444444444444444444444444, 0.277777777777777777777777777779};
+
+} // namespace
+
+extern "C" int mw_dycore_init(mw_dycore_t d, int init_data, double *rho_d, double *u, double *v, double *w, double *temp,
+                              double *const *tracers) {
+  if (!d) MW_FAIL("null handle");
+  if (init_data < 0 || init_data > 3) MW_FAIL("ERROR: Invalid init_data");      // :1310
+  CouplerPtrs c;
+  if (make_coupler_ptrs(d, rho_d, u, v, w, temp, tracers, c)) return 1;
+  mw_grid_t &g = d->g;
+  g.latitude = 0;                                                                // :1249
+  g.bc_x = MW_BC_PERIODIC; g.bc_y = MW_BC_PERIODIC; g.bc_z = MW_BC_WALL;         // :1332-1334, 1340-1342, 1423-1425, 1551-1553
+  g.use_immersed = (init_data == MW_DATA_CITY || init_data == MW_DATA_BUILDING); // :1312, 1426, 1554
+  d->etime = 0;                                                                  // :1317
+  const int nz = g.nz, nens = g.nens, ord = 5;
+  const double dz = g.zlen / g.nz, dx = g.xlen / g.nx_glob;
+  size_t nzc = (size_t)nz * nens, nze = (size_t)(nz + 1) * nens;
+  double *hyc = d->hy_host.data(), *hytc = hyc + nzc, *hye = hyc + 2 * nzc, *hyte = hye + nze;
+  std::vector<double> gllcols;     // supercell: hyDensGLL | hyDensThetaGLL | hyDensVapGLL, each (nz,5)
+  InitP q;  memset(&q, 0, sizeof(q));
+  q.init_data = init_data; q.i_beg = g.i_beg; q.j_beg = g.j_beg; q.xlen = g.xlen; q.ylen = g.ylen; q.cp_d = g.cp_d; q.p0 = g.p0;
+  q.nx_glob = g.nx_glob; q.ny_glob = g.ny_glob;
+  std::vector<double> bheights;
+  if (init_data == MW_DATA_SUPERCELL) {                                          // init_supercell, :1687-1840
+    const double z_0 = 0, z_trop = 12000, T_0 = 300, T_trop = 213, T_top = 213, p_0 = 100000;
+    const double R_d = g.R_d, R_v = g.R_v, grav = g.grav, gamma = g.gamma_d, C0 = g.C0, ztop = g.zlen;
+    std::vector<double> quad_temp((size_t)nz * (ord - 1) * ord), hyP((size_t)nz * ord);
+    gllcols.assign((size_t)3 * nz * ord, 0.0);
+    double *hyDensGLL = gllcols.data(), *hyDensThetaGLL = hyDensGLL + (size_t)nz * ord, *hyDensVapGLL = hyDensThetaGLL + (size_t)nz * ord;
+    for (int k = 0; k < nz; k++) for (int kk = 0; kk < ord - 1; kk++) for (int kkk = 0; kkk < ord; kkk++) {       // :1736-1756
+      double cellmid = (k + 0.5) * dz;
+      double ord_b = cellmid + h_gll5_pts[kk] * dz, ord_t = cellmid + h_gll5_pts[kk + 1] * dz;
+      double ord_m = 0.5 * (ord_b + ord_t);
+      double ord_dz = dz * (h_gll5_pts[kk + 1] - h_gll5_pts[kk]);
+      double zloc = ord_m + ord_dz * h_gll5_pts[kkk];
+      double T = h_supercell_temperature(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top);
+      double press_dry = h_supercell_pressure_dry(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top, p_0, R_d, grav);
+      double qvs = h_supercell_sat_mix_dry(press_dry, T);
+      double relhum = h_supercell_relhum(zloc, z_0, z_trop);
+      if (relhum * qvs > 0.014) relhum = 0.014 / qvs;
+      double qv = std::min(0.014, qvs * relhum);
+      quad_temp[((size_t)k * (ord - 1) + kk) * ord + kkk] = -(1 + qv) * grav / (R_d + qv * R_v) / T;
+    }
+    hyP[0] = p_0;                                                                                                   // :1759-1774
+    for (int k = 0; k < nz; k++) for (int kk = 0; kk < ord - 1; kk++) {
+      double tot = 0;
+      for (int kkk = 0; kkk < ord; kkk++) tot += quad_temp[((size_t)k * (ord - 1) + kk) * ord + kkk] * h_gll5_wts[kkk];
+      tot *= dz * (h_gll5_pts[kk + 1] - h_gll5_pts[kk]);
+      hyP[(size_t)k * ord + kk + 1] = hyP[(size_t)k * ord + kk] * exp(tot);
+      if (kk == ord - 2 && k < nz - 1) hyP[(size_t)(k + 1) * ord] = hyP[(size_t)k * ord + ord - 1];
+    }
+    for (int k = 0; k < nz; k++) for (int kk = 0; kk < ord; kk++) {                                               // :1777-1805
+      double zloc = (k + 0.5) * dz + h_gll5_pts[kk] * dz;
+      double T = h_supercell_temperature(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top);
+      double press_tmp = h_supercell_pressure_dry(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top, p_0, R_d, grav);
+      double qvs = h_supercell_sat_mix_dry(press_tmp, T);
+      double relhum = h_supercell_relhum(zloc, z_0, z_trop);
+      if (relhum * qvs > 0.014) relhum = 0.014 / qvs;
+      double qv = std::min(0.014, qvs * relhum);
+      double press = hyP[(size_t)k * ord + kk];
+      double dens_dry = press / (R_d + qv * R_v) / T;
+      double dens_vap = qv * dens_dry;
+      double dens = dens_dry + dens_vap;
+      double dens_theta = pow(press / C0, 1.0 / gamma);
+      hyDensGLL[(size_t)k * ord + kk] = dens; hyDensThetaGLL[(size_t)k * ord + kk] = dens_theta; hyDensVapGLL[(size_t)k * ord + kk] = dens_vap;
+      if (kk == 0) for (int e = 0; e < nens; e++) { hye[(size_t)k * nens + e] = dens; hyte[(size_t)k * nens + e] = dens_theta; }
+      if (k == nz - 1 && kk == ord - 1) for (int e = 0; e < nens; e++) { hye[(size_t)(k + 1) * nens + e] = dens; hyte[(size_t)(k + 1) * nens + e] = dens_theta; }
+    }
+    for (int k = 0; k < nz; k++) {                                                                                  // :1808-1840
+      double dens_tot = 0, dens_theta_tot = 0;
+      for (int kk = 0; kk < ord; kk++) { dens_tot += hyDensGLL[(size_t)k * ord + kk] * h_gll5_wts[kk];
+                                         dens_theta_tot += hyDensThetaGLL[(size_t)k * ord + kk] * h_gll5_wts[kk]; }
+      for (int e = 0; e < nens; e++) { hyc[(size_t)k * nens + e] = dens_tot; hytc[(size_t)k * nens + e] = dens_theta_tot; }
+    }
+  } else {
+    bool use_hydro = (init_data == MW_DATA_THERMAL) || g.enable_gravity;
+    if (use_hydro) {                                                             // :1396-1419, 1516-1541, 1620-1645
+      const int nq = (init_data == MW_DATA_THERMAL) ? 3 : 9;
+      const double *qp = (init_data == MW_DATA_THERMAL) ? h_gl3_pts : h_gll9_pts;
+      const double *qw = (init_data == MW_DATA_THERMAL) ? h_gl3_wts : h_gll9_wts;
+      for (int k = 0; k < nz; k++) for (int e = 0; e < nens; e++) {
+        hyc[(size_t)k * nens + e] = 0.; hytc[(size_t)k * nens + e] = 0.;
+        for (int kk = 0; kk < nq; kk++) {
+          double z = (k + 0.5) * dz + (qp[kk] - 0.5) * dz;
+          double hr, ht;
+          h_hydro_const_theta(z, g.grav, g.C0, g.cp_d, g.p0, g.gamma_d, g.R_d, hr, ht);
+          hyc[(size_t)k * nens + e] += hr * qw[kk];
+          hytc[(size_t)k * nens + e] += hr * ht * qw[kk];
+        }
+      }
+      for (int k = 0; k < nz + 1; k++) for (int e = 0; e < nens; e++) {
+        double z = k * dz, hr, ht;
+        h_hydro_const_theta(z, g.grav, g.C0, g.cp_d, g.p0, g.gamma_d, g.R_d, hr, ht);
+        hye[(size_t)k * nens + e] = hr; hyte[(size_t)k * nens + e] = hr * ht;
+      }
+    } else {                                                                     // :1542-1547, 1646-1651
+      for (size_t n = 0; n < nzc; n++) { hyc[n] = 1.15; hytc[n] = 1.15 * 300; }
+      for (size_t n = 0; n < nze; n++) { hye[n] = 1.15; hyte[n] = 1.15 * 300; }
+    }
+    if (init_data == MW_DATA_CITY) {                                             // :1429-1452
+      int building_length = 30;
+      q.cells_per_building = (int)std::round(building_length / dx);
+      q.buildings_pad = 20;
+      q.nblocks_x = (static_cast<int>(g.xlen) / building_length - 2 * q.buildings_pad) / 3;
+      q.nblocks_y = (static_cast<int>(g.ylen) / building_length - 2 * q.buildings_pad) / 9;
+      q.nbx = q.nblocks_x * 3; q.nby = q.nblocks_y * 9;
+      if (q.cells_per_building < 1) MW_FAIL("city init: dx too coarse for 30 m buildings");
+      bheights.assign((size_t)std::max(1, q.nbx * q.nby), 0.0);
+      std::mt19937 gen{17};
+      std::normal_distribution<> dist{60, 10};
+      for (int j = 0; j < q.nby; j++) for (int i = 0; i < q.nbx; i++) bheights[(size_t)j * q.nbx + i] = dist(gen);
+    }
+  }
+  if (upload_background(d)) return 1;
+  fill_params(d);
+  double *dev_cols = nullptr, *dev_bh = nullptr;
+  if (!gllcols.empty()) {
+    MW_HIP(hipMalloc(&dev_cols, gllcols.size() * 8));
+    MW_HIP(hipMemcpy(dev_cols, gllcols.data(), gllcols.size() * 8, hipMemcpyHostToDevice));
+    q.hyDensGLL = dev_cols; q.hyDensThetaGLL = dev_cols + (size_t)nz * ord; q.hyDensVapGLL = dev_cols + (size_t)2 * nz * ord;
+  }
+  if (!bheights.empty()) {
+    MW_HIP(hipMalloc(&dev_bh, bheights.size() * 8));
+    MW_HIP(hipMemcpy(dev_bh, bheights.data(), bheights.size() * 8, hipMemcpyHostToDevice));
+    q.bheights = dev_bh;
+  }
+  MW_HIP(hipMemsetAsync(d->imm, 0, (size_t)d->p.nC * 8, d->stream));                    // :1315
+  const DyP &p = d->p;
+  hipLaunchKernelGGL(k_init_cells, plane_grid((long long)p.ny * p.nx * p.nens, p.nz), dim3(256), 0, d->stream, p, q, c, d->imm);
+  MW_LAUNCH_CHECK();
+  MW_HIP(hipStreamSynchronize(d->stream));
+  if (dev_cols) (void)hipFree(dev_cols);
+  if (dev_bh) (void)hipFree(dev_bh);
+  // the six flux arrays start at zero (:1677-1682)
+  MW_HIP(hipMemsetAsync(d->FX, 0, (size_t)p.V * p.fxV * 8, d->stream));
+  MW_HIP(hipMemsetAsync(d->FY, 0, (size_t)p.V * p.fyV * 8, d->stream));
+  MW_HIP(hipMemsetAsync(d->FZ, 0, (size_t)p.V * p.fzV * 8, d->stream));
+  return 0;
+}

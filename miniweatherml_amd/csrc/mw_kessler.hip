@@ -1,0 +1,173 @@
+// =====================================================================================================
+// mw_kessler.hip -- Microphysics_Kessler::time_step for gfx950
+// reference: model/modules/microphysics_kessler.h:99-162 (time_step) and :234-339 (kessler()).
+//
+// Two kernels, no host synchronisation:
+//   k_kessler_prep   [K1,K2,K3]  per cell: exner, r, rhalf, velqr, CFL limit; block min -> one 64-bit atomicMin
+//   k_kessler_column [K4,K5]     one thread per column, top-down sweep per rain sub-cycle.  The reference's
+//                                "all sed(k) first, then adjust" (:288-335) only needs the pre-update value of
+//                                r*qr*velqr at k+1, which the sweep carries in a register.  rainsplit is read
+//                                from device memory, so the reference's device->host minval sync (:276) disappears.
+// Arrays are the (nz,ncol) views of the coupler fields (DataManager::get_lev_col), column index fastest:
+// thread i walks k with perfectly coalesced accesses.
+// =====================================================================================================
+#include "../../include/mw_cdna4.h"
+#include "mw_common.h"
+#include <cmath>
+#include <cstring>
+
+namespace mw {
+
+struct KesP {
+  int nz; long long ncol;
+  double dz, dt;
+  double R_d, cp_d, R_v, p0;       // module constants, microphysics_kessler.h:29-41
+};
+
+// workspace layout (doubles): [0] dt_max bits (as unsigned long long) | velqr(nz,ncol) | theta | qv | qc | qr
+__global__ __launch_bounds__(256) void k_kessler_init_min(unsigned long long *dtmax_bits) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dtmax_bits = 0x7FF0000000000000ull;   // +inf
+}
+
+__global__ __launch_bounds__(256) void k_kessler_prep(KesP p, const double *__restrict__ rho_v, const double *__restrict__ rho_r,
+                                                      const double *__restrict__ rho_d, const double *__restrict__ temp,
+                                                      double *__restrict__ velqr_out, unsigned long long *dtmax_bits) {
+#pragma clang fp contract(off)
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y;
+  double dtc = __longlong_as_double(0x7FF0000000000000ll);
+  if (i < p.ncol) {
+    long long idx = (long long)k * p.ncol + i;
+    double rd = rho_d[idx];
+    double qr = rho_r[idx] / rd;                              // :140
+    double r = 0.001 * rd;                                    // :256
+    double rhalf = sqrt(rho_d[i] / rd);                       // :257  rho(0,i)/rho(k,i)
+    double velqr = 36.34 * pow(qr * r, 0.1364) * rhalf;       // :260
+    velqr_out[idx] = velqr;
+    if (k < p.nz - 1) {                                       // :262-268
+      double zk = (k + 0.5) * p.dz, zk1 = (k + 1 + 0.5) * p.dz;   // zmid, :137
+      if (velqr > 1.e-10) dtc = 0.8 * (zk1 - zk) / velqr; else dtc = p.dt;
+    }
+  }
+  // block min (wave shuffle, then LDS across the 4 waves); positive doubles order like their bit patterns
+  for (int off = 32; off > 0; off >>= 1) { double o = __shfl_down(dtc, off, 64); dtc = fmin(dtc, o); }
+  __shared__ double smin[4];
+  int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) smin[wv] = dtc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+    atomicMin(dtmax_bits, (unsigned long long)__double_as_longlong(m));     // :276 minval(dt2d)
+  }
+}
+
+__global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restrict__ rho_v, double *__restrict__ rho_c,
+                                                        double *__restrict__ rho_r, const double *__restrict__ rho_d,
+                                                        double *__restrict__ temp, double *__restrict__ precl,
+                                                        const unsigned long long *dtmax_bits, double *__restrict__ ws) {
+#pragma clang fp contract(off)
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.ncol) return;
+  const long long n = (long long)p.nz * p.ncol;
+  double *w_velqr = ws, *w_theta = ws + n, *w_qv = ws + 2 * n, *w_qc = ws + 3 * n, *w_qr = ws + 4 * n;
+  const double dt_max = __longlong_as_double((long long)*dtmax_bits);
+  const int rainsplit = (int)ceil(p.dt / dt_max);             // :279
+  const double dt0 = p.dt / (double)rainsplit;                // :280
+  const double Rd = p.R_d, cp = p.cp_d;
+  const double psl = p.p0 / 100;                              // :246
+  const double rhoqr = 1000., lv = 2.5e6;                     // :247-248
+  const int nz = p.nz;
+  const double rho0 = rho_d[i];
+  double precl_acc = 0;                                       // :270-272
+  for (int nt = 0; nt < rainsplit; nt++) {
+    const bool first = (nt == 0), lastp = (nt == rainsplit - 1);
+    double flux_above = 0;                                    // r(k+1)*qr(k+1)*velqr(k+1), pre-update
+    for (int k = nz - 1; k >= 0; k--) {
+      long long idx = (long long)k * p.ncol + i;
+      double rd = rho_d[idx];
+      double T_in = temp[idx], rv_in = rho_v[idx];
+      double pressure = Rd * rd * T_in + p.R_v * rv_in * T_in;            // :141
+      double pk = pow(pressure / p.p0, Rd / cp);                          // :142 exner
+      double theta, qv, qc, qr;
+      if (first) {
+        qv = rv_in / rd; qc = rho_c[idx] / rd; qr = rho_r[idx] / rd;      // :138-140
+        theta = T_in / pk;                                                // :143
+      } else { theta = w_theta[idx]; qv = w_qv[idx]; qc = w_qc[idx]; qr = w_qr[idx]; }
+      double velqr = w_velqr[idx];
+      double r = 0.001 * rd;                                              // :256
+      double rhalf = sqrt(rho0 / rd);                                     // :257
+      double pc = 3.8 / (pow(pk, cp / Rd) * psl);                         // :258
+      double zk = (k + 0.5) * p.dz;
+      // sedimentation (:288-299) from pre-update values
+      if (k == 0) precl_acc = precl_acc + rho0 * qr * velqr / rhoqr;      // :292 (rho(0,i) qr(0,i) velqr(0,i))
+      double flux_here = r * qr * velqr;
+      double sed;
+      if (k == nz - 1) {
+        double zm = (k - 1 + 0.5) * p.dz;
+        sed = -dt0 * qr * velqr / (0.5 * (zk - zm));                      // :295
+      } else {
+        double zp = (k + 1 + 0.5) * p.dz;
+        sed = dt0 * (flux_above - flux_here) / (r * (zp - zk));           // :297-298
+      }
+      flux_above = flux_here;
+      // adjustment terms (:302-335)
+      double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.0)) / (1 + dt0 * 2.2 * pow(qr, 0.875));
+      qc = fmax(qc - qrprod, 0.0);
+      qr = fmax(qr + qrprod + sed, 0.0);
+      double tmp = pk * theta - 36.;
+      double qvs = pc * exp(17.27 * (pk * theta - 273.) / tmp);
+      double prod = (qv - qvs) / (1. + qvs * (4093. * lv / cp) / (tmp * tmp));
+      double tmp1 = dt0 * (((1.6 + 124.9 * pow(r * qr, 0.2046)) * pow(r * qr, 0.525)) / (2550000. * pc / (3.8 * qvs) + 540000.)) *
+                    (fmax(qvs - qv, 0.0) / (r * qvs));
+      double tmp2 = fmax(-prod - qc, 0.0);
+      double tmp3 = qr;
+      double ern = fmin(tmp1, fmin(tmp2, tmp3));
+      double cond = fmax(prod, -qc);
+      theta = theta + lv / (cp * pk) * (cond - ern);
+      qv = fmax(qv - cond + ern, 0.0);
+      qc = qc + cond;
+      qr = qr - ern;
+      velqr = 36.34 * pow(qr * r, 0.1364) * rhalf;                        // :331
+      if (lastp) {                                                        // :154-161 [K5]
+        rho_v[idx] = qv * rd; rho_c[idx] = qc * rd; rho_r[idx] = qr * rd;
+        temp[idx] = theta * pk;
+      } else { w_theta[idx] = theta; w_qv[idx] = qv; w_qc[idx] = qc; w_qr[idx] = qr; w_velqr[idx] = velqr; }
+    }
+  }
+  precl[i] = precl_acc / (double)rainsplit;                               // :332-334
+}
+
+} // namespace mw
+
+using namespace mw;
+
+extern "C" {
+
+long long mw_kessler_workspace_bytes(int nz, long long ncol) { return (long long)sizeof(double) * (16 + 5ll * nz * ncol); }
+
+int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *rho_v, double *rho_c, double *rho_r,
+                         const double *rho_d, double *temp, double *precl, void *workspace, int *rainsplit_out, void *stream) {
+  if (nz < 2 || ncol < 1) MW_FAIL("kessler: need nz >= 2 and ncol >= 1");
+  if (dt <= 0) MW_FAIL("kessler.f90 called with nonpositive dt");          // :242
+  if (!rho_v || !rho_c || !rho_r || !rho_d || !temp || !precl || !workspace) MW_FAIL("kessler: null pointer");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipStream_t st = (hipStream_t)stream;
+  KesP p; p.nz = nz; p.ncol = ncol; p.dz = dz; p.dt = dt; p.R_d = 287.; p.cp_d = 1003.; p.R_v = 461.; p.p0 = 1.e5;
+  unsigned long long *bits = (unsigned long long *)workspace;
+  double *ws = (double *)workspace + 16;
+  hipLaunchKernelGGL(k_kessler_init_min, dim3(1), dim3(64), 0, st, bits); MW_LAUNCH_CHECK();
+  dim3 grid((unsigned)((ncol + 255) / 256), (unsigned)nz);
+  hipLaunchKernelGGL(k_kessler_prep, grid, dim3(256), 0, st, p, rho_v, rho_r, rho_d, temp, ws, bits); MW_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_kessler_column, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp,
+                     precl, bits, ws); MW_LAUNCH_CHECK();
+  if (rainsplit_out) {
+    unsigned long long hb = 0;
+    MW_HIP(hipMemcpyAsync(&hb, bits, 8, hipMemcpyDeviceToHost, st));
+    MW_HIP(hipStreamSynchronize(st));
+    double dt_max; memcpy(&dt_max, &hb, 8);
+    *rainsplit_out = (int)std::ceil(dt / dt_max);
+  }
+  return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,129 @@
+// =====================================================================================================
+// mw_mlp.hip -- the ponni 5 -> 10 -> 4 surrogate MLP as a batched MFMA GEMM on gfx950
+// reference call sites: experiments/supercell_kessler_surrogate/custom_modules/microphysics_kessler_ponni.h
+//   :103-110 (Matvec, Bias, Relu(negative_slope 0.1), Matvec, Bias), :180-187 (input scaling -> float),
+//   :189 (forward_batch_parallel), :196-201 (un-scaling, clip >= 0).
+//
+// One fused kernel: scale (fp64) -> layer 1 -> leaky ReLU -> layer 2 -> un-scale + clip (fp64), 72 B of HBM
+// traffic per cell and nothing else.  Matrix work rides v_mfma_f32_16x16x4_f32 (exact f32 fma chain):
+//   tile = 16 cells on the N (column = lane & 15) axis; the K axis (lane >> 4 = "group" g) carries input features.
+//   Layer 1: D1[16 x 16cells] = W1p^T[16 x 8] * X[8 x 16cells] + b1p      (2 MFMAs, K = 5 padded to 8)
+//   Layer 2: D2[16 x 16cells] = W2p^T[16 x 12] * H[12 x 16cells] + b2p    (3 MFMAs, K = 10 padded to 12)
+// The C/D layout (row = 4*g + reg) is used as the next B operand WITHOUT any lane movement: hidden unit u is
+// placed at row rho(u) with rho(u) % 4 < 3, so register j of group g *is* k-slot g of MFMA j.  Output n is
+// placed at row 4n, so lane group n holds output n in register 0 and stores 16 contiguous doubles.
+// Inputs are fetched the same way: lane group g reads feature g's array (128 contiguous bytes per group).
+// =====================================================================================================
+#include "../../include/mw_cdna4.h"
+#include "mw_common.h"
+#include <cstring>
+
+namespace mw {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpP {
+  float a1[2][64];      // layer-1 A operand per MFMA m, per lane
+  float c1[4][4];       // layer-1 C init (bias) [g][reg]
+  float a2[3][64];      // layer-2 A operand per MFMA j, per lane
+  float c2[4];          // layer-2 C init for reg 0 of group g (bias of output g)
+  double in_min[5], in_rng[5];     // scl_in(:,0), scl_in(:,1)-scl_in(:,0)
+  double out_min[4], out_rng[4];
+};
+
+__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : 0.1f * x; }
+
+// TILES 16-cell tiles per wave per iteration
+template <int TILES>
+__global__ __launch_bounds__(256) void k_mlp(MlpP P, long long ncells, const double *__restrict__ temp,
+                                             const double *__restrict__ rho_d, const double *__restrict__ rho_v,
+                                             const double *__restrict__ rho_c, const double *__restrict__ rho_r,
+                                             double *__restrict__ o_temp, double *__restrict__ o_rv,
+                                             double *__restrict__ o_rc, double *__restrict__ o_rr) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, cidx = lane & 15;
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * 256) >> 6;
+  // per-lane constants
+  const double *in_g = (g == 0) ? temp : (g == 1) ? rho_d : (g == 2) ? rho_v : rho_c;
+  double *out_g = (g == 0) ? o_temp : (g == 1) ? o_rv : (g == 2) ? o_rc : o_rr;
+  const double imin = P.in_min[g], irng = P.in_rng[g], imin4 = P.in_min[4], irng4 = P.in_rng[4];
+  const double omin = P.out_min[g], orng = P.out_rng[g];
+  const float a10 = P.a1[0][lane], a11 = P.a1[1][lane];
+  const float a20 = P.a2[0][lane], a21 = P.a2[1][lane], a22 = P.a2[2][lane];
+  const f32x4 c1 = {P.c1[g][0], P.c1[g][1], P.c1[g][2], P.c1[g][3]};
+  const f32x4 c2 = {P.c2[g], 0.f, 0.f, 0.f};
+  const long long ntiles = (ncells + 15) / 16;
+  for (long long t0 = wave * TILES; t0 < ntiles; t0 += nwaves * TILES) {
+    double xin[TILES], xin4[TILES];
+#pragma unroll
+    for (int u = 0; u < TILES; u++) {
+      long long cell = (t0 + u) * 16 + cidx;
+      bool ok = cell < ncells;
+      xin[u]  = ok ? in_g[cell] : imin;
+      xin4[u] = (ok && g == 0) ? rho_r[cell] : imin4;
+    }
+#pragma unroll
+    for (int u = 0; u < TILES; u++) {
+      long long cell = (t0 + u) * 16 + cidx;
+      float b0 = (float)((xin[u] - imin) / irng);                         // :182-186 (fp64 math, stored as float)
+      float b1 = (g == 0) ? (float)((xin4[u] - imin4) / irng4) : 0.f;
+      f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10, b0, c1, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11, b1, d1, 0, 0, 0);
+      float h0 = leaky(d1[0]), h1 = leaky(d1[1]), h2 = leaky(d1[2]);      // Relu(negative_slope = 0.1), :105
+      f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a20, h0, c2, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a21, h1, d2, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a22, h2, d2, 0, 0, 0);
+      double y = (double)d2[0] * orng + omin;                             // :198-201
+      if (g != 0) y = fmax(0.0, y);
+      if (cell < ncells) out_g[cell] = y;
+    }
+  }
+}
+
+} // namespace mw
+
+using namespace mw;
+
+extern "C" int mw_mlp_forward(long long ncells, const double *temp, const double *rho_d, const double *rho_v, const double *rho_c,
+                              const double *rho_r, const float *W1, const float *b1, const float *W2, const float *b2,
+                              const double *scl_in, const double *scl_out, double *temp_out, double *rho_v_out,
+                              double *rho_c_out, double *rho_r_out, void *stream) {
+  if (ncells < 1) MW_FAIL("mlp: ncells must be >= 1");
+  if (!temp || !rho_d || !rho_v || !rho_c || !rho_r || !W1 || !b1 || !W2 || !b2 || !scl_in || !scl_out || !temp_out ||
+      !rho_v_out || !rho_c_out || !rho_r_out) MW_FAIL("mlp: null pointer");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  MlpP P;          // operand images built per call (cheap: 104 weights)
+  memset(&P, 0, sizeof(P));
+  auto rho = [](int u) { return (u / 3) * 4 + (u % 3); };      // hidden unit u -> D1 row with row % 4 < 3
+  for (int lane = 0; lane < 64; lane++) {
+    int o = lane & 15, g = lane >> 4;
+    int u = -1;
+    for (int uu = 0; uu < 10; uu++) if (rho(uu) == o) u = uu;
+    for (int m = 0; m < 2; m++) { int in = 4 * m + g; P.a1[m][lane] = (u >= 0 && in < 5) ? W1[in * 10 + u] : 0.f; }
+    int n = (o % 4 == 0) ? o / 4 : -1;                          // output n lives at row 4n
+    for (int j = 0; j < 3; j++) {
+      int row = 4 * g + j, uk = -1;                             // k-slot g of MFMA j is hidden row 4g + j
+      for (int uu = 0; uu < 10; uu++) if (rho(uu) == row) uk = uu;
+      P.a2[j][lane] = (n >= 0 && uk >= 0) ? W2[uk * 4 + n] : 0.f;
+    }
+  }
+  for (int g = 0; g < 4; g++) {
+    for (int r = 0; r < 4; r++) { int row = 4 * g + r, u = -1; for (int uu = 0; uu < 10; uu++) if (rho(uu) == row) u = uu;
+                                  P.c1[g][r] = (u >= 0) ? b1[u] : 0.f; }
+    P.c2[g] = b2[g];
+  }
+  for (int i = 0; i < 5; i++) { P.in_min[i] = scl_in[i * 2 + 0]; P.in_rng[i] = scl_in[i * 2 + 1] - scl_in[i * 2 + 0]; }
+  for (int i = 0; i < 4; i++) { P.out_min[i] = scl_out[i * 2 + 0]; P.out_rng[i] = scl_out[i * 2 + 1] - scl_out[i * 2 + 0]; }
+  constexpr int TILES = 4;
+  long long ntiles = (ncells + 15) / 16;
+  long long waves_needed = (ntiles + TILES - 1) / TILES;
+  long long blocks = (waves_needed + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;                     // grid-stride beyond 16 blocks per CU
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_mlp<TILES>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, ncells, temp, rho_d, rho_v, rho_c,
+                     rho_r, temp_out, rho_v_out, rho_c_out, rho_r_out);
+  MW_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,313 @@
+"""Host-side mirror of the reference *modules* for the hot path (same class names, method names, argument
+meaning, error behaviour), each a thin driver of the C ABI in include/mw_cdna4.h:
+
+  Dynamics_Euler_Stratified_WenoFV   model/modules/dynamics_euler_stratified_wenofv.h:20-2196
+  Microphysics_Kessler               model/modules/microphysics_kessler.h:8-346
+  Microphysics_Kessler_Surrogate     experiments/supercell_kessler_surrogate/custom_modules/microphysics_kessler_ponni.h
+  perturb_temperature                model/modules/perturb_temperature.h:8-67
+
+No arithmetic happens in Python: everything runs in libmw_cdna4.so on the GPU (no fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import capi
+from .capi import MWError, check
+from .coupler import Coupler, endrun
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def _ptr(t):
+    if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise MWError("field tensors must be contiguous fp64 CUDA tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Dynamics_Euler_Stratified_WenoFV:
+    ord = 5
+    hs = 2
+    num_state = 5
+    idR, idU, idV, idW, idT = 0, 1, 2, 3, 4
+
+    def __init__(self):
+        self.h = C.c_void_p(None)
+        self.etime = 0.0
+        self._tracer_ptrs = None
+        self._fields = None
+
+    def __del__(self):
+        try:
+            if self.h and self.h.value:
+                capi.lib().mw_dycore_destroy(self.h)
+                self.h = C.c_void_p(None)
+        except Exception:
+            pass
+
+    # dynamics_euler_stratified_wenofv.h:70-77
+    def compute_time_step(self, coupler):
+        return capi.lib().mw_dycore_compute_time_step(C.byref(coupler.grid))
+
+    def _bind(self, coupler):
+        dm = coupler.get_data_manager_readwrite()
+        names = coupler.get_tracer_names()
+        self._fields = [dm.get(n) for n in ("density_dry", "uvel", "vvel", "wvel", "temp")]
+        self._tracers = [dm.get(n) for n in names]
+        arr = (C.c_void_p * max(1, len(names)))()
+        for i, t in enumerate(self._tracers):
+            arr[i] = _ptr(t).value
+        self._tracer_ptrs = arr
+
+    # dynamics_euler_stratified_wenofv.h:1197-1683
+    def init(self, coupler):
+        L = capi.lib()
+        g = coupler.grid
+        nz, ny, nx, nens = coupler.get_nz(), coupler.get_ny(), coupler.get_nx(), coupler.get_nens()
+        # physical constants only if absent (:1227-1249)
+        gc = capi.Grid()
+        check(L.mw_default_constants(C.byref(gc)))
+        for k in ("R_d", "cp_d", "R_v", "cp_v", "p0", "grav", "earthrot"):
+            if not coupler.option_exists(k):
+                coupler.set_option(k, getattr(gc, k))
+        R_d, cp_d, p0 = coupler.get_option("R_d"), coupler.get_option("cp_d"), coupler.get_option("p0")
+        if not coupler.option_exists("cv_d"): coupler.set_option("cv_d", cp_d - R_d)
+        if not coupler.option_exists("gamma_d"): coupler.set_option("gamma_d", cp_d / coupler.get_option("cv_d"))
+        if not coupler.option_exists("kappa_d"): coupler.set_option("kappa_d", R_d / cp_d)
+        if not coupler.option_exists("cv_v"): coupler.set_option("cv_v", coupler.get_option("R_v") - coupler.get_option("cp_v"))
+        if not coupler.option_exists("C0"):
+            coupler.set_option("C0", gc.C0 if (R_d, cp_d, p0) == (gc.R_d, gc.cp_d, gc.p0) else
+                               float(np.power(R_d * np.power(p0, -coupler.get_option("kappa_d")), coupler.get_option("gamma_d"))))
+        coupler.set_option("latitude", 0.0)
+        for k in ("R_d", "R_v", "cp_d", "cp_v", "p0", "grav", "gamma_d", "kappa_d", "C0", "earthrot", "latitude"):
+            setattr(g, k, float(coupler.get_option(k)))
+        dm = coupler.get_data_manager_readwrite()
+        for n in ("density_dry", "uvel", "vvel", "wvel", "temp"):            # :1253-1257
+            dm.register_and_allocate(n, "", (nz, ny, nx, nens))
+        names = coupler.get_tracer_names()
+        T = len(names)
+        if "water_vapor" not in names:
+            endrun("ERROR: a tracer named water_vapor must be registered before dycore.init (idWV, :1292)")
+        pos = bytes(int(coupler.get_tracer_info(n)[2]) for n in names)
+        adds = bytes(int(coupler.get_tracer_info(n)[3]) for n in names)
+        g.num_tracers = T
+        g.idWV = names.index("water_vapor")
+        coupler.set_option("idWV", g.idWV)                                     # :1300
+        dm.register_and_allocate("tracer_adds_mass", "", (T,), dtype=torch.bool)
+        dm.get("tracer_adds_mass").copy_(torch.tensor([b != 0 for b in adds]))
+        init_data = coupler.get_option("init_data")
+        self.out_freq = coupler.get_option("out_freq", -1.0)
+        if init_data not in capi.INIT_IDS:
+            endrun("ERROR: Invalid init_data in yaml input file")              # :1310
+        g.enable_gravity = int(bool(coupler.get_option("enable_gravity", True)))
+        g.bc_x, g.bc_y, g.bc_z, g.use_immersed = capi.BC_PERIODIC, capi.BC_PERIODIC, capi.BC_WALL, 0
+        with torch.cuda.device(coupler.device):
+            check(L.mw_dycore_create(C.byref(self.h), C.byref(g), pos, adds, _stream_ptr(coupler.device)))
+            self._bind(coupler)
+            check(L.mw_dycore_init(self.h, capi.INIT_IDS[init_data], *[_ptr(t) for t in self._fields], self._tracer_ptrs))
+        check(L.mw_dycore_get_grid(self.h, C.byref(g)))
+        coupler.set_option("use_immersed_boundaries", bool(g.use_immersed))    # :1312,1426,1554
+        coupler.add_option("bc_x", g.bc_x); coupler.add_option("bc_y", g.bc_y); coupler.add_option("bc_z", g.bc_z)
+        # fields the reference registers for other modules (:1313, :1663-1682) -- zero-copy views of the handle's memory
+        hy = [np.zeros((nz, nens)), np.zeros((nz, nens)), np.zeros((nz + 1, nens)), np.zeros((nz + 1, nens))]
+        check(L.mw_dycore_get_background(self.h, *[a.ctypes.data_as(C.POINTER(C.c_double)) for a in hy]))
+        self.hy_dens_cells, self.hy_dens_theta_cells, self.hy_dens_edges, self.hy_dens_theta_edges = hy
+        dm.register_and_allocate("hy_dens_cells", "hydrostatic density cell averages", (nz, nens)).copy_(torch.from_numpy(hy[0]))
+        dm.register_and_allocate("hy_dens_theta_cells", "hydrostatic density*theta cell averages", (nz, nens)).copy_(torch.from_numpy(hy[1]))
+        self.etime = 0.0
+        self.num_out = 0
+
+    def _wrap(self, ptr, shape):
+        """Zero-copy CUDA tensor over library-owned device memory."""
+        n = int(np.prod(shape))
+
+        class _Arr:
+            pass
+        a = _Arr()
+        a.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(int(ptr), False), version=2)
+        return torch.as_tensor(a, device="cuda").view(*shape)
+
+    def fluxes(self, coupler):
+        """state_flux_{x,y,z}, tracers_flux_{x,y,z} as the reference registers them (:1671-1676)."""
+        out = (C.c_void_p * 6)()
+        check(capi.lib().mw_dycore_get_fluxes(self.h, out))
+        nz, ny, nx, nens, T = coupler.get_nz(), coupler.get_ny(), coupler.get_nx(), coupler.get_nens(), coupler.get_num_tracers()
+        shp = [(5, nz, ny, nx + 1, nens), (5, nz, ny + 1, nx, nens), (5, nz + 1, ny, nx, nens),
+               (T, nz, ny, nx + 1, nens), (T, nz, ny + 1, nx, nens), (T, nz + 1, ny, nx, nens)]
+        names = ["state_flux_x", "state_flux_y", "state_flux_z", "tracers_flux_x", "tracers_flux_y", "tracers_flux_z"]
+        with torch.cuda.device(coupler.device):
+            return {n: self._wrap(out[i], shp[i]) for i, n in enumerate(names)}
+
+    def immersed_proportion(self, coupler):
+        p = capi.lib().mw_dycore_immersed_proportion(self.h)
+        with torch.cuda.device(coupler.device):
+            return self._wrap(p, (coupler.get_nz(), coupler.get_ny(), coupler.get_nx(), coupler.get_nens()))
+
+    # dynamics_euler_stratified_wenofv.h:81-198 (file output excluded)
+    def time_step(self, coupler, dt_phys):
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_dycore_time_step(self.h, *[_ptr(t) for t in self._fields], self._tracer_ptrs, float(dt_phys)))
+        self.etime += dt_phys
+
+    # one compute_tendencies(state(coupler), dt) (:204-552): returns (state_tend, tracers_tend); fluxes via .fluxes()
+    def compute_tendencies(self, coupler, dt):
+        nz, ny, nx, nens, T = coupler.get_nz(), coupler.get_ny(), coupler.get_nx(), coupler.get_nens(), coupler.get_num_tracers()
+        st = torch.zeros((5, nz, ny, nx, nens), dtype=torch.float64, device=coupler.device)
+        tt = torch.zeros((T, nz, ny, nx, nens), dtype=torch.float64, device=coupler.device)
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_dycore_compute_tendencies(self.h, *[_ptr(t) for t in self._fields], self._tracer_ptrs, float(dt),
+                                                          _ptr(st), _ptr(tt)))
+        return st, tt
+
+    def set_strict(self, strict):
+        check(capi.lib().mw_dycore_set_strict(self.h, int(strict)))
+
+    def set_bc(self, coupler, bc_x, bc_y, bc_z):
+        check(capi.lib().mw_dycore_set_bc(self.h, bc_x, bc_y, bc_z))
+        coupler.set_option("bc_x", bc_x); coupler.set_option("bc_y", bc_y); coupler.set_option("bc_z", bc_z)
+
+    def profile(self, enable):
+        check(capi.lib().mw_dycore_profile(self.h, int(enable)))
+
+    def profile_get(self, which):
+        ms, n = C.c_double(), C.c_longlong()
+        check(capi.lib().mw_dycore_profile_get(self.h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+class Microphysics_Kessler:
+    num_tracers = 3
+    ID_V, ID_C, ID_R = 0, 1, 2
+
+    def __init__(self):                                                        # microphysics_kessler.h:29-41
+        self.R_d, self.cp_d = 287., 1003.
+        self.cv_d = self.cp_d - self.R_d
+        self.gamma_d = self.cp_d / self.cv_d
+        self.kappa_d = self.R_d / self.cp_d
+        self.R_v, self.cp_v = 461., 1859.
+        self.cv_v = self.R_v - self.cp_v
+        self.p0, self.grav = 1.e5, 9.81
+        self._ws = None
+
+    @staticmethod
+    def get_num_tracers():
+        return 3
+
+    def micro_name(self):
+        return "kessler"
+
+    def init(self, coupler):                                                   # :51-96
+        coupler.add_tracer("water_vapor", "Water Vapor", True, True)
+        coupler.add_tracer("cloud_liquid", "Cloud liquid", True, True)
+        coupler.add_tracer("precip_liquid", "precip_liquid", True, True)
+        dm = coupler.get_data_manager_readwrite()
+        dm.register_and_allocate("precl", "precipitation rate", (coupler.get_ny(), coupler.get_nx(), coupler.get_nens()),
+                                 ["y", "x", "nens"])
+        coupler.set_option("micro", "kessler")
+        for k in ("R_d", "cp_d", "cv_d", "gamma_d", "kappa_d", "R_v", "cp_v", "cv_v", "p0", "grav"):
+            coupler.set_option(k, getattr(self, k))
+
+    def time_step(self, coupler, dt, return_rainsplit=False):                  # :99-162
+        dm = coupler.get_data_manager_readwrite()
+        rho_v, rho_c, rho_r = dm.get("water_vapor"), dm.get("cloud_liquid"), dm.get("precip_liquid")
+        rho_d, temp, precl = dm.get("density_dry", readonly=True), dm.get("temp"), dm.get("precl")
+        nz = coupler.get_nz()
+        ncol = coupler.get_ny() * coupler.get_nx() * coupler.get_nens()
+        L = capi.lib()
+        nbytes = L.mw_kessler_workspace_bytes(nz, ncol)
+        if self._ws is None or self._ws.numel() * 8 < nbytes:
+            self._ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=coupler.device)
+        rs = C.c_int(0)
+        with torch.cuda.device(coupler.device):
+            check(L.mw_kessler_time_step(nz, ncol, coupler.get_dz(), float(dt), _ptr(rho_v), _ptr(rho_c), _ptr(rho_r), _ptr(rho_d),
+                                         _ptr(temp), _ptr(precl), _ptr(self._ws), C.byref(rs) if return_rainsplit else None,
+                                         _stream_ptr(coupler.device)))
+        return rs.value if return_rainsplit else None
+
+
+def load_surrogate_weights(weights_txt=None, in_scaling_txt=None, out_scaling_txt=None):
+    """The shipped Keras weights (exported to text by tools/export_mlp_weights.sh) + min/max scaling tables
+    (microphysics_kessler_ponni.h:97-135)."""
+    w = np.loadtxt(weights_txt or os.path.join(_DATA, "kessler_surrogate_weights.txt"), dtype=np.float64, comments="#").astype(np.float32)
+    if w.size != 104:
+        endrun("surrogate weight file must hold 104 values")
+    W1, b1, W2, b2 = w[:50].reshape(5, 10).copy(), w[50:60].copy(), w[60:100].reshape(10, 4).copy(), w[100:104].copy()
+    scl_in = np.loadtxt(in_scaling_txt or os.path.join(_DATA, "kessler_surrogate_input_scaling.txt")).reshape(5, 2)
+    scl_out = np.loadtxt(out_scaling_txt or os.path.join(_DATA, "kessler_surrogate_output_scaling.txt")).reshape(4, 2)
+    return W1, b1, W2, b2, np.ascontiguousarray(scl_in), np.ascontiguousarray(scl_out)
+
+
+def mlp_forward(temp, rho_d, rho_v, rho_c, rho_r, W1, b1, W2, b2, scl_in, scl_out, outs=None):
+    """model.forward_batch_parallel with the fused scaling (microphysics_kessler_ponni.h:176-202)."""
+    fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    if outs is None:
+        outs = [torch.empty_like(temp) for _ in range(4)]
+    with torch.cuda.device(temp.device):
+        check(capi.lib().mw_mlp_forward(temp.numel(), _ptr(temp), _ptr(rho_d), _ptr(rho_v), _ptr(rho_c), _ptr(rho_r),
+                                        W1.ctypes.data_as(fp), b1.ctypes.data_as(fp), W2.ctypes.data_as(fp), b2.ctypes.data_as(fp),
+                                        scl_in.ctypes.data_as(dp), scl_out.ctypes.data_as(dp), *[_ptr(o) for o in outs],
+                                        _stream_ptr(temp.device)))
+    return outs
+
+
+class Microphysics_Kessler_Surrogate(Microphysics_Kessler):
+    """custom_modules::Microphysics_Kessler of the surrogate experiment: NN inference beside the true Kessler
+    (microphysics_kessler_ponni.h:149-278).  The NN result is returned (and diffed) but not written back,
+    exactly like the reference with lines :273-276 commented out."""
+
+    def init(self, coupler, weights_txt=None, in_scaling_txt=None, out_scaling_txt=None):
+        super().init(coupler)
+        self.W1, self.b1, self.W2, self.b2, self.scl_in, self.scl_out = load_surrogate_weights(weights_txt, in_scaling_txt,
+                                                                                              out_scaling_txt)
+        self._nn_out = None
+
+    def time_step(self, coupler, dt):
+        dm = coupler.get_data_manager_readwrite()
+        temp, rho_d = dm.get("temp"), dm.get("density_dry", readonly=True)
+        rho_v, rho_c, rho_r = dm.get("water_vapor"), dm.get("cloud_liquid"), dm.get("precip_liquid")
+        self._nn_out = mlp_forward(temp, rho_d, rho_v, rho_c, rho_r, self.W1, self.b1, self.W2, self.b2, self.scl_in, self.scl_out,
+                                   self._nn_out)
+        super().time_step(coupler, dt)
+        return self._nn_out            # (temp_tmp, rho_v_tmp, rho_c_tmp, rho_r_tmp)
+
+    def mean_diffs(self, coupler):
+        """The four 'Relative diff' prints (:266-269): mean(NN - Kessler)."""
+        dm = coupler.get_data_manager_readonly()
+        t, v, c, r = self._nn_out
+        return dict(rho_v=float((v - dm.get("water_vapor", True)).mean()), rho_c=float((c - dm.get("cloud_liquid", True)).mean()),
+                    rho_r=float((r - dm.get("precip_liquid", True)).mean()), temp=float((t - dm.get("temp", True)).mean()))
+
+
+def perturb_temperature(coupler, thermal=True, random=False):                   # perturb_temperature.h:8-67
+    if random:
+        endrun("perturb_temperature(random=true) needs yakl::Random and is not on the hot path")
+    if thermal:
+        temp = coupler.get_data_manager_readwrite().get("temp")
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_perturb_temperature(C.byref(coupler.grid), _ptr(temp), _stream_ptr(coupler.device)))
+
+
+def make_supercell(nx_glob, ny_glob, nz, nens=1, xlen=1.0e5, ylen=1.0e5, zlen=2.0e4, init_data="supercell", device="cuda:0",
+                   nranks=1, myrank=0, micro=None, enable_gravity=None, perturb=True):
+    """The set-up sequence of experiments/supercell_example/driver.cpp:41-61 (column nudger excluded)."""
+    coupler = Coupler(device)
+    coupler.set_option("out_prefix", "test")
+    coupler.set_option("init_data", init_data)
+    coupler.set_option("out_freq", -1.0)
+    if enable_gravity is not None:
+        coupler.set_option("enable_gravity", bool(enable_gravity))
+    coupler.distribute_mpi_and_allocate_coupled_state(nz, ny_glob, nx_glob, nens, nranks, myrank)
+    coupler.set_grid(xlen, ylen, zlen)
+    micro = micro or Microphysics_Kessler()
+    dycore = Dynamics_Euler_Stratified_WenoFV()
+    micro.init(coupler)
+    dycore.init(coupler)
+    if perturb:
+        perturb_temperature(coupler)
+    return coupler, dycore, micro
