@@ -41,7 +41,9 @@ struct DyP {                      // kernel parameter block (by value)
   unsigned pos_mask, mass_mask;
   double dx, dy, dz, C0, gamma, grav, fcor, R_d, R_v;
   const double *hyc, *hytc, *hye, *hyte;       // device (nz,nens) / (nz+1,nens)
+  const double *p0c, *p0e, *ihytc, *ihyte;     // C0*hyt^gamma and 1/hyt at cells / edges (fast pressure path)
   const double *imm;                           // device (nz,ny,nx,nens)
+  double bn[17];                               // binomial series coefficients C(gamma, n), n = 0..16
 };
 
 struct CouplerPtrs {
@@ -53,6 +55,23 @@ struct CouplerPtrs {
 // pow(x, gamma): strict = device libm pow; fast = same for now (kept separate so it can be specialised)
 // -----------------------------------------------------------------------------------------------------
 template <bool STRICT> __device__ __forceinline__ double pow_gamma(double x, double g) { return pow(x, g); }
+
+// p = C0 (hyt + e)^gamma for the fast path.  The Riemann solver needs two of these per face (6 per cell and stage,
+// :401,:426,:457); the device-libm pow costs ~230 fp64-VALU instructions.  Writing (hyt + e)^gamma =
+// hyt^gamma (1 + delta)^gamma with delta = e/hyt (|delta| is a few per cent: e is the reconstructed PERTURBATION of
+// rho*theta) turns it into p0(k) * sum_n C(gamma,n) delta^n: 16 FMAs, error < 1 ulp for |delta| <= 0.1.
+// Larger perturbations take the generic pow (per-lane branch).
+__device__ __forceinline__ double pressure_fast(const DyP &p, double e, double hyt, double p0, double ihyt) {
+#pragma clang fp contract(fast)
+  double dl = e * ihyt;
+  if (fabs(dl) <= 0.1) {
+    double acc = p.bn[16];
+#pragma unroll
+    for (int n = 15; n >= 1; n--) acc = acc * dl + p.bn[n];
+    return p0 + p0 * (acc * dl);
+  }
+  return p.C0 * pow(hyt + e, p.gamma);
+}
 
 // -----------------------------------------------------------------------------------------------------
 // D1  convert_coupler_to_dynamics (:1955-2015) fused with the stage-1 divide D2 (:248-255)
@@ -224,15 +243,16 @@ __device__ __forceinline__ double edge_value(const double *__restrict__ q, long 
 
 template <bool STRICT>
 __device__ __forceinline__ void face_flux(const DyP &p, const double *__restrict__ cL, int eL, const double *__restrict__ cR,
-                                          int eR, long long st, int nrm, double hyr, double hyt, bool zero_nrm,
-                                          double *__restrict__ f, long long fV) {
+                                          int eR, long long st, int nrm, double hyr, double hyt, double p0, double ihyt,
+                                          bool zero_nrm, double *__restrict__ f, long long fV) {
   const double cs = 350;
   double rL = edge_value<STRICT>(cL + idR * p.sV, st, eL) + hyr;
   double rR = edge_value<STRICT>(cR + idR * p.sV, st, eR) + hyr;
   double uL = edge_value<STRICT>(cL + nrm * p.sV, st, eL);
   double uR = edge_value<STRICT>(cR + nrm * p.sV, st, eR);
-  double tL = edge_value<STRICT>(cL + idT * p.sV, st, eL) + hyt;
-  double tR = edge_value<STRICT>(cR + idT * p.sV, st, eR) + hyt;
+  double eTL = edge_value<STRICT>(cL + idT * p.sV, st, eL), eTR = edge_value<STRICT>(cR + idT * p.sV, st, eR);
+  double tL = eTL + hyt;
+  double tR = eTR + hyt;
   if (STRICT) {
 #pragma clang fp contract(off)
     double mL = zero_nrm ? 0.0 : uL * rL;
@@ -257,7 +277,7 @@ __device__ __forceinline__ void face_flux(const DyP &p, const double *__restrict
 #pragma clang fp contract(fast)
     double mL = zero_nrm ? 0.0 : uL * rL;
     double mR = zero_nrm ? 0.0 : uR * rR;
-    double p_L = p.C0 * pow_gamma<false>(tL, p.gamma), p_R = p.C0 * pow_gamma<false>(tR, p.gamma);
+    double p_L = pressure_fast(p, eTL, hyt, p0, ihyt), p_R = pressure_fast(p, eTR, hyt, p0, ihyt);
     double w1 = 0.5 * (p_R - cs * mR);
     double w2 = 0.5 * (p_L + cs * mL);
     double p_upw = w1 + w2;
@@ -299,7 +319,7 @@ __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ 
       }
     }
     double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
-    face_flux<STRICT>(p, cL, eL, cR, eR, p.nens, idU, hyr, hyt, zero,
+    face_flux<STRICT>(p, cL, eL, cR, eR, p.nens, idU, hyr, hyt, p.p0c[k * p.nens + e], p.ihytc[k * p.nens + e], zero,
                       FX + (long long)k * p.fxK + (long long)j * p.fxJ + ie, p.fxV);
   }
   // ---------------- Y face j-1/2
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ 
       }
     }
     double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
-    face_flux<STRICT>(p, cL, eL, cR, eR, p.sJ, idV, hyr, hyt, zero,
+    face_flux<STRICT>(p, cL, eL, cR, eR, p.sJ, idV, hyr, hyt, p.p0c[k * p.nens + e], p.ihytc[k * p.nens + e], zero,
                       FY + (long long)k * p.fyK + (long long)j * p.fyJ + ie, p.fyV);
   }
   // ---------------- Z face k-1/2 : wall / open edge-value rule at k = 0 and k = nz  (:1020-1038)
@@ -323,7 +343,7 @@ __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ 
     if (k == 0)    { cL = cR; eL = eR; zero = (p.bc_z == MW_BC_WALL); }
     if (k == p.nz) { cR = cL; eR = eL; zero = (p.bc_z == MW_BC_WALL); }
     double hyr = p.hye[k * p.nens + e], hyt = p.hyte[k * p.nens + e];      // edges for z (:368-377)
-    face_flux<STRICT>(p, cL, eL, cR, eR, p.sK, idW, hyr, hyt, zero,
+    face_flux<STRICT>(p, cL, eL, cR, eR, p.sK, idW, hyr, hyt, p.p0e[k * p.nens + e], p.ihyte[k * p.nens + e], zero,
                       FZ + (long long)k * p.fzK + (long long)j * p.fzJ + (long long)i * p.nens + e, p.fzV);
   }
 }
@@ -661,9 +681,9 @@ struct mw_dycore_s {
   DyP p;
   double *S0 = nullptr, *S1 = nullptr;
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
-  double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte
+  double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte
   double *imm = nullptr;
-  std::vector<double> hy_host;               // same packing
+  std::vector<double> hy_host;               // same packing (the last four are derived in upload_background)
   double etime = 0;
   int strict = 0;
   // halo exchange
@@ -701,10 +721,24 @@ static void fill_params(mw_dycore_s *d) {
   p.fcor = 2 * g.earthrot * sin(g.latitude);                                           // :213
   size_t nzc = (size_t)g.nz * g.nens, nze = (size_t)(g.nz + 1) * g.nens;
   p.hyc = d->hy_dev; p.hytc = d->hy_dev + nzc; p.hye = d->hy_dev + 2 * nzc; p.hyte = d->hy_dev + 2 * nzc + nze;
+  const double *ext = d->hy_dev + 2 * nzc + 2 * nze;
+  p.p0c = ext; p.ihytc = ext + nzc; p.p0e = ext + 2 * nzc; p.ihyte = ext + 2 * nzc + nze;
   p.imm = d->imm;
+  long double bn = 1.0L;                                    // C(gamma, n) = C(gamma, n-1) (gamma - n + 1) / n
+  p.bn[0] = 1.0;
+  for (int n = 1; n <= 16; n++) { bn = bn * ((long double)g.gamma_d - (n - 1)) / n; p.bn[n] = (double)bn; }
 }
 
 static int upload_background(mw_dycore_s *d) {
+  {  // derived tables of the fast pressure path: p0 = C0 hyt^gamma, 1/hyt (cells and edges)
+    const mw_grid_t &g = d->g;
+    size_t nzc = (size_t)g.nz * g.nens, nze = (size_t)(g.nz + 1) * g.nens;
+    double *h = d->hy_host.data();
+    const double *hytc = h + nzc, *hyte = h + 2 * nzc + nze;
+    double *ext = h + 2 * nzc + 2 * nze;
+    for (size_t n = 0; n < nzc; n++) { ext[n] = g.C0 * pow(hytc[n], g.gamma_d); ext[nzc + n] = 1.0 / hytc[n]; }
+    for (size_t n = 0; n < nze; n++) { ext[2 * nzc + n] = g.C0 * pow(hyte[n], g.gamma_d); ext[2 * nzc + nze + n] = 1.0 / hyte[n]; }
+  }
   MW_HIP(hipMemcpyAsync(d->hy_dev, d->hy_host.data(), d->hy_host.size() * sizeof(double), hipMemcpyHostToDevice, d->stream));
   MW_HIP(hipStreamSynchronize(d->stream));
   return 0;
@@ -826,7 +860,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
   const char *s = getenv("MW_STRICT");
   d->strict = (s && s[0] == '1');
   size_t nzc = (size_t)g->nz * g->nens, nze = (size_t)(g->nz + 1) * g->nens;
-  d->hy_host.assign(2 * nzc + 2 * nze, 0.0);
+  d->hy_host.assign(4 * nzc + 4 * nze, 0.0);
   auto fail = [&](void) { mw_dycore_destroy(d); return 1; };
   if (hipMalloc(&d->hy_dev, d->hy_host.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(hy) failed"); return fail(); }
   fill_params(d);

@@ -78,59 +78,53 @@ __device__ __forceinline__ void weno5_edges_strict(double s0, double s1, double 
 __device__ __forceinline__ void weno5_edges_fast(double s0, double s1, double s2, double s3, double s4,
                                                   double &left, double &right) {
 #pragma clang fp contract(fast)
-  // second differences are shared by the three quadratic fits (L2, C2, R2) and feed H2/H4
-  const double d01 = s1 - s0, d12 = s2 - s1, d23 = s3 - s2, d34 = s4 - s3;
-  const double L2 = 0.5*(d12 - d01);            // 0.5 s0 - s1 + 0.5 s2
-  const double C2 = 0.5*(d23 - d12);
-  const double R2 = 0.5*(d34 - d23);
-  const double L1 = d12 + L2;                   // 0.5 s0 - 2 s1 + 1.5 s2  = (s2-s1) + L2
-  const double C1 = 0.5*(s3 - s1);
-  const double R1 = d23 - R2;                   // -1.5 s2 + 2 s3 - 0.5 s4 = (s3-s2) - R2
-  const double k24 = 0.041666666666666666666666666666666666667;   // 1/24
-  const double L0 = s2 - k24*(2.0*L2);          // -1/24 s0 + 1/12 s1 + 23/24 s2 = s2 - (1/12) L2
-  const double C0 = s2 - k24*(2.0*C2);
-  const double R0 = s2 - k24*(2.0*R2);
-  // quartic fit
-  const double H4 = (2.0*k24)*((L2 + R2) - 2.0*C2);   // 1/24 (s0 - 4 s1 + 6 s2 - 4 s3 + s4) = 1/12 (L2 + R2 - 2 C2)
-  const double H3 = 0.083333333333333333333333333333333333333*((s4 - s0) - 2.0*(s3 - s1));
-  const double H2x = -0.0625*(s0 + s4) + 0.75*(s1 + s3) - 1.375*s2;
-  const double H1 = 0.10416666666666666666666666666666666667*(s0 - s4) + 0.70833333333333333333333333333333333333*(s3 - s1);
-  const double H0 = 0.0046875*(s0 + s4) - 0.060416666666666666666666666666666666667*(s1 + s3) + 1.1114583333333333333333333333333333333*s2;
-  const double k133 = 4.3333333333333333333333333333333333333;
-  double tL = L1*L1 + k133*(L2*L2);
-  double tC = C1*C1 + k133*(C2*C2);
-  double tR = R1*R1 + k133*(R2*R2);
-  double tH = H1*H1 + k133*(H2x*H2x) + 0.5*H1*H3 + 39.1125*(H3*H3) + 4.2*H2x*H4 + 625.83571428571428571428571428571428571*(H4*H4);
-  // convexify #1: t_i / S  (skipped when S <= 1e-20, as the reference does)
+  // First differences; everything else is built from them.  Names with a trailing 'p' are the reference's
+  // coefficients times a power-of-two / small-integer factor that is folded into the constants further down.
+  const double a = s1 - s0, b = s2 - s1, c = s3 - s2, d = s4 - s3;
+  const double L2p = b - a, C2p = c - b, R2p = d - c;       // 2*coefs3_shift{1,2,3}(2)
+  const double C1p = b + c;                                 // 2*coefs3_shift2(1) = s3 - s1
+  const double L1 = b + 0.5*L2p;                            // coefs3_shift1(1) =  0.5 s0 - 2 s1 + 1.5 s2
+  const double R1 = c - 0.5*R2p;                            // coefs3_shift3(1) = -1.5 s2 + 2 s3 - 0.5 s4
+  const double k24 = 0.041666666666666666666666666666666666667;    // 1/24
+  const double L0 = s2 - k24*L2p, C0 = s2 - k24*C2p, R0 = s2 - k24*R2p;     // coefs3_shift*(0): cell mean preserved
+  const double e = s4 - s0;
+  const double sLR = L2p + R2p;
+  const double H4p = sLR - 2.0*C2p;                         // 24*coefs5_shift3(4)
+  const double H3p = e - 2.0*C1p;                           // 12*coefs5_shift3(3)
+  const double H2p = 10.0*C2p - sLR;                        // 16*coefs5_shift3(2)
+  const double H1 = 0.70833333333333333333333333333333333333*C1p - 0.10416666666666666666666666666666666667*e;  // coefs5_shift3(1)
+  const double H0 = s2 - (1.0/192.0)*H2p - (1.0/1920.0)*H4p;                 // s2 - H2/12 - H4/80
+  // TV (WenoLimiter_recon.h:37-56) with the scale factors folded into the constants
+  const double k1312 = 1.0833333333333333333333333333333333333;             // (13/3)/4
+  const double tL = L1*L1 + k1312*(L2p*L2p);
+  const double tC = 0.25*(C1p*C1p) + k1312*(C2p*C2p);
+  const double tR = R1*R1 + k1312*(R2p*R2p);
+  const double tH = H1*(H1 + (0.5/12.0)*H3p) + H2p*((4.3333333333333333333333333333333333333/256.0)*H2p + (4.2/384.0)*H4p)
+                  + (39.1125/144.0)*(H3p*H3p) + (625.83571428571428571428571428571428571/576.0)*(H4p*H4p);
+  // convexify #1 divides every t by S = sum(t) (when S > 1e-20); then w_i = idl_i / (t_i^2 + 1e-20).  Scaling all
+  // four denominators by S^2 leaves the normalised weights unchanged:  d_i = t_i^2 + 1e-20 S^2   (no division).
   const double S = (tL + tC) + (tR + tH);
-  const double rS = (S > 1.e-20) ? __builtin_amdgcn_rcp(S) : 1.0;
-  // two Newton steps bring v_rcp_f64 to full fp64 accuracy
-  double rS1 = rS;
-  if (S > 1.e-20) { rS1 = rS + rS*(1.0 - S*rS); rS1 = rS1 + rS1*(1.0 - S*rS1); }
-  tL *= rS1; tC *= rS1; tR *= rS1; tH *= rS1;
-  // w_i = idl_i / (t_i^2 + eps), then normalised: the common 1/prod(d) cancels ->
-  //   w_i  ~  idl_i * prod_{j != i} d_j        (d in [1e-20, 1]: no under/overflow in fp64)
-  const double dL = tL*tL + 1.e-20, dC = tC*tC + 1.e-20, dR = tR*tR + 1.e-20, dH = tH*tH + 1.e-20;
+  const double eS = (S > 1.e-20) ? (1.e-20*S)*S : 1.e-20;
+  const double dL = tL*tL + eS, dC = tC*tC + eS, dR = tR*tR + eS, dH = tH*tH + eS;
+  // normalised w_i = (idl_i / d_i) / sum_j (idl_j / d_j)  =  idl_i prod_{j != i} d_j / N   (idl = 1,2,1,1000; /1004 cancels)
   const double dLC = dL*dC, dRH = dR*dH;
-  double nL = dC*dRH;            // idl_L = 1/1004 ; the common 1/1004 cancels in the normalisation
-  double nC = 2.0*(dL*dRH);
-  double nR = dLC*dH;
-  double nH = 1.e3*(dLC*dR);
+  const double nL = dC*dRH;
+  const double nC = (dL + dL)*dRH;
+  const double nR = dLC*dH;
+  const double nH = (1.e3*dLC)*dR;
   const double N = (nL + nC) + (nR + nH);
-  double rN = __builtin_amdgcn_rcp(N);
+  double rN = __builtin_amdgcn_rcp(N);           // v_rcp_f64 + two Newton steps = full fp64 accuracy
   rN = rN + rN*(1.0 - N*rN);
   rN = rN + rN*(1.0 - N*rN);
-  const double wL = nL*rN, wC = nC*rN, wR = nR*rN, wH = nH*rN;
-  // (third convexify: weights already sum to 1 within rounding)
-  const double c0 = H0*wH + L0*wL + C0*wC + R0*wR;
-  const double c1 = H1*wH + L1*wL + C1*wC + R1*wR;
-  const double c2 = H2x*wH + L2*wL + C2*wC + R2*wR;
-  const double c3 = H3*wH;
-  const double c4 = H4*wH;
-  const double ev = c0 + 0.25*c2 + 0.0625*c4;     // even part
-  const double od = 0.5*c1 + 0.125*c3;            // odd part
-  left  = ev - od;
-  right = ev + od;
+  // (the reference's 2nd/3rd convexify only re-normalise weights that already sum to 1)
+  // limited coefficients (un-normalised) evaluated at -1/2 and +1/2:  even part c0 + c2/4 + c4/16, odd part c1/2 + c3/8
+  const double c0 = H0*nH + L0*nL + C0*nC + R0*nR;
+  const double c1 = H1*nH + L1*nL + (0.5*C1p)*nC + R1*nR;
+  const double c2h = (0.125)*(H2p*nH) + L2p*nL + C2p*nC + R2p*nR;          // 2*c2   (H2 = H2p/16 -> 2*H2 = H2p/8)
+  const double ev = c0 + 0.125*c2h + (0.0625/24.0)*(H4p*nH);
+  const double od = 0.5*c1 + (0.125/12.0)*(H3p*nH);
+  left  = (ev - od)*rN;
+  right = (ev + od)*rN;
 }
 
 } // namespace mw
