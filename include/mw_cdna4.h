@@ -90,8 +90,10 @@ double *mw_dycore_immersed_proportion(mw_dycore_t h);
 int  mw_dycore_get_grid(mw_dycore_t h, mw_grid_t *g);
 /* coupler options "bc_x","bc_y","bc_z" (read at :588-590, :846-848); mw_dycore_init sets them like :1332-1334. */
 int  mw_dycore_set_bc(mw_dycore_t h, int bc_x, int bc_y, int bc_z);
-/* strict = 1: flux stencil in the reference's exact operation order with FMA contraction off (diagnostic /
- * parity proof; also selected by env MW_STRICT=1 at create).  strict = 0 (default): re-associated fast path. */
+/* Kernel path.  0 (default): production path (shared reconstruction, marching kernels, state fluxes never
+ * materialised; re-associated WENO and series pressure).  1: "strict": the general flux-materialising kernels in the
+ * reference's exact operation order with FMA contraction off (diagnostic / parity proof; also env MW_STRICT=1 at
+ * create).  2: the general flux-materialising kernels with the fast arithmetic (A/B of the two kernel structures). */
 int  mw_dycore_set_strict(mw_dycore_t h, int strict);
 
 /* Dynamics_Euler_Stratified_WenoFV::time_step(coupler, dt_phys), :81-198: convert-in, ncycles x SSPRK3,

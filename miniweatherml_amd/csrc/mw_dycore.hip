@@ -504,6 +504,10 @@ __global__ __launch_bounds__(256) void k_state_to_coupler(DyP p, const double *_
   c.temp[ci] = press / (rho_d * p.R_d + rho_v * p.R_v);
 }
 
+} // namespace mw
+#include "mw_march.h"
+namespace mw {
+
 // -----------------------------------------------------------------------------------------------------
 // Initial data (input construction, :1197-1683, :1687-1887).  Column profiles are built on the host
 // (mw_init.cpp part below); the per-cell quadrature + convert_dynamics_to_coupler (:1656) runs here.
@@ -679,8 +683,11 @@ struct mw_dycore_s {
   unsigned char pos[MW_MAX_TRACERS], adds[MW_MAX_TRACERS];
   hipStream_t stream;
   DyP p;
-  double *S0 = nullptr, *S1 = nullptr;
+  double *S0 = nullptr, *S1 = nullptr, *S2 = nullptr;   // q^n and two stage slabs (rotated, never aliased in a launch)
+  double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
+  const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
+  int chunk_y = 0, chunk_z = 0;
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte
   double *imm = nullptr;
   std::vector<double> hy_host;               // same packing (the last four are derived in upload_background)
@@ -798,7 +805,7 @@ static int launch_flux(mw_dycore_s *d, const double *S) {
   const DyP &p = d->p;
   long long per_plane = (long long)(p.sim2d ? p.ny : p.ny + 1) * (p.nx + 1) * p.nens;
   dim3 grid = plane_grid(per_plane, p.nz + 1);
-  if (d->strict) hipLaunchKernelGGL(k_flux<true>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+  if (d->strict == 1) hipLaunchKernelGGL(k_flux<true>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
   else           hipLaunchKernelGGL(k_flux<false>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
   MW_LAUNCH_CHECK();
   return 0;
@@ -823,6 +830,83 @@ static int launch_update(mw_dycore_s *d, const double *Sstar, const double *Sn, 
   hipLaunchKernelGGL((k_update<STAGE, MODE>), grid, dim3(256), 0, d->stream, p, Sstar, Sn, Sout, d->FX, d->FY, d->FZ, dt_stage,
                      dt_dyn, c, st, tt);
   MW_LAUNCH_CHECK();
+  return 0;
+}
+
+static int pick_chunk(int n, long long base_waves, const char *env) {
+  const char *s = getenv(env);
+  if (s && atoi(s) > 0) return std::min(n, atoi(s));
+  const int cand[] = {32, 25, 20, 16, 12, 8};
+  for (int c : cand) if (base_waves * ((n + c - 1) / c) >= 6000) return std::min(n, c);
+  return std::min(n, 8);
+}
+
+template <int V>
+static int launch_pass_y(mw_dycore_s *d, const double *S) {
+  const DyP &p = d->p;
+  if (p.sim2d) return 0;
+  ProfScope ps(d, 0);
+  long long threads = (long long)p.nz * p.nx * p.nens;
+  int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = pick_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y"));
+  dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
+  hipLaunchKernelGGL((k_pass_y<V>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int V, int STAGE>
+static int launch_pass_xz(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn) {
+  const DyP &p = d->p;
+  ProfScope ps(d, 0);
+  int U = 64 - 6 * p.nens;
+  if (U < 1) MW_FAIL("nens too large for the 64-lane x tiling (need nens <= 10)");
+  int tiles_x = (p.nx * p.nens + U - 1) / U;
+  long long waves = (long long)p.ny * tiles_x;
+  int chunk = d->chunk_z ? d->chunk_z : (d->chunk_z = pick_chunk(p.nz, waves, "MW_CHUNK_Z"));
+  dim3 grid((unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
+  if (p.nens == 1) hipLaunchKernelGGL((k_pass_xz<V, STAGE, true>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->FX, d->FZ, d->tendY,
+                                      dt_stage, dt_dyn, chunk, tiles_x);
+  else             hipLaunchKernelGGL((k_pass_xz<V, STAGE, false>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->FX, d->FZ, d->tendY,
+                                      dt_stage, dt_dyn, chunk, tiles_x);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int STAGE, int MODE>
+static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const double *Sn, double *Sout, double dt_dyn, const CouplerPtrs &c) {
+  ProfScope ps(d, 2);
+  const DyP &p = d->p;
+  dim3 grid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
+  hipLaunchKernelGGL((k_tracer_update<STAGE, MODE>), grid, dim3(256), 0, d->stream, p, Sstar, Sn, Sout, d->FX, d->FY, d->FZ, dt_dyn, c);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+// One SSPRK3 sub-cycle on the production path (shared reconstruction, state fluxes never materialised).
+// Slabs: P = q^n, A, B scratch; on return the new q^n is in A (caller swaps).
+template <int V>
+static int rk_cycle_march(mw_dycore_s *d, double *P, double *A, double *B, double dt_dyn, bool last, const CouplerPtrs &c) {
+  const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
+  // stage 1 (:119-132)
+  if (halo_fill(d, P)) return 1;
+  if (launch_pass_y<V>(d, P)) return 1;
+  if (launch_pass_xz<V, 1>(d, P, P, A, dt_dyn, dt_dyn)) return 1;
+  if (launch_fct(d, P, dt_dyn)) return 1;
+  if (launch_tracer_update<1, 0>(d, P, P, A, dt_dyn, c)) return 1;
+  // stage 2 (:136-153)
+  if (halo_fill(d, A)) return 1;
+  if (launch_pass_y<V>(d, A)) return 1;
+  if (launch_pass_xz<V, 2>(d, A, P, B, dt2, dt_dyn)) return 1;
+  if (launch_fct(d, A, dt2)) return 1;
+  if (launch_tracer_update<2, 0>(d, A, P, B, dt_dyn, c)) return 1;
+  // stage 3 (:157-174)
+  if (halo_fill(d, B)) return 1;
+  if (launch_pass_y<V>(d, B)) return 1;
+  if (launch_pass_xz<V, 3>(d, B, P, A, dt3, dt_dyn)) return 1;
+  if (launch_fct(d, B, dt3)) return 1;
+  if (last) { if (launch_tracer_update<3, 1>(d, B, P, A, dt_dyn, c)) return 1; }      // + convert_dynamics_to_coupler (:178)
+  else      { if (launch_tracer_update<3, 0>(d, B, P, A, dt_dyn, c)) return 1; }
+  d->flux_src = B; d->flux_dt = dt3;
   return 0;
 }
 
@@ -867,11 +951,13 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
   const DyP &p = d->p;
   size_t slab = (size_t)p.V * p.sV * sizeof(double);
   size_t fxb = (size_t)p.V * p.fxV * sizeof(double), fyb = (size_t)p.V * p.fyV * sizeof(double), fzb = (size_t)p.V * p.fzV * sizeof(double);
-  if (hipMalloc(&d->S0, slab) != hipSuccess || hipMalloc(&d->S1, slab) != hipSuccess || hipMalloc(&d->FX, fxb) != hipSuccess ||
+  if (hipMalloc(&d->S0, slab) != hipSuccess || hipMalloc(&d->S1, slab) != hipSuccess || hipMalloc(&d->S2, slab) != hipSuccess ||
+      hipMalloc(&d->tendY, (size_t)5 * p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->FX, fxb) != hipSuccess ||
       hipMalloc(&d->FY, fyb) != hipSuccess || hipMalloc(&d->FZ, fzb) != hipSuccess ||
       hipMalloc(&d->imm, (size_t)p.nC * sizeof(double)) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return fail(); }
   // zero everything once: halo corners are never written and the flux arrays start at 0 (:1677-1682)
   (void)hipMemsetAsync(d->S0, 0, slab, d->stream); (void)hipMemsetAsync(d->S1, 0, slab, d->stream);
+  (void)hipMemsetAsync(d->S2, 0, slab, d->stream); (void)hipMemsetAsync(d->tendY, 0, (size_t)5 * p.nC * sizeof(double), d->stream);
   (void)hipMemsetAsync(d->FX, 0, fxb, d->stream); (void)hipMemsetAsync(d->FY, 0, fyb, d->stream); (void)hipMemsetAsync(d->FZ, 0, fzb, d->stream);
   (void)hipMemsetAsync(d->imm, 0, (size_t)p.nC * sizeof(double), d->stream);
   d->nWE = (long long)p.V * p.nz * p.ny * p.HX * p.nens;
@@ -885,7 +971,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
 void mw_dycore_destroy(mw_dycore_t d) {
   if (!d) return;
   (void)hipStreamSynchronize(d->stream);
-  for (double *ptr : {d->S0, d->S1, d->FX, d->FY, d->FZ, d->hy_dev, d->imm}) if (ptr) (void)hipFree(ptr);
+  for (double *ptr : {d->S0, d->S1, d->S2, d->tendY, d->FX, d->FY, d->FZ, d->hy_dev, d->imm}) if (ptr) (void)hipFree(ptr);
   for (int b = 0; b < 8; b++) if (d->bufs[b]) (void)hipFree(d->bufs[b]);
   for (int w = 0; w < 5; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete d;
@@ -928,6 +1014,11 @@ int mw_dycore_get_background(mw_dycore_t d, double *hyc, double *hytc, double *h
 
 int mw_dycore_get_fluxes(mw_dycore_t d, double **out6) {
   if (!d || !out6) MW_FAIL("null argument");
+  if (d->flux_src) {     // production path: the state-variable fluxes of the last stage were never written; rebuild all six
+    if (launch_flux(d, d->flux_src)) return 1;              // arrays from the retained stage input exactly as D9+D10 leave them
+    if (launch_fct(d, d->flux_src, d->flux_dt)) return 1;
+    d->flux_src = nullptr;
+  }
   out6[0] = d->FX; out6[1] = d->FY; out6[2] = d->FZ;
   out6[3] = d->FX + 5 * d->p.fxV; out6[4] = d->FY + 5 * d->p.fyV; out6[5] = d->FZ + 5 * d->p.fzV;
   return 0;
@@ -979,8 +1070,22 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   double dt_dyn = mw_dycore_compute_time_step(&d->g);                     // :104
   int ncycles = (int)std::ceil(dt_phys / dt_dyn);                         // :107
   dt_dyn = dt_phys / ncycles;                                             // :108
+  const bool march = (d->strict == 0) && p.V >= 6 && p.V <= 9;      // production path; other tracer counts / strict use the
+                                                              // general flux-materialising kernels below
   for (int icycle = 0; icycle < ncycles; icycle++) {
     bool last = (icycle == ncycles - 1);
+    if (march) {
+      int rc = 1;
+      switch (p.V) {
+        case 6: rc = rk_cycle_march<6>(d, d->S0, d->S1, d->S2, dt_dyn, last, c); break;
+        case 7: rc = rk_cycle_march<7>(d, d->S0, d->S1, d->S2, dt_dyn, last, c); break;
+        case 8: rc = rk_cycle_march<8>(d, d->S0, d->S1, d->S2, dt_dyn, last, c); break;
+        case 9: rc = rk_cycle_march<9>(d, d->S0, d->S1, d->S2, dt_dyn, last, c); break;
+      }
+      if (rc) return 1;
+      std::swap(d->S0, d->S1);                                // the new q^n
+      continue;
+    }
     // stage 1 (:119-132)
     if (halo_fill(d, d->S0)) return 1;
     if (launch_flux(d, d->S0)) return 1;
@@ -999,6 +1104,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     if (launch_fct(d, d->S1, dt3)) return 1;
     if (last) { if (launch_update<3, 1>(d, d->S1, d->S0, d->S0, dt3, dt_dyn, c, nullptr, nullptr)) return 1; }     // + :178
     else      { if (launch_update<3, 0>(d, d->S1, d->S0, d->S0, dt3, dt_dyn, c, nullptr, nullptr)) return 1; }
+    d->flux_src = nullptr;                                    // all six flux arrays are already materialised
   }
   d->etime += dt_phys;                                                    // :181
   return 0;
@@ -1016,6 +1122,7 @@ int mw_dycore_compute_tendencies(mw_dycore_t d, const double *rho_d, const doubl
   if (halo_fill(d, d->S0)) return 1;
   if (launch_flux(d, d->S0)) return 1;
   if (launch_fct(d, d->S0, dt)) return 1;
+  d->flux_src = nullptr;
   if (state_tend && tracers_tend) { if (launch_update<1, 2>(d, d->S0, d->S0, nullptr, dt, dt, c, state_tend, tracers_tend)) return 1; }
   return 0;
 }

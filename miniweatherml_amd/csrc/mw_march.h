@@ -1,0 +1,418 @@
+// =====================================================================================================
+// mw_march.h -- the production RK-stage kernels ("shared reconstruction, marching").   Included by mw_dycore.hip.
+//
+// Each cell is reconstructed ONCE per direction and variable (24 WENO calls per cell and stage for V = 8, like the
+// reference's D6 kernel) and its two edge values are handed to the two adjacent faces without touching memory:
+//   * along the marching direction (y in k_pass_y, z in k_pass_xz) a thread walks a chunk of cells with a 5-deep
+//     register window per variable; the previous cell's upper edge values and face fluxes are carried in registers;
+//   * along x (k_pass_xz) a wavefront spans 64 consecutive (x,ens) lanes; stencil neighbours, the west cell's east-edge
+//     values and the east face's fluxes travel by wavefront shuffles (ds_bpermute), 3*nens lanes of overlap per side.
+// k_pass_y   : y faces -> tracer y-fluxes (public array) + the y part of the state tendencies (scratch, 5 doubles/cell)
+// k_pass_xz  : x and z faces -> tracer x/z-fluxes + COMPLETE state tendencies -> SSPRK3 combine -> new state slab.
+//              The state-variable fluxes (15 of the 24 flux doubles per cell) never go to HBM.
+// k_tracer_update : tracer divergence of the FCT-corrected fluxes + SSPRK3 combine (+ D13 on the last stage).
+// reference: dynamics_euler_stratified_wenofv.h:271-388 (D6), :395-485 (D9), :519-551 (D11), :121-174 (D12).
+// =====================================================================================================
+#pragma once
+
+namespace mw {
+
+__device__ __forceinline__ double shfl_from(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+// Whole-wavefront shifts by one lane as DPP moves (v_mov_b32_dpp wave_shr:1 / wave_shl:1, gfx9 family): two full-rate
+// VALU moves per double and no LDS round trip.  Used when nens == 1 (x neighbours are adjacent lanes).
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// value held by the lane n lanes to the west (lower x) / east (higher x)
+template <bool N1> __device__ __forceinline__ double from_west(double v, int lane, int n) {
+  if (N1) return dpp_mov<0x138>(v);            // wave_shr:1
+  return shfl_from(v, lane - n);
+}
+template <bool N1> __device__ __forceinline__ double from_east(double v, int lane, int n) {
+  if (N1) return dpp_mov<0x130>(v);            // wave_shl:1
+  return shfl_from(v, lane + n);
+}
+
+struct FaceState {   // what the passive variables need from the Riemann solve of one face
+  double m_upw;      // upwind mass flux (= flux of idR)
+  int ind;           // 0: upwind is the low ("L") side, 1: the high ("R") side
+};
+
+// Acoustic-upwind Riemann solve for the three primary variables of one face (:399-414).  Edge values:
+// rX = rho edge (perturbation + hy), uX = normal velocity edge, eTX = (rho theta)' edge (perturbation only).
+// Returns the fluxes of idR, the normal momentum and idT, plus the upwind selector.
+__device__ __forceinline__ FaceState riemann_primary(const DyP &p, double rL, double rR, double uL, double uR, double eTL,
+                                                     double eTR, double hyt, double p0, double ihyt, bool zero_nrm,
+                                                     double &f_nrm, double &f_T) {
+#pragma clang fp contract(fast)
+  const double cs = 350;
+  double mL = zero_nrm ? 0.0 : uL * rL;
+  double mR = zero_nrm ? 0.0 : uR * rR;
+  double p_L = pressure_fast(p, eTL, hyt, p0, ihyt), p_R = pressure_fast(p, eTR, hyt, p0, ihyt);
+  double w1 = 0.5 * (p_R - cs * mR);
+  double w2 = 0.5 * (p_L + cs * mL);
+  double p_upw = w1 + w2;
+  FaceState fs;
+  fs.m_upw = (w2 - w1) * (1.0 / 350.0);
+  fs.ind = (mL + mR > 0) ? 0 : 1;
+  double r_upw = fs.ind ? rR : rL;
+  double u_upw = zero_nrm ? 0.0 : (fs.ind ? uR : uL);
+  f_nrm = fs.m_upw * u_upw + p_upw;
+  f_T = fs.m_upw * ((fs.ind ? eTR : eTL) + hyt) / r_upw;
+  return fs;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Y pass.  thread = (k, interior fused-x lane), marches j over [ja-1, jb] for the chunk [ja, jb) of rows.
+// Writes FY (tracer part) for faces ja..jb(-1 unless last chunk) and tendY (5, nz, ny, nx, nens) for rows ja..jb-1.
+// ---------------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void k_pass_y(DyP p, const double *__restrict__ S, double *__restrict__ FY,
+                                                double *__restrict__ tendY, int chunk) {
+  const int NXI = p.nx * p.nens;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
+  if (t >= (long long)p.nz * NXI) return;
+  const int k = (int)(t / NXI);
+  const int ie = (int)(t - (long long)k * NXI);
+  const int ja = blockIdx.y * chunk;
+  const int jb = min(ja + chunk, p.ny);
+  const int e = ie % p.nens;
+  const double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
+  const double p0 = p.p0c[k * p.nens + e], ihyt = p.ihytc[k * p.nens + e];
+  const double *col = S + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;      // row j at col + (j+HY)*sJ
+  double *fy = FY + (long long)k * p.fyK + ie;                                               // face j at fy + j*fyJ (+ l*fyV)
+  double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
+  constexpr int VMAX = V;
+  double w[VMAX][5];
+  double cn[VMAX];          // north-edge values of the previous cell
+  double fprev[5];          // state fluxes of the previous face
+  double nxt[VMAX];         // row j+3, fetched one iteration ahead of its use
+#pragma unroll
+  for (int v = 0; v < VMAX; v++) {
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(ja - 1 - 2 + s + p.HY) * p.sJ];
+  }
+  for (int j = ja - 1; j <= jb; j++) {
+    // window = rows j-2..j+2.  Issue the loads of row j+3 now; they are consumed by the shift at the end of the iteration.
+    {
+      const int jn = min(j + 3, p.ny + p.HY - 1);               // clamp: the last prefetch is never used
+#pragma unroll
+      for (int v = 0; v < VMAX; v++) nxt[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
+    }
+    double se[VMAX], ne[VMAX];
+#pragma unroll
+    for (int v = 0; v < VMAX; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
+    if (j >= ja) {
+      // face j: L = north edge of cell j-1 (cn), R = south edge of cell j (se); y boundary rule :1061-1081
+      bool zero = false;
+      double Lr = cn[idR], Lu = cn[idV], Lt = cn[idT], Rr = se[idR], Ru = se[idV], Rt = se[idT];
+      int bcmode = 0;        // 1: L := R   2: R := L
+      if (p.bc_y != MW_BC_PERIODIC) {
+        if (p.py == 0) { if (j == 0) bcmode = 1; else if (j == p.ny && p.nproc_y == 1) bcmode = 3; }
+        else if (p.py == p.nproc_y - 1) { if (j == p.ny) bcmode = 2; }
+        if (bcmode == 1 || bcmode == 2) zero = (p.bc_y == MW_BC_WALL);
+      }
+      if (__builtin_expect(bcmode == 3, 0)) {                  // quirk 1: slot 1 at face ny keeps row 0's south edge (:997)
+        for (int v = 0; v < V; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_;
+          weno5_edges_fast(qv[-2 * p.sJ], qv[-p.sJ], qv[0], qv[p.sJ], qv[2 * p.sJ], l_, r_); se[v] = l_; }
+        Rr = se[idR]; Ru = se[idV]; Rt = se[idT];
+      }
+      if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; }
+      if (bcmode == 2) { Rr = Lr; Ru = Lu; Rt = Lt; }
+      double f[5];
+      double fn, fT;
+      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, zero, fn, fT);
+      int up = fs.ind;
+      if (bcmode == 1) up = 1;     // both sides hold the R (cell j) values
+      if (bcmode == 2) up = 0;
+      f[idR] = fs.m_upw; f[idV] = fn; f[idT] = fT;
+      f[idU] = fs.m_upw * (up ? se[idU] : cn[idU]);
+      f[idW] = fs.m_upw * (up ? se[idW] : cn[idW]);
+#pragma unroll
+      for (int v = 5; v < VMAX; v++) fy[(long long)v * p.fyV + (long long)j * p.fyJ] = fs.m_upw * (up ? se[v] : cn[v]);
+      if (j > ja) {
+#pragma unroll
+        for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fprev[l]) / p.dy;
+      }
+#pragma unroll
+      for (int l = 0; l < 5; l++) fprev[l] = f[l];
+    }
+#pragma unroll
+    for (int v = 0; v < VMAX; v++) {
+      cn[v] = ne[v];
+      w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// XZ pass (final pass of a stage).  wave = 64 fused-x lanes of one row j; lanes [0,2n) only feed stencils, lanes
+// [2n,64-2n) reconstruct in x, lanes [3n,64-2n) own a lower x face, lanes [3n,64-3n) own a complete cell (n = nens).
+// Marches k over [ka-1, kb] for the chunk [ka, kb).  For every owned cell: complete tendency -> RK combine -> Sout.
+// All global loads of an iteration (next window level, q^n and the y-tendency of the cells being finalised) are
+// issued at the top of the iteration and consumed at its end, so their latency hides behind ~2.5k VALU instructions.
+// ---------------------------------------------------------------------------------------------------------------
+template <int V, int STAGE, bool N1>
+__global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
+                                                 double *__restrict__ Sout, double *__restrict__ FX, double *__restrict__ FZ,
+                                                 const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
+                                                 int tiles_x) {
+  const int n = N1 ? 1 : p.nens;
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int NXI = p.nx * n;
+  const int U = 64 - 6 * n;                                   // cells (fused) a wave completes
+  const long long wid = (long long)blockIdx.x * 4 + wave_in_block;     // wave id -> (row j, x tile)
+  const int j = (int)(wid / tiles_x);
+  const int tx = (int)(wid - (long long)j * tiles_x);
+  if (j >= p.ny) return;                                      // whole wave exits together
+  const int q = tx * U - 3 * n + lane;                        // interior fused-x index of this lane (may be in the halo)
+  const bool in_row = (q < NXI + 3 * n);                      // inside the allocated row
+  const bool owns_face = (lane >= 3 * n) && (lane < 64 - 2 * n) && (q < NXI + n);
+  const bool owns_cell = (lane >= 3 * n) && (lane < 64 - 3 * n) && (q < NXI);
+  const int qq = in_row ? q : (NXI + 3 * n - 1);               // clamped for addressing
+  const int e = N1 ? 0 : ((qq % n) + n) % n;
+  const int i = (qq - e) / n;                                  // x cell index (can be -3..nx+2)
+  const int qc = owns_cell ? q : 0;                            // safe index for per-cell arrays
+  const int ka = blockIdx.y * chunk;
+  const int kb = min(ka + chunk, p.nz);
+  const double *col = S + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qq;             // level k at col + (k+HZ)*sK
+  const long long cell0 = (long long)j * NXI + qc;                                             // + k*ny*NXI
+  const long long slab0 = (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qc;             // + (k+HZ)*sK
+  const long long planeC = (long long)p.ny * NXI;
+  double w[V][5];
+  double nxt[V];            // window level fetched one iteration ahead
+  double ct[V];             // top-edge values of the previous cell
+  double fzprev[5];         // state z-fluxes of the previous face
+  double xpart[5];          // x (+y) part of the tendency of the previous cell
+#pragma unroll
+  for (int l = 0; l < 5; l++) { fzprev[l] = 0; xpart[l] = 0; }
+  const int kstart = (ka == 0) ? 0 : ka - 1;                   // no ghost cell below the wall
+#pragma unroll
+  for (int v = 0; v < V; v++) {
+    ct[v] = 0;
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(kstart - 2 + s + p.HZ) * p.sK];
+  }
+  for (int k = kstart; k <= kb; k++) {
+    const bool top = (k == p.nz);                              // only the boundary face nz, no cell to reconstruct
+    const bool xwork = (k >= ka) && (k < kb);                  // cells of this chunk (ghost levels only do z)
+    const bool zface = (k >= ka);                              // face k belongs to this chunk (k == kb: closing face)
+    const bool fin = (k > ka);                                 // cell k-1 gets finalised in this iteration
+    // ---------------- issue this iteration's global loads
+    {
+      const int kn = min(k + 3, p.nz + p.HZ - 1);
+#pragma unroll
+      for (int v = 0; v < V; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
+    }
+    double snv[5], tyv[5], immv = 0;
+#pragma unroll
+    for (int l = 0; l < 5; l++) { snv[l] = 0; tyv[l] = 0; }
+    if (STAGE != 1 && fin) {
+#pragma unroll
+      for (int l = 0; l < 5; l++) snv[l] = Sn[(long long)l * p.sV + slab0 + (long long)(k - 1 + p.HZ) * p.sK];
+    }
+    if (xwork && !p.sim2d) {
+#pragma unroll
+      for (int l = 0; l < 5; l++) tyv[l] = tendY[(long long)l * p.nC + cell0 + (long long)k * planeC];
+    }
+    if (p.use_immersed && fin) immv = p.imm[cell0 + (long long)(k - 1) * planeC];
+    // ------------------------------------------------ X direction (cell k = window centre)
+    double fxs[5];                                             // state x-fluxes of the lower x face
+    if (xwork) {
+      const double hyr = p.hyc[k * n + e], hyt = p.hytc[k * n + e], p0 = p.p0c[k * n + e], ihyt = p.ihytc[k * n + e];
+      double we[V], ee[V];
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        double c0 = w[v][2];
+        double m1 = from_west<N1>(c0, lane, n), p1 = from_east<N1>(c0, lane, n);
+        double m2 = N1 ? from_west<N1>(m1, lane, n) : shfl_from(c0, lane - 2 * n);
+        double p2 = N1 ? from_east<N1>(p1, lane, n) : shfl_from(c0, lane + 2 * n);
+        weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
+      }
+      // west neighbour's east-edge values
+      double Lr = from_west<N1>(ee[idR], lane, n), Lu = from_west<N1>(ee[idU], lane, n), Lt = from_west<N1>(ee[idT], lane, n);
+      double Rr = we[idR], Ru = we[idU], Rt = we[idT];
+      bool zero = false; int bcmode = 0;
+      if (p.bc_x != MW_BC_PERIODIC) {                          // :1040-1060
+        if (p.px == 0) { if (i == 0) bcmode = 1; else if (i == p.nx && p.nproc_x == 1) bcmode = 3; }
+        else if (p.px == p.nproc_x - 1) { if (i == p.nx) bcmode = 2; }
+        if (bcmode == 1 || bcmode == 2) zero = (p.bc_x == MW_BC_WALL);
+      }
+      if (__builtin_expect(bcmode == 3, 0)) {                  // quirk 1: slot 1 at face nx keeps cell 0's west edge (:985)
+        const double *c0p = col + (long long)(k + p.HZ) * p.sK - (long long)p.nx * n;
+#pragma unroll
+        for (int v = 0; v < V; v++) { const double *qv = c0p + (long long)v * p.sV; double l_, r_;
+          weno5_edges_fast(qv[-2 * n], qv[-n], qv[0], qv[n], qv[2 * n], l_, r_); we[v] = l_; }
+        Rr = we[idR]; Ru = we[idU]; Rt = we[idT];
+      }
+      if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; }
+      if (bcmode == 2) { Rr = Lr; Ru = Lu; Rt = Lt; }
+      double fn, fT;
+      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, zero, fn, fT);
+      int up = fs.ind;
+      if (bcmode == 1) up = 1;
+      if (bcmode == 2) up = 0;
+      fxs[idR] = fs.m_upw; fxs[idU] = fn; fxs[idT] = fT;
+      {
+        double Lv = from_west<N1>(ee[idV], lane, n), Lw = from_west<N1>(ee[idW], lane, n);
+        fxs[idV] = fs.m_upw * (up ? we[idV] : Lv);
+        fxs[idW] = fs.m_upw * (up ? we[idW] : Lw);
+      }
+      double *fx = FX + (long long)k * p.fxK + (long long)j * p.fxJ + q;
+      const bool st = owns_face && (owns_cell || q >= NXI);
+#pragma unroll
+      for (int v = 5; v < V; v++) {
+        double Lq = from_west<N1>(ee[v], lane, n);
+        double fl = fs.m_upw * (up ? we[v] : Lq);
+        if (st) fx[(long long)v * p.fxV] = fl;
+      }
+    }
+    // ------------------------------------------------ Z direction: reconstruct cell k, solve face k
+    double be[V], te[V];
+    if (!top) {
+#pragma unroll
+      for (int v = 0; v < V; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be[v], te[v]);
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; v++) { be[v] = 0; te[v] = 0; }
+    }
+    double fzs[5];
+#pragma unroll
+    for (int l = 0; l < 5; l++) fzs[l] = 0;
+    if (zface) {
+      const double hyr = p.hye[k * n + e], hyt = p.hyte[k * n + e], p0 = p.p0e[k * n + e], ihyt = p.ihyte[k * n + e];
+      double Lr = ct[idR], Lu = ct[idW], Lt = ct[idT], Rr = be[idR], Ru = be[idW], Rt = be[idT];
+      bool zero = false; int bcmode = 0;
+      if (k == 0) bcmode = 1;                                  // :1020-1038 wall/open edge-value rule
+      if (top) bcmode = 2;
+      if (bcmode) zero = (p.bc_z == MW_BC_WALL);
+      if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; }
+      if (bcmode == 2) { Rr = Lr; Ru = Lu; Rt = Lt; }
+      double fn, fT;
+      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, zero, fn, fT);
+      int up = fs.ind;
+      if (bcmode == 1) up = 1;
+      if (bcmode == 2) up = 0;
+      fzs[idR] = fs.m_upw; fzs[idW] = fn; fzs[idT] = fT;
+      fzs[idU] = fs.m_upw * (up ? be[idU] : ct[idU]);
+      fzs[idV] = fs.m_upw * (up ? be[idV] : ct[idV]);
+      double *fz = FZ + (long long)k * p.fzK + (long long)j * p.fzJ + q;
+#pragma unroll
+      for (int v = 5; v < V; v++) {
+        double fl = fs.m_upw * (up ? be[v] : ct[v]);
+        if (owns_cell) fz[(long long)v * p.fzV] = fl;
+      }
+    }
+    // ------------------------------------------------ finalise cell k-1 (it now has its upper z face)
+    if (fin) {
+      const int kc = k - 1;
+      const double hyc = p.hyc[kc * n + e];
+      const int wi = 1;                                        // window slot that holds level k-1 (window is centred on k)
+      const double rho_s = w[idR][wi] + hyc;
+      const double rho_n = (STAGE == 1) ? rho_s : snv[idR] + hyc;
+      double imm_coef = 0;
+      if (p.use_immersed) { double tau = 1.e3 * dt_stage; imm_coef = -fmin(1.0, dt_stage / tau); }
+      const double ru_s = w[idU][wi] * rho_s, rv_s = w[idV][wi] * rho_s;
+      double rho_new = 1.0;
+      double *so = Sout + slab0 + (long long)(kc + p.HZ) * p.sK;
+#pragma unroll
+      for (int l = 0; l < 5; l++) {
+        double raw_s = w[l][wi];
+        double q_s = (l == idR || l == idT) ? raw_s : raw_s * rho_s;
+        double q_n;
+        if (STAGE == 1) q_n = q_s;
+        else q_n = (l == idR || l == idT) ? snv[l] : snv[l] * rho_n;
+        double tend = xpart[l] - (fzs[l] - fzprev[l]) / p.dz;
+        if (l == idW && p.enable_gravity) tend += -p.grav * rho_s;
+        if (l == idU) tend += p.fcor * rv_s;
+        if (l == idV) tend -= p.fcor * ru_s;
+        if (l == idV && p.sim2d) tend = 0;
+        if (p.use_immersed) { double imm_tend = imm_coef * q_s / dt_stage; tend = immv * imm_tend + (1 - immv) * tend; }
+        double qnew;
+        if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
+        else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
+        else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
+        if (l == idR) rho_new = qnew + hyc;
+        if (owns_cell) so[(long long)l * p.sV] = (l == idR || l == idT) ? qnew : qnew / rho_new;
+      }
+    }
+    // ------------------------------------------------ carries for the next level
+    if (xwork) {                                               // x (+ y) part of cell k: east face = lower face of lane + n
+#pragma unroll
+      for (int l = 0; l < 5; l++) {
+        double fe = from_east<N1>(fxs[l], lane, n);
+        xpart[l] = -(fe - fxs[l]) / p.dx + tyv[l];
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 5; l++) fzprev[l] = fzs[l];
+    if (!top) {
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        ct[v] = te[v];
+        w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tracer update: divergence of the (FCT-corrected) tracer fluxes + SSPRK3 combine + clip + storage divide.
+//   MODE 0: write the tracer part of the new slab;   MODE 1 (last stage of the last cycle): also D13 (:1927-1950).
+// The new density is read from the slab k_pass_xz has just written.
+// ---------------------------------------------------------------------------------------------------------------
+template <int STAGE, int MODE>
+__global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Sstar, const double *Sn, double *Sout,
+                                                       const double *__restrict__ FX, const double *__restrict__ FY,
+                                                       const double *__restrict__ FZ, double dt_dyn, CouplerPtrs c) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int k = blockIdx.y;
+  int NXI = p.nx * p.nens;
+  if (t >= (long long)p.ny * NXI) return;
+  int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  int e = ie % p.nens;
+  long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
+  long long ci = ((long long)k * p.ny + j) * NXI + ie;
+  const double *fx = FX + (long long)k * p.fxK + (long long)j * p.fxJ + ie;
+  const double *fy = FY + (long long)k * p.fyK + (long long)j * p.fyJ + ie;
+  const double *fz = FZ + (long long)k * p.fzK + (long long)j * p.fzJ + ie;
+  const double hyc = p.hyc[k * p.nens + e], hytc = p.hytc[k * p.nens + e];
+  const double rho_s = Sstar[so + idR * p.sV] + hyc;
+  const double rho_n = (STAGE == 1) ? rho_s : Sn[so + idR * p.sV] + hyc;
+  const double rho_new = Sout[so + idR * p.sV] + hyc;
+  double rho_dry = rho_new, rho_v = 0;
+  for (int l = 5; l < p.V; l++) {
+    double q_s = Sstar[so + l * p.sV] * rho_s;
+    double q_n = (STAGE == 1) ? q_s : Sn[so + l * p.sV] * rho_n;
+    double tend = -(fx[l * p.fxV + p.nens] - fx[l * p.fxV]) / p.dx
+                  -(fy[l * p.fyV + p.fyJ ] - fy[l * p.fyV]) / p.dy
+                  -(fz[l * p.fzV + p.fzK ] - fz[l * p.fzV]) / p.dz;
+    double qnew;
+    if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
+    else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
+    else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
+    if ((p.pos_mask >> (l - 5)) & 1u) qnew = fmax(0.0, qnew);
+    if (MODE == 0) Sout[so + l * p.sV] = qnew / rho_new;
+    else {
+      c.tr[l - 5][ci] = qnew;
+      if (l - 5 == p.idWV) rho_v = qnew;
+      if ((p.mass_mask >> (l - 5)) & 1u) rho_dry -= qnew;
+    }
+  }
+  if (MODE == 1) {
+    // the slab holds u = (rho u)/rho etc. -- exactly what convert_dynamics_to_coupler computes (:1929-1932)
+    double theta = (Sout[so + idT * p.sV] + hytc) / rho_new;
+    double press = p.C0 * pow(rho_new * theta, p.gamma);
+    c.rho_d[ci] = rho_dry;
+    c.u[ci] = Sout[so + idU * p.sV]; c.v[ci] = Sout[so + idV * p.sV]; c.w[ci] = Sout[so + idW * p.sV];
+    c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);
+  }
+}
+
+} // namespace mw
