@@ -115,7 +115,7 @@ def main():
         dycore.time_step(coupler, dt)
     sync()
     el = time.perf_counter() - t0
-    prof = {n: dycore.profile_get(i) for i, n in enumerate(["flux", "fct", "update", "halo", "convert"])}
+    prof = {n: dycore.profile_get(i) for i, n in enumerate(["xz_state", "fct", "tracer_update", "halo", "convert", "y_state", "y_tracers", "xz_tracers"])}
     dycore.profile(0)
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=device)
@@ -130,7 +130,7 @@ def main():
         ncycles = 1
         total_updates = float(ncells_local) * world * ncycles * a.steps
         value = total_updates / el
-        flux_ms, flux_n = prof["flux"]
+        flux_ms, flux_n = prof["xz_state"]
         avg_flux_s = flux_ms / 1e3 / max(1, flux_n)
         alg_bytes = 32.0 * V * ncells_local                      # per launch: read V, write 3V doubles per cell
         achieved = alg_bytes / avg_flux_s / 1e9 if flux_n else None

@@ -39,11 +39,11 @@ struct DyP {                      // kernel parameter block (by value)
   int sim2d, bc_x, bc_y, bc_z, px, py, nproc_x, nproc_y;
   int enable_gravity, use_immersed, idWV;
   unsigned pos_mask, mass_mask;
-  double dx, dy, dz, C0, gamma, grav, fcor, R_d, R_v;
+  double dx, dy, dz, rdx, rdy, rdz, C0, gamma, grav, fcor, R_d, R_v;
   const double *hyc, *hytc, *hye, *hyte;       // device (nz,nens) / (nz+1,nens)
   const double *p0c, *p0e, *ihytc, *ihyte;     // C0*hyt^gamma and 1/hyt at cells / edges (fast pressure path)
   const double *imm;                           // device (nz,ny,nx,nens)
-  double bn[17];                               // binomial series coefficients C(gamma, n), n = 0..16
+  double bn[11];                               // binomial series coefficients C(gamma, n), n = 0..10
 };
 
 struct CouplerPtrs {
@@ -59,15 +59,15 @@ template <bool STRICT> __device__ __forceinline__ double pow_gamma(double x, dou
 // p = C0 (hyt + e)^gamma for the fast path.  The Riemann solver needs two of these per face (6 per cell and stage,
 // :401,:426,:457); the device-libm pow costs ~230 fp64-VALU instructions.  Writing (hyt + e)^gamma =
 // hyt^gamma (1 + delta)^gamma with delta = e/hyt (|delta| is a few per cent: e is the reconstructed PERTURBATION of
-// rho*theta) turns it into p0(k) * sum_n C(gamma,n) delta^n: 16 FMAs, error < 1 ulp for |delta| <= 0.1.
-// Larger perturbations take the generic pow (per-lane branch).
+// rho*theta) turns it into p0(k) * sum_n C(gamma,n) delta^n: 10 FMAs; truncation |C(gamma,11)| 0.05^11 ~ 1e-17 for
+// |delta| <= 0.05.  Larger perturbations take the generic pow (per-lane branch).
 __device__ __forceinline__ double pressure_fast(const DyP &p, double e, double hyt, double p0, double ihyt) {
 #pragma clang fp contract(fast)
   double dl = e * ihyt;
-  if (fabs(dl) <= 0.1) {
-    double acc = p.bn[16];
+  if (fabs(dl) <= 0.05) {
+    double acc = p.bn[10];
 #pragma unroll
-    for (int n = 15; n >= 1; n--) acc = acc * dl + p.bn[n];
+    for (int n = 9; n >= 1; n--) acc = acc * dl + p.bn[n];
     return p0 + p0 * (acc * dl);
   }
   return p.C0 * pow(hyt + e, p.gamma);
@@ -352,6 +352,7 @@ __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ 
 // D10  FCT positivity (:498-516).  In-place scaling of outgoing tracer fluxes; race-free by the reference's
 // sign argument (:495-497): a face is only ever rescaled by the cell it leaves.
 // -----------------------------------------------------------------------------------------------------
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_fct(DyP p, const double *__restrict__ S, double *__restrict__ FX,
                                              double *__restrict__ FY, double *__restrict__ FZ, double dt) {
 #pragma clang fp contract(off)
@@ -371,9 +372,16 @@ __global__ __launch_bounds__(256) void k_fct(DyP p, const double *__restrict__ S
   double *fz = FZ + (long long)(5 + tr) * p.fzV + (long long)k * p.fzK + (long long)j * p.fzJ + ie;
   double fxm = fx[0], fxp = fx[p.nens], fym = fy[0], fyp = fy[p.fyJ], fzm = fz[0], fzp = fz[p.fzK];
   double mass_available = fmax(tracer, 0.0) * dx * dy * dz;
-  double flux_out_x = (fmax(fxp, 0.0) - fmin(fxm, 0.0)) / dx;
-  double flux_out_y = (fmax(fyp, 0.0) - fmin(fym, 0.0)) / dy;
-  double flux_out_z = (fmax(fzp, 0.0) - fmin(fzm, 0.0)) / dz;
+  double flux_out_x, flux_out_y, flux_out_z;
+  if (FAST) {   // production path: multiply by the reciprocal grid spacings (1 ulp from the reference's divisions)
+    flux_out_x = (fmax(fxp, 0.0) - fmin(fxm, 0.0)) * p.rdx;
+    flux_out_y = (fmax(fyp, 0.0) - fmin(fym, 0.0)) * p.rdy;
+    flux_out_z = (fmax(fzp, 0.0) - fmin(fzm, 0.0)) * p.rdz;
+  } else {
+    flux_out_x = (fmax(fxp, 0.0) - fmin(fxm, 0.0)) / dx;
+    flux_out_y = (fmax(fyp, 0.0) - fmin(fym, 0.0)) / dy;
+    flux_out_z = (fmax(fzp, 0.0) - fmin(fzm, 0.0)) / dz;
+  }
   double mass_out = (flux_out_x + flux_out_y + flux_out_z) * dt * dx * dy * dz;
   if (mass_out > mass_available) {
     double mult = mass_available / mass_out;
@@ -685,6 +693,7 @@ struct mw_dycore_s {
   DyP p;
   double *S0 = nullptr, *S1 = nullptr, *S2 = nullptr;   // q^n and two stage slabs (rotated, never aliased in a launch)
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
+  unsigned char *UPX = nullptr, *UPY = nullptr, *UPZ = nullptr;   // upwind selector of every x / y / z face
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
   int chunk_y = 0, chunk_z = 0;
@@ -699,8 +708,8 @@ struct mw_dycore_s {
   long long nWE = 0, nSN = 0;
   // profiling
   int prof = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[5];
-  size_t ev_used[5] = {0, 0, 0, 0, 0};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[8];
+  size_t ev_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   void *rccl = nullptr;                      // mw_rccl.cpp state
 };
 
@@ -724,6 +733,7 @@ static void fill_params(mw_dycore_s *d) {
   p.pos_mask = 0; p.mass_mask = 0;
   for (int t = 0; t < g.num_tracers; t++) { if (d->pos[t]) p.pos_mask |= 1u << t; if (d->adds[t]) p.mass_mask |= 1u << t; }
   p.dx = g.xlen / g.nx_glob; p.dy = g.ylen / g.ny_glob; p.dz = g.zlen / g.nz;        // coupler.h:262-268
+  p.rdx = 1.0 / p.dx; p.rdy = 1.0 / p.dy; p.rdz = 1.0 / p.dz;
   p.C0 = g.C0; p.gamma = g.gamma_d; p.grav = g.grav; p.R_d = g.R_d; p.R_v = g.R_v;
   p.fcor = 2 * g.earthrot * sin(g.latitude);                                           // :213
   size_t nzc = (size_t)g.nz * g.nens, nze = (size_t)(g.nz + 1) * g.nens;
@@ -733,7 +743,7 @@ static void fill_params(mw_dycore_s *d) {
   p.imm = d->imm;
   long double bn = 1.0L;                                    // C(gamma, n) = C(gamma, n-1) (gamma - n + 1) / n
   p.bn[0] = 1.0;
-  for (int n = 1; n <= 16; n++) { bn = bn * ((long double)g.gamma_d - (n - 1)) / n; p.bn[n] = (double)bn; }
+  for (int n = 1; n <= 10; n++) { bn = bn * ((long double)g.gamma_d - (n - 1)) / n; p.bn[n] = (double)bn; }
 }
 
 static int upload_background(mw_dycore_s *d) {
@@ -816,7 +826,8 @@ static int launch_fct(mw_dycore_s *d, const double *S, double dt) {
   if (p.nt == 0 || p.pos_mask == 0) return 0;
   ProfScope ps(d, 1);
   dim3 grid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz, p.nt);
-  hipLaunchKernelGGL(k_fct, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ, dt);
+  if (d->strict == 1) hipLaunchKernelGGL(k_fct<false>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ, dt);
+  else                hipLaunchKernelGGL(k_fct<true>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ, dt);
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -841,34 +852,88 @@ static int pick_chunk(int n, long long base_waves, const char *env) {
   return std::min(n, 8);
 }
 
-template <int V>
-static int launch_pass_y(mw_dycore_s *d, const double *S) {
+static int launch_y_state(mw_dycore_s *d, const double *S) {
   const DyP &p = d->p;
   if (p.sim2d) return 0;
-  ProfScope ps(d, 0);
+  ProfScope ps(d, 5);
   long long threads = (long long)p.nz * p.nx * p.nens;
   int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = pick_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y"));
   dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
-  hipLaunchKernelGGL((k_pass_y<V>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk);
+  hipLaunchKernelGGL(k_y_state, grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, d->tendY, chunk);
   MW_LAUNCH_CHECK();
   return 0;
 }
 
-template <int V, int STAGE>
-static int launch_pass_xz(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn) {
+static int launch_y_tracers(mw_dycore_s *d, const double *S) {
   const DyP &p = d->p;
-  ProfScope ps(d, 0);
+  if (p.sim2d) return 0;
+  ProfScope ps(d, 6);
+  long long threads = (long long)p.nz * p.nx * p.nens;
+  int chunk = d->chunk_y;
+  dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
+  for (int t0 = 0; t0 < p.nt; t0 += 4) {
+    int cnt = std::min(4, p.nt - t0);
+    switch (cnt) {
+      case 1: hipLaunchKernelGGL((k_y_tracers<1>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, chunk, t0); break;
+      case 2: hipLaunchKernelGGL((k_y_tracers<2>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, chunk, t0); break;
+      case 3: hipLaunchKernelGGL((k_y_tracers<3>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, chunk, t0); break;
+      default: hipLaunchKernelGGL((k_y_tracers<4>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, chunk, t0); break;
+    }
+    MW_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+static int xz_grid(mw_dycore_s *d, dim3 &grid, int &chunk, int &tiles_x) {
+  const DyP &p = d->p;
   int U = 64 - 6 * p.nens;
   if (U < 1) MW_FAIL("nens too large for the 64-lane x tiling (need nens <= 10)");
-  int tiles_x = (p.nx * p.nens + U - 1) / U;
+  tiles_x = (p.nx * p.nens + U - 1) / U;
   long long waves = (long long)p.ny * tiles_x;
-  int chunk = d->chunk_z ? d->chunk_z : (d->chunk_z = pick_chunk(p.nz, waves, "MW_CHUNK_Z"));
-  dim3 grid((unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
-  if (p.nens == 1) hipLaunchKernelGGL((k_pass_xz<V, STAGE, true>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->FX, d->FZ, d->tendY,
-                                      dt_stage, dt_dyn, chunk, tiles_x);
-  else             hipLaunchKernelGGL((k_pass_xz<V, STAGE, false>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->FX, d->FZ, d->tendY,
-                                      dt_stage, dt_dyn, chunk, tiles_x);
+  chunk = d->chunk_z ? d->chunk_z : (d->chunk_z = pick_chunk(p.nz, waves, "MW_CHUNK_Z"));
+  grid = dim3((unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
+  return 0;
+}
+
+template <int STAGE>
+static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn) {
+  const DyP &p = d->p;
+  ProfScope ps(d, 0);
+  dim3 grid; int chunk, tiles_x;
+  if (xz_grid(d, grid, chunk, tiles_x)) return 1;
+  if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->FX, d->FZ, d->UPX,
+                                      d->UPZ, d->tendY, dt_stage, dt_dyn, chunk, tiles_x);
+  else             hipLaunchKernelGGL((k_xz_state<STAGE, false>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->FX, d->FZ, d->UPX,
+                                      d->UPZ, d->tendY, dt_stage, dt_dyn, chunk, tiles_x);
   MW_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int T, bool N1>
+static void launch_xz_tracers_t(mw_dycore_s *d, const double *S, dim3 grid, int chunk, int tiles_x, int t0) {
+  hipLaunchKernelGGL((k_xz_tracers<T, N1>), grid, dim3(256), 0, d->stream, d->p, S, d->FX, d->FZ, d->UPX, d->UPZ, chunk, tiles_x, t0);
+}
+
+static int launch_xz_tracers(mw_dycore_s *d, const double *S) {
+  const DyP &p = d->p;
+  ProfScope ps(d, 7);
+  dim3 grid; int chunk, tiles_x;
+  if (xz_grid(d, grid, chunk, tiles_x)) return 1;
+  for (int t0 = 0; t0 < p.nt; t0 += 4) {
+    int cnt = std::min(4, p.nt - t0);
+    if (p.nens == 1) {
+      switch (cnt) { case 1: launch_xz_tracers_t<1, true>(d, S, grid, chunk, tiles_x, t0); break;
+                     case 2: launch_xz_tracers_t<2, true>(d, S, grid, chunk, tiles_x, t0); break;
+                     case 3: launch_xz_tracers_t<3, true>(d, S, grid, chunk, tiles_x, t0); break;
+                     default: launch_xz_tracers_t<4, true>(d, S, grid, chunk, tiles_x, t0); break; }
+    } else {
+      switch (cnt) { case 1: launch_xz_tracers_t<1, false>(d, S, grid, chunk, tiles_x, t0); break;
+                     case 2: launch_xz_tracers_t<2, false>(d, S, grid, chunk, tiles_x, t0); break;
+                     case 3: launch_xz_tracers_t<3, false>(d, S, grid, chunk, tiles_x, t0); break;
+                     default: launch_xz_tracers_t<4, false>(d, S, grid, chunk, tiles_x, t0); break; }
+    }
+    MW_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -884,26 +949,23 @@ static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const doubl
 
 // One SSPRK3 sub-cycle on the production path (shared reconstruction, state fluxes never materialised).
 // Slabs: P = q^n, A, B scratch; on return the new q^n is in A (caller swaps).
-template <int V>
+template <int STAGE>
+static int rk_stage_march(mw_dycore_s *d, const double *Sin, const double *Sn, double *Sout, double dt_stage, double dt_dyn) {
+  if (halo_fill(d, const_cast<double *>(Sin))) return 1;
+  if (launch_y_state(d, Sin)) return 1;                                   // y faces: m_upw, selector, y tendencies
+  if (launch_xz_state<STAGE>(d, Sin, Sn, Sout, dt_stage, dt_dyn)) return 1;   // x,z faces + finished state variables
+  if (launch_y_tracers(d, Sin)) return 1;                                 // tracer fluxes (public arrays)
+  if (launch_xz_tracers(d, Sin)) return 1;
+  if (launch_fct(d, Sin, dt_stage)) return 1;                             // D10
+  return 0;
+}
 static int rk_cycle_march(mw_dycore_s *d, double *P, double *A, double *B, double dt_dyn, bool last, const CouplerPtrs &c) {
   const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
-  // stage 1 (:119-132)
-  if (halo_fill(d, P)) return 1;
-  if (launch_pass_y<V>(d, P)) return 1;
-  if (launch_pass_xz<V, 1>(d, P, P, A, dt_dyn, dt_dyn)) return 1;
-  if (launch_fct(d, P, dt_dyn)) return 1;
+  if (rk_stage_march<1>(d, P, P, A, dt_dyn, dt_dyn)) return 1;                        // stage 1 (:119-132)
   if (launch_tracer_update<1, 0>(d, P, P, A, dt_dyn, c)) return 1;
-  // stage 2 (:136-153)
-  if (halo_fill(d, A)) return 1;
-  if (launch_pass_y<V>(d, A)) return 1;
-  if (launch_pass_xz<V, 2>(d, A, P, B, dt2, dt_dyn)) return 1;
-  if (launch_fct(d, A, dt2)) return 1;
+  if (rk_stage_march<2>(d, A, P, B, dt2, dt_dyn)) return 1;                           // stage 2 (:136-153)
   if (launch_tracer_update<2, 0>(d, A, P, B, dt_dyn, c)) return 1;
-  // stage 3 (:157-174)
-  if (halo_fill(d, B)) return 1;
-  if (launch_pass_y<V>(d, B)) return 1;
-  if (launch_pass_xz<V, 3>(d, B, P, A, dt3, dt_dyn)) return 1;
-  if (launch_fct(d, B, dt3)) return 1;
+  if (rk_stage_march<3>(d, B, P, A, dt3, dt_dyn)) return 1;                           // stage 3 (:157-174)
   if (last) { if (launch_tracer_update<3, 1>(d, B, P, A, dt_dyn, c)) return 1; }      // + convert_dynamics_to_coupler (:178)
   else      { if (launch_tracer_update<3, 0>(d, B, P, A, dt_dyn, c)) return 1; }
   d->flux_src = B; d->flux_dt = dt3;
@@ -953,6 +1015,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
   size_t fxb = (size_t)p.V * p.fxV * sizeof(double), fyb = (size_t)p.V * p.fyV * sizeof(double), fzb = (size_t)p.V * p.fzV * sizeof(double);
   if (hipMalloc(&d->S0, slab) != hipSuccess || hipMalloc(&d->S1, slab) != hipSuccess || hipMalloc(&d->S2, slab) != hipSuccess ||
       hipMalloc(&d->tendY, (size_t)5 * p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->FX, fxb) != hipSuccess ||
+      hipMalloc(&d->UPX, (size_t)p.fxV) != hipSuccess || hipMalloc(&d->UPY, (size_t)p.fyV) != hipSuccess || hipMalloc(&d->UPZ, (size_t)p.fzV) != hipSuccess ||
       hipMalloc(&d->FY, fyb) != hipSuccess || hipMalloc(&d->FZ, fzb) != hipSuccess ||
       hipMalloc(&d->imm, (size_t)p.nC * sizeof(double)) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return fail(); }
   // zero everything once: halo corners are never written and the flux arrays start at 0 (:1677-1682)
@@ -972,8 +1035,9 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (!d) return;
   (void)hipStreamSynchronize(d->stream);
   for (double *ptr : {d->S0, d->S1, d->S2, d->tendY, d->FX, d->FY, d->FZ, d->hy_dev, d->imm}) if (ptr) (void)hipFree(ptr);
+  for (unsigned char *ptr : {d->UPX, d->UPY, d->UPZ}) if (ptr) (void)hipFree(ptr);
   for (int b = 0; b < 8; b++) if (d->bufs[b]) (void)hipFree(d->bufs[b]);
-  for (int w = 0; w < 5; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (int w = 0; w < 8; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete d;
 }
 
@@ -1042,11 +1106,11 @@ int mw_dycore_profile(mw_dycore_t d, int enable) {
   if (!d) MW_FAIL("null handle");
   MW_HIP(hipStreamSynchronize(d->stream));
   d->prof = enable;
-  for (int w = 0; w < 5; w++) d->ev_used[w] = 0;
+  for (int w = 0; w < 8; w++) d->ev_used[w] = 0;
   return 0;
 }
 int mw_dycore_profile_get(mw_dycore_t d, int which, double *total_ms, long long *launches) {
-  if (!d || which < 0 || which > 4) MW_FAIL("bad argument");
+  if (!d || which < 0 || which > 7) MW_FAIL("bad argument");
   MW_HIP(hipStreamSynchronize(d->stream));
   double tot = 0;
   for (size_t i = 0; i < d->ev_used[which]; i++) { float ms = 0; MW_HIP(hipEventElapsedTime(&ms, d->ev[which][i].first, d->ev[which][i].second)); tot += ms; }
@@ -1070,19 +1134,12 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   double dt_dyn = mw_dycore_compute_time_step(&d->g);                     // :104
   int ncycles = (int)std::ceil(dt_phys / dt_dyn);                         // :107
   dt_dyn = dt_phys / ncycles;                                             // :108
-  const bool march = (d->strict == 0) && p.V >= 6 && p.V <= 9;      // production path; other tracer counts / strict use the
-                                                              // general flux-materialising kernels below
+  const bool march = (d->strict == 0);                        // production path; strict = 1/2 use the general
+                                                              // flux-materialising kernels below
   for (int icycle = 0; icycle < ncycles; icycle++) {
     bool last = (icycle == ncycles - 1);
     if (march) {
-      int rc = 1;
-      switch (p.V) {
-        case 6: rc = rk_cycle_march<6>(d, d->S0, d->S1, d->S2, dt_dyn, last, c); break;
-        case 7: rc = rk_cycle_march<7>(d, d->S0, d->S1, d->S2, dt_dyn, last, c); break;
-        case 8: rc = rk_cycle_march<8>(d, d->S0, d->S1, d->S2, dt_dyn, last, c); break;
-        case 9: rc = rk_cycle_march<9>(d, d->S0, d->S1, d->S2, dt_dyn, last, c); break;
-      }
-      if (rc) return 1;
+      if (rk_cycle_march(d, d->S0, d->S1, d->S2, dt_dyn, last, c)) return 1;
       std::swap(d->S0, d->S1);                                // the new q^n
       continue;
     }

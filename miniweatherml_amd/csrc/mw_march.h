@@ -19,6 +19,15 @@ namespace mw {
 
 __device__ __forceinline__ double shfl_from(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 
+// 1/x to full fp64 accuracy: v_rcp_f64 + two Newton steps (5 instructions instead of the ~12 of an IEEE division)
+__device__ __forceinline__ double fast_rcp(double x) {
+#pragma clang fp contract(fast)
+  double r = __builtin_amdgcn_rcp(x);
+  r = r + r * (1.0 - x * r);
+  r = r + r * (1.0 - x * r);
+  return r;
+}
+
 // Whole-wavefront shifts by one lane as DPP moves (v_mov_b32_dpp wave_shr:1 / wave_shl:1, gfx9 family): two full-rate
 // VALU moves per double and no LDS round trip.  Used when nens == 1 (x neighbours are adjacent lanes).
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
@@ -62,17 +71,38 @@ __device__ __forceinline__ FaceState riemann_primary(const DyP &p, double rL, do
   double r_upw = fs.ind ? rR : rL;
   double u_upw = zero_nrm ? 0.0 : (fs.ind ? uR : uL);
   f_nrm = fs.m_upw * u_upw + p_upw;
-  f_T = fs.m_upw * ((fs.ind ? eTR : eTL) + hyt) / r_upw;
+  f_T = fs.m_upw * ((fs.ind ? eTR : eTL) + hyt) * fast_rcp(r_upw);
   return fs;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Y pass.  thread = (k, interior fused-x lane), marches j over [ja-1, jb] for the chunk [ja, jb) of rows.
-// Writes FY (tracer part) for faces ja..jb(-1 unless last chunk) and tendY (5, nz, ny, nx, nens) for rows ja..jb-1.
+// The work of one stage is split by variable group so that every kernel keeps its register windows small enough
+// for >= 2-3 wavefronts per SIMD (a single 8-variable kernel needs ~320 VGPR+AGPR = 1 wave/SIMD):
+//   state kernels  (rho', u, v, w, (rho theta)'): Riemann solve, publish the upwind mass flux m_upw (it IS the public
+//                  state_flux_*(idR) array) and the upwind selector (1 byte per face), finish the state variables;
+//   tracer kernels (q_t): flux = m_upw * upwind edge value -> the public tracers_flux_* arrays.
 // ---------------------------------------------------------------------------------------------------------------
-template <int V>
-__global__ __launch_bounds__(256) void k_pass_y(DyP p, const double *__restrict__ S, double *__restrict__ FY,
-                                                double *__restrict__ tendY, int chunk) {
+
+// y boundary rule (:1061-1081): 0 none, 1: L := R (low wall/open), 2: R := L (high), 3: quirk 1 (R = row 0's south edge)
+__device__ __forceinline__ int bc_mode_y(const DyP &p, int j) {
+  if (p.bc_y == MW_BC_PERIODIC) return 0;
+  if (p.py == 0) { if (j == 0) return 1; if (j == p.ny && p.nproc_y == 1) return 3; return 0; }
+  if (p.py == p.nproc_y - 1 && j == p.ny) return 2;
+  return 0;
+}
+__device__ __forceinline__ int bc_mode_x(const DyP &p, int i) {                      // :1040-1060
+  if (p.bc_x == MW_BC_PERIODIC) return 0;
+  if (p.px == 0) { if (i == 0) return 1; if (i == p.nx && p.nproc_x == 1) return 3; return 0; }
+  if (p.px == p.nproc_x - 1 && i == p.nx) return 2;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Y pass, state variables.  thread = (k, interior fused-x lane), marches j over [ja-1, jb] for the chunk [ja, jb).
+// Writes FY[idR] (= m_upw), UPY (selector) for faces ja..jb and tendY (5,nz,ny,nx,nens) for rows ja..jb-1.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restrict__ S, double *__restrict__ FY,
+                                                 unsigned char *__restrict__ UPY, double *__restrict__ tendY, int chunk) {
   const int NXI = p.nx * p.nens;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
   if (t >= (long long)p.nz * NXI) return;
@@ -84,47 +114,38 @@ __global__ __launch_bounds__(256) void k_pass_y(DyP p, const double *__restrict_
   const double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
   const double p0 = p.p0c[k * p.nens + e], ihyt = p.ihytc[k * p.nens + e];
   const double *col = S + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;      // row j at col + (j+HY)*sJ
-  double *fy = FY + (long long)k * p.fyK + ie;                                               // face j at fy + j*fyJ (+ l*fyV)
+  double *fy = FY + (long long)k * p.fyK + ie;                                               // face j at fy + j*fyJ
+  unsigned char *upy = UPY + (long long)k * p.fyK + ie;
   double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
-  constexpr int VMAX = V;
-  double w[VMAX][5];
-  double cn[VMAX];          // north-edge values of the previous cell
-  double fprev[5];          // state fluxes of the previous face
-  double nxt[VMAX];         // row j+3, fetched one iteration ahead of its use
+  double w[5][5], nxt[5], cn[5], fprev[5];
 #pragma unroll
-  for (int v = 0; v < VMAX; v++) {
+  for (int v = 0; v < 5; v++) {
+    cn[v] = 0; fprev[v] = 0;
 #pragma unroll
     for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(ja - 1 - 2 + s + p.HY) * p.sJ];
   }
   for (int j = ja - 1; j <= jb; j++) {
-    // window = rows j-2..j+2.  Issue the loads of row j+3 now; they are consumed by the shift at the end of the iteration.
     {
       const int jn = min(j + 3, p.ny + p.HY - 1);               // clamp: the last prefetch is never used
 #pragma unroll
-      for (int v = 0; v < VMAX; v++) nxt[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
+      for (int v = 0; v < 5; v++) nxt[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
     }
-    double se[VMAX], ne[VMAX];
+    double se[5], ne[5];
 #pragma unroll
-    for (int v = 0; v < VMAX; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
+    for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
     if (j >= ja) {
-      // face j: L = north edge of cell j-1 (cn), R = south edge of cell j (se); y boundary rule :1061-1081
-      bool zero = false;
-      double Lr = cn[idR], Lu = cn[idV], Lt = cn[idT], Rr = se[idR], Ru = se[idV], Rt = se[idT];
-      int bcmode = 0;        // 1: L := R   2: R := L
-      if (p.bc_y != MW_BC_PERIODIC) {
-        if (p.py == 0) { if (j == 0) bcmode = 1; else if (j == p.ny && p.nproc_y == 1) bcmode = 3; }
-        else if (p.py == p.nproc_y - 1) { if (j == p.ny) bcmode = 2; }
-        if (bcmode == 1 || bcmode == 2) zero = (p.bc_y == MW_BC_WALL);
-      }
-      if (__builtin_expect(bcmode == 3, 0)) {                  // quirk 1: slot 1 at face ny keeps row 0's south edge (:997)
-        for (int v = 0; v < V; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_;
+      // face j: L = north edge of cell j-1 (cn), R = south edge of cell j (se)
+      const int bcmode = bc_mode_y(p, j);
+      const bool zero = (bcmode == 1 || bcmode == 2) && (p.bc_y == MW_BC_WALL);
+      if (__builtin_expect(bcmode == 3, 0)) {
+#pragma unroll
+        for (int v = 0; v < 5; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_;
           weno5_edges_fast(qv[-2 * p.sJ], qv[-p.sJ], qv[0], qv[p.sJ], qv[2 * p.sJ], l_, r_); se[v] = l_; }
-        Rr = se[idR]; Ru = se[idV]; Rt = se[idT];
       }
+      double Lr = cn[idR], Lu = cn[idV], Lt = cn[idT], Rr = se[idR], Ru = se[idV], Rt = se[idT];
       if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; }
       if (bcmode == 2) { Rr = Lr; Ru = Lu; Rt = Lt; }
-      double f[5];
-      double fn, fT;
+      double f[5], fn, fT;
       FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, zero, fn, fT);
       int up = fs.ind;
       if (bcmode == 1) up = 1;     // both sides hold the R (cell j) values
@@ -132,17 +153,64 @@ __global__ __launch_bounds__(256) void k_pass_y(DyP p, const double *__restrict_
       f[idR] = fs.m_upw; f[idV] = fn; f[idT] = fT;
       f[idU] = fs.m_upw * (up ? se[idU] : cn[idU]);
       f[idW] = fs.m_upw * (up ? se[idW] : cn[idW]);
-#pragma unroll
-      for (int v = 5; v < VMAX; v++) fy[(long long)v * p.fyV + (long long)j * p.fyJ] = fs.m_upw * (up ? se[v] : cn[v]);
+      fy[(long long)j * p.fyJ] = fs.m_upw;
+      upy[(long long)j * p.fyJ] = (unsigned char)up;
       if (j > ja) {
 #pragma unroll
-        for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fprev[l]) / p.dy;
+        for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fprev[l]) * p.rdy;
       }
 #pragma unroll
       for (int l = 0; l < 5; l++) fprev[l] = f[l];
     }
 #pragma unroll
-    for (int v = 0; v < VMAX; v++) {
+    for (int v = 0; v < 5; v++) {
+      cn[v] = ne[v];
+      w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
+    }
+  }
+}
+
+// Y pass, tracers: flux(face j) = m_upw * (up ? south edge of cell j : north edge of cell j-1)
+template <int T>
+__global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restrict__ S, double *__restrict__ FY,
+                                                   const unsigned char *__restrict__ UPY, int chunk, int t0) {
+  const int NXI = p.nx * p.nens;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)p.nz * NXI) return;
+  const int k = (int)(t / NXI);
+  const int ie = (int)(t - (long long)k * NXI);
+  const int ja = blockIdx.y * chunk;
+  const int jb = min(ja + chunk, p.ny);
+  const double *col = S + (long long)(5 + t0) * p.sV + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;
+  double *fy = FY + (long long)k * p.fyK + ie;
+  const unsigned char *upy = UPY + (long long)k * p.fyK + ie;
+  double w[T][5], nxt[T], cn[T];
+#pragma unroll
+  for (int v = 0; v < T; v++) {
+    cn[v] = 0;
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(ja - 1 - 2 + s + p.HY) * p.sJ];
+  }
+  for (int j = ja - 1; j <= jb; j++) {
+    const int jn = min(j + 3, p.ny + p.HY - 1);
+#pragma unroll
+    for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
+    double m = 0; int up = 0;
+    if (j >= ja) { m = fy[(long long)j * p.fyJ]; up = upy[(long long)j * p.fyJ]; }
+    double se[T], ne[T];
+#pragma unroll
+    for (int v = 0; v < T; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
+    if (j >= ja) {
+      if (__builtin_expect(bc_mode_y(p, j) == 3, 0)) {
+#pragma unroll
+        for (int v = 0; v < T; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_;
+          weno5_edges_fast(qv[-2 * p.sJ], qv[-p.sJ], qv[0], qv[p.sJ], qv[2 * p.sJ], l_, r_); se[v] = l_; }
+      }
+#pragma unroll
+      for (int v = 0; v < T; v++) fy[(long long)(5 + t0 + v) * p.fyV + (long long)j * p.fyJ] = m * (up ? se[v] : cn[v]);
+    }
+#pragma unroll
+    for (int v = 0; v < T; v++) {
       cn[v] = ne[v];
       w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
     }
@@ -150,64 +218,69 @@ __global__ __launch_bounds__(256) void k_pass_y(DyP p, const double *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// XZ pass (final pass of a stage).  wave = 64 fused-x lanes of one row j; lanes [0,2n) only feed stencils, lanes
-// [2n,64-2n) reconstruct in x, lanes [3n,64-2n) own a lower x face, lanes [3n,64-3n) own a complete cell (n = nens).
-// Marches k over [ka-1, kb] for the chunk [ka, kb).  For every owned cell: complete tendency -> RK combine -> Sout.
-// All global loads of an iteration (next window level, q^n and the y-tendency of the cells being finalised) are
-// issued at the top of the iteration and consumed at its end, so their latency hides behind ~2.5k VALU instructions.
+// XZ pass.  wave = 64 fused-x lanes of one row j; lanes [0,2n) only feed stencils, lanes [2n,64-2n) reconstruct in x,
+// lanes [3n,64-2n) own a lower x face, lanes [3n,64-3n) own a complete cell (n = nens).  Marches k over [ka-1, kb]
+// for the chunk [ka, kb).  All global loads of an iteration are issued at its top and consumed at its end.
 // ---------------------------------------------------------------------------------------------------------------
-template <int V, int STAGE, bool N1>
-__global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
-                                                 double *__restrict__ Sout, double *__restrict__ FX, double *__restrict__ FZ,
-                                                 const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
-                                                 int tiles_x) {
-  const int n = N1 ? 1 : p.nens;
-  const int lane = threadIdx.x & 63;
-  const int wave_in_block = threadIdx.x >> 6;
-  const int NXI = p.nx * n;
-  const int U = 64 - 6 * n;                                   // cells (fused) a wave completes
-  const long long wid = (long long)blockIdx.x * 4 + wave_in_block;     // wave id -> (row j, x tile)
-  const int j = (int)(wid / tiles_x);
-  const int tx = (int)(wid - (long long)j * tiles_x);
-  if (j >= p.ny) return;                                      // whole wave exits together
-  const int q = tx * U - 3 * n + lane;                        // interior fused-x index of this lane (may be in the halo)
-  const bool in_row = (q < NXI + 3 * n);                      // inside the allocated row
-  const bool owns_face = (lane >= 3 * n) && (lane < 64 - 2 * n) && (q < NXI + n);
-  const bool owns_cell = (lane >= 3 * n) && (lane < 64 - 3 * n) && (q < NXI);
-  const int qq = in_row ? q : (NXI + 3 * n - 1);               // clamped for addressing
-  const int e = N1 ? 0 : ((qq % n) + n) % n;
-  const int i = (qq - e) / n;                                  // x cell index (can be -3..nx+2)
-  const int qc = owns_cell ? q : 0;                            // safe index for per-cell arrays
-  const int ka = blockIdx.y * chunk;
-  const int kb = min(ka + chunk, p.nz);
-  const double *col = S + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qq;             // level k at col + (k+HZ)*sK
-  const long long cell0 = (long long)j * NXI + qc;                                             // + k*ny*NXI
-  const long long slab0 = (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qc;             // + (k+HZ)*sK
+struct XzGeom {
+  int n, lane, NXI, j, q, qq, e, i, qc, ka, kb, kstart;
+  bool owns_face, owns_cell, valid;
+};
+template <bool N1>
+__device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x) {
+  XzGeom g;
+  g.n = N1 ? 1 : p.nens;
+  g.lane = threadIdx.x & 63;
+  g.NXI = p.nx * g.n;
+  const int U = 64 - 6 * g.n;                                 // cells (fused) a wave completes
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // wave id -> (row j, x tile)
+  g.j = (int)(wid / tiles_x);
+  const int tx = (int)(wid - (long long)g.j * tiles_x);
+  g.valid = g.j < p.ny;                                       // whole wave
+  g.q = tx * U - 3 * g.n + g.lane;                            // interior fused-x index of this lane (may be in the halo)
+  const bool in_row = (g.q < g.NXI + 3 * g.n);
+  g.owns_face = (g.lane >= 3 * g.n) && (g.lane < 64 - 2 * g.n) && (g.q < g.NXI + g.n);
+  g.owns_cell = (g.lane >= 3 * g.n) && (g.lane < 64 - 3 * g.n) && (g.q < g.NXI);
+  g.qq = in_row ? g.q : (g.NXI + 3 * g.n - 1);                // clamped for addressing
+  g.e = N1 ? 0 : ((g.qq % g.n) + g.n) % g.n;
+  g.i = (g.qq - g.e) / g.n;                                   // x cell index (can be -3..nx+2)
+  g.qc = g.owns_cell ? g.q : 0;                               // safe index for per-cell arrays
+  g.ka = blockIdx.y * chunk;
+  g.kb = min(g.ka + chunk, p.nz);
+  g.kstart = (g.ka == 0) ? 0 : g.ka - 1;                      // no ghost cell below the wall
+  return g;
+}
+
+template <int STAGE, bool N1>
+__global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
+                                                  double *__restrict__ Sout, double *__restrict__ FX, double *__restrict__ FZ,
+                                                  unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
+                                                  const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
+                                                  int tiles_x) {
+  const XzGeom g = xz_geom<N1>(p, chunk, tiles_x);
+  if (!g.valid) return;
+  const int n = g.n, lane = g.lane, NXI = g.NXI, j = g.j, q = g.q, e = g.e;
+  const double *col = S + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qq;           // level k at col + (k+HZ)*sK
+  const long long cell0 = (long long)j * NXI + g.qc;                                           // + k*ny*NXI
+  const long long slab0 = (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qc;           // + (k+HZ)*sK
   const long long planeC = (long long)p.ny * NXI;
-  double w[V][5];
-  double nxt[V];            // window level fetched one iteration ahead
-  double ct[V];             // top-edge values of the previous cell
-  double fzprev[5];         // state z-fluxes of the previous face
-  double xpart[5];          // x (+y) part of the tendency of the previous cell
+  double w[5][5], nxt[5], ct[5], fzprev[5], xpart[5];
 #pragma unroll
-  for (int l = 0; l < 5; l++) { fzprev[l] = 0; xpart[l] = 0; }
-  const int kstart = (ka == 0) ? 0 : ka - 1;                   // no ghost cell below the wall
+  for (int v = 0; v < 5; v++) {
+    ct[v] = 0; fzprev[v] = 0; xpart[v] = 0;
 #pragma unroll
-  for (int v = 0; v < V; v++) {
-    ct[v] = 0;
-#pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(kstart - 2 + s + p.HZ) * p.sK];
+    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(g.kstart - 2 + s + p.HZ) * p.sK];
   }
-  for (int k = kstart; k <= kb; k++) {
+  for (int k = g.kstart; k <= g.kb; k++) {
     const bool top = (k == p.nz);                              // only the boundary face nz, no cell to reconstruct
-    const bool xwork = (k >= ka) && (k < kb);                  // cells of this chunk (ghost levels only do z)
-    const bool zface = (k >= ka);                              // face k belongs to this chunk (k == kb: closing face)
-    const bool fin = (k > ka);                                 // cell k-1 gets finalised in this iteration
+    const bool xwork = (k >= g.ka) && (k < g.kb);              // cells of this chunk (ghost levels only do z)
+    const bool zface = (k >= g.ka);                            // face k belongs to this chunk (k == kb: closing face)
+    const bool fin = (k > g.ka);                               // cell k-1 gets finalised in this iteration
     // ---------------- issue this iteration's global loads
     {
       const int kn = min(k + 3, p.nz + p.HZ - 1);
 #pragma unroll
-      for (int v = 0; v < V; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
+      for (int v = 0; v < 5; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
     }
     double snv[5], tyv[5], immv = 0;
 #pragma unroll
@@ -222,34 +295,30 @@ __global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict
     }
     if (p.use_immersed && fin) immv = p.imm[cell0 + (long long)(k - 1) * planeC];
     // ------------------------------------------------ X direction (cell k = window centre)
-    double fxs[5];                                             // state x-fluxes of the lower x face
+    double fxs[5];
     if (xwork) {
       const double hyr = p.hyc[k * n + e], hyt = p.hytc[k * n + e], p0 = p.p0c[k * n + e], ihyt = p.ihytc[k * n + e];
-      double we[V], ee[V];
+      double we[5], ee[5];
 #pragma unroll
-      for (int v = 0; v < V; v++) {
+      for (int v = 0; v < 5; v++) {
         double c0 = w[v][2];
         double m1 = from_west<N1>(c0, lane, n), p1 = from_east<N1>(c0, lane, n);
         double m2 = N1 ? from_west<N1>(m1, lane, n) : shfl_from(c0, lane - 2 * n);
         double p2 = N1 ? from_east<N1>(p1, lane, n) : shfl_from(c0, lane + 2 * n);
         weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
       }
-      // west neighbour's east-edge values
-      double Lr = from_west<N1>(ee[idR], lane, n), Lu = from_west<N1>(ee[idU], lane, n), Lt = from_west<N1>(ee[idT], lane, n);
-      double Rr = we[idR], Ru = we[idU], Rt = we[idT];
-      bool zero = false; int bcmode = 0;
-      if (p.bc_x != MW_BC_PERIODIC) {                          // :1040-1060
-        if (p.px == 0) { if (i == 0) bcmode = 1; else if (i == p.nx && p.nproc_x == 1) bcmode = 3; }
-        else if (p.px == p.nproc_x - 1) { if (i == p.nx) bcmode = 2; }
-        if (bcmode == 1 || bcmode == 2) zero = (p.bc_x == MW_BC_WALL);
-      }
+      const int bcmode = bc_mode_x(p, g.i);
+      const bool zero = (bcmode == 1 || bcmode == 2) && (p.bc_x == MW_BC_WALL);
       if (__builtin_expect(bcmode == 3, 0)) {                  // quirk 1: slot 1 at face nx keeps cell 0's west edge (:985)
         const double *c0p = col + (long long)(k + p.HZ) * p.sK - (long long)p.nx * n;
 #pragma unroll
-        for (int v = 0; v < V; v++) { const double *qv = c0p + (long long)v * p.sV; double l_, r_;
+        for (int v = 0; v < 5; v++) { const double *qv = c0p + (long long)v * p.sV; double l_, r_;
           weno5_edges_fast(qv[-2 * n], qv[-n], qv[0], qv[n], qv[2 * n], l_, r_); we[v] = l_; }
-        Rr = we[idR]; Ru = we[idU]; Rt = we[idT];
       }
+      double Lv[5];
+#pragma unroll
+      for (int v = 0; v < 5; v++) Lv[v] = from_west<N1>(ee[v], lane, n);       // west neighbour's east-edge values
+      double Lr = Lv[idR], Lu = Lv[idU], Lt = Lv[idT], Rr = we[idR], Ru = we[idU], Rt = we[idT];
       if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; }
       if (bcmode == 2) { Rr = Lr; Ru = Lu; Rt = Lt; }
       double fn, fT;
@@ -258,28 +327,21 @@ __global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict
       if (bcmode == 1) up = 1;
       if (bcmode == 2) up = 0;
       fxs[idR] = fs.m_upw; fxs[idU] = fn; fxs[idT] = fT;
-      {
-        double Lv = from_west<N1>(ee[idV], lane, n), Lw = from_west<N1>(ee[idW], lane, n);
-        fxs[idV] = fs.m_upw * (up ? we[idV] : Lv);
-        fxs[idW] = fs.m_upw * (up ? we[idW] : Lw);
-      }
-      double *fx = FX + (long long)k * p.fxK + (long long)j * p.fxJ + q;
-      const bool st = owns_face && (owns_cell || q >= NXI);
-#pragma unroll
-      for (int v = 5; v < V; v++) {
-        double Lq = from_west<N1>(ee[v], lane, n);
-        double fl = fs.m_upw * (up ? we[v] : Lq);
-        if (st) fx[(long long)v * p.fxV] = fl;
+      fxs[idV] = fs.m_upw * (up ? we[idV] : Lv[idV]);
+      fxs[idW] = fs.m_upw * (up ? we[idW] : Lv[idW]);
+      if (g.owns_face && (g.owns_cell || q >= NXI)) {
+        const long long fo = (long long)k * p.fxK + (long long)j * p.fxJ + q;
+        FX[fo] = fs.m_upw;  UPX[fo] = (unsigned char)up;
       }
     }
     // ------------------------------------------------ Z direction: reconstruct cell k, solve face k
-    double be[V], te[V];
+    double be[5], te[5];
     if (!top) {
 #pragma unroll
-      for (int v = 0; v < V; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be[v], te[v]);
+      for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be[v], te[v]);
     } else {
 #pragma unroll
-      for (int v = 0; v < V; v++) { be[v] = 0; te[v] = 0; }
+      for (int v = 0; v < 5; v++) { be[v] = 0; te[v] = 0; }
     }
     double fzs[5];
 #pragma unroll
@@ -287,10 +349,10 @@ __global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict
     if (zface) {
       const double hyr = p.hye[k * n + e], hyt = p.hyte[k * n + e], p0 = p.p0e[k * n + e], ihyt = p.ihyte[k * n + e];
       double Lr = ct[idR], Lu = ct[idW], Lt = ct[idT], Rr = be[idR], Ru = be[idW], Rt = be[idT];
-      bool zero = false; int bcmode = 0;
+      int bcmode = 0;
       if (k == 0) bcmode = 1;                                  // :1020-1038 wall/open edge-value rule
       if (top) bcmode = 2;
-      if (bcmode) zero = (p.bc_z == MW_BC_WALL);
+      const bool zero = bcmode && (p.bc_z == MW_BC_WALL);
       if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; }
       if (bcmode == 2) { Rr = Lr; Ru = Lu; Rt = Lt; }
       double fn, fT;
@@ -301,11 +363,9 @@ __global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict
       fzs[idR] = fs.m_upw; fzs[idW] = fn; fzs[idT] = fT;
       fzs[idU] = fs.m_upw * (up ? be[idU] : ct[idU]);
       fzs[idV] = fs.m_upw * (up ? be[idV] : ct[idV]);
-      double *fz = FZ + (long long)k * p.fzK + (long long)j * p.fzJ + q;
-#pragma unroll
-      for (int v = 5; v < V; v++) {
-        double fl = fs.m_upw * (up ? be[v] : ct[v]);
-        if (owns_cell) fz[(long long)v * p.fzV] = fl;
+      if (g.owns_cell) {
+        const long long fo = (long long)k * p.fzK + (long long)j * p.fzJ + q;
+        FZ[fo] = fs.m_upw;  UPZ[fo] = (unsigned char)up;
       }
     }
     // ------------------------------------------------ finalise cell k-1 (it now has its upper z face)
@@ -318,7 +378,7 @@ __global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict
       double imm_coef = 0;
       if (p.use_immersed) { double tau = 1.e3 * dt_stage; imm_coef = -fmin(1.0, dt_stage / tau); }
       const double ru_s = w[idU][wi] * rho_s, rv_s = w[idV][wi] * rho_s;
-      double rho_new = 1.0;
+      double inv_rho_new = 1.0;
       double *so = Sout + slab0 + (long long)(kc + p.HZ) * p.sK;
 #pragma unroll
       for (int l = 0; l < 5; l++) {
@@ -327,7 +387,7 @@ __global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict
         double q_n;
         if (STAGE == 1) q_n = q_s;
         else q_n = (l == idR || l == idT) ? snv[l] : snv[l] * rho_n;
-        double tend = xpart[l] - (fzs[l] - fzprev[l]) / p.dz;
+        double tend = xpart[l] - (fzs[l] - fzprev[l]) * p.rdz;
         if (l == idW && p.enable_gravity) tend += -p.grav * rho_s;
         if (l == idU) tend += p.fcor * rv_s;
         if (l == idV) tend -= p.fcor * ru_s;
@@ -337,8 +397,8 @@ __global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict
         if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
         else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
         else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
-        if (l == idR) rho_new = qnew + hyc;
-        if (owns_cell) so[(long long)l * p.sV] = (l == idR || l == idT) ? qnew : qnew / rho_new;
+        if (l == idR) inv_rho_new = fast_rcp(qnew + hyc);
+        if (g.owns_cell) so[(long long)l * p.sV] = (l == idR || l == idT) ? qnew : qnew * inv_rho_new;
       }
     }
     // ------------------------------------------------ carries for the next level
@@ -346,14 +406,78 @@ __global__ __launch_bounds__(256) void k_pass_xz(DyP p, const double *__restrict
 #pragma unroll
       for (int l = 0; l < 5; l++) {
         double fe = from_east<N1>(fxs[l], lane, n);
-        xpart[l] = -(fe - fxs[l]) / p.dx + tyv[l];
+        xpart[l] = -(fe - fxs[l]) * p.rdx + tyv[l];
       }
     }
 #pragma unroll
     for (int l = 0; l < 5; l++) fzprev[l] = fzs[l];
     if (!top) {
 #pragma unroll
-      for (int v = 0; v < V; v++) {
+      for (int v = 0; v < 5; v++) {
+        ct[v] = te[v];
+        w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
+      }
+    }
+  }
+}
+
+// XZ pass, tracers.
+template <int T, bool N1>
+__global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restrict__ S, double *__restrict__ FX,
+                                                    double *__restrict__ FZ, const unsigned char *__restrict__ UPX,
+                                                    const unsigned char *__restrict__ UPZ, int chunk, int tiles_x, int t0) {
+  const XzGeom g = xz_geom<N1>(p, chunk, tiles_x);
+  if (!g.valid) return;
+  const int n = g.n, lane = g.lane, NXI = g.NXI, j = g.j, q = g.q;
+  const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qq;
+  const bool st_x = g.owns_face && (g.owns_cell || q >= NXI);
+  const long long fxo = (long long)j * p.fxJ + (st_x ? q : 0);
+  const long long fzo = (long long)j * p.fzJ + g.qc;
+  double w[T][5], nxt[T], ct[T];
+#pragma unroll
+  for (int v = 0; v < T; v++) {
+    ct[v] = 0;
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(g.kstart - 2 + s + p.HZ) * p.sK];
+  }
+  for (int k = g.kstart; k <= g.kb; k++) {
+    const bool top = (k == p.nz);
+    const bool xwork = (k >= g.ka) && (k < g.kb);
+    const bool zface = (k >= g.ka);
+    const int kn = min(k + 3, p.nz + p.HZ - 1);
+#pragma unroll
+    for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
+    double mx = 0, mz = 0; int upx = 0, upz = 0;
+    if (xwork) { mx = FX[(long long)k * p.fxK + fxo]; upx = UPX[(long long)k * p.fxK + fxo]; }
+    if (zface) { mz = FZ[(long long)k * p.fzK + fzo]; upz = UPZ[(long long)k * p.fzK + fzo]; }
+    if (xwork) {
+      const bool quirk = bc_mode_x(p, g.i) == 3;
+#pragma unroll
+      for (int v = 0; v < T; v++) {
+        double c0 = w[v][2];
+        double m1 = from_west<N1>(c0, lane, n), p1 = from_east<N1>(c0, lane, n);
+        double m2 = N1 ? from_west<N1>(m1, lane, n) : shfl_from(c0, lane - 2 * n);
+        double p2 = N1 ? from_east<N1>(p1, lane, n) : shfl_from(c0, lane + 2 * n);
+        double we, ee;
+        weno5_edges_fast(m2, m1, c0, p1, p2, we, ee);
+        if (__builtin_expect(quirk, 0)) {
+          const double *qv = col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK - (long long)p.nx * n; double r_;
+          weno5_edges_fast(qv[-2 * n], qv[-n], qv[0], qv[n], qv[2 * n], we, r_);
+        }
+        double Lq = from_west<N1>(ee, lane, n);
+        if (st_x) FX[(long long)(5 + t0 + v) * p.fxV + (long long)k * p.fxK + fxo] = mx * (upx ? we : Lq);
+      }
+    }
+    double te[T];
+#pragma unroll
+    for (int v = 0; v < T; v++) {
+      double be = 0; te[v] = 0;
+      if (!top) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be, te[v]);
+      if (zface && g.owns_cell) FZ[(long long)(5 + t0 + v) * p.fzV + (long long)k * p.fzK + fzo] = mz * (upz ? be : ct[v]);
+    }
+    if (!top) {
+#pragma unroll
+      for (int v = 0; v < T; v++) {
         ct[v] = te[v];
         w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
       }
@@ -386,19 +510,20 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
   const double rho_s = Sstar[so + idR * p.sV] + hyc;
   const double rho_n = (STAGE == 1) ? rho_s : Sn[so + idR * p.sV] + hyc;
   const double rho_new = Sout[so + idR * p.sV] + hyc;
+  const double inv_rho_new = fast_rcp(rho_new);
   double rho_dry = rho_new, rho_v = 0;
   for (int l = 5; l < p.V; l++) {
     double q_s = Sstar[so + l * p.sV] * rho_s;
     double q_n = (STAGE == 1) ? q_s : Sn[so + l * p.sV] * rho_n;
-    double tend = -(fx[l * p.fxV + p.nens] - fx[l * p.fxV]) / p.dx
-                  -(fy[l * p.fyV + p.fyJ ] - fy[l * p.fyV]) / p.dy
-                  -(fz[l * p.fzV + p.fzK ] - fz[l * p.fzV]) / p.dz;
+    double tend = -(fx[l * p.fxV + p.nens] - fx[l * p.fxV]) * p.rdx
+                  -(fy[l * p.fyV + p.fyJ ] - fy[l * p.fyV]) * p.rdy
+                  -(fz[l * p.fzV + p.fzK ] - fz[l * p.fzV]) * p.rdz;
     double qnew;
     if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
     else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
     else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
     if ((p.pos_mask >> (l - 5)) & 1u) qnew = fmax(0.0, qnew);
-    if (MODE == 0) Sout[so + l * p.sV] = qnew / rho_new;
+    if (MODE == 0) Sout[so + l * p.sV] = qnew * inv_rho_new;
     else {
       c.tr[l - 5][ci] = qnew;
       if (l - 5 == p.idWV) rho_v = qnew;
