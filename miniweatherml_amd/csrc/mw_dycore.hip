@@ -37,6 +37,7 @@ struct DyP {                      // kernel parameter block (by value)
   long long nC;                   // nz*ny*nx*nens
   long long fxJ, fxK, fxV, fyJ, fyK, fyV, fzJ, fzK, fzV;   // flux strides
   int sim2d, bc_x, bc_y, bc_z, px, py, nproc_x, nproc_y;
+  int v0;                         // halo/pack kernels: index of the first variable of the group being processed
   int enable_gravity, use_immersed, idWV;
   unsigned pos_mask, mass_mask;
   double dx, dy, dz, rdx, rdy, rdz, C0, gamma, grav, fcor, R_d, R_v;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void k_halo_x(DyP p, double *__restrict__ S) {
     int src = lo ? ih + p.nx : ih - p.nx;
     val = row[(long long)src * p.nens];
   } else {                                          // :782-803 (both sides, two independent ifs)
-    if (v == idU && p.bc_x == MW_BC_WALL) val = 0;
+    if (v + p.v0 == idU && p.bc_x == MW_BC_WALL) val = 0;
     else val = row[(long long)(lo ? p.HX : p.HX + p.nx - 1) * p.nens];
   }
   row[(long long)ih * p.nens] = val;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void k_halo_y(DyP p, double *__restrict__ S) {
     int src = lo ? jh + p.ny : jh - p.ny;
     val = col[(long long)src * p.sJ];
   } else {                                          // :804-825
-    if (v == idV && p.bc_y == MW_BC_WALL) val = 0;
+    if (v + p.v0 == idV && p.bc_y == MW_BC_WALL) val = 0;
     else val = col[(long long)(lo ? p.HY : p.HY + p.ny - 1) * p.sJ];
   }
   col[(long long)jh * p.sJ] = val;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void k_halo_z(DyP p, double *__restrict__ S) {
   int lo = h < p.HZ;
   int kh = lo ? h : p.nz + h;
   double val;
-  if (v == idW && p.bc_z == MW_BC_WALL) val = 0;
+  if (v + p.v0 == idW && p.bc_z == MW_BC_WALL) val = 0;
   else val = col[(long long)(lo ? p.HZ : p.HZ + p.nz - 1) * p.sK];
   col[(long long)kh * p.sK] = val;
 }
@@ -691,9 +692,14 @@ struct mw_dycore_s {
   unsigned char pos[MW_MAX_TRACERS], adds[MW_MAX_TRACERS];
   hipStream_t stream;
   DyP p;
-  double *S0 = nullptr, *S1 = nullptr, *S2 = nullptr;   // q^n and two stage slabs (rotated, never aliased in a launch)
+  double *S0 = nullptr, *S1 = nullptr, *S2 = nullptr, *S3 = nullptr;   // q^n and three stage slabs (rotated, never aliased)
+  double *M[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};          // upwind mass flux of every x/y/z face,
+  unsigned char *UP[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // upwind selector; double-buffered by stage parity
+  hipStream_t tstream = nullptr;                        // tracer pipeline (runs one stage behind / beside the state pipeline)
+  hipEvent_t ev_state[8] = {nullptr}, ev_tr[8] = {nullptr}, ev_misc = nullptr;
+  long long gstage = 0;                                 // global stage counter (event ring index, buffer parity)
+  int overlap = 1;
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
-  unsigned char *UPX = nullptr, *UPY = nullptr, *UPZ = nullptr;   // upwind selector of every x / y / z face
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
   int chunk_y = 0, chunk_z = 0;
@@ -704,8 +710,8 @@ struct mw_dycore_s {
   int strict = 0;
   // halo exchange
   mw_exchange_fn xchg = nullptr; void *xchg_ctx = nullptr;
-  double *bufs[8] = {nullptr};               // sW sE sS sN rW rE rS rN
-  long long nWE = 0, nSN = 0;
+  double *bufs[2][8] = {{nullptr}, {nullptr}};   // [group: 0 state (or all), 1 tracers][sW sE sS sN rW rE rS rN]
+  long long nWE1 = 0, nSN1 = 0;                  // per variable
   // profiling
   int prof = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[8];
@@ -728,6 +734,7 @@ static void fill_params(mw_dycore_s *d) {
   p.fxJ = (long long)(g.nx + 1) * g.nens; p.fxK = (long long)g.ny * p.fxJ;       p.fxV = (long long)g.nz * p.fxK;
   p.fyJ = (long long)g.nx * g.nens;       p.fyK = (long long)(g.ny + 1) * p.fyJ; p.fyV = (long long)g.nz * p.fyK;
   p.fzJ = (long long)g.nx * g.nens;       p.fzK = (long long)g.ny * p.fzJ;       p.fzV = (long long)(g.nz + 1) * p.fzK;
+  p.v0 = 0;
   p.bc_x = g.bc_x; p.bc_y = g.bc_y; p.bc_z = g.bc_z; p.px = g.px; p.py = g.py; p.nproc_x = g.nproc_x; p.nproc_y = g.nproc_y;
   p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
   p.pos_mask = 0; p.mass_mask = 0;
@@ -762,51 +769,55 @@ static int upload_background(mw_dycore_s *d) {
 }
 
 struct ProfScope {
-  mw_dycore_s *d; int which; size_t idx; bool on;
-  ProfScope(mw_dycore_s *d_, int w) : d(d_), which(w), idx(0), on(d_->prof != 0) {
+  mw_dycore_s *d; int which; size_t idx; bool on; hipStream_t st;
+  ProfScope(mw_dycore_s *d_, int w, hipStream_t st_ = nullptr) : d(d_), which(w), idx(0), on(d_->prof != 0), st(st_ ? st_ : d_->stream) {
     if (!on) return;
     if (d->ev_used[which] == d->ev[which].size()) {
       hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); d->ev[which].push_back({a, b});
     }
     idx = d->ev_used[which]++;
-    (void)hipEventRecord(d->ev[which][idx].first, d->stream);
+    (void)hipEventRecord(d->ev[which][idx].first, st);
   }
-  ~ProfScope() { if (on) (void)hipEventRecord(d->ev[which][idx].second, d->stream); }
+  ~ProfScope() { if (on) (void)hipEventRecord(d->ev[which][idx].second, st); }
 };
 
-// halo fill of one slab: neighbour exchange (or self wrap) in x/y, then BCs -- replaces halo_exchange (:574-827)
-static int halo_fill(mw_dycore_s *d, double *S) {
-  ProfScope ps(d, 3);
-  const DyP &p = d->p;
+// halo fill of variables [v0, v0+nv) of one slab: neighbour exchange (or self wrap) in x/y, then BCs -- replaces
+// halo_exchange (:574-827).  `grp` selects the pack-buffer set (0: state or all variables, 1: tracers).
+static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hipStream_t st = nullptr, int grp = 0) {
+  if (!st) st = d->stream;
+  if (nv < 0) nv = d->p.V;
+  if (nv == 0) return 0;
+  ProfScope ps(d, 3, st);
+  DyP q = d->p;
+  q.v0 = v0; q.V = nv;
+  double *S = Sbase + (long long)v0 * q.sV;
+  const DyP &p = q;
   bool ex_x = d->xchg && (p.nproc_x > 1), ex_y = d->xchg && (p.nproc_y > 1) && !p.sim2d;
+  long long nWE = d->nWE1 * nv, nSN = d->nSN1 * nv;
+  double **bf = d->bufs[grp];
   if (ex_x || ex_y) {
     // a rank grid with more than one rank in a direction: ship 3-cell strips to the face neighbours.
     // Directions with a single rank still wrap locally below.
-    if (ex_x) { hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((d->nWE + 255) / 256)), dim3(256), 0, d->stream, p, S, d->bufs[0], d->bufs[1]); MW_LAUNCH_CHECK(); }
-    if (ex_y) { hipLaunchKernelGGL(k_pack_y, dim3((unsigned)((d->nSN + 255) / 256)), dim3(256), 0, d->stream, p, S, d->bufs[2], d->bufs[3]); MW_LAUNCH_CHECK(); }
-    int rc = d->xchg(d->xchg_ctx, ex_x ? d->bufs[0] : nullptr, ex_x ? d->bufs[1] : nullptr, ex_y ? d->bufs[2] : nullptr,
-                     ex_y ? d->bufs[3] : nullptr, ex_x ? d->bufs[4] : nullptr, ex_x ? d->bufs[5] : nullptr,
-                     ex_y ? d->bufs[6] : nullptr, ex_y ? d->bufs[7] : nullptr, ex_x ? d->nWE : 0, ex_y ? d->nSN : 0, d->stream);
+    if (ex_x) { hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((nWE + 255) / 256)), dim3(256), 0, st, p, S, bf[0], bf[1]); MW_LAUNCH_CHECK(); }
+    if (ex_y) { hipLaunchKernelGGL(k_pack_y, dim3((unsigned)((nSN + 255) / 256)), dim3(256), 0, st, p, S, bf[2], bf[3]); MW_LAUNCH_CHECK(); }
+    int rc = d->xchg(d->xchg_ctx, ex_x ? bf[0] : nullptr, ex_x ? bf[1] : nullptr, ex_y ? bf[2] : nullptr, ex_y ? bf[3] : nullptr,
+                     ex_x ? bf[4] : nullptr, ex_x ? bf[5] : nullptr, ex_y ? bf[6] : nullptr, ex_y ? bf[7] : nullptr, ex_x ? nWE : 0,
+                     ex_y ? nSN : 0, st);
     if (rc) MW_FAIL("halo exchange callback failed");
-    if (ex_x) { hipLaunchKernelGGL(k_unpack_x, dim3((unsigned)((d->nWE + 255) / 256)), dim3(256), 0, d->stream, p, S, d->bufs[4], d->bufs[5]); MW_LAUNCH_CHECK(); }
-    if (ex_y) { hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((d->nSN + 255) / 256)), dim3(256), 0, d->stream, p, S, d->bufs[6], d->bufs[7]); MW_LAUNCH_CHECK(); }
+    if (ex_x) { hipLaunchKernelGGL(k_unpack_x, dim3((unsigned)((nWE + 255) / 256)), dim3(256), 0, st, p, S, bf[4], bf[5]); MW_LAUNCH_CHECK(); }
+    if (ex_y) { hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((nSN + 255) / 256)), dim3(256), 0, st, p, S, bf[6], bf[7]); MW_LAUNCH_CHECK(); }
   }
   // local wrap / BC:  x when this direction has one rank (periodic self-wrap) or a non-periodic BC on an edge rank
-  {
-    DyP q = p;
-    bool local_x = !ex_x;
-    if (local_x) {
-      long long n = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens;
-      hipLaunchKernelGGL(k_halo_x, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, q, S); MW_LAUNCH_CHECK();
-    } else if (p.bc_x != MW_BC_PERIODIC) MW_FAIL("wall/open bc_x with nproc_x > 1 is not implemented");
-    bool local_y = !ex_y && !p.sim2d;
-    if (local_y) {
-      long long n = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
-      hipLaunchKernelGGL(k_halo_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, q, S); MW_LAUNCH_CHECK();
-    } else if (!p.sim2d && p.bc_y != MW_BC_PERIODIC) MW_FAIL("wall/open bc_y with nproc_y > 1 is not implemented");
-    long long n = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
-    hipLaunchKernelGGL(k_halo_z, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, q, S); MW_LAUNCH_CHECK();
-  }
+  if (!ex_x) {
+    long long n = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens;
+    hipLaunchKernelGGL(k_halo_x, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, S); MW_LAUNCH_CHECK();
+  } else if (p.bc_x != MW_BC_PERIODIC) MW_FAIL("wall/open bc_x with nproc_x > 1 is not implemented");
+  if (!ex_y && !p.sim2d) {
+    long long n = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
+    hipLaunchKernelGGL(k_halo_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, S); MW_LAUNCH_CHECK();
+  } else if (!p.sim2d && p.bc_y != MW_BC_PERIODIC) MW_FAIL("wall/open bc_y with nproc_y > 1 is not implemented");
+  long long n = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
+  hipLaunchKernelGGL(k_halo_z, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, S); MW_LAUNCH_CHECK();
   return 0;
 }
 
@@ -821,13 +832,14 @@ static int launch_flux(mw_dycore_s *d, const double *S) {
   return 0;
 }
 
-static int launch_fct(mw_dycore_s *d, const double *S, double dt) {
+static int launch_fct(mw_dycore_s *d, const double *S, double dt, hipStream_t st = nullptr) {
   const DyP &p = d->p;
+  if (!st) st = d->stream;
   if (p.nt == 0 || p.pos_mask == 0) return 0;
-  ProfScope ps(d, 1);
+  ProfScope ps(d, 1, st);
   dim3 grid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz, p.nt);
-  if (d->strict == 1) hipLaunchKernelGGL(k_fct<false>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ, dt);
-  else                hipLaunchKernelGGL(k_fct<true>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ, dt);
+  if (d->strict == 1) hipLaunchKernelGGL(k_fct<false>, grid, dim3(256), 0, st, p, S, d->FX, d->FY, d->FZ, dt);
+  else                hipLaunchKernelGGL(k_fct<true>, grid, dim3(256), 0, st, p, S, d->FX, d->FY, d->FZ, dt);
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -852,32 +864,33 @@ static int pick_chunk(int n, long long base_waves, const char *env) {
   return std::min(n, 8);
 }
 
-static int launch_y_state(mw_dycore_s *d, const double *S) {
+static int launch_y_state(mw_dycore_s *d, const double *S, int par) {
   const DyP &p = d->p;
   if (p.sim2d) return 0;
   ProfScope ps(d, 5);
   long long threads = (long long)p.nz * p.nx * p.nens;
   int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = pick_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y"));
   dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
-  hipLaunchKernelGGL(k_y_state, grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, d->tendY, chunk);
+  hipLaunchKernelGGL(k_y_state, grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk);
   MW_LAUNCH_CHECK();
   return 0;
 }
 
-static int launch_y_tracers(mw_dycore_s *d, const double *S) {
+static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_t st) {
   const DyP &p = d->p;
   if (p.sim2d) return 0;
-  ProfScope ps(d, 6);
+  ProfScope ps(d, 6, st);
   long long threads = (long long)p.nz * p.nx * p.nens;
   int chunk = d->chunk_y;
   dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
   for (int t0 = 0; t0 < p.nt; t0 += 4) {
     int cnt = std::min(4, p.nt - t0);
+    const double *M = d->M[par][1]; const unsigned char *U = d->UP[par][1];
     switch (cnt) {
-      case 1: hipLaunchKernelGGL((k_y_tracers<1>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, chunk, t0); break;
-      case 2: hipLaunchKernelGGL((k_y_tracers<2>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, chunk, t0); break;
-      case 3: hipLaunchKernelGGL((k_y_tracers<3>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, chunk, t0); break;
-      default: hipLaunchKernelGGL((k_y_tracers<4>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->UPY, chunk, t0); break;
+      case 1: hipLaunchKernelGGL((k_y_tracers<1>), grid, dim3(256), 0, st, p, S, d->FY, M, U, chunk, t0); break;
+      case 2: hipLaunchKernelGGL((k_y_tracers<2>), grid, dim3(256), 0, st, p, S, d->FY, M, U, chunk, t0); break;
+      case 3: hipLaunchKernelGGL((k_y_tracers<3>), grid, dim3(256), 0, st, p, S, d->FY, M, U, chunk, t0); break;
+      default: hipLaunchKernelGGL((k_y_tracers<4>), grid, dim3(256), 0, st, p, S, d->FY, M, U, chunk, t0); break;
     }
     MW_LAUNCH_CHECK();
   }
@@ -896,41 +909,42 @@ static int xz_grid(mw_dycore_s *d, dim3 &grid, int &chunk, int &tiles_x) {
 }
 
 template <int STAGE>
-static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn) {
+static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn, int par) {
   const DyP &p = d->p;
   ProfScope ps(d, 0);
   dim3 grid; int chunk, tiles_x;
   if (xz_grid(d, grid, chunk, tiles_x)) return 1;
-  if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->FX, d->FZ, d->UPX,
-                                      d->UPZ, d->tendY, dt_stage, dt_dyn, chunk, tiles_x);
-  else             hipLaunchKernelGGL((k_xz_state<STAGE, false>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->FX, d->FZ, d->UPX,
-                                      d->UPZ, d->tendY, dt_stage, dt_dyn, chunk, tiles_x);
+  if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
+                                      d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x);
+  else             hipLaunchKernelGGL((k_xz_state<STAGE, false>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
+                                      d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x);
   MW_LAUNCH_CHECK();
   return 0;
 }
 
 template <int T, bool N1>
-static void launch_xz_tracers_t(mw_dycore_s *d, const double *S, dim3 grid, int chunk, int tiles_x, int t0) {
-  hipLaunchKernelGGL((k_xz_tracers<T, N1>), grid, dim3(256), 0, d->stream, d->p, S, d->FX, d->FZ, d->UPX, d->UPZ, chunk, tiles_x, t0);
+static void launch_xz_tracers_t(mw_dycore_s *d, const double *S, dim3 grid, int chunk, int tiles_x, int t0, int par, hipStream_t st) {
+  hipLaunchKernelGGL((k_xz_tracers<T, N1>), grid, dim3(256), 0, st, d->p, S, d->FX, d->FZ, d->M[par][0], d->M[par][2], d->UP[par][0],
+                     d->UP[par][2], chunk, tiles_x, t0);
 }
 
-static int launch_xz_tracers(mw_dycore_s *d, const double *S) {
+static int launch_xz_tracers(mw_dycore_s *d, const double *S, int par, hipStream_t st) {
   const DyP &p = d->p;
-  ProfScope ps(d, 7);
+  ProfScope ps(d, 7, st);
   dim3 grid; int chunk, tiles_x;
   if (xz_grid(d, grid, chunk, tiles_x)) return 1;
   for (int t0 = 0; t0 < p.nt; t0 += 4) {
     int cnt = std::min(4, p.nt - t0);
     if (p.nens == 1) {
-      switch (cnt) { case 1: launch_xz_tracers_t<1, true>(d, S, grid, chunk, tiles_x, t0); break;
-                     case 2: launch_xz_tracers_t<2, true>(d, S, grid, chunk, tiles_x, t0); break;
-                     case 3: launch_xz_tracers_t<3, true>(d, S, grid, chunk, tiles_x, t0); break;
-                     default: launch_xz_tracers_t<4, true>(d, S, grid, chunk, tiles_x, t0); break; }
+      switch (cnt) { case 1: launch_xz_tracers_t<1, true>(d, S, grid, chunk, tiles_x, t0, par, st); break;
+                     case 2: launch_xz_tracers_t<2, true>(d, S, grid, chunk, tiles_x, t0, par, st); break;
+                     case 3: launch_xz_tracers_t<3, true>(d, S, grid, chunk, tiles_x, t0, par, st); break;
+                     default: launch_xz_tracers_t<4, true>(d, S, grid, chunk, tiles_x, t0, par, st); break; }
     } else {
-      switch (cnt) { case 1: launch_xz_tracers_t<1, false>(d, S, grid, chunk, tiles_x, t0); break;
-                     case 2: launch_xz_tracers_t<2, false>(d, S, grid, chunk, tiles_x, t0); break;
-                     case 3: launch_xz_tracers_t<3, false>(d, S, grid, chunk, tiles_x, t0); break;
-                     default: launch_xz_tracers_t<4, false>(d, S, grid, chunk, tiles_x, t0); break; }
+      switch (cnt) { case 1: launch_xz_tracers_t<1, false>(d, S, grid, chunk, tiles_x, t0, par, st); break;
+                     case 2: launch_xz_tracers_t<2, false>(d, S, grid, chunk, tiles_x, t0, par, st); break;
+                     case 3: launch_xz_tracers_t<3, false>(d, S, grid, chunk, tiles_x, t0, par, st); break;
+                     default: launch_xz_tracers_t<4, false>(d, S, grid, chunk, tiles_x, t0, par, st); break; }
     }
     MW_LAUNCH_CHECK();
   }
@@ -938,37 +952,55 @@ static int launch_xz_tracers(mw_dycore_s *d, const double *S) {
 }
 
 template <int STAGE, int MODE>
-static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const double *Sn, double *Sout, double dt_dyn, const CouplerPtrs &c) {
-  ProfScope ps(d, 2);
+static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const double *Sn, double *Sout, double dt_dyn, const CouplerPtrs &c,
+                                hipStream_t st) {
+  ProfScope ps(d, 2, st);
   const DyP &p = d->p;
   dim3 grid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
-  hipLaunchKernelGGL((k_tracer_update<STAGE, MODE>), grid, dim3(256), 0, d->stream, p, Sstar, Sn, Sout, d->FX, d->FY, d->FZ, dt_dyn, c);
+  hipLaunchKernelGGL((k_tracer_update<STAGE, MODE>), grid, dim3(256), 0, st, p, Sstar, Sn, Sout, d->FX, d->FY, d->FZ, dt_dyn, c);
   MW_LAUNCH_CHECK();
   return 0;
 }
 
-// One SSPRK3 sub-cycle on the production path (shared reconstruction, state fluxes never materialised).
-// Slabs: P = q^n, A, B scratch; on return the new q^n is in A (caller swaps).
-template <int STAGE>
-static int rk_stage_march(mw_dycore_s *d, const double *Sin, const double *Sn, double *Sout, double dt_stage, double dt_dyn) {
-  if (halo_fill(d, const_cast<double *>(Sin))) return 1;
-  if (launch_y_state(d, Sin)) return 1;                                   // y faces: m_upw, selector, y tendencies
-  if (launch_xz_state<STAGE>(d, Sin, Sn, Sout, dt_stage, dt_dyn)) return 1;   // x,z faces + finished state variables
-  if (launch_y_tracers(d, Sin)) return 1;                                 // tracer fluxes (public arrays)
-  if (launch_xz_tracers(d, Sin)) return 1;
-  if (launch_fct(d, Sin, dt_stage)) return 1;                             // D10
+// ---------------------------------------------------------------------------------------------------------------------
+// One RK stage on the production path, as two pipelines on two HIP streams:
+//   state stream  (the handle's stream): halo(state vars) -> k_y_state -> k_xz_state        [fp64-VALU bound]
+//   tracer stream (side stream)        : halo(tracers) -> k_y_tracers -> k_xz_tracers -> k_fct -> k_tracer_update  [HBM/latency bound]
+// The state variables of stage s+1 depend only on the state variables of stage s, so the state pipeline runs ahead
+// while the tracer pipeline of stage s fills the memory system beside it.  Hand-offs: the tracer kernels need the
+// mass fluxes / selectors / new density of their stage (event ev_state); the state pipeline may not run more than
+// one stage ahead because the M/UP buffers are double-buffered and the four slabs rotate (event ev_tr of stage s-2).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int STAGE, int MODE>
+static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double *Sout, double dt_stage, double dt_dyn,
+                          const CouplerPtrs &c) {
+  const long long gs = d->gstage++;
+  const int par = (int)(gs & 1), slot = (int)(gs & 7);
+  hipStream_t ss = d->stream, ts = d->overlap ? d->tstream : d->stream;
+  const int T = d->p.nt;
+  if (d->overlap && gs >= 2) MW_HIP(hipStreamWaitEvent(ss, d->ev_tr[(gs - 2) & 7], 0));
+  // ---- state pipeline
+  if (halo_fill(d, Sin, 0, 5, ss, 0)) return 1;
+  if (launch_y_state(d, Sin, par)) return 1;                                  // y faces: m_upw, selector, y tendencies
+  if (launch_xz_state<STAGE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par)) return 1;   // x,z faces + finished state variables
+  if (d->overlap) { MW_HIP(hipEventRecord(d->ev_state[slot], ss)); MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0)); }
+  // ---- tracer pipeline
+  if (halo_fill(d, Sin, 5, T, ts, 1)) return 1;
+  if (launch_y_tracers(d, Sin, par, ts)) return 1;                            // tracer fluxes (public arrays)
+  if (launch_xz_tracers(d, Sin, par, ts)) return 1;
+  if (launch_fct(d, Sin, dt_stage, ts)) return 1;                             // D10
+  if (launch_tracer_update<STAGE, MODE>(d, Sin, Sn, Sout, dt_dyn, c, ts)) return 1;
+  if (d->overlap) MW_HIP(hipEventRecord(d->ev_tr[slot], ts));
   return 0;
 }
-static int rk_cycle_march(mw_dycore_s *d, double *P, double *A, double *B, double dt_dyn, bool last, const CouplerPtrs &c) {
+// One SSPRK3 sub-cycle.  Slabs: Q[0] = q^n, Q[1..3] scratch; on return the new q^n is in Q[3] (caller rotates).
+static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, const CouplerPtrs &c) {
   const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
-  if (rk_stage_march<1>(d, P, P, A, dt_dyn, dt_dyn)) return 1;                        // stage 1 (:119-132)
-  if (launch_tracer_update<1, 0>(d, P, P, A, dt_dyn, c)) return 1;
-  if (rk_stage_march<2>(d, A, P, B, dt2, dt_dyn)) return 1;                           // stage 2 (:136-153)
-  if (launch_tracer_update<2, 0>(d, A, P, B, dt_dyn, c)) return 1;
-  if (rk_stage_march<3>(d, B, P, A, dt3, dt_dyn)) return 1;                           // stage 3 (:157-174)
-  if (last) { if (launch_tracer_update<3, 1>(d, B, P, A, dt_dyn, c)) return 1; }      // + convert_dynamics_to_coupler (:178)
-  else      { if (launch_tracer_update<3, 0>(d, B, P, A, dt_dyn, c)) return 1; }
-  d->flux_src = B; d->flux_dt = dt3;
+  if (rk_stage_march<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;                        // stage 1 (:119-132)
+  if (rk_stage_march<2, 0>(d, Q[1], Q[0], Q[2], dt2, dt_dyn, c)) return 1;                           // stage 2 (:136-153)
+  if (last) { if (rk_stage_march<3, 1>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }             // stage 3 (:157-174) + :178
+  else      { if (rk_stage_march<3, 0>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }
+  d->flux_src = Q[2]; d->flux_dt = dt3;
   return 0;
 }
 
@@ -1014,17 +1046,28 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
   size_t slab = (size_t)p.V * p.sV * sizeof(double);
   size_t fxb = (size_t)p.V * p.fxV * sizeof(double), fyb = (size_t)p.V * p.fyV * sizeof(double), fzb = (size_t)p.V * p.fzV * sizeof(double);
   if (hipMalloc(&d->S0, slab) != hipSuccess || hipMalloc(&d->S1, slab) != hipSuccess || hipMalloc(&d->S2, slab) != hipSuccess ||
+      hipMalloc(&d->S3, slab) != hipSuccess ||
       hipMalloc(&d->tendY, (size_t)5 * p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->FX, fxb) != hipSuccess ||
-      hipMalloc(&d->UPX, (size_t)p.fxV) != hipSuccess || hipMalloc(&d->UPY, (size_t)p.fyV) != hipSuccess || hipMalloc(&d->UPZ, (size_t)p.fzV) != hipSuccess ||
       hipMalloc(&d->FY, fyb) != hipSuccess || hipMalloc(&d->FZ, fzb) != hipSuccess ||
       hipMalloc(&d->imm, (size_t)p.nC * sizeof(double)) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return fail(); }
   // zero everything once: halo corners are never written and the flux arrays start at 0 (:1677-1682)
   (void)hipMemsetAsync(d->S0, 0, slab, d->stream); (void)hipMemsetAsync(d->S1, 0, slab, d->stream);
-  (void)hipMemsetAsync(d->S2, 0, slab, d->stream); (void)hipMemsetAsync(d->tendY, 0, (size_t)5 * p.nC * sizeof(double), d->stream);
+  (void)hipMemsetAsync(d->S2, 0, slab, d->stream); (void)hipMemsetAsync(d->S3, 0, slab, d->stream); (void)hipMemsetAsync(d->tendY, 0, (size_t)5 * p.nC * sizeof(double), d->stream);
   (void)hipMemsetAsync(d->FX, 0, fxb, d->stream); (void)hipMemsetAsync(d->FY, 0, fyb, d->stream); (void)hipMemsetAsync(d->FZ, 0, fzb, d->stream);
   (void)hipMemsetAsync(d->imm, 0, (size_t)p.nC * sizeof(double), d->stream);
-  d->nWE = (long long)p.V * p.nz * p.ny * p.HX * p.nens;
-  d->nSN = (long long)p.V * p.nz * p.HY * p.nx * p.nens;
+  d->nWE1 = (long long)p.nz * p.ny * p.HX * p.nens;
+  d->nSN1 = (long long)p.nz * p.HY * p.nx * p.nens;
+  {
+    const size_t fn[3] = {(size_t)p.fxV, (size_t)p.fyV, (size_t)p.fzV};
+    for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) {
+      if (hipMalloc(&d->M[b][a], fn[a] * sizeof(double)) != hipSuccess || hipMalloc(&d->UP[b][a], fn[a]) != hipSuccess) { set_error("hipMalloc(M/UP) failed"); return fail(); }
+      (void)hipMemsetAsync(d->M[b][a], 0, fn[a] * sizeof(double), d->stream); (void)hipMemsetAsync(d->UP[b][a], 0, fn[a], d->stream);
+    }
+    if (hipStreamCreateWithFlags(&d->tstream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(); }
+    for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
+                                    hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
+    if (hipEventCreateWithFlags(&d->ev_misc, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
+  }
   fill_params(d);
   if (hipStreamSynchronize(d->stream) != hipSuccess) { set_error("stream sync failed in create"); return fail(); }
   *h = d;
@@ -1034,9 +1077,13 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
 void mw_dycore_destroy(mw_dycore_t d) {
   if (!d) return;
   (void)hipStreamSynchronize(d->stream);
-  for (double *ptr : {d->S0, d->S1, d->S2, d->tendY, d->FX, d->FY, d->FZ, d->hy_dev, d->imm}) if (ptr) (void)hipFree(ptr);
-  for (unsigned char *ptr : {d->UPX, d->UPY, d->UPZ}) if (ptr) (void)hipFree(ptr);
-  for (int b = 0; b < 8; b++) if (d->bufs[b]) (void)hipFree(d->bufs[b]);
+  if (d->tstream) (void)hipStreamSynchronize(d->tstream);
+  for (double *ptr : {d->S0, d->S1, d->S2, d->S3, d->tendY, d->FX, d->FY, d->FZ, d->hy_dev, d->imm}) if (ptr) (void)hipFree(ptr);
+  for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
+  for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
+  if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
+  if (d->tstream) (void)hipStreamDestroy(d->tstream);
+  for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
   for (int w = 0; w < 8; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete d;
 }
@@ -1092,11 +1139,11 @@ int mw_dycore_set_exchange(mw_dycore_t d, mw_exchange_fn fn, void *ctx) {
   if (!d) MW_FAIL("null handle");
   d->xchg = fn; d->xchg_ctx = ctx;
   if (fn) {
-    for (int b = 0; b < 8; b++) {
-      if (d->bufs[b]) continue;
-      long long n = (b % 4 < 2) ? d->nWE : d->nSN;
+    for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) {
+      if (d->bufs[g][b]) continue;
+      long long n = ((b % 4 < 2) ? d->nWE1 : d->nSN1) * d->p.V;          // sized for all V variables
       if (n == 0) n = 1;
-      MW_HIP(hipMalloc(&d->bufs[b], (size_t)n * sizeof(double)));
+      MW_HIP(hipMalloc(&d->bufs[g][b], (size_t)n * sizeof(double)));
     }
   }
   return 0;
@@ -1131,16 +1178,19 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
   { ProfScope ps(d, 4);
     hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK(); }       // :101 (+ D2)
+  const bool march = (d->strict == 0);                        // production path; strict = 1/2 use the general
+                                                              // flux-materialising kernels below
+  d->overlap = march && d->tstream && !getenv("MW_NO_OVERLAP");
+  if (d->overlap) { MW_HIP(hipEventRecord(d->ev_misc, d->stream)); MW_HIP(hipStreamWaitEvent(d->tstream, d->ev_misc, 0)); d->gstage = 0; }
   double dt_dyn = mw_dycore_compute_time_step(&d->g);                     // :104
   int ncycles = (int)std::ceil(dt_phys / dt_dyn);                         // :107
   dt_dyn = dt_phys / ncycles;                                             // :108
-  const bool march = (d->strict == 0);                        // production path; strict = 1/2 use the general
-                                                              // flux-materialising kernels below
   for (int icycle = 0; icycle < ncycles; icycle++) {
     bool last = (icycle == ncycles - 1);
     if (march) {
-      if (rk_cycle_march(d, d->S0, d->S1, d->S2, dt_dyn, last, c)) return 1;
-      std::swap(d->S0, d->S1);                                // the new q^n
+      double *Q[4] = {d->S0, d->S1, d->S2, d->S3};
+      if (rk_cycle_march(d, Q, dt_dyn, last, c)) return 1;
+      std::swap(d->S0, d->S3);                                // (P,A,B,C) -> (C,A,B,P): the new q^n is C
       continue;
     }
     // stage 1 (:119-132)
@@ -1163,6 +1213,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     else      { if (launch_update<3, 0>(d, d->S1, d->S0, d->S0, dt3, dt_dyn, c, nullptr, nullptr)) return 1; }
     d->flux_src = nullptr;                                    // all six flux arrays are already materialised
   }
+  if (d->overlap) MW_HIP(hipStreamWaitEvent(d->stream, d->ev_tr[(d->gstage - 1) & 7], 0));   // join: the handle's stream owns the result
   d->etime += dt_phys;                                                    // :181
   return 0;
 }

@@ -101,7 +101,7 @@ __device__ __forceinline__ int bc_mode_x(const DyP &p, int i) {                 
 // Y pass, state variables.  thread = (k, interior fused-x lane), marches j over [ja-1, jb] for the chunk [ja, jb).
 // Writes FY[idR] (= m_upw), UPY (selector) for faces ja..jb and tendY (5,nz,ny,nx,nens) for rows ja..jb-1.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restrict__ S, double *__restrict__ FY,
+__global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restrict__ S, double *__restrict__ MY,
                                                  unsigned char *__restrict__ UPY, double *__restrict__ tendY, int chunk) {
   const int NXI = p.nx * p.nens;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   const double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
   const double p0 = p.p0c[k * p.nens + e], ihyt = p.ihytc[k * p.nens + e];
   const double *col = S + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;      // row j at col + (j+HY)*sJ
-  double *fy = FY + (long long)k * p.fyK + ie;                                               // face j at fy + j*fyJ
+  double *fy = MY + (long long)k * p.fyK + ie;                                               // face j at fy + j*fyJ
   unsigned char *upy = UPY + (long long)k * p.fyK + ie;
   double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
   double w[5][5], nxt[5], cn[5], fprev[5];
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 // Y pass, tracers: flux(face j) = m_upw * (up ? south edge of cell j : north edge of cell j-1)
 template <int T>
 __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restrict__ S, double *__restrict__ FY,
-                                                   const unsigned char *__restrict__ UPY, int chunk, int t0) {
+                                                   const double *__restrict__ MY, const unsigned char *__restrict__ UPY, int chunk,
+                                                   int t0) {
   const int NXI = p.nx * p.nens;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= (long long)p.nz * NXI) return;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
 #pragma unroll
     for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
     double m = 0; int up = 0;
-    if (j >= ja) { m = fy[(long long)j * p.fyJ]; up = upy[(long long)j * p.fyJ]; }
+    if (j >= ja) { m = MY[(long long)k * p.fyK + ie + (long long)j * p.fyJ]; up = upy[(long long)j * p.fyJ]; }
     double se[T], ne[T];
 #pragma unroll
     for (int v = 0; v < T; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
@@ -253,7 +254,7 @@ __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x) 
 
 template <int STAGE, bool N1>
 __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
-                                                  double *__restrict__ Sout, double *__restrict__ FX, double *__restrict__ FZ,
+                                                  double *__restrict__ Sout, double *__restrict__ MX, double *__restrict__ MZ,
                                                   unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                   const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
                                                   int tiles_x) {
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       fxs[idW] = fs.m_upw * (up ? we[idW] : Lv[idW]);
       if (g.owns_face && (g.owns_cell || q >= NXI)) {
         const long long fo = (long long)k * p.fxK + (long long)j * p.fxJ + q;
-        FX[fo] = fs.m_upw;  UPX[fo] = (unsigned char)up;
+        MX[fo] = fs.m_upw;  UPX[fo] = (unsigned char)up;
       }
     }
     // ------------------------------------------------ Z direction: reconstruct cell k, solve face k
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       fzs[idV] = fs.m_upw * (up ? be[idV] : ct[idV]);
       if (g.owns_cell) {
         const long long fo = (long long)k * p.fzK + (long long)j * p.fzJ + q;
-        FZ[fo] = fs.m_upw;  UPZ[fo] = (unsigned char)up;
+        MZ[fo] = fs.m_upw;  UPZ[fo] = (unsigned char)up;
       }
     }
     // ------------------------------------------------ finalise cell k-1 (it now has its upper z face)
@@ -424,7 +425,8 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
 // XZ pass, tracers.
 template <int T, bool N1>
 __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restrict__ S, double *__restrict__ FX,
-                                                    double *__restrict__ FZ, const unsigned char *__restrict__ UPX,
+                                                    double *__restrict__ FZ, const double *__restrict__ MX,
+                                                    const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
                                                     const unsigned char *__restrict__ UPZ, int chunk, int tiles_x, int t0) {
   const XzGeom g = xz_geom<N1>(p, chunk, tiles_x);
   if (!g.valid) return;
@@ -448,8 +450,8 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
 #pragma unroll
     for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
     double mx = 0, mz = 0; int upx = 0, upz = 0;
-    if (xwork) { mx = FX[(long long)k * p.fxK + fxo]; upx = UPX[(long long)k * p.fxK + fxo]; }
-    if (zface) { mz = FZ[(long long)k * p.fzK + fzo]; upz = UPZ[(long long)k * p.fzK + fzo]; }
+    if (xwork) { mx = MX[(long long)k * p.fxK + fxo]; upx = UPX[(long long)k * p.fxK + fxo]; }
+    if (zface) { mz = MZ[(long long)k * p.fzK + fzo]; upz = UPZ[(long long)k * p.fzK + fzo]; }
     if (xwork) {
       const bool quirk = bc_mode_x(p, g.i) == 3;
 #pragma unroll
