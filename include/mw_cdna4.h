@@ -125,6 +125,13 @@ int  mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream);
  * unnecessary (bitwise identical: reconstruction is a pure function of the 5-cell stencil).
  * The callback receives DEVICE buffers packed as (V,nz,ny,3,nens) [W/E] and (V,nz,3,nx,nens) [S/N] and must
  * deliver sendW to the west neighbour's recvE etc., ordered on `stream`.  NULL => single-rank periodic wrap. */
+/* Posting plan of one exchange (host only; single source of truth for mw_rccl.cpp and for the CPU gloo tests):
+ * peers[4] = west, east, south, north rank (neigh(1,0), neigh(1,2), neigh(0,1), neigh(2,1), :651-655);
+ * send_order[4] / recv_order[4] = directions (0 W, 1 E, 2 S, 3 N) in posting order.  Messages between one pair of
+ * ranks match in FIFO order, so when west == east (two ranks in x) or south == north the receives are posted E,W / N,S
+ * against sends W,E / S,N: the peer's first send (its W strip) is my E halo.  active[4]: direction takes part
+ * (more than one rank in that direction and, for S/N, a 3-D run). */
+int  mw_exchange_plan(const mw_grid_t *g, int *peers, int *send_order, int *recv_order, int *active);
 typedef int (*mw_exchange_fn)(void *ctx, const double *sendW, const double *sendE, const double *sendS,
                               const double *sendN, double *recvW, double *recvE, double *recvS, double *recvN,
                               long long nWE, long long nSN, void *stream);

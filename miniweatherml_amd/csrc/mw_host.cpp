@@ -62,6 +62,18 @@ int mw_default_constants(mw_grid_t *g) {
   return 0;
 }
 
+// halo_exchange's four face neighbours (dynamics_euler_stratified_wenofv.h:651-663) and a FIFO-safe posting order
+int mw_exchange_plan(const mw_grid_t *g, int *peers, int *send_order, int *recv_order, int *active) {
+  if (!g || !peers || !send_order || !recv_order || !active) MW_FAIL("mw_exchange_plan: null argument");
+  peers[0] = g->neigh[1 * 3 + 0]; peers[1] = g->neigh[1 * 3 + 2]; peers[2] = g->neigh[0 * 3 + 1]; peers[3] = g->neigh[2 * 3 + 1];
+  const int so[4] = {0, 1, 2, 3}, ro[4] = {1, 0, 3, 2};
+  for (int i = 0; i < 4; i++) { send_order[i] = so[i]; recv_order[i] = ro[i]; }
+  bool sim2d = (g->ny_glob == 1);
+  active[0] = active[1] = (g->nproc_x > 1);
+  active[2] = active[3] = (g->nproc_y > 1) && !sim2d;
+  return 0;
+}
+
 // dynamics_euler_stratified_wenofv.h:70-77
 double mw_dycore_compute_time_step(const mw_grid_t *g) {
   double dx = g->xlen / g->nx_glob, dy = g->ylen / g->ny_glob, dz = g->zlen / g->nz;   // coupler.h:262-268

@@ -18,7 +18,7 @@ struct RcclCtx {
   ncclComm_t comm = nullptr;
   hipStream_t side = nullptr;
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
-  int west, east, south, north;
+  int peers[4], send_order[4], recv_order[4], active[4];        // mw_exchange_plan
 };
 
 #define MW_NCCL(call)                                                                                   \
@@ -31,15 +31,14 @@ int rccl_exchange(void *vctx, const double *sW, const double *sE, const double *
   hipStream_t main_stream = (hipStream_t)vstream;
   MW_HIP(hipEventRecord(c->ev_ready, main_stream));          // pack kernels done
   MW_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+  const double *sbuf[4] = {sW, sE, sS, sN};
+  double *rbuf[4] = {rW, rE, rS, rN};
+  const long long cnt[4] = {nWE, nWE, nSN, nSN};
   MW_NCCL(ncclGroupStart());
-  if (nWE > 0) { MW_NCCL(ncclSend(sW, (size_t)nWE, ncclDouble, c->west, c->comm, c->side));
-                 MW_NCCL(ncclSend(sE, (size_t)nWE, ncclDouble, c->east, c->comm, c->side)); }
-  if (nSN > 0) { MW_NCCL(ncclSend(sS, (size_t)nSN, ncclDouble, c->south, c->comm, c->side));
-                 MW_NCCL(ncclSend(sN, (size_t)nSN, ncclDouble, c->north, c->comm, c->side)); }
-  if (nWE > 0) { MW_NCCL(ncclRecv(rE, (size_t)nWE, ncclDouble, c->east, c->comm, c->side));
-                 MW_NCCL(ncclRecv(rW, (size_t)nWE, ncclDouble, c->west, c->comm, c->side)); }
-  if (nSN > 0) { MW_NCCL(ncclRecv(rN, (size_t)nSN, ncclDouble, c->north, c->comm, c->side));
-                 MW_NCCL(ncclRecv(rS, (size_t)nSN, ncclDouble, c->south, c->comm, c->side)); }
+  for (int o = 0; o < 4; o++) { int dir = c->send_order[o];
+    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(ncclSend(sbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], c->comm, c->side)); }
+  for (int o = 0; o < 4; o++) { int dir = c->recv_order[o];
+    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(ncclRecv(rbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], c->comm, c->side)); }
   MW_NCCL(ncclGroupEnd());
   MW_HIP(hipEventRecord(c->ev_done, c->side));
   MW_HIP(hipStreamWaitEvent(main_stream, c->ev_done, 0));    // unpack kernels wait for the strips
@@ -69,8 +68,7 @@ int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, in
   MW_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   MW_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
   MW_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-  c->west = g.neigh[1 * 3 + 0]; c->east = g.neigh[1 * 3 + 2];          // neigh(1,0), neigh(1,2)  (:651-652)
-  c->south = g.neigh[0 * 3 + 1]; c->north = g.neigh[2 * 3 + 1];         // neigh(0,1), neigh(2,1)  (:654-655)
+  if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return 1;
   return mw_dycore_set_exchange(h, rccl_exchange, c);
 }
 

@@ -1,0 +1,132 @@
+"""CPU-only checks of the C ABI: the shared library loads, exports every symbol include/mw_cdna4.h declares, the
+host-only entry points agree with the oracle, and the device entry points fail LOUDLY without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "mw_cdna4.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mw_[a-z0-9_]+)\s*\(", txt)) - {"mw_exchange_fn"})
+
+
+def test_header_and_binding_tables_agree(mw):
+    from miniweatherml_amd import capi
+    assert header_functions() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(mw):
+    from miniweatherml_amd import capi
+    L = C.CDLL(capi.LIB_PATH)
+    for name in header_functions():
+        assert hasattr(L, name), name
+
+
+def test_no_oracle_or_cpu_fallback_in_product():
+    """The product package must never import or link the oracle."""
+    pkg = os.path.join(ROOT, "miniweatherml_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "mw_oracle" not in src and "libmw_oracle" not in src, os.path.join(dirpath, f)
+    for f in ("mw_cdna4.h",):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower()
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3, 4, 6, 8, 12, 16])
+@pytest.mark.parametrize("grid", [(100, 1), (400, 400), (1024, 1024), (37, 53), (256, 512)])
+def test_decompose_matches_oracle(mw, oracle, nranks, grid):
+    from miniweatherml_amd import capi
+    nxg, nyg = grid
+    for rank in range(nranks):
+        g = capi.Grid()
+        capi.check(capi.lib().mw_decompose(nranks, rank, nxg, nyg, C.byref(g)))
+        p, neigh = oracle.make_params(nxg, nyg, 8, nranks=nranks, rank=rank)
+        assert (g.nproc_x, g.nproc_y, g.px, g.py) == (p.nproc_x, p.nproc_y, p.px, p.py)
+        assert (g.nx, g.ny, g.i_beg, g.j_beg) == (p.nx, p.ny, p.i_beg, p.j_beg)
+        assert list(g.neigh) == neigh
+    # blocks tile the domain
+    tot = 0
+    for rank in range(nranks):
+        g = capi.Grid()
+        capi.check(capi.lib().mw_decompose(nranks, rank, nxg, nyg, C.byref(g)))
+        tot += g.nx * g.ny
+    assert tot == nxg * nyg
+
+
+def test_reference_rank_grids():
+    """1x1, 1x2, 2x2, 4x2 for 1/2/4/8 ranks in 3-D, nranks x 1 in 2-D."""
+    from miniweatherml_amd import capi
+    L = capi.lib()
+    want = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (4, 2)}
+    for n, (npx, npy) in want.items():
+        g = capi.Grid()
+        capi.check(L.mw_decompose(n, 0, 1024, 1024, C.byref(g)))
+        assert (g.nproc_x, g.nproc_y) == (npx, npy)
+        capi.check(L.mw_decompose(n, 0, 1024, 1, C.byref(g)))
+        assert (g.nproc_x, g.nproc_y) == (n, 1)
+
+
+def test_constants_and_time_step_match_oracle(mw, oracle):
+    from miniweatherml_amd import capi
+    L = capi.lib()
+    g = capi.Grid()
+    capi.check(L.mw_default_constants(C.byref(g)))
+    p, _ = oracle.make_params(200, 200, 50)
+    for k in ("R_d", "R_v", "cp_d", "cp_v", "p0", "grav", "gamma_d", "kappa_d", "C0", "earthrot", "latitude"):
+        assert getattr(g, k) == getattr(p, k), k
+    capi.check(L.mw_decompose(1, 0, 200, 200, C.byref(g)))
+    g.nz, g.xlen, g.ylen, g.zlen = 50, 1.0e5, 1.0e5, 2.0e4
+    assert L.mw_dycore_compute_time_step(C.byref(g)) == oracle.lib().mwo_compute_time_step(p) == 0.5581395348837209
+
+
+def test_exchange_plan_fifo_safe(mw):
+    from miniweatherml_amd import capi
+    L = capi.lib()
+    for nranks in (2, 4, 8):
+        for rank in range(nranks):
+            g = capi.Grid()
+            capi.check(L.mw_decompose(nranks, rank, 512, 512, C.byref(g)))
+            peers, so, ro, act = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+            capi.check(L.mw_exchange_plan(C.byref(g), peers, so, ro, act))
+            assert list(so) == [0, 1, 2, 3] and list(ro) == [1, 0, 3, 2]
+            assert list(act) == [int(g.nproc_x > 1)] * 2 + [int(g.nproc_y > 1)] * 2
+            assert peers[0] == g.neigh[3] and peers[1] == g.neigh[5] and peers[2] == g.neigh[1] and peers[3] == g.neigh[7]
+
+
+def test_device_entry_points_fail_loudly_without_gpu(mw):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from miniweatherml_amd import capi
+    L = capi.lib()
+    g = capi.Grid()
+    capi.check(L.mw_decompose(1, 0, 16, 16, C.byref(g)))
+    capi.check(L.mw_default_constants(C.byref(g)))
+    g.nz, g.nens, g.num_tracers, g.idWV = 8, 1, 3, 0
+    g.xlen, g.ylen, g.zlen = 8000., 8000., 20000.
+    g.bc_z = capi.BC_WALL
+    h = C.c_void_p()
+    rc = L.mw_dycore_create(C.byref(h), C.byref(g), bytes([1, 1, 1]), bytes([1, 1, 1]), None)
+    assert rc != 0
+    assert b"no HIP device" in L.mw_last_error()
+    with pytest.raises(capi.MWError):
+        capi.check(rc)
+
+
+def test_create_rejects_bad_grids(mw):
+    from miniweatherml_amd import capi
+    L = capi.lib()
+    g = capi.Grid()
+    capi.check(L.mw_decompose(1, 0, 16, 16, C.byref(g)))
+    capi.check(L.mw_default_constants(C.byref(g)))
+    g.nz, g.nens, g.num_tracers, g.idWV = 8, 1, 0, 0        # no water_vapor tracer
+    h = C.c_void_p()
+    assert L.mw_dycore_create(C.byref(h), C.byref(g), None, None, None) != 0
+    assert b"water_vapor" in L.mw_last_error()

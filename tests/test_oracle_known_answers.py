@@ -1,0 +1,102 @@
+"""Pins the CPU oracle on the reference-run known answers recorded in BASELINE.md section 2 / SURVEY.md 4, 8(c)
+(tests/golden/baseline_known_answers.json).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KA = json.load(open(os.path.join(HERE, "golden", "baseline_known_answers.json")))
+
+
+def serial_sum(a):
+    s = 0.0
+    for x in a.ravel().tolist():
+        s += x
+    return s
+
+
+def test_weno_ideal_weights(oracle):
+    w = oracle.weno5_ideal_weights()
+    ref = KA["weno5_ideal_weights"]
+    assert w[0] == ref["idl_L"] and w[1] == ref["idl_C"] and w[2] == ref["idl_R"] and w[3] == ref["idl_H"]
+
+
+def test_weno_step_stencil_falls_back_to_left_stencil(oracle):
+    coefs, gll = oracle.weno5(KA["weno5_step_stencil"]["stencil"])
+    ref = KA["weno5_step_stencil"]["coefs_approx"]
+    assert coefs[0] == 1.0
+    for c, r in zip(coefs[1:], ref[1:]):
+        assert abs(c - r) <= 0.06 * abs(r)            # recorded to two significant digits
+    assert gll[0] == 1.0 and gll[1] == 1.0
+
+
+def _cell_averages(poly, x0=-2.5):
+    """cell averages of a polynomial (coefficients low->high) over 5 unit cells centred at -2..2"""
+    P = np.polynomial.Polynomial(poly).integ()
+    return np.array([P(x0 + i + 1) - P(x0 + i) for i in range(5)])
+
+
+def test_weno_polynomial_exactness(oracle):
+    rng = np.random.default_rng(3)
+    for deg in (0, 1, 2):
+        for _ in range(20):
+            poly = rng.normal(size=deg + 1)
+            s = _cell_averages(poly)
+            _, gll = oracle.weno5(s)
+            P = np.polynomial.Polynomial(poly)
+            err = max(abs(gll[0] - P(-0.5)), abs(gll[1] - P(0.5))) / max(1.0, np.max(np.abs(s)))
+            assert err <= 4 * KA["weno5_polynomial_exactness"]["degree_le_2_max_error"]
+    # degree 3 and 4 at O(1) amplitude are deliberately NOT reproduced (the limiter engages)
+    for deg, order in ((3, KA["weno5_polynomial_exactness"]["degree_3_error_order"]), (4, KA["weno5_polynomial_exactness"]["degree_4_error_order"])):
+        poly = np.zeros(deg + 1); poly[deg] = 1.0
+        s = _cell_averages(poly)
+        _, gll = oracle.weno5(s)
+        P = np.polynomial.Polynomial(poly)
+        err = max(abs(gll[0] - P(-0.5)), abs(gll[1] - P(0.5)))
+        assert 0.2 * order <= err <= 5 * order
+
+
+def test_cfl_time_steps(oracle):
+    p, _ = oracle.make_params(32, 32, 16, 1, 16000., 16000., 20000.)
+    assert oracle.lib().mwo_compute_time_step(p) == KA["dt_32x32x16"]
+    p, _ = oracle.make_params(200, 200, 50, 1, 1.0e5, 1.0e5, 2.0e4)
+    assert oracle.lib().mwo_compute_time_step(p) == KA["dt_config1_200x200x50"]
+
+
+def test_supercell_32x32x16_three_steps_bitwise(oracle):
+    ref = KA["supercell_32x32x16_3steps"]
+    dyc, f = oracle.supercell_setup(32, 32, 16, 1, 16000., 16000., 20000.)
+    dt = dyc.compute_time_step()
+    assert serial_sum(f.rho_d) == ref["density_dry_sum_init"]
+    for _ in range(3):
+        dyc.time_step(f, dt)
+    assert float(f.wvel.max()) == ref["wvel_max"]
+    assert float(f.wvel.min()) == ref["wvel_min"]
+    assert float(f.temp.max()) == ref["temp_max"]
+    assert serial_sum(f.rho_d) == ref["density_dry_sum_after"]
+
+
+def test_supercell_initial_perturbations_vanish(oracle):
+    """rho' and (rho theta)' are exactly 0 after init_supercell."""
+    dyc, f = oracle.supercell_setup(12, 12, 10, 1, 6000., 6000., 20000., perturb=False)
+    hy = dyc.hy()
+    rho = f.rho_d + f.tracers[0]
+    assert np.array_equal(rho[:, 0, 0, 0], rho[:, 3, 5, 0])
+    # rho == hy_dens_cells exactly wherever the sum rho_d + rho_v rounds back (mass is carried by rho_d = rho - rho_v)
+    assert np.max(np.abs(rho[:, 0, 0, 0] - hy["hy_dens_cells"][:, 0])) <= 2e-16 * hy["hy_dens_cells"].max()
+    assert np.all(f.vvel == 0) and np.all(f.wvel == 0)
+
+
+def test_fp_literals_are_double_rounding_safe():
+    """Every `x_fp` literal of the reference goes long double -> double (main_header.h:61-63).  The HIP kernels use plain
+    double literals; this checks both routes give the same bits for every literal the oracle uses."""
+    import re
+    src = open(os.path.join(os.path.dirname(HERE), "oracle", "mw_oracle.cpp")).read()
+    lits = sorted(set(re.findall(r"FP\(([0-9.eE+-]+)\)", src)))
+    assert len(lits) > 40
+    if np.finfo(np.longdouble).nmant < 63:
+        pytest.skip("no 80-bit long double on this host")
+    for l in lits:
+        assert float(np.longdouble(l)) == float(l), l
