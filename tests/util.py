@@ -34,13 +34,46 @@ def push_fields(coupler, f):
 ABS_FLOOR = {"vvel": 1e-11, "wvel": 1e-11, "uvel": 1e-11, "tracer1": 1e-14, "tracer2": 1e-14}
 
 
-def compare_fields(got, ref, tol, what=""):
+def compare_fields(got, ref, tol, what="", sens=None):
+    """tol: relative to max|field|.  sens: optional per-field absolute sensitivity of the
+    reference ALGORITHM itself to a 1-ulp input perturbation (oracle_sensitivity below); the limit is then
+    max(tol*scale, 10*sens): an implementation cannot be asked to track the oracle more closely than the oracle tracks
+    itself across the algorithm's own branch discontinuities (`if (tot > 1.e-20)` in convexify,
+    WenoLimiter_recon.h:12-15, and the upwind selector `ind = (m_L + m_R > 0) ? 0 : 1`, :408)."""
     worst = {}
     for k in ref:
         scale = np.max(np.abs(ref[k]))
         d = np.max(np.abs(got[k] - ref[k]))
         lim = tol * scale + ABS_FLOOR.get(k, 0.0) * (tol / 1e-11)
+        if sens is not None:
+            lim = max(lim, 10.0 * sens[k])
         worst[k] = (d, scale)
         assert np.all(np.isfinite(got[k])), "%s: non-finite values in %s" % (what, k)
         assert d <= lim, "%s: field %s max|diff| %.3e > %.3e (scale %.3e)" % (what, k, d, lim, scale)
     return worst
+ABS_FLOOR.update({"tracer%d" % t: 1e-14 for t in range(3, 16)})
+
+
+_SENS_CACHE = {}
+
+
+def oracle_sensitivity(oracle, key, make, steps):
+    """Runs the CPU oracle twice from inputs that differ by ONE ULP in `temp` (random sign per cell) and returns
+    {step: {field: max|difference|}} for the requested step counts.  `make()` -> (OracleDycore, Fields)."""
+    key = (key, tuple(steps))
+    if key in _SENS_CACHE:
+        return _SENS_CACHE[key]
+    d1, f1 = make()
+    d2, f2 = make()
+    rng = np.random.default_rng(1234)
+    f2.temp *= (1.0 + np.sign(rng.normal(size=f2.temp.shape)) * 2.0 ** -52)
+    dt = d1.compute_time_step()
+    out = {}
+    for s in range(1, max(steps) + 1):
+        d1.time_step(f1, dt)
+        d2.time_step(f2, dt)
+        if s in steps:
+            a, b = f1.as_dict(), f2.as_dict()
+            out[s] = {k: float(np.max(np.abs(a[k] - b[k]))) for k in a}
+    _SENS_CACHE[key] = out
+    return out

@@ -8,14 +8,15 @@ from util import gpu_fields, push_fields
 nx, ny, nz = [int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (16, 16, 8))]
 nsteps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 xl = float(os.environ.get("XL", 500.0 * nx))
-odyc, of = O.supercell_setup(nx, ny, nz, 1, xl, xl if ny > 1 else 1e5, 20000.)
+INIT = os.environ.get("INIT", "supercell"); ZL = float(os.environ.get("ZL", 20000.))
+odyc, of = O.supercell_setup(nx, ny, nz, 1, xl, xl if ny > 1 else 1e5, ZL, init_data=INIT, perturb=(INIT == "supercell"))
 refs = []
 f = of.copy()
 dt = odyc.compute_time_step()
 for s in range(nsteps):
     odyc.time_step(f, dt); refs.append(f.copy())
 for mode in (1, 2, 0):
-    coupler, dycore, micro = modules.make_supercell(nx, ny, nz, 1, xl, xl if ny > 1 else 1e5, 20000.)
+    coupler, dycore, micro = modules.make_supercell(nx, ny, nz, 1, xl, xl if ny > 1 else 1e5, ZL, INIT, perturb=(INIT == "supercell"))
     push_fields(coupler, of)
     dycore.set_strict(mode)
     out = []
