@@ -1,0 +1,53 @@
+// The reference's canonical caller, experiments/supercell_example/driver.cpp:41-79 (and the timed loop of
+// experiments/community_benchmark/driver.cpp:66-82), against the MI355X-native modules through
+// miniweatherml_amd/host/mw_facade.h.  Parameters that the reference reads from YAML come from argv:
+//     supercell_driver nx_glob ny_glob nz nens xlen ylen zlen nsteps [init_data] [kessler(0|1)]
+// sponge_layer and ColumnNudger (SURVEY.md 8(f) "next" rows) are not part of the hot path and are not called.
+// Prints max|w|, the serial sum of density_dry and steps/s; used by tests/test_gpu_cpp_facade.py.
+#include "../miniweatherml_amd/host/mw_facade.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+int main(int argc, char **argv) {
+  if (argc < 9) { fprintf(stderr, "usage: %s nx_glob ny_glob nz nens xlen ylen zlen nsteps [init_data] [kessler]\n", argv[0]); return 2; }
+  size_t nx_glob = atoll(argv[1]), ny_glob = atoll(argv[2]);
+  int nz = atoi(argv[3]), nens = atoi(argv[4]);
+  real xlen = atof(argv[5]), ylen = atof(argv[6]), zlen = atof(argv[7]);
+  int nsteps = atoi(argv[8]);
+  std::string init_data = argc > 9 ? argv[9] : "supercell";
+  bool run_micro = argc > 10 ? atoi(argv[10]) != 0 : false;
+  try {
+    core::Coupler coupler;
+    coupler.set_option<std::string>("out_prefix", "test");
+    coupler.set_option<std::string>("init_data", init_data);
+    coupler.set_option<real>("out_freq", -1.);
+    coupler.distribute_mpi_and_allocate_coupled_state(nz, ny_glob, nx_glob, nens);        // driver.cpp:41
+    coupler.set_grid(xlen, ylen, zlen);                                                   // :44
+    modules::Microphysics_Kessler micro;
+    modules::Dynamics_Euler_Stratified_WenoFV dycore;
+    micro.init(coupler);                                                                  // :58
+    dycore.init(coupler);                                                                 // :59
+    modules::perturb_temperature(coupler);                                                // :61
+    real etime = 0;
+    (void)hipDeviceSynchronize();
+    auto t0 = std::chrono::steady_clock::now();
+    for (int s = 0; s < nsteps; s++) {                                                    // :66-79
+      real dtphys = dycore.compute_time_step(coupler);
+      dycore.time_step(coupler, dtphys);
+      if (run_micro) micro.time_step(coupler, dtphys);
+      etime += dtphys;
+    }
+    (void)hipDeviceSynchronize();
+    double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    auto &dm = coupler.get_data_manager_readwrite();
+    size_t n = (size_t)nz * coupler.get_ny() * coupler.get_nx() * nens;
+    std::vector<double> w(n), r(n);
+    (void)hipMemcpy(w.data(), dm.get<real>("wvel").data(), n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(r.data(), dm.get<real>("density_dry").data(), n * 8, hipMemcpyDeviceToHost);
+    double maxw = 0, sum = 0;
+    for (size_t i = 0; i < n; i++) { maxw = std::max(maxw, std::fabs(w[i])); sum += r[i]; }
+    printf("etime %.17g maxw %.17e sum_density_dry %.17e steps_per_s %.4f\n", etime, maxw, sum, nsteps / el);
+  } catch (std::exception &e) { fprintf(stderr, "endrun: %s\n", e.what()); return 1; }
+  return 0;
+}

@@ -46,5 +46,22 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_examples(verbose=True):
+    """The C++ caller of examples/ (mirror of the reference's driver) against the C++ facade + C ABI."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "supercell_driver.cpp")
+    exe = os.path.join(root, "examples", "supercell_driver")
+    deps = [src, os.path.join(HERE, "host", "mw_facade.h"), os.path.join(root, "include", "mw_cdna4.h"), LIB]
+    if _stale(exe, deps):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-x", "c++", src, "-o", exe, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+               "-L" + HERE, "-lmw_cdna4", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../miniweatherml_amd",
+               "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return exe
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_examples()

@@ -1,0 +1,288 @@
+// =====================================================================================================
+// mw_facade.h -- C++ host-side mirror of miniWeatherML's module API on top of the C ABI (include/mw_cdna4.h).
+//
+// The reference's "plugin API" is a header-level C++ convention: a driver owns a core::Coupler,
+// calls module.init(coupler) once and module.time_step(coupler, dt) every step.  This header provides the same
+// names with the same argument meaning so that the reference drivers' call sequence
+// (experiments/supercell_example/driver.cpp:41-79) compiles line-for-line against the MI355X-native kernels:
+//
+//   core::Coupler            model/core/coupler.h:17-493        options, tracer registry, grid, decomposition
+//   core::DataManager        model/core/DataManager.h:20-585    name -> device allocation (+dims, dirty, positive)
+//   modules::Dynamics_Euler_Stratified_WenoFV                    model/modules/dynamics_euler_stratified_wenofv.h
+//   modules::Microphysics_Kessler                                model/modules/microphysics_kessler.h
+//   modules::perturb_temperature                                 model/modules/perturb_temperature.h
+//
+// No YAKL: arrays are raw device allocations (hipMalloc) handed to the C ABI as plain pointers; `DeviceView<T>` is a
+// non-owning (pointer, dims) pair like the non-owning yakl::Array the reference's DataManager::get returns (:262,:283).
+// Errors: endrun(msg) throws std::runtime_error (reference: yakl_throw, main_header.h:66-68).
+// =====================================================================================================
+#pragma once
+#include "../../include/mw_cdna4.h"
+#include <hip/hip_runtime_api.h>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <typeinfo>
+#include <variant>
+#include <vector>
+
+typedef double real;                                                  // main_header.h:59
+
+inline void endrun(const std::string &msg) { throw std::runtime_error(msg); }
+inline void mw_check(int rc) { if (rc) endrun(mw_last_error()); }
+
+template <class T> struct DeviceView {                                // non-owning view
+  T *ptr = nullptr;
+  std::vector<int> dimension;
+  T *data() const { return ptr; }
+  size_t size() const { size_t n = 1; for (int d : dimension) n *= (size_t)d; return n; }
+  int extent(int i) const { return dimension[i]; }
+};
+
+namespace core {
+
+class Options {                                                       // model/core/Options.h:11-167
+  std::map<std::string, std::variant<int, real, bool, std::string, long long>> opts;
+ public:
+  template <class T> void add_option(const std::string &key, T v) { if (!opts.count(key)) opts[key] = v; }     // :60-74
+  template <class T> void set_option(const std::string &key, T v) { opts[key] = v; }                           // :77-89
+  template <class T> T get_option(const std::string &key) const {                                              // :92-108
+    auto it = opts.find(key);
+    if (it == opts.end()) endrun("ERROR: option not found: " + key);
+    if (!std::holds_alternative<T>(it->second)) endrun("ERROR: Requesting option using the wrong type: " + key);
+    return std::get<T>(it->second);
+  }
+  bool option_exists(const std::string &key) const { return opts.count(key) > 0; }
+  void delete_option(const std::string &key) { opts.erase(key); }
+};
+
+class DataManager {                                                   // model/core/DataManager.h
+  struct Entry { std::string name, desc; size_t type_hash; void *ptr; size_t bytes; std::vector<int> dims;
+                 std::vector<std::string> dim_names; bool positive, dirty; };
+  std::vector<Entry> entries;
+  std::map<std::string, int> dimensions;
+  int find_entry(const std::string &n) const { for (size_t i = 0; i < entries.size(); i++) if (entries[i].name == n) return (int)i; return -1; }
+ public:
+  DataManager() = default;
+  DataManager(const DataManager &) = delete;
+  ~DataManager() { finalize(); }
+  void finalize() { for (auto &e : entries) if (e.ptr) (void)hipFree(e.ptr); entries.clear(); dimensions.clear(); }   // :571-578
+  void add_dimension(const std::string &name, int len) {                                                       // :106-120
+    auto it = dimensions.find(name);
+    if (it != dimensions.end() && it->second != len) endrun("ERROR: Attempting to add a dimension of the same name as an existing dimension but not the same size");
+    dimensions[name] = len;
+  }
+  int find_dimension(const std::string &n) const { return dimensions.count(n) ? 0 : -1; }
+  int get_dimension_size(const std::string &n) const { auto it = dimensions.find(n); if (it == dimensions.end()) endrun("ERROR: Could not find dimension."); return it->second; }
+  template <class T> void register_and_allocate(const std::string &name, const std::string &desc, std::vector<int> dims,
+                                                std::vector<std::string> dim_names = {}, bool positive = false) {   // :122-181
+    if (name.empty()) endrun("ERROR: You cannot register_and_allocate with an empty string");
+    if (find_entry(name) != -1) endrun("ERROR: Duplicate entry name: " + name);
+    size_t n = 1; for (int d : dims) n *= (size_t)d;
+    void *p = nullptr;
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) endrun("ERROR: device allocation failed for " + name);
+    (void)hipMemset(p, 0, n * sizeof(T));
+    entries.push_back({name, desc, typeid(T).hash_code(), p, n * sizeof(T), dims, dim_names, positive, false});
+  }
+  bool entry_exists(const std::string &n) const { return find_entry(n) != -1; }
+  template <class T> DeviceView<T> get(const std::string &name) {                                              // :246-286
+    int id = find_entry(name);
+    if (id == -1) endrun("ERROR: Could not find entry name: " + name);
+    typedef typename std::remove_cv<T>::type TNC;
+    if (entries[id].type_hash != typeid(TNC).hash_code()) endrun("ERROR: Requested Array type does not match entry type");   // :256-261
+    if (!std::is_const<T>::value) entries[id].dirty = true;                                                     // :275
+    return DeviceView<T>{(T *)entries[id].ptr, entries[id].dims};
+  }
+  template <class T> DeviceView<T> get_lev_col(const std::string &name) {                                      // :289-330
+    auto v = get<T>(name); int nlev = v.dimension[0]; int ncol = (int)(v.size() / (size_t)nlev);
+    return DeviceView<T>{v.ptr, {nlev, ncol}};
+  }
+  template <class T> DeviceView<T> get_collapsed(const std::string &name) { auto v = get<T>(name); return DeviceView<T>{v.ptr, {(int)v.size()}}; }   // :333-365
+  bool get_dirty(const std::string &n) const { int id = find_entry(n); return id >= 0 && entries[id].dirty; }
+  void clean_all() { for (auto &e : entries) e.dirty = false; }
+};
+
+class Coupler {                                                       // model/core/coupler.h:17-493
+  Options options;
+  real xlen = -1, ylen = -1, zlen = -1, dt_gcm = -1;
+  int nranks = 1, myrank = 0;
+  struct Tracer { std::string name, desc; bool positive, adds_mass; };
+  std::vector<Tracer> tracers;
+  DataManager dm;
+ public:
+  mw_grid_t grid;                                                     // what the C ABI needs from the getters below
+  Coupler() { memset(&grid, 0, sizeof(grid)); }
+  Coupler(const Coupler &) = delete;                                  // move-only in the reference too (:67-70)
+  // coupler.h:110-214.  Pass the rank layout explicitly (the reference reads it from MPI_COMM_WORLD).
+  void distribute_mpi_and_allocate_coupled_state(int nz, size_t ny_glob, size_t nx_glob, int nens, int nranks_in = 1, int myrank_in = 0) {
+    nranks = nranks_in; myrank = myrank_in;
+    mw_check(mw_decompose(nranks, myrank, (long long)nx_glob, (long long)ny_glob, &grid));
+    grid.nz = nz; grid.nens = nens;
+    dm.add_dimension("nens", nens); dm.add_dimension("x", grid.nx); dm.add_dimension("y", grid.ny); dm.add_dimension("z", nz);
+  }
+  void set_grid(real xl, real yl, real zl) { xlen = xl; ylen = yl; zlen = zl; grid.xlen = xl; grid.ylen = yl; grid.zlen = zl; }
+  real get_xlen() const { return xlen; }  real get_ylen() const { return ylen; }  real get_zlen() const { return zlen; }
+  int get_nranks() const { return nranks; }  int get_myrank() const { return myrank; }  int get_nens() const { return grid.nens; }
+  size_t get_nx_glob() const { return (size_t)grid.nx_glob; }  size_t get_ny_glob() const { return (size_t)grid.ny_glob; }
+  int get_nproc_x() const { return grid.nproc_x; }  int get_nproc_y() const { return grid.nproc_y; }
+  int get_px() const { return grid.px; }  int get_py() const { return grid.py; }
+  size_t get_i_beg() const { return (size_t)grid.i_beg; }  size_t get_j_beg() const { return (size_t)grid.j_beg; }
+  bool is_sim2d() const { return grid.ny_glob == 1; }  bool is_mainproc() const { return myrank == 0; }
+  const int *get_neighbor_rankid_matrix() const { return grid.neigh; }       // [y][x], row-major 3x3
+  DataManager const &get_data_manager_readonly() const { return dm; }
+  DataManager &get_data_manager_readwrite() { return dm; }
+  int get_nx() const { return dm.find_dimension("x") == -1 ? -1 : dm.get_dimension_size("x"); }
+  int get_ny() const { return dm.find_dimension("y") == -1 ? -1 : dm.get_dimension_size("y"); }
+  int get_nz() const { return dm.find_dimension("z") == -1 ? -1 : dm.get_dimension_size("z"); }
+  real get_dx() const { return get_xlen() / grid.nx_glob; }                 // :262
+  real get_dy() const { return get_ylen() / grid.ny_glob; }                 // :265
+  real get_dz() const { return get_zlen() / get_nz(); }                     // :268
+  int get_num_tracers() const { return (int)tracers.size(); }
+  template <class T> void add_option(const std::string &k, T v) { options.add_option<T>(k, v); }
+  template <class T> void set_option(const std::string &k, T v) { options.set_option<T>(k, v); }
+  template <class T> T get_option(const std::string &k) const { return options.get_option<T>(k); }
+  template <class T> T get_option(const std::string &k, T dflt) const { return options.option_exists(k) ? options.get_option<T>(k) : dflt; }
+  bool option_exists(const std::string &k) const { return options.option_exists(k); }
+  void delete_option(const std::string &k) { options.delete_option(k); }
+  void add_tracer(const std::string &name, const std::string &desc, bool positive, bool adds_mass) {           // :323-330
+    dm.register_and_allocate<real>(name, desc, {get_nz(), get_ny(), get_nx(), get_nens()}, {"z", "y", "x", "nens"}, positive);
+    tracers.push_back({name, desc, positive, adds_mass});
+  }
+  std::vector<std::string> get_tracer_names() const { std::vector<std::string> r; for (auto &t : tracers) r.push_back(t.name); return r; }
+  void get_tracer_info(const std::string &name, std::string &desc, bool &found, bool &positive, bool &adds_mass) const {   // :340-353
+    for (auto &t : tracers) if (t.name == name) { positive = t.positive; desc = t.desc; adds_mass = t.adds_mass; found = true; return; }
+    found = false;
+  }
+  bool tracer_exists(const std::string &name) const { for (auto &t : tracers) if (t.name == name) return true; return false; }
+};
+
+} // namespace core
+
+namespace modules {
+
+class Microphysics_Kessler {                                          // model/modules/microphysics_kessler.h
+  void *ws = nullptr; long long ws_bytes = 0;
+ public:
+  int static constexpr num_tracers = 3;
+  real R_d, cp_d, cv_d, gamma_d, kappa_d, R_v, cp_v, cv_v, p0, grav;
+  Microphysics_Kessler() { R_d = 287.; cp_d = 1003.; cv_d = cp_d - R_d; gamma_d = cp_d / cv_d; kappa_d = R_d / cp_d; R_v = 461.;
+                           cp_v = 1859; cv_v = R_v - cp_v; p0 = 1.e5; grav = 9.81; }                             // :29-41
+  ~Microphysics_Kessler() { if (ws) (void)hipFree(ws); }
+  static int get_num_tracers() { return num_tracers; }
+  std::string micro_name() const { return "kessler"; }
+  void init(core::Coupler &coupler) {                                 // :51-96
+    coupler.add_tracer("water_vapor", "Water Vapor", true, true);
+    coupler.add_tracer("cloud_liquid", "Cloud liquid", true, true);
+    coupler.add_tracer("precip_liquid", "precip_liquid", true, true);
+    coupler.get_data_manager_readwrite().register_and_allocate<real>("precl", "precipitation rate",
+        {coupler.get_ny(), coupler.get_nx(), coupler.get_nens()}, {"y", "x", "nens"});
+    coupler.set_option<std::string>("micro", "kessler");
+    coupler.set_option<real>("R_d", R_d); coupler.set_option<real>("cp_d", cp_d); coupler.set_option<real>("cv_d", cv_d);
+    coupler.set_option<real>("gamma_d", gamma_d); coupler.set_option<real>("kappa_d", kappa_d); coupler.set_option<real>("R_v", R_v);
+    coupler.set_option<real>("cp_v", cp_v); coupler.set_option<real>("cv_v", cv_v); coupler.set_option<real>("p0", p0);
+    coupler.set_option<real>("grav", grav);
+  }
+  void time_step(core::Coupler &coupler, real dt) {                   // :99-162
+    auto &dm = coupler.get_data_manager_readwrite();
+    auto rho_v = dm.get_lev_col<real>("water_vapor"), rho_c = dm.get_lev_col<real>("cloud_liquid"), rho_r = dm.get_lev_col<real>("precip_liquid");
+    auto rho_dry = dm.get_lev_col<real const>("density_dry");
+    auto temp = dm.get_lev_col<real>("temp");
+    auto precl = dm.get_collapsed<real>("precl");
+    int nz = coupler.get_nz(); long long ncol = (long long)coupler.get_ny() * coupler.get_nx() * coupler.get_nens();
+    long long need = mw_kessler_workspace_bytes(nz, ncol);
+    if (need > ws_bytes) { if (ws) (void)hipFree(ws); if (hipMalloc(&ws, (size_t)need) != hipSuccess) endrun("kessler workspace allocation failed"); ws_bytes = need; }
+    mw_check(mw_kessler_time_step(nz, ncol, coupler.get_dz(), dt, rho_v.data(), rho_c.data(), rho_r.data(), rho_dry.data(), temp.data(),
+                                  precl.data(), ws, nullptr, nullptr));
+  }
+};
+
+class Dynamics_Euler_Stratified_WenoFV {                              // model/modules/dynamics_euler_stratified_wenofv.h
+  mw_dycore_t h = nullptr;
+  std::vector<double *> tracer_ptrs;
+  double *f_rho = nullptr, *f_u = nullptr, *f_v = nullptr, *f_w = nullptr, *f_T = nullptr;
+ public:
+  int static constexpr ord = 5, hs = 2, num_state = 5;
+  int static constexpr idR = 0, idU = 1, idV = 2, idW = 3, idT = 4;
+  real etime = 0, out_freq = -1;  int num_out = 0, idWV = 0;
+  std::vector<real> hy_dens_cells, hy_dens_theta_cells, hy_dens_edges, hy_dens_theta_edges;     // (nz[,+1],nens), host copies
+  ~Dynamics_Euler_Stratified_WenoFV() { if (h) mw_dycore_destroy(h); }
+  real compute_time_step(core::Coupler const &coupler) const { return mw_dycore_compute_time_step(&coupler.grid); }     // :70-77
+  void init(core::Coupler &coupler) {                                 // :1197-1683
+    mw_grid_t &g = coupler.grid;
+    mw_grid_t c; memset(&c, 0, sizeof(c)); mw_check(mw_default_constants(&c));
+    if (!coupler.option_exists("R_d")) coupler.set_option<real>("R_d", c.R_d);                 // :1227-1249
+    if (!coupler.option_exists("cp_d")) coupler.set_option<real>("cp_d", c.cp_d);
+    if (!coupler.option_exists("R_v")) coupler.set_option<real>("R_v", c.R_v);
+    if (!coupler.option_exists("cp_v")) coupler.set_option<real>("cp_v", c.cp_v);
+    if (!coupler.option_exists("p0")) coupler.set_option<real>("p0", c.p0);
+    if (!coupler.option_exists("grav")) coupler.set_option<real>("grav", c.grav);
+    if (!coupler.option_exists("earthrot")) coupler.set_option<real>("earthrot", c.earthrot);
+    real R_d = coupler.get_option<real>("R_d"), cp_d = coupler.get_option<real>("cp_d"), p0 = coupler.get_option<real>("p0");
+    if (!coupler.option_exists("cv_d")) coupler.set_option<real>("cv_d", cp_d - R_d);
+    if (!coupler.option_exists("gamma_d")) coupler.set_option<real>("gamma_d", cp_d / coupler.get_option<real>("cv_d"));
+    if (!coupler.option_exists("kappa_d")) coupler.set_option<real>("kappa_d", R_d / cp_d);
+    if (!coupler.option_exists("cv_v")) coupler.set_option<real>("cv_v", coupler.get_option<real>("R_v") - coupler.get_option<real>("cp_v"));
+    real gamma = coupler.get_option<real>("gamma_d"), kappa = coupler.get_option<real>("kappa_d");
+    if (!coupler.option_exists("C0")) coupler.set_option<real>("C0", pow(R_d * pow(p0, -kappa), gamma));
+    coupler.set_option<real>("latitude", 0);
+    g.R_d = R_d; g.cp_d = cp_d; g.p0 = p0; g.R_v = coupler.get_option<real>("R_v"); g.cp_v = coupler.get_option<real>("cp_v");
+    g.grav = coupler.get_option<real>("grav"); g.gamma_d = gamma; g.kappa_d = kappa; g.C0 = coupler.get_option<real>("C0");
+    g.earthrot = coupler.get_option<real>("earthrot"); g.latitude = 0;
+    auto &dm = coupler.get_data_manager_readwrite();
+    int nz = coupler.get_nz(), ny = coupler.get_ny(), nx = coupler.get_nx(), nens = coupler.get_nens();
+    for (const char *n : {"density_dry", "uvel", "vvel", "wvel", "temp"}) dm.register_and_allocate<real>(n, "", {nz, ny, nx, nens});   // :1253-1257
+    auto names = coupler.get_tracer_names();
+    int T = (int)names.size();
+    std::vector<unsigned char> pos(T), adds(T);
+    bool haveWV = false;
+    for (int tr = 0; tr < T; tr++) { std::string d; bool f, p, a; coupler.get_tracer_info(names[tr], d, f, p, a); pos[tr] = p; adds[tr] = a;
+                                     if (names[tr] == "water_vapor") { idWV = tr; haveWV = true; } }                 // :1285-1293
+    if (!haveWV) endrun("ERROR: a tracer named water_vapor must be registered before dycore.init");
+    g.num_tracers = T; g.idWV = idWV;
+    coupler.set_option<int>("idWV", idWV);                                                                      // :1300
+    auto init_data = coupler.get_option<std::string>("init_data");
+    out_freq = coupler.get_option<real>("out_freq", -1.);
+    int init_id = init_data == "thermal" ? MW_DATA_THERMAL : init_data == "supercell" ? MW_DATA_SUPERCELL : init_data == "city" ? MW_DATA_CITY
+                : init_data == "building" ? MW_DATA_BUILDING : -1;
+    if (init_id < 0) endrun("ERROR: Invalid init_data in yaml input file");                                     // :1310
+    g.enable_gravity = coupler.get_option<bool>("enable_gravity", true);
+    g.bc_x = g.bc_y = MW_BC_PERIODIC; g.bc_z = MW_BC_WALL; g.use_immersed = 0;
+    mw_check(mw_dycore_create(&h, &g, pos.data(), adds.data(), nullptr));
+    bind(coupler);
+    mw_check(mw_dycore_init(h, init_id, f_rho, f_u, f_v, f_w, f_T, tracer_ptrs.data()));
+    mw_check(mw_dycore_get_grid(h, &g));
+    coupler.set_option<bool>("use_immersed_boundaries", g.use_immersed != 0);                                   // :1312,1426,1554
+    coupler.add_option<int>("bc_x", g.bc_x); coupler.add_option<int>("bc_y", g.bc_y); coupler.add_option<int>("bc_z", g.bc_z);
+    hy_dens_cells.resize((size_t)nz * nens); hy_dens_theta_cells.resize((size_t)nz * nens);
+    hy_dens_edges.resize((size_t)(nz + 1) * nens); hy_dens_theta_edges.resize((size_t)(nz + 1) * nens);
+    mw_check(mw_dycore_get_background(h, hy_dens_cells.data(), hy_dens_theta_cells.data(), hy_dens_edges.data(), hy_dens_theta_edges.data()));
+    dm.register_and_allocate<real>("hy_dens_cells", "hydrostatic density cell averages", {nz, nens});            // :1663-1668
+    dm.register_and_allocate<real>("hy_dens_theta_cells", "hydrostatic density*theta cell averages", {nz, nens});
+    (void)hipMemcpy(dm.get<real>("hy_dens_cells").data(), hy_dens_cells.data(), hy_dens_cells.size() * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dm.get<real>("hy_dens_theta_cells").data(), hy_dens_theta_cells.data(), hy_dens_theta_cells.size() * 8, hipMemcpyHostToDevice);
+    etime = 0; num_out = 0;
+  }
+  void time_step(core::Coupler &coupler, real &dt_phys) {             // :81-198 (file output excluded)
+    if (!h) endrun("dycore.time_step before init");
+    mw_check(mw_dycore_time_step(h, f_rho, f_u, f_v, f_w, f_T, tracer_ptrs.data(), dt_phys));
+    etime += dt_phys;
+  }
+  mw_dycore_t handle() const { return h; }
+ private:
+  void bind(core::Coupler &coupler) {
+    auto &dm = coupler.get_data_manager_readwrite();
+    f_rho = dm.get<real>("density_dry").data(); f_u = dm.get<real>("uvel").data(); f_v = dm.get<real>("vvel").data();
+    f_w = dm.get<real>("wvel").data(); f_T = dm.get<real>("temp").data();
+    tracer_ptrs.clear();
+    for (auto &n : coupler.get_tracer_names()) tracer_ptrs.push_back(dm.get<real>(n).data());
+  }
+};
+
+inline void perturb_temperature(core::Coupler &coupler, bool thermal = true, bool random = false) {   // perturb_temperature.h:8-67
+  if (random) endrun("perturb_temperature(random=true) needs yakl::Random and is not on the hot path");
+  if (thermal) mw_check(mw_perturb_temperature(&coupler.grid, coupler.get_data_manager_readwrite().get<real>("temp").data(), nullptr));
+}
+
+} // namespace modules
