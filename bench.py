@@ -5,15 +5,20 @@
 
 metric  : cell-updates/s (whole job) of Dynamics_Euler_Stratified_WenoFV::time_step on the supercell grid.
           One cell-update = one (k,j,i,iens) cell advanced through one dycore sub-cycle (3 SSPRK stages, all
-          V = 8 prognostic variables) -- SURVEY.md 8(d).  A "step" = one time_step(coupler, dt_CFL) call.
+          V = 8 prognostic variables) -- SURVEY.md 8(d).  A "step" = one time_step(coupler, dt_CFL) call = 1 sub-cycle.
 workload: BASELINE.json configs[1]: supercell 400x400x100, nens 1, fp64, 3 Kessler tracers advected, dycore only,
           dx = dy = 500 m, dz = 200 m, out_freq = -1, dt_phys = CFL step (community_benchmark/driver.cpp:66-82 timed
           region).  N > 1: weak scaling, every GPU keeps a 400x400x100 block of a (400*nproc_x) x (400*nproc_y) x 100
-          grid (2-D x/y decomposition of coupler.h:127-179), 3-cell halos exchanged over RCCL once per RK stage.
+          grid (2-D x/y decomposition of coupler.h:127-179), 3-cell halos exchanged over RCCL once per RK stage and group.
 timing  : W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(); max over ranks.
-roofline: dominant kernel k_flux (WENO reconstruction + Riemann, one launch per RK stage): algorithmic bytes
-          32*V B/cell (read V, write 3V fluxes) / average launch duration from hipEvents recorded on the kernel's
-          stream inside the timed region (mw_dycore_profile); peak 8 TB/s HBM3E spec.
+roofline: dominant kernel k_xz_state (x/z WENO reconstruction + Riemann + complete state tendencies + SSPRK3 combine, one
+          launch per RK stage).  achieved = algorithmic bytes per launch / average launch duration, the duration from
+          hipEvents recorded on the kernel's own stream inside the timed region (mw_dycore_profile).  Algorithmic bytes
+          per cell and launch: read 5 state + 5 y-tendencies (+ 5 q^n in stages 2,3), write 5 state
+          + 2 face mass fluxes + 2 selector bytes = 138 B (stage 1) / 178 B (stages 2,3), 164.7 B on average.
+          peak 8 TB/s HBM3E spec.  traffic = measured HBM bytes per launch from profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
+          calibrated with mw_calib_copy).  The whole-pipeline figure (512 B per cell-update) is
+          config.hbm_frac_cell_update.  The kernel is fp64-VALU bound: see roofline.valu_busy_frac.
 cpu_baseline: the CPU oracle (a port: the reference itself is unbuildable here) timed on one host core
           on BASELINE.json configs[0] (supercell 200x200x50), rank 0, N = 1 only.
 """
@@ -132,15 +137,21 @@ def main():
         value = total_updates / el
         flux_ms, flux_n = prof["xz_state"]
         avg_flux_s = flux_ms / 1e3 / max(1, flux_n)
-        alg_bytes = 32.0 * V * ncells_local                      # per launch: read V, write 3V doubles per cell
+        # k_xz_state per cell and launch: read 5 (state) + 5 (y tendencies) [+ 5 q^n in stages 2,3], write 5 + 2 doubles + 2 bytes
+        alg_bytes = ((15 + 20 + 20) / 3.0 + 7) * 8.0 * ncells_local + 2.0 * ncells_local
+        if a.strict:                                             # general path: k_flux reads V, writes 3V doubles per cell
+            alg_bytes = 32.0 * V * ncells_local
         achieved = alg_bytes / avg_flux_s / 1e9 if flux_n else None
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_flux_latest.json")
-        if os.path.exists(pmc):
+        traffic, valu_busy, valu_instr = None, None, None
+        pmc = os.path.join(ROOT, "profiles", "latest_summary.json")
+        if os.path.exists(pmc) and not a.strict:
             try:
                 pj = json.load(open(pmc))
-                if pj.get("workload") == "%dx%dx%dx%d" % (a.nx, a.ny, a.nz, a.nens):
-                    traffic = pj.get("hbm_bytes_per_launch")
+                if int(pj.get("cells_per_launch", 0)) == ncells_local:
+                    ks = [v for k, v in pj["kernels"].items() if k.startswith("k_xz_state")]
+                    traffic = sum(k["hbm_read_bytes"] + k["hbm_write_bytes"] for k in ks) / len(ks)
+                    valu_busy = sum(k["valu_busy_frac"] for k in ks) / len(ks)
+                    valu_instr = sum(k["valu_instr_per_cell"] for k in ks) / len(ks)
             except Exception:
                 traffic = None
         out = {
@@ -152,11 +163,12 @@ def main():
                        "parallelism": "%dx%d slab" % (npx, npy), "V": V, "strict": a.strict,
                        "alg_bytes_per_cell_update": 64 * V,
                        "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world},
-            "roofline": {"bound": "hbm", "kernel": "k_flux", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
-                         "avg_launch_ms": avg_flux_s * 1e3, "launches": flux_n,
-                         "alg_bytes_per_launch": alg_bytes,
-                         "fp64_nominal_tflops": (4.4e3 * ncells_local / avg_flux_s / 1e12) if flux_n else None},
+            "roofline": {"bound": "hbm", "kernel": "k_flux" if a.strict else "k_xz_state", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
+                         "avg_launch_ms": avg_flux_s * 1e3, "launches": flux_n, "alg_bytes_per_launch": alg_bytes,
+                         "valu_busy_frac": valu_busy, "valu_instr_per_cell": valu_instr,
+                         "note": "fp64-VALU bound kernel (SURVEY.md 8(d)): valu_busy_frac / valu_instr_per_cell from the committed "
+                                 "rocprofv3 PMC summary profiles/latest_summary.json; duration measured live with hipEvents"},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -116,6 +116,10 @@ double mw_dycore_get_etime(mw_dycore_t h);   /* member etime, :55 */
 int  mw_dycore_profile(mw_dycore_t h, int enable);
 int  mw_dycore_profile_get(mw_dycore_t h, int which, double *total_ms, long long *launches);
 
+/* Measurement aid (no reference counterpart): copies n doubles with this library's access shape (8 B per lane).  A launch
+ * moves exactly 8n bytes each way, which calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE counters (tools/calib_pmc.py). */
+int  mw_calib_copy(const double *in, double *out, long long n, void *stream);
+
 /* modules::perturb_temperature(coupler, thermal=true, random=false), perturb_temperature.h:41-66 */
 int  mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream);
 

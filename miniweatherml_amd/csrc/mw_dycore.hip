@@ -680,6 +680,13 @@ __global__ __launch_bounds__(256) void k_perturb_temperature(int nz, int ny, int
   if (rad < 1) temp[t] += amp * pow(cos(M_PI * rad / 2), 2.0);
 }
 
+// Streaming copy with this library's access shape (8 bytes per lane, consecutive lanes consecutive doubles): the known-byte
+// workload used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950 (MI355X_MICROARCH.md, HBM section).
+__global__ __launch_bounds__(256) void k_calib_copy(const double *__restrict__ in, double *__restrict__ out, long long n) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
 } // namespace mw
 
 // =====================================================================================================
@@ -1232,6 +1239,13 @@ int mw_dycore_compute_tendencies(mw_dycore_t d, const double *rho_d, const doubl
   if (launch_fct(d, d->S0, dt)) return 1;
   d->flux_src = nullptr;
   if (state_tend && tracers_tend) { if (launch_update<1, 2>(d, d->S0, d->S0, nullptr, dt, dt, c, state_tend, tracers_tend)) return 1; }
+  return 0;
+}
+
+int mw_calib_copy(const double *in, double *out, long long n, void *stream) {
+  if (!in || !out || n < 1) MW_FAIL("mw_calib_copy: bad arguments");
+  hipLaunchKernelGGL(k_calib_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+  MW_LAUNCH_CHECK();
   return 0;
 }
 
