@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="200x200x50", help="oracle sample grid nx x ny x nz")
     ap.add_argument("--strict", type=int, default=0)
+    ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl", help="halo-exchange transport for N > 1")
     return ap.parse_args()
 
 
@@ -92,14 +93,21 @@ def main():
                                                     nranks=world, myrank=rank)
     assert coupler.get_nx() == a.nx and (coupler.get_ny() == a.ny or ny_glob == 1)
     dycore.set_strict(a.strict)
+    transport = "none"
     if world > 1:
-        ident = torch.zeros(128, dtype=torch.uint8, device=device)
-        if rank == 0:
-            buf = C.create_string_buffer(128)
-            capi.check(L.mw_rccl_unique_id(buf))
-            ident.copy_(torch.tensor(list(buf.raw), dtype=torch.uint8))
-        dist.broadcast(ident, 0)
-        capi.check(L.mw_dycore_use_rccl(dycore.h, bytes(ident.cpu().tolist()), world, rank))
+        transport = a.transport
+        if transport == "rccl":
+            try:
+                modules.use_rccl_exchange(dycore, coupler)
+            except capi.MWError as e:                              # e.g. communicator creation refused: use torch's RCCL group
+                print("rank %d: built-in RCCL transport unavailable (%s); using torch.distributed p2p" % (rank, e), file=sys.stderr)
+                transport = "torch"
+            flag = torch.tensor([1 if transport == "torch" else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)          # all ranks must agree on the transport
+            if int(flag.item()) == 1:
+                transport = "torch"
+        if transport == "torch":
+            modules.use_torch_distributed_exchange(dycore, coupler)
 
     dt = dycore.compute_time_step(coupler)
     V = 5 + coupler.get_num_tracers()
@@ -160,7 +168,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "supercell %dx%dx%d nens=%d per GPU (global %dx%dx%d), WENO-FV dycore only, 3 tracers, "
                                    "CFL dt" % (a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz),
-                       "parallelism": "%dx%d slab" % (npx, npy), "V": V, "strict": a.strict,
+                       "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict,
                        "alg_bytes_per_cell_update": 64 * V,
                        "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world},
             "roofline": {"bound": "hbm", "kernel": "k_flux" if a.strict else "k_xz_state", "achieved": achieved, "peak": 8000.0,

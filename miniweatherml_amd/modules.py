@@ -293,6 +293,77 @@ def perturb_temperature(coupler, thermal=True, random=False):                   
             check(capi.lib().mw_perturb_temperature(C.byref(coupler.grid), _ptr(temp), _stream_ptr(coupler.device)))
 
 
+def use_rccl_exchange(dycore, coupler, group=None):
+    """Slab halo exchange over RCCL point-to-point inside the library (mw_rccl.cpp): rank 0 creates the ncclUniqueId,
+    torch.distributed broadcasts it, every rank joins.  Replaces the MPI_Isend/Irecv of halo_exchange (:641-723)."""
+    import torch.distributed as dist
+    L = capi.lib()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ident = torch.zeros(128, dtype=torch.uint8, device=coupler.device)
+    if rank == 0:
+        buf = C.create_string_buffer(128)
+        check(L.mw_rccl_unique_id(buf))
+        ident.copy_(torch.tensor(list(buf.raw), dtype=torch.uint8))
+    dist.broadcast(ident, 0, group=group)
+    with torch.cuda.device(coupler.device):
+        check(L.mw_dycore_use_rccl(dycore.h, bytes(ident.cpu().tolist()), world, rank))
+
+
+def use_torch_distributed_exchange(dycore, coupler, group=None, host_staged=False):
+    """Alternative transport for the same exchange: torch.distributed point-to-point ops (backend "nccl" = RCCL) issued
+    from the library's exchange callback in the order of mw_exchange_plan.  Same wire pattern as the built-in transport.
+    host_staged=True copies the strips through host buffers first -- the reference's non-GPU-aware-MPI mode
+    (dynamics_euler_stratified_wenofv.h:687-722); works with the gloo backend."""
+    import torch.distributed as dist
+    L = capi.lib()
+    peers, so, ro, act = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+    check(L.mw_exchange_plan(C.byref(coupler.grid), peers, so, ro, act))
+    dev = coupler.device
+
+    def wrap(ptr, n):
+        class _A:
+            pass
+        a = _A()
+        a.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f8", data=(int(ptr), False), version=2)
+        return torch.as_tensor(a, device=dev)
+
+    def cb(ctx, sW, sE, sS, sN, rW, rE, rS, rN, nWE, nSN, stream):
+        try:
+            st = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+            with torch.cuda.device(dev), torch.cuda.stream(st):
+                sb, rb, cnt = [sW, sE, sS, sN], [rW, rE, rS, rN], [nWE, nWE, nSN, nSN]
+                if host_staged:
+                    hs = {d: wrap(sb[d], cnt[d]).cpu() for d in range(4) if act[d] and cnt[d] and sb[d]}     # syncs the stream
+                    hr = {d: torch.empty(cnt[d], dtype=torch.float64) for d in range(4) if act[d] and cnt[d] and rb[d]}
+                    reqs = [dist.isend(hs[so[o]], peers[so[o]], group=group) for o in range(4) if so[o] in hs]
+                    reqs += [dist.irecv(hr[ro[o]], peers[ro[o]], group=group) for o in range(4) if ro[o] in hr]
+                    for r in reqs:
+                        r.wait()
+                    for d, t in hr.items():
+                        wrap(rb[d], cnt[d]).copy_(t, non_blocking=False)
+                    return 0
+                ops = []
+                for o in range(4):
+                    d = so[o]
+                    if act[d] and cnt[d] and sb[d]:
+                        ops.append(dist.P2POp(dist.isend, wrap(sb[d], cnt[d]), peers[d], group))
+                for o in range(4):
+                    d = ro[o]
+                    if act[d] and cnt[d] and rb[d]:
+                        ops.append(dist.P2POp(dist.irecv, wrap(rb[d], cnt[d]), peers[d], group))
+                if ops:
+                    for r in dist.batch_isend_irecv(ops):
+                        r.wait()
+            return 0
+        except Exception as e:                                   # pragma: no cover
+            import sys
+            print("exchange callback failed: %r" % (e,), file=sys.stderr)
+            return 1
+
+    dycore._xchg_cb = capi.EXCHANGE_FN(cb)                       # keep alive
+    check(L.mw_dycore_set_exchange(dycore.h, dycore._xchg_cb, None))
+
+
 def make_supercell(nx_glob, ny_glob, nz, nens=1, xlen=1.0e5, ylen=1.0e5, zlen=2.0e4, init_data="supercell", device="cuda:0",
                    nranks=1, myrank=0, micro=None, enable_gravity=None, perturb=True):
     """The set-up sequence of experiments/supercell_example/driver.cpp:41-61 (column nudger excluded)."""

@@ -1,0 +1,66 @@
+"""Worker of tests/test_gpu_multiprocess.py: one rank of a multi-PROCESS job on one GPU (gloo rendezvous, host-staged
+strips).  Each rank owns its block through the product path (C ABI + HIP kernels) and exchanges halos through the
+torch.distributed transport of miniweatherml_amd.modules; rank 0 gathers and compares with a single-rank GPU run."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from miniweatherml_amd import modules  # noqa: E402
+from util import gpu_fields  # noqa: E402
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    nxg, nyg, nz, nsteps = [int(v) for v in sys.argv[4:8]]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    xlen, ylen = 500.0 * nxg, (500.0 * nyg if nyg > 1 else 1.0e5)
+    coupler, dycore, _ = modules.make_supercell(nxg, nyg, nz, 1, xlen, ylen, 20000., nranks=world, myrank=rank)
+    modules.use_torch_distributed_exchange(dycore, coupler, host_staged=True)
+    dt = dycore.compute_time_step(coupler)
+    for _ in range(nsteps):
+        dycore.time_step(coupler, dt)
+    torch.cuda.synchronize()
+    g = gpu_fields(coupler)
+    names = sorted(g)
+    mine = np.stack([g[k] for k in names])
+    meta = torch.tensor([coupler.grid.i_beg, coupler.grid.j_beg, coupler.get_nx(), coupler.get_ny()], dtype=torch.int64)
+    metas = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    ok = 1
+    if rank == 0:
+        full = np.zeros((len(names), nz, nyg, nxg, 1))
+        for r in range(world):
+            ib, jb, nx, ny = [int(v) for v in metas[r]]
+            if r == 0:
+                blk = mine
+            else:
+                buf = torch.empty((len(names), nz, ny, nx, 1), dtype=torch.float64)
+                dist.recv(buf, r)
+                blk = buf.numpy()
+            full[:, :, jb:jb + ny, ib:ib + nx] = blk
+        c1, d1, _ = modules.make_supercell(nxg, nyg, nz, 1, xlen, ylen, 20000.)
+        for _ in range(nsteps):
+            d1.time_step(c1, dt)
+        ref = gpu_fields(c1)
+        for i, k in enumerate(names):
+            if not np.array_equal(full[i], ref[k]):
+                ok = 0
+                print("MISMATCH", k, float(np.max(np.abs(full[i] - ref[k]))))
+    else:
+        dist.send(torch.from_numpy(mine.copy()), 0)
+    flag = torch.tensor([ok])
+    dist.broadcast(flag, 0)
+    dist.destroy_process_group()
+    sys.exit(0 if int(flag.item()) == 1 else 1)
+
+
+if __name__ == "__main__":
+    main()
