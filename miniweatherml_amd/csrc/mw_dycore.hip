@@ -726,8 +726,13 @@ struct mw_dycore_s {
   void *rccl = nullptr;                      // mw_rccl.cpp state
 };
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Padding the blocks-per-plane count to a
+// multiple of 8 puts the block that owns tile (j,i) of level k+1 on the SAME XCD as the block of level k, so the z-neighbour
+// face/cell reads of the plane kernels hit that XCD's L2 instead of going out to the Infinity Cache / HBM.
 static inline dim3 plane_grid(long long per_plane, int nk, int nzdim = 1) {
-  return dim3((unsigned)((per_plane + 255) / 256), (unsigned)nk, (unsigned)nzdim);
+  unsigned nb = (unsigned)((per_plane + 255) / 256);
+  nb = (nb + 7u) & ~7u;
+  return dim3(nb, (unsigned)nk, (unsigned)nzdim);
 }
 
 static void fill_params(mw_dycore_s *d) {

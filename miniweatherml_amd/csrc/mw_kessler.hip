@@ -18,6 +18,11 @@
 
 namespace mw {
 
+// x^a for x >= 0 as exp(a log x): device pow is ~230 fp64-VALU instructions, log + exp ~140, and the three powers of
+// r*qr in the evaporation/fall-speed formulas share one log.  |a log x| <= ~25 here, so the result is within ~3e-15 relative
+// of pow (x = 0 gives exp(-inf) = 0 = pow(0, a) for a > 0).
+__device__ __forceinline__ double pow_pos(double x, double a) { return exp(a * log(x)); }
+
 struct KesP {
   int nz; long long ncol;
   double dz, dt;
@@ -33,20 +38,23 @@ __global__ __launch_bounds__(256) void k_kessler_prep(KesP p, const double *__re
                                                       const double *__restrict__ rho_d, const double *__restrict__ temp,
                                                       double *__restrict__ velqr_out, unsigned long long *dtmax_bits) {
 #pragma clang fp contract(off)
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  int k = blockIdx.y;
+  // grid-stride over all (k, column) cells: a few thousand workgroups -> a few thousand atomics on the one min word
+  // (62500 single-address atomics cost 0.7 ms on MI355X: ~88 per microsecond per address)
   double dtc = __longlong_as_double(0x7FF0000000000000ll);
-  if (i < p.ncol) {
-    long long idx = (long long)k * p.ncol + i;
+  const long long n = (long long)p.nz * p.ncol;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
+    const int k = (int)(idx / p.ncol);
+    const long long i = idx - (long long)k * p.ncol;
     double rd = rho_d[idx];
     double qr = rho_r[idx] / rd;                              // :140
     double r = 0.001 * rd;                                    // :256
     double rhalf = sqrt(rho_d[i] / rd);                       // :257  rho(0,i)/rho(k,i)
-    double velqr = 36.34 * pow(qr * r, 0.1364) * rhalf;       // :260
+    double velqr = 36.34 * pow_pos(qr * r, 0.1364) * rhalf;   // :260
     velqr_out[idx] = velqr;
     if (k < p.nz - 1) {                                       // :262-268
       double zk = (k + 0.5) * p.dz, zk1 = (k + 1 + 0.5) * p.dz;   // zmid, :137
-      if (velqr > 1.e-10) dtc = 0.8 * (zk1 - zk) / velqr; else dtc = p.dt;
+      double c = (velqr > 1.e-10) ? 0.8 * (zk1 - zk) / velqr : p.dt;
+      dtc = fmin(dtc, c);
     }
   }
   // block min (wave shuffle, then LDS across the 4 waves); positive doubles order like their bit patterns
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restri
       double rd = rho_d[idx];
       double T_in = temp[idx], rv_in = rho_v[idx];
       double pressure = Rd * rd * T_in + p.R_v * rv_in * T_in;            // :141
-      double pk = pow(pressure / p.p0, Rd / cp);                          // :142 exner
+      double pk = pow_pos(pressure / p.p0, Rd / cp);                      // :142 exner
       double theta, qv, qc, qr;
       if (first) {
         qv = rv_in / rd; qc = rho_c[idx] / rd; qr = rho_r[idx] / rd;      // :138-140
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restri
       double velqr = w_velqr[idx];
       double r = 0.001 * rd;                                              // :256
       double rhalf = sqrt(rho0 / rd);                                     // :257
-      double pc = 3.8 / (pow(pk, cp / Rd) * psl);                         // :258
+      double pc = 3.8 / (pow_pos(pk, cp / Rd) * psl);                     // :258
       double zk = (k + 0.5) * p.dz;
       // sedimentation (:288-299) from pre-update values
       if (k == 0) precl_acc = precl_acc + rho0 * qr * velqr / rhoqr;      // :292 (rho(0,i) qr(0,i) velqr(0,i))
@@ -111,13 +119,14 @@ __global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restri
       }
       flux_above = flux_here;
       // adjustment terms (:302-335)
-      double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.0)) / (1 + dt0 * 2.2 * pow(qr, 0.875));
+      double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.0)) / (1 + dt0 * 2.2 * pow_pos(qr, 0.875));
       qc = fmax(qc - qrprod, 0.0);
       qr = fmax(qr + qrprod + sed, 0.0);
       double tmp = pk * theta - 36.;
       double qvs = pc * exp(17.27 * (pk * theta - 273.) / tmp);
       double prod = (qv - qvs) / (1. + qvs * (4093. * lv / cp) / (tmp * tmp));
-      double tmp1 = dt0 * (((1.6 + 124.9 * pow(r * qr, 0.2046)) * pow(r * qr, 0.525)) / (2550000. * pc / (3.8 * qvs) + 540000.)) *
+      const double lrq = log(r * qr);                                      // one log for the three powers of r*qr below
+      double tmp1 = dt0 * (((1.6 + 124.9 * exp(0.2046 * lrq)) * exp(0.525 * lrq)) / (2550000. * pc / (3.8 * qvs) + 540000.)) *
                     (fmax(qvs - qv, 0.0) / (r * qvs));
       double tmp2 = fmax(-prod - qc, 0.0);
       double tmp3 = qr;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restri
       qv = fmax(qv - cond + ern, 0.0);
       qc = qc + cond;
       qr = qr - ern;
-      velqr = 36.34 * pow(qr * r, 0.1364) * rhalf;                        // :331
+      velqr = 36.34 * pow_pos(qr * r, 0.1364) * rhalf;                    // :331 (qr changed by ern: its own log)
       if (lastp) {                                                        // :154-161 [K5]
         rho_v[idx] = qv * rd; rho_c[idx] = qc * rd; rho_r[idx] = qr * rd;
         temp[idx] = theta * pk;
@@ -156,8 +165,9 @@ int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *r
   unsigned long long *bits = (unsigned long long *)workspace;
   double *ws = (double *)workspace + 16;
   hipLaunchKernelGGL(k_kessler_init_min, dim3(1), dim3(64), 0, st, bits); MW_LAUNCH_CHECK();
-  dim3 grid((unsigned)((ncol + 255) / 256), (unsigned)nz);
-  hipLaunchKernelGGL(k_kessler_prep, grid, dim3(256), 0, st, p, rho_v, rho_r, rho_d, temp, ws, bits); MW_LAUNCH_CHECK();
+  long long nb = ((long long)nz * ncol + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_kessler_prep, dim3((unsigned)nb), dim3(256), 0, st, p, rho_v, rho_r, rho_d, temp, ws, bits); MW_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_kessler_column, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp,
                      precl, bits, ws); MW_LAUNCH_CHECK();
   if (rainsplit_out) {

@@ -1,0 +1,86 @@
+"""Kessler and surrogate-MLP throughput on the supercell 400x400x100 grid (BASELINE.json configs[1]/[2] sizes), with the
+CPU oracle timed beside them on a bounded sample.  Prints one JSON object; results are quoted in DESIGN.md section 5.
+    python tools/bench_micro.py [--nx 400 --ny 400 --nz 100 --iters 20]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from miniweatherml_amd import modules
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nx", type=int, default=400); ap.add_argument("--ny", type=int, default=400); ap.add_argument("--nz", type=int, default=100)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--no-cpu", action="store_true")
+a = ap.parse_args()
+
+coupler, dycore, micro = modules.make_supercell(a.nx, a.ny, a.nz, 1, 500.0 * a.nx, 500.0 * a.ny, 20000.)
+dm = coupler.get_data_manager_readwrite()
+ncell = a.nx * a.ny * a.nz
+# a rainy state so that every Kessler branch runs (about 40 % of the cells active, generate_micro_surrogate_data.h:47-49)
+g = torch.Generator(device="cuda").manual_seed(1)
+rho_d = dm.get("density_dry")
+qc = torch.rand(rho_d.shape, generator=g, device="cuda", dtype=torch.float64) * 2e-3 * (torch.rand(rho_d.shape, generator=g, device="cuda") > 0.6)
+qr = torch.rand(rho_d.shape, generator=g, device="cuda", dtype=torch.float64) * 3e-4 * (torch.rand(rho_d.shape, generator=g, device="cuda") > 0.6)
+dm.get("cloud_liquid").copy_(qc * rho_d); dm.get("precip_liquid").copy_(qr * rho_d)
+saved = {n: dm.get(n).clone() for n in ("water_vapor", "cloud_liquid", "precip_liquid", "temp")}
+dt = dycore.compute_time_step(coupler)
+
+
+def timed(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def kessler_once():
+    for n, t in saved.items():
+        dm.get(n).copy_(t)
+    micro.time_step(coupler, dt)
+
+
+def restore_only():
+    for n, t in saved.items():
+        dm.get(n).copy_(t)
+
+
+t_k = timed(kessler_once, a.iters) - timed(restore_only, a.iters)
+rs = micro.time_step(coupler, dt, return_rainsplit=True)
+W1, b1, W2, b2, si, so = modules.load_surrogate_weights()
+ins = [dm.get(n) for n in ("temp", "density_dry", "water_vapor", "cloud_liquid", "precip_liquid")]
+outs = [torch.empty_like(ins[0]) for _ in range(4)]
+t_m = timed(lambda: modules.mlp_forward(*ins, W1, b1, W2, b2, si, so, outs), a.iters)
+res = {"grid": [a.nx, a.ny, a.nz], "cells": ncell,
+       "kessler": {"s_per_call": t_k, "cells_per_s": ncell / t_k, "rainsplit": rs, "alg_bytes_per_cell": 72 + 8.0 / a.nz,
+                   "hbm_GBps_alg": ncell * (72 + 8.0 / a.nz) / t_k / 1e9, "frac_of_8TBps": ncell * (72 + 8.0 / a.nz) / t_k / 8e12},
+       "mlp": {"s_per_call": t_m, "cells_per_s": ncell / t_m, "alg_bytes_per_cell": 72, "hbm_GBps_alg": ncell * 72 / t_m / 1e9,
+               "frac_of_8TBps": ncell * 72 / t_m / 8e12, "fp32_gflops_nominal": ncell * 208 / t_m / 1e9}}
+if not a.no_cpu:
+    from oracle import mw_oracle as O
+    nxs, nys = 100, 100
+    dyc, f = O.supercell_setup(nxs, nys, a.nz, 1, 500.0 * nxs, 500.0 * nys, 20000.)
+    rng = np.random.default_rng(1)
+    f.tracers[1][...] = rng.uniform(0, 2e-3, f.rho_d.shape) * (rng.uniform(size=f.rho_d.shape) > 0.6) * f.rho_d
+    f.tracers[2][...] = rng.uniform(0, 3e-4, f.rho_d.shape) * (rng.uniform(size=f.rho_d.shape) > 0.6) * f.rho_d
+    precl = np.zeros((nys, nxs, 1))
+    t0 = time.perf_counter()
+    for _ in range(5):
+        O.kessler_time_step(20000. / a.nz, dt, f.tracers[0], f.tracers[1], f.tracers[2], f.rho_d, f.temp, precl)
+    tk = (time.perf_counter() - t0) / 5
+    t0 = time.perf_counter()
+    for _ in range(5):
+        O.mlp_forward(f.temp, f.rho_d, f.tracers[0], f.tracers[1], f.tracers[2], W1, b1, W2, b2, si, so)
+    tm = (time.perf_counter() - t0) / 5
+    res["cpu_oracle_1core"] = {"sample_cells": nxs * nys * a.nz, "kessler_cells_per_s": nxs * nys * a.nz / tk,
+                               "mlp_cells_per_s": nxs * nys * a.nz / tm}
+print(json.dumps(res))
