@@ -184,3 +184,42 @@ def test_many_tracers_general_grouping(mw, oracle):
         dycore.time_step(coupler, dt)
         odyc.time_step(of, dt)
     compare_fields(gpu_fields(coupler), of.as_dict(), 1e-10, "7 tracers")
+
+
+RAGGED = {
+    # name: (nx, ny, nz, nens, xlen, ylen, zlen, init_data, num_tracers, enable_gravity, nsteps)
+    "ragged_37x11x5_nens3": (37, 11, 5, 3, 18500., 5500., 20000., "supercell", 3, True, 2),       # x tiles of 46 cells, nens 3
+    "ragged_130x7x9": (130, 7, 9, 1, 65000., 3500., 20000., "supercell", 3, True, 2),             # 3 x tiles, 2 z chunks
+    "ragged2d_70x1x6": (70, 1, 6, 1, 35000., 1.0e5, 20000., "supercell", 3, True, 2),             # 2-D, 2 x tiles
+    "ragged_3x3x3": (3, 3, 3, 1, 1500., 1500., 20000., "supercell", 3, True, 2),                  # the smallest legal grid
+    "ragged_20x5x33_nens10": (20, 5, 33, 10, 10000., 2500., 20000., "supercell", 3, True, 1),     # nens 10: 4 useful lanes per wave
+}
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("name", sorted(RAGGED))
+def test_ragged_sizes(mw, oracle, name, mode):
+    """Tile / chunk / halo edge cases of the marching kernels (partial x tiles, several z and y chunks, nens > 1, tiny grids)."""
+    case = RAGGED[name]
+    coupler, dycore, odyc, of = setup_case(oracle, case)
+    push_fields(coupler, of)
+    dycore.set_strict(mode)
+    dt = dycore.compute_time_step(coupler)
+    nx, ny, nz, nens, xlen, ylen, zlen, init, nt, grav, nsteps = case
+    make = lambda: oracle.supercell_setup(nx, ny, nz, nens, xlen, ylen, zlen, init_data=init, num_tracers=nt,   # noqa: E731
+                                          enable_gravity=grav, perturb=True)
+    sens = oracle_sensitivity(oracle, name, make, (nsteps,))
+    for _ in range(nsteps):
+        dycore.time_step(coupler, dt)
+        odyc.time_step(of, dt)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-10, "%s mode %d" % (name, mode), sens[nsteps])
+
+
+def test_unsupported_options_fail_loudly(mw):
+    from miniweatherml_amd import modules
+    from miniweatherml_amd.capi import MWError
+    coupler, dycore, _ = modules.make_supercell(8, 8, 8, 1, 4000., 4000., 20000.)
+    with pytest.raises(MWError, match="periodic"):
+        dycore.set_bc(coupler, 0, 0, 0)                       # bc_z = periodic: no reference case uses it
+    with pytest.raises(MWError, match="dt_phys"):
+        dycore.time_step(coupler, 0.0)
