@@ -2,7 +2,7 @@
 // experiments/community_benchmark/driver.cpp:66-82), against the MI355X-native modules through
 // miniweatherml_amd/host/mw_facade.h.  Parameters that the reference reads from YAML come from argv:
 //     supercell_driver nx_glob ny_glob nz nens xlen ylen zlen nsteps [init_data] [kessler(0|1)]
-// sponge_layer and ColumnNudger (SURVEY.md 8(f) "next" rows) are not part of the hot path and are not called.
+// kessler = 2 runs the complete loop of driver.cpp:73-76 (dycore, Kessler, sponge_layer, ColumnNudger).
 // Prints max|w|, the serial sum of density_dry and steps/s; used by tests/test_gpu_cpp_facade.py.
 #include "../miniweatherml_amd/host/mw_facade.h"
 #include <chrono>
@@ -16,7 +16,8 @@ int main(int argc, char **argv) {
   real xlen = atof(argv[5]), ylen = atof(argv[6]), zlen = atof(argv[7]);
   int nsteps = atoi(argv[8]);
   std::string init_data = argc > 9 ? argv[9] : "supercell";
-  bool run_micro = argc > 10 ? atoi(argv[10]) != 0 : false;
+  int mode = argc > 10 ? atoi(argv[10]) : 0;
+  bool run_micro = mode != 0, full_loop = mode == 2;
   try {
     core::Coupler coupler;
     coupler.set_option<std::string>("out_prefix", "test");
@@ -28,6 +29,8 @@ int main(int argc, char **argv) {
     modules::Dynamics_Euler_Stratified_WenoFV dycore;
     micro.init(coupler);                                                                  // :58
     dycore.init(coupler);                                                                 // :59
+    modules::ColumnNudger column_nudger;
+    if (full_loop) column_nudger.set_column(coupler);                                     // :60
     modules::perturb_temperature(coupler);                                                // :61
     real etime = 0;
     (void)hipDeviceSynchronize();
@@ -35,7 +38,8 @@ int main(int argc, char **argv) {
     for (int s = 0; s < nsteps; s++) {                                                    // :66-79
       real dtphys = dycore.compute_time_step(coupler);
       dycore.time_step(coupler, dtphys);
-      if (run_micro) micro.time_step(coupler, dtphys);
+      if (run_micro) micro.time_step(coupler, dtphys);                                    // :74
+      if (full_loop) { modules::sponge_layer(coupler, dtphys); column_nudger.nudge_to_column(coupler, dtphys); }   // :75-76
       etime += dtphys;
     }
     (void)hipDeviceSynchronize();

@@ -155,6 +155,25 @@ int  mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *
                           const double *rho_d, double *temp, double *precl, void *workspace, int *rainsplit_out,
                           void *stream);
 
+/* ---- sponge layer + column nudging (the two remaining per-step modules of the supercell loop) ---- */
+/* Sums `buf` (DEVICE, n doubles) in place over all ranks, ordered on `stream` -- MPI_Allreduce(SUM) in the reference
+ * (sponge_layer.h:53-63, column_nudging.h:89-99).  Pass NULL on a single rank. */
+typedef int (*mw_allreduce_fn)(void *ctx, double *buf, long long n, void *stream);
+/* DEVICE scratch size for the three calls below (num_fields = 5 + T for the sponge, 5 for the nudger). */
+long long mw_column_workspace_bytes(const mw_grid_t *g, int num_fields);
+/* modules::sponge_layer(coupler, dt, time_scale = 60), sponge_layer.h:8-77: relax the top 10 levels of every field to the
+ * horizontal mean (w to zero).  fields: HOST array of num_fields DEVICE pointers in the reference's MultiField order
+ * (density_dry, uvel, vvel, wvel, temp, tracers...).  Horizontal sums are deterministic (no atomics). */
+int  mw_sponge_layer(const mw_grid_t *g, double *const *fields, int num_fields, double dt, double time_scale, void *workspace,
+                     mw_allreduce_fn allreduce, void *ctx, void *stream);
+/* ColumnNudger::get_column_average, column_nudging.h:69-106: state5 = density_dry, uvel, vvel, temp, water_vapor;
+ * column_out: DEVICE (5,nz,nens).  set_column (:15-36) is this call on the initial state. */
+int  mw_column_average(const mw_grid_t *g, const double *const *state5, double *column_out, void *workspace,
+                       mw_allreduce_fn allreduce, void *ctx, void *stream);
+/* ColumnNudger::nudge_to_column(coupler, dt), :39-66: state += dt (column - column_average(state)) / 900. */
+int  mw_nudge_to_column(const mw_grid_t *g, double *const *state5, const double *column, double dt, void *workspace,
+                        mw_allreduce_fn allreduce, void *ctx, void *stream);
+
 /* ---- ponni surrogate MLP -------------------------------------------------------------------------- */
 /* NN block of custom_modules::Microphysics_Kessler::time_step,
  * experiments/supercell_kessler_surrogate/custom_modules/microphysics_kessler_ponni.h:176-202

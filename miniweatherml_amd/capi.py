@@ -35,6 +35,8 @@ class Grid(C.Structure):
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_void_p, C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p)
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p)
+
 # every symbol include/mw_cdna4.h declares (checked by tests/test_capi_symbols.py against the header text)
 SYMBOLS = {
     "mw_last_error": (C.c_char_p, []),
@@ -67,6 +69,12 @@ SYMBOLS = {
     "mw_kessler_workspace_bytes": (C.c_longlong, [C.c_int, C.c_longlong]),
     "mw_kessler_time_step": (C.c_int, [C.c_int, C.c_longlong, C.c_double, C.c_double] + [C.c_void_p] * 7 +
                              [C.POINTER(C.c_int), C.c_void_p]),
+    "mw_column_workspace_bytes": (C.c_longlong, [C.POINTER(Grid), C.c_int]),
+    "mw_sponge_layer": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.c_int, C.c_double, C.c_double, C.c_void_p, ALLREDUCE_FN,
+                                  C.c_void_p, C.c_void_p]),
+    "mw_column_average": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_void_p]),
+    "mw_nudge_to_column": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.c_void_p, C.c_double, C.c_void_p, ALLREDUCE_FN,
+                                     C.c_void_p, C.c_void_p]),
     "mw_mlp_forward": (C.c_int, [C.c_longlong] + [C.c_void_p] * 5 + [C.POINTER(C.c_float)] * 4 +
                        [C.POINTER(C.c_double)] * 2 + [C.c_void_p] * 4 + [C.c_void_p]),
 }

@@ -1,0 +1,166 @@
+// =====================================================================================================
+// mw_column.hip -- the two remaining per-step modules of the supercell loop:
+//   modules::sponge_layer(coupler, dt, time_scale)      model/modules/sponge_layer.h:8-77
+//   modules::ColumnNudger::{set_column, nudge_to_column} model/modules/column_nudging.h:15-106
+// Both need horizontal sums per (field, level, ensemble member).  The reference accumulates them with atomicAdd
+// (order undefined on a GPU, sponge_layer.h:50, column_nudging.h:86); here they are DETERMINISTIC: fixed slices of a level
+// are tree-reduced per workgroup, the slice partials are added in index order, ranks are combined by the caller's
+// all-reduce (MPI_Allreduce in the reference, :53-63 / :89-99; ncclAllReduce / torch.distributed natively).
+// =====================================================================================================
+#include "../../include/mw_cdna4.h"
+#include "mw_common.h"
+#include <cmath>
+
+namespace mw {
+
+struct FieldPtrs { double *f[5 + MW_MAX_TRACERS]; };
+
+static constexpr int SLICE = 16384;       // cells per partial sum
+
+// partial[((fld*nlev + lev)*nens + e)*S + s] = sum over slice s of level `lev0 + dir*lev` of field fld, member e
+__global__ __launch_bounds__(256) void k_hsum_partial(FieldPtrs fp, int nlev, int lev0, int dir, long long ncell_lev, int nens, int S,
+                                                      int skip_field, double *__restrict__ partial) {
+  const int s = blockIdx.x, lev = blockIdx.y, fe = blockIdx.z;
+  const int fld = fe / nens, e = fe - fld * nens;
+  double acc = 0;
+  if (fld != skip_field) {
+    const double *src = fp.f[fld] + (long long)(lev0 + dir * lev) * ncell_lev * nens + e;
+    const long long c0 = (long long)s * SLICE, c1 = min(c0 + SLICE, ncell_lev);
+    for (long long c = c0 + threadIdx.x; c < c1; c += 256) acc += src[c * nens];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[((long long)(fld * nlev + lev) * nens + e) * S + s] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ __launch_bounds__(256) void k_hsum_finish(const double *__restrict__ partial, long long n, int S, double *__restrict__ out) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  double a = 0;
+  for (int s = 0; s < S; s++) a += partial[t * S + s];
+  out[t] = a;
+}
+
+// sponge_layer.h:66-76
+__global__ __launch_bounds__(256) void k_sponge_apply(FieldPtrs fp, int num_fields, int num_layers, int nz, long long ncell_lev, int nens,
+                                                      double zlen, double dz, double time_factor, double nglob,
+                                                      const double *__restrict__ havg) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int kloc = blockIdx.y, ifld = blockIdx.z;
+  if (t >= ncell_lev * nens) return;
+  const int e = (int)(t % nens);
+  const int k = nz - 1 - kloc;
+  double z = (k + 0.5) * dz;
+  double rel_dist = (zlen - z) / (num_layers * dz);
+  double space_factor = (cos(M_PI * rel_dist) + 1) / 2;
+  double factor = space_factor * time_factor;
+  double *q = fp.f[ifld] + (long long)k * ncell_lev * nens + t;
+  double v = *q;
+  *q = v + (havg[(ifld * num_layers + kloc) * nens + e] / nglob - v) * factor;
+}
+
+__global__ __launch_bounds__(256) void k_div_scalar(double *__restrict__ a, long long n, double d) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) a[t] = a[t] / d;
+}
+
+// column_nudging.h:62-65
+__global__ __launch_bounds__(256) void k_nudge_apply(FieldPtrs fp, int nz, long long ncell_lev, int nens, double dt,
+                                                     const double *__restrict__ column, const double *__restrict__ avg) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y, l = blockIdx.z;
+  if (t >= ncell_lev * nens) return;
+  const int e = (int)(t % nens);
+  const double time_scale = 900;
+  const long long m = ((long long)l * nz + k) * nens + e;
+  double *q = fp.f[l] + (long long)k * ncell_lev * nens + t;
+  *q = *q + dt * (column[m] - avg[m]) / time_scale;
+}
+
+} // namespace mw
+
+using namespace mw;
+
+// horizontal sums of `nf` fields over levels lev0, lev0+dir, ... (nlev of them) -> out (nf, nlev, nens), all ranks combined
+static int hsum(const mw_grid_t *g, const FieldPtrs &fp, int nf, int nlev, int lev0, int dir, int skip_field, double *out, double *partial,
+                mw_allreduce_fn ar, void *ctx, hipStream_t st) {
+  const long long ncell_lev = (long long)g->ny * g->nx;
+  const int S = (int)((ncell_lev + SLICE - 1) / SLICE);
+  dim3 grid((unsigned)S, (unsigned)nlev, (unsigned)(nf * g->nens));
+  hipLaunchKernelGGL(k_hsum_partial, grid, dim3(256), 0, st, fp, nlev, lev0, dir, ncell_lev, g->nens, S, skip_field, partial);
+  MW_LAUNCH_CHECK();
+  const long long n = (long long)nf * nlev * g->nens;
+  hipLaunchKernelGGL(k_hsum_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, n, S, out);
+  MW_LAUNCH_CHECK();
+  if (ar && g->nproc_x * g->nproc_y > 1) { if (ar(ctx, out, n, st)) MW_FAIL("all-reduce callback failed"); }
+  return 0;
+}
+
+extern "C" {
+
+long long mw_column_workspace_bytes(const mw_grid_t *g, int num_fields) {
+  if (!g || num_fields < 1) return -1;
+  const long long ncell_lev = (long long)g->ny * g->nx;
+  const long long S = (ncell_lev + SLICE - 1) / SLICE;
+  const long long nlev = g->nz;                       // the nudger sums every level; the sponge only 10
+  return (long long)sizeof(double) * ((long long)num_fields * nlev * g->nens * (S + 2) + 64);
+}
+
+int mw_sponge_layer(const mw_grid_t *g, double *const *fields, int num_fields, double dt, double time_scale, void *workspace,
+                    mw_allreduce_fn allreduce, void *ctx, void *stream) {
+  if (!g || !fields || !workspace) MW_FAIL("sponge_layer: null argument");
+  if (num_fields < 5 || num_fields > 5 + MW_MAX_TRACERS) MW_FAIL("sponge_layer: num_fields out of range");
+  const int num_layers = 10, WFLD = 3;                                       // sponge_layer.h:19-21
+  if (g->nz < num_layers) MW_FAIL("sponge_layer: needs nz >= 10");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipStream_t st = (hipStream_t)stream;
+  FieldPtrs fp;
+  for (int f = 0; f < num_fields; f++) { if (!fields[f]) MW_FAIL("sponge_layer: null field"); fp.f[f] = fields[f]; }
+  double *havg = (double *)workspace;
+  double *partial = havg + (long long)num_fields * num_layers * g->nens;
+  if (hsum(g, fp, num_fields, num_layers, g->nz - 1, -1, WFLD, havg, partial, allreduce, ctx, st)) return 1;
+  const long long ncell_lev = (long long)g->ny * g->nx;
+  dim3 grid((unsigned)((ncell_lev * g->nens + 255) / 256), (unsigned)num_layers, (unsigned)num_fields);
+  const double dz = g->zlen / g->nz;
+  const double nglob = (double)((unsigned long long)g->nx_glob * (unsigned long long)g->ny_glob);      // size_t product (:75)
+  hipLaunchKernelGGL(k_sponge_apply, grid, dim3(256), 0, st, fp, num_fields, num_layers, g->nz, ncell_lev, g->nens, g->zlen, dz,
+                     dt / time_scale, nglob, havg);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+int mw_column_average(const mw_grid_t *g, const double *const *state5, double *column_out, void *workspace, mw_allreduce_fn allreduce,
+                      void *ctx, void *stream) {
+  if (!g || !state5 || !column_out || !workspace) MW_FAIL("column_average: null argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipStream_t st = (hipStream_t)stream;
+  FieldPtrs fp;
+  for (int f = 0; f < 5; f++) { if (!state5[f]) MW_FAIL("column_average: null field"); fp.f[f] = (double *)state5[f]; }
+  if (hsum(g, fp, 5, g->nz, 0, +1, -1, column_out, (double *)workspace, allreduce, ctx, st)) return 1;
+  const long long n = 5ll * g->nz * g->nens;
+  const double nglob = (double)((int)g->nx_glob * (int)g->ny_glob);          // int product (column_nudging.h:73-74,103)
+  hipLaunchKernelGGL(k_div_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, column_out, n, nglob);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+int mw_nudge_to_column(const mw_grid_t *g, double *const *state5, const double *column, double dt, void *workspace,
+                       mw_allreduce_fn allreduce, void *ctx, void *stream) {
+  if (!g || !state5 || !column || !workspace) MW_FAIL("nudge_to_column: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  double *avg = (double *)workspace;
+  double *rest = avg + 5ll * g->nz * g->nens;
+  if (mw_column_average(g, state5, avg, rest, allreduce, ctx, stream)) return 1;
+  FieldPtrs fp;
+  for (int f = 0; f < 5; f++) fp.f[f] = state5[f];
+  const long long ncell_lev = (long long)g->ny * g->nx;
+  dim3 grid((unsigned)((ncell_lev * g->nens + 255) / 256), (unsigned)g->nz, 5u);
+  hipLaunchKernelGGL(k_nudge_apply, grid, dim3(256), 0, st, fp, g->nz, ncell_lev, g->nens, dt, column, avg);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+} // extern "C"

@@ -280,6 +280,44 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
   }
 };
 
+// modules::sponge_layer(coupler, dt, time_scale = 60)   model/modules/sponge_layer.h:8-77  (single rank: no all-reduce)
+inline void sponge_layer(core::Coupler &coupler, real dt, real time_scale = 60, mw_allreduce_fn allreduce = nullptr, void *ctx = nullptr) {
+  auto &dm = coupler.get_data_manager_readwrite();
+  std::vector<double *> f;
+  for (const char *n : {"density_dry", "uvel", "vvel", "wvel", "temp"}) f.push_back(dm.get<real>(n).data());
+  for (auto &n : coupler.get_tracer_names()) f.push_back(dm.get<real>(n).data());
+  static thread_local void *ws = nullptr; static thread_local long long ws_bytes = 0;
+  long long need = mw_column_workspace_bytes(&coupler.grid, (int)f.size());
+  if (need > ws_bytes) { if (ws) (void)hipFree(ws); if (hipMalloc(&ws, (size_t)need) != hipSuccess) endrun("sponge workspace allocation failed"); ws_bytes = need; }
+  mw_check(mw_sponge_layer(&coupler.grid, f.data(), (int)f.size(), dt, time_scale, ws, allreduce, ctx, nullptr));
+}
+
+class ColumnNudger {                                                  // model/modules/column_nudging.h:9-108
+  double *column = nullptr; void *ws = nullptr; long long ws_bytes = 0;
+  static std::vector<double *> state(core::Coupler &c) {
+    auto &dm = c.get_data_manager_readwrite(); std::vector<double *> s;
+    for (const char *n : {"density_dry", "uvel", "vvel", "temp", "water_vapor"}) s.push_back(dm.get<real>(n).data());
+    return s;
+  }
+  void ensure(core::Coupler &c) {
+    long long need = mw_column_workspace_bytes(&c.grid, 5);
+    if (need > ws_bytes) { if (ws) (void)hipFree(ws); if (hipMalloc(&ws, (size_t)need) != hipSuccess) endrun("nudger workspace allocation failed"); ws_bytes = need; }
+    if (!column && hipMalloc((void **)&column, sizeof(double) * 5 * (size_t)c.get_nz() * c.get_nens()) != hipSuccess) endrun("nudger column allocation failed");
+  }
+ public:
+  int static constexpr num_fields = 5;
+  ~ColumnNudger() { if (column) (void)hipFree(column); if (ws) (void)hipFree(ws); }
+  void set_column(core::Coupler &coupler, mw_allreduce_fn ar = nullptr, void *ctx = nullptr) {                 // :15-36
+    ensure(coupler); auto s = state(coupler);
+    mw_check(mw_column_average(&coupler.grid, s.data(), column, ws, ar, ctx, nullptr));
+  }
+  void nudge_to_column(core::Coupler &coupler, real dt, mw_allreduce_fn ar = nullptr, void *ctx = nullptr) {   // :39-66
+    if (!column) endrun("ColumnNudger::nudge_to_column before set_column");
+    auto s = state(coupler);
+    mw_check(mw_nudge_to_column(&coupler.grid, s.data(), column, dt, ws, ar, ctx, nullptr));
+  }
+};
+
 inline void perturb_temperature(core::Coupler &coupler, bool thermal = true, bool random = false) {   // perturb_temperature.h:8-67
   if (random) endrun("perturb_temperature(random=true) needs yakl::Random and is not on the hot path");
   if (thermal) mw_check(mw_perturb_temperature(&coupler.grid, coupler.get_data_manager_readwrite().get<real>("temp").data(), nullptr));

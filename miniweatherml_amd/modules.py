@@ -293,6 +293,92 @@ def perturb_temperature(coupler, thermal=True, random=False):                   
             check(capi.lib().mw_perturb_temperature(C.byref(coupler.grid), _ptr(temp), _stream_ptr(coupler.device)))
 
 
+def _torch_allreduce(coupler, group=None):
+    """mw_allreduce_fn over torch.distributed (RCCL on GPUs) for the sponge / nudger horizontal means; None on one rank."""
+    import torch.distributed as dist
+    if coupler.get_nranks() <= 1 or not dist.is_initialized():
+        return C.cast(None, capi.ALLREDUCE_FN), None
+    dev = coupler.device
+
+    def cb(ctx, buf, n, stream):
+        try:
+            class _A:
+                pass
+            a = _A()
+            a.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f8", data=(int(buf), False), version=2)
+            st = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+            with torch.cuda.device(dev), torch.cuda.stream(st):
+                t = torch.as_tensor(a, device=dev)
+                if dist.get_backend(group) == "gloo":
+                    h = t.cpu(); dist.all_reduce(h, group=group); t.copy_(h)
+                else:
+                    dist.all_reduce(t, group=group)
+            return 0
+        except Exception as e:                                   # pragma: no cover
+            import sys
+            print("allreduce callback failed: %r" % (e,), file=sys.stderr)
+            return 1
+    fn = capi.ALLREDUCE_FN(cb)
+    return fn, fn
+
+
+def _field_ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = _ptr(t).value
+    return arr
+
+
+def _column_ws(coupler, nf, holder):
+    nbytes = capi.lib().mw_column_workspace_bytes(C.byref(coupler.grid), nf)
+    ws = getattr(holder, "_ws_col", None)
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=coupler.device)
+        holder._ws_col = ws
+    return ws
+
+
+def sponge_layer(coupler, dt, time_scale=60.0):
+    """modules::sponge_layer(coupler, dt, time_scale), model/modules/sponge_layer.h:8-77."""
+    dm = coupler.get_data_manager_readwrite()
+    fields = [dm.get(n) for n in ("density_dry", "uvel", "vvel", "wvel", "temp")] + [dm.get(n) for n in coupler.get_tracer_names()]
+    ws = _column_ws(coupler, len(fields), coupler)
+    fn, keep = _torch_allreduce(coupler)
+    with torch.cuda.device(coupler.device):
+        check(capi.lib().mw_sponge_layer(C.byref(coupler.grid), _field_ptr_array(fields), len(fields), float(dt), float(time_scale),
+                                         _ptr(ws), fn, None, _stream_ptr(coupler.device)))
+
+
+class ColumnNudger:
+    """modules::ColumnNudger, model/modules/column_nudging.h:9-108."""
+    num_fields = 5
+
+    def __init__(self):
+        self.column = None
+
+    @staticmethod
+    def _state(coupler):
+        dm = coupler.get_data_manager_readwrite()
+        return [dm.get(n) for n in ("density_dry", "uvel", "vvel", "temp", "water_vapor")]
+
+    def set_column(self, coupler):                                             # :15-36
+        self.column = torch.zeros((5, coupler.get_nz(), coupler.get_nens()), dtype=torch.float64, device=coupler.device)
+        ws = _column_ws(coupler, 5, self)
+        fn, keep = _torch_allreduce(coupler)
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_column_average(C.byref(coupler.grid), _field_ptr_array(self._state(coupler)), _ptr(self.column), _ptr(ws),
+                                               fn, None, _stream_ptr(coupler.device)))
+
+    def nudge_to_column(self, coupler, dt):                                    # :39-66
+        if self.column is None:
+            endrun("ColumnNudger.nudge_to_column before set_column")
+        ws = _column_ws(coupler, 5, self)
+        fn, keep = _torch_allreduce(coupler)
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_nudge_to_column(C.byref(coupler.grid), _field_ptr_array(self._state(coupler)), _ptr(self.column), float(dt),
+                                                _ptr(ws), fn, None, _stream_ptr(coupler.device)))
+
+
 def use_rccl_exchange(dycore, coupler, group=None):
     """Slab halo exchange over RCCL point-to-point inside the library (mw_rccl.cpp): rank 0 creates the ncclUniqueId,
     torch.distributed broadcasts it, every rank joins.  Replaces the MPI_Isend/Irecv of halo_exchange (:641-723)."""
@@ -365,7 +451,7 @@ def use_torch_distributed_exchange(dycore, coupler, group=None, host_staged=Fals
 
 
 def make_supercell(nx_glob, ny_glob, nz, nens=1, xlen=1.0e5, ylen=1.0e5, zlen=2.0e4, init_data="supercell", device="cuda:0",
-                   nranks=1, myrank=0, micro=None, enable_gravity=None, perturb=True):
+                   nranks=1, myrank=0, micro=None, enable_gravity=None, perturb=True, with_nudger=False):
     """The set-up sequence of experiments/supercell_example/driver.cpp:41-61 (column nudger excluded)."""
     coupler = Coupler(device)
     coupler.set_option("out_prefix", "test")
@@ -379,6 +465,22 @@ def make_supercell(nx_glob, ny_glob, nz, nens=1, xlen=1.0e5, ylen=1.0e5, zlen=2.
     dycore = Dynamics_Euler_Stratified_WenoFV()
     micro.init(coupler)
     dycore.init(coupler)
+    if with_nudger:
+        nudger = ColumnNudger()
+        nudger.set_column(coupler)                 # driver.cpp:60: set the column BEFORE perturbing
     if perturb:
         perturb_temperature(coupler)
+    if with_nudger:
+        return coupler, dycore, micro, nudger
     return coupler, dycore, micro
+
+
+def supercell_step(coupler, dycore, micro, nudger, dtphys=None):
+    """One iteration of the reference's time loop, experiments/supercell_example/driver.cpp:66-79."""
+    if dtphys is None:
+        dtphys = dycore.compute_time_step(coupler)
+    dycore.time_step(coupler, dtphys)
+    micro.time_step(coupler, dtphys)
+    sponge_layer(coupler, dtphys)
+    nudger.nudge_to_column(coupler, dtphys)
+    return dtphys

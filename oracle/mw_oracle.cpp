@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <random>
 #include <algorithm>
+#include <vector>
 
 #define FP(x) ((double)(x##L))
 
@@ -1472,6 +1473,71 @@ int mwo_kessler_time_step(int nz, long long ncol_ll, double dz, double dt,
   free(qv); free(qc); free(qr); free(pressure); free(theta); free(exner); free(zmid);
   free(r); free(rhalf); free(pc); free(velqr); free(dt2d); free(sed);
   return rainsplit;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// modules::sponge_layer(coupler, dt, time_scale = 60)       model/modules/sponge_layer.h:8-77
+// fields: 5 + T pointers in the reference's MultiField order (density_dry, uvel, vvel, wvel, temp, tracers...).
+// The horizontal sums are accumulated in the serial-backend order (j, i, iens innermost) -- the reference uses
+// atomicAdd (:50), so the order is backend dependent there.  allreduce (may be NULL) sums buf in place over ranks (:53-63).
+// -----------------------------------------------------------------------------------------------------
+typedef void (*mwo_allreduce_fn)(void *ctx, double *buf, long long n);
+
+void mwo_sponge_layer(const mwo_params *pp, double *const *fields, int num_fields, double dt, double time_scale,
+                      mwo_allreduce_fn allreduce, void *ctx) {
+  const mwo_params &p = *pp;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens;
+  real zlen = p.zlen, dz = get_dz(p);
+  size_t nx_glob = (size_t)p.nx_glob, ny_glob = (size_t)p.ny_glob;
+  int num_layers = 10;
+  int WFLD = 3;
+  std::vector<real> havg((size_t)num_fields*num_layers*nens, 0.0);
+  #define HAVG(f,kl,e) havg[((size_t)(f)*num_layers+(kl))*nens+(e)]
+  for (int ifld=0; ifld<num_fields; ifld++) for (int kloc=0; kloc<num_layers; kloc++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    int k = nz - 1 - kloc;
+    if (ifld != WFLD) HAVG(ifld,kloc,iens) += fields[ifld][D.C(k,j,i,iens)];
+  }
+  if (allreduce) allreduce(ctx, havg.data(), (long long)havg.size());
+  real time_factor = dt / time_scale;
+  for (int ifld=0; ifld<num_fields; ifld++) for (int kloc=0; kloc<num_layers; kloc++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    int k = nz - 1 - kloc;
+    real z = (k+FP(0.5))*dz;
+    real rel_dist = ( zlen - z ) / ( num_layers * dz );
+    real space_factor = ( cos(M_PI*rel_dist) + 1 ) / 2;
+    real factor = space_factor * time_factor;
+    fields[ifld][D.C(k,j,i,iens)] += ( HAVG(ifld,kloc,iens)/(nx_glob*ny_glob) - fields[ifld][D.C(k,j,i,iens)] ) * factor;
+  }
+  #undef HAVG
+}
+
+// ColumnNudger::get_column_average      model/modules/column_nudging.h:69-106
+// state: 5 pointers (density_dry, uvel, vvel, temp, water_vapor); column_out (5,nz,nens)
+void mwo_column_average(const mwo_params *pp, const double *const *state, double *column_out, mwo_allreduce_fn allreduce, void *ctx) {
+  const mwo_params &p = *pp;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens;
+  int nx_glob = (int)p.nx_glob, ny_glob = (int)p.ny_glob;      // `int nx_glob = coupler.get_nx_glob()` :73-74
+  const int num_fields = 5;
+  size_t n = (size_t)num_fields*nz*nens;
+  for (size_t m=0;m<n;m++) column_out[m] = 0;
+  for (int l=0;l<num_fields;l++) for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    column_out[((size_t)l*nz+k)*nens+iens] += state[l][D.C(k,j,i,iens)];
+  }
+  if (allreduce) allreduce(ctx, column_out, (long long)n);
+  for (size_t m=0;m<n;m++) column_out[m] = column_out[m] / (nx_glob*ny_glob);
+}
+
+// ColumnNudger::nudge_to_column(coupler, dt)      :39-66   (column = what set_column stored, :15-36)
+void mwo_nudge_to_column(const mwo_params *pp, double *const *state, const double *column, double dt, mwo_allreduce_fn allreduce, void *ctx) {
+  const mwo_params &p = *pp;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens;
+  const int num_fields = 5;
+  std::vector<real> avg((size_t)num_fields*nz*nens);
+  mwo_column_average(pp, state, avg.data(), allreduce, ctx);
+  const real time_scale = 900;
+  for (int l=0;l<num_fields;l++) for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+    size_t m = ((size_t)l*nz+k)*nens+iens;
+    state[l][D.C(k,j,i,iens)] += dt * ( column[m] - avg[m] ) / time_scale;
+  }
 }
 
 // -----------------------------------------------------------------------------------------------------

@@ -36,6 +36,8 @@ XCHG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int,
                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                       C.c_longlong, C.c_longlong)
 
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_longlong)
+
 _lib = None
 
 
@@ -83,6 +85,9 @@ def lib():
     L.mwo_time_step.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, pdp, C.c_double]
     L.mwo_kessler_time_step.restype = C.c_int
     L.mwo_kessler_time_step.argtypes = [C.c_int, C.c_longlong, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
+    L.mwo_sponge_layer.argtypes = [C.POINTER(Params), pdp, C.c_int, C.c_double, C.c_double, ALLREDUCE_FN, C.c_void_p]
+    L.mwo_column_average.argtypes = [C.POINTER(Params), pdp, dp, ALLREDUCE_FN, C.c_void_p]
+    L.mwo_nudge_to_column.argtypes = [C.POINTER(Params), pdp, dp, C.c_double, ALLREDUCE_FN, C.c_void_p]
     fp = C.POINTER(C.c_float)
     L.mwo_mlp_forward.argtypes = [C.c_longlong, dp, dp, dp, dp, dp, fp, fp, fp, fp, dp, dp, dp, dp, dp, dp]
     _lib = L
@@ -258,6 +263,40 @@ def mlp_forward(temp, rho_d, rho_v, rho_c, rho_r, W1, b1, W2, b2, scl_in, scl_ou
     lib().mwo_mlp_forward(n, _dp(temp), _dp(rho_d), _dp(rho_v), _dp(rho_c), _dp(rho_r), _fp(W1), _fp(b1), _fp(W2), _fp(b2),
                           _dp(scl_in), _dp(scl_out), *[_dp(o) for o in outs])
     return outs
+
+
+def _ptr_array(arrs):
+    a = (C.POINTER(C.c_double) * len(arrs))()
+    for i, x in enumerate(arrs):
+        a[i] = _dp(x)
+    return a
+
+
+def _ar(allreduce):
+    return ALLREDUCE_FN(allreduce) if allreduce else C.cast(None, ALLREDUCE_FN)
+
+
+def sponge_layer(p, f, dt, time_scale=60.0, allreduce=None):
+    """modules::sponge_layer on Fields f (density_dry, uvel, vvel, wvel, temp, tracers...)."""
+    arrs = [f.rho_d, f.uvel, f.vvel, f.wvel, f.temp] + list(f.tracers)
+    cb = _ar(allreduce)
+    lib().mwo_sponge_layer(C.byref(p), _ptr_array(arrs), len(arrs), float(dt), float(time_scale), cb, None)
+
+
+class ColumnNudger:
+    """modules::ColumnNudger (column_nudging.h): set_column / nudge_to_column on (density_dry, uvel, vvel, temp, water_vapor)."""
+
+    def _state(self, f, idWV=0):
+        return [f.rho_d, f.uvel, f.vvel, f.temp, f.tracers[idWV]]
+
+    def set_column(self, p, f, allreduce=None):
+        self.column = np.zeros((5, p.nz, p.nens))
+        cb = _ar(allreduce)
+        lib().mwo_column_average(C.byref(p), _ptr_array(self._state(f, p.idWV)), _dp(self.column), cb, None)
+
+    def nudge_to_column(self, p, f, dt, allreduce=None):
+        cb = _ar(allreduce)
+        lib().mwo_nudge_to_column(C.byref(p), _ptr_array(self._state(f, p.idWV)), _dp(self.column), float(dt), cb, None)
 
 
 def city_building_heights(p):

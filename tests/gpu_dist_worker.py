@@ -18,15 +18,20 @@ from util import gpu_fields  # noqa: E402
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     nxg, nyg, nz, nsteps = [int(v) for v in sys.argv[4:8]]
+    full = len(sys.argv) > 8 and sys.argv[8] == "full"      # the complete driver loop (Kessler, sponge, nudger with all-reduce)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     xlen, ylen = 500.0 * nxg, (500.0 * nyg if nyg > 1 else 1.0e5)
-    coupler, dycore, _ = modules.make_supercell(nxg, nyg, nz, 1, xlen, ylen, 20000., nranks=world, myrank=rank)
+    coupler, dycore, micro, nudger = modules.make_supercell(nxg, nyg, nz, 1, xlen, ylen, 20000., nranks=world, myrank=rank,
+                                                            with_nudger=True)
     modules.use_torch_distributed_exchange(dycore, coupler, host_staged=True)
     dt = dycore.compute_time_step(coupler)
     for _ in range(nsteps):
-        dycore.time_step(coupler, dt)
+        if full:
+            modules.supercell_step(coupler, dycore, micro, nudger, dt)
+        else:
+            dycore.time_step(coupler, dt)
     torch.cuda.synchronize()
     g = gpu_fields(coupler)
     names = sorted(g)
@@ -36,7 +41,7 @@ def main():
     dist.all_gather(metas, meta)
     ok = 1
     if rank == 0:
-        full = np.zeros((len(names), nz, nyg, nxg, 1))
+        gathered = np.zeros((len(names), nz, nyg, nxg, 1))
         for r in range(world):
             ib, jb, nx, ny = [int(v) for v in metas[r]]
             if r == 0:
@@ -45,15 +50,24 @@ def main():
                 buf = torch.empty((len(names), nz, ny, nx, 1), dtype=torch.float64)
                 dist.recv(buf, r)
                 blk = buf.numpy()
-            full[:, :, jb:jb + ny, ib:ib + nx] = blk
-        c1, d1, _ = modules.make_supercell(nxg, nyg, nz, 1, xlen, ylen, 20000.)
+            gathered[:, :, jb:jb + ny, ib:ib + nx] = blk
+        c1, d1, m1, n1 = modules.make_supercell(nxg, nyg, nz, 1, xlen, ylen, 20000., with_nudger=True)
         for _ in range(nsteps):
-            d1.time_step(c1, dt)
+            if full:
+                modules.supercell_step(c1, d1, m1, n1, dt)
+            else:
+                d1.time_step(c1, dt)
         ref = gpu_fields(c1)
         for i, k in enumerate(names):
-            if not np.array_equal(full[i], ref[k]):
+            if full:      # the cross-rank sum order of the horizontal means differs from the single-rank order (and the
+                          # Kessler rainsplit is rank-local in the reference, quirk 5): rounding-level agreement
+                err, scale = float(np.max(np.abs(gathered[i] - ref[k]))), float(np.max(np.abs(ref[k])))
+                if err > 1e-9 * scale + 1e-9:
+                    ok = 0
+                    print("MISMATCH", k, err, scale)
+            elif not np.array_equal(gathered[i], ref[k]):
                 ok = 0
-                print("MISMATCH", k, float(np.max(np.abs(full[i] - ref[k]))))
+                print("MISMATCH", k, float(np.max(np.abs(gathered[i] - ref[k]))))
     else:
         dist.send(torch.from_numpy(mine.copy()), 0)
     flag = torch.tensor([ok])

@@ -51,3 +51,17 @@ def test_cpp_driver_reports_endrun(mw):
     exe = os.path.join(ROOT, "examples", "supercell_driver")
     out = subprocess.run([exe, "16", "16", "8", "1", "8000", "8000", "20000", "1", "no_such_case"], capture_output=True, text=True)
     assert out.returncode == 1 and "Invalid init_data" in out.stderr
+
+
+def test_cpp_driver_full_loop_equals_python(mw):
+    from miniweatherml_amd import modules
+    etime, maxw, sumr, _ = run_driver(20, 16, 12, 1, 10000., 8000., 20000., 3, "supercell", 2)
+    coupler, dycore, micro, nudger = modules.make_supercell(20, 16, 12, 1, 10000., 8000., 20000., with_nudger=True)
+    for _ in range(3):
+        modules.supercell_step(coupler, dycore, micro, nudger)
+    w = coupler.get_data_manager_readonly().get("wvel", True).cpu().numpy()
+    r = coupler.get_data_manager_readonly().get("density_dry", True).cpu().numpy()
+    s = 0.0
+    for x in r.ravel().tolist():
+        s += x
+    assert float(np.abs(w).max()) == maxw and s == sumr

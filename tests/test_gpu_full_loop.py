@@ -1,0 +1,82 @@
+"""The complete time loop of experiments/supercell_example/driver.cpp:66-79 on the GPU -- dycore -> Kessler ->
+sponge_layer -> ColumnNudger -- against the CPU oracle's loop, plus the two extra modules on their own."""
+import numpy as np
+import pytest
+import torch
+
+from util import compare_fields, gpu_fields, oracle_sensitivity, push_fields
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_loop_setup(oracle, nx, ny, nz, nens, xlen, ylen, zlen):
+    p, _ = oracle.make_params(nx, ny, nz, nens, xlen, ylen, zlen)
+    dyc = oracle.OracleDycore(p)
+    f = oracle.Fields(dyc.p)
+    dyc.init("supercell", f)
+    nud = oracle.ColumnNudger()
+    nud.set_column(dyc.p, f)
+    oracle.perturb_temperature(dyc.p, f.temp)
+    return dyc, f, nud
+
+
+def oracle_step(oracle, dyc, f, nud, dt, precl):
+    dyc.time_step(f, dt)
+    oracle.kessler_time_step(dyc.p.zlen / dyc.p.nz, dt, f.tracers[0], f.tracers[1], f.tracers[2], f.rho_d, f.temp, precl)
+    oracle.sponge_layer(dyc.p, f, dt)
+    nud.nudge_to_column(dyc.p, f, dt)
+
+
+@pytest.mark.parametrize("shape", [(24, 20, 16, 1), (64, 1, 24, 1), (12, 10, 12, 2)])
+def test_full_supercell_loop(mw, oracle, shape):
+    from miniweatherml_amd import modules
+    nx, ny, nz, nens = shape
+    xlen, ylen = 500.0 * nx, (500.0 * ny if ny > 1 else 1.0e5)
+    coupler, dycore, micro, nudger = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000., with_nudger=True)
+    dyc, f, nud = oracle_loop_setup(oracle, nx, ny, nz, nens, xlen, ylen, 20000.)
+    assert np.max(np.abs(nudger.column.cpu().numpy() - nud.column)) <= 1e-13 * np.max(np.abs(nud.column))
+    push_fields(coupler, f)
+    dt = dycore.compute_time_step(coupler)
+    precl = np.zeros((ny, nx, nens))
+    sens = oracle_sensitivity(oracle, ("loop",) + shape, lambda: oracle.supercell_setup(nx, ny, nz, nens, xlen, ylen, 20000.), (5,))
+    for _ in range(5):
+        modules.supercell_step(coupler, dycore, micro, nudger, dt)
+        oracle_step(oracle, dyc, f, nud, dt, precl)
+    compare_fields(gpu_fields(coupler), f.as_dict(), 1e-10, "full loop %s" % (shape,), sens[5])
+
+
+def test_sponge_layer_alone(mw, oracle):
+    from miniweatherml_amd import modules
+    coupler, dycore, micro = modules.make_supercell(20, 16, 24, 2, 10000., 8000., 20000.)
+    dyc, f = oracle.supercell_setup(20, 16, 24, 2, 10000., 8000., 20000.)
+    rng = np.random.default_rng(2)
+    for a in [f.uvel, f.vvel, f.wvel, f.temp] + f.tracers:
+        a += rng.normal(size=a.shape) * 0.01 * max(1e-6, np.max(np.abs(a)))
+    push_fields(coupler, f)
+    modules.sponge_layer(coupler, 0.7, 60.0)
+    oracle.sponge_layer(dyc.p, f, 0.7, 60.0)
+    compare_fields(gpu_fields(coupler), f.as_dict(), 1e-13, "sponge")
+    g = gpu_fields(coupler)
+    assert np.array_equal(g["temp"][:14], f.temp[:14])                  # only the top 10 levels are touched (:19,:47)
+
+
+def test_column_nudger_alone(mw, oracle):
+    from miniweatherml_amd import modules
+    coupler, dycore, micro, nudger = modules.make_supercell(18, 14, 12, 1, 9000., 7000., 20000., with_nudger=True)
+    dyc, f, nud = oracle_loop_setup(oracle, 18, 14, 12, 1, 9000., 7000., 20000.)
+    push_fields(coupler, f)
+    nudger.nudge_to_column(coupler, 5.0)
+    nud.nudge_to_column(dyc.p, f, 5.0)
+    compare_fields(gpu_fields(coupler), f.as_dict(), 1e-13, "nudger")
+    # the temperature bubble raised the column mean, so nudging lowers temp everywhere on the bubble's levels (:62-65)
+    assert np.all(gpu_fields(coupler)["wvel"] == 0.0)                   # wvel is not one of the five nudged fields
+
+
+def test_horizontal_sums_are_deterministic(mw):
+    from miniweatherml_amd import modules
+    coupler, dycore, micro, nudger = modules.make_supercell(200, 150, 12, 1, 100000., 75000., 20000., with_nudger=True)
+    nudger.set_column(coupler)
+    c0 = nudger.column.clone()
+    for _ in range(3):
+        nudger.set_column(coupler)
+        assert torch.equal(nudger.column, c0)                           # no atomics: bitwise reproducible

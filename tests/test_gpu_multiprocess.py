@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run_job(world, nxg, nyg, nz, nsteps):
+def run_job(world, nxg, nyg, nz, nsteps, mode="dycore"):
     port = free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "gpu_dist_worker.py"), str(r), str(world), str(port), str(nxg),
-                               str(nyg), str(nz), str(nsteps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(nyg), str(nz), str(nsteps), mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     outs = []
     for p in procs:
@@ -37,3 +37,8 @@ def test_two_processes_3d():
 
 def test_four_processes_2x2():
     run_job(4, 32, 32, 10, 2)
+
+
+def test_two_processes_full_loop_with_allreduce():
+    """dycore + Kessler + sponge_layer + ColumnNudger on 2 processes: halo strips AND the horizontal-mean all-reduce."""
+    run_job(2, 24, 32, 12, 3, "full")
