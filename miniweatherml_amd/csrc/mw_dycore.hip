@@ -935,28 +935,32 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
 }
 
 template <int T, bool N1>
-static void launch_xz_tracers_t(mw_dycore_s *d, const double *S, dim3 grid, int chunk, int tiles_x, int t0, int par, hipStream_t st) {
-  hipLaunchKernelGGL((k_xz_tracers<T, N1>), grid, dim3(256), 0, st, d->p, S, d->FX, d->FZ, d->M[par][0], d->M[par][2], d->UP[par][0],
-                     d->UP[par][2], chunk, tiles_x, t0);
+static void launch_xz_tracers_t(mw_dycore_s *d, const double *S, dim3 grid, int chunk, int tiles_x, int t0, int par, double dt, int rows4,
+                                hipStream_t st) {
+  hipLaunchKernelGGL((k_xz_tracers<T, N1>), grid, dim3(256), 0, st, d->p, S, d->FX, d->FY, d->FZ, d->M[par][0], d->M[par][2], d->UP[par][0],
+                     d->UP[par][2], dt, chunk, tiles_x, t0, rows4);
 }
 
-static int launch_xz_tracers(mw_dycore_s *d, const double *S, int par, hipStream_t st) {
+// tracer x/z fluxes + FCT (dt = the stage's dt, like k_fct)
+static int launch_xz_tracers(mw_dycore_s *d, const double *S, int par, double dt, hipStream_t st) {
   const DyP &p = d->p;
   ProfScope ps(d, 7, st);
   dim3 grid; int chunk, tiles_x;
   if (xz_grid(d, grid, chunk, tiles_x)) return 1;
+  const int rows4 = p.ny >= 4 ? 1 : 0;                         // block = 4 rows of one x tile (shares the FY rows)
+  if (rows4) grid.x = (unsigned)(((p.ny + 3) / 4) * tiles_x);
   for (int t0 = 0; t0 < p.nt; t0 += 4) {
     int cnt = std::min(4, p.nt - t0);
     if (p.nens == 1) {
-      switch (cnt) { case 1: launch_xz_tracers_t<1, true>(d, S, grid, chunk, tiles_x, t0, par, st); break;
-                     case 2: launch_xz_tracers_t<2, true>(d, S, grid, chunk, tiles_x, t0, par, st); break;
-                     case 3: launch_xz_tracers_t<3, true>(d, S, grid, chunk, tiles_x, t0, par, st); break;
-                     default: launch_xz_tracers_t<4, true>(d, S, grid, chunk, tiles_x, t0, par, st); break; }
+      switch (cnt) { case 1: launch_xz_tracers_t<1, true>(d, S, grid, chunk, tiles_x, t0, par, dt, rows4, st); break;
+                     case 2: launch_xz_tracers_t<2, true>(d, S, grid, chunk, tiles_x, t0, par, dt, rows4, st); break;
+                     case 3: launch_xz_tracers_t<3, true>(d, S, grid, chunk, tiles_x, t0, par, dt, rows4, st); break;
+                     default: launch_xz_tracers_t<4, true>(d, S, grid, chunk, tiles_x, t0, par, dt, rows4, st); break; }
     } else {
-      switch (cnt) { case 1: launch_xz_tracers_t<1, false>(d, S, grid, chunk, tiles_x, t0, par, st); break;
-                     case 2: launch_xz_tracers_t<2, false>(d, S, grid, chunk, tiles_x, t0, par, st); break;
-                     case 3: launch_xz_tracers_t<3, false>(d, S, grid, chunk, tiles_x, t0, par, st); break;
-                     default: launch_xz_tracers_t<4, false>(d, S, grid, chunk, tiles_x, t0, par, st); break; }
+      switch (cnt) { case 1: launch_xz_tracers_t<1, false>(d, S, grid, chunk, tiles_x, t0, par, dt, rows4, st); break;
+                     case 2: launch_xz_tracers_t<2, false>(d, S, grid, chunk, tiles_x, t0, par, dt, rows4, st); break;
+                     case 3: launch_xz_tracers_t<3, false>(d, S, grid, chunk, tiles_x, t0, par, dt, rows4, st); break;
+                     default: launch_xz_tracers_t<4, false>(d, S, grid, chunk, tiles_x, t0, par, dt, rows4, st); break; }
     }
     MW_LAUNCH_CHECK();
   }
@@ -999,8 +1003,7 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   // ---- tracer pipeline
   if (halo_fill(d, Sin, 5, T, ts, 1)) return 1;
   if (launch_y_tracers(d, Sin, par, ts)) return 1;                            // tracer fluxes (public arrays)
-  if (launch_xz_tracers(d, Sin, par, ts)) return 1;
-  if (launch_fct(d, Sin, dt_stage, ts)) return 1;                             // D10
+  if (launch_xz_tracers(d, Sin, par, dt_stage, ts)) return 1;                 // x/z fluxes + D10 (FCT)
   if (launch_tracer_update<STAGE, MODE>(d, Sin, Sn, Sout, dt_dyn, c, ts)) return 1;
   if (d->overlap) MW_HIP(hipEventRecord(d->ev_tr[slot], ts));
   return 0;

@@ -151,8 +151,11 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
       if (bcmode == 1) up = 1;     // both sides hold the R (cell j) values
       if (bcmode == 2) up = 0;
       f[idR] = fs.m_upw; f[idV] = fn; f[idT] = fT;
-      f[idU] = fs.m_upw * (up ? se[idU] : cn[idU]);
-      f[idW] = fs.m_upw * (up ? se[idW] : cn[idW]);
+      {   // scalar copies first: a select between elements of two arrays is lowered to a pointer select -> scratch memory
+        const double sU = se[idU], cU = cn[idU], sW = se[idW], cW = cn[idW];
+        f[idU] = fs.m_upw * (up ? sU : cU);
+        f[idW] = fs.m_upw * (up ? sW : cW);
+      }
       fy[(long long)j * p.fyJ] = fs.m_upw;
       upy[(long long)j * p.fyJ] = (unsigned char)up;
       if (j > ja) {
@@ -208,7 +211,10 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
           weno5_edges_fast(qv[-2 * p.sJ], qv[-p.sJ], qv[0], qv[p.sJ], qv[2 * p.sJ], l_, r_); se[v] = l_; }
       }
 #pragma unroll
-      for (int v = 0; v < T; v++) fy[(long long)(5 + t0 + v) * p.fyV + (long long)j * p.fyJ] = m * (up ? se[v] : cn[v]);
+      for (int v = 0; v < T; v++) {   // scalar copies first (a select between two arrays' elements would go through scratch)
+        const double sv = se[v], cv = cn[v];
+        fy[(long long)(5 + t0 + v) * p.fyV + (long long)j * p.fyJ] = m * (up ? sv : cv);
+      }
     }
 #pragma unroll
     for (int v = 0; v < T; v++) {
@@ -228,15 +234,16 @@ struct XzGeom {
   bool owns_face, owns_cell, valid;
 };
 template <bool N1>
-__device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x) {
+__device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, int rows4 = 0) {
   XzGeom g;
   g.n = N1 ? 1 : p.nens;
   g.lane = threadIdx.x & 63;
   g.NXI = p.nx * g.n;
   const int U = 64 - 6 * g.n;                                 // cells (fused) a wave completes
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // wave id -> (row j, x tile)
-  g.j = (int)(wid / tiles_x);
-  const int tx = (int)(wid - (long long)g.j * tiles_x);
+  int tx;
+  if (rows4) { const int jg = (int)(blockIdx.x / tiles_x); tx = (int)(blockIdx.x - (unsigned)jg * tiles_x); g.j = jg * 4 + (threadIdx.x >> 6); }
+  else       { g.j = (int)(wid / tiles_x); tx = (int)(wid - (long long)g.j * tiles_x); }
   g.valid = g.j < p.ny;                                       // whole wave
   g.q = tx * U - 3 * g.n + g.lane;                            // interior fused-x index of this lane (may be in the halo)
   const bool in_row = (g.q < g.NXI + 3 * g.n);
@@ -422,23 +429,42 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   }
 }
 
-// XZ pass, tracers.
+// XZ pass, tracers, with the FCT positivity step (D10, :498-516) folded in.
+//   flux(face) = m_upw * upwind edge value.  The x and z fluxes of a cell are kept in registers for one more level; when the
+//   cell's top face is known, all six of its face fluxes are at hand (the y pair is read from FY, written by k_y_tracers
+//   before), so the cell's FCT multiplier  mult = min(1, mass_available / mass_out)  is computed here and every x/z face is
+//   stored ONCE, already scaled by its donor cell's multiplier -- there is no separate FCT pass over the flux arrays.
+//   Outgoing y faces are rescaled in place only where mult < 1 (rare); the race with the neighbouring rows that read them is
+//   the reference's own benign one (:495-497: a face is only rescaled by the cell it leaves, and the sign never changes).
+//   Faces on a wave's or chunk's edge have exactly one writer: the side that owns the donor cell (the other side computes
+//   the identical flux value and drops it); domain-edge faces whose donor lies outside are stored unscaled, like the
+//   reference's interior-only loop leaves them.
+//   Block = 4 waves = 4 consecutive rows j of one x tile (rows4), so that FY rows are shared through the CU's L1.
 template <int T, bool N1>
 __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restrict__ S, double *__restrict__ FX,
-                                                    double *__restrict__ FZ, const double *__restrict__ MX,
+                                                    double *FY, double *__restrict__ FZ, const double *__restrict__ MX,
                                                     const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
-                                                    const unsigned char *__restrict__ UPZ, int chunk, int tiles_x, int t0) {
-  const XzGeom g = xz_geom<N1>(p, chunk, tiles_x);
+                                                    const unsigned char *__restrict__ UPZ, double dt, int chunk, int tiles_x, int t0,
+                                                    int rows4) {
+  const XzGeom g = xz_geom<N1>(p, chunk, tiles_x, rows4);
   if (!g.valid) return;
   const int n = g.n, lane = g.lane, NXI = g.NXI, j = g.j, q = g.q;
   const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qq;
-  const bool st_x = g.owns_face && (g.owns_cell || q >= NXI);
-  const long long fxo = (long long)j * p.fxJ + (st_x ? q : 0);
+  const double *rcol = S + (long long)idR * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qq;
+  const long long fxo = (long long)j * p.fxJ + (g.owns_face ? q : 0);
   const long long fzo = (long long)j * p.fzJ + g.qc;
+  const long long fyo = (long long)j * p.fyJ + g.qc;
+  const bool west_owns = (lane - n >= 3 * n) && (lane - n < 64 - 3 * n) && (q - n < NXI);
+  const bool first_face = g.owns_face && (q < n);              // i == 0: the donor of an eastward flux is outside the rank
+  const bool last_face = g.owns_face && (q >= NXI);            // i == nx
+  const bool do_y = !p.sim2d;
+  const double vol = p.dx * p.dy * p.dz;
   double w[T][5], nxt[T], ct[T];
+  double fxp[T], fzp[T], fys[T], fyn[T], multp[T];
+  bool pend = false;
 #pragma unroll
   for (int v = 0; v < T; v++) {
-    ct[v] = 0;
+    ct[v] = 0; fxp[v] = fzp[v] = fys[v] = fyn[v] = 0; multp[v] = 1;
 #pragma unroll
     for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(g.kstart - 2 + s + p.HZ) * p.sK];
   }
@@ -449,9 +475,22 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
     const int kn = min(k + 3, p.nz + p.HZ - 1);
 #pragma unroll
     for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
-    double mx = 0, mz = 0; int upx = 0, upz = 0;
+    double mx = 0, mz = 0, rhop = 0; int upx = 0, upz = 0;
     if (xwork) { mx = MX[(long long)k * p.fxK + fxo]; upx = UPX[(long long)k * p.fxK + fxo]; }
+    if (pend) {                                                // what the cell below (k-1) still needs for its FCT multiplier
+      rhop = rcol[(long long)(k - 1 + p.HZ) * p.sK] + p.hyc[(k - 1) * p.nens + g.e];
+      if (do_y) {
+#pragma unroll
+        for (int v = 0; v < T; v++) {
+          const double *fy = FY + (long long)(5 + t0 + v) * p.fyV + (long long)(k - 1) * p.fyK + fyo;
+          fys[v] = fy[0]; fyn[v] = fy[p.fyJ];
+        }
+      }
+    }
     if (zface) { mz = MZ[(long long)k * p.fzK + fzo]; upz = UPZ[(long long)k * p.fzK + fzo]; }
+    double fxn[T], fzn[T];
+#pragma unroll
+    for (int v = 0; v < T; v++) fxn[v] = fzn[v] = 0;
     if (xwork) {
       const bool quirk = bc_mode_x(p, g.i) == 3;
 #pragma unroll
@@ -467,7 +506,7 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
           weno5_edges_fast(qv[-2 * n], qv[-n], qv[0], qv[n], qv[2 * n], we, r_);
         }
         double Lq = from_west<N1>(ee, lane, n);
-        if (st_x) FX[(long long)(5 + t0 + v) * p.fxV + (long long)k * p.fxK + fxo] = mx * (upx ? we : Lq);
+        fxn[v] = g.owns_face ? mx * (upx ? we : Lq) : 0.0;
       }
     }
     double te[T];
@@ -475,8 +514,53 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
     for (int v = 0; v < T; v++) {
       double be = 0; te[v] = 0;
       if (!top) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be, te[v]);
-      if (zface && g.owns_cell) FZ[(long long)(5 + t0 + v) * p.fzV + (long long)k * p.fzK + fzo] = mz * (upz ? be : ct[v]);
+      if (zface && g.owns_cell) fzn[v] = mz * (upz ? be : ct[v]);
     }
+    if (pend) {                                                // finish cell kp = k-1 (all six face fluxes known now)
+      const int kp = k - 1;
+#pragma unroll
+      for (int v = 0; v < T; v++) {
+        const double fe = from_east<N1>(fxp[v], lane, n);
+        double mult = 1.0;
+        {
+#pragma clang fp contract(off)
+          const double mass_available = fmax(w[v][1] * rhop, 0.0) * p.dx * p.dy * p.dz;
+          const double out_x = (fmax(fe, 0.0) - fmin(fxp[v], 0.0)) * p.rdx;
+          const double out_y = (fmax(fyn[v], 0.0) - fmin(fys[v], 0.0)) * p.rdy;
+          const double out_z = (fmax(fzn[v], 0.0) - fmin(fzp[v], 0.0)) * p.rdz;
+          const double mass_out = (out_x + out_y + out_z) * dt * p.dx * p.dy * p.dz;
+          if (g.owns_cell && ((p.pos_mask >> (t0 + v)) & 1u) && mass_out > mass_available) mult = mass_available / mass_out;
+        }
+        const double mult_w = from_west<N1>(mult, lane, n);
+        // x face (west face of this lane), level kp
+        {
+          const double F = fxp[v];
+          double *dst = FX + (long long)(5 + t0 + v) * p.fxV + (long long)kp * p.fxK + fxo;
+          if (F > 0) { if (west_owns) *dst = F * mult_w; else if (first_face) *dst = F; }
+          else       { if (g.owns_cell) *dst = F * mult; else if (last_face) *dst = F; }
+        }
+        if (g.owns_cell) {
+          // z face kp (bottom of the cell)
+          const double G = fzp[v];
+          double *dz_ = FZ + (long long)(5 + t0 + v) * p.fzV + (long long)kp * p.fzK + fzo;
+          if (G > 0) { if (kp > g.ka) *dz_ = G * multp[v]; else if (kp == 0) *dz_ = G; }
+          else       *dz_ = G * mult;
+          if (k == g.kb) {                                     // top face of the chunk
+            const double H = fzn[v];
+            if (H > 0) dz_[p.fzK] = H * mult; else if (top) dz_[p.fzK] = H;
+          }
+          if (__builtin_expect(mult < 1.0, 0)) {               // outgoing y faces, in place
+            double *fy = FY + (long long)(5 + t0 + v) * p.fyV + (long long)kp * p.fyK + fyo;
+            if (fys[v] < 0) fy[0] = fys[v] * mult;
+            if (fyn[v] > 0) fy[p.fyJ] = fyn[v] * mult;
+          }
+        }
+        multp[v] = mult;
+      }
+    }
+    pend = xwork;
+#pragma unroll
+    for (int v = 0; v < T; v++) { fxp[v] = fxn[v]; fzp[v] = fzn[v]; }
     if (!top) {
 #pragma unroll
       for (int v = 0; v < T; v++) {
