@@ -709,7 +709,9 @@ struct mw_dycore_s {
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
-  int chunk_y = 0, chunk_z = 0;
+  int chunk_y = 0, chunk_z = 0, chunk_f = 0;
+  unsigned char *flags = nullptr;          // fused tracer stage: per-cell "a y face of this cell was FCT-scaled" bits
+  int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte
   double *imm = nullptr;
   std::vector<double> hy_host;               // same packing (the last four are derived in upload_background)
@@ -978,6 +980,41 @@ static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const doubl
   return 0;
 }
 
+template <int STAGE, int MODE, int T, bool N1>
+static void launch_tracers_fused_t(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
+                                   double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
+  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1>), grid, dim3(256), 0, st, d->p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2],
+                     d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, dt, dt_dyn, c, chunk, tiles_x, rows4);
+}
+// x/z tracer fluxes + FCT + update in one kernel, then the (normally empty) y-face correction
+template <int STAGE, int MODE>
+static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, int par, double dt, double dt_dyn,
+                                const CouplerPtrs &c, hipStream_t st) {
+  const DyP &p = d->p;
+  {
+    ProfScope ps(d, 7, st);
+    const int U = 64 - 8 * p.nens;
+    const int tiles_x = (p.nx * p.nens + U - 1) / U;
+    const int rows4 = p.ny >= 4 ? 1 : 0;
+    const long long waves = (long long)p.ny * tiles_x;
+    const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = pick_chunk(p.nz, waves, "MW_CHUNK_F"));
+    dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
+#define MW_FUSED_CASE(TT) \
+    case TT: if (p.nens == 1) launch_tracers_fused_t<STAGE, MODE, TT, true>(d, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); \
+             else             launch_tracers_fused_t<STAGE, MODE, TT, false>(d, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); break;
+    switch (p.nt) { MW_FUSED_CASE(1) MW_FUSED_CASE(2) MW_FUSED_CASE(3) MW_FUSED_CASE(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
+#undef MW_FUSED_CASE
+    MW_LAUNCH_CHECK();
+  }
+  if (!p.sim2d && p.pos_mask && !getenv("MW_DEBUG_NO_PATCH")) {   // (the switch exists for the negative control in tests/)
+    ProfScope ps(d, 1, st);
+    hipLaunchKernelGGL((k_tracer_patch<STAGE, MODE>), plane_grid((long long)p.ny * p.nx * p.nens, p.nz), dim3(256), 0, st, p, Sout, d->flags,
+                       d->FX, d->FZ, dt_dyn, c);
+    MW_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // One RK stage on the production path, as two pipelines on two HIP streams:
 //   state stream  (the handle's stream): halo(state vars) -> k_y_state -> k_xz_state        [fp64-VALU bound]
@@ -1003,8 +1040,12 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   // ---- tracer pipeline
   if (halo_fill(d, Sin, 5, T, ts, 1)) return 1;
   if (launch_y_tracers(d, Sin, par, ts)) return 1;                            // tracer fluxes (public arrays)
-  if (launch_xz_tracers(d, Sin, par, dt_stage, ts)) return 1;                 // x/z fluxes + D10 (FCT)
-  if (launch_tracer_update<STAGE, MODE>(d, Sin, Sn, Sout, dt_dyn, c, ts)) return 1;
+  if (d->fused) {
+    if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ts)) return 1;   // x/z fluxes + D10 + D11/D12 (+ D13)
+  } else {
+    if (launch_xz_tracers(d, Sin, par, dt_stage, ts)) return 1;               // x/z fluxes + D10 (FCT)
+    if (launch_tracer_update<STAGE, MODE>(d, Sin, Sn, Sout, dt_dyn, c, ts)) return 1;
+  }
   if (d->overlap) MW_HIP(hipEventRecord(d->ev_tr[slot], ts));
   return 0;
 }
@@ -1064,7 +1105,11 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
       hipMalloc(&d->S3, slab) != hipSuccess ||
       hipMalloc(&d->tendY, (size_t)5 * p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->FX, fxb) != hipSuccess ||
       hipMalloc(&d->FY, fyb) != hipSuccess || hipMalloc(&d->FZ, fzb) != hipSuccess ||
-      hipMalloc(&d->imm, (size_t)p.nC * sizeof(double)) != hipSuccess) { set_error("hipMalloc(workspace) failed"); return fail(); }
+      hipMalloc(&d->imm, (size_t)p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->flags, (size_t)p.nC) != hipSuccess) {
+    set_error("hipMalloc(workspace) failed"); return fail(); }
+  (void)hipMemsetAsync(d->flags, 0, (size_t)p.nC, d->stream);
+  { const char *f = getenv("MW_FUSED_TRACERS");
+    d->fused = (g->num_tracers <= 4 && g->nens <= 7 && !(f && f[0] == '0')) ? 1 : 0; }
   // zero everything once: halo corners are never written and the flux arrays start at 0 (:1677-1682)
   (void)hipMemsetAsync(d->S0, 0, slab, d->stream); (void)hipMemsetAsync(d->S1, 0, slab, d->stream);
   (void)hipMemsetAsync(d->S2, 0, slab, d->stream); (void)hipMemsetAsync(d->S3, 0, slab, d->stream); (void)hipMemsetAsync(d->tendY, 0, (size_t)5 * p.nC * sizeof(double), d->stream);
@@ -1094,6 +1139,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   (void)hipStreamSynchronize(d->stream);
   if (d->tstream) (void)hipStreamSynchronize(d->tstream);
   for (double *ptr : {d->S0, d->S1, d->S2, d->S3, d->tendY, d->FX, d->FY, d->FZ, d->hy_dev, d->imm}) if (ptr) (void)hipFree(ptr);
+  if (d->flags) (void)hipFree(d->flags);
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);

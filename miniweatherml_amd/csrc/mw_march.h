@@ -626,4 +626,255 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused tracer stage (<= 4 tracers, nens <= 7): x/z fluxes + FCT + flux divergence + SSPRK3 combine (+ D13) in ONE marching
+// kernel -- the x/z tracer fluxes never go to HBM and the separate update pass disappears.
+//   pipeline per wave (row j, 64 fused-x lanes, 4 n halo lanes per side), marching k:
+//     S1(k)   : x-face fluxes of level k, z-face flux k                       (registers)
+//     S2(k-1) : all six face fluxes of cell k-1 are known -> FCT multiplier; x faces and z face k-1 scaled by their donors'
+//               multipliers (west/east lanes by DPP, level k-2 carried); partial tendency P = -dFx/dx - dFy/dy
+//     S3(k-2) : cell k-2's upper z face (= face k-1) is final -> tendency, SSPRK3 combine, clip, store.
+//   y direction: a face's donor may be a cell of another row (another wave), whose multiplier is not known here.  S3 uses
+//   the UNSCALED value for incoming y fluxes ("provisional"); a donor that does scale an outgoing y flux (mult < 1: rare)
+//   records the flux change in a side array (the idle public x/z flux slots) and sets a bit in its cell's flag byte; the
+//   receiver-centred k_tracer_patch then subtracts the recorded change from the two neighbours' new values (exact up to
+//   rounding: the provisional value over-estimates the inflow, so a clipped provisional value stays clipped).
+//   FY itself is never modified here, so what a receiver used is always the unscaled flux (no race).
+// ---------------------------------------------------------------------------------------------------------------
+template <int STAGE, int MODE, int T, bool N1>
+__global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *__restrict__ S, const double *__restrict__ Sn, double *Sout,
+                                                       const double *__restrict__ FY, const double *__restrict__ MX,
+                                                       const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
+                                                       const unsigned char *__restrict__ UPZ, double *__restrict__ DS,
+                                                       double *__restrict__ DN, unsigned char *__restrict__ flags, double dt,
+                                                       double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4) {
+  const int n = N1 ? 1 : p.nens;
+  constexpr int t0 = 0;                                       // one group: all (<= 4) tracers of the cell
+  const int lane = threadIdx.x & 63;
+  const int NXI = p.nx * n;
+  const int U = 64 - 8 * n;
+  int j, tx;
+  if (rows4) { const int jg = (int)(blockIdx.x / tiles_x); tx = (int)(blockIdx.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
+  else       { const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
+  if (j >= p.ny) return;
+  const int q = tx * U - 4 * n + lane;                        // fused-x index of this lane's cell (halo lanes included)
+  const int qq = min(max(q, -3 * n), NXI + 3 * n - 1);        // clamped into the 3-cell halo for addressing
+  const int e = N1 ? 0 : ((qq % n) + n) % n;
+  const int i = (qq - e) / n;
+  const bool interior = (q >= 0) && (q < NXI);
+  const bool has_mult = (lane >= 3 * n) && (lane < 64 - 3 * n) && interior;     // both x faces of the cell are known
+  const bool upd = (lane >= 4 * n) && (lane < 64 - 4 * n) && interior;          // the cell this lane completes
+  const int qm = interior ? q : 0;
+  const int qf = (q >= 0 && q < NXI + n) ? q : 0;
+  const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qq;
+  const long long so_row = (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qm;     // + (k+HZ)*sK + l*sV
+  const long long fxo = (long long)j * p.fxJ + qf;
+  const long long fzo = (long long)j * p.fzJ + qm;
+  const long long fyo = (long long)j * p.fyJ + qm;
+  const bool do_y = !p.sim2d;
+  const int ka = blockIdx.y * chunk, kb = min(ka + chunk, p.nz);
+  const int k_lo = max(ka - 1, 0);                            // cells k_lo .. k_hi get all six fluxes (FCT multiplier)
+  const int k_hi = min(kb, p.nz - 1);
+  const int kstart = max(ka - 2, 0);
+  double w[T][5], nxt[T], ct[T];
+  double fxp[T], fzp[T], multp[T], szf[T], P[T];
+  double rhos2 = 0;
+#pragma unroll
+  for (int v = 0; v < T; v++) {
+    ct[v] = 0; fxp[v] = fzp[v] = szf[v] = P[v] = 0; multp[v] = 1;
+#pragma unroll
+    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(kstart - 2 + s + p.HZ) * p.sK];
+  }
+  // The loop body is branch-free apart from predicated stores and the rare limiter paths: every load uses a clamped
+  // (always valid) address and is issued at the top, the z reconstruction (registers only) runs while they are in flight.
+  // Iterations outside a quantity's range compute values that are never stored or carried into a used result.
+  for (int k = kstart; k <= kb + 1; k++) {
+    const bool cell = (k < p.nz);
+    const int kp = k - 1, ku = k - 2;
+    const bool s2cell = (kp >= k_lo) && (kp <= k_hi);          // cell kp has all six fluxes (kp == nz: only the top face is scaled)
+    const bool s3 = (ku >= ka) && (ku < kb);
+    const int kx = min(k, p.nz - 1), kz = min(k, p.nz);
+    const int kpc = min(max(kp, 0), p.nz - 1), kuc = min(max(ku, 0), p.nz - 1);
+    // ------------------------------------------------ loads of this iteration
+    const int kn = min(k + 3, p.nz + p.HZ - 1);
+#pragma unroll
+    for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
+    const double mx = MX[(long long)kx * p.fxK + fxo];
+    const int upx = UPX[(long long)kx * p.fxK + fxo];
+    const double mz = MZ[(long long)kz * p.fzK + fzo];
+    const int upz = UPZ[(long long)kz * p.fzK + fzo];
+    const double rhop = S[(long long)idR * p.sV + (long long)(kpc + p.HZ) * p.sK + so_row] + p.hyc[kpc * p.nens + e];
+    double fys[T], fyn[T];
+#pragma unroll
+    for (int v = 0; v < T; v++) {
+      const double *fy = FY + (long long)(5 + t0 + v) * p.fyV + (long long)kpc * p.fyK + fyo;
+      fys[v] = do_y ? fy[0] : 0.0; fyn[v] = do_y ? fy[p.fyJ] : 0.0;
+    }
+    const long long so = (long long)(kuc + p.HZ) * p.sK + so_row;
+    const double hyc_u = p.hyc[kuc * p.nens + e];
+    const double rho_new = Sout[so + idR * p.sV] + hyc_u;
+    double qn_[T], rho_n = 0, st_T = 0, st_U = 0, st_V = 0, st_W = 0;
+#pragma unroll
+    for (int v = 0; v < T; v++) qn_[v] = 0;
+    if (STAGE != 1) {
+      rho_n = Sn[so + idR * p.sV] + hyc_u;
+#pragma unroll
+      for (int v = 0; v < T; v++) qn_[v] = Sn[so + (5 + t0 + v) * p.sV];
+    }
+    if (MODE == 1) { st_T = Sout[so + idT * p.sV]; st_U = Sout[so + idU * p.sV]; st_V = Sout[so + idV * p.sV]; st_W = Sout[so + idW * p.sV]; }
+    // ------------------------------------------------ S1: z reconstruction (registers only), then the fluxes of level k
+    double te[T], fxn[T], fzn[T], be_[T], xe_[T];
+#pragma unroll
+    for (int v = 0; v < T; v++) {                                // all reconstructions first: they need no loaded operand
+      weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be_[v], te[v]);
+      if (!cell) be_[v] = 0;
+    }
+    {
+      const bool quirk = bc_mode_x(p, i) == 3;
+#pragma unroll
+      for (int v = 0; v < T; v++) {
+        double c0 = w[v][2];
+        double m1 = from_west<N1>(c0, lane, n), p1 = from_east<N1>(c0, lane, n);
+        double m2 = N1 ? from_west<N1>(m1, lane, n) : shfl_from(c0, lane - 2 * n);
+        double p2 = N1 ? from_east<N1>(p1, lane, n) : shfl_from(c0, lane + 2 * n);
+        double we, ee;
+        weno5_edges_fast(m2, m1, c0, p1, p2, we, ee);
+        if (__builtin_expect(quirk, 0)) {
+          const double *qv = col + (long long)v * p.sV + (long long)(kx + p.HZ) * p.sK - (long long)p.nx * n; double r_;
+          weno5_edges_fast(qv[-2 * n], qv[-n], qv[0], qv[n], qv[2 * n], we, r_);
+        }
+        double Lq = from_west<N1>(ee, lane, n);
+        be_[v] = upz ? be_[v] : ct[v];
+        xe_[v] = upx ? we : Lq;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < T; v++) { fzn[v] = mz * be_[v]; fxn[v] = mx * xe_[v]; }
+    // ------------------------------------------------ S2: cell k-1 -> multiplier, scaled faces, partial tendency
+    double szn[T], Pn[T];
+    {
+      const bool rec = upd && s2cell && (kp >= ka) && (kp < kb);           // the unique owner of cell (kp, j, q)
+      unsigned fl = 0;
+#pragma unroll
+      for (int v = 0; v < T; v++) {
+#pragma clang fp contract(off)
+        const double fe = from_east<N1>(fxp[v], lane, n);
+        double mult = 1.0;
+        {
+          const double mass_available = fmax(w[v][1] * rhop, 0.0) * p.dx * p.dy * p.dz;
+          const double out_x = (fmax(fe, 0.0) - fmin(fxp[v], 0.0)) * p.rdx;
+          const double out_y = (fmax(fyn[v], 0.0) - fmin(fys[v], 0.0)) * p.rdy;
+          const double out_z = (fmax(fzn[v], 0.0) - fmin(fzp[v], 0.0)) * p.rdz;
+          const double mass_out = (out_x + out_y + out_z) * dt * p.dx * p.dy * p.dz;
+          if (__builtin_expect(s2cell && has_mult && ((p.pos_mask >> (t0 + v)) & 1u) && mass_out > mass_available, 0))
+            mult = mass_available / mass_out;
+        }
+        const double mult_w = from_west<N1>(mult, lane, n);
+        const double F = fxp[v];
+        const double sFw = (F > 0) ? F * mult_w : F * mult;                  // west face, scaled by its donor
+        const double sFe = from_east<N1>(sFw, lane, n);
+        const double G = fzp[v];
+        szn[v] = (G > 0) ? G * multp[v] : G * mult;                          // z face kp, scaled by its donor
+        const double ys = (fys[v] < 0) ? fys[v] * mult : fys[v];             // outgoing y faces scaled, incoming provisional
+        const double yn = (fyn[v] > 0) ? fyn[v] * mult : fyn[v];
+        Pn[v] = -(sFe - sFw) * p.rdx - (yn - ys) * p.rdy;
+        if (__builtin_expect(rec && mult < 1.0, 0)) {
+          if (fys[v] < 0) { DS[(long long)(5 + t0 + v) * p.fxV + (long long)kp * p.fxK + (long long)j * p.fxJ + q] = ys - fys[v]; fl |= 1u << (2 * v); }
+          if (fyn[v] > 0) { DN[(long long)(5 + t0 + v) * p.fzV + (long long)kp * p.fzK + (long long)j * p.fzJ + q] = yn - fyn[v]; fl |= 2u << (2 * v); }
+        }
+        multp[v] = mult;
+      }
+      if (rec && do_y) flags[((long long)kp * p.ny + j) * NXI + q] = (unsigned char)fl;     // 2 bits per tracer: (south, north) face scaled
+    }
+    // ------------------------------------------------ S3: cell k-2 -> new value
+    {
+#pragma clang fp contract(off)
+      const bool st = s3 && upd;
+      const long long ci = ((long long)kuc * p.ny + j) * NXI + qm;
+      const double inv_rho_new = fast_rcp(rho_new);
+      double rho_dry = rho_new, rho_v = 0;
+#pragma unroll
+      for (int v = 0; v < T; v++) {
+        const double q_s = w[v][0] * rhos2;
+        const double q_n = (STAGE == 1) ? q_s : qn_[v] * rho_n;
+        const double tend = P[v] - (szn[v] - szf[v]) * p.rdz;
+        double qnew;
+        if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
+        else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
+        else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
+        if ((p.pos_mask >> (t0 + v)) & 1u) qnew = fmax(0.0, qnew);
+        if (MODE == 0) { if (st) Sout[so + (5 + t0 + v) * p.sV] = qnew * inv_rho_new; }
+        else {
+          if (st) c.tr[v][ci] = qnew;
+          if (v == p.idWV) rho_v = qnew;
+          if ((p.mass_mask >> v) & 1u) rho_dry -= qnew;
+        }
+      }
+      if (MODE == 1 && st) {
+        const double hytc = p.hytc[kuc * p.nens + e];
+        double theta = (st_T + hytc) / rho_new;
+        double press = p.C0 * pow(rho_new * theta, p.gamma);
+        c.rho_d[ci] = rho_dry;
+        c.u[ci] = st_U; c.v[ci] = st_V; c.w[ci] = st_W;
+        c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);
+      }
+    }
+    // ------------------------------------------------ carries
+    rhos2 = rhop;
+#pragma unroll
+    for (int v = 0; v < T; v++) {
+      fxp[v] = fxn[v]; fzp[v] = fzn[v]; szf[v] = szn[v]; P[v] = Pn[v];
+      ct[v] = te[v];
+      w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
+    }
+  }
+}
+
+// Receiver-centred correction for y faces whose donor (the row above or below) scaled them: see k_tracers_fused.
+template <int STAGE, int MODE>
+__global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const unsigned char *__restrict__ flags,
+                                                      const double *__restrict__ DS, const double *__restrict__ DN, double dt_dyn,
+                                                      CouplerPtrs c) {
+#pragma clang fp contract(off)
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  const int NXI = p.nx * p.nens;
+  if (t >= (long long)p.ny * NXI) return;
+  const int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  const long long ci = ((long long)k * p.ny + j) * NXI + ie;
+  const unsigned fN = (j + 1 < p.ny) ? flags[ci + NXI] : 0u;      // northern neighbour scaled its south face = my north face
+  const unsigned fS = (j >= 1) ? flags[ci - NXI] : 0u;            // southern neighbour scaled its north face = my south face
+  if (((fN & 0x55u) | (fS & 0xAAu)) == 0u) return;
+  const int e = ie % p.nens;
+  const long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
+  const double rho_new = Sout[so + idR * p.sV] + p.hyc[k * p.nens + e];
+  const double inv_rho_new = fast_rcp(rho_new);
+  const double cdt = (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;
+  for (int v = 0; v < p.nt && v < 4; v++) {
+    double dN = 0, dS = 0;
+    if ((fN >> (2 * v)) & 1u) dN = DS[(long long)(5 + v) * p.fxV + (long long)k * p.fxK + (long long)(j + 1) * p.fxJ + ie];
+    if ((fS >> (2 * v)) & 2u) dS = DN[(long long)(5 + v) * p.fzV + (long long)k * p.fzK + (long long)(j - 1) * p.fzJ + ie];
+    if (dN == 0 && dS == 0) continue;
+    const double corr = cdt * ((dN - dS) * p.rdy);                // tend' = tend - (dN - dS)/dy
+    if (MODE == 0) {
+      const double qp = Sout[so + (5 + v) * p.sV] * rho_new;
+      Sout[so + (5 + v) * p.sV] = fmax(0.0, qp - corr) * inv_rho_new;
+    } else {
+      c.tr[v][ci] = fmax(0.0, c.tr[v][ci] - corr);
+    }
+  }
+  if (MODE == 1) {
+    double rho_dry = rho_new, rho_v = 0;
+    for (int v = 0; v < p.nt; v++) {
+      const double qv = c.tr[v][ci];
+      if (v == p.idWV) rho_v = qv;
+      if ((p.mass_mask >> v) & 1u) rho_dry -= qv;
+    }
+    const double theta = (Sout[so + idT * p.sV] + p.hytc[k * p.nens + e]) / rho_new;
+    const double press = p.C0 * pow(rho_new * theta, p.gamma);
+    c.rho_d[ci] = rho_dry;
+    c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);
+  }
+}
+
 } // namespace mw

@@ -223,3 +223,53 @@ def test_unsupported_options_fail_loudly(mw):
         dycore.set_bc(coupler, 0, 0, 0)                       # bc_z = periodic: no reference case uses it
     with pytest.raises(MWError, match="dt_phys"):
         dycore.time_step(coupler, 0.0)
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("shape", [(70, 9, 12, 1), (23, 6, 11, 2), (64, 1, 9, 1)])
+def test_fct_limiter_heavy(mw, oracle, fused, shape, monkeypatch):
+    """Sparse cloud/rain blobs in a strong random wind: the FCT multiplier is < 1 in a large share of the cells, in all three
+    directions and across wave (x tile), row and z-chunk edges.  fused=1: k_tracers_fused + k_tracer_patch (y faces scaled
+    by a donor in another row are corrected afterwards); fused=0: k_xz_tracers + k_tracer_update."""
+    from miniweatherml_amd import modules
+    nx, ny, nz, nens = shape
+    monkeypatch.setenv("MW_FUSED_TRACERS", fused)
+    monkeypatch.setenv("MW_CHUNK_F", "4")
+    monkeypatch.setenv("MW_CHUNK_Z", "4")
+    xlen, ylen = 500.0 * nx, 500.0 * max(ny, 2)
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000.)
+
+    def make(positive=(1, 1, 1)):
+        p, _ = oracle.make_params(nx, ny, nz, nens, xlen, ylen, 20000.)
+        odyc = oracle.OracleDycore(p, tracer_positive=list(positive), tracer_adds_mass=[1, 1, 1])
+        of = oracle.Fields(odyc.p)
+        odyc.init("supercell", of)
+        rng = np.random.default_rng(11)
+        for a, amp in ((of.uvel, 25.0), (of.vvel, 25.0 if ny > 1 else 0.0), (of.wvel, 8.0)):
+            a += amp * rng.uniform(-1, 1, a.shape)
+        for t in (1, 2):
+            blob = rng.uniform(size=of.tracers[t].shape)
+            of.tracers[t][...] = np.where(blob > 0.7, 2e-3 * rng.uniform(size=blob.shape), 0.0)
+        return odyc, of
+
+    odyc, of = make()
+    push_fields(coupler, of)
+    dt = dycore.compute_time_step(coupler)
+    onof, fnof = make(positive=(1, 0, 0))                      # the same run without the limiter on cloud/rain
+    for step in range(3):
+        dycore.time_step(coupler, dt)
+        odyc.time_step(of, dt)
+        onof.time_step(fnof, dt)
+        got = gpu_fields(coupler)
+        compare_fields(got, of.as_dict(), 1e-10, "limiter-heavy fused=%s step %d" % (fused, step + 1))
+        assert got["tracer1"].min() >= 0 and got["tracer2"].min() >= 0
+    # the limiter really was at work: without it the oracle ends up somewhere else
+    assert np.max(np.abs(fnof.tracers[1] - of.tracers[1])) > 1e-3 * np.max(np.abs(of.tracers[1]))
+
+
+def test_fct_patch_pass_is_exercised(mw, oracle, monkeypatch):
+    """Negative control for the test above: with the y-face correction pass switched off the fused path must MISS the
+    oracle on the limiter-heavy case (i.e. donors in neighbouring rows really do scale y faces there)."""
+    monkeypatch.setenv("MW_DEBUG_NO_PATCH", "1")
+    with pytest.raises(AssertionError):
+        test_fct_limiter_heavy(mw, oracle, "1", (70, 9, 12, 1), monkeypatch)
