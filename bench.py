@@ -128,7 +128,7 @@ def main():
         dycore.time_step(coupler, dt)
     sync()
     el = time.perf_counter() - t0
-    KNAMES = ["xz_state", "fct", "tracer_update", "halo", "convert", "y_state", "y_tracers", "xz_tracers"]
+    KNAMES = ["xz_state", "tracer_patch", "tracer_update_unfused", "halo", "convert", "y_state", "y_tracers", "tracers_fused"]
     prof = {n: dycore.profile_get(i) for i, n in enumerate(KNAMES)}
     dycore.profile(0)
     # Outside the timed region: the same kernels with the two pipelines serialised, so that each kernel's duration is

@@ -3,14 +3,16 @@
 //
 // Each cell is reconstructed ONCE per direction and variable (24 WENO calls per cell and stage for V = 8, like the
 // reference's D6 kernel) and its two edge values are handed to the two adjacent faces without touching memory:
-//   * along the marching direction (y in k_pass_y, z in k_pass_xz) a thread walks a chunk of cells with a 5-deep
+//   * along the marching direction (y in the k_y_* kernels, z in the k_xz_* / fused kernels) a thread walks a chunk of cells with a 5-deep
 //     register window per variable; the previous cell's upper edge values and face fluxes are carried in registers;
-//   * along x (k_pass_xz) a wavefront spans 64 consecutive (x,ens) lanes; stencil neighbours, the west cell's east-edge
+//   * along x a wavefront spans 64 consecutive (x,ens) lanes; stencil neighbours, the west cell's east-edge
 //     values and the east face's fluxes travel by wavefront shuffles (ds_bpermute), 3*nens lanes of overlap per side.
-// k_pass_y   : y faces -> tracer y-fluxes (public array) + the y part of the state tendencies (scratch, 5 doubles/cell)
-// k_pass_xz  : x and z faces -> tracer x/z-fluxes + COMPLETE state tendencies -> SSPRK3 combine -> new state slab.
+// k_y_state / k_y_tracers : y faces -> y part of the state tendencies (scratch, 5 doubles/cell), the upwind mass flux and
+//              selector of every y face, and the tracer y-fluxes.
+// k_xz_state : x and z faces of the state variables -> COMPLETE state tendencies -> SSPRK3 combine -> new state slab.
 //              The state-variable fluxes (15 of the 24 flux doubles per cell) never go to HBM.
-// k_tracer_update : tracer divergence of the FCT-corrected fluxes + SSPRK3 combine (+ D13 on the last stage).
+// k_tracers_fused + k_tracer_patch : x and z tracer faces + FCT + divergence + SSPRK3 combine (+ D13 on the last stage);
+//              the x/z tracer fluxes never go to HBM either.  (k_xz_tracers + k_tracer_update: the unfused form.)
 // reference: dynamics_euler_stratified_wenofv.h:271-388 (D6), :395-485 (D9), :519-551 (D11), :121-174 (D12).
 // =====================================================================================================
 #pragma once
