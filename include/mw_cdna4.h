@@ -187,6 +187,44 @@ int  mw_mlp_forward(long long ncells, const double *temp, const double *rho_d, c
                     const float *b2, const double *scl_in, const double *scl_out, double *temp_out,
                     double *rho_v_out, double *rho_c_out, double *rho_r_out, void *stream);
 
+/* ---- file output ------------------------------------------------------------ */
+/* A minimal netCDF *classic* writer (mw_netcdf.cpp): the reference writes through PnetCDF with NC_CLOBBER | NC_64BIT_DATA,
+ * i.e. the CDF-5 on-disk format, dims x,y,z (+ unlimited t), double variables, no attributes
+ * (dynamics_euler_stratified_wenofv.h:2106-2131, time_averager.h:104-120).  format: 5 = CDF-5 (the reference's), 2 = CDF-2
+ * (64-bit offset; same structure with 32-bit sizes -- readable by readers that predate CDF-5).  header_align / var_align are
+ * PnetCDF's nc_header_align_size / nc_var_align_size hints (:2103-2104: 1048576 each; <= 0: 512 / 4).  All HOST calls.
+ * Sharing: the creating rank runs create..enddef; after that any process on the node may mw_nc_open the file and write
+ * disjoint hyperslabs (pwrite); the main rank publishes the record count with mw_nc_set_numrecs. */
+typedef struct mw_nc_s *mw_nc_t;
+int  mw_nc_create(mw_nc_t *nc, const char *path, int format, long long header_align, long long var_align);   /* nc.create        */
+int  mw_nc_def_dim(mw_nc_t nc, const char *name, long long len, int *dimid);          /* create_dim; len 0 = create_unlim_dim   */
+int  mw_nc_def_var(mw_nc_t nc, const char *name, int ndims, const int *dimids, int *varid);   /* create_var<real>               */
+int  mw_nc_enddef(mw_nc_t nc);                                                         /* nc.enddef: lays out + writes header    */
+int  mw_nc_open(mw_nc_t *nc, const char *path);                                        /* nc.open (read-write)                   */
+int  mw_nc_inq_varid(mw_nc_t nc, const char *name, int *varid);
+int  mw_nc_inq_dimlen(mw_nc_t nc, const char *name, long long *len);                   /* get_dim_size; record dim: # records    */
+int  mw_nc_put_vara_double(mw_nc_t nc, int varid, const long long *start, const long long *count, const double *host_data);
+int  mw_nc_set_numrecs(mw_nc_t nc, long long numrecs);
+int  mw_nc_close(mw_nc_t nc);
+/* The body of Dynamics_Euler_Stratified_WenoFV::output's variable loop, :2176-2185 (and Time_Averager::finalize's,
+ * time_averager.h:131-136): ensemble member 0 of the DEVICE field (nz,ny,nx,nens) -> host -> this rank's hyperslab
+ * {record, 0, j_beg, i_beg} x {1, nz, ny, nx} of variable varid (record < 0: a variable without the t dimension). */
+int  mw_output_put_field(mw_nc_t nc, int varid, long long record, const mw_grid_t *g, const double *field, void *stream);
+
+/* ---- simple_city custom modules ------------------------------------------- */
+/* fields6 / avg6: HOST arrays of 6 DEVICE pointers: density_dry, uvel, vvel, wvel, temp, water_vapor. */
+/* custom_modules::Horizontal_Sponge::init, horizontal_sponge.h:54-61: column (6,nz,nens) DEVICE = cell (k,0,0,iens) of this
+ * rank; the reference takes the main rank's and MPI_Bcast's it (:73-78) -- the host broadcasts `column` from rank 0. */
+int  mw_horizontal_sponge_column(const mw_grid_t *g, const double *const *fields6, double *column, void *stream);
+/* Horizontal_Sponge::apply(coupler, dt, x1, x2, y1, y2), :101-192: cosine-weighted relaxation of the 6 fields to the stored
+ * column within sponge_cells of the enabled domain edges (only on the ranks that own the edge). */
+int  mw_horizontal_sponge_apply(const mw_grid_t *g, double *const *fields6, const double *column, int sponge_cells,
+                                double time_scale, double dt, int x1, int x2, int y1, int y2, void *stream);
+/* custom_modules::Time_Averager::accumulate, time_averager.h:37-78: avg = inertia*avg + (1-inertia)*field with
+ * inertia = etime/(etime+dt); the caller advances its etime by dt afterwards (:77). */
+int  mw_time_average_accumulate(const mw_grid_t *g, const double *const *fields6, double *const *avg6, double etime, double dt,
+                                void *stream);
+
 #ifdef __cplusplus
 }
 #endif

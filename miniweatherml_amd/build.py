@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmw_cdna4.so")
-SOURCES = ["mw_host.cpp", "mw_dycore.hip", "mw_kessler.hip", "mw_mlp.hip", "mw_column.hip", "mw_rccl.cpp"]
+SOURCES = ["mw_host.cpp", "mw_dycore.hip", "mw_kessler.hip", "mw_mlp.hip", "mw_column.hip", "mw_output.hip", "mw_netcdf.cpp", "mw_rccl.cpp"]
 HEADERS = ["mw_common.h", "mw_weno.h", "mw_march.h", os.path.join("..", "..", "include", "mw_cdna4.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
@@ -47,19 +47,22 @@ def build(force=False, verbose=True):
 
 
 def build_examples(verbose=True):
-    """The C++ caller of examples/ (mirror of the reference's driver) against the C++ facade + C ABI."""
+    """The C++ callers of examples/ (mirrors of the reference's drivers) against the C++ facade + C ABI."""
     root = os.path.dirname(HERE)
-    src = os.path.join(root, "examples", "supercell_driver.cpp")
-    exe = os.path.join(root, "examples", "supercell_driver")
-    deps = [src, os.path.join(HERE, "host", "mw_facade.h"), os.path.join(root, "include", "mw_cdna4.h"), LIB]
-    if _stale(exe, deps):
-        cmd = [HIPCC, "-O2", "-std=c++17", "-x", "c++", src, "-o", exe, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
-               "-L" + HERE, "-lmw_cdna4", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../miniweatherml_amd",
-               "-Wl,-rpath,/opt/rocm/lib"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    return exe
+    exes = []
+    for name in ("supercell_driver", "simple_city_driver"):
+        src = os.path.join(root, "examples", name + ".cpp")
+        exe = os.path.join(root, "examples", name)
+        deps = [src, os.path.join(HERE, "host", "mw_facade.h"), os.path.join(root, "include", "mw_cdna4.h"), LIB]
+        if _stale(exe, deps):
+            cmd = [HIPCC, "-O2", "-std=c++17", "-x", "c++", src, "-o", exe, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                   "-L" + HERE, "-lmw_cdna4", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../miniweatherml_amd",
+                   "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        exes.append(exe)
+    return exes[0]
 
 
 if __name__ == "__main__":

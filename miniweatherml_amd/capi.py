@@ -75,6 +75,22 @@ SYMBOLS = {
     "mw_column_average": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_void_p]),
     "mw_nudge_to_column": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.c_void_p, C.c_double, C.c_void_p, ALLREDUCE_FN,
                                      C.c_void_p, C.c_void_p]),
+    "mw_nc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_longlong, C.c_longlong]),
+    "mw_nc_def_dim": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong, C.POINTER(C.c_int)]),
+    "mw_nc_def_var": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mw_nc_enddef": (C.c_int, [C.c_void_p]),
+    "mw_nc_open": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p]),
+    "mw_nc_inq_varid": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "mw_nc_inq_dimlen": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]),
+    "mw_nc_put_vara_double": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_void_p]),
+    "mw_nc_set_numrecs": (C.c_int, [C.c_void_p, C.c_longlong]),
+    "mw_nc_close": (C.c_int, [C.c_void_p]),
+    "mw_output_put_field": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.POINTER(Grid), C.c_void_p, C.c_void_p]),
+    "mw_horizontal_sponge_column": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]),
+    "mw_horizontal_sponge_apply": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_double, C.c_double] +
+                                   [C.c_int] * 4 + [C.c_void_p]),
+    "mw_time_average_accumulate": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_double, C.c_double,
+                                             C.c_void_p]),
     "mw_mlp_forward": (C.c_int, [C.c_longlong] + [C.c_void_p] * 5 + [C.POINTER(C.c_float)] * 4 +
                        [C.POINTER(C.c_double)] * 2 + [C.c_void_p] * 4 + [C.c_void_p]),
 }

@@ -1,0 +1,144 @@
+// =====================================================================================================
+// mw_output.hip -- SURVEY.md 8(f) rank 2 and 3:
+//   * the device side of the reference's file output (dynamics_euler_stratified_wenofv.h:2019-2191, time_averager.h:82-141):
+//     member 0 of a (nz,ny,nx,nens) field -> contiguous (nz,ny,nx) -> host -> this rank's hyperslab of the shared CDF-5 file
+//   * the two element-wise modules of the simple_city loop (experiments/simple_city/driver.cpp:72-75):
+//     custom_modules::Horizontal_Sponge::{init, apply}   custom_modules/horizontal_sponge.h:18-193
+//     custom_modules::Time_Averager::accumulate          custom_modules/time_averager.h:37-78
+// =====================================================================================================
+#include "../../include/mw_cdna4.h"
+#include "mw_common.h"
+#include <cmath>
+#include <vector>
+
+namespace mw {
+
+struct Six { double *f[6]; };
+
+__global__ __launch_bounds__(256) void k_extract_member(const double *__restrict__ in, long long ncell, int nens, int e,
+                                                        double *__restrict__ out) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t < ncell) out[t] = in[t * nens + e];
+}
+
+// horizontal_sponge.h:54-61: the reference column = cell (k, 0, 0, iens) of the main rank
+__global__ __launch_bounds__(256) void k_hsponge_column(Six f, int nz, long long plane, int nens, double *__restrict__ col) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 6 * nz * nens) return;
+  int e = t % nens, k = (t / nens) % nz, l = t / (nens * nz);
+  col[t] = f.f[l][(long long)k * plane + e];
+}
+
+// horizontal_sponge.h:133-190.  The reference runs up to four full-domain passes (x1, x2, y1, y2) one after the other; each
+// touches a cell with weight 0 outside its own strip (w*col + (1-w)*v = v exactly), so applying the four relaxations in the
+// same order to the value in a register is the same arithmetic in one pass.
+__global__ __launch_bounds__(256) void k_hsponge_apply(Six f, int nz, int ny, int nx, int nens, int sponge_cells, double time_factor,
+                                                       int x1, int x2, int y1, int y2, const double *__restrict__ col) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y, l = blockIdx.z;
+  if (t >= (long long)ny * nx * nens) return;
+  const int e = (int)(t % nens);
+  const int i = (int)((t / nens) % nx), j = (int)(t / ((long long)nens * nx));
+  const int d[4] = {i, nx - 1 - i, j, ny - 1 - j};
+  const int on[4] = {x1, x2, y1, y2};
+  bool any = false;
+  for (int s = 0; s < 4; s++) any = any || (on[s] && d[s] < sponge_cells);
+  if (!any) return;                                                          // weight 0 in every enabled pass: value unchanged
+  double *q = f.f[l] + (long long)k * ny * nx * nens + t;
+  const double c = col[(l * nz + k) * nens + e];
+  double v = *q;
+  for (int s = 0; s < 4; s++) {
+    if (!on[s]) continue;
+    double loc = d[s] / (sponge_cells - 1.0);
+    double weight = d[s] < sponge_cells ? (cos(M_PI * loc) + 1) / 2 : 0;
+    weight *= time_factor;
+    v = weight * c + (1 - weight) * v;
+  }
+  *q = v;
+}
+
+// time_averager.h:64-75
+__global__ __launch_bounds__(256) void k_time_average(Six f, Six avg, long long n, double inertia) {
+#pragma clang fp contract(off)
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int l = blockIdx.y;
+  if (t >= n) return;
+  avg.f[l][t] = inertia * avg.f[l][t] + (1 - inertia) * f.f[l][t];
+}
+
+} // namespace mw
+
+using namespace mw;
+
+static int six_ptrs(double *const *p, Six &s, const char *what) {
+  if (!p) { set_error(std::string(what) + ": null field list"); return 1; }
+  for (int l = 0; l < 6; l++) { if (!p[l]) { set_error(std::string(what) + ": null field"); return 1; } s.f[l] = p[l]; }
+  return 0;
+}
+
+extern "C" {
+
+int mw_output_put_field(mw_nc_t nc, int varid, long long record, const mw_grid_t *g, const double *field, void *stream) {
+  if (!nc || !g || !field) MW_FAIL("output_put_field: null argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipStream_t st = (hipStream_t)stream;
+  const long long ncell = (long long)g->nz * g->ny * g->nx;
+  double *dev = nullptr, *host = nullptr;
+  MW_HIP(hipMalloc(&dev, (size_t)ncell * sizeof(double)));
+  if (hipHostMalloc(&host, (size_t)ncell * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipFree(dev); MW_FAIL("hipHostMalloc failed"); }
+  int rc = 0;
+  hipLaunchKernelGGL(k_extract_member, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, field, ncell, g->nens, 0, dev);   // iens = 0 (:2035)
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(host, dev, (size_t)ncell * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) { set_error("output_put_field: device to host copy failed"); rc = 1; }
+  if (!rc) {
+    if (record >= 0) { const long long start[4] = {record, 0, g->j_beg, g->i_beg}, count[4] = {1, g->nz, g->ny, g->nx};
+                       rc = mw_nc_put_vara_double(nc, varid, start, count, host); }
+    else             { const long long start[3] = {0, g->j_beg, g->i_beg}, count[3] = {g->nz, g->ny, g->nx};
+                       rc = mw_nc_put_vara_double(nc, varid, start, count, host); }
+  }
+  (void)hipHostFree(host); (void)hipFree(dev);
+  return rc;
+}
+
+int mw_horizontal_sponge_column(const mw_grid_t *g, const double *const *fields6, double *column, void *stream) {
+  if (!g || !column) MW_FAIL("horizontal_sponge_column: null argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  Six f; if (six_ptrs((double *const *)fields6, f, "horizontal_sponge_column")) return 1;
+  const int n = 6 * g->nz * g->nens;
+  hipLaunchKernelGGL(k_hsponge_column, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f, g->nz,
+                     (long long)g->ny * g->nx * g->nens, g->nens, column);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+int mw_horizontal_sponge_apply(const mw_grid_t *g, double *const *fields6, const double *column, int sponge_cells, double time_scale,
+                               double dt, int x1, int x2, int y1, int y2, void *stream) {
+  if (!g || !column) MW_FAIL("horizontal_sponge_apply: null argument");
+  if (sponge_cells < 2) MW_FAIL("horizontal_sponge_apply: sponge_cells must be >= 2 (the reference divides by sponge_cells - 1)");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  Six f; if (six_ptrs(fields6, f, "horizontal_sponge_apply")) return 1;
+  // a pass only runs on the ranks that own that domain edge (horizontal_sponge.h:133,148,163,178)
+  x1 = x1 && g->px == 0; x2 = x2 && g->px == g->nproc_x - 1; y1 = y1 && g->py == 0; y2 = y2 && g->py == g->nproc_y - 1;
+  if (!(x1 || x2 || y1 || y2)) return 0;
+  const long long plane = (long long)g->ny * g->nx * g->nens;
+  dim3 grid((unsigned)((plane + 255) / 256), (unsigned)g->nz, 6u);
+  hipLaunchKernelGGL(k_hsponge_apply, grid, dim3(256), 0, (hipStream_t)stream, f, g->nz, g->ny, g->nx, g->nens, sponge_cells, dt / time_scale,
+                     x1, x2, y1, y2, column);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+int mw_time_average_accumulate(const mw_grid_t *g, const double *const *fields6, double *const *avg6, double etime, double dt, void *stream) {
+  if (!g) MW_FAIL("time_average_accumulate: null argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  Six f, a;
+  if (six_ptrs((double *const *)fields6, f, "time_average_accumulate") || six_ptrs(avg6, a, "time_average_accumulate")) return 1;
+  const long long n = (long long)g->nz * g->ny * g->nx * g->nens;
+  const double inertia = etime / (etime + dt);                               // time_averager.h:62
+  hipLaunchKernelGGL(k_time_average, dim3((unsigned)((n + 255) / 256), 6u), dim3(256), 0, (hipStream_t)stream, f, a, n, inertia);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+} // extern "C"

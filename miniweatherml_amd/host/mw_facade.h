@@ -269,6 +269,44 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
     mw_check(mw_dycore_time_step(h, f_rho, f_u, f_v, f_w, f_T, tracer_ptrs.data(), dt_phys));
     etime += dt_phys;
   }
+  // output(coupler, etime), :2019-2191, shared-file branch: CDF-5 `<out_prefix>.nc`, dims x,y,z,t, one (t,z,y,x) double
+  // variable per coupler field, ensemble member 0.  Single-process form (the ranks of a multi-process run order themselves
+  // with their own barrier around create / set_numrecs, as miniweatherml_amd/modules.py does).
+  void output(core::Coupler const &coupler, real etime_) const {
+    if (coupler.get_option<bool>("file_per_process", false)) endrun("output: file_per_process (NetCDF-4/HDF5) is not provided");
+    const mw_grid_t &g = coupler.grid;
+    std::string path = coupler.get_option<std::string>("out_prefix") + ".nc";
+    std::vector<std::string> names = {"density_dry", "uvel", "vvel", "wvel", "temp"};
+    for (auto &n : coupler.get_tracer_names()) names.push_back(n);
+    mw_nc_t nc = nullptr; long long rec = 0; int v = 0;
+    auto put1 = [&](const char *name, long long start, std::vector<double> const &a) {
+      long long st[1] = {start}, ct[1] = {(long long)a.size()};
+      mw_check(mw_nc_inq_varid(nc, name, &v)); mw_check(mw_nc_put_vara_double(nc, v, st, ct, a.data())); };
+    if (etime_ == 0) {
+      mw_check(mw_nc_create(&nc, path.c_str(), 5, 1048576, 1048576));                                            // :2103-2106
+      int dx_, dy_, dz_, dt_;
+      mw_check(mw_nc_def_dim(nc, "x", (long long)coupler.get_nx_glob(), &dx_)); mw_check(mw_nc_def_dim(nc, "y", (long long)coupler.get_ny_glob(), &dy_));
+      mw_check(mw_nc_def_dim(nc, "z", g.nz, &dz_)); mw_check(mw_nc_def_dim(nc, "t", 0, &dt_));
+      mw_check(mw_nc_def_var(nc, "x", 1, &dx_, &v)); mw_check(mw_nc_def_var(nc, "y", 1, &dy_, &v));
+      mw_check(mw_nc_def_var(nc, "z", 1, &dz_, &v)); mw_check(mw_nc_def_var(nc, "t", 1, &dt_, &v));
+      int d4[4] = {dt_, dz_, dy_, dx_};
+      for (auto &n : names) mw_check(mw_nc_def_var(nc, n.c_str(), 4, d4, &v));
+      mw_check(mw_nc_enddef(nc));
+      std::vector<double> xs(g.nx), ys(g.ny), zs(g.nz);
+      for (int i = 0; i < g.nx; i++) xs[i] = (i + g.i_beg + 0.5) * coupler.get_dx();
+      for (int j = 0; j < g.ny; j++) ys[j] = (j + g.j_beg + 0.5) * coupler.get_dy();
+      for (int k = 0; k < g.nz; k++) zs[k] = (k + 0.5) * coupler.get_dz();
+      put1("x", g.i_beg, xs); put1("y", g.j_beg, ys); put1("z", 0, zs); put1("t", 0, {0.0});
+    } else {
+      mw_check(mw_nc_open(&nc, path.c_str()));
+      mw_check(mw_nc_inq_dimlen(nc, "t", &rec));
+      put1("t", rec, {(double)etime_});
+    }
+    auto &dm = const_cast<core::DataManager &>(coupler.get_data_manager_readonly());
+    for (auto &n : names) { mw_check(mw_nc_inq_varid(nc, n.c_str(), &v)); mw_check(mw_output_put_field(nc, v, rec, &g, dm.get<real>(n).data(), nullptr)); }
+    mw_check(mw_nc_set_numrecs(nc, rec + 1));
+    mw_check(mw_nc_close(nc));
+  }
   mw_dycore_t handle() const { return h; }
  private:
   void bind(core::Coupler &coupler) {
@@ -324,3 +362,76 @@ inline void perturb_temperature(core::Coupler &coupler, bool thermal = true, boo
 }
 
 } // namespace modules
+
+namespace custom_modules {                                             // experiments/simple_city/custom_modules/
+
+inline std::vector<double *> six_fields(core::Coupler &c, const char *prefix = "") {
+  auto &dm = c.get_data_manager_readwrite(); std::vector<double *> s;
+  for (const char *n : {"density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor"}) s.push_back(dm.get<real>(std::string(prefix) + n).data());
+  return s;
+}
+
+struct Horizontal_Sponge {                                             // horizontal_sponge.h:7-194 (single rank: no MPI_Bcast)
+  double *column = nullptr; int nz = 0, nens = 0; int sponge_cells = 10; real time_scale = 1;
+  ~Horizontal_Sponge() { if (column) (void)hipFree(column); }
+  void init(core::Coupler &coupler, int sponge_cells_ = 10, real time_scale_ = 1) {                              // :18-91
+    nz = coupler.get_nz(); nens = coupler.get_nens();
+    if (!column && hipMalloc((void **)&column, sizeof(double) * 6 * (size_t)nz * nens) != hipSuccess) endrun("Horizontal_Sponge: allocation failed");
+    auto f = six_fields(coupler);
+    mw_check(mw_horizontal_sponge_column(&coupler.grid, f.data(), column, nullptr));
+    sponge_cells = sponge_cells_; time_scale = time_scale_;
+  }
+  void override_field(int l, real val) { std::vector<double> h((size_t)nz * nens, val);
+    (void)hipMemcpy(column + (size_t)l * nz * nens, h.data(), h.size() * 8, hipMemcpyHostToDevice); }
+  void override_rho_d(real v) { override_field(0, v); }  void override_uvel(real v) { override_field(1, v); }      // :94-99
+  void override_vvel(real v) { override_field(2, v); }   void override_wvel(real v) { override_field(3, v); }
+  void override_temp(real v) { override_field(4, v); }   void override_rho_v(real v) { override_field(5, v); }
+  void apply(core::Coupler &coupler, real dt, bool x1 = true, bool x2 = true, bool y1 = true, bool y2 = true) {  // :101-192
+    if (!column) endrun("Horizontal_Sponge::apply before init");
+    auto f = six_fields(coupler);
+    mw_check(mw_horizontal_sponge_apply(&coupler.grid, f.data(), column, sponge_cells, time_scale, dt, x1, x2, y1, y2, nullptr));
+  }
+};
+
+struct Time_Averager {                                                 // time_averager.h:7-143
+  real etime = 0;
+  void init(core::Coupler &coupler) {                                  // :10-35
+    auto &dm = coupler.get_data_manager_readwrite();
+    int nz = coupler.get_nz(), ny = coupler.get_ny(), nx = coupler.get_nx(), nens = coupler.get_nens();
+    for (const char *n : {"density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor"}) {
+      dm.register_and_allocate<real>(std::string("time_avg_") + n, "", {nz, ny, nx, nens});
+      (void)hipMemset(dm.get<real>(std::string("time_avg_") + n).data(), 0, sizeof(double) * (size_t)nz * ny * nx * nens);
+    }
+    etime = 0;
+  }
+  void accumulate(core::Coupler &coupler, real dt) {                   // :37-78
+    auto f = six_fields(coupler), a = six_fields(coupler, "time_avg_");
+    mw_check(mw_time_average_accumulate(&coupler.grid, f.data(), a.data(), etime, dt, nullptr));
+    etime += dt;
+  }
+  void finalize(core::Coupler &coupler, const std::string &path = "time_averaged_fields.nc") {                  // :80-141
+    const mw_grid_t &g = coupler.grid;
+    mw_nc_t nc = nullptr; int v = 0, dx_, dy_, dz_;
+    mw_check(mw_nc_create(&nc, path.c_str(), 5, 0, 0));                                                          // NC_CLOBBER | NC_64BIT_DATA
+    mw_check(mw_nc_def_dim(nc, "x", (long long)coupler.get_nx_glob(), &dx_)); mw_check(mw_nc_def_dim(nc, "y", (long long)coupler.get_ny_glob(), &dy_));
+    mw_check(mw_nc_def_dim(nc, "z", g.nz, &dz_));
+    mw_check(mw_nc_def_var(nc, "x", 1, &dx_, &v)); mw_check(mw_nc_def_var(nc, "y", 1, &dy_, &v)); mw_check(mw_nc_def_var(nc, "z", 1, &dz_, &v));
+    int d3[3] = {dz_, dy_, dx_};
+    const char *names[6] = {"density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor"};
+    for (auto n : names) mw_check(mw_nc_def_var(nc, n, 3, d3, &v));
+    mw_check(mw_nc_enddef(nc));
+    auto put1 = [&](const char *name, long long start, std::vector<double> const &a) {
+      long long st[1] = {start}, ct[1] = {(long long)a.size()};
+      mw_check(mw_nc_inq_varid(nc, name, &v)); mw_check(mw_nc_put_vara_double(nc, v, st, ct, a.data())); };
+    std::vector<double> xs(g.nx), ys(g.ny), zs(g.nz);
+    for (int i = 0; i < g.nx; i++) xs[i] = (i + g.i_beg + 0.5) * coupler.get_dx();
+    for (int j = 0; j < g.ny; j++) ys[j] = (j + g.j_beg + 0.5) * coupler.get_dy();
+    for (int k = 0; k < g.nz; k++) zs[k] = (k + 0.5) * coupler.get_dz();
+    put1("x", g.i_beg, xs); put1("y", g.j_beg, ys); put1("z", 0, zs);
+    auto a = six_fields(coupler, "time_avg_");
+    for (int l = 0; l < 6; l++) { mw_check(mw_nc_inq_varid(nc, names[l], &v)); mw_check(mw_output_put_field(nc, v, -1, &g, a[l], nullptr)); }
+    mw_check(mw_nc_close(nc));
+  }
+};
+
+} // namespace custom_modules

@@ -379,6 +379,215 @@ class ColumnNudger:
                                                 _ptr(ws), fn, None, _stream_ptr(coupler.device)))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# File output and the simple_city custom modules (rank 3)
+# ---------------------------------------------------------------------------------------------------------------------
+def _barrier(coupler):
+    import torch.distributed as dist
+    if coupler.get_nranks() > 1 and dist.is_initialized():
+        dist.barrier()
+
+
+class _NcFile:
+    """RAII wrapper over the mw_nc_* writer (CDF-5 by default, like the reference's NC_64BIT_DATA)."""
+
+    def __init__(self, path, create, fmt=5, header_align=0, var_align=0):
+        self.h = C.c_void_p(None)
+        L = capi.lib()
+        if create:
+            check(L.mw_nc_create(C.byref(self.h), path.encode(), fmt, header_align, var_align))
+        else:
+            check(L.mw_nc_open(C.byref(self.h), path.encode()))
+
+    def def_dim(self, name, n):
+        d = C.c_int(-1)
+        check(capi.lib().mw_nc_def_dim(self.h, name.encode(), int(n), C.byref(d)))
+        return d.value
+
+    def def_var(self, name, dims):
+        v = C.c_int(-1)
+        arr = (C.c_int * max(1, len(dims)))(*dims)
+        check(capi.lib().mw_nc_def_var(self.h, name.encode(), len(dims), arr, C.byref(v)))
+        return v.value
+
+    def enddef(self):
+        check(capi.lib().mw_nc_enddef(self.h))
+
+    def varid(self, name):
+        v = C.c_int(-1)
+        check(capi.lib().mw_nc_inq_varid(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def dimlen(self, name):
+        n = C.c_longlong(-1)
+        check(capi.lib().mw_nc_inq_dimlen(self.h, name.encode(), C.byref(n)))
+        return n.value
+
+    def put(self, varid, start, count, data):
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        st = (C.c_longlong * max(1, len(start)))(*start)
+        ct = (C.c_longlong * max(1, len(count)))(*count)
+        check(capi.lib().mw_nc_put_vara_double(self.h, varid, st, ct, data.ctypes.data_as(C.c_void_p)))
+
+    def put_field(self, varid, record, coupler, tensor):
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_output_put_field(self.h, varid, record, C.byref(coupler.grid), _ptr(tensor), _stream_ptr(coupler.device)))
+
+    def set_numrecs(self, n):
+        check(capi.lib().mw_nc_set_numrecs(self.h, int(n)))
+
+    def close(self):
+        if self.h and self.h.value:
+            h, self.h = self.h, C.c_void_p(None)
+            check(capi.lib().mw_nc_close(h))
+
+
+def _coords(coupler):
+    """x/y/z cell-centre coordinates of this rank's block (:2133-2147)."""
+    g = coupler.grid
+    dx, dy, dz = coupler.get_dx(), coupler.get_dy(), coupler.get_dz()
+    return ((np.arange(g.nx) + g.i_beg + 0.5) * dx, (np.arange(g.ny) + g.j_beg + 0.5) * dy, (np.arange(g.nz) + 0.5) * dz)
+
+
+def dycore_output(coupler, etime, fmt=5, barrier=None):
+    """Dynamics_Euler_Stratified_WenoFV::output(coupler, etime), dynamics_euler_stratified_wenofv.h:2019-2191, shared-file
+    branch (:2092-2188): one CDF-5 file `<out_prefix>.nc`, dims x,y,z (global sizes) and unlimited t, variables x,y,z,t and
+    one (t,z,y,x) double variable per coupler field (ensemble member 0).  etime == 0 creates the file (main rank), later calls
+    append a record.  `file_per_process` (:2038-2090) writes NetCDF-4/HDF5 files in the reference and is not provided."""
+    if coupler.get_option("file_per_process", False):
+        endrun("output: file_per_process needs the NetCDF-4/HDF5 writer, which is not provided; use the shared file")
+    barrier = barrier or (lambda: _barrier(coupler))
+    path = str(coupler.get_option("out_prefix")) + ".nc"
+    names = ["density_dry", "uvel", "vvel", "wvel", "temp"] + list(coupler.get_tracer_names())
+    g = coupler.grid
+    xs, ys, zs = _coords(coupler)
+    main = coupler.is_mainproc()
+    if etime == 0:
+        if main:
+            nc = _NcFile(path, True, fmt, 1048576, 1048576)                  # nc_header_align_size / nc_var_align_size, :2103-2104
+            dx_, dy_, dz_ = nc.def_dim("x", coupler.get_nx_glob()), nc.def_dim("y", coupler.get_ny_glob()), nc.def_dim("z", g.nz)
+            dt_ = nc.def_dim("t", 0)
+            for n_, d_ in (("x", [dx_]), ("y", [dy_]), ("z", [dz_]), ("t", [dt_])):
+                nc.def_var(n_, d_)
+            for n_ in names:
+                nc.def_var(n_, [dt_, dz_, dy_, dx_])
+            nc.enddef()
+            nc.put(nc.varid("z"), [0], [g.nz], zs)
+            nc.put(nc.varid("t"), [0], [1], [0.0])
+        barrier()
+        if not main:
+            nc = _NcFile(path, False)
+        nc.put(nc.varid("x"), [g.i_beg], [g.nx], xs)
+        nc.put(nc.varid("y"), [g.j_beg], [g.ny], ys)
+        rec = 0
+    else:
+        nc = _NcFile(path, False)
+        rec = nc.dimlen("t")
+        if main:
+            nc.put(nc.varid("t"), [rec], [1], [float(etime)])
+    dm = coupler.get_data_manager_readonly()
+    for n_ in names:
+        nc.put_field(nc.varid(n_), rec, coupler, dm.get(n_))
+    barrier()                                                                  # every rank's block is in the file ...
+    if main:
+        nc.set_numrecs(rec + 1)                                                # ... before the record becomes visible
+    nc.close()
+    barrier()
+
+
+Dynamics_Euler_Stratified_WenoFV.output = lambda self, coupler, etime, **kw: dycore_output(coupler, etime, **kw)
+
+_SIX = ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor")
+
+
+class Horizontal_Sponge:
+    """custom_modules::Horizontal_Sponge, experiments/simple_city/custom_modules/horizontal_sponge.h:7-194."""
+
+    def __init__(self):
+        self.column = None                                                     # (6, nz, nens): col_rho_d .. col_rho_v
+        self.sponge_cells, self.time_scale = 10, 1.0
+
+    def init(self, coupler, sponge_cells=10, time_scale=1.0):                  # :18-91
+        dm = coupler.get_data_manager_readonly()
+        self.column = torch.zeros((6, coupler.get_nz(), coupler.get_nens()), dtype=torch.float64, device=coupler.device)
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_horizontal_sponge_column(C.byref(coupler.grid), _field_ptr_array([dm.get(n) for n in _SIX]),
+                                                         _ptr(self.column), _stream_ptr(coupler.device)))
+        import torch.distributed as dist
+        if coupler.get_nranks() > 1 and dist.is_initialized():                 # MPI_Bcast from the main rank, :73-78
+            if dist.get_backend() == "gloo":
+                h = self.column.cpu(); dist.broadcast(h, 0); self.column.copy_(h)
+            else:
+                dist.broadcast(self.column, 0)
+        self.sponge_cells, self.time_scale = int(sponge_cells), float(time_scale)
+
+    def _override(self, l, val):
+        self.column[l].fill_(float(val))
+
+    def override_rho_d(self, val): self._override(0, val)                      # noqa: E704   :94-99
+    def override_uvel(self, val): self._override(1, val)                       # noqa: E704
+    def override_vvel(self, val): self._override(2, val)                       # noqa: E704
+    def override_wvel(self, val): self._override(3, val)                       # noqa: E704
+    def override_temp(self, val): self._override(4, val)                       # noqa: E704
+    def override_rho_v(self, val): self._override(5, val)                      # noqa: E704
+
+    def apply(self, coupler, dt, x1=True, x2=True, y1=True, y2=True):          # :101-192
+        if self.column is None:
+            endrun("Horizontal_Sponge.apply before init")
+        dm = coupler.get_data_manager_readwrite()
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_horizontal_sponge_apply(C.byref(coupler.grid), _field_ptr_array([dm.get(n) for n in _SIX]), _ptr(self.column),
+                                                        self.sponge_cells, self.time_scale, float(dt), int(x1), int(x2), int(y1), int(y2),
+                                                        _stream_ptr(coupler.device)))
+
+
+class Time_Averager:
+    """custom_modules::Time_Averager, experiments/simple_city/custom_modules/time_averager.h:7-143."""
+
+    def __init__(self):
+        self.etime = 0.0
+
+    def init(self, coupler):                                                   # :10-35
+        dm = coupler.get_data_manager_readwrite()
+        shape = (coupler.get_nz(), coupler.get_ny(), coupler.get_nx(), coupler.get_nens())
+        for n in _SIX:
+            dm.register_and_allocate("time_avg_" + n, "", shape)
+            dm.get("time_avg_" + n).zero_()
+        self.etime = 0.0
+
+    def accumulate(self, coupler, dt):                                         # :37-78
+        dm = coupler.get_data_manager_readwrite()
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_time_average_accumulate(C.byref(coupler.grid), _field_ptr_array([dm.get(n) for n in _SIX]),
+                                                        _field_ptr_array([dm.get("time_avg_" + n) for n in _SIX]), float(self.etime),
+                                                        float(dt), _stream_ptr(coupler.device)))
+        self.etime += dt
+
+    def finalize(self, coupler, path="time_averaged_fields.nc", fmt=5, barrier=None):   # :80-141
+        barrier = barrier or (lambda: _barrier(coupler))
+        g = coupler.grid
+        xs, ys, zs = _coords(coupler)
+        if coupler.is_mainproc():
+            nc = _NcFile(path, True, fmt)
+            dx_, dy_, dz_ = nc.def_dim("x", coupler.get_nx_glob()), nc.def_dim("y", coupler.get_ny_glob()), nc.def_dim("z", g.nz)
+            for n_, d_ in (("x", [dx_]), ("y", [dy_]), ("z", [dz_])):
+                nc.def_var(n_, d_)
+            for n_ in _SIX:
+                nc.def_var(n_, [dz_, dy_, dx_])
+            nc.enddef()
+            nc.put(nc.varid("z"), [0], [g.nz], zs)
+        barrier()
+        if not coupler.is_mainproc():
+            nc = _NcFile(path, False)
+        nc.put(nc.varid("x"), [g.i_beg], [g.nx], xs)
+        nc.put(nc.varid("y"), [g.j_beg], [g.ny], ys)
+        dm = coupler.get_data_manager_readonly()
+        for n_ in _SIX:
+            nc.put_field(nc.varid(n_), -1, coupler, dm.get("time_avg_" + n_))
+        nc.close()
+        barrier()
+
+
 def use_rccl_exchange(dycore, coupler, group=None):
     """Slab halo exchange over RCCL point-to-point inside the library (mw_rccl.cpp): rank 0 creates the ncclUniqueId,
     torch.distributed broadcasts it, every rank joins.  Replaces the MPI_Isend/Irecv of halo_exchange (:641-723)."""
@@ -473,6 +682,37 @@ def make_supercell(nx_glob, ny_glob, nz, nens=1, xlen=1.0e5, ylen=1.0e5, zlen=2.
     if with_nudger:
         return coupler, dycore, micro, nudger
     return coupler, dycore, micro
+
+
+def make_simple_city(nx_glob, ny_glob, nz, nens=1, xlen=2400.0, ylen=2400.0, zlen=120.0, init_data="city", device="cuda:0",
+                     nranks=1, myrank=0, out_prefix="test"):
+    """The set-up sequence of experiments/simple_city/driver.cpp:32-62: only water_vapor is registered (zero), gravity off,
+    dycore.init -> horiz_sponge.init(coupler, 10, 1.) -> time_averager.init."""
+    coupler = Coupler(device)
+    coupler.set_option("out_prefix", out_prefix)
+    coupler.set_option("init_data", init_data)
+    coupler.set_option("out_freq", -1.0)
+    coupler.set_option("enable_gravity", False)
+    coupler.distribute_mpi_and_allocate_coupled_state(nz, ny_glob, nx_glob, nens, nranks, myrank)
+    coupler.set_grid(xlen, ylen, zlen)
+    coupler.add_tracer("water_vapor", "water_vapor", True, True)               # driver.cpp:55-56
+    coupler.get_data_manager_readwrite().get("water_vapor").zero_()
+    dycore, horiz_sponge, time_averager = Dynamics_Euler_Stratified_WenoFV(), Horizontal_Sponge(), Time_Averager()
+    dycore.init(coupler)
+    horiz_sponge.init(coupler, 10, 1.0)
+    time_averager.init(coupler)
+    return coupler, dycore, horiz_sponge, time_averager
+
+
+def simple_city_step(coupler, dycore, horiz_sponge, time_averager, dtphys=None):
+    """One iteration of experiments/simple_city/driver.cpp:66-79."""
+    if dtphys is None or dtphys <= 0:
+        dtphys = dycore.compute_time_step(coupler)
+    horiz_sponge.apply(coupler, dtphys, True, True, False, False)
+    dycore.time_step(coupler, dtphys)
+    sponge_layer(coupler, dtphys, 1)
+    time_averager.accumulate(coupler, dtphys)
+    return dtphys
 
 
 def supercell_step(coupler, dycore, micro, nudger, dtphys=None):

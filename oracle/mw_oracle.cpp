@@ -1541,6 +1541,41 @@ void mwo_nudge_to_column(const mwo_params *pp, double *const *state, const doubl
 }
 
 // -----------------------------------------------------------------------------------------------------
+// simple_city custom modules: element-wise, restated pass by pass
+// fields6 / avg6: density_dry, uvel, vvel, wvel, temp, water_vapor ; col (6,nz,nens)
+// -----------------------------------------------------------------------------------------------------
+// custom_modules::Horizontal_Sponge::apply   experiments/simple_city/custom_modules/horizontal_sponge.h:101-192
+void mwo_horizontal_sponge_apply(const mwo_params *pp, double *const *fields6, const double *col, int sponge_cells, double time_scale,
+                                 double dt, int x1, int x2, int y1, int y2) {
+  const mwo_params &p = *pp;  Dims D(p);
+  int nz=p.nz, ny=p.ny, nx=p.nx, nens=p.nens;
+  real time_factor = dt / time_scale;
+  for (int pass = 0; pass < 4; pass++) {                       // four full-domain passes, in the reference's order (:133-190)
+    bool on = (pass == 0) ? (p.px == 0 && x1) : (pass == 1) ? (p.px == p.nproc_x-1 && x2)
+            : (pass == 2) ? (p.py == 0 && y1) : (p.py == p.nproc_y-1 && y2);
+    if (!on) continue;
+    for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
+      int d = (pass == 0) ? i : (pass == 1) ? nx-1-i : (pass == 2) ? j : ny-1-j;
+      real loc    = d / (sponge_cells-FP(1.));
+      real weight = d < sponge_cells ? (cos(M_PI*loc)+1)/2 : 0;
+      weight *= time_factor;
+      for (int l=0;l<6;l++) {
+        size_t c = D.C(k,j,i,iens);
+        fields6[l][c] = weight*col[((size_t)l*nz+k)*nens+iens] + (1-weight)*fields6[l][c];
+      }
+    }
+  }
+}
+
+// custom_modules::Time_Averager::accumulate   time_averager.h:37-78 (the caller adds dt to its etime afterwards, :77)
+void mwo_time_average_accumulate(const mwo_params *pp, const double *const *fields6, double *const *avg6, double etime, double dt) {
+  const mwo_params &p = *pp;
+  size_t n = (size_t)p.nz*p.ny*p.nx*p.nens;
+  double inertia = etime / (etime + dt);
+  for (int l=0;l<6;l++) for (size_t c=0;c<n;c++) avg6[l][c] = inertia * avg6[l][c] + (1-inertia) * fields6[l][c];
+}
+
+// -----------------------------------------------------------------------------------------------------
 // Surrogate NN block   experiments/supercell_kessler_surrogate/custom_modules/microphysics_kessler_ponni.h:176-202
 // ponni source is absent (empty submodule): layers restated from the call sites :103-110 and Keras Dense
 // semantics (kernel stored (in,out); y = x.W + b; LeakyReLU alpha = 0.1), fp32, accumulation in index order

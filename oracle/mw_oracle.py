@@ -88,6 +88,8 @@ def lib():
     L.mwo_sponge_layer.argtypes = [C.POINTER(Params), pdp, C.c_int, C.c_double, C.c_double, ALLREDUCE_FN, C.c_void_p]
     L.mwo_column_average.argtypes = [C.POINTER(Params), pdp, dp, ALLREDUCE_FN, C.c_void_p]
     L.mwo_nudge_to_column.argtypes = [C.POINTER(Params), pdp, dp, C.c_double, ALLREDUCE_FN, C.c_void_p]
+    L.mwo_horizontal_sponge_apply.argtypes = [C.POINTER(Params), pdp, dp, C.c_int, C.c_double, C.c_double] + [C.c_int] * 4
+    L.mwo_time_average_accumulate.argtypes = [C.POINTER(Params), pdp, pdp, C.c_double, C.c_double]
     fp = C.POINTER(C.c_float)
     L.mwo_mlp_forward.argtypes = [C.c_longlong, dp, dp, dp, dp, dp, fp, fp, fp, fp, dp, dp, dp, dp, dp, dp]
     _lib = L
@@ -297,6 +299,34 @@ class ColumnNudger:
     def nudge_to_column(self, p, f, dt, allreduce=None):
         cb = _ar(allreduce)
         lib().mwo_nudge_to_column(C.byref(p), _ptr_array(self._state(f, p.idWV)), _dp(self.column), float(dt), cb, None)
+
+
+class HorizontalSponge:
+    """custom_modules::Horizontal_Sponge (simple_city): column = cell (k,0,0,iens) of the main rank; cosine relaxation strips."""
+
+    @staticmethod
+    def _six(f, idWV=0):
+        return [f.rho_d, f.uvel, f.vvel, f.wvel, f.temp, f.tracers[idWV]]
+
+    def init(self, p, f, sponge_cells=10, time_scale=1.0):
+        self.column = np.stack([a[:, 0, 0, :].copy() for a in self._six(f, p.idWV)])      # (6, nz, nens)
+        self.sponge_cells, self.time_scale = int(sponge_cells), float(time_scale)
+
+    def apply(self, p, f, dt, x1=True, x2=True, y1=True, y2=True):
+        lib().mwo_horizontal_sponge_apply(C.byref(p), _ptr_array(self._six(f, p.idWV)), _dp(self.column), self.sponge_cells,
+                                          self.time_scale, float(dt), int(x1), int(x2), int(y1), int(y2))
+
+
+class TimeAverager:
+    """custom_modules::Time_Averager (simple_city): running time mean of the six fields."""
+
+    def init(self, p, f):
+        self.avg = [np.zeros_like(a) for a in HorizontalSponge._six(f, p.idWV)]
+        self.etime = 0.0
+
+    def accumulate(self, p, f, dt):
+        lib().mwo_time_average_accumulate(C.byref(p), _ptr_array(HorizontalSponge._six(f, p.idWV)), _ptr_array(self.avg), self.etime, float(dt))
+        self.etime += dt
 
 
 def city_building_heights(p):

@@ -68,3 +68,29 @@ def test_default_2d_run_reaches_the_recorded_state_at_step_800(oracle):
     assert 0.9 * R["rho_c_max"] < f.tracers[1].max() < 1.1 * R["rho_c_max"]
     assert 0.6 * R["rho_r_max"] < f.tracers[2].max() < 1.4 * R["rho_r_max"]
     assert f.tracers[1].min() >= 0 and f.tracers[2].min() >= 0
+
+
+def test_simple_city_modules_of_the_oracle(oracle):
+    """Horizontal_Sponge / Time_Averager restatements: closed-form properties."""
+    dyc, f = oracle.supercell_setup(24, 22, 6, 1, 1200., 1100., 120., init_data="city", num_tracers=1, enable_gravity=False, perturb=False)
+    hs, ta = oracle.HorizontalSponge(), oracle.TimeAverager()
+    hs.init(dyc.p, f, 10, 1.0)
+    ta.init(dyc.p, f)
+    rng = np.random.default_rng(4)
+    f.uvel += rng.normal(size=f.uvel.shape)
+    u0 = f.uvel.copy()
+    hs.apply(dyc.p, f, 0.25, 1, 1, 0, 0)
+    # i = 0 and i = nx-1: weight = (cos 0 + 1)/2 * dt/tau = 0.25 ; the 4 interior columns 10..13 are untouched ; y edges off
+    col = hs.column[1][:, None, :]
+    assert np.allclose(f.uvel[:, :, 0, :], 0.25 * col + 0.75 * u0[:, :, 0, :], rtol=0, atol=1e-15)
+    assert np.allclose(f.uvel[:, :, -1, :], 0.25 * col + 0.75 * u0[:, :, -1, :], rtol=0, atol=1e-15)
+    assert np.array_equal(f.uvel[:, :, 10:14, :], u0[:, :, 10:14, :])
+    assert np.array_equal(f.uvel[:, :, 9, :], u0[:, :, 9, :])                 # i = 9: cos(pi) + 1 = 0
+    # running mean with unequal steps = time-weighted mean
+    vals, dts = [], [0.5, 0.25, 1.0]
+    for dt in dts:
+        f.temp += 1.0
+        vals.append(f.temp.copy())
+        ta.accumulate(dyc.p, f, dt)
+    want = sum(v * dt for v, dt in zip(vals, dts)) / sum(dts)
+    assert np.max(np.abs(ta.avg[4] - want)) <= 1e-13 * np.max(np.abs(want)) and abs(ta.etime - 1.75) < 1e-15
