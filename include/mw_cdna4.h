@@ -225,6 +225,15 @@ int  mw_horizontal_sponge_apply(const mw_grid_t *g, double *const *fields6, cons
 int  mw_time_average_accumulate(const mw_grid_t *g, const double *const *fields6, double *const *avg6, double etime, double dt,
                                 void *stream);
 
+/* ---- surrogate workflow statistics ----------------------------------------- */
+/* custom_modules::StatisticsGatherer::gather_micro_statistics, experiments/supercell_kessler_surrogate/custom_modules/
+ * gather_micro_statistics.h:19-58: number of cells (ensemble member 0) whose temp / water_vapor / cloud_liquid /
+ * precip_liquid changed by more than 1e-10 across the microphysics call (is_active, :61-74).  in4 / out4: HOST arrays of 4
+ * DEVICE pointers (temp, water_vapor, cloud_liquid, precip_liquid) before / after; mask: optional DEVICE (nz,ny,nx) bytes
+ * (the `active` array, :40-52); *count: the sum the reference adds to `numer` (:56).  Integer, hence exact. */
+int  mw_micro_active_count(const mw_grid_t *g, const double *const *in4, const double *const *out4, unsigned char *mask,
+                           long long *count, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

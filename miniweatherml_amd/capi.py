@@ -91,6 +91,8 @@ SYMBOLS = {
                                    [C.c_int] * 4 + [C.c_void_p]),
     "mw_time_average_accumulate": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_double, C.c_double,
                                              C.c_void_p]),
+    "mw_micro_active_count": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_longlong),
+                                        C.c_void_p]),
     "mw_mlp_forward": (C.c_int, [C.c_longlong] + [C.c_void_p] * 5 + [C.POINTER(C.c_float)] * 4 +
                        [C.POINTER(C.c_double)] * 2 + [C.c_void_p] * 4 + [C.c_void_p]),
 }

@@ -67,6 +67,24 @@ __global__ __launch_bounds__(256) void k_time_average(Six f, Six avg, long long 
   avg.f[l][t] = inertia * avg.f[l][t] + (1 - inertia) * f.f[l][t];
 }
 
+// custom_modules::StatisticsGatherer::is_active, gather_micro_statistics.h:61-74 (member 0 only, :42-45)
+struct Eight { const double *a[8]; };
+__global__ __launch_bounds__(256) void k_active_count(Eight f, long long ncell, int nens, unsigned long long *count,
+                                                      unsigned char *__restrict__ mask) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  int act = 0;
+  if (t < ncell) {
+    const double tol = 1.e-10;
+    for (int v = 0; v < 4; v++) act |= (fabs(f.a[4 + v][t * nens] - f.a[v][t * nens]) > tol) ? 1 : 0;
+    if (mask) mask[t] = (unsigned char)act;
+  }
+  unsigned long long b = __ballot(act);
+  __shared__ int sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) { int n = sm[0] + sm[1] + sm[2] + sm[3]; if (n) atomicAdd(count, (unsigned long long)n); }
+}
+
 } // namespace mw
 
 using namespace mw;
@@ -126,6 +144,27 @@ int mw_horizontal_sponge_apply(const mw_grid_t *g, double *const *fields6, const
   hipLaunchKernelGGL(k_hsponge_apply, grid, dim3(256), 0, (hipStream_t)stream, f, g->nz, g->ny, g->nx, g->nens, sponge_cells, dt / time_scale,
                      x1, x2, y1, y2, column);
   MW_LAUNCH_CHECK();
+  return 0;
+}
+
+int mw_micro_active_count(const mw_grid_t *g, const double *const *in4, const double *const *out4, unsigned char *mask,
+                          long long *count, void *stream) {
+  if (!g || !in4 || !out4 || !count) MW_FAIL("micro_active_count: null argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  Eight f;
+  for (int v = 0; v < 4; v++) { if (!in4[v] || !out4[v]) MW_FAIL("micro_active_count: null field"); f.a[v] = in4[v]; f.a[4 + v] = out4[v]; }
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long *dev = nullptr, host = 0;
+  MW_HIP(hipMalloc(&dev, sizeof(unsigned long long)));
+  int rc = 0;
+  const long long ncell = (long long)g->nz * g->ny * g->nx;
+  if (hipMemsetAsync(dev, 0, sizeof(unsigned long long), st) != hipSuccess) rc = 1;
+  if (!rc) { hipLaunchKernelGGL(k_active_count, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, f, ncell, g->nens, dev, mask);
+             if (hipGetLastError() != hipSuccess) rc = 1; }
+  if (!rc && (hipMemcpyAsync(&host, dev, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = 1;
+  (void)hipFree(dev);
+  if (rc) MW_FAIL("micro_active_count: device operation failed");
+  *count = (long long)host;
   return 0;
 }
 

@@ -263,11 +263,13 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
     (void)hipMemcpy(dm.get<real>("hy_dens_cells").data(), hy_dens_cells.data(), hy_dens_cells.size() * 8, hipMemcpyHostToDevice);
     (void)hipMemcpy(dm.get<real>("hy_dens_theta_cells").data(), hy_dens_theta_cells.data(), hy_dens_theta_cells.size() * 8, hipMemcpyHostToDevice);
     etime = 0; num_out = 0;
+    if (out_freq >= 0.) output(coupler, etime);                                                                  // :1659
   }
-  void time_step(core::Coupler &coupler, real &dt_phys) {             // :81-198 (file output excluded)
+  void time_step(core::Coupler &coupler, real &dt_phys) {             // :81-198
     if (!h) endrun("dycore.time_step before init");
     mw_check(mw_dycore_time_step(h, f_rho, f_u, f_v, f_w, f_T, tracer_ptrs.data(), dt_phys));
     etime += dt_phys;
+    if (out_freq >= 0. && etime / out_freq >= num_out + 1) { output(coupler, etime); num_out++; }                  // :183-186
   }
   // output(coupler, etime), :2019-2191, shared-file branch: CDF-5 `<out_prefix>.nc`, dims x,y,z,t, one (t,z,y,x) double
   // variable per coupler field, ensemble member 0.  Single-process form (the ranks of a multi-process run order themselves

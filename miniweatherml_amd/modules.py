@@ -122,6 +122,8 @@ class Dynamics_Euler_Stratified_WenoFV:
         dm.register_and_allocate("hy_dens_theta_cells", "hydrostatic density*theta cell averages", (nz, nens)).copy_(torch.from_numpy(hy[1]))
         self.etime = 0.0
         self.num_out = 0
+        if self.out_freq >= 0.0:                                               # :1659: the initial state is record 0
+            self.output(coupler, self.etime)
 
     def _wrap(self, ptr, shape):
         """Zero-copy CUDA tensor over library-owned device memory."""
@@ -154,6 +156,9 @@ class Dynamics_Euler_Stratified_WenoFV:
         with torch.cuda.device(coupler.device):
             check(capi.lib().mw_dycore_time_step(self.h, *[_ptr(t) for t in self._fields], self._tracer_ptrs, float(dt_phys)))
         self.etime += dt_phys
+        if self.out_freq >= 0.0 and self.etime / self.out_freq >= self.num_out + 1:    # :183-186
+            self.output(coupler, self.etime)
+            self.num_out += 1
 
     # one compute_tendencies(state(coupler), dt) (:204-552): returns (state_tend, tracers_tend); fluxes via .fluxes()
     def compute_tendencies(self, coupler, dt):
@@ -261,6 +266,8 @@ class Microphysics_Kessler_Surrogate(Microphysics_Kessler):
     (microphysics_kessler_ponni.h:149-278).  The NN result is returned (and diffed) but not written back,
     exactly like the reference with lines :273-276 commented out."""
 
+    online = False        # True = the four deep_copy_to lines :273-276 un-commented: the NN result replaces Kessler's
+
     def init(self, coupler, weights_txt=None, in_scaling_txt=None, out_scaling_txt=None):
         super().init(coupler)
         self.W1, self.b1, self.W2, self.b2, self.scl_in, self.scl_out = load_surrogate_weights(weights_txt, in_scaling_txt,
@@ -274,6 +281,10 @@ class Microphysics_Kessler_Surrogate(Microphysics_Kessler):
         self._nn_out = mlp_forward(temp, rho_d, rho_v, rho_c, rho_r, self.W1, self.b1, self.W2, self.b2, self.scl_in, self.scl_out,
                                    self._nn_out)
         super().time_step(coupler, dt)
+        if self.online:                                                        # :273-276
+            self._diffs = self.mean_diffs(coupler)                             # (the prints of :266-269 come first)
+            for dst, src in zip((temp, rho_v, rho_c, rho_r), self._nn_out):
+                dst.copy_(src)
         return self._nn_out            # (temp_tmp, rho_v_tmp, rho_c_tmp, rho_r_tmp)
 
     def mean_diffs(self, coupler):
@@ -586,6 +597,49 @@ class Time_Averager:
             nc.put_field(nc.varid(n_), -1, coupler, dm.get("time_avg_" + n_))
         nc.close()
         barrier()
+
+
+class StatisticsGatherer:
+    """custom_modules::StatisticsGatherer, experiments/supercell_kessler_surrogate/custom_modules/gather_micro_statistics.h:9-90:
+    which share of the cells has active microphysics (input = the coupler cloned before micro.time_step, output = after)."""
+
+    def __init__(self):
+        self.numer, self.denom, self.num_out = 0.0, 0.0, 0
+        self.last_mask = None
+
+    def gather_micro_statistics(self, inp, out, dt, etime, keep_mask=False):    # :19-58
+        names = ("temp", "water_vapor", "cloud_liquid", "precip_liquid")
+        a = [inp.get_data_manager_readonly().get(n, True) for n in names]
+        b = [out.get_data_manager_readonly().get(n, True) for n in names]
+        mask = torch.empty((inp.get_nz(), inp.get_ny(), inp.get_nx()), dtype=torch.uint8, device=inp.device) if keep_mask else None
+        cnt = C.c_longlong(0)
+        with torch.cuda.device(inp.device):
+            check(capi.lib().mw_micro_active_count(C.byref(inp.grid), _field_ptr_array(a), _field_ptr_array(b),
+                                                   C.c_void_p(mask.data_ptr()) if keep_mask else None, C.byref(cnt), _stream_ptr(inp.device)))
+        self.last_mask = mask
+        if etime > (self.num_out + 1) * 200:                                   # :54
+            self.print(inp)
+            self.num_out += 1
+        self.numer += float(cnt.value)
+        self.denom += float(inp.get_nz() * inp.get_ny() * inp.get_nx())
+        return cnt.value
+
+    def ratio(self, coupler):                                                  # MPI_Reduce(SUM) of numer and denom, :77-86
+        import torch.distributed as dist
+        v = torch.tensor([self.numer, self.denom], dtype=torch.float64)
+        if coupler.get_nranks() > 1 and dist.is_initialized():
+            v = v.to(coupler.device) if dist.get_backend() != "gloo" else v
+            dist.all_reduce(v)
+            v = v.cpu()
+        return float(v[0] / v[1]) if float(v[1]) > 0 else float("nan")
+
+    def print(self, coupler):
+        r = self.ratio(coupler)
+        if coupler.is_mainproc():
+            print("*** Ratio Active ***:  %10.6e" % r, flush=True)
+
+    def finalize(self, coupler):                                               # :89
+        self.print(coupler)
 
 
 def use_rccl_exchange(dycore, coupler, group=None):

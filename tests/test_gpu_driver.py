@@ -1,0 +1,119 @@
+"""The YAML-driven drivers on the GPU: each reference main's call sequence gives exactly what the hand-written loop over the
+same modules gives; output cadence follows out_freq (dynamics_euler_stratified_wenofv.h:183-186, :1659)."""
+import os
+
+import numpy as np
+import pytest
+
+import cdf
+from util import gpu_fields
+
+pytestmark = pytest.mark.gpu
+
+YAML = """
+sim_time: {sim_time}
+nens   : {nens}
+nx_glob: {nx}
+ny_glob: {ny}
+nz     : {nz}
+xlen: {xlen}
+ylen: {ylen}
+zlen: {zlen}
+init_data: {init}
+out_prefix: {prefix}
+dt_gcm: 900
+dt_phys: 0.
+out_freq: {out_freq}
+{extra}
+"""
+
+
+def write_yaml(tmp_path, **kw):
+    d = dict(sim_time=1e9, nens=1, nx=24, ny=16, nz=12, xlen=12000., ylen=8000., zlen=20000., init="supercell",
+             prefix=str(tmp_path / "out"), out_freq=-1, extra="")
+    d.update(kw)
+    p = tmp_path / "input.yaml"
+    p.write_text(YAML.format(**d))
+    return str(p), d
+
+
+def test_supercell_example_equals_the_manual_loop_and_writes_records(mw, tmp_path):
+    from miniweatherml_amd import driver, modules
+    path, d = write_yaml(tmp_path, out_freq=1.5)
+    coupler, dycore, info = driver.run("supercell_example", path, max_steps=6, quiet=True)
+    c2, d2, m2, n2 = modules.make_supercell(24, 16, 12, 1, 12000., 8000., 20000., with_nudger=True)
+    for _ in range(6):
+        modules.supercell_step(c2, d2, m2, n2)
+    a, b = gpu_fields(coupler), gpu_fields(c2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    dt = dycore.compute_time_step(coupler)
+    assert info["steps"] == 6 and abs(info["etime"] - 6 * dt) < 1e-12
+    # record 0 at init, then one whenever etime/out_freq passes the next integer
+    expect = [0.0]
+    t, nout = 0.0, 0
+    for _ in range(6):
+        t += dt
+        if t / 1.5 >= nout + 1:
+            expect.append(t)
+            nout += 1
+    r = cdf.Reader(d["prefix"] + ".nc")
+    assert r.numrecs == len(expect) and np.allclose(r.get("t"), expect, rtol=0, atol=1e-12)
+    assert [v["name"] for v in r.vars][4:] == ["density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid", "precip_liquid"]
+
+
+def test_sim_time_clips_the_last_step(mw, tmp_path):
+    from miniweatherml_amd import driver
+    path, _ = write_yaml(tmp_path, sim_time=2.0)
+    coupler, dycore, info = driver.run("community_benchmark", path, quiet=True)
+    assert abs(info["etime"] - 2.0) < 1e-14 and abs(dycore.etime - 2.0) < 1e-12 and info["simulation_loop_s"] > 0
+    assert info["steps"] == int(np.ceil(2.0 / dycore.compute_time_step(coupler)))
+
+
+def test_simple_city_driver(mw, tmp_path, monkeypatch):
+    from miniweatherml_amd import driver, modules
+    monkeypatch.chdir(tmp_path)                                    # time_averaged_fields.nc goes to the working directory
+    path, d = write_yaml(tmp_path, nx=40, ny=40, nz=16, xlen=200., ylen=200., zlen=80., init="building", extra="enable_gravity: false")
+    coupler, dycore, info = driver.run("simple_city", path, max_steps=3, quiet=True)
+    c2, d2, hs, ta = modules.make_simple_city(40, 40, 16, 1, 200., 200., 80., "building")
+    for _ in range(3):
+        modules.simple_city_step(c2, d2, hs, ta)
+    a, b = gpu_fields(coupler), gpu_fields(c2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    r = cdf.Reader(str(tmp_path / "time_averaged_fields.nc"))
+    g = c2.get_data_manager_readonly().get("time_avg_uvel", True).cpu().numpy()[..., 0]
+    assert np.array_equal(r.get("uvel"), g)
+
+
+def test_surrogate_drivers(mw, tmp_path):
+    from miniweatherml_amd import driver
+    path, _ = write_yaml(tmp_path, nx=32, ny=1, nz=20, xlen=32000., extra='keras_weights_h5: "./inputs/examples/x.h5"')
+    coupler, dycore, info = driver.run("inference_ponni", path, max_steps=3, quiet=True)
+    assert info["steps"] == 3 and np.isfinite(gpu_fields(coupler)["temp"]).all()
+    coupler, dycore, info = driver.run("gather_statistics", path, max_steps=4, quiet=True)
+    assert 0.0 <= info["ratio_active"] <= 1.0
+
+
+def test_statistics_gatherer_counts_exactly(mw):
+    """is_active (gather_micro_statistics.h:61-74): integer count == the same predicate evaluated with torch on the host."""
+    import torch
+    from miniweatherml_amd import modules
+    from miniweatherml_amd.coupler import Coupler
+    coupler, dycore, micro = modules.make_supercell(20, 12, 10, 2, 10000., 6000., 20000.)
+    dm = coupler.get_data_manager_readwrite()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rho_d = dm.get("density_dry")
+    dm.get("cloud_liquid").copy_(2e-3 * rho_d * (torch.rand(rho_d.shape, generator=g, device="cuda") > 0.7))
+    dm.get("precip_liquid").copy_(3e-4 * rho_d * (torch.rand(rho_d.shape, generator=g, device="cuda") > 0.8))
+    inp = Coupler("cuda:0")
+    coupler.clone_into(inp)
+    micro.time_step(coupler, 2.0)
+    st = modules.StatisticsGatherer()
+    n = st.gather_micro_statistics(inp, coupler, 2.0, 0.0, keep_mask=True)
+    act = torch.zeros(rho_d.shape[:3], dtype=torch.bool, device="cuda")
+    for name in ("temp", "water_vapor", "cloud_liquid", "precip_liquid"):
+        act |= (coupler.get_data_manager_readonly().get(name, True)[..., 0] - inp.get_data_manager_readonly().get(name, True)[..., 0]).abs() > 1e-10
+    assert n == int(act.sum()) and 0 < n < act.numel()
+    assert torch.equal(st.last_mask.bool(), act)
+    assert st.numer == float(n) and st.denom == float(act.numel()) and abs(st.ratio(coupler) - n / act.numel()) < 1e-15
