@@ -199,11 +199,14 @@ typedef struct mw_nc_s *mw_nc_t;
 int  mw_nc_create(mw_nc_t *nc, const char *path, int format, long long header_align, long long var_align);   /* nc.create        */
 int  mw_nc_def_dim(mw_nc_t nc, const char *name, long long len, int *dimid);          /* create_dim; len 0 = create_unlim_dim   */
 int  mw_nc_def_var(mw_nc_t nc, const char *name, int ndims, const int *dimids, int *varid);   /* create_var<real>               */
+/* nc_type 4 = int, 5 = float, 6 = double (the surrogate sample files hold floats and one int, generate_micro_surrogate_data.h) */
+int  mw_nc_def_var_typed(mw_nc_t nc, const char *name, int nc_type, int ndims, const int *dimids, int *varid);
 int  mw_nc_enddef(mw_nc_t nc);                                                         /* nc.enddef: lays out + writes header    */
 int  mw_nc_open(mw_nc_t *nc, const char *path);                                        /* nc.open (read-write)                   */
 int  mw_nc_inq_varid(mw_nc_t nc, const char *name, int *varid);
 int  mw_nc_inq_dimlen(mw_nc_t nc, const char *name, long long *len);                   /* get_dim_size; record dim: # records    */
 int  mw_nc_put_vara_double(mw_nc_t nc, int varid, const long long *start, const long long *count, const double *host_data);
+int  mw_nc_put_vara(mw_nc_t nc, int varid, const long long *start, const long long *count, const void *host_data);   /* variable's own type */
 int  mw_nc_set_numrecs(mw_nc_t nc, long long numrecs);
 int  mw_nc_close(mw_nc_t nc);
 /* The body of Dynamics_Euler_Stratified_WenoFV::output's variable loop, :2176-2185 (and Time_Averager::finalize's,
@@ -233,6 +236,16 @@ int  mw_time_average_accumulate(const mw_grid_t *g, const double *const *fields6
  * (the `active` array, :40-52); *count: the sum the reference adds to `numer` (:56).  Integer, hence exact. */
 int  mw_micro_active_count(const mw_grid_t *g, const double *const *in4, const double *const *out4, unsigned char *mask,
                            long long *count, void *stream);
+/* custom_modules::DataGenerator::generate_samples_stencil, .../generate_micro_surrogate_data.h:35-153, device parts.
+ * mw_micro_sample_mask: mask[k,j,i] (DEVICE bytes) = u01(key0 + k*ny*nx + j*nx + i) < (is_active ? thr_active : thr_inactive),
+ * :83-101; key0 = (seed + myrank)*nz*ny*nx as in the reference; u01 = splitmix64 (yakl::Random is not available).
+ * mw_micro_gather_samples: for the n cell indices `cells` (DEVICE int64, k*ny*nx + j*nx + i, member 0) fills inputs (n,5,2) and
+ * outputs (n,4) (DEVICE fp32) exactly as :139-156 (inputs: temp, density_dry, water_vapor, cloud_liquid, precip_liquid at k;
+ * slot 1 as assigned there at min(nz-1,k+1); outputs: temp, water_vapor, cloud_liquid, precip_liquid after micro). */
+int  mw_micro_sample_mask(const mw_grid_t *g, const double *const *in4, const double *const *out4, unsigned long long key0,
+                          double thr_active, double thr_inactive, unsigned char *mask, void *stream);
+int  mw_micro_gather_samples(const mw_grid_t *g, const double *rho_d, const double *const *in4, const double *const *out4,
+                             const long long *cells, long long n, float *inputs, float *outputs, void *stream);
 
 #ifdef __cplusplus
 }

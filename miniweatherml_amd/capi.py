@@ -78,6 +78,8 @@ SYMBOLS = {
     "mw_nc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_longlong, C.c_longlong]),
     "mw_nc_def_dim": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong, C.POINTER(C.c_int)]),
     "mw_nc_def_var": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mw_nc_def_var_typed": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mw_nc_put_vara": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_void_p]),
     "mw_nc_enddef": (C.c_int, [C.c_void_p]),
     "mw_nc_open": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p]),
     "mw_nc_inq_varid": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
@@ -93,6 +95,10 @@ SYMBOLS = {
                                              C.c_void_p]),
     "mw_micro_active_count": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_longlong),
                                         C.c_void_p]),
+    "mw_micro_sample_mask": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_ulonglong, C.c_double, C.c_double,
+                                       C.c_void_p, C.c_void_p]),
+    "mw_micro_gather_samples": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_longlong,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "mw_mlp_forward": (C.c_int, [C.c_longlong] + [C.c_void_p] * 5 + [C.POINTER(C.c_float)] * 4 +
                        [C.POINTER(C.c_double)] * 2 + [C.c_void_p] * 4 + [C.c_void_p]),
 }

@@ -15,7 +15,7 @@
 //   nelems, ndims, dimid, length, vsize are INT32 [INT64 in CDF-5]
 //   data     = fixed-size variables at their `begin`, then the records: record r holds, for every record variable in
 //              definition order, that variable's slab r (vsize bytes) at begin + r * recsize.
-// Only double variables and no attributes are written -- which is all the reference writes.
+// Only int / float / double variables and no attributes are written -- which is all the reference writes.
 // =====================================================================================================
 #include "../../include/mw_cdna4.h"
 #include "mw_common.h"
@@ -32,7 +32,8 @@ using mw::set_error;
 namespace {
 
 struct Dim { std::string name; long long len; };
-struct Var { std::string name; std::vector<int> dims; long long vsize = 0, begin = 0; bool rec = false; };
+struct Var { std::string name; std::vector<int> dims; long long vsize = 0, begin = 0; bool rec = false; int type = 6;
+             int esize() const { return type == 6 ? 8 : 4; } };       // nc_type: 4 = NC_INT, 5 = NC_FLOAT, 6 = NC_DOUBLE
 
 uint64_t be64(uint64_t v) { return __builtin_bswap64(v); }
 uint32_t be32(uint32_t v) { return __builtin_bswap32(v); }
@@ -70,7 +71,7 @@ struct mw_nc_s {
         putn(b, (long long)v.dims.size());
         for (int d : v.dims) putn(b, d);
         put32(b, 0); putn(b, 0);                                   // no variable attributes
-        put32(b, 6);                                               // NC_DOUBLE
+        put32(b, (uint32_t)v.type);                                // nc_type
         putn(b, v.vsize);
         put64(b, (uint64_t)v.begin);
       }
@@ -126,10 +127,11 @@ int mw_nc_def_dim(mw_nc_t nc, const char *name, long long len, int *dimid) {
   return 0;
 }
 
-int mw_nc_def_var(mw_nc_t nc, const char *name, int ndims, const int *dimids, int *varid) {
+int mw_nc_def_var_typed(mw_nc_t nc, const char *name, int nc_type, int ndims, const int *dimids, int *varid) {
   if (!nc || !name || !varid || (ndims > 0 && !dimids)) MW_FAIL("nc_def_var: null argument");
   if (!nc->defining) MW_FAIL("nc_def_var: not in define mode");
-  Var v; v.name = name;
+  if (nc_type != 4 && nc_type != 5 && nc_type != 6) MW_FAIL("nc_def_var: nc_type must be 4 (int), 5 (float) or 6 (double)");
+  Var v; v.name = name; v.type = nc_type;
   for (int i = 0; i < ndims; i++) {
     if (dimids[i] < 0 || dimids[i] >= (int)nc->dims.size()) MW_FAIL("nc_def_var: bad dimension id");
     if (nc->dims[dimids[i]].len == 0) { if (i != 0) MW_FAIL("nc_def_var: the record dimension must come first"); v.rec = true; }
@@ -140,11 +142,15 @@ int mw_nc_def_var(mw_nc_t nc, const char *name, int ndims, const int *dimids, in
   return 0;
 }
 
+int mw_nc_def_var(mw_nc_t nc, const char *name, int ndims, const int *dimids, int *varid) {
+  return mw_nc_def_var_typed(nc, name, 6, ndims, dimids, varid);
+}
+
 int mw_nc_enddef(mw_nc_t nc) {
   if (!nc) MW_FAIL("nc_enddef: null handle");
   if (!nc->defining) MW_FAIL("nc_enddef: not in define mode");
   for (auto &v : nc->vars) {
-    long long n = 8;
+    long long n = v.esize();
     for (int d : v.dims) if (nc->dims[d].len > 0) n *= nc->dims[d].len;
     v.vsize = round_up(n, 4);
     if (nc->format == 2 && v.vsize > 0xFFFFFFFFll) MW_FAIL("nc_enddef: variable too large for CDF-2; use format 5");
@@ -196,7 +202,8 @@ int mw_nc_open(mw_nc_t *out, const char *path) {
     for (long long k = 0; k < nd && !bad; k++) { int d = (int)getn(); if (d < 0 || d >= (int)nc->dims.size()) bad = true; else v.dims.push_back(d); }
     long long atag = get32(), an = getn();
     if (atag != 0 || an != 0) return fail("nc_open: files with attributes are not supported");
-    if (get32() != 6) return fail("nc_open: only double variables are supported");
+    v.type = (int)get32();
+    if (v.type != 4 && v.type != 5 && v.type != 6) return fail("nc_open: only int, float and double variables are supported");
     v.vsize = getn(); v.begin = get64();
     v.rec = !v.dims.empty() && nc->dims[v.dims[0]].len == 0;
     nc->vars.push_back(v);
@@ -230,13 +237,15 @@ int mw_nc_inq_dimlen(mw_nc_t nc, const char *name, long long *len) {
   MW_FAIL("nc_inq_dimlen: no such dimension");
 }
 
-// Writes the hyperslab start[], count[] (one entry per dimension of the variable) from HOST doubles (C order).
-int mw_nc_put_vara_double(mw_nc_t nc, int varid, const long long *start, const long long *count, const double *data) {
-  if (!nc || !start || !count || !data) MW_FAIL("nc_put_vara: null argument");
+// Writes the hyperslab start[], count[] (one entry per dimension of the variable) from HOST data of the variable's own type
+// (C order); values are byte-swapped to big-endian on the way.
+int mw_nc_put_vara(mw_nc_t nc, int varid, const long long *start, const long long *count, const void *data) {
+  if (!nc || !data) MW_FAIL("nc_put_vara: null argument");
   if (nc->defining) MW_FAIL("nc_put_vara: still in define mode");
   if (varid < 0 || varid >= (int)nc->vars.size()) MW_FAIL("nc_put_vara: bad variable id");
   const Var &v = nc->vars[varid];
-  const int nd = (int)v.dims.size();
+  const int nd = (int)v.dims.size(), es = v.esize();
+  if (nd > 0 && (!start || !count)) MW_FAIL("nc_put_vara: null argument");
   std::vector<long long> len(nd), stride(nd);
   for (int i = 0; i < nd; i++) {
     len[i] = nc->dims[v.dims[i]].len;
@@ -249,22 +258,29 @@ int mw_nc_put_vara_double(mw_nc_t nc, int varid, const long long *start, const l
   long long acc = 1;
   for (int i = nd - 1; i >= 0; i--) { stride[i] = acc; if (!(v.rec && i == 0)) acc *= len[i]; }
   const long long row = nd ? count[nd - 1] : 1;                      // contiguous run in the file
-  nc->swapbuf.resize((size_t)row * 8);
+  nc->swapbuf.resize((size_t)row * es);
   std::vector<long long> idx(nd, 0);
-  const double *src = data;
+  const unsigned char *src = (const unsigned char *)data;
   for (long long done = 0; done < total; done += row) {
     long long off = v.begin;
     for (int i = 0; i < nd; i++) {
       const long long c = start[i] + idx[i];
-      off += (v.rec && i == 0) ? c * nc->recsize : c * stride[i] * 8;
+      off += (v.rec && i == 0) ? c * nc->recsize : c * stride[i] * es;
     }
-    uint64_t *sb = (uint64_t *)nc->swapbuf.data();
-    for (long long r = 0; r < row; r++) { uint64_t u; memcpy(&u, src + r, 8); sb[r] = be64(u); }
-    if (pwrite_all(nc->fd, sb, (size_t)row * 8, off)) MW_FAIL("nc_put_vara: write failed");
-    src += row;
+    if (es == 8) { uint64_t *sb = (uint64_t *)nc->swapbuf.data();
+                   for (long long r = 0; r < row; r++) { uint64_t u; memcpy(&u, src + r * 8, 8); sb[r] = be64(u); } }
+    else         { uint32_t *sb = (uint32_t *)nc->swapbuf.data();
+                   for (long long r = 0; r < row; r++) { uint32_t u; memcpy(&u, src + r * 4, 4); sb[r] = be32(u); } }
+    if (pwrite_all(nc->fd, nc->swapbuf.data(), (size_t)row * es, off)) MW_FAIL("nc_put_vara: write failed");
+    src += row * es;
     for (int i = nd - 2; i >= 0; i--) { if (++idx[i] < count[i]) break; idx[i] = 0; }
   }
   return 0;
+}
+
+int mw_nc_put_vara_double(mw_nc_t nc, int varid, const long long *start, const long long *count, const double *data) {
+  if (nc && varid >= 0 && varid < (int)nc->vars.size() && nc->vars[varid].type != 6) MW_FAIL("nc_put_vara_double: not a double variable");
+  return mw_nc_put_vara(nc, varid, start, count, data);
 }
 
 // Sets the record count in the header (the creating / main rank calls this after a record has been written).

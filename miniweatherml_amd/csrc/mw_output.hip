@@ -85,6 +85,45 @@ __global__ __launch_bounds__(256) void k_active_count(Eight f, long long ncell, 
   if (threadIdx.x == 0) { int n = sm[0] + sm[1] + sm[2] + sm[3]; if (n) atomicAdd(count, (unsigned long long)n); }
 }
 
+// custom_modules::DataGenerator::generate_samples_stencil, generate_micro_surrogate_data.h:83-101: which cells to sample.
+// The reference draws yakl::Random(key).genFP<double>() with key = (seed+myrank)*nz*ny*nx + k*ny*nx + j*nx + i; YAKL's generator
+// is not available, so the same key goes through the splitmix64 finaliser (53 random bits -> [0,1)).
+__device__ __forceinline__ double u01_from_key(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+__global__ __launch_bounds__(256) void k_sample_mask(Eight f, long long ncell, int nens, unsigned long long key0, double thr_active,
+                                                     double thr_inactive, unsigned char *__restrict__ mask) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= ncell) return;
+  const double tol = 1.e-10;
+  int act = 0;
+  for (int v = 0; v < 4; v++) act |= (fabs(f.a[4 + v][t * nens] - f.a[v][t * nens]) > tol) ? 1 : 0;
+  const double thresh = act ? thr_active : thr_inactive;
+  mask[t] = u01_from_key(key0 + (unsigned long long)t) < thresh ? 1 : 0;
+}
+// :139-160: one sample = inputs (5 variables x 2-cell vertical stencil) + outputs (4), fp32.  Stencil slot 1 reproduces the
+// reference's assignments (:147-150): (0,1) temp(k+1), (1,1) rho_v(k+1), (2,1) rho_c(k+1), (3,1) rho_p(k+1); (4,1) is never
+// assigned there (uninitialised host memory) and is written as 0 here.
+__global__ __launch_bounds__(256) void k_gather_samples(const double *__restrict__ rho_d, Eight f, const long long *__restrict__ cells,
+                                                        long long n, int nz, long long plane, int nens, float *__restrict__ inputs,
+                                                        float *__restrict__ outputs) {
+  long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  const long long c = cells[s];
+  const int k = (int)(c / plane);
+  const long long up = (k + 1 < nz ? c + plane : c);            // min(nz-1, k+1)
+  float *in = inputs + s * 10, *out = outputs + s * 4;
+  in[0] = (float)f.a[0][c * nens];  in[2] = (float)rho_d[c * nens];  in[4] = (float)f.a[1][c * nens];
+  in[6] = (float)f.a[2][c * nens];  in[8] = (float)f.a[3][c * nens];
+  in[1] = (float)f.a[0][up * nens]; in[3] = (float)f.a[1][up * nens]; in[5] = (float)f.a[2][up * nens];
+  in[7] = (float)f.a[3][up * nens]; in[9] = 0.0f;
+  for (int v = 0; v < 4; v++) out[v] = (float)f.a[4 + v][c * nens];
+}
+
 } // namespace mw
 
 using namespace mw;
@@ -165,6 +204,32 @@ int mw_micro_active_count(const mw_grid_t *g, const double *const *in4, const do
   (void)hipFree(dev);
   if (rc) MW_FAIL("micro_active_count: device operation failed");
   *count = (long long)host;
+  return 0;
+}
+
+int mw_micro_sample_mask(const mw_grid_t *g, const double *const *in4, const double *const *out4, unsigned long long key0,
+                         double thr_active, double thr_inactive, unsigned char *mask, void *stream) {
+  if (!g || !in4 || !out4 || !mask) MW_FAIL("micro_sample_mask: null argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  Eight f;
+  for (int v = 0; v < 4; v++) { if (!in4[v] || !out4[v]) MW_FAIL("micro_sample_mask: null field"); f.a[v] = in4[v]; f.a[4 + v] = out4[v]; }
+  const long long ncell = (long long)g->nz * g->ny * g->nx;
+  hipLaunchKernelGGL(k_sample_mask, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, (hipStream_t)stream, f, ncell, g->nens, key0,
+                     thr_active, thr_inactive, mask);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+int mw_micro_gather_samples(const mw_grid_t *g, const double *rho_d, const double *const *in4, const double *const *out4,
+                            const long long *cells, long long n, float *inputs, float *outputs, void *stream) {
+  if (!g || !rho_d || !in4 || !out4 || (n > 0 && (!cells || !inputs || !outputs))) MW_FAIL("micro_gather_samples: null argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  if (n <= 0) return 0;
+  Eight f;
+  for (int v = 0; v < 4; v++) { if (!in4[v] || !out4[v]) MW_FAIL("micro_gather_samples: null field"); f.a[v] = in4[v]; f.a[4 + v] = out4[v]; }
+  hipLaunchKernelGGL(k_gather_samples, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rho_d, f, cells, n, g->nz,
+                     (long long)g->ny * g->nx, g->nens, inputs, outputs);
+  MW_LAUNCH_CHECK();
   return 0;
 }
 

@@ -9,6 +9,7 @@ community_benchmark   experiments/community_benchmark/driver.cpp:12-92          
 simple_city           experiments/simple_city/driver.cpp:9-88                           horiz. sponge, dycore, sponge_layer(dt,1), averager
 inference_ponni       experiments/supercell_kessler_surrogate/inference_ponni.cpp        dycore, NN + Kessler, sponge, nudger
 gather_statistics     experiments/supercell_kessler_surrogate/gather_statistics.cpp      dycore, Kessler (+ active-cell ratio), sponge, nudger
+generate_micro_data   experiments/supercell_kessler_surrogate/generate_micro_data.cpp    dycore, Kessler (+ training samples), sponge, nudger
 
 The YAML keys are the reference's (sim_time, nens, nx_glob, ny_glob, nz, xlen, ylen, zlen, dt_phys, out_prefix, init_data,
 out_freq, enable_gravity, file_per_process; keras_weights_h5 / nn_input_scaling / nn_output_scaling for the surrogate).  The
@@ -22,7 +23,7 @@ import time
 
 import yaml
 
-EXPERIMENTS = ("supercell_example", "community_benchmark", "simple_city", "inference_ponni", "gather_statistics")
+EXPERIMENTS = ("supercell_example", "community_benchmark", "simple_city", "inference_ponni", "gather_statistics", "generate_micro_data")
 
 
 def load_config(path):
@@ -150,17 +151,25 @@ def run(experiment, yaml_path, max_steps=None, device="cuda:0", quiet=False):
         _exchange(dycore, coupler)
         column_nudger.set_column(coupler)                                      # :60
         modules.perturb_temperature(coupler)                                   # :61
+        from .coupler import Coupler
+        datagen = None
         if experiment == "gather_statistics":
-            from .coupler import Coupler
             stats = modules.StatisticsGatherer()
+        if experiment == "generate_micro_data":
+            datagen = modules.DataGenerator()
+            datagen.init(coupler, os.getcwd())                                 # generate_micro_data.cpp:66
+            info["samples"] = 0
 
         def body(dt, etime):                                                   # :73-76
             dycore.time_step(coupler, dt)
-            if stats is not None:
+            if stats is not None or datagen is not None:
                 inp = Coupler(device)
                 coupler.clone_into(inp)                                        # gather_statistics.cpp:79-80
                 micro.time_step(coupler, dt)
-                stats.gather_micro_statistics(inp, coupler, dt, etime)
+                if stats is not None:
+                    stats.gather_micro_statistics(inp, coupler, dt, etime)
+                else:
+                    info["samples"] += datagen.generate_samples_stencil(inp, coupler, dt, etime)
             else:
                 micro.time_step(coupler, dt)
                 if experiment == "inference_ponni" and not quiet and coupler.is_mainproc():

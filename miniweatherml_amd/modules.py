@@ -434,6 +434,19 @@ class _NcFile:
         check(capi.lib().mw_nc_inq_dimlen(self.h, name.encode(), C.byref(n)))
         return n.value
 
+    def def_var_typed(self, name, nc_type, dims):
+        v = C.c_int(-1)
+        arr = (C.c_int * max(1, len(dims)))(*dims)
+        check(capi.lib().mw_nc_def_var_typed(self.h, name.encode(), nc_type, len(dims), arr, C.byref(v)))
+        return v.value
+
+    def put_typed(self, varid, start, count, data):
+        """data: a contiguous numpy array of the variable's own type (int32 / float32 / float64)."""
+        data = np.ascontiguousarray(data)
+        st = (C.c_longlong * max(1, len(start)))(*start)
+        ct = (C.c_longlong * max(1, len(count)))(*count)
+        check(capi.lib().mw_nc_put_vara(self.h, varid, st, ct, data.ctypes.data_as(C.c_void_p)))
+
     def put(self, varid, start, count, data):
         data = np.ascontiguousarray(data, dtype=np.float64)
         st = (C.c_longlong * max(1, len(start)))(*start)
@@ -640,6 +653,79 @@ class StatisticsGatherer:
 
     def finalize(self, coupler):                                               # :89
         self.print(coupler)
+
+
+class DataGenerator:
+    """custom_modules::DataGenerator, experiments/supercell_kessler_surrogate/custom_modules/generate_micro_surrogate_data.h:11-156:
+    samples (5 inputs x 2-cell vertical stencil, 4 outputs; fp32) of the microphysics' effect, about half of them from active
+    cells, appended to one file per rank.  The file is classic netCDF (CDF-5) instead of the reference's NetCDF-4 container, all
+    variables are defined when it is created, and the random numbers come from splitmix64 (include/mw_cdna4.h)."""
+
+    ratio_active = 0.4                       # :47-49 (from gather_statistics)
+    desired_samples_per_time_step = 50.0     # :53
+    desired_ratio_active = 0.5               # :55
+
+    def init(self, coupler, directory="."):                                    # :17-33
+        self.fname = os.path.join(directory, "supercell_kessler_data_task_%d.nc" % coupler.get_myrank())
+        nc = _NcFile(self.fname, True, 5)
+        ds, dvi, dst, dvo = nc.def_dim("nsamples", 0), nc.def_dim("num_vars_in", 5), nc.def_dim("sten_size", 2), nc.def_dim("num_vars_out", 4)
+        for n in ("time_step_size", "dx", "dy", "dz", "xlen", "ylen", "zlen"):
+            nc.def_var_typed(n, 6, [])
+        nc.def_var_typed("only_two_dimensions", 4, [])
+        nc.def_var_typed("inputs", 5, [ds, dvi, dst])
+        nc.def_var_typed("outputs", 5, [ds, dvo])
+        nc.enddef()
+        nc.close()
+        self._meta_written = False
+        if coupler.is_mainproc():
+            with open(os.path.join(directory, "supercell_kessler_metadata.txt"), "w") as f:
+                f.write("This dataset contains data for training a surrogate model to emulate Kessler microphysics.\n\n"
+                        "vars_in : temperature, dry air density, water vapor density, cloud liquid density, precipitation density\n"
+                        "vars_out: temperature, water vapor density, cloud liquid density, precipitation density\n")
+
+    def generate_samples_stencil(self, inp, out, dt, etime, seed=None):        # :35-153
+        import time as _time
+        nx, ny, nz, nranks, myrank = inp.get_nx(), inp.get_ny(), inp.get_nz(), inp.get_nranks(), inp.get_myrank()
+        ncell = nx * ny * nz
+        want_act = self.desired_ratio_active * self.desired_samples_per_time_step / nranks          # :58-59
+        want_inact = (1 - self.desired_ratio_active) * self.desired_samples_per_time_step / nranks
+        thr_act = want_act / (self.ratio_active * ncell)                                             # :61-62
+        thr_inact = want_inact / ((1 - self.ratio_active) * ncell)
+        max_mag = (2 ** 64 - 1) // (nranks + ncell)                                                  # :84-85
+        seed = (int(_time.time()) if seed is None else int(seed)) % max_mag
+        key0 = ((seed + myrank) * ncell) % (2 ** 64)
+        names = ("temp", "water_vapor", "cloud_liquid", "precip_liquid")
+        a = [inp.get_data_manager_readonly().get(n, True) for n in names]
+        b = [out.get_data_manager_readonly().get(n, True) for n in names]
+        rho_d = inp.get_data_manager_readonly().get("density_dry", True)
+        dev = inp.device
+        mask = torch.empty(ncell, dtype=torch.uint8, device=dev)
+        L = capi.lib()
+        with torch.cuda.device(dev):
+            check(L.mw_micro_sample_mask(C.byref(inp.grid), _field_ptr_array(a), _field_ptr_array(b), key0, thr_act, thr_inact,
+                                         C.c_void_p(mask.data_ptr()), _stream_ptr(dev)))
+            cells = torch.nonzero(mask).flatten().contiguous()                 # ascending = the reference's (k,j,i) loop order
+            n = int(cells.numel())
+            ins = torch.empty((n, 5, 2), dtype=torch.float32, device=dev)
+            outs = torch.empty((n, 4), dtype=torch.float32, device=dev)
+            check(L.mw_micro_gather_samples(C.byref(inp.grid), _ptr(rho_d), _field_ptr_array(a), _field_ptr_array(b),
+                                            C.c_void_p(cells.data_ptr()), n, C.c_void_p(ins.data_ptr()), C.c_void_p(outs.data_ptr()),
+                                            _stream_ptr(dev)))
+        self.last_cells = cells.cpu().numpy()                                 # k*ny*nx + j*nx + i of the samples (diagnostic)
+        nc = _NcFile(self.fname, False)
+        ul = nc.dimlen("nsamples")                                             # :116
+        if not self._meta_written:                                             # :118-125 (`if (!nc.varExists(..)) nc.write(..)`)
+            for name, val in (("time_step_size", dt), ("dx", inp.get_dx()), ("dy", inp.get_dy()), ("dz", inp.get_dz()),
+                              ("xlen", inp.get_xlen()), ("ylen", inp.get_ylen()), ("zlen", inp.get_zlen())):
+                nc.put_typed(nc.varid(name), [], [], np.array([val], dtype=np.float64))
+            nc.put_typed(nc.varid("only_two_dimensions"), [], [], np.array([0 if inp.get_ny_glob() == 1 else 1], dtype=np.int32))
+            self._meta_written = True
+        if n:
+            nc.put_typed(nc.varid("inputs"), [ul, 0, 0], [n, 5, 2], ins.cpu().numpy())
+            nc.put_typed(nc.varid("outputs"), [ul, 0], [n, 4], outs.cpu().numpy())
+            nc.set_numrecs(ul + n)
+        nc.close()
+        return n
 
 
 def use_rccl_exchange(dycore, coupler, group=None):

@@ -137,3 +137,51 @@ def test_errors(L, tmp_path):
     with pytest.raises(MWError):
         check(L.mw_nc_put_vara_double(nc, v.value, (C.c_longlong * 1)(2), (C.c_longlong * 1)(4), buf.ctypes.data_as(C.c_void_p)))   # out of range
     check(L.mw_nc_close(nc))
+
+
+@pytest.mark.parametrize("fmt", [2, 5])
+def test_typed_variables_and_scalars(L, tmp_path, fmt):
+    """The surrogate sample files: float record variables, double scalars, one int scalar (generate_micro_surrogate_data.h)."""
+    from miniweatherml_amd.capi import MWError, check
+    path = str(tmp_path / "typed.nc")
+    nc = C.c_void_p()
+    check(L.mw_nc_create(C.byref(nc), path.encode(), fmt, 0, 0))
+    ids = {}
+    for n, ln in (("nsamples", 0), ("num_vars_in", 5), ("sten_size", 2), ("num_vars_out", 4)):
+        d = C.c_int()
+        check(L.mw_nc_def_dim(nc, n.encode(), ln, C.byref(d)))
+        ids[n] = d.value
+    v = C.c_int()
+    vid = {}
+    for name, ty, dims in (("dx", 6, []), ("only_two_dimensions", 4, []), ("inputs", 5, [ids["nsamples"], ids["num_vars_in"], ids["sten_size"]]),
+                           ("outputs", 5, [ids["nsamples"], ids["num_vars_out"]])):
+        check(L.mw_nc_def_var_typed(nc, name.encode(), ty, len(dims), (C.c_int * max(1, len(dims)))(*dims), C.byref(v)))
+        vid[name] = v.value
+    with pytest.raises(MWError):
+        check(L.mw_nc_def_var_typed(nc, b"bad", 2, 0, (C.c_int * 1)(0), C.byref(v)))                 # NC_CHAR is not provided
+    check(L.mw_nc_enddef(nc))
+    rng = np.random.default_rng(8)
+    ins, outs = rng.normal(size=(7, 5, 2)).astype(np.float32), rng.normal(size=(7, 4)).astype(np.float32)
+
+    def put(name, start, count, arr):
+        check(L.mw_nc_put_vara(nc, vid[name], (C.c_longlong * max(1, len(start)))(*start), (C.c_longlong * max(1, len(count)))(*count),
+                               arr.ctypes.data_as(C.c_void_p)))
+    put("dx", [], [], np.array([250.0]))
+    put("only_two_dimensions", [], [], np.array([1], dtype=np.int32))
+    put("inputs", [0, 0, 0], [4, 5, 2], ins[:4]); put("outputs", [0, 0], [4, 4], outs[:4])
+    check(L.mw_nc_set_numrecs(nc, 4))
+    put("inputs", [4, 0, 0], [3, 5, 2], ins[4:]); put("outputs", [4, 0], [3, 4], outs[4:])        # a later time step appends
+    check(L.mw_nc_set_numrecs(nc, 7))
+    with pytest.raises(MWError):
+        check(L.mw_nc_put_vara_double(nc, vid["inputs"], (C.c_longlong * 3)(0, 0, 0), (C.c_longlong * 3)(1, 5, 2), np.zeros(10).ctypes.data_as(C.c_void_p)))
+    check(L.mw_nc_close(nc))
+    r = cdf.Reader(path)
+    assert r.numrecs == 7 and [(v["name"], v["type"]) for v in r.vars] == [("dx", 6), ("only_two_dimensions", 4), ("inputs", 5), ("outputs", 5)]
+    assert r.get("dx") == 250.0 and r.get("only_two_dimensions") == 1
+    assert np.array_equal(r.get("inputs"), ins) and np.array_equal(r.get("outputs"), outs)
+    if fmt == 2:
+        scipy_io = pytest.importorskip("scipy.io")
+        f = scipy_io.netcdf_file(path, "r", mmap=False)
+        assert np.array_equal(f.variables["inputs"][:], ins) and np.array_equal(f.variables["outputs"][:], outs)
+        assert f.variables["only_two_dimensions"].getValue() == 1 and f.variables["dx"].getValue() == 250.0
+        f.close()
