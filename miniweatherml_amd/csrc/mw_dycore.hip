@@ -110,9 +110,8 @@ __global__ __launch_bounds__(256) void k_coupler_to_state(DyP p, CouplerPtrs c, 
 // Regions: 0 = x halos (k,j interior), 1 = y halos (k,i interior), 2 = z halos (j,i interior); corners are
 // never read.  `do_x`/`do_y` = 0 when that direction's halos come from a neighbour.
 // -----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_halo_x(DyP p, double *__restrict__ S) {
+__device__ __forceinline__ void halo_x_body(const DyP &p, double *__restrict__ S, long long t) {
   // threads: (v, k, j, h in [0,2HX), e)
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   int H2 = 2 * p.HX;
   long long n = (long long)p.V * p.nz * p.ny * H2 * p.nens;
   if (t >= n) return;
@@ -133,9 +132,8 @@ __global__ __launch_bounds__(256) void k_halo_x(DyP p, double *__restrict__ S) {
   }
   row[(long long)ih * p.nens] = val;
 }
-__global__ __launch_bounds__(256) void k_halo_y(DyP p, double *__restrict__ S) {
+__device__ __forceinline__ void halo_y_body(const DyP &p, double *__restrict__ S, long long t) {
   // threads: (v, k, h in [0,2HY), ie interior)
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   int H2 = 2 * p.HY, NXI = p.nx * p.nens;
   long long n = (long long)p.V * p.nz * H2 * NXI;
   if (t >= n) return;
@@ -155,9 +153,8 @@ __global__ __launch_bounds__(256) void k_halo_y(DyP p, double *__restrict__ S) {
   }
   col[(long long)jh * p.sJ] = val;
 }
-__global__ __launch_bounds__(256) void k_halo_z(DyP p, double *__restrict__ S) {
+__device__ __forceinline__ void halo_z_body(const DyP &p, double *__restrict__ S, long long t) {
   // threads: (v, h in [0,2HZ), j, ie interior)   :752-781
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   int H2 = 2 * p.HZ, NXI = p.nx * p.nens;
   long long n = (long long)p.V * H2 * p.ny * NXI;
   if (t >= n) return;
@@ -171,6 +168,18 @@ __global__ __launch_bounds__(256) void k_halo_z(DyP p, double *__restrict__ S) {
   if (v + p.v0 == idW && p.bc_z == MW_BC_WALL) val = 0;
   else val = col[(long long)(lo ? p.HZ : p.HZ + p.nz - 1) * p.sK];
   col[(long long)kh * p.sK] = val;
+}
+
+__global__ __launch_bounds__(256) void k_halo_x(DyP p, double *__restrict__ S) { halo_x_body(p, S, (long long)blockIdx.x * 256 + threadIdx.x); }
+__global__ __launch_bounds__(256) void k_halo_y(DyP p, double *__restrict__ S) { halo_y_body(p, S, (long long)blockIdx.x * 256 + threadIdx.x); }
+__global__ __launch_bounds__(256) void k_halo_z(DyP p, double *__restrict__ S) { halo_z_body(p, S, (long long)blockIdx.x * 256 + threadIdx.x); }
+// All three regions in one launch (they are independent: each writes its own halo cells from interior cells, and the corners
+// are never read): blocks [0, nbx) do x, [nbx, nbx+nby) do y, the rest z.  Used when no direction needs a neighbour exchange.
+__global__ __launch_bounds__(256) void k_halo_xyz(DyP p, double *__restrict__ S, unsigned nbx, unsigned nby) {
+  const unsigned b = blockIdx.x;
+  if (b < nbx) halo_x_body(p, S, (long long)b * 256 + threadIdx.x);
+  else if (b < nbx + nby) halo_y_body(p, S, (long long)(b - nbx) * 256 + threadIdx.x);
+  else halo_z_body(p, S, (long long)(b - nbx - nby) * 256 + threadIdx.x);
 }
 
 // Pack / unpack for a neighbour exchange (3-cell halos of all V variables; interior rows only, like :606-631,:725-747)
@@ -822,16 +831,14 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
     if (ex_y) { hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((nSN + 255) / 256)), dim3(256), 0, st, p, S, bf[6], bf[7]); MW_LAUNCH_CHECK(); }
   }
   // local wrap / BC:  x when this direction has one rank (periodic self-wrap) or a non-periodic BC on an edge rank
-  if (!ex_x) {
-    long long n = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens;
-    hipLaunchKernelGGL(k_halo_x, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, S); MW_LAUNCH_CHECK();
-  } else if (p.bc_x != MW_BC_PERIODIC) MW_FAIL("wall/open bc_x with nproc_x > 1 is not implemented");
-  if (!ex_y && !p.sim2d) {
-    long long n = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
-    hipLaunchKernelGGL(k_halo_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, S); MW_LAUNCH_CHECK();
-  } else if (!p.sim2d && p.bc_y != MW_BC_PERIODIC) MW_FAIL("wall/open bc_y with nproc_y > 1 is not implemented");
-  long long n = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
-  hipLaunchKernelGGL(k_halo_z, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, S); MW_LAUNCH_CHECK();
+  if (ex_x && p.bc_x != MW_BC_PERIODIC) MW_FAIL("wall/open bc_x with nproc_x > 1 is not implemented");
+  if (ex_y && !p.sim2d && p.bc_y != MW_BC_PERIODIC) MW_FAIL("wall/open bc_y with nproc_y > 1 is not implemented");
+  const long long nx_ = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens;
+  const long long ny_ = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
+  const long long nz_ = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
+  const unsigned nbx = ex_x ? 0u : (unsigned)((nx_ + 255) / 256), nby = (ex_y || p.sim2d) ? 0u : (unsigned)((ny_ + 255) / 256);
+  const unsigned nbz = (unsigned)((nz_ + 255) / 256);
+  hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + nbz), dim3(256), 0, st, p, S, nbx, nby); MW_LAUNCH_CHECK();
   return 0;
 }
 
