@@ -920,8 +920,8 @@ static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_
 
 static int xz_grid(mw_dycore_s *d, dim3 &grid, int &chunk, int &tiles_x) {
   const DyP &p = d->p;
-  int U = 64 - 6 * p.nens;
-  if (U < 1) MW_FAIL("nens too large for the 64-lane x tiling (need nens <= 10)");
+  int U = xz_cells_per_wave(p.nens);
+  if (U < 4) MW_FAIL("nens too large for the 64-lane x tiling (need nens <= 30)");
   tiles_x = (p.nx * p.nens + U - 1) / U;
   long long waves = (long long)p.ny * tiles_x;
   chunk = d->chunk_z ? d->chunk_z : (d->chunk_z = pick_chunk(p.nz, waves, "MW_CHUNK_Z"));
@@ -1000,7 +1000,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
   const DyP &p = d->p;
   {
     ProfScope ps(d, 7, st);
-    const int U = 64 - 8 * p.nens;
+    const int U = p.nens == 1 ? 56 : 64 - 4 * p.nens;
     const int tiles_x = (p.nx * p.nens + U - 1) / U;
     const int rows4 = p.ny >= 4 ? 1 : 0;
     const long long waves = (long long)p.ny * tiles_x;
@@ -1116,7 +1116,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
     set_error("hipMalloc(workspace) failed"); return fail(); }
   (void)hipMemsetAsync(d->flags, 0, (size_t)p.nC, d->stream);
   { const char *f = getenv("MW_FUSED_TRACERS");
-    d->fused = (g->num_tracers <= 4 && g->nens <= 7 && !(f && f[0] == '0')) ? 1 : 0; }
+    d->fused = (g->num_tracers <= 4 && g->nens <= 12 && !(f && f[0] == '0')) ? 1 : 0; }
   // zero everything once: halo corners are never written and the flux arrays start at 0 (:1677-1682)
   (void)hipMemsetAsync(d->S0, 0, slab, d->stream); (void)hipMemsetAsync(d->S1, 0, slab, d->stream);
   (void)hipMemsetAsync(d->S2, 0, slab, d->stream); (void)hipMemsetAsync(d->S3, 0, slab, d->stream); (void)hipMemsetAsync(d->tendY, 0, (size_t)5 * p.nC * sizeof(double), d->stream);

@@ -227,38 +227,58 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// XZ pass.  wave = 64 fused-x lanes of one row j; lanes [0,2n) only feed stencils, lanes [2n,64-2n) reconstruct in x,
-// lanes [3n,64-2n) own a lower x face, lanes [3n,64-3n) own a complete cell (n = nens).  Marches k over [ka-1, kb]
-// for the chunk [ka, kb).  All global loads of an iteration are issued at its top and consumed at its end.
+// XZ pass.  wave = 64 fused-x lanes of one row j (n = nens lanes per x cell).  Marches k over [ka-1, kb] for the chunk
+// [ka, kb).  Two ways to get a cell's four x-stencil neighbours:
+//   nens == 1: whole-wave DPP shifts.  Lanes [0,2n) only feed stencils, [2n,64-2n) reconstruct, [3n,64-2n) own a lower x
+//              face, [3n,64-3n) own a complete cell: 3 halo cells per side, 58 cells per wave.
+//   nens  > 1: a DPP shift cannot move by n lanes and 3n halo lanes per side would idle 6n of 64 lanes (38 % for nens = 4),
+//              so the neighbours are read from global memory (the same cache lines the wave has just touched: L1 hits) and
+//              EVERY lane reconstructs; only the west neighbour's east-edge value and the east face's flux still travel
+//              by lane (ds_bpermute): 1 halo cell per side, 64 - 2n cells per wave.
 // ---------------------------------------------------------------------------------------------------------------
 struct XzGeom {
   int n, lane, NXI, j, q, qq, e, i, qc, ka, kb, kstart;
+  int cell_lo, cell_hi, face_hi;                              // lanes [cell_lo, cell_hi) own a cell, [cell_lo, face_hi) a lower x face
+  int om2, om1, op1, op2;                                     // nens > 1: offsets (doubles) of the x neighbours from the lane's own cell
   bool owns_face, owns_cell, valid;
 };
+__host__ __device__ __forceinline__ int xz_cells_per_wave(int nens) { return nens == 1 ? 58 : 64 - 2 * nens; }
 template <bool N1>
 __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, int rows4 = 0) {
   XzGeom g;
   g.n = N1 ? 1 : p.nens;
   g.lane = threadIdx.x & 63;
   g.NXI = p.nx * g.n;
-  const int U = 64 - 6 * g.n;                                 // cells (fused) a wave completes
+  const int hw = N1 ? 3 : 1;                                  // halo cells per side
+  const int U = 64 - 2 * hw * g.n;                            // cells (fused) a wave completes
+  g.cell_lo = hw * g.n; g.cell_hi = 64 - hw * g.n; g.face_hi = N1 ? 64 - 2 * g.n : 64;
   const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // wave id -> (row j, x tile)
   int tx;
   if (rows4) { const int jg = (int)(blockIdx.x / tiles_x); tx = (int)(blockIdx.x - (unsigned)jg * tiles_x); g.j = jg * 4 + (threadIdx.x >> 6); }
   else       { g.j = (int)(wid / tiles_x); tx = (int)(wid - (long long)g.j * tiles_x); }
   g.valid = g.j < p.ny;                                       // whole wave
-  g.q = tx * U - 3 * g.n + g.lane;                            // interior fused-x index of this lane (may be in the halo)
-  const bool in_row = (g.q < g.NXI + 3 * g.n);
-  g.owns_face = (g.lane >= 3 * g.n) && (g.lane < 64 - 2 * g.n) && (g.q < g.NXI + g.n);
-  g.owns_cell = (g.lane >= 3 * g.n) && (g.lane < 64 - 3 * g.n) && (g.q < g.NXI);
-  g.qq = in_row ? g.q : (g.NXI + 3 * g.n - 1);                // clamped for addressing
+  g.q = tx * U - hw * g.n + g.lane;                           // interior fused-x index of this lane (may be in the halo)
+  const int q_hi = g.NXI + (N1 ? 3 : 1) * g.n - 1;            // last index a lane may address (nens > 1: +2n must stay in the halo)
+  g.owns_face = (g.lane >= g.cell_lo) && (g.lane < g.face_hi) && (g.q < g.NXI + g.n);
+  g.owns_cell = (g.lane >= g.cell_lo) && (g.lane < g.cell_hi) && (g.q < g.NXI);
+  g.qq = min(g.q, q_hi);                                      // clamped for addressing
   g.e = N1 ? 0 : ((g.qq % g.n) + g.n) % g.n;
   g.i = (g.qq - g.e) / g.n;                                   // x cell index (can be -3..nx+2)
   g.qc = g.owns_cell ? g.q : 0;                               // safe index for per-cell arrays
+  g.om2 = -2 * g.n; g.om1 = -g.n; g.op1 = g.n; g.op2 = 2 * g.n;             // qq in [-n, NXI+n): all four stay inside the 3-cell halo
   g.ka = blockIdx.y * chunk;
   g.kb = min(g.ka + chunk, p.nz);
   g.kstart = (g.ka == 0) ? 0 : g.ka - 1;                      // no ghost cell below the wall
   return g;
+}
+// The four x-stencil neighbours of the lane's cell value c0 (level pointer lvl = the lane's own cell at that level).
+template <bool N1>
+__device__ __forceinline__ void x_neighbours(double c0, const double *__restrict__ lvl, int om2, int om1, int op1, int op2, int lane, int n,
+                                             double &m2, double &m1, double &p1, double &p2) {
+  if (N1) {
+    m1 = from_west<true>(c0, lane, n); p1 = from_east<true>(c0, lane, n);
+    m2 = from_west<true>(m1, lane, n); p2 = from_east<true>(p1, lane, n);
+  } else { m2 = lvl[om2]; m1 = lvl[om1]; p1 = lvl[op1]; p2 = lvl[op2]; }
 }
 
 template <int STAGE, bool N1>
@@ -315,10 +335,8 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       double we[5], ee[5];
 #pragma unroll
       for (int v = 0; v < 5; v++) {
-        double c0 = w[v][2];
-        double m1 = from_west<N1>(c0, lane, n), p1 = from_east<N1>(c0, lane, n);
-        double m2 = N1 ? from_west<N1>(m1, lane, n) : shfl_from(c0, lane - 2 * n);
-        double p2 = N1 ? from_east<N1>(p1, lane, n) : shfl_from(c0, lane + 2 * n);
+        double c0 = w[v][2], m2, m1, p1, p2;
+        x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK, g.om2, g.om1, g.op1, g.op2, lane, n, m2, m1, p1, p2);
         weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
       }
       const int bcmode = bc_mode_x(p, g.i);
@@ -460,7 +478,7 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
   const long long fxo = (long long)j * p.fxJ + (g.owns_face ? q : 0);
   const long long fzo = (long long)j * p.fzJ + g.qc;
   const long long fyo = (long long)j * p.fyJ + g.qc;
-  const bool west_owns = (lane - n >= 3 * n) && (lane - n < 64 - 3 * n) && (q - n < NXI);
+  const bool west_owns = (lane - n >= g.cell_lo) && (lane - n < g.cell_hi) && (q - n < NXI);
   const bool first_face = g.owns_face && (q < n);              // i == 0: the donor of an eastward flux is outside the rank
   const bool last_face = g.owns_face && (q >= NXI);            // i == nx
   const bool do_y = !p.sim2d;
@@ -501,10 +519,8 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
       const bool quirk = bc_mode_x(p, g.i) == 3;
 #pragma unroll
       for (int v = 0; v < T; v++) {
-        double c0 = w[v][2];
-        double m1 = from_west<N1>(c0, lane, n), p1 = from_east<N1>(c0, lane, n);
-        double m2 = N1 ? from_west<N1>(m1, lane, n) : shfl_from(c0, lane - 2 * n);
-        double p2 = N1 ? from_east<N1>(p1, lane, n) : shfl_from(c0, lane + 2 * n);
+        double c0 = w[v][2], m2, m1, p1, p2;
+        x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK, g.om2, g.om1, g.op1, g.op2, lane, n, m2, m1, p1, p2);
         double we, ee;
         weno5_edges_fast(m2, m1, c0, p1, p2, we, ee);
         if (__builtin_expect(quirk, 0)) {
@@ -658,18 +674,22 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   constexpr int t0 = 0;                                       // one group: all (<= 4) tracers of the cell
   const int lane = threadIdx.x & 63;
   const int NXI = p.nx * n;
-  const int U = 64 - 8 * n;
+  const int hw = N1 ? 4 : 2;                                  // halo cells per side (see xz_geom: DPP shifts vs. neighbour loads)
+  const int U = 64 - 2 * hw * n;
   int j, tx;
   if (rows4) { const int jg = (int)(blockIdx.x / tiles_x); tx = (int)(blockIdx.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
   else       { const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
   if (j >= p.ny) return;
-  const int q = tx * U - 4 * n + lane;                        // fused-x index of this lane's cell (halo lanes included)
+  const int q = tx * U - hw * n + lane;                       // fused-x index of this lane's cell (halo lanes included)
   const int qq = min(max(q, -3 * n), NXI + 3 * n - 1);        // clamped into the 3-cell halo for addressing
   const int e = N1 ? 0 : ((qq % n) + n) % n;
   const int i = (qq - e) / n;
   const bool interior = (q >= 0) && (q < NXI);
-  const bool has_mult = (lane >= 3 * n) && (lane < 64 - 3 * n) && interior;     // both x faces of the cell are known
-  const bool upd = (lane >= 4 * n) && (lane < 64 - 4 * n) && interior;          // the cell this lane completes
+  const bool has_mult = (lane >= (hw - 1) * n) && (lane < 64 - (hw - 1) * n) && interior;   // both x faces of the cell are known
+  const bool upd = (lane >= hw * n) && (lane < 64 - hw * n) && interior;                    // the cell this lane completes
+  // nens > 1: neighbour offsets, clamped so that every load stays inside the row's 3-cell halo
+  const int om2 = max(q - 2 * n, -3 * n) - qq, om1 = max(q - n, -3 * n) - qq;
+  const int op1 = min(q + n, NXI + 3 * n - 1) - qq, op2 = min(q + 2 * n, NXI + 3 * n - 1) - qq;
   const int qm = interior ? q : 0;
   const int qf = (q >= 0 && q < NXI + n) ? q : 0;
   const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qq;
@@ -739,10 +759,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       const bool quirk = bc_mode_x(p, i) == 3;
 #pragma unroll
       for (int v = 0; v < T; v++) {
-        double c0 = w[v][2];
-        double m1 = from_west<N1>(c0, lane, n), p1 = from_east<N1>(c0, lane, n);
-        double m2 = N1 ? from_west<N1>(m1, lane, n) : shfl_from(c0, lane - 2 * n);
-        double p2 = N1 ? from_east<N1>(p1, lane, n) : shfl_from(c0, lane + 2 * n);
+        double c0 = w[v][2], m2, m1, p1, p2;
+        x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(kx + p.HZ) * p.sK, om2, om1, op1, op2, lane, n, m2, m1, p1, p2);
         double we, ee;
         weno5_edges_fast(m2, m1, c0, p1, p2, we, ee);
         if (__builtin_expect(quirk, 0)) {

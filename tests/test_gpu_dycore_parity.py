@@ -188,11 +188,11 @@ def test_many_tracers_general_grouping(mw, oracle):
 
 RAGGED = {
     # name: (nx, ny, nz, nens, xlen, ylen, zlen, init_data, num_tracers, enable_gravity, nsteps)
-    "ragged_37x11x5_nens3": (37, 11, 5, 3, 18500., 5500., 20000., "supercell", 3, True, 2),       # x tiles of 46 cells, nens 3
+    "ragged_37x11x5_nens3": (37, 11, 5, 3, 18500., 5500., 20000., "supercell", 3, True, 2),       # x tiles of 58 fused lanes (19 cells), nens 3
     "ragged_130x7x9": (130, 7, 9, 1, 65000., 3500., 20000., "supercell", 3, True, 2),             # 3 x tiles, 2 z chunks
     "ragged2d_70x1x6": (70, 1, 6, 1, 35000., 1.0e5, 20000., "supercell", 3, True, 2),             # 2-D, 2 x tiles
     "ragged_3x3x3": (3, 3, 3, 1, 1500., 1500., 20000., "supercell", 3, True, 2),                  # the smallest legal grid
-    "ragged_20x5x33_nens10": (20, 5, 33, 10, 10000., 2500., 20000., "supercell", 3, True, 1),     # nens 10: 4 useful lanes per wave
+    "ragged_20x5x33_nens10": (20, 5, 33, 10, 10000., 2500., 20000., "supercell", 3, True, 1),     # nens 10: 44 cells per wave (state), 24 (fused tracers)
 }
 
 
