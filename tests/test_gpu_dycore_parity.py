@@ -192,6 +192,9 @@ RAGGED = {
     "ragged_130x7x9": (130, 7, 9, 1, 65000., 3500., 20000., "supercell", 3, True, 2),             # 3 x tiles, 2 z chunks
     "ragged2d_70x1x6": (70, 1, 6, 1, 35000., 1.0e5, 20000., "supercell", 3, True, 2),             # 2-D, 2 x tiles
     "ragged_3x3x3": (3, 3, 3, 1, 1500., 1500., 20000., "supercell", 3, True, 2),                  # the smallest legal grid
+    "ragged_50x6x7_nens4": (50, 6, 7, 4, 25000., 3000., 20000., "supercell", 3, True, 2),          # nens 4: 4 x tiles (state), 5 (fused)
+    "ragged_9x4x6_nens12": (9, 4, 6, 12, 4500., 2000., 20000., "supercell", 3, True, 1),           # the widest ensemble the fused stage takes
+    "ragged_9x4x6_nens13": (9, 4, 6, 13, 4500., 2000., 20000., "supercell", 3, True, 1),           # -> unfused tracer kernels
     "ragged_20x5x33_nens10": (20, 5, 33, 10, 10000., 2500., 20000., "supercell", 3, True, 1),     # nens 10: 44 cells per wave (state), 24 (fused tracers)
 }
 
