@@ -1043,9 +1043,11 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   if (halo_fill(d, Sin, 0, 5, ss, 0)) return 1;
   if (launch_y_state(d, Sin, par)) return 1;                                  // y faces: m_upw, selector, y tendencies
   if (launch_xz_state<STAGE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par)) return 1;   // x,z faces + finished state variables
-  if (d->overlap) { MW_HIP(hipEventRecord(d->ev_state[slot], ss)); MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0)); }
-  // ---- tracer pipeline
+  // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
+  // previous stage, which this stream produced itself: it is issued BEFORE the wait for this stage's state kernels and so
+  // runs beside them; the state stream's exchange for stage s+1 in turn runs beside this stage's tracer kernels.
   if (halo_fill(d, Sin, 5, T, ts, 1)) return 1;
+  if (d->overlap) { MW_HIP(hipEventRecord(d->ev_state[slot], ss)); MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0)); }
   if (launch_y_tracers(d, Sin, par, ts)) return 1;                            // tracer fluxes (public arrays)
   if (d->fused) {
     if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ts)) return 1;   // x/z fluxes + D10 + D11/D12 (+ D13)

@@ -43,6 +43,9 @@ class Exchanger:
                     if recv[d] and cnt[d] and act[d]:
                         src = self.send[peers[d]][d ^ 1]
                         assert hip.hipMemcpy(recv[d], src, cnt[d] * 8, 3) == 0      # hipMemcpyDeviceToDevice
+                # a device-to-device hipMemcpy is not synchronous with the host, and the library's streams do not synchronise
+                # with the null stream it runs on: finish the copies before the unpack kernels are enqueued
+                assert hip.hipStreamSynchronize(None) == 0
                 self.bar.wait(timeout=60)
                 return 0
             except Exception as e:                                      # pragma: no cover
