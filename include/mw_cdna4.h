@@ -146,6 +146,9 @@ int  mw_dycore_set_exchange(mw_dycore_t h, mw_exchange_fn fn, void *ctx);
  * unique_id: the 128-byte ncclUniqueId created on rank 0 (mw_rccl_unique_id) and broadcast by the host. */
 int  mw_rccl_unique_id(unsigned char *id128);
 int  mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, int myrank);
+/* Diagnostic: one rank sends 4 strips of n doubles to itself through the exchange's own ncclGroup / side stream / event
+ * sequence and compares; 0 = RCCL initialises on this box and the ordering against `stream` holds. */
+int  mw_rccl_selftest(long long n, void *stream);
 
 /* ---- Kessler microphysics ------------------------------------------------------------------------- */
 /* Microphysics_Kessler::time_step(coupler, dt), microphysics_kessler.h:99-162 + kessler() :234-339.

@@ -12,6 +12,7 @@
 #include "mw_common.h"
 #include <rccl/rccl.h>
 #include <cstring>
+#include <vector>
 
 namespace {
 struct RcclCtx {
@@ -70,6 +71,41 @@ int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, in
   MW_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return 1;
   return mw_dycore_set_exchange(h, rccl_exchange, c);
+}
+
+// Diagnostic: a 1-rank communicator that sends n doubles to itself through the same group/stream/event sequence as
+// rccl_exchange (two sends + two receives in one ncclGroup on a side stream).  Checks, on a single GPU, that RCCL initialises
+// on the box and that the ordering against the caller's stream holds.  Returns 0 when the received data equal the sent data.
+int mw_rccl_selftest(long long n, void *vstream) {
+  if (n < 1) MW_FAIL("rccl_selftest: n must be >= 1");
+  hipStream_t main_stream = (hipStream_t)vstream;
+  ncclUniqueId id;
+  MW_NCCL(ncclGetUniqueId(&id));
+  RcclCtx c;
+  MW_NCCL(ncclCommInitRank(&c.comm, 1, id, 0));
+  MW_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+  MW_HIP(hipEventCreateWithFlags(&c.ev_ready, hipEventDisableTiming));
+  MW_HIP(hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming));
+  for (int d = 0; d < 4; d++) { c.peers[d] = 0; c.send_order[d] = d; c.active[d] = 1; }
+  c.recv_order[0] = 1; c.recv_order[1] = 0; c.recv_order[2] = 3; c.recv_order[3] = 2;      // E,W,N,S like mw_exchange_plan
+  std::vector<double> h((size_t)4 * n), back((size_t)4 * n, -1.0);
+  for (size_t i = 0; i < h.size(); i++) h[i] = 1.0 + (double)i * 0.5;
+  double *src = nullptr, *dst = nullptr;
+  MW_HIP(hipMalloc(&src, h.size() * 8)); MW_HIP(hipMalloc(&dst, h.size() * 8));
+  MW_HIP(hipMemcpyAsync(src, h.data(), h.size() * 8, hipMemcpyHostToDevice, main_stream));
+  MW_HIP(hipMemsetAsync(dst, 0, h.size() * 8, main_stream));
+  // strips W,E (n each) and S,N (n each); my E halo = the "peer's" W strip etc.
+  int rc = rccl_exchange(&c, src, src + n, src + 2 * n, src + 3 * n, dst, dst + n, dst + 2 * n, dst + 3 * n, n, n, main_stream);
+  if (!rc) { MW_HIP(hipMemcpyAsync(back.data(), dst, h.size() * 8, hipMemcpyDeviceToHost, main_stream)); MW_HIP(hipStreamSynchronize(main_stream)); }
+  (void)hipFree(src); (void)hipFree(dst);
+  (void)hipEventDestroy(c.ev_ready); (void)hipEventDestroy(c.ev_done); (void)hipStreamDestroy(c.side);
+  (void)ncclCommDestroy(c.comm);
+  if (rc) return 1;
+  // receives were posted E,W,N,S against sends W,E,S,N: rE <- sW, rW <- sE, rN <- sS, rS <- sN
+  const int from[4] = {1, 0, 3, 2};                                      // dst strip d holds src strip from[d]
+  for (int d = 0; d < 4; d++) for (long long i = 0; i < n; i++)
+    if (back[(size_t)d * n + i] != h[(size_t)from[d] * n + i]) MW_FAIL("rccl_selftest: received data differ from the sent data");
+  return 0;
 }
 
 } // extern "C"

@@ -109,3 +109,14 @@ def test_eight_ranks_4x2_nens2(mw):
 
 def test_two_ranks_2d(mw):
     run_ranks(2, 64, 1, 16, 1, 3)           # 2x1: west == east peer
+
+
+def test_rccl_transport_selftest(mw):
+    """The RCCL transport itself (mw_rccl.cpp) on one GPU: a 1-rank communicator sends the four strips to itself through the
+    exchange's own ncclGroup / side-stream / event sequence (receives posted E,W,N,S against sends W,E,S,N)."""
+    import torch
+    from miniweatherml_amd import capi
+    with torch.cuda.device(0):
+        st = torch.cuda.current_stream().cuda_stream
+        capi.check(capi.lib().mw_rccl_selftest(3 * 100 * 400 * 5, C.c_void_p(st)))          # one state strip of config 2
+        capi.check(capi.lib().mw_rccl_selftest(7, C.c_void_p(st)))
