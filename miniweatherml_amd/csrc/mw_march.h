@@ -674,7 +674,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   constexpr int t0 = 0;                                       // one group: all (<= 4) tracers of the cell
   const int lane = threadIdx.x & 63;
   const int NXI = p.nx * n;
-  const int hw = N1 ? 4 : 2;                                  // halo cells per side (see xz_geom: DPP shifts vs. neighbour loads)
+  const int hw = N1 ? 4 : 2;                                  // halo cells per side (see xz_geom: DPP shifts vs. neighbour loads; patching only
+                                                              // the edge lanes of the DPP variant from memory was measured: 20 % slower)
   const int U = 64 - 2 * hw * n;
   int j, tx;
   if (rows4) { const int jg = (int)(blockIdx.x / tiles_x); tx = (int)(blockIdx.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
@@ -748,6 +749,14 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       for (int v = 0; v < T; v++) qn_[v] = Sn[so + (5 + t0 + v) * p.sV];
     }
     if (MODE == 1) { st_T = Sout[so + idT * p.sV]; st_U = Sout[so + idU * p.sV]; st_V = Sout[so + idV * p.sV]; st_W = Sout[so + idW * p.sV]; }
+    // nens > 1: the x-stencil neighbours of level k come from memory (issued here, with the iteration's other loads)
+    double nbw2[T], nbw1[T], nbe1[T], nbe2[T];
+#pragma unroll
+    for (int v = 0; v < T; v++) {
+      const double *lvl = col + (long long)v * p.sV + (long long)(kx + p.HZ) * p.sK;
+      nbw2[v] = nbw1[v] = nbe1[v] = nbe2[v] = 0;
+      if (!N1) { nbw2[v] = lvl[om2]; nbw1[v] = lvl[om1]; nbe1[v] = lvl[op1]; nbe2[v] = lvl[op2]; }
+    }
     // ------------------------------------------------ S1: z reconstruction (registers only), then the fluxes of level k
     double te[T], fxn[T], fzn[T], be_[T], xe_[T];
 #pragma unroll
@@ -759,8 +768,11 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       const bool quirk = bc_mode_x(p, i) == 3;
 #pragma unroll
       for (int v = 0; v < T; v++) {
-        double c0 = w[v][2], m2, m1, p1, p2;
-        x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(kx + p.HZ) * p.sK, om2, om1, op1, op2, lane, n, m2, m1, p1, p2);
+        double c0 = w[v][2], m2 = nbw2[v], m1 = nbw1[v], p1 = nbe1[v], p2 = nbe2[v];
+        if (N1) {                                              // whole-wave DPP shifts
+          m1 = from_west<true>(c0, lane, 1); p1 = from_east<true>(c0, lane, 1);
+          m2 = from_west<true>(m1, lane, 1); p2 = from_east<true>(p1, lane, 1);
+        }
         double we, ee;
         weno5_edges_fast(m2, m1, c0, p1, p2, we, ee);
         if (__builtin_expect(quirk, 0)) {
