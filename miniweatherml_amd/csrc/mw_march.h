@@ -201,8 +201,9 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
     const int jn = min(j + 3, p.ny + p.HY - 1);
 #pragma unroll
     for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
-    double m = 0; int up = 0;
-    if (j >= ja) { m = MY[(long long)k * p.fyK + ie + (long long)j * p.fyJ]; up = upy[(long long)j * p.fyJ]; }
+    const int jl = max(j, ja);                                  // unconditional loads (clamped row): nothing waits inside a branch
+    const double m = MY[(long long)k * p.fyK + ie + (long long)jl * p.fyJ];
+    const int up = upy[(long long)jl * p.fyJ];
     double se[T], ne[T];
 #pragma unroll
     for (int v = 0; v < T; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
