@@ -848,9 +848,10 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         }
       }
       if (MODE == 1 && st) {
-        const double hytc = p.hytc[kuc * p.nens + e];
-        double theta = (st_T + hytc) / rho_new;
-        double press = p.C0 * pow(rho_new * theta, p.gamma);
+        // D13 (:1929-1935): p = C0 (rho theta)^gamma with rho theta = hy + (rho theta)' -- the same series around the hydrostatic
+        // state as in the Riemann solver (device pow for large perturbations); rho*(rho theta / rho) differs from rho theta by rounding
+        const int hi = kuc * p.nens + e;
+        double press = pressure_fast(p, st_T, p.hytc[hi], p.p0c[hi], p.ihytc[hi]);
         c.rho_d[ci] = rho_dry;
         c.u[ci] = st_U; c.v[ci] = st_V; c.w[ci] = st_W;
         c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);
@@ -907,8 +908,8 @@ __global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const
       if (v == p.idWV) rho_v = qv;
       if ((p.mass_mask >> v) & 1u) rho_dry -= qv;
     }
-    const double theta = (Sout[so + idT * p.sV] + p.hytc[k * p.nens + e]) / rho_new;
-    const double press = p.C0 * pow(rho_new * theta, p.gamma);
+    const int hi = k * p.nens + e;                                // the same pressure evaluation as k_tracers_fused (D13)
+    const double press = pressure_fast(p, Sout[so + idT * p.sV], p.hytc[hi], p.p0c[hi], p.ihytc[hi]);
     c.rho_d[ci] = rho_dry;
     c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);
   }
