@@ -62,6 +62,10 @@ template <bool STRICT> __device__ __forceinline__ double pow_gamma(double x, dou
 // hyt^gamma (1 + delta)^gamma with delta = e/hyt (|delta| is a few per cent: e is the reconstructed PERTURBATION of
 // rho*theta) turns it into p0(k) * sum_n C(gamma,n) delta^n: 10 FMAs; truncation |C(gamma,11)| 0.05^11 ~ 1e-17 for
 // |delta| <= 0.05.  Larger perturbations take the generic pow (per-lane branch).
+// out of line on purpose: the libm pow body (~230 instructions, ~60 VGPRs) would otherwise be inlined twice per Riemann solve
+// into kernels that sit at the register limit; it only runs for |(rho theta)'| > 5 % of the hydrostatic value.
+__device__ __attribute__((noinline)) double pressure_pow(double C0, double x, double gamma) { return C0 * pow(x, gamma); }
+
 __device__ __forceinline__ double pressure_fast(const DyP &p, double e, double hyt, double p0, double ihyt) {
 #pragma clang fp contract(fast)
   double dl = e * ihyt;
@@ -71,7 +75,7 @@ __device__ __forceinline__ double pressure_fast(const DyP &p, double e, double h
     for (int n = 9; n >= 1; n--) acc = acc * dl + p.bn[n];
     return p0 + p0 * (acc * dl);
   }
-  return p.C0 * pow(hyt + e, p.gamma);
+  return pressure_pow(p.C0, hyt + e, p.gamma);
 }
 
 // -----------------------------------------------------------------------------------------------------

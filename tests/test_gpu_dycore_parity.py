@@ -276,3 +276,19 @@ def test_fct_patch_pass_is_exercised(mw, oracle, monkeypatch):
     monkeypatch.setenv("MW_DEBUG_NO_PATCH", "1")
     with pytest.raises(AssertionError):
         test_fct_limiter_heavy(mw, oracle, "1", (70, 9, 12, 1), monkeypatch)
+
+
+def test_large_perturbation_takes_the_pow_fallback(mw, oracle):
+    """(rho theta)' beyond 5 % of the hydrostatic value: the Riemann solver's pressure series hands over to the out-of-line
+    device pow (pressure_pow) on those lanes; a +-12 % temperature field exercises it on roughly half of the faces."""
+    from miniweatherml_amd import modules
+    coupler, dycore, _ = modules.make_supercell(20, 14, 10, 1, 10000., 7000., 20000.)
+    odyc, of = oracle.supercell_setup(20, 14, 10, 1, 10000., 7000., 20000.)
+    rng = np.random.default_rng(21)
+    of.temp *= 1.0 + rng.uniform(-0.12, 0.12, of.temp.shape)
+    push_fields(coupler, of)
+    dt = 0.25 * dycore.compute_time_step(coupler)              # a violent state: small steps
+    for step in range(2):
+        dycore.time_step(coupler, dt)
+        odyc.time_step(of, dt)
+        compare_fields(gpu_fields(coupler), of.as_dict(), 1e-10, "large perturbation step %d" % (step + 1))
