@@ -85,15 +85,12 @@ __device__ __forceinline__ void weno5_edges_fast(double s0, double s1, double s2
   const double C1p = b + c;                                 // 2*coefs3_shift2(1) = s3 - s1
   const double L1 = b + 0.5*L2p;                            // coefs3_shift1(1) =  0.5 s0 - 2 s1 + 1.5 s2
   const double R1 = c - 0.5*R2p;                            // coefs3_shift3(1) = -1.5 s2 + 2 s3 - 0.5 s4
-  const double k24 = 0.041666666666666666666666666666666666667;    // 1/24
-  const double L0 = s2 - k24*L2p, C0 = s2 - k24*C2p, R0 = s2 - k24*R2p;     // coefs3_shift*(0): cell mean preserved
   const double e = s4 - s0;
   const double sLR = L2p + R2p;
   const double H4p = sLR - 2.0*C2p;                         // 24*coefs5_shift3(4)
   const double H3p = e - 2.0*C1p;                           // 12*coefs5_shift3(3)
   const double H2p = 10.0*C2p - sLR;                        // 16*coefs5_shift3(2)
   const double H1 = 0.70833333333333333333333333333333333333*C1p - 0.10416666666666666666666666666666666667*e;  // coefs5_shift3(1)
-  const double H0 = s2 - (1.0/192.0)*H2p - (1.0/1920.0)*H4p;                 // s2 - H2/12 - H4/80
   // TV (WenoLimiter_recon.h:37-56) with the scale factors folded into the constants
   const double k1312 = 1.0833333333333333333333333333333333333;             // (13/3)/4
   const double tL = L1*L1 + k1312*(L2p*L2p);
@@ -117,14 +114,17 @@ __device__ __forceinline__ void weno5_edges_fast(double s0, double s1, double s2
   rN = rN + rN*(1.0 - N*rN);
   rN = rN + rN*(1.0 - N*rN);
   // (the reference's 2nd/3rd convexify only re-normalise weights that already sum to 1)
-  // limited coefficients (un-normalised) evaluated at -1/2 and +1/2:  even part c0 + c2/4 + c4/16, odd part c1/2 + c3/8
-  const double c0 = H0*nH + L0*nL + C0*nC + R0*nR;
+  // Limited polynomial (un-normalised weights n_i, sum N) evaluated at -1/2 and +1/2.  Every candidate preserves the cell mean:
+  // its constant coefficient is s2 - c2/12 (- c4/80 for the 5th-order one), so the even part  c0 + c2/4 + c4/16  collapses to
+  //   s2 N + (1/4 - 1/12) c2 + (1/16 - 1/80) c4  =  s2 N + c2/6 + c4/20
+  // and the constant coefficients never have to be formed (c2 = c2h/2, c4 = H4p nH / 24).
+  const double h4n = H4p*nH;
   const double c1 = H1*nH + L1*nL + (0.5*C1p)*nC + R1*nR;
   const double c2h = (0.125)*(H2p*nH) + L2p*nL + C2p*nC + R2p*nR;          // 2*c2   (H2 = H2p/16 -> 2*H2 = H2p/8)
-  const double ev = c0 + 0.125*c2h + (0.0625/24.0)*(H4p*nH);
+  const double ev = (1.0/12.0)*c2h + (1.0/480.0)*h4n;                      // even part minus s2 N
   const double od = 0.5*c1 + (0.125/12.0)*(H3p*nH);
-  left  = (ev - od)*rN;
-  right = (ev + od)*rN;
+  left  = s2 + (ev - od)*rN;
+  right = s2 + (ev + od)*rN;
 }
 
 } // namespace mw
