@@ -798,11 +798,12 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         const double fe = from_east<N1>(fxp[v], lane, n);
         double mult = 1.0;
         {
-          const double mass_available = fmax(w[v][1] * rhop, 0.0) * p.dx * p.dy * p.dz;
+          // the cell volume dx dy dz multiplies both sides of the reference's test (:506-511) and cancels in the multiplier
+          const double mass_available = fmax(w[v][1] * rhop, 0.0);
           const double out_x = (fmax(fe, 0.0) - fmin(fxp[v], 0.0)) * p.rdx;
           const double out_y = (fmax(fyn[v], 0.0) - fmin(fys[v], 0.0)) * p.rdy;
           const double out_z = (fmax(fzn[v], 0.0) - fmin(fzp[v], 0.0)) * p.rdz;
-          const double mass_out = (out_x + out_y + out_z) * dt * p.dx * p.dy * p.dz;
+          const double mass_out = (out_x + out_y + out_z) * dt;
           if (__builtin_expect(s2cell && has_mult && ((p.pos_mask >> (t0 + v)) & 1u) && mass_out > mass_available, 0))
             mult = mass_available / mass_out;
         }
