@@ -34,8 +34,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // VALU moves per double and no LDS round trip.  Used when nens == 1 (x neighbours are adjacent lanes).
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);      // bound_ctrl: the edge lane reads 0, so no "old value" mov is needed
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // value held by the lane n lanes to the west (lower x) / east (higher x)
