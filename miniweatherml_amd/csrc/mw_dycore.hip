@@ -44,7 +44,10 @@ struct DyP {                      // kernel parameter block (by value)
   const double *hyc, *hytc, *hye, *hyte;       // device (nz,nens) / (nz+1,nens)
   const double *p0c, *p0e, *ihytc, *ihyte;     // C0*hyt^gamma and 1/hyt at cells / edges (fast pressure path)
   const double *imm;                           // device (nz,ny,nx,nens)
+  const double *hypk;                          // the eight profile values of level k packed as rows of 8: (hyc, hytc, p0c, ihytc, hye, hyte,
+                                               // p0e, ihyte)[(k*nens+e)*8 + f], nz+1 rows: one pointer instead of eight in the hot kernels
   double bn[11];                               // binomial series coefficients C(gamma, n), n = 0..10
+  int bn_default;                              // bn[] equals the literal table for gamma = 1003/716 bit for bit (the usual case)
 };
 
 struct CouplerPtrs {
@@ -66,16 +69,32 @@ template <bool STRICT> __device__ __forceinline__ double pow_gamma(double x, dou
 // into kernels that sit at the register limit; it only runs for |(rho theta)'| > 5 % of the hydrostatic value.
 __device__ __attribute__((noinline)) double pressure_pow(double C0, double x, double gamma) { return C0 * pow(x, gamma); }
 
+// C(gamma, n), n = 1..10, for the default gamma = cp_d/(cp_d - R_d) = 1003/716 (the long-double recurrence of fill_params, as
+// hex literals).  Literal operands are materialised by scalar moves where they are used; the same numbers read from the
+// parameter block stay resident in 22 SGPRs for the whole kernel -- and the marching kernels already spill SGPRs to VGPR lanes.
+__device__ __forceinline__ double pressure_series_default(double dl) {
+#pragma clang fp contract(fast)
+  double acc = 0x1.d587239f51368p-10;
+  acc = acc * dl + -0x1.34ef19ee96d45p-9;
+  acc = acc * dl + 0x1.a553bdf108378p-9;
+  acc = acc * dl + -0x1.2cfe340a81e1p-8;
+  acc = acc * dl + 0x1.ca1dc2cec496fp-8;
+  acc = acc * dl + -0x1.7dda38e0cc64cp-7;
+  acc = acc * dl + 0x1.6f48bfb7e5329p-6;
+  acc = acc * dl + -0x1.cb58863e4dd29p-5;
+  acc = acc * dl + 0x1.1f7e1e502b562p-2;
+  acc = acc * dl + 0x1.669d5185016e2p+0;
+  return acc;
+}
+static const double BN_DEFAULT[11] = {1.0, 0x1.669d5185016e2p+0, 0x1.1f7e1e502b562p-2, -0x1.cb58863e4dd29p-5, 0x1.6f48bfb7e5329p-6,
+                                      -0x1.7dda38e0cc64cp-7, 0x1.ca1dc2cec496fp-8, -0x1.2cfe340a81e1p-8, 0x1.a553bdf108378p-9,
+                                      -0x1.34ef19ee96d45p-9, 0x1.d587239f51368p-10};
+
 __device__ __forceinline__ double pressure_fast(const DyP &p, double e, double hyt, double p0, double ihyt) {
 #pragma clang fp contract(fast)
   double dl = e * ihyt;
-  if (fabs(dl) <= 0.05) {
-    double acc = p.bn[10];
-#pragma unroll
-    for (int n = 9; n >= 1; n--) acc = acc * dl + p.bn[n];
-    return p0 + p0 * (acc * dl);
-  }
-  return pressure_pow(p.C0, hyt + e, p.gamma);
+  if (fabs(dl) <= 0.05 && p.bn_default) return p0 + p0 * (pressure_series_default(dl) * dl);
+  return pressure_pow(p.C0, hyt + e, p.gamma);                  // large perturbation, or a non-default gamma
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -725,7 +744,7 @@ struct mw_dycore_s {
   int chunk_y = 0, chunk_z = 0, chunk_f = 0;
   unsigned char *flags = nullptr;          // fused tracer stage: per-cell "a y face of this cell was FCT-scaled" bits
   int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
-  double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte
+  double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows (see DyP::hypk)
   double *imm = nullptr;
   std::vector<double> hy_host;               // same packing (the last four are derived in upload_background)
   double etime = 0;
@@ -775,9 +794,12 @@ static void fill_params(mw_dycore_s *d) {
   const double *ext = d->hy_dev + 2 * nzc + 2 * nze;
   p.p0c = ext; p.ihytc = ext + nzc; p.p0e = ext + 2 * nzc; p.ihyte = ext + 2 * nzc + nze;
   p.imm = d->imm;
+  p.hypk = d->hy_dev + 4 * nzc + 4 * nze;
   long double bn = 1.0L;                                    // C(gamma, n) = C(gamma, n-1) (gamma - n + 1) / n
   p.bn[0] = 1.0;
   for (int n = 1; n <= 10; n++) { bn = bn * ((long double)g.gamma_d - (n - 1)) / n; p.bn[n] = (double)bn; }
+  p.bn_default = 1;
+  for (int n = 0; n <= 10; n++) if (p.bn[n] != BN_DEFAULT[n]) p.bn_default = 0;
 }
 
 static int upload_background(mw_dycore_s *d) {
@@ -789,6 +811,9 @@ static int upload_background(mw_dycore_s *d) {
     double *ext = h + 2 * nzc + 2 * nze;
     for (size_t n = 0; n < nzc; n++) { ext[n] = g.C0 * pow(hytc[n], g.gamma_d); ext[nzc + n] = 1.0 / hytc[n]; }
     for (size_t n = 0; n < nze; n++) { ext[2 * nzc + n] = g.C0 * pow(hyte[n], g.gamma_d); ext[2 * nzc + nze + n] = 1.0 / hyte[n]; }
+    double *pk = h + 4 * nzc + 4 * nze;                      // packed rows
+    const double *src[8] = {h, h + nzc, ext, ext + nzc, h + 2 * nzc, h + 2 * nzc + nze, ext + 2 * nzc, ext + 2 * nzc + nze};
+    for (size_t n = 0; n < nze; n++) for (int f = 0; f < 8; f++) pk[n * 8 + f] = (f < 4 && n >= nzc) ? 0.0 : src[f][n];
   }
   MW_HIP(hipMemcpyAsync(d->hy_dev, d->hy_host.data(), d->hy_host.size() * sizeof(double), hipMemcpyHostToDevice, d->stream));
   MW_HIP(hipStreamSynchronize(d->stream));
@@ -1115,7 +1140,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
   const char *s = getenv("MW_STRICT");
   d->strict = (s && s[0] == '1');
   size_t nzc = (size_t)g->nz * g->nens, nze = (size_t)(g->nz + 1) * g->nens;
-  d->hy_host.assign(4 * nzc + 4 * nze, 0.0);
+  d->hy_host.assign(4 * nzc + 4 * nze + 8 * nze, 0.0);
   auto fail = [&](void) { mw_dycore_destroy(d); return 1; };
   if (hipMalloc(&d->hy_dev, d->hy_host.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(hy) failed"); return fail(); }
   fill_params(d);

@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   const int ja = blockIdx.y * chunk;
   const int jb = min(ja + chunk, p.ny);
   const int e = ie % p.nens;
-  const double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
-  const double p0 = p.p0c[k * p.nens + e], ihyt = p.ihytc[k * p.nens + e];
+  const double *hp = p.hypk + (long long)(k * p.nens + e) * 8;
+  const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
   const double *col = S + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;      // row j at col + (j+HY)*sJ
   double *fy = MY + (long long)k * p.fyK + ie;                                               // face j at fy + j*fyJ
   unsigned char *upy = UPY + (long long)k * p.fyK + ie;
@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     // ------------------------------------------------ X direction (cell k = window centre)
     double fxs[5];
     if (xwork) {
-      const double hyr = p.hyc[k * n + e], hyt = p.hytc[k * n + e], p0 = p.p0c[k * n + e], ihyt = p.ihytc[k * n + e];
+      const double *hp = p.hypk + (long long)(k * n + e) * 8;
+      const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
       double we[5], ee[5];
 #pragma unroll
       for (int v = 0; v < 5; v++) {
@@ -380,7 +381,8 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
 #pragma unroll
     for (int l = 0; l < 5; l++) fzs[l] = 0;
     if (zface) {
-      const double hyr = p.hye[k * n + e], hyt = p.hyte[k * n + e], p0 = p.p0e[k * n + e], ihyt = p.ihyte[k * n + e];
+      const double *hp = p.hypk + (long long)(k * n + e) * 8;
+      const double hyr = hp[4], hyt = hp[5], p0 = hp[6], ihyt = hp[7];
       double Lr = ct[idR], Lu = ct[idW], Lt = ct[idT], Rr = be[idR], Ru = be[idW], Rt = be[idT];
       int bcmode = 0;
       if (k == 0) bcmode = 1;                                  // :1020-1038 wall/open edge-value rule
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     // ------------------------------------------------ finalise cell k-1 (it now has its upper z face)
     if (fin) {
       const int kc = k - 1;
-      const double hyc = p.hyc[kc * n + e];
+      const double hyc = p.hypk[(long long)(kc * n + e) * 8];
       const int wi = 1;                                        // window slot that holds level k-1 (window is centred on k)
       const double rho_s = w[idR][wi] + hyc;
       const double rho_n = (STAGE == 1) ? rho_s : snv[idR] + hyc;
