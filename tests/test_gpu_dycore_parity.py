@@ -292,3 +292,39 @@ def test_large_perturbation_takes_the_pow_fallback(mw, oracle):
         dycore.time_step(coupler, dt)
         odyc.time_step(of, dt)
         compare_fields(gpu_fields(coupler), of.as_dict(), 1e-10, "large perturbation step %d" % (step + 1))
+
+
+def test_non_default_gamma_uses_the_generic_pressure(mw, oracle):
+    """cp_d set by the caller (options are only defaulted when absent, :1227-1249): gamma != 1003/716, so the literal series
+    table does not apply and every pressure goes through the generic pow."""
+    from miniweatherml_amd import modules
+    from miniweatherml_amd.coupler import Coupler
+    nx, ny, nz = 16, 12, 10
+    coupler = Coupler("cuda:0")
+    coupler.set_option("out_prefix", "test"); coupler.set_option("init_data", "supercell"); coupler.set_option("out_freq", -1.0)
+    coupler.distribute_mpi_and_allocate_coupled_state(nz, ny, nx, 1)
+    coupler.set_grid(8000., 6000., 20000.)
+    micro, dycore = modules.Microphysics_Kessler(), modules.Dynamics_Euler_Stratified_WenoFV()
+    micro.init(coupler)
+    coupler.set_option("cp_d", 1010.0)                             # after micro.init (which sets 1003), before dycore.init
+    for k in ("cv_d", "gamma_d", "kappa_d", "C0"):
+        if coupler.option_exists(k):
+            coupler.delete_option(k)
+    dycore.init(coupler)
+    p, _ = oracle.make_params(nx, ny, nz, 1, 8000., 6000., 20000.)
+    p.cp_d = 1010.0
+    p.gamma_d = p.cp_d / (p.cp_d - p.R_d)
+    p.kappa_d = p.R_d / p.cp_d
+    p.C0 = oracle.lib().mwo_compute_C0(p.R_d, p.p0, p.kappa_d, p.gamma_d)
+    assert coupler.grid.gamma_d == p.gamma_d and coupler.grid.C0 == p.C0
+    odyc = oracle.OracleDycore(p)
+    of = oracle.Fields(odyc.p)
+    odyc.init("supercell", of)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-13, "init, cp_d = 1010")
+    oracle.perturb_temperature(odyc.p, of.temp)
+    push_fields(coupler, of)
+    dt = dycore.compute_time_step(coupler)
+    for step in range(2):
+        dycore.time_step(coupler, dt)
+        odyc.time_step(of, dt)
+        compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11 if step == 0 else 1e-10, "cp_d = 1010, step %d" % (step + 1))
