@@ -27,6 +27,16 @@ namespace mw {
 // r*qr in the evaporation/fall-speed formulas share one log.  |a log x| <= ~25 here, so the result is within ~3e-15 relative
 // of pow (x = 0 gives exp(-inf) = 0 = pow(0, a) for a > 0).
 __device__ __forceinline__ double pow_pos(double x, double a) { return exp(a * log(x)); }
+// 1/x to full fp64 accuracy (v_rcp_f64 + two Newton steps, 5 instructions; an IEEE division is ~25).  A rain-free cell of the
+// reference's formulas holds ~17 divisions against one exp/log pair and one exp: they dominate, so a/b is evaluated as a*rcp(b)
+// (<= 1.5 ulp from the quotient; the parity tolerance of this module is 1e-12).
+__device__ __forceinline__ double rcp64(double x) {
+#pragma clang fp contract(fast)
+  double r = __builtin_amdgcn_rcp(x);
+  r = r + r * (1.0 - x * r);
+  r = r + r * (1.0 - x * r);
+  return r;
+}
 // The same where x is a rain quantity: rain-free wavefronts (most of the domain) skip the log/exp pair.  exp(a log 0) =
 // exp(-inf) = 0, so the short cut returns exactly what the formula returns; mixed wavefronts evaluate the formula.
 __device__ __forceinline__ double pow_rain(double x, double a) {
@@ -93,8 +103,8 @@ __device__ __forceinline__ double kessler_cell(const KesP &p, int k, double rd, 
   const double rhoqr = 1000., lv = 2.5e6;                     // :247-248
   const int nz = p.nz;
   double r = 0.001 * rd;                                              // :256
-  double rhalf = sqrt(rho0 / rd);                                     // :257
-  double pc = 3.8 / (pp0 * psl);                                      // :258  pow(pk, cp/Rd) = pressure/p0 (pk = (pressure/p0)^(Rd/cp))
+  double rhalf = sqrt(rho0 * rcp64(rd));                              // :257
+  double pc = 3.8 * rcp64(pp0 * psl);                                      // :258  pow(pk, cp/Rd) = pressure/p0 (pk = (pressure/p0)^(Rd/cp))
   double zk = (k + 0.5) * p.dz;
   // sedimentation (:288-299) from pre-update values
   if (k == 0) precl_acc = precl_acc + rho0 * qr * velqr / rhoqr;      // :292 (rho(0,i) qr(0,i) velqr(0,i))
@@ -102,29 +112,31 @@ __device__ __forceinline__ double kessler_cell(const KesP &p, int k, double rd, 
   double sed;
   if (k == nz - 1) {
     double zm = (k - 1 + 0.5) * p.dz;
-    sed = -dt0 * qr * velqr / (0.5 * (zk - zm));                      // :295
+    sed = -dt0 * qr * velqr * rcp64(0.5 * (zk - zm));                 // :295
   } else {
     double zp = (k + 1 + 0.5) * p.dz;
-    sed = dt0 * (flux_above - flux_here) / (r * (zp - zk));           // :297-298
+    sed = dt0 * (flux_above - flux_here) * rcp64(r * (zp - zk));      // :297-298
   }
   // adjustment terms (:302-335)
-  double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.0)) / (1 + dt0 * 2.2 * pow_rain(qr, 0.875));
+  double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.0)) * rcp64(1 + dt0 * 2.2 * pow_rain(qr, 0.875));
   qc = fmax(qc - qrprod, 0.0);
   qr = fmax(qr + qrprod + sed, 0.0);
   double tmp = pk * theta - 36.;
-  double qvs = pc * exp(17.27 * (pk * theta - 273.) / tmp);
-  double prod = (qv - qvs) / (1. + qvs * (4093. * lv / cp) / (tmp * tmp));
+  const double rtmp = rcp64(tmp);
+  double qvs = pc * exp(17.27 * (pk * theta - 273.) * rtmp);
+  double prod = (qv - qvs) * rcp64(1. + qvs * (4093. * lv / cp) * (rtmp * rtmp));
   double tmp1 = 0.0;                                                   // rain-free wavefront: (1.6 + 0) * 0 / (..) * (..) = 0
   if (__any(r * qr != 0.0)) {
     const double lrq = log(r * qr);                                    // one log for the two powers of r*qr
-    tmp1 = dt0 * (((1.6 + 124.9 * exp(0.2046 * lrq)) * exp(0.525 * lrq)) / (2550000. * pc / (3.8 * qvs) + 540000.)) *
-           (fmax(qvs - qv, 0.0) / (r * qvs));
+    const double rqvs = rcp64(qvs);
+    tmp1 = dt0 * (((1.6 + 124.9 * exp(0.2046 * lrq)) * exp(0.525 * lrq)) * rcp64(2550000. * pc * ((1.0 / 3.8) * rqvs) + 540000.)) *
+           (fmax(qvs - qv, 0.0) * (rcp64(r) * rqvs));
   }
   double tmp2 = fmax(-prod - qc, 0.0);
   double tmp3 = qr;
   double ern = fmin(tmp1, fmin(tmp2, tmp3));
   double cond = fmax(prod, -qc);
-  theta = theta + lv / (cp * pk) * (cond - ern);
+  theta = theta + lv * rcp64(cp * pk) * (cond - ern);
   qv = fmax(qv - cond + ern, 0.0);
   qc = qc + cond;
   qr = qr - ern;
@@ -157,10 +169,11 @@ __global__ __launch_bounds__(256) void k_kessler_chunks(KesP p, double *__restri
     const long long nidx = (long long)max(k - 1, k_lo) * p.ncol + i;
     const double rd_n = rho_d[nidx], T_n = temp[nidx], rv_n = rho_v[nidx], rc_n = rho_c[nidx], rr_n = rho_r[nidx], vq_n = velqr_in[nidx];
     double pressure = p.R_d * rd * T_in + p.R_v * rv_in * T_in;          // :141
-    const double pp0 = pressure / p.p0;
+    const double pp0 = pressure * (1.0 / p.p0);
     double pk = pow_pos(pp0, p.R_d / p.cp_d);                            // :142 exner
-    double qv = rv_in / rd, qc = rc_in / rd, qr = rr_in / rd;            // :138-140
-    double theta = T_in / pk;                                            // :143
+    const double ird = rcp64(rd);
+    double qv = rv_in * ird, qc = rc_in * ird, qr = rr_in * ird;         // :138-140
+    double theta = T_in * rcp64(pk);                                     // :143
     double velqr = vq_in;                                                // :260 (k_kessler_prep)
     flux_above = kessler_cell(p, k, rd, rho0, pk, pp0, dt0, flux_above, theta, qv, qc, qr, velqr, precl_acc);
     rho_v[idx] = qv * rd; rho_c[idx] = qc * rd; rho_r[idx] = qr * rd;    // :154-161 [K5]
