@@ -17,8 +17,8 @@ roofline: dominant kernel k_xz_state (x/z WENO reconstruction + Riemann + comple
           per cell and launch: read 5 state + 5 y-tendencies (+ 5 q^n in stages 2,3), write 5 state
           + 2 face mass fluxes + 2 selector bytes = 138 B (stage 1) / 178 B (stages 2,3), 164.7 B on average.
           peak 8 TB/s HBM3E spec.  traffic = measured HBM bytes per launch from profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
-          calibrated with mw_calib_copy).  The whole-pipeline figure (512 B per cell-update) is
-          config.hbm_frac_cell_update.  The kernel is fp64-VALU bound: see roofline.valu_busy_frac.
+          calibrated with mw_calib_copy).  SURVEY.md 8(d)'s own figures are reported beside it: roofline.pipeline (512 B per
+          cell-update) and roofline.flux_stencil_stage (256 B per cell and stage, against one third of the step).  The kernel is fp64-VALU bound: see roofline.valu_busy_frac.
 cpu_baseline: the CPU oracle (a port: the reference itself is unbuildable here) timed on one host core
           on BASELINE.json configs[0] (supercell 200x200x50), rank 0, N = 1 only.
 """
@@ -197,6 +197,14 @@ def main():
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in prof.items()},
             "kernel_ms_per_step_exclusive": ({k: v[0] / 3.0 for k, v in prof_excl.items()} if prof_excl else None),
         }
+        # SURVEY.md 8(d)'s own per-unit figures, next to the dominant kernel's: whole pipeline = 64 V B per cell-update
+        # ("roofline.achieved = cell_updates_per_s x B_alg / 8.0e12"); flux stencil of one stage = 32 V B per cell, priced
+        # against one third of the step (everything a stage does, per GPU)
+        per_gpu = value / world
+        out["roofline"]["pipeline"] = {"alg_bytes_per_cell_update": 64 * V, "achieved": per_gpu * 64 * V / 1e9,
+                                       "frac": per_gpu * 64 * V / 8.0e12}
+        out["roofline"]["flux_stencil_stage"] = {"alg_bytes_per_cell": 32 * V, "achieved": 3.0 * per_gpu * 32 * V / 1e9,
+                                                 "frac": 3.0 * per_gpu * 32 * V / 8.0e12}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         print(json.dumps(out))
