@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nx", type=int, default=400, help="local block, x")
     ap.add_argument("--ny", type=int, default=400, help="local block, y")
