@@ -83,3 +83,41 @@ def test_production_path_equals_general_path_at_size(mw):
         scale = float(out[1][n].abs().max())
         floor = 1e-11 if n in ("uvel", "vvel", "wvel") else 0.0
         assert float((out[0][n] - out[1][n]).abs().max()) <= 1e-10 * scale + floor, n
+
+
+def test_config4_block_per_gpu(mw):
+    """BASELINE.json configs[3]: the per-GPU block of the 8-GPU supercell run, 256 x 512 x 128 with 4 ensemble members
+    (6.7e7 cells, 4.3 GB per slab: byte offsets far beyond 2^32).  Members identical, mass conserved, tracers positive."""
+    from miniweatherml_amd import modules
+    coupler, dycore, _ = modules.make_supercell(256, 512, 128, 4, 256 * 800., 512 * 800., 20000.)
+    dt = dycore.compute_time_step(coupler)
+    m0 = total_mass(coupler)
+    for _ in range(2):
+        dycore.time_step(coupler, dt)
+    assert abs(total_mass(coupler) - m0) <= 1e-11 * m0
+    dm = coupler.get_data_manager_readonly()
+    for n in ("density_dry", "uvel", "wvel", "temp") + tuple(coupler.get_tracer_names()):
+        f = dm.get(n, True)
+        assert bool(torch.isfinite(f).all()), n
+        assert bool((f[..., 0:1] == f).all()), n                  # all four members bit-identical
+    assert float(dm.get("water_vapor", True).min()) >= 0.0
+    del coupler, dycore
+    torch.cuda.empty_cache()
+
+
+def test_config5_city_block(mw):
+    """BASELINE.json configs[4]: simple_city immersed-boundary flow 512 x 512 x 256 (one tracer, gravity off), 5 m spacing."""
+    from miniweatherml_amd import modules
+    coupler, dycore, hs, ta = modules.make_simple_city(512, 512, 256, 1, 2560., 2560., 1280., "city")
+    imm = dycore.immersed_proportion(coupler)
+    frac = float(imm.mean())
+    assert 0.001 < frac < 0.2 and float(imm.max()) == 1.0          # buildings are there (45 x 45 blocks, :1432-1447)
+    for _ in range(2):
+        modules.simple_city_step(coupler, dycore, hs, ta)
+    dm = coupler.get_data_manager_readonly()
+    for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "time_avg_uvel"):
+        assert bool(torch.isfinite(dm.get(n, True)).all()), n
+    u = dm.get("uvel", True)
+    assert 15.0 < float(u.max()) < 40.0 and float(u[imm > 0.5].abs().max()) < float(u.max())   # the flow is being braked inside the buildings
+    del coupler, dycore, hs, ta
+    torch.cuda.empty_cache()
