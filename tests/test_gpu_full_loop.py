@@ -80,3 +80,23 @@ def test_horizontal_sums_are_deterministic(mw):
     for _ in range(3):
         nudger.set_column(coupler)
         assert torch.equal(nudger.column, c0)                           # no atomics: bitwise reproducible
+
+
+def test_default_2d_run_reaches_the_recorded_state_at_step_800(mw):
+    """The reference's default input (experiments/supercell_example/inputs/input_euler3d.yaml: 100 x 1 x 40, CFL dt), complete
+    loop on the GPU for 800 steps: the value ranges SURVEY.md 8(d) recorded from the reference at that step (the same check the
+    CPU oracle passes in tests/test_oracle_full_loop.py).  Long-run evidence for dycore + Kessler + sponge + nudger together."""
+    from miniweatherml_amd import modules
+    from test_oracle_full_loop import RANGES_STEP_800 as R
+    coupler, dycore, micro, nudger = modules.make_supercell(100, 1, 40, 1, 1.0e5, 1.0e5, 2.0e4, with_nudger=True)
+    for _ in range(800):
+        modules.supercell_step(coupler, dycore, micro, nudger)
+    f = gpu_fields(coupler)
+    assert abs(f["density_dry"].min() - R["rho_d"][0]) < 1e-3 and abs(f["density_dry"].max() - R["rho_d"][1]) < 5e-3
+    assert abs(f["temp"].min() - R["T"][0]) < 0.05 and abs(f["temp"].max() - R["T"][1]) < 0.05
+    assert abs(f["uvel"].min() - R["u"][0]) < 0.5 and abs(f["uvel"].max() - R["u"][1]) < 0.5
+    assert abs(f["wvel"].min() - R["w"][0]) < 0.3 and abs(f["wvel"].max() - R["w"][1]) < 0.3
+    assert abs(f["tracer0"].max() - R["rho_v_max"]) < 1e-4
+    assert 0.9 * R["rho_c_max"] < f["tracer1"].max() < 1.1 * R["rho_c_max"]
+    assert 0.6 * R["rho_r_max"] < f["tracer2"].max() < 1.4 * R["rho_r_max"]
+    assert f["tracer1"].min() >= 0 and f["tracer2"].min() >= 0
