@@ -1062,7 +1062,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
 // ---------------------------------------------------------------------------------------------------------------------
 // One RK stage on the production path, as two pipelines on two HIP streams:
 //   state stream  (the handle's stream): halo(state vars) -> k_y_state -> k_xz_state        [fp64-VALU bound]
-//   tracer stream (side stream)        : halo(tracers) -> k_y_tracers -> k_xz_tracers -> k_fct -> k_tracer_update  [HBM/latency bound]
+//   tracer stream (side stream)        : halo(tracers) -> k_y_tracers -> k_tracers_fused -> k_tracer_patch                 [fp64-VALU bound too]
 // The state variables of stage s+1 depend only on the state variables of stage s, so the state pipeline runs ahead
 // while the tracer pipeline of stage s fills the memory system beside it.  Hand-offs: the tracer kernels need the
 // mass fluxes / selectors / new density of their stage (event ev_state); the state pipeline may not run more than

@@ -652,9 +652,9 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Fused tracer stage (<= 4 tracers, nens <= 7): x/z fluxes + FCT + flux divergence + SSPRK3 combine (+ D13) in ONE marching
+// Fused tracer stage (<= 4 tracers, nens <= 12): x/z fluxes + FCT + flux divergence + SSPRK3 combine (+ D13) in ONE marching
 // kernel -- the x/z tracer fluxes never go to HBM and the separate update pass disappears.
-//   pipeline per wave (row j, 64 fused-x lanes, 4 n halo lanes per side), marching k:
+//   pipeline per wave (row j, 64 fused-x lanes, 4 halo cells per side with nens == 1, 2 with nens > 1), marching k:
 //     S1(k)   : x-face fluxes of level k, z-face flux k                       (registers)
 //     S2(k-1) : all six face fluxes of cell k-1 are known -> FCT multiplier; x faces and z face k-1 scaled by their donors'
 //               multipliers (west/east lanes by DPP, level k-2 carried); partial tendency P = -dFx/dx - dFy/dy
