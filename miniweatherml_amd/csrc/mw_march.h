@@ -135,9 +135,11 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
     double se[5], ne[5];
 #pragma unroll
     for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
-    if (j >= ja) {
+    {                                                          // (computed on the ghost iteration j = ja-1 too: only the stores are predicated)
+      const bool face = (j >= ja);
+      const int jc = max(j, 0);
       // face j: L = north edge of cell j-1 (cn), R = south edge of cell j (se)
-      const int bcmode = bc_mode_y(p, j);
+      const int bcmode = bc_mode_y(p, jc);
       const bool zero = (bcmode == 1 || bcmode == 2) && (p.bc_y == MW_BC_WALL);
       if (__builtin_expect(bcmode == 3, 0)) {
 #pragma unroll
@@ -158,8 +160,7 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
         f[idU] = fs.m_upw * (up ? sU : cU);
         f[idW] = fs.m_upw * (up ? sW : cW);
       }
-      fy[(long long)j * p.fyJ] = fs.m_upw;
-      upy[(long long)j * p.fyJ] = (unsigned char)up;
+      if (face) { fy[(long long)j * p.fyJ] = fs.m_upw; upy[(long long)j * p.fyJ] = (unsigned char)up; }
       if (j > ja) {
 #pragma unroll
         for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fprev[l]) * p.rdy;
