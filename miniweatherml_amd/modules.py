@@ -477,9 +477,9 @@ def dycore_output(coupler, etime, fmt=5, barrier=None):
     """Dynamics_Euler_Stratified_WenoFV::output(coupler, etime), dynamics_euler_stratified_wenofv.h:2019-2191, shared-file
     branch (:2092-2188): one CDF-5 file `<out_prefix>.nc`, dims x,y,z (global sizes) and unlimited t, variables x,y,z,t and
     one (t,z,y,x) double variable per coupler field (ensemble member 0).  etime == 0 creates the file (main rank), later calls
-    append a record.  `file_per_process` (:2038-2090) writes NetCDF-4/HDF5 files in the reference and is not provided."""
+    append a record.  `file_per_process` (:2038-2090): see _dycore_output_per_process."""
     if coupler.get_option("file_per_process", False):
-        endrun("output: file_per_process needs the NetCDF-4/HDF5 writer, which is not provided; use the shared file")
+        return _dycore_output_per_process(coupler, etime, fmt)
     barrier = barrier or (lambda: _barrier(coupler))
     path = str(coupler.get_option("out_prefix")) + ".nc"
     names = ["density_dry", "uvel", "vvel", "wvel", "temp"] + list(coupler.get_tracer_names())
@@ -517,6 +517,38 @@ def dycore_output(coupler, etime, fmt=5, barrier=None):
         nc.set_numrecs(rec + 1)                                                # ... before the record becomes visible
     nc.close()
     barrier()
+
+
+def _dycore_output_per_process(coupler, etime, fmt=5):
+    """The `file_per_process` branch (:2038-2090): every rank writes `<out_prefix>_<rank, 8 digits>.nc` with its LOCAL x/y sizes
+    and its own coordinate values; no communication.  (The reference's SimpleNetCDF produces a NetCDF-4 container here; this
+    writer produces the classic CDF-5 layout with the same dimensions, variables and values.)"""
+    path = "%s_%08d.nc" % (coupler.get_option("out_prefix"), coupler.get_myrank())
+    names = ["density_dry", "uvel", "vvel", "wvel", "temp"] + list(coupler.get_tracer_names())
+    g = coupler.grid
+    xs, ys, zs = _coords(coupler)
+    local = capi.Grid.from_buffer_copy(g)                                       # hyperslab offsets are local in a per-rank file
+    local.i_beg, local.j_beg = 0, 0
+    if etime == 0:
+        nc = _NcFile(path, True, fmt)
+        dx_, dy_, dz_, dt_ = nc.def_dim("x", g.nx), nc.def_dim("y", g.ny), nc.def_dim("z", g.nz), nc.def_dim("t", 0)
+        for n_, d_ in (("x", [dx_]), ("y", [dy_]), ("z", [dz_]), ("t", [dt_])):
+            nc.def_var(n_, d_)
+        for n_ in names:
+            nc.def_var(n_, [dt_, dz_, dy_, dx_])
+        nc.enddef()
+        nc.put(nc.varid("x"), [0], [g.nx], xs); nc.put(nc.varid("y"), [0], [g.ny], ys); nc.put(nc.varid("z"), [0], [g.nz], zs)
+        rec = 0
+    else:
+        nc = _NcFile(path, False)
+        rec = nc.dimlen("t")
+    nc.put(nc.varid("t"), [rec], [1], [float(etime)])
+    dm = coupler.get_data_manager_readonly()
+    for n_ in names:
+        with torch.cuda.device(coupler.device):
+            check(capi.lib().mw_output_put_field(nc.h, nc.varid(n_), rec, C.byref(local), _ptr(dm.get(n_)), _stream_ptr(coupler.device)))
+    nc.set_numrecs(rec + 1)
+    nc.close()
 
 
 Dynamics_Euler_Stratified_WenoFV.output = lambda self, coupler, etime, **kw: dycore_output(coupler, etime, **kw)

@@ -131,3 +131,19 @@ def test_output_from_two_ranks_into_one_file(mw, oracle, tmp_path):
         for rec in range(2):
             assert np.array_equal(r.get(name)[rec], ref[key][..., 0]), name
     assert np.array_equal(r.get("y"), (np.arange(12) + 0.5) * 500.0) and list(r.get("t")) == [0.0, 12.5]
+
+
+def test_file_per_process_output(mw, tmp_path):
+    """The file_per_process branch (:2038-2090): one file per rank with local sizes and the rank's own coordinates."""
+    from miniweatherml_amd import modules
+    prefix = str(tmp_path / "fpp")
+    ranks = [modules.make_supercell(16, 12, 6, 1, 8000., 6000., 20000., nranks=2, myrank=r) for r in range(2)]
+    for r, (c, d, _) in enumerate(ranks):
+        c.set_option("out_prefix", prefix)
+        c.set_option("file_per_process", True)
+        d.output(c, 0.0)
+        d.output(c, 3.5)
+        rd = cdf.Reader("%s_%08d.nc" % (prefix, r))
+        assert rd.numrecs == 2 and rd.dims == [("x", 16), ("y", 6), ("z", 6), ("t", 0)] and list(rd.get("t")) == [0.0, 3.5]
+        assert np.array_equal(rd.get("y"), (np.arange(6) + 6 * r + 0.5) * 500.0)
+        assert np.array_equal(rd.get("temp")[1], gpu_fields(c)["temp"][..., 0])
