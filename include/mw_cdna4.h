@@ -118,6 +118,11 @@ double mw_dycore_get_etime(mw_dycore_t h);   /* member etime, :55 */
 int  mw_dycore_profile(mw_dycore_t h, int enable);
 int  mw_dycore_profile_get(mw_dycore_t h, int which, double *total_ms, long long *launches);
 
+/* Diagnostic: weno::WenoLimiter<5>::compute_limited_coefs + coefs_to_gll_lower<5,2> (WenoLimiter.h:68-93, TransformMatrices.h:1132-1144)
+ * on n caller-supplied 5-cell stencils (DEVICE (n,5)) -> the two edge values (DEVICE (n,2)); strict = 1: the reference's operation
+ * order with contraction off, 0: the production arithmetic (mw_weno.h). */
+int  mw_weno5_edges(long long n, const double *stencils, double *edges, int strict, void *stream);
+
 /* Measurement aid (no reference counterpart): copies n doubles with this library's access shape (8 B per lane).  A launch
  * moves exactly 8n bytes each way, which calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE counters (tools/calib_pmc.py). */
 int  mw_calib_copy(const double *in, double *out, long long n, void *stream);

@@ -714,6 +714,17 @@ __global__ __launch_bounds__(256) void k_perturb_temperature(int nz, int ny, int
 
 // Streaming copy with this library's access shape (8 bytes per lane, consecutive lanes consecutive doubles): the known-byte
 // workload used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950 (MI355X_MICROARCH.md, HBM section).
+// Diagnostic: the device WENO-5 routines on caller-supplied stencils (unit test of the core arithmetic against the golden vectors)
+__global__ __launch_bounds__(256) void k_weno5_edges(const double *__restrict__ st, double *__restrict__ out, long long n, int strict) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const double *s = st + t * 5;
+  double l, r;
+  if (strict) weno5_edges_strict(s[0], s[1], s[2], s[3], s[4], l, r);
+  else        weno5_edges_fast(s[0], s[1], s[2], s[3], s[4], l, r);
+  out[t * 2] = l; out[t * 2 + 1] = r;
+}
+
 __global__ __launch_bounds__(256) void k_calib_copy(const double *__restrict__ in, double *__restrict__ out, long long n) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = in[i];
@@ -1339,6 +1350,14 @@ int mw_dycore_compute_tendencies(mw_dycore_t d, const double *rho_d, const doubl
   if (launch_fct(d, d->S0, dt)) return 1;
   d->flux_src = nullptr;
   if (state_tend && tracers_tend) { if (launch_update<1, 2>(d, d->S0, d->S0, nullptr, dt, dt, c, state_tend, tracers_tend)) return 1; }
+  return 0;
+}
+
+int mw_weno5_edges(long long n, const double *stencils, double *edges, int strict, void *stream) {
+  if (n < 1 || !stencils || !edges) MW_FAIL("weno5_edges: bad argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipLaunchKernelGGL(k_weno5_edges, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stencils, edges, n, strict);
+  MW_LAUNCH_CHECK();
   return 0;
 }
 

@@ -1,0 +1,75 @@
+"""Regenerates tests/golden/oracle_vectors.json: input/output VECTORS of the CPU oracle for the pieces SURVEY.md 8(c) lists --
+WENO-5 stencils, hydrostatic columns, Kessler states (incl. a heavy-rain set with rainsplit > 1) and surrogate-MLP rows.
+ORACLE SELF-SNAPSHOTS (regression guard for oracle/mw_oracle.cpp and a GPU check that does not need the oracle at run time);
+the reference-run numbers are baseline_known_answers.json.
+
+    python tests/golden/make_oracle_vectors.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import mw_oracle as O  # noqa: E402
+
+
+def weno_vectors():
+    rng = np.random.default_rng(42)
+    st = [[1.0] * 5, [0.0] * 5, [1, 2, 3, 4, 5], [5, 4, 3, 2, 1], [0, 0, 0, 1, 1], [1, 1, 0, 0, 0], [0, 0, 1, 0, 0],
+          [1, 4, 9, 16, 25], [1, 16, 81, 256, 625], [1e-30, 2e-30, -1e-30, 3e-30, 0.0], [-1, 2, -3, 4, -5], [300.0, 300.0, 300.1, 300.0, 299.9]]
+    for _ in range(26):
+        st.append(rng.normal(size=5).tolist())
+    for _ in range(26):
+        st.append((1.0 + 1e-3 * rng.normal(size=5)).tolist())                 # smooth data: near-ideal weights
+    out = []
+    for s in st:
+        coefs, gll = O.weno5(np.array(s, dtype=np.float64))
+        out.append({"stencil": [float(x) for x in s], "coefs": coefs.tolist(), "gll": gll.tolist()})
+    return out
+
+
+def hydrostatic():
+    out = {}
+    for nz in (16, 40, 50, 100):
+        dyc, f = O.supercell_setup(8, 1, nz, 1, 8000., 1.0e5, 20000., perturb=False)
+        out[str(nz)] = {k: v[:, 0].tolist() for k, v in dyc.hy().items()}
+    return out
+
+
+def kessler_vectors():
+    out = {}
+    for name, dt, nz, ncol, rain in (("moderate", 2.0, 20, 8, 3e-4), ("heavy_rainsplit", 90.0, 24, 6, 8e-3)):
+        rng = np.random.default_rng(7 if name == "moderate" else 8)
+        dyc, f = O.supercell_setup(ncol, 1, nz, 1, 500.0 * ncol, 1.0e5, 20000., perturb=False)
+        rho_d, temp, rho_v = f.rho_d.copy(), f.temp.copy(), f.tracers[0].copy()
+        rho_c = 2e-3 * rho_d * (rng.uniform(size=rho_d.shape) > 0.5) * rng.uniform(size=rho_d.shape)
+        rho_r = rain * rho_d * (rng.uniform(size=rho_d.shape) > 0.4) * rng.uniform(size=rho_d.shape)
+        temp = temp + rng.normal(size=temp.shape)
+        before = {"rho_d": rho_d, "temp": temp.copy(), "rho_v": rho_v.copy(), "rho_c": rho_c.copy(), "rho_r": rho_r.copy()}
+        precl = np.zeros((1, ncol, 1))
+        rs = O.kessler_time_step(20000. / nz, dt, rho_v, rho_c, rho_r, rho_d, temp, precl)
+        after = {"temp": temp, "rho_v": rho_v, "rho_c": rho_c, "rho_r": rho_r, "precl": precl}
+        out[name] = {"dt": dt, "dz": 20000. / nz, "nz": nz, "ncol": ncol, "rainsplit": int(rs),
+                     "before": {k: v.ravel().tolist() for k, v in before.items()}, "after": {k: v.ravel().tolist() for k, v in after.items()}}
+    return out
+
+
+def mlp_vectors():
+    from miniweatherml_amd import modules                                       # the shipped weight export (data only)
+    W1, b1, W2, b2, si, so = modules.load_surrogate_weights()
+    rng = np.random.default_rng(9)
+    n = 192
+    ins = [si[i, 0] + (si[i, 1] - si[i, 0]) * rng.uniform(-0.1, 1.1, n) for i in range(5)]      # a little outside the training range too
+    outs = O.mlp_forward(*[np.ascontiguousarray(a) for a in ins], W1, b1, W2, b2, si, so)
+    return {"inputs": [a.tolist() for a in ins], "outputs": [a.tolist() for a in outs]}
+
+
+if __name__ == "__main__":
+    data = {"weno5": weno_vectors(), "hydrostatic": hydrostatic(), "kessler": kessler_vectors(), "mlp": mlp_vectors()}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_vectors.json")
+    with open(path, "w") as fh:
+        json.dump(data, fh, sort_keys=True)
+    print("wrote", path, os.path.getsize(path), "bytes")

@@ -1,0 +1,53 @@
+"""CPU: the oracle reproduces the committed vectors of tests/golden/oracle_vectors.json bit for bit (regression guard for
+oracle/mw_oracle.cpp -- a change of the oracle cannot go unnoticed), plus closed-form properties of those vectors."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+VEC = json.load(open(os.path.join(HERE, "golden", "oracle_vectors.json")))
+
+
+def test_weno5_vectors(oracle):
+    for v in VEC["weno5"]:
+        coefs, gll = oracle.weno5(np.array(v["stencil"]))
+        assert coefs.tolist() == v["coefs"] and gll.tolist() == v["gll"], v["stencil"]
+    # polynomial data of degree <= 2 is reproduced exactly at the edges (WenoLimiter: all candidates agree)
+    quad = next(v for v in VEC["weno5"] if v["stencil"] == [1.0, 4.0, 9.0, 16.0, 25.0])
+    # cell means of (x+3)^2 + 1/12 ... : the edge values of the mean-preserving parabola at x = 2.5 / 3.5 of q(x) = x^2 - 1/12
+    assert abs(quad["gll"][0] - (2.5 ** 2 - 1.0 / 12)) < 1e-12 and abs(quad["gll"][1] - (3.5 ** 2 - 1.0 / 12)) < 1e-12
+    const = next(v for v in VEC["weno5"] if v["stencil"] == [1.0] * 5)
+    assert max(abs(g - 1.0) for g in const["gll"]) <= 2.3e-16                   # the reference operation order is 1 ulp off here
+
+
+def test_hydrostatic_columns(oracle):
+    for nz, cols in VEC["hydrostatic"].items():
+        dyc, f = oracle.supercell_setup(8, 1, int(nz), 1, 8000., 1.0e5, 20000., perturb=False)
+        hy = dyc.hy()
+        for k, a in cols.items():
+            assert hy[k][:, 0].tolist() == a, (nz, k)
+        assert np.all(np.diff(cols["hy_dens_cells"]) < 0) and len(cols["hy_dens_edges"]) == int(nz) + 1
+
+
+def test_kessler_vectors(oracle):
+    for name, v in VEC["kessler"].items():
+        nz, ncol = v["nz"], v["ncol"]
+        a = {k: np.array(x).reshape(nz, ncol, 1, 1) for k, x in v["before"].items()}
+        precl = np.zeros((1, ncol, 1))
+        rs = oracle.kessler_time_step(v["dz"], v["dt"], a["rho_v"], a["rho_c"], a["rho_r"], a["rho_d"], a["temp"], precl)
+        assert rs == v["rainsplit"]
+        for k in ("temp", "rho_v", "rho_c", "rho_r"):
+            assert a[k].ravel().tolist() == v["after"][k], (name, k)
+        assert precl.ravel().tolist() == v["after"]["precl"]
+    assert VEC["kessler"]["moderate"]["rainsplit"] == 1 and VEC["kessler"]["heavy_rainsplit"]["rainsplit"] > 1
+
+
+def test_mlp_vectors(oracle):
+    from miniweatherml_amd import modules
+    W1, b1, W2, b2, si, so = modules.load_surrogate_weights()
+    ins = [np.array(a) for a in VEC["mlp"]["inputs"]]
+    outs = oracle.mlp_forward(*ins, W1, b1, W2, b2, si, so)
+    for got, want in zip(outs, VEC["mlp"]["outputs"]):
+        assert got.tolist() == want
+    assert min(min(o) for o in VEC["mlp"]["outputs"][1:]) >= 0.0               # densities are clipped at 0 (:199-201)
