@@ -15,8 +15,8 @@
 namespace mw {
 
 // `x_fp` literals in the reference are long double -> double (main_header.h:61-63).  All constants used by
-// WenoLimiter<5> are rationals whose double rounding is the same either way (verified on the host by
-// tests/test_constants.py against the oracle's long-double route), so plain double literals are exact here.
+// WenoLimiter<5> are rationals whose double rounding is the same either way (tests/test_gpu_golden_vectors.py: the strict
+// routine below reproduces vectors computed through the long-double route bit for bit), so plain double literals are exact here.
 #define MW_C(x) (x)
 
 // convexified ideal weights idl = (1,2,1,1000)/1004  (WenoLimiter.h:55-66); computed with the reference's

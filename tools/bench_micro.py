@@ -1,5 +1,5 @@
-"""Kessler and surrogate-MLP throughput on the supercell 400x400x100 grid (BASELINE.json configs[1]/[2] sizes), with the
-CPU oracle timed beside them on a bounded sample.  Prints one JSON object; results are quoted in DESIGN.md section 5.
+"""Kessler and surrogate-MLP throughput on the supercell 400x400x100 grid (BASELINE.json configs[1]/[2] sizes), GPU only
+(the CPU oracle is test infrastructure: tests/bench_oracle_micro.py times it).  Prints one JSON object; results are quoted in DESIGN.md section 5.
     python tools/bench_micro.py [--nx 400 --ny 400 --nz 100 --iters 20]"""
 import argparse
 import json
@@ -8,14 +8,13 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 from miniweatherml_amd import modules
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--nx", type=int, default=400); ap.add_argument("--ny", type=int, default=400); ap.add_argument("--nz", type=int, default=100)
 ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--no-cpu", action="store_true")
+ap.add_argument("--no-cpu", action="store_true", help="(kept for old command lines; the CPU oracle is timed by tests/bench_oracle_micro.py)")
 a = ap.parse_args()
 
 coupler, dycore, micro = modules.make_supercell(a.nx, a.ny, a.nz, 1, 500.0 * a.nx, 500.0 * a.ny, 20000.)
@@ -78,22 +77,4 @@ res = {"grid": [a.nx, a.ny, a.nz], "cells": ncell,
                    "one_storm": {"s_per_call": t_kc, "cells_per_s": ncell / t_kc, "frac_of_8TBps": ncell * (72 + 8.0 / a.nz) / t_kc / 8e12}},
        "mlp": {"s_per_call": t_m, "cells_per_s": ncell / t_m, "alg_bytes_per_cell": 72, "hbm_GBps_alg": ncell * 72 / t_m / 1e9,
                "frac_of_8TBps": ncell * 72 / t_m / 8e12, "fp32_gflops_nominal": ncell * 208 / t_m / 1e9}}
-if not a.no_cpu:
-    from oracle import mw_oracle as O
-    nxs, nys = 100, 100
-    dyc, f = O.supercell_setup(nxs, nys, a.nz, 1, 500.0 * nxs, 500.0 * nys, 20000.)
-    rng = np.random.default_rng(1)
-    f.tracers[1][...] = rng.uniform(0, 2e-3, f.rho_d.shape) * (rng.uniform(size=f.rho_d.shape) > 0.6) * f.rho_d
-    f.tracers[2][...] = rng.uniform(0, 3e-4, f.rho_d.shape) * (rng.uniform(size=f.rho_d.shape) > 0.6) * f.rho_d
-    precl = np.zeros((nys, nxs, 1))
-    t0 = time.perf_counter()
-    for _ in range(5):
-        O.kessler_time_step(20000. / a.nz, dt, f.tracers[0], f.tracers[1], f.tracers[2], f.rho_d, f.temp, precl)
-    tk = (time.perf_counter() - t0) / 5
-    t0 = time.perf_counter()
-    for _ in range(5):
-        O.mlp_forward(f.temp, f.rho_d, f.tracers[0], f.tracers[1], f.tracers[2], W1, b1, W2, b2, si, so)
-    tm = (time.perf_counter() - t0) / 5
-    res["cpu_oracle_1core"] = {"sample_cells": nxs * nys * a.nz, "kessler_cells_per_s": nxs * nys * a.nz / tk,
-                               "mlp_cells_per_s": nxs * nys * a.nz / tm}
 print(json.dumps(res))
