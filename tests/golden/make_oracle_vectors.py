@@ -67,8 +67,28 @@ def mlp_vectors():
     return {"inputs": [a.tolist() for a in ins], "outputs": [a.tolist() for a in outs]}
 
 
+def astats(a):
+    import math
+    a = np.asarray(a, dtype=np.float64).ravel()
+    return {"min": float(a.min()), "max": float(a.max()), "sum": math.fsum(a.tolist()), "sumsq": math.fsum((a * a).tolist())}
+
+
+def tendency_stats():
+    """One compute_tendencies (stage 1) on two small grids: per-variable statistics of the tendencies and of the six flux arrays."""
+    out = {}
+    for name, (nx, ny, nz) in (("supercell3d_16x16x8", (16, 16, 8)), ("supercell2d_24x1x16", (24, 1, 16))):
+        dyc, f = O.supercell_setup(nx, ny, nz, 1, 500.0 * nx, 500.0 * max(ny, 2) if ny > 1 else 1.0e5, 20000.)
+        dt = dyc.compute_time_step()
+        st, tt = dyc.stage_tendencies(f, dt)
+        fl = dyc.fluxes()
+        out[name] = {"grid": [nx, ny, nz], "state_tend": [astats(st[v]) for v in range(5)], "tracers_tend": [astats(tt[v]) for v in range(3)],
+                     "fluxes": {k: [astats(a[v]) for v in range(a.shape[0])] for k, a in fl.items()}}
+    return out
+
+
 if __name__ == "__main__":
-    data = {"weno5": weno_vectors(), "hydrostatic": hydrostatic(), "kessler": kessler_vectors(), "mlp": mlp_vectors()}
+    data = {"weno5": weno_vectors(), "hydrostatic": hydrostatic(), "kessler": kessler_vectors(), "mlp": mlp_vectors(),
+            "tendencies": tendency_stats()}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_vectors.json")
     with open(path, "w") as fh:
         json.dump(data, fh, sort_keys=True)

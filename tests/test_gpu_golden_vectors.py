@@ -65,3 +65,32 @@ def test_mlp_on_the_golden_rows(mw):
     for i, (got, want) in enumerate(zip(outs, VEC["mlp"]["outputs"])):
         rng = so[i, 1] - so[i, 0]
         assert np.max(np.abs(got.cpu().numpy() - np.array(want))) <= 1e-5 * abs(rng), i
+
+
+@pytest.mark.parametrize("name", sorted(VEC["tendencies"]))
+def test_stage_tendencies_and_fluxes_against_the_golden_statistics(mw, name):
+    """mw_dycore_compute_tendencies + the six public flux arrays on the strict path: sum, sum of squares, min and max of every
+    variable's tendency and flux array against the committed oracle statistics (no oracle at run time)."""
+    import math
+    from miniweatherml_amd import modules
+    v = VEC["tendencies"][name]
+    nx, ny, nz = v["grid"]
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 500.0 * nx, 500.0 * max(ny, 2) if ny > 1 else 1.0e5, 20000.)
+    dycore.set_strict(1)
+    dt = dycore.compute_time_step(coupler)
+    st, tt = dycore.compute_tendencies(coupler, dt)
+    fl = {k: a.cpu().numpy() for k, a in dycore.fluxes(coupler).items()}
+
+    def check(arr, want, what, scale):
+        a = np.asarray(arr, dtype=np.float64).ravel()
+        got = {"min": float(a.min()), "max": float(a.max()), "sum": math.fsum(a.tolist()), "sumsq": math.fsum((a * a).tolist())}
+        n = a.size
+        assert abs(got["min"] - want["min"]) <= 1e-11 * scale and abs(got["max"] - want["max"]) <= 1e-11 * scale, what
+        assert abs(got["sum"] - want["sum"]) <= 1e-11 * scale * n and abs(got["sumsq"] - want["sumsq"]) <= 1e-10 * scale * scale * n, what
+    for grp, arrs, wants in (("state_tend", st.cpu().numpy(), v["state_tend"]), ("tracers_tend", tt.cpu().numpy(), v["tracers_tend"])):
+        for i, w in enumerate(wants):
+            check(arrs[i], w, (grp, i), max(abs(w["min"]), abs(w["max"]), 1e-30))
+    for k, wants in v["fluxes"].items():
+        for i, w in enumerate(wants):
+            scale = max(max(abs(x["min"]), abs(x["max"])) for d in "xyz" for x in [v["fluxes"][k[:-1] + d][i]])
+            check(fl[k][i], w, (k, i), max(scale, 1e-30))

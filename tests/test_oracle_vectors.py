@@ -51,3 +51,23 @@ def test_mlp_vectors(oracle):
     for got, want in zip(outs, VEC["mlp"]["outputs"]):
         assert got.tolist() == want
     assert min(min(o) for o in VEC["mlp"]["outputs"][1:]) >= 0.0               # densities are clipped at 0 (:199-201)
+
+
+def _astats(a):
+    import math
+    a = np.asarray(a, dtype=np.float64).ravel()
+    return {"min": float(a.min()), "max": float(a.max()), "sum": math.fsum(a.tolist()), "sumsq": math.fsum((a * a).tolist())}
+
+
+def test_stage_tendencies_and_fluxes(oracle):
+    for name, v in VEC["tendencies"].items():
+        nx, ny, nz = v["grid"]
+        dyc, f = oracle.supercell_setup(nx, ny, nz, 1, 500.0 * nx, 500.0 * max(ny, 2) if ny > 1 else 1.0e5, 20000.)
+        dt = dyc.compute_time_step()
+        st, tt = dyc.stage_tendencies(f, dt)
+        assert [_astats(st[i]) for i in range(5)] == v["state_tend"] and [_astats(tt[i]) for i in range(3)] == v["tracers_tend"], name
+        for k, a in dyc.fluxes().items():
+            assert [_astats(a[i]) for i in range(a.shape[0])] == v["fluxes"][k], (name, k)
+    # a 2-D run has no y fluxes and no v tendency (:443-450, :527)
+    two_d = VEC["tendencies"]["supercell2d_24x1x16"]
+    assert all(s["min"] == 0.0 and s["max"] == 0.0 for s in two_d["fluxes"]["state_flux_y"]) and two_d["state_tend"][2]["sumsq"] == 0.0
