@@ -1048,7 +1048,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
   const DyP &p = d->p;
   {
     ProfScope ps(d, 7, st);
-    const int U = p.nens == 1 ? 56 : 64 - 4 * p.nens;           // 4 / 2 halo cells per side (k_tracers_fused)
+    const int U = p.nens == 1 ? 58 : 64 - 4 * p.nens;   // 3 / 2 halo cells per side (k_tracers_fused)
     const int tiles_x = (p.nx * p.nens + U - 1) / U;
     const int rows4 = p.ny >= 4 ? 1 : 0;
     const long long waves = (long long)p.ny * tiles_x;

@@ -38,6 +38,13 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
+// The same shift, but the edge lane (no source lane) keeps `old` instead of reading 0.
+template <int CTRL> __device__ __forceinline__ double dpp_mov_old(double old, double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 // value held by the lane n lanes to the west (lower x) / east (higher x)
 template <bool N1> __device__ __forceinline__ double from_west(double v, int lane, int n) {
   if (N1) return dpp_mov<0x138>(v);            // wave_shr:1
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
 // ---------------------------------------------------------------------------------------------------------------
 // Fused tracer stage (<= 4 tracers, nens <= 12): x/z fluxes + FCT + flux divergence + SSPRK3 combine (+ D13) in ONE marching
 // kernel -- the x/z tracer fluxes never go to HBM and the separate update pass disappears.
-//   pipeline per wave (row j, 64 fused-x lanes, 4 halo cells per side with nens == 1, 2 with nens > 1), marching k:
+//   pipeline per wave (row j, 64 fused-x lanes, 3 halo cells per side with nens == 1 (+ one loaded cell), 2 with nens > 1), marching k:
 //     S1(k)   : x-face fluxes of level k, z-face flux k                       (registers)
 //     S2(k-1) : all six face fluxes of cell k-1 are known -> FCT multiplier; x faces and z face k-1 scaled by their donors'
 //               multipliers (west/east lanes by DPP, level k-2 carried); partial tendency P = -dFx/dx - dFy/dy
@@ -678,8 +685,11 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   constexpr int t0 = 0;                                       // one group: all (<= 4) tracers of the cell
   const int lane = threadIdx.x & 63;
   const int NXI = p.nx * n;
-  const int hw = N1 ? 4 : 2;                                  // halo cells per side (see xz_geom: DPP shifts vs. neighbour loads; patching only
-                                                              // the edge lanes of the DPP variant from memory was measured: 20 % slower)
+  // halo cells per side.  nens == 1 (DPP shifts): the multiplier of the cell next to the updated range needs the x flux of
+  // its outer face, whose upwind reconstruction reaches a 4th cell -- lanes 0 and 63 load that cell (a clamped all-lane load
+  // issued first in the iteration) and the DPP shift hands it on as its edge fill, so 3 lanes per side are enough
+  // (58 cells per wave: 7 instead of 8 waves per 400-cell row).  nens > 1: neighbour loads, 2 cells per side.
+  const int hw = N1 ? 3 : 2;
   const int U = 64 - 2 * hw * n;
   int j, tx;
   if (rows4) { const int jg = (int)(blockIdx.x / tiles_x); tx = (int)(blockIdx.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
@@ -697,6 +707,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const int op1 = min(q + n, NXI + 3 * n - 1) - qq, op2 = min(q + 2 * n, NXI + 3 * n - 1) - qq;
   const int qm = interior ? q : 0;
   const int qf = (q >= 0 && q < NXI + n) ? q : 0;
+  const int opatch = (lane == 0) ? max(q - 1, -3) - qq : (lane == 63) ? min(q + 1, NXI + 2) - qq : 0;
   const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qq;
   const long long so_row = (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qm;     // + (k+HZ)*sK + l*sV
   const long long fxo = (long long)j * p.fxJ + qf;
@@ -728,6 +739,9 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     const int kpc = min(max(kp, 0), p.nz - 1), kuc = min(max(ku, 0), p.nz - 1);
     // ------------------------------------------------ loads of this iteration
     const int kn = min(k + 3, p.nz + p.HZ - 1);
+    double xpatch[T];                                            // level k, the cell beyond lane 0 / lane 63 (first: needed first)
+#pragma unroll
+    for (int v = 0; v < T; v++) xpatch[v] = N1 ? col[(long long)v * p.sV + (long long)(kx + p.HZ) * p.sK + opatch] : 0.0;
 #pragma unroll
     for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
     const double mx = MX[(long long)kx * p.fxK + fxo];
@@ -774,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       for (int v = 0; v < T; v++) {
         double c0 = w[v][2], m2 = nbw2[v], m1 = nbw1[v], p1 = nbe1[v], p2 = nbe2[v];
         if (N1) {                                              // whole-wave DPP shifts
-          m1 = from_west<true>(c0, lane, 1); p1 = from_east<true>(c0, lane, 1);
+          m1 = dpp_mov_old<0x138>(xpatch[v], c0); p1 = dpp_mov_old<0x130>(xpatch[v], c0);   // lanes 0 / 63 keep the loaded cell
           m2 = from_west<true>(m1, lane, 1); p2 = from_east<true>(p1, lane, 1);
         }
         double we, ee;
