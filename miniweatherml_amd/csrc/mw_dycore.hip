@@ -925,6 +925,16 @@ static int pick_chunk(int n, long long base_waves, const char *env) {
   return std::min(n, 8);
 }
 
+// Equal z chunks for the marching x/z kernels: enough of them for ~5 rounds of 2 waves/SIMD over the 1024 SIMDs, none shorter
+// than 8 levels (every chunk re-primes its pipeline).
+static int balanced_chunk(int nz, long long base_waves, const char *env) {
+  const char *s = getenv(env);
+  if (s && atoi(s) > 0) return std::min(nz, atoi(s));
+  long long nch = std::max(1ll, (10000 + base_waves - 1) / base_waves);
+  nch = std::min<long long>(nch, std::max(1, nz / 8));
+  return (int)((nz + nch - 1) / nch);
+}
+
 static int launch_y_state(mw_dycore_s *d, const double *S, int par) {
   const DyP &p = d->p;
   if (p.sim2d) return 0;
@@ -967,10 +977,7 @@ static int xz_grid(mw_dycore_s *d, dim3 &grid, int &chunk, int &tiles_x) {
   if (!d->chunk_z) {
     // k_xz_state: equal chunks, enough of them for ~5 rounds of 2 waves/SIMD over the 1024 SIMDs (measured on 400x400x100:
     // 4 x 25 levels beats 32,32,32,4 by 4 %)
-    const char *s = getenv("MW_CHUNK_Z");
-    if (s && atoi(s) > 0) d->chunk_z = std::min(p.nz, atoi(s));
-    else { long long nch = std::max(1ll, (10000 + waves - 1) / waves); nch = std::min<long long>(nch, std::max(1, p.nz / 8));
-           d->chunk_z = (int)((p.nz + nch - 1) / nch); }
+    d->chunk_z = balanced_chunk(p.nz, waves, "MW_CHUNK_Z");
   }
   chunk = d->chunk_z;
   grid = dim3((unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
@@ -1052,7 +1059,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
     const int tiles_x = (p.nx * p.nens + U - 1) / U;
     const int rows4 = p.ny >= 4 ? 1 : 0;
     const long long waves = (long long)p.ny * tiles_x;
-    const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = pick_chunk(p.nz, waves, "MW_CHUNK_F"));
+    const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F"));
     dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
 #define MW_FUSED_CASE(TT) \
     case TT: if (p.nens == 1) launch_tracers_fused_t<STAGE, MODE, TT, true>(d, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); \
