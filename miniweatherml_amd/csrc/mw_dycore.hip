@@ -752,7 +752,7 @@ struct mw_dycore_s {
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
-  int chunk_y = 0, chunk_z = 0, chunk_f = 0;
+  int chunk_y = 0, chunk_yt = 0, chunk_z = 0, chunk_f = 0;
   unsigned char *flags = nullptr;          // fused tracer stage: per-cell "a y face of this cell was FCT-scaled" bits
   int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows (see DyP::hypk)
@@ -917,20 +917,12 @@ static int launch_update(mw_dycore_s *d, const double *Sstar, const double *Sn, 
   return 0;
 }
 
-static int pick_chunk(int n, long long base_waves, const char *env) {
-  const char *s = getenv(env);
-  if (s && atoi(s) > 0) return std::min(n, atoi(s));
-  const int cand[] = {32, 25, 20, 16, 12, 8};
-  for (int c : cand) if (base_waves * ((n + c - 1) / c) >= 6000) return std::min(n, c);
-  return std::min(n, 8);
-}
-
-// Equal z chunks for the marching x/z kernels: enough of them for ~5 rounds of 2 waves/SIMD over the 1024 SIMDs, none shorter
-// than 8 levels (every chunk re-primes its pipeline).
-static int balanced_chunk(int nz, long long base_waves, const char *env) {
+// Equal chunks along the marching direction: enough of them for `target` waves (x/z kernels: ~5 rounds of 2 waves/SIMD over
+// the 1024 SIMDs), none shorter than 8 cells (every chunk re-primes its pipeline).
+static int balanced_chunk(int nz, long long base_waves, const char *env, long long target = 10000) {
   const char *s = getenv(env);
   if (s && atoi(s) > 0) return std::min(nz, atoi(s));
-  long long nch = std::max(1ll, (10000 + base_waves - 1) / base_waves);
+  long long nch = std::max(1ll, (target + base_waves - 1) / base_waves);
   nch = std::min<long long>(nch, std::max(1, nz / 8));
   return (int)((nz + nch - 1) / nch);
 }
@@ -940,7 +932,8 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par) {
   if (p.sim2d) return 0;
   ProfScope ps(d, 5);
   long long threads = (long long)p.nz * p.nx * p.nens;
-  int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = pick_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y"));
+  // measured on 400x400x100 (625 wave columns): 8 x 50 rows for k_y_state, 14 x 29 for k_y_tracers (-5 % / -2 % vs. 32-row chunks)
+  int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000));
   dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
   hipLaunchKernelGGL(k_y_state, grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk);
   MW_LAUNCH_CHECK();
@@ -952,7 +945,7 @@ static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_
   if (p.sim2d) return 0;
   ProfScope ps(d, 6, st);
   long long threads = (long long)p.nz * p.nx * p.nens;
-  int chunk = d->chunk_y;
+  int chunk = d->chunk_yt ? d->chunk_yt : (d->chunk_yt = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_YT", 8400));
   dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
   for (int t0 = 0; t0 < p.nt; t0 += 4) {
     int cnt = std::min(4, p.nt - t0);
