@@ -198,20 +198,27 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
   const double *col = S + (long long)(5 + t0) * p.sV + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;
   double *fy = FY + (long long)k * p.fyK + ie;
   const unsigned char *upy = UPY + (long long)k * p.fyK + ie;
-  double w[T][5], nxt[T], cn[T];
+  // Loads run two rows ahead of their use (row j+4 and the face data of row j+1 are requested in iteration j): with ~75 VALU
+  // instructions per tracer and row, one iteration is shorter than the memory latency.
+  double w[T][5], nxt[T], nxt2[T], cn[T];
 #pragma unroll
   for (int v = 0; v < T; v++) {
     cn[v] = 0;
 #pragma unroll
     for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(ja - 1 - 2 + s + p.HY) * p.sJ];
+    nxt[v] = col[(long long)v * p.sV + (long long)(min(ja - 1 + 3, p.ny + p.HY - 1) + p.HY) * p.sJ];
   }
+  double m_n = MY[(long long)k * p.fyK + ie + (long long)ja * p.fyJ];
+  int up_n = upy[(long long)ja * p.fyJ];
   for (int j = ja - 1; j <= jb; j++) {
-    const int jn = min(j + 3, p.ny + p.HY - 1);
+    const int jn = min(j + 4, p.ny + p.HY - 1);
 #pragma unroll
-    for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
-    const int jl = max(j, ja);                                  // unconditional loads (clamped row): nothing waits inside a branch
-    const double m = MY[(long long)k * p.fyK + ie + (long long)jl * p.fyJ];
-    const int up = upy[(long long)jl * p.fyJ];
+    for (int v = 0; v < T; v++) nxt2[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
+    const int jl = min(max(j + 1, ja), jb);                     // unconditional loads (clamped row): nothing waits inside a branch
+    const double m = m_n;
+    const int up = up_n;
+    m_n = MY[(long long)k * p.fyK + ie + (long long)jl * p.fyJ];
+    up_n = upy[(long long)jl * p.fyJ];
     double se[T], ne[T];
 #pragma unroll
     for (int v = 0; v < T; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
 #pragma unroll
     for (int v = 0; v < T; v++) {
       cn[v] = ne[v];
-      w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
+      w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v]; nxt[v] = nxt2[v];
     }
   }
 }
