@@ -148,7 +148,8 @@ def main():
     prof = {n: dycore.profile_get(i) for i, n in enumerate(KNAMES)}
     dycore.profile(0)
     # Outside the timed region: the same kernels with the two pipelines serialised, so that each kernel's duration is
-    # exclusive (inside the timed region the state and tracer pipelines overlap on two streams and share the chip).
+    # exclusive (inside the timed region the state and tracer pipelines run on two streams and share the chip; the tracer
+    # stream has the higher priority, so k_xz_state mostly runs after the tracer kernels of the previous stage have drained).
     prof_excl = None
     if not a.strict:
         os.environ["MW_NO_OVERLAP"] = "1"
@@ -199,6 +200,7 @@ def main():
             "config": {"workload": "supercell %dx%dx%d nens=%d per GPU (global %dx%dx%d), WENO-FV dycore only, 3 tracers, "
                                    "CFL dt" % (a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz),
                        "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict,
+                       "schedule": ("two streams (state | tracers, tracer stream at high priority)" if (os.environ.get("MW_OVERLAP", "1") != "0" and not a.strict) else "one stream"),
                        "alg_bytes_per_cell_update": 64 * V,
                        "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world},
             "roofline": {"bound": "hbm", "kernel": "k_flux" if a.strict else "k_xz_state", "achieved": achieved, "peak": 8000.0,

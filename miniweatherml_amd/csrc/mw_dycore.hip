@@ -1180,7 +1180,15 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
       if (hipMalloc(&d->M[b][a], fn[a] * sizeof(double)) != hipSuccess || hipMalloc(&d->UP[b][a], fn[a]) != hipSuccess) { set_error("hipMalloc(M/UP) failed"); return fail(); }
       (void)hipMemsetAsync(d->M[b][a], 0, fn[a] * sizeof(double), d->stream); (void)hipMemsetAsync(d->UP[b][a], 0, fn[a], d->stream);
     }
-    if (hipStreamCreateWithFlags(&d->tstream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(); }
+    { // The tracer stream gets the highest stream priority: its kernels are the older work (stage s while the state stream is
+      // already in stage s+1), and with both pipelines fp64-VALU bound an even split of the chip only stretches both.  Measured
+      // (400x400x100): step time as with equal priorities (-0.3 %), 1.5 % better than one stream, and k_xz_state runs at its
+      // exclusive duration (0.81 instead of 1.09 ms).  MW_TSTREAM_PRIO=0 / 1 selects default / lowest priority instead.
+      int least = 0, greatest = 0; (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      const char *pe = getenv("MW_TSTREAM_PRIO"); const int pm = pe ? atoi(pe) : 2;
+      hipError_t er = (pm == 0) ? hipStreamCreateWithFlags(&d->tstream, hipStreamNonBlocking)
+                                : hipStreamCreateWithPriority(&d->tstream, hipStreamNonBlocking, pm == 1 ? least : greatest);
+      if (er != hipSuccess) { set_error("hipStreamCreate failed"); return fail(); } }
     for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
                                     hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
     if (hipEventCreateWithFlags(&d->ev_misc, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
@@ -1298,7 +1306,11 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK(); }       // :101 (+ D2)
   const bool march = (d->strict == 0);                        // production path; strict = 1/2 use the general
                                                               // flux-materialising kernels below
-  d->overlap = march && d->tstream && !getenv("MW_NO_OVERLAP");
+  // Two-stream schedule (see rk_stage_march); MW_OVERLAP=0 (or MW_NO_OVERLAP) puts both pipelines on the handle's stream.
+  { const char *ov = getenv("MW_OVERLAP");
+    bool want = ov ? (atoi(ov) != 0) : true;
+    if (getenv("MW_NO_OVERLAP")) want = false;
+    d->overlap = march && d->tstream && want; }
   if (d->overlap) { MW_HIP(hipEventRecord(d->ev_misc, d->stream)); MW_HIP(hipStreamWaitEvent(d->tstream, d->ev_misc, 0)); d->gstage = 0; }
   double dt_dyn = mw_dycore_compute_time_step(&d->g);                     // :104
   int ncycles = (int)std::ceil(dt_phys / dt_dyn);                         // :107

@@ -228,15 +228,18 @@ def test_unsupported_options_fail_loudly(mw):
         dycore.time_step(coupler, 0.0)
 
 
+@pytest.mark.parametrize("overlap", ["0", "1"])
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("shape", [(70, 9, 12, 1), (23, 6, 11, 2), (64, 1, 9, 1)])
-def test_fct_limiter_heavy(mw, oracle, fused, shape, monkeypatch):
-    """Sparse cloud/rain blobs in a strong random wind: the FCT multiplier is < 1 in a large share of the cells, in all three
+def test_fct_limiter_heavy(mw, oracle, fused, shape, monkeypatch, overlap):
+    """(overlap: the two-stream schedule -- state | tracer pipelines, the default -- or both pipelines on one stream.)
+    Sparse cloud/rain blobs in a strong random wind: the FCT multiplier is < 1 in a large share of the cells, in all three
     directions and across wave (x tile), row and z-chunk edges.  fused=1: k_tracers_fused + k_tracer_patch (y faces scaled
     by a donor in another row are corrected afterwards); fused=0: k_xz_tracers + k_tracer_update."""
     from miniweatherml_amd import modules
     nx, ny, nz, nens = shape
     monkeypatch.setenv("MW_FUSED_TRACERS", fused)
+    monkeypatch.setenv("MW_OVERLAP", overlap)
     monkeypatch.setenv("MW_CHUNK_F", "4")
     monkeypatch.setenv("MW_CHUNK_Z", "4")
     xlen, ylen = 500.0 * nx, 500.0 * max(ny, 2)
@@ -275,7 +278,7 @@ def test_fct_patch_pass_is_exercised(mw, oracle, monkeypatch):
     oracle on the limiter-heavy case (i.e. donors in neighbouring rows really do scale y faces there)."""
     monkeypatch.setenv("MW_DEBUG_NO_PATCH", "1")
     with pytest.raises(AssertionError):
-        test_fct_limiter_heavy(mw, oracle, "1", (70, 9, 12, 1), monkeypatch)
+        test_fct_limiter_heavy(mw, oracle, "1", (70, 9, 12, 1), monkeypatch, "0")
 
 
 def test_large_perturbation_takes_the_pow_fallback(mw, oracle):

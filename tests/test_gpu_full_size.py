@@ -85,6 +85,25 @@ def test_production_path_equals_general_path_at_size(mw):
         assert float((out[0][n] - out[1][n]).abs().max()) <= 1e-10 * scale + floor, n
 
 
+def test_two_stream_schedule_is_bitwise_the_one_stream_schedule(mw, monkeypatch):
+    """MW_OVERLAP=1 runs the state and tracer pipelines on two streams (the default), MW_OVERLAP=0 on
+    one: the same kernels on the same data, so any difference would be a missing stream dependency."""
+    import torch
+    from miniweatherml_amd import modules
+    out = []
+    for ov in ("0", "1"):
+        monkeypatch.setenv("MW_OVERLAP", ov)
+        coupler, dycore, _ = modules.make_supercell(160, 120, 60, 1, 80000., 60000., 20000.)
+        modules.perturb_temperature(coupler)
+        dt = dycore.compute_time_step(coupler)
+        for _ in range(6):
+            dycore.time_step(coupler, dt)
+        dm = coupler.get_data_manager_readonly()
+        out.append({n: dm.get(n, True).clone() for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor")})
+    for n in out[0]:
+        assert torch.equal(out[0][n], out[1][n]), n
+
+
 def test_config4_block_per_gpu(mw):
     """BASELINE.json configs[3]: the per-GPU block of the 8-GPU supercell run, 256 x 512 x 128 with 4 ensemble members
     (6.7e7 cells, 4.3 GB per slab: byte offsets far beyond 2^32).  Members identical, mass conserved, tracers positive."""
