@@ -753,6 +753,8 @@ struct mw_dycore_s {
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
   int chunk_y = 0, chunk_yt = 0, chunk_z = 0, chunk_f = 0;
+  unsigned int *dirty = nullptr;           // two words: "a y face was scaled in this / the next fused tracer launch"
+  unsigned long long fused_launches = 0;
   unsigned char *flags = nullptr;          // fused tracer stage: per-cell "a y face of this cell was FCT-scaled" bits
   int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows (see DyP::hypk)
@@ -1039,7 +1041,7 @@ template <int STAGE, int MODE, int T, bool N1>
 static void launch_tracers_fused_t(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
   hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1>), grid, dim3(256), 0, st, d->p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2],
-                     d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, dt, dt_dyn, c, chunk, tiles_x, rows4);
+                     d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4);
 }
 // x/z tracer fluxes + FCT + update in one kernel, then the (normally empty) y-face correction
 template <int STAGE, int MODE>
@@ -1064,9 +1066,12 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
   if (!p.sim2d && p.pos_mask && !getenv("MW_DEBUG_NO_PATCH")) {   // (the switch exists for the negative control in tests/)
     ProfScope ps(d, 1, st);
     hipLaunchKernelGGL((k_tracer_patch<STAGE, MODE>), plane_grid((long long)p.ny * p.nx * p.nens, p.nz), dim3(256), 0, st, p, Sout, d->flags,
-                       d->FX, d->FZ, dt_dyn, c);
+                       d->FX, d->FZ, dt_dyn, c, d->dirty + (d->fused_launches & 1), d->dirty + ((d->fused_launches + 1) & 1));
     MW_LAUNCH_CHECK();
+  } else if (!p.sim2d && p.pos_mask) {                          // (negative-control switch) nobody else clears the next word
+    (void)hipMemsetAsync(d->dirty + ((d->fused_launches + 1) & 1), 0, sizeof(unsigned int), st);
   }
+  d->fused_launches++;
   return 0;
 }
 
@@ -1162,9 +1167,11 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
       hipMalloc(&d->S3, slab) != hipSuccess ||
       hipMalloc(&d->tendY, (size_t)5 * p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->FX, fxb) != hipSuccess ||
       hipMalloc(&d->FY, fyb) != hipSuccess || hipMalloc(&d->FZ, fzb) != hipSuccess ||
-      hipMalloc(&d->imm, (size_t)p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->flags, (size_t)p.nC) != hipSuccess) {
+      hipMalloc(&d->imm, (size_t)p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->flags, (size_t)p.nC) != hipSuccess ||
+      hipMalloc(&d->dirty, 2 * sizeof(unsigned int)) != hipSuccess) {
     set_error("hipMalloc(workspace) failed"); return fail(); }
   (void)hipMemsetAsync(d->flags, 0, (size_t)p.nC, d->stream);
+  (void)hipMemsetAsync(d->dirty, 0, 2 * sizeof(unsigned int), d->stream);
   { const char *f = getenv("MW_FUSED_TRACERS");
     d->fused = (g->num_tracers <= 4 && g->nens <= 12 && !(f && f[0] == '0')) ? 1 : 0; }
   // zero everything once: halo corners are never written and the flux arrays start at 0 (:1677-1682)
@@ -1205,6 +1212,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->tstream) (void)hipStreamSynchronize(d->tstream);
   for (double *ptr : {d->S0, d->S1, d->S2, d->S3, d->tendY, d->FX, d->FY, d->FZ, d->hy_dev, d->imm}) if (ptr) (void)hipFree(ptr);
   if (d->flags) (void)hipFree(d->flags);
+  if (d->dirty) (void)hipFree(d->dirty);
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);

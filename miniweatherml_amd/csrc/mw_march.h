@@ -686,8 +686,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
                                                        const double *__restrict__ FY, const double *__restrict__ MX,
                                                        const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
                                                        const unsigned char *__restrict__ UPZ, double *__restrict__ DS,
-                                                       double *__restrict__ DN, unsigned char *__restrict__ flags, double dt,
-                                                       double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4) {
+                                                       double *__restrict__ DN, unsigned char *__restrict__ flags, unsigned int *__restrict__ dirty,
+                                                       double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4) {
   const int n = N1 ? 1 : p.nens;
   constexpr int t0 = 0;                                       // one group: all (<= 4) tracers of the cell
   const int lane = threadIdx.x & 63;
@@ -847,6 +847,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         multp[v] = mult;
       }
       if (rec && do_y) flags[((long long)kp * p.ny + j) * NXI + q] = (unsigned char)fl;     // 2 bits per tracer: (south, north) face scaled
+      if (__builtin_expect(fl != 0u, 0)) *dirty = 1u;           // (only set inside `rec`) lets k_tracer_patch return at once when nothing was scaled
     }
     // ------------------------------------------------ S3: cell k-2 -> new value
     {
@@ -897,8 +898,12 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 template <int STAGE, int MODE>
 __global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const unsigned char *__restrict__ flags,
                                                       const double *__restrict__ DS, const double *__restrict__ DN, double dt_dyn,
-                                                      CouplerPtrs c) {
+                                                      CouplerPtrs c, const unsigned int *__restrict__ dirty, unsigned int *dirty_next) {
 #pragma clang fp contract(off)
+  // `dirty` is this launch's "some y face was scaled" word, written by the k_tracers_fused before it; the other word is
+  // cleared here for the next stage's k_tracers_fused (launches on the tracer stream are serial).
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dirty_next = 0u;
+  if (*dirty == 0u) return;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int k = blockIdx.y;
   const int NXI = p.nx * p.nens;
