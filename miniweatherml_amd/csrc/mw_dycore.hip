@@ -848,7 +848,7 @@ struct ProfScope {
 
 // halo fill of variables [v0, v0+nv) of one slab: neighbour exchange (or self wrap) in x/y, then BCs -- replaces
 // halo_exchange (:574-827).  `grp` selects the pack-buffer set (0: state or all variables, 1: tracers).
-static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hipStream_t st = nullptr, int grp = 0) {
+static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hipStream_t st = nullptr, int grp = 0, bool skip_z = false) {
   if (!st) st = d->stream;
   if (nv < 0) nv = d->p.V;
   if (nv == 0) return 0;
@@ -879,8 +879,8 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
   const long long ny_ = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
   const long long nz_ = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
   const unsigned nbx = ex_x ? 0u : (unsigned)((nx_ + 255) / 256), nby = (ex_y || p.sim2d) ? 0u : (unsigned)((ny_ + 255) / 256);
-  const unsigned nbz = (unsigned)((nz_ + 255) / 256);
-  hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + nbz), dim3(256), 0, st, p, S, nbx, nby); MW_LAUNCH_CHECK();
+  const unsigned nbz = skip_z ? 0u : (unsigned)((nz_ + 255) / 256);      // (the marching kernels apply the z rule while loading)
+  if (nbx + nby + nbz) { hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + nbz), dim3(256), 0, st, p, S, nbx, nby); MW_LAUNCH_CHECK(); }
   return 0;
 }
 
@@ -1093,13 +1093,13 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   const int T = d->p.nt;
   if (d->overlap && gs >= 2) MW_HIP(hipStreamWaitEvent(ss, d->ev_tr[(gs - 2) & 7], 0));
   // ---- state pipeline
-  if (halo_fill(d, Sin, 0, 5, ss, 0)) return 1;
+  if (halo_fill(d, Sin, 0, 5, ss, 0, true)) return 1;
   if (launch_y_state(d, Sin, par)) return 1;                                  // y faces: m_upw, selector, y tendencies
   if (launch_xz_state<STAGE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par)) return 1;   // x,z faces + finished state variables
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
   // previous stage, which this stream produced itself: it is issued BEFORE the wait for this stage's state kernels and so
   // runs beside them; the state stream's exchange for stage s+1 in turn runs beside this stage's tracer kernels.
-  if (halo_fill(d, Sin, 5, T, ts, 1)) return 1;
+  if (halo_fill(d, Sin, 5, T, ts, 1, true)) return 1;
   if (d->overlap) { MW_HIP(hipEventRecord(d->ev_state[slot], ss)); MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0)); }
   if (launch_y_tracers(d, Sin, par, ts)) return 1;                            // tracer fluxes (public arrays)
   if (d->fused) {
@@ -1260,6 +1260,11 @@ int mw_dycore_get_background(mw_dycore_t d, double *hyc, double *hytc, double *h
 int mw_dycore_get_fluxes(mw_dycore_t d, double **out6) {
   if (!d || !out6) MW_FAIL("null argument");
   if (d->flux_src) {     // production path: the state-variable fluxes of the last stage were never written; rebuild all six
+    { // the marching kernels apply the z boundary rule while loading and leave the slab's z halo unfilled: fill it for k_flux
+      const DyP &p = d->p;
+      const long long nz_ = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
+      hipLaunchKernelGGL(k_halo_z, dim3((unsigned)((nz_ + 255) / 256)), dim3(256), 0, d->stream, p, const_cast<double *>(d->flux_src));
+      MW_LAUNCH_CHECK(); }
     if (launch_flux(d, d->flux_src)) return 1;              // arrays from the retained stage input exactly as D9+D10 leave them
     if (launch_fct(d, d->flux_src, d->flux_dt)) return 1;
     d->flux_src = nullptr;

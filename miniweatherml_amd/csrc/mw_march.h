@@ -55,6 +55,16 @@ template <bool N1> __device__ __forceinline__ double from_east(double v, int lan
   return shfl_from(v, lane + n);
 }
 
+// Level kl of a marching column (kl may lie in the z halo, -3..nz+2) with the z boundary rule (:752-781) applied on the fly: halo
+// levels repeat the nearest interior level, w is 0 behind a wall.  The marching kernels therefore never read the slab's z halo
+// and the production path does not fill it (k is wave-uniform: the clamp is scalar work).
+__device__ __forceinline__ double load_zlevel(const DyP &p, const double *__restrict__ colv, int kl, bool is_w) {
+  const int kc = min(max(kl, 0), p.nz - 1);
+  double val = colv[(long long)(kc + p.HZ) * p.sK];
+  if (is_w && kc != kl && p.bc_z == MW_BC_WALL) val = 0.0;
+  return val;
+}
+
 struct FaceState {   // what the passive variables need from the Riemann solve of one face
   double m_upw;      // upwind mass flux (= flux of idR)
   int ind;           // 0: upwind is the low ("L") side, 1: the high ("R") side
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   for (int v = 0; v < 5; v++) {
     ct[v] = 0; lds_fzprev[v][threadIdx.x] = 0; lds_xpart[v][threadIdx.x] = 0;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(g.kstart - 2 + s + p.HZ) * p.sK];
+    for (int s = 0; s < 5; s++) w[v][s] = load_zlevel(p, col + (long long)v * p.sV, g.kstart - 2 + s, v == idW);
   }
   for (int k = g.kstart; k <= g.kb; k++) {
     const bool top = (k == p.nz);                              // only the boundary face nz, no cell to reconstruct
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     {
       const int kn = min(k + 3, p.nz + p.HZ - 1);
 #pragma unroll
-      for (int v = 0; v < 5; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
+      for (int v = 0; v < 5; v++) nxt[v] = load_zlevel(p, col + (long long)v * p.sV, kn, v == idW);
     }
     double snv[5], tyv[5], immv = 0;
 #pragma unroll
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
   for (int v = 0; v < T; v++) {
     ct[v] = 0; fxp[v] = fzp[v] = fys[v] = fyn[v] = 0; multp[v] = 1;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(g.kstart - 2 + s + p.HZ) * p.sK];
+    for (int s = 0; s < 5; s++) w[v][s] = load_zlevel(p, col + (long long)v * p.sV, g.kstart - 2 + s, false);
   }
   for (int k = g.kstart; k <= g.kb; k++) {
     const bool top = (k == p.nz);
@@ -516,7 +526,7 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
     const bool zface = (k >= g.ka);
     const int kn = min(k + 3, p.nz + p.HZ - 1);
 #pragma unroll
-    for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
+    for (int v = 0; v < T; v++) nxt[v] = load_zlevel(p, col + (long long)v * p.sV, kn, false);
     double mx = 0, mz = 0, rhop = 0; int upx = 0, upz = 0;
     if (xwork) { mx = MX[(long long)k * p.fxK + fxo]; upx = UPX[(long long)k * p.fxK + fxo]; }
     if (pend) {                                                // what the cell below (k-1) still needs for its FCT multiplier
@@ -732,7 +742,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   for (int v = 0; v < T; v++) {
     ct[v] = 0; fxp[v] = fzp[v] = szf[v] = P[v] = 0; multp[v] = 1;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(kstart - 2 + s + p.HZ) * p.sK];
+    for (int s = 0; s < 5; s++) w[v][s] = load_zlevel(p, col + (long long)v * p.sV, kstart - 2 + s, false);
   }
   // The loop body is branch-free apart from predicated stores and the rare limiter paths: every load uses a clamped
   // (always valid) address and is issued at the top, the z reconstruction (registers only) runs while they are in flight.
@@ -750,7 +760,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #pragma unroll
     for (int v = 0; v < T; v++) xpatch[v] = N1 ? col[(long long)v * p.sV + (long long)(kx + p.HZ) * p.sK + opatch] : 0.0;
 #pragma unroll
-    for (int v = 0; v < T; v++) nxt[v] = col[(long long)v * p.sV + (long long)(kn + p.HZ) * p.sK];
+    for (int v = 0; v < T; v++) nxt[v] = load_zlevel(p, col + (long long)v * p.sV, kn, false);
     const double mx = MX[(long long)kx * p.fxK + fxo];
     const int upx = UPX[(long long)kx * p.fxK + fxo];
     const double mz = MZ[(long long)kz * p.fzK + fzo];
