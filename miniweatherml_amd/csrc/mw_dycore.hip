@@ -38,6 +38,8 @@ struct DyP {                      // kernel parameter block (by value)
   long long fxJ, fxK, fxV, fyJ, fyK, fyV, fzJ, fzK, fzV;   // flux strides
   int sim2d, bc_x, bc_y, bc_z, px, py, nproc_x, nproc_y;
   int v0;                         // halo/pack kernels: index of the first variable of the group being processed
+  int wrap_x, wrap_y;             // production path, periodic direction owned by one rank: the marching kernels wrap their x / row index
+                                  // instead of reading halo cells, and that halo is not filled
   int enable_gravity, use_immersed, idWV;
   unsigned pos_mask, mass_mask;
   double dx, dy, dz, rdx, rdy, rdz, C0, gamma, grav, fcor, R_d, R_v;
@@ -793,7 +795,7 @@ static void fill_params(mw_dycore_s *d) {
   p.fxJ = (long long)(g.nx + 1) * g.nens; p.fxK = (long long)g.ny * p.fxJ;       p.fxV = (long long)g.nz * p.fxK;
   p.fyJ = (long long)g.nx * g.nens;       p.fyK = (long long)(g.ny + 1) * p.fyJ; p.fyV = (long long)g.nz * p.fyK;
   p.fzJ = (long long)g.nx * g.nens;       p.fzK = (long long)g.ny * p.fzJ;       p.fzV = (long long)(g.nz + 1) * p.fzK;
-  p.v0 = 0;
+  p.v0 = 0; p.wrap_x = 0; p.wrap_y = 0;
   p.bc_x = g.bc_x; p.bc_y = g.bc_y; p.bc_z = g.bc_z; p.px = g.px; p.py = g.py; p.nproc_x = g.nproc_x; p.nproc_y = g.nproc_y;
   p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
   p.pos_mask = 0; p.mass_mask = 0;
@@ -878,7 +880,8 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
   const long long nx_ = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens;
   const long long ny_ = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
   const long long nz_ = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
-  const unsigned nbx = ex_x ? 0u : (unsigned)((nx_ + 255) / 256), nby = (ex_y || p.sim2d) ? 0u : (unsigned)((ny_ + 255) / 256);
+  const unsigned nbx = (ex_x || (skip_z && p.wrap_x)) ? 0u : (unsigned)((nx_ + 255) / 256);      // skip_z = production path
+  const unsigned nby = (ex_y || p.sim2d || (skip_z && p.wrap_y)) ? 0u : (unsigned)((ny_ + 255) / 256);
   const unsigned nbz = skip_z ? 0u : (unsigned)((nz_ + 255) / 256);      // (the marching kernels apply the z rule while loading)
   if (nbx + nby + nbz) { hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + nbz), dim3(256), 0, st, p, S, nbx, nby); MW_LAUNCH_CHECK(); }
   return 0;
@@ -1260,10 +1263,14 @@ int mw_dycore_get_background(mw_dycore_t d, double *hyc, double *hytc, double *h
 int mw_dycore_get_fluxes(mw_dycore_t d, double **out6) {
   if (!d || !out6) MW_FAIL("null argument");
   if (d->flux_src) {     // production path: the state-variable fluxes of the last stage were never written; rebuild all six
-    { // the marching kernels apply the z boundary rule while loading and leave the slab's z halo unfilled: fill it for k_flux
-      const DyP &p = d->p;
+    { // the marching kernels apply the z boundary rule (and, in a periodic direction owned by one rank, the wrap) while
+      // loading and leave those halos of the slab unfilled: fill them for k_flux
+      DyP p = d->p; p.v0 = 0;
+      double *S = const_cast<double *>(d->flux_src);
+      const long long nx_ = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens, ny_ = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
       const long long nz_ = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
-      hipLaunchKernelGGL(k_halo_z, dim3((unsigned)((nz_ + 255) / 256)), dim3(256), 0, d->stream, p, const_cast<double *>(d->flux_src));
+      const unsigned nbx = p.wrap_x ? (unsigned)((nx_ + 255) / 256) : 0u, nby = p.wrap_y ? (unsigned)((ny_ + 255) / 256) : 0u;
+      hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + (unsigned)((nz_ + 255) / 256)), dim3(256), 0, d->stream, p, S, nbx, nby);
       MW_LAUNCH_CHECK(); }
     if (launch_flux(d, d->flux_src)) return 1;              // arrays from the retained stage input exactly as D9+D10 leave them
     if (launch_fct(d, d->flux_src, d->flux_dt)) return 1;
@@ -1319,6 +1326,10 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK(); }       // :101 (+ D2)
   const bool march = (d->strict == 0);                        // production path; strict = 1/2 use the general
                                                               // flux-materialising kernels below
+  if (march && !getenv("MW_NO_WRAP")) {                       // index wrap instead of halo cells (see DyP::wrap_x)
+    d->p.wrap_x = (p.bc_x == MW_BC_PERIODIC) && !(d->xchg && p.nproc_x > 1) && p.nx >= 3;
+    d->p.wrap_y = !p.sim2d && (p.bc_y == MW_BC_PERIODIC) && !(d->xchg && p.nproc_y > 1) && p.ny >= 3;
+  }
   // Two-stream schedule (see rk_stage_march); MW_OVERLAP=0 (or MW_NO_OVERLAP) puts both pipelines on the handle's stream.
   { const char *ov = getenv("MW_OVERLAP");
     bool want = ov ? (atoi(ov) != 0) : true;

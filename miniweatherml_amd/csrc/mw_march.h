@@ -55,6 +55,10 @@ template <bool N1> __device__ __forceinline__ double from_east(double v, int lan
   return shfl_from(v, lane + n);
 }
 
+// Periodic direction owned by one rank (DyP::wrap_x / wrap_y): the interior index that a halo index stands for.
+__device__ __forceinline__ int wrap_xq(const DyP &p, int q, int NXI) { return p.wrap_x ? (q < 0 ? q + NXI : (q >= NXI ? q - NXI : q)) : q; }
+__device__ __forceinline__ int wrap_row(const DyP &p, int j) { return p.wrap_y ? (j < 0 ? j + p.ny : (j >= p.ny ? j - p.ny : j)) : j; }
+
 // Level kl of a marching column (kl may lie in the z halo, -3..nz+2) with the z boundary rule (:752-781) applied on the fly: halo
 // levels repeat the nearest interior level, w is 0 behind a wall.  The marching kernels therefore never read the slab's z halo
 // and the production path does not fill it (k is wave-uniform: the clamp is scalar work).
@@ -141,13 +145,13 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   for (int v = 0; v < 5; v++) {
     cn[v] = 0; fprev[v] = 0;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(ja - 1 - 2 + s + p.HY) * p.sJ];
+    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - 2 + s) + p.HY) * p.sJ];
   }
   for (int j = ja - 1; j <= jb; j++) {
     {
       const int jn = min(j + 3, p.ny + p.HY - 1);               // clamp: the last prefetch is never used
 #pragma unroll
-      for (int v = 0; v < 5; v++) nxt[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
+      for (int v = 0; v < 5; v++) nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
     }
     double se[5], ne[5];
 #pragma unroll
@@ -215,15 +219,15 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
   for (int v = 0; v < T; v++) {
     cn[v] = 0;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(ja - 1 - 2 + s + p.HY) * p.sJ];
-    nxt[v] = col[(long long)v * p.sV + (long long)(min(ja - 1 + 3, p.ny + p.HY - 1) + p.HY) * p.sJ];
+    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - 2 + s) + p.HY) * p.sJ];
+    nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, min(ja - 1 + 3, p.ny + p.HY - 1)) + p.HY) * p.sJ];
   }
   double m_n = MY[(long long)k * p.fyK + ie + (long long)ja * p.fyJ];
   int up_n = upy[(long long)ja * p.fyJ];
   for (int j = ja - 1; j <= jb; j++) {
     const int jn = min(j + 4, p.ny + p.HY - 1);
 #pragma unroll
-    for (int v = 0; v < T; v++) nxt2[v] = col[(long long)v * p.sV + (long long)(jn + p.HY) * p.sJ];
+    for (int v = 0; v < T; v++) nxt2[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
     const int jl = min(max(j + 1, ja), jb);                     // unconditional loads (clamped row): nothing waits inside a branch
     const double m = m_n;
     const int up = up_n;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
 //              by lane (ds_bpermute): 1 halo cell per side, 64 - 2n cells per wave.
 // ---------------------------------------------------------------------------------------------------------------
 struct XzGeom {
-  int n, lane, NXI, j, q, qq, e, i, qc, ka, kb, kstart;
+  int n, lane, NXI, j, q, qq, qa, e, i, qc, ka, kb, kstart;   // qq: index incl. halo (BC logic), qa: the index that is addressed (wrapped)
   int cell_lo, cell_hi, face_hi;                              // lanes [cell_lo, cell_hi) own a cell, [cell_lo, face_hi) a lower x face
   int om2, om1, op1, op2;                                     // nens > 1: offsets (doubles) of the x neighbours from the lane's own cell
   bool owns_face, owns_cell, valid;
@@ -291,7 +295,9 @@ __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, 
   g.e = N1 ? 0 : ((g.qq % g.n) + g.n) % g.n;
   g.i = (g.qq - g.e) / g.n;                                   // x cell index (can be -3..nx+2)
   g.qc = g.owns_cell ? g.q : 0;                               // safe index for per-cell arrays
-  g.om2 = -2 * g.n; g.om1 = -g.n; g.op1 = g.n; g.op2 = 2 * g.n;             // qq in [-n, NXI+n): all four stay inside the 3-cell halo
+  g.qa = wrap_xq(p, g.qq, g.NXI);
+  g.om2 = wrap_xq(p, g.qq - 2 * g.n, g.NXI) - g.qa; g.om1 = wrap_xq(p, g.qq - g.n, g.NXI) - g.qa;       // qq in [-n, NXI+n): all four stay
+  g.op1 = wrap_xq(p, g.qq + g.n, g.NXI) - g.qa;     g.op2 = wrap_xq(p, g.qq + 2 * g.n, g.NXI) - g.qa;   // inside the 3-cell halo
   g.ka = blockIdx.y * chunk;
   g.kb = min(g.ka + chunk, p.nz);
   g.kstart = (g.ka == 0) ? 0 : g.ka - 1;                      // no ghost cell below the wall
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   const XzGeom g = xz_geom<N1>(p, chunk, tiles_x);
   if (!g.valid) return;
   const int n = g.n, lane = g.lane, NXI = g.NXI, j = g.j, q = g.q, e = g.e;
-  const double *col = S + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qq;           // level k at col + (k+HZ)*sK
+  const double *col = S + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qa;           // level k at col + (k+HZ)*sK
   const long long cell0 = (long long)j * NXI + g.qc;                                           // + k*ny*NXI
   const long long slab0 = (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qc;           // + (k+HZ)*sK
   const long long planeC = (long long)p.ny * NXI;
@@ -501,8 +507,8 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
   const XzGeom g = xz_geom<N1>(p, chunk, tiles_x, rows4);
   if (!g.valid) return;
   const int n = g.n, lane = g.lane, NXI = g.NXI, j = g.j, q = g.q;
-  const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qq;
-  const double *rcol = S + (long long)idR * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qq;
+  const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qa;
+  const double *rcol = S + (long long)idR * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qa;
   const long long fxo = (long long)j * p.fxJ + (g.owns_face ? q : 0);
   const long long fzo = (long long)j * p.fzJ + g.qc;
   const long long fyo = (long long)j * p.fyJ + g.qc;
@@ -720,12 +726,13 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const bool has_mult = (lane >= (hw - 1) * n) && (lane < 64 - (hw - 1) * n) && interior;   // both x faces of the cell are known
   const bool upd = (lane >= hw * n) && (lane < 64 - hw * n) && interior;                    // the cell this lane completes
   // nens > 1: neighbour offsets, clamped so that every load stays inside the row's 3-cell halo
-  const int om2 = max(q - 2 * n, -3 * n) - qq, om1 = max(q - n, -3 * n) - qq;
-  const int op1 = min(q + n, NXI + 3 * n - 1) - qq, op2 = min(q + 2 * n, NXI + 3 * n - 1) - qq;
+  const int qa = wrap_xq(p, qq, NXI);                         // the index that is addressed
+  const int om2 = wrap_xq(p, max(q - 2 * n, -3 * n), NXI) - qa, om1 = wrap_xq(p, max(q - n, -3 * n), NXI) - qa;
+  const int op1 = wrap_xq(p, min(q + n, NXI + 3 * n - 1), NXI) - qa, op2 = wrap_xq(p, min(q + 2 * n, NXI + 3 * n - 1), NXI) - qa;
   const int qm = interior ? q : 0;
   const int qf = (q >= 0 && q < NXI + n) ? q : 0;
-  const int opatch = (lane == 0) ? max(q - 1, -3) - qq : (lane == 63) ? min(q + 1, NXI + 2) - qq : 0;
-  const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qq;
+  const int opatch = (lane == 0) ? wrap_xq(p, max(q - 1, -3), NXI) - qa : (lane == 63) ? wrap_xq(p, min(q + 1, NXI + 2), NXI) - qa : 0;
+  const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qa;
   const long long so_row = (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qm;     // + (k+HZ)*sK + l*sV
   const long long fxo = (long long)j * p.fxJ + qf;
   const long long fzo = (long long)j * p.fzJ + qm;
