@@ -104,6 +104,29 @@ def test_two_stream_schedule_is_bitwise_the_one_stream_schedule(mw, monkeypatch)
         assert torch.equal(out[0][n], out[1][n]), n
 
 
+def test_index_wrap_is_bitwise_the_halo_fill(mw, monkeypatch):
+    """Periodic x/y on one rank: the marching kernels wrap their indices and no halo is filled (default); MW_NO_WRAP=1 fills the
+    x/y halos and reads them.  Same values reach the same arithmetic, so the fields must be identical -- also with 3 members."""
+    import torch
+    from miniweatherml_amd import modules
+    for nens in (1, 3):
+        out = []
+        for nowrap in (None, "1"):
+            if nowrap: monkeypatch.setenv("MW_NO_WRAP", nowrap)
+            else: monkeypatch.delenv("MW_NO_WRAP", raising=False)
+            coupler, dycore, _ = modules.make_supercell(100, 61, 24, nens, 50000., 30500., 20000.)
+            modules.perturb_temperature(coupler)
+            dt = dycore.compute_time_step(coupler)
+            for _ in range(4):
+                dycore.time_step(coupler, dt)
+            fl = dycore.fluxes(coupler)                          # on-demand rebuild fills the skipped halos first
+            dm = coupler.get_data_manager_readonly()
+            out.append({n: dm.get(n, True).clone() for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor")})
+            out[-1].update({k: v.clone() for k, v in fl.items()})
+        for n in out[0]:
+            assert torch.equal(out[0][n], out[1][n]), (nens, n)
+
+
 def test_config4_block_per_gpu(mw):
     """BASELINE.json configs[3]: the per-GPU block of the 8-GPU supercell run, 256 x 512 x 128 with 4 ensemble members
     (6.7e7 cells, 4.3 GB per slab: byte offsets far beyond 2^32).  Members identical, mass conserved, tracers positive."""
