@@ -1068,7 +1068,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
   }
   if (!p.sim2d && p.pos_mask && !getenv("MW_DEBUG_NO_PATCH")) {   // (the switch exists for the negative control in tests/)
     ProfScope ps(d, 1, st);
-    hipLaunchKernelGGL((k_tracer_patch<STAGE, MODE>), plane_grid((long long)p.ny * p.nx * p.nens, p.nz), dim3(256), 0, st, p, Sout, d->flags,
+    hipLaunchKernelGGL((k_tracer_patch<STAGE, MODE>), plane_grid((long long)p.ny * p.nx * p.nens, (p.nz + MW_PATCH_LEVELS - 1) / MW_PATCH_LEVELS), dim3(256), 0, st, p, Sout, d->flags,
                        d->FX, d->FZ, dt_dyn, c, d->dirty + (d->fused_launches & 1), d->dirty + ((d->fused_launches + 1) & 1));
     MW_LAUNCH_CHECK();
   } else if (!p.sim2d && p.pos_mask) {                          // (negative-control switch) nobody else clears the next word

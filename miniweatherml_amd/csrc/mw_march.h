@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 
 // Receiver-centred correction for y faces whose donor (the row above or below) scaled them: see k_tracers_fused.
 template <int STAGE, int MODE>
+#define MW_PATCH_LEVELS 8
 __global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const unsigned char *__restrict__ flags,
                                                       const double *__restrict__ DS, const double *__restrict__ DN, double dt_dyn,
                                                       CouplerPtrs c, const unsigned int *__restrict__ dirty, unsigned int *dirty_next) {
@@ -922,14 +923,14 @@ __global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dirty_next = 0u;
   if (*dirty == 0u) return;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int k = blockIdx.y;
   const int NXI = p.nx * p.nens;
   if (t >= (long long)p.ny * NXI) return;
   const int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
-  const long long ci = ((long long)k * p.ny + j) * NXI + ie;
+  for (int k = blockIdx.y * MW_PATCH_LEVELS; k < min(p.nz, (int)(blockIdx.y + 1) * MW_PATCH_LEVELS); k++) {   // (few, fat blocks: the launch
+  const long long ci = ((long long)k * p.ny + j) * NXI + ie;                                                // is normally a no-op)
   const unsigned fN = (j + 1 < p.ny) ? flags[ci + NXI] : 0u;      // northern neighbour scaled its south face = my north face
   const unsigned fS = (j >= 1) ? flags[ci - NXI] : 0u;            // southern neighbour scaled its north face = my south face
-  if (((fN & 0x55u) | (fS & 0xAAu)) == 0u) return;
+  if (((fN & 0x55u) | (fS & 0xAAu)) == 0u) continue;
   const int e = ie % p.nens;
   const long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
   const double rho_new = Sout[so + idR * p.sV] + p.hyc[k * p.nens + e];
@@ -959,6 +960,7 @@ __global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const
     const double press = pressure_fast(p, Sout[so + idT * p.sV], p.hytc[hi], p.p0c[hi], p.ihytc[hi]);
     c.rho_d[ci] = rho_dry;
     c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);
+  }
   }
 }
 
