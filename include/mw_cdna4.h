@@ -111,7 +111,8 @@ int  mw_dycore_compute_tendencies(mw_dycore_t h, const double *density_dry, cons
 int  mw_dycore_get_fluxes(mw_dycore_t h, double **out6);
 double mw_dycore_get_etime(mw_dycore_t h);   /* member etime, :55 */
 /* Name + total time (ms) of this handle's kernels measured with hipEvents on the handle's stream since the
- * last reset (enabled by mw_dycore_profile(h,1)); which: 0 x/z flux stencil + state update (k_xz_state; k_flux on the
+ * last reset (enabled by mw_dycore_profile(h,1); mw_dycore_profile(h,2) times class 0 only -- two events per launch of the
+ * dominant kernel instead of two around every kernel, whose markers cost about 2 % of the step); which: 0 x/z flux stencil + state update (k_xz_state; k_flux on the
  * general path), 1 fct (general path) / y-face correction pass of the fused tracer stage, 2 update (general path; tracer update
  * of the unfused production path), 3 halo, 4 convert, 5 y stencil state, 6 y stencil tracers, 7 x/z tracer stage (fused:
  * fluxes + FCT + update). */

@@ -837,7 +837,7 @@ static int upload_background(mw_dycore_s *d) {
 
 struct ProfScope {
   mw_dycore_s *d; int which; size_t idx; bool on; hipStream_t st;
-  ProfScope(mw_dycore_s *d_, int w, hipStream_t st_ = nullptr) : d(d_), which(w), idx(0), on(d_->prof != 0), st(st_ ? st_ : d_->stream) {
+  ProfScope(mw_dycore_s *d_, int w, hipStream_t st_ = nullptr) : d(d_), which(w), idx(0), on(d_->prof == 1 || (d_->prof == 2 && w == 0)), st(st_ ? st_ : d_->stream) {
     if (!on) return;
     if (d->ev_used[which] == d->ev[which].size()) {
       hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); d->ev[which].push_back({a, b});
@@ -1191,9 +1191,8 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
       (void)hipMemsetAsync(d->M[b][a], 0, fn[a] * sizeof(double), d->stream); (void)hipMemsetAsync(d->UP[b][a], 0, fn[a], d->stream);
     }
     { // The tracer stream gets the highest stream priority: its kernels are the older work (stage s while the state stream is
-      // already in stage s+1), and with both pipelines fp64-VALU bound an even split of the chip only stretches both.  Measured
-      // (400x400x100): step time as with equal priorities (-0.3 %), 1.5 % better than one stream, and k_xz_state runs at its
-      // exclusive duration (0.81 instead of 1.09 ms).  MW_TSTREAM_PRIO=0 / 1 selects default / lowest priority instead.
+      // already in stage s+1), and with both pipelines fp64-VALU bound an even split of the chip only stretches both (measured on
+      // one rank with MW_OVERLAP=1: step time -0.5 % against equal priorities).  MW_TSTREAM_PRIO=0 / 1: default / lowest priority.
       int least = 0, greatest = 0; (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
       const char *pe = getenv("MW_TSTREAM_PRIO"); const int pm = pe ? atoi(pe) : 2;
       hipError_t er = (pm == 0) ? hipStreamCreateWithFlags(&d->tstream, hipStreamNonBlocking)
@@ -1330,9 +1329,12 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     d->p.wrap_x = (p.bc_x == MW_BC_PERIODIC) && !(d->xchg && p.nproc_x > 1) && p.nx >= 3;
     d->p.wrap_y = !p.sim2d && (p.bc_y == MW_BC_PERIODIC) && !(d->xchg && p.nproc_y > 1) && p.ny >= 3;
   }
-  // Two-stream schedule (see rk_stage_march); MW_OVERLAP=0 (or MW_NO_OVERLAP) puts both pipelines on the handle's stream.
+  // Two-stream schedule (see rk_stage_march): the default when strips are exchanged with neighbour ranks (the exchange of one
+  // pipeline then runs beside the kernels of the other).  On one rank both pipelines are fp64-VALU bound, the step takes the
+  // same time either way (measured without any timing events: +-0.3 %) and sharing the chip only stretches every kernel, so the
+  // default there is the handle's stream for everything.  MW_OVERLAP=1 / 0 forces either schedule.
   { const char *ov = getenv("MW_OVERLAP");
-    bool want = ov ? (atoi(ov) != 0) : true;
+    bool want = ov ? (atoi(ov) != 0) : (d->xchg != nullptr);
     if (getenv("MW_NO_OVERLAP")) want = false;
     d->overlap = march && d->tstream && want; }
   if (d->overlap) { MW_HIP(hipEventRecord(d->ev_misc, d->stream)); MW_HIP(hipStreamWaitEvent(d->tstream, d->ev_misc, 0)); d->gstage = 0; }

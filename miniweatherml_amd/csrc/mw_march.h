@@ -731,7 +731,10 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const int op1 = wrap_xq(p, min(q + n, NXI + 3 * n - 1), NXI) - qa, op2 = wrap_xq(p, min(q + 2 * n, NXI + 3 * n - 1), NXI) - qa;
   const int qm = interior ? q : 0;
   const int qf = (q >= 0 && q < NXI + n) ? q : 0;
-  const int opatch = (lane == 0) ? wrap_xq(p, max(q - 1, -3), NXI) - qa : (lane == 63) ? wrap_xq(p, min(q + 1, NXI + 2), NXI) - qa : 0;
+  // (lanes 1..62 read lane 0's cell too -- the value is unused there -- so that the load touches two cache lines instead of the
+  //  wave's own four: every line costs HBM traffic here, neither L1 nor L2 keeps a level for the three iterations since its first use)
+  const int qw0 = __builtin_amdgcn_readfirstlane(wrap_xq(p, max(q - 1, -3), NXI));
+  const int opatch = (lane == 63) ? wrap_xq(p, min(q + 1, NXI + 2), NXI) - qa : qw0 - qa;
   const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qa;
   const long long so_row = (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + qm;     // + (k+HZ)*sK + l*sV
   const long long fxo = (long long)j * p.fxJ + qf;

@@ -232,7 +232,7 @@ def test_unsupported_options_fail_loudly(mw):
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("shape", [(70, 9, 12, 1), (23, 6, 11, 2), (64, 1, 9, 1)])
 def test_fct_limiter_heavy(mw, oracle, fused, shape, monkeypatch, overlap):
-    """(overlap: the two-stream schedule -- state | tracer pipelines, the default -- or both pipelines on one stream.)
+    """(overlap: the two-stream schedule -- state | tracer pipelines, the default with a neighbour exchange -- or one stream.)
     Sparse cloud/rain blobs in a strong random wind: the FCT multiplier is < 1 in a large share of the cells, in all three
     directions and across wave (x tile), row and z-chunk edges.  fused=1: k_tracers_fused + k_tracer_patch (y faces scaled
     by a donor in another row are corrected afterwards); fused=0: k_xz_tracers + k_tracer_update."""

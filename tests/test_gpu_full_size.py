@@ -86,8 +86,8 @@ def test_production_path_equals_general_path_at_size(mw):
 
 
 def test_two_stream_schedule_is_bitwise_the_one_stream_schedule(mw, monkeypatch):
-    """MW_OVERLAP=1 runs the state and tracer pipelines on two streams (the default), MW_OVERLAP=0 on
-    one: the same kernels on the same data, so any difference would be a missing stream dependency."""
+    """MW_OVERLAP=1 runs the state and tracer pipelines on two streams (the default with a neighbour exchange), MW_OVERLAP=0 on
+    one (the default on one rank): the same kernels on the same data, so any difference would be a missing stream dependency."""
     import torch
     from miniweatherml_amd import modules
     out = []
