@@ -16,6 +16,9 @@
 // reference: dynamics_euler_stratified_wenofv.h:271-388 (D6), :395-485 (D9), :519-551 (D11), :121-174 (D12).
 // =====================================================================================================
 #pragma once
+#ifndef MW_XCD_SWIZZLE
+#define MW_XCD_SWIZZLE 1
+#endif
 
 namespace mw {
 
@@ -53,6 +56,22 @@ template <bool N1> __device__ __forceinline__ double from_west(double v, int lan
 template <bool N1> __device__ __forceinline__ double from_east(double v, int lane, int n) {
   if (N1) return dpp_mov<0x130>(v);            // wave_shl:1
   return shfl_from(v, lane + n);
+}
+
+// Logical (x, y) block of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (observed, not promised: a speed
+// matter only), so physical blocks b and b+8 share an L2; the bijective remap below makes the blocks of one XCD logical
+// NEIGHBOURS -- adjacent x tiles / row groups, whose 512-byte wave loads overlap by one 128-byte line (the 58-cell tiles are
+// not line-aligned) and whose halo columns and boundary flux rows coincide -- so that the second reader finds the line in L2.
+struct BlockXY { unsigned x, y; };
+__device__ __forceinline__ BlockXY xcd_block() {
+#if MW_XCD_SWIZZLE
+  const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+  const unsigned l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+  BlockXY b; b.y = l / gridDim.x; b.x = l - b.y * gridDim.x; return b;
+#else
+  BlockXY b; b.x = blockIdx.x; b.y = blockIdx.y; return b;
+#endif
 }
 
 // Periodic direction owned by one rank (DyP::wrap_x / wrap_y): the interior index that a halo index stands for.
@@ -282,9 +301,10 @@ __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, 
   const int hw = N1 ? 3 : 1;                                  // halo cells per side
   const int U = 64 - 2 * hw * g.n;                            // cells (fused) a wave completes
   g.cell_lo = hw * g.n; g.cell_hi = 64 - hw * g.n; g.face_hi = N1 ? 64 - 2 * g.n : 64;
-  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // wave id -> (row j, x tile)
+  const BlockXY blk = xcd_block();
+  const long long wid = (long long)blk.x * 4 + (threadIdx.x >> 6);           // wave id -> (row j, x tile)
   int tx;
-  if (rows4) { const int jg = (int)(blockIdx.x / tiles_x); tx = (int)(blockIdx.x - (unsigned)jg * tiles_x); g.j = jg * 4 + (threadIdx.x >> 6); }
+  if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); g.j = jg * 4 + (threadIdx.x >> 6); }
   else       { g.j = (int)(wid / tiles_x); tx = (int)(wid - (long long)g.j * tiles_x); }
   g.valid = g.j < p.ny;                                       // whole wave
   g.q = tx * U - hw * g.n + g.lane;                           // interior fused-x index of this lane (may be in the halo)
@@ -298,7 +318,7 @@ __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, 
   g.qa = wrap_xq(p, g.qq, g.NXI);
   g.om2 = wrap_xq(p, g.qq - 2 * g.n, g.NXI) - g.qa; g.om1 = wrap_xq(p, g.qq - g.n, g.NXI) - g.qa;       // qq in [-n, NXI+n): all four stay
   g.op1 = wrap_xq(p, g.qq + g.n, g.NXI) - g.qa;     g.op2 = wrap_xq(p, g.qq + 2 * g.n, g.NXI) - g.qa;   // inside the 3-cell halo
-  g.ka = blockIdx.y * chunk;
+  g.ka = blk.y * chunk;
   g.kb = min(g.ka + chunk, p.nz);
   g.kstart = (g.ka == 0) ? 0 : g.ka - 1;                      // no ghost cell below the wall
   return g;
@@ -715,8 +735,9 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const int hw = N1 ? 3 : 2;
   const int U = 64 - 2 * hw * n;
   int j, tx;
-  if (rows4) { const int jg = (int)(blockIdx.x / tiles_x); tx = (int)(blockIdx.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
-  else       { const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
+  const BlockXY blk = xcd_block();
+  if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
+  else       { const long long wid = (long long)blk.x * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
   if (j >= p.ny) return;
   const int q = tx * U - hw * n + lane;                       // fused-x index of this lane's cell (halo lanes included)
   const int qq = min(max(q, -3 * n), NXI + 3 * n - 1);        // clamped into the 3-cell halo for addressing
@@ -741,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const long long fzo = (long long)j * p.fzJ + qm;
   const long long fyo = (long long)j * p.fyJ + qm;
   const bool do_y = !p.sim2d;
-  const int ka = blockIdx.y * chunk, kb = min(ka + chunk, p.nz);
+  const int ka = blk.y * chunk, kb = min(ka + chunk, p.nz);
   const int k_lo = max(ka - 1, 0);                            // cells k_lo .. k_hi get all six fluxes (FCT multiplier)
   const int k_hi = min(kb, p.nz - 1);
   const int kstart = max(ka - 2, 0);
