@@ -94,7 +94,8 @@ __device__ __forceinline__ void weno5_edges_fast(double s0, double s1, double s2
   // TV (WenoLimiter_recon.h:37-56) with the scale factors folded into the constants
   const double k1312 = 1.0833333333333333333333333333333333333;             // (13/3)/4
   const double tL = L1*L1 + k1312*(L2p*L2p);
-  const double tC = 0.25*(C1p*C1p) + k1312*(C2p*C2p);
+  const double hC = 0.5*C1p;                                // coefs3_shift2(1)
+  const double tC = hC*hC + k1312*(C2p*C2p);
   const double tR = R1*R1 + k1312*(R2p*R2p);
   const double tH = H1*(H1 + (0.5/12.0)*H3p) + H2p*((4.3333333333333333333333333333333333333/256.0)*H2p + (4.2/384.0)*H4p)
                   + (39.1125/144.0)*(H3p*H3p) + (625.83571428571428571428571428571428571/576.0)*(H4p*H4p);
@@ -120,12 +121,12 @@ __device__ __forceinline__ void weno5_edges_fast(double s0, double s1, double s2
   // Limited polynomial (un-normalised weights n_i, sum N) evaluated at -1/2 and +1/2.  Every candidate preserves the cell mean:
   // its constant coefficient is s2 - c2/12 (- c4/80 for the 5th-order one), so the even part  c0 + c2/4 + c4/16  collapses to
   //   s2 N + (1/4 - 1/12) c2 + (1/16 - 1/80) c4  =  s2 N + c2/6 + c4/20
-  // and the constant coefficients never have to be formed (c2 = c2h/2, c4 = H4p nH / 24).
-  const double h4n = H4p*nH;
-  const double c1 = H1*nH + L1*nL + (0.5*C1p)*nC + R1*nR;
-  const double c2h = (0.125)*(H2p*nH) + L2p*nL + C2p*nC + R2p*nR;          // 2*c2   (H2 = H2p/16 -> 2*H2 = H2p/8)
-  const double ev = (1.0/12.0)*c2h + (1.0/480.0)*h4n;                      // even part minus s2 N
-  const double od = 0.5*c1 + (0.125/12.0)*(H3p*nH);
+  // and the constant coefficients never have to be formed.
+  // The 5th-order candidate's odd (c1/2 + c3/8) and even (c2/6 + c4/20) parts are combined before the weighting:
+  const double oH = 0.5*H1 + (0.125/12.0)*H3p;
+  const double eH = (0.125/12.0)*H2p + (1.0/480.0)*H4p;                    // H2 = H2p/16 -> c2/6 = H2p/96;  c4/20 = H4p/480
+  const double od = oH*nH + 0.5*(L1*nL + hC*nC + R1*nR);
+  const double ev = eH*nH + (1.0/12.0)*(L2p*nL + C2p*nC + R2p*nR);         // even part minus s2 N   (c2 = coefs3(2) = X2p/2)
   left  = s2 + (ev - od)*rN;
   right = s2 + (ev + od)*rN;
 }
