@@ -466,6 +466,9 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       const double ru_s = w[idU][wi] * rho_s, rv_s = w[idV][wi] * rho_s;
       double inv_rho_new = 1.0;
       double *so = Sout + slab0 + (long long)(kc + p.HZ) * p.sK;
+      double xpart[5], fzprev[5];                              // the LDS reads in one batch: one exposed LDS latency, not five
+#pragma unroll
+      for (int l = 0; l < 5; l++) { xpart[l] = lds_xpart[l][threadIdx.x]; fzprev[l] = lds_fzprev[l][threadIdx.x]; }
 #pragma unroll
       for (int l = 0; l < 5; l++) {
         double raw_s = w[l][wi];
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
         double q_n;
         if (STAGE == 1) q_n = q_s;
         else q_n = (l == idR || l == idT) ? snv[l] : snv[l] * rho_n;
-        double tend = lds_xpart[l][threadIdx.x] - (fzs[l] - lds_fzprev[l][threadIdx.x]) * p.rdz;
+        double tend = xpart[l] - (fzs[l] - fzprev[l]) * p.rdz;
         if (l == idW && p.enable_gravity) tend += -p.grav * rho_s;
         if (l == idU) tend += p.fcor * rv_s;
         if (l == idV) tend -= p.fcor * ru_s;
