@@ -55,6 +55,17 @@ __global__ __launch_bounds__(256) void k_kessler_init_min(unsigned long long *dt
   if (threadIdx.x == 0 && blockIdx.x == 0) *dtmax_bits = 0x7FF0000000000000ull;   // +inf
 }
 
+// Terminal velocity of rain, :256-260, from the density fields (one definition for the CFL pass, the chunk sweep and the
+// column sweep: the 16 bytes per cell of a stored copy cost more than recomputing it, and a rain-free wavefront skips it).
+__device__ __forceinline__ double kessler_velqr(double rho_r, double rd, double rho0) {
+#pragma clang fp contract(off)
+  if (!__any(rho_r != 0.0)) return 0.0;                       // wave-uniform; exact: 36.34 * 0^0.1364 * rhalf = 0
+  const double qr = rho_r / rd;                               // :140
+  const double r = 0.001 * rd;                                // :256
+  const double rhalf = sqrt(rho0 / rd);                       // :257  rho(0,i)/rho(k,i)
+  return 36.34 * pow_rain(qr * r, 0.1364) * rhalf;            // :260
+}
+
 __global__ __launch_bounds__(256) void k_kessler_prep(KesP p, const double *__restrict__ rho_v, const double *__restrict__ rho_r,
                                                       const double *__restrict__ rho_d, const double *__restrict__ temp,
                                                       double *__restrict__ velqr_out, double *__restrict__ flux_top, int chunk,
@@ -68,11 +79,10 @@ __global__ __launch_bounds__(256) void k_kessler_prep(KesP p, const double *__re
     const int k = (int)(idx / p.ncol);
     const long long i = idx - (long long)k * p.ncol;
     double rd = rho_d[idx];
-    double qr = rho_r[idx] / rd;                              // :140
+    const double rr = rho_r[idx];
+    double qr = rr / rd;                                      // :140
     double r = 0.001 * rd;                                    // :256
-    double rhalf = sqrt(rho_d[i] / rd);                       // :257  rho(0,i)/rho(k,i)
-    double velqr = 36.34 * pow_rain(qr * r, 0.1364) * rhalf;  // :260
-    velqr_out[idx] = velqr;
+    double velqr = kessler_velqr(rr, rd, rho_d[i]);           // :257-260
     if (k > 0 && k % chunk == 0) flux_top[(long long)(k / chunk - 1) * p.ncol + i] = r * qr * velqr;   // flux entering the chunk below
     if (k < p.nz - 1) {                                       // :262-268
       double zk = (k + 0.5) * p.dz, zk1 = (k + 1 + 0.5) * p.dz;   // zmid, :137
@@ -163,22 +173,22 @@ __global__ __launch_bounds__(256) void k_kessler_chunks(KesP p, double *__restri
   double flux_above = (k_hi < p.nz - 1) ? flux_top[(long long)c * p.ncol + i] : 0.0;
   // software prefetch: the next level's five inputs are in flight while this level is computed
   long long idx = (long long)k_hi * p.ncol + i;
-  double rd = rho_d[idx], T_in = temp[idx], rv_in = rho_v[idx], rc_in = rho_c[idx], rr_in = rho_r[idx], vq_in = velqr_in[idx];
+  double rd = rho_d[idx], T_in = temp[idx], rv_in = rho_v[idx], rc_in = rho_c[idx], rr_in = rho_r[idx];
   for (int k = k_hi; k >= k_lo; k--) {
     idx = (long long)k * p.ncol + i;
     const long long nidx = (long long)max(k - 1, k_lo) * p.ncol + i;
-    const double rd_n = rho_d[nidx], T_n = temp[nidx], rv_n = rho_v[nidx], rc_n = rho_c[nidx], rr_n = rho_r[nidx], vq_n = velqr_in[nidx];
+    const double rd_n = rho_d[nidx], T_n = temp[nidx], rv_n = rho_v[nidx], rc_n = rho_c[nidx], rr_n = rho_r[nidx];
     double pressure = p.R_d * rd * T_in + p.R_v * rv_in * T_in;          // :141
     const double pp0 = pressure * (1.0 / p.p0);
     double pk = pow_pos(pp0, p.R_d / p.cp_d);                            // :142 exner
     const double ird = rcp64(rd);
     double qv = rv_in * ird, qc = rc_in * ird, qr = rr_in * ird;         // :138-140
     double theta = T_in * rcp64(pk);                                     // :143
-    double velqr = vq_in;                                                // :260 (k_kessler_prep)
+    double velqr = kessler_velqr(rr_in, rd, rho0);                       // :260 (as k_kessler_prep saw it)
     flux_above = kessler_cell(p, k, rd, rho0, pk, pp0, dt0, flux_above, theta, qv, qc, qr, velqr, precl_acc);
     rho_v[idx] = qv * rd; rho_c[idx] = qc * rd; rho_r[idx] = qr * rd;    // :154-161 [K5]
     temp[idx] = theta * pk;
-    rd = rd_n; T_in = T_n; rv_in = rv_n; rc_in = rc_n; rr_in = rr_n; vq_in = vq_n;
+    rd = rd_n; T_in = T_n; rv_in = rv_n; rc_in = rc_n; rr_in = rr_n;
   }
   if (c == 0) precl[i] = precl_acc / 1.0;                                // :332-334
 }
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restri
       if (first) {
         qv = rv_in / rd; qc = rho_c[idx] / rd; qr = rho_r[idx] / rd;      // :138-140
         theta = T_in / pk;                                                // :143
-        velqr = w_velqr[idx];                                             // :260 (k_kessler_prep)
+        velqr = kessler_velqr(rho_r[idx], rd, rho0);                      // :260 (as k_kessler_prep saw it)
       } else { theta = w_theta[idx]; qv = w_qv[idx]; qc = w_qc[idx]; qr = w_qr[idx]; velqr = w_velqr[idx]; }
       flux_above = kessler_cell(p, k, rd, rho0, pk, pp0, dt0, flux_above, theta, qv, qc, qr, velqr, precl_acc);
       if (lastp) {                                                        // :154-161 [K5]
