@@ -982,16 +982,17 @@ static int xz_grid(mw_dycore_s *d, dim3 &grid, int &chunk, int &tiles_x) {
   return 0;
 }
 
-template <int STAGE>
-static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn, int par) {
+template <int STAGE, int MODE>
+static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn, int par,
+                           const CouplerPtrs &c) {
   const DyP &p = d->p;
   ProfScope ps(d, 0);
   dim3 grid; int chunk, tiles_x;
   if (xz_grid(d, grid, chunk, tiles_x)) return 1;
-  if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
-                                      d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x);
-  else             hipLaunchKernelGGL((k_xz_state<STAGE, false>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
-                                      d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x);
+  if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true, MODE>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
+                                      d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);
+  else             hipLaunchKernelGGL((k_xz_state<STAGE, false, MODE>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
+                                      d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -1098,7 +1099,7 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   // ---- state pipeline
   if (halo_fill(d, Sin, 0, 5, ss, 0, true)) return 1;
   if (launch_y_state(d, Sin, par)) return 1;                                  // y faces: m_upw, selector, y tendencies
-  if (launch_xz_state<STAGE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par)) return 1;   // x,z faces + finished state variables
+  if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
   // previous stage, which this stream produced itself: it is issued BEFORE the wait for this stage's state kernels and so
   // runs beside them; the state stream's exchange for stage s+1 in turn runs beside this stage's tracer kernels.

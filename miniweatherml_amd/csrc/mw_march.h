@@ -333,12 +333,14 @@ __device__ __forceinline__ void x_neighbours(double c0, const double *__restrict
   } else { m2 = lvl[om2]; m1 = lvl[om1]; p1 = lvl[op1]; p2 = lvl[op2]; }
 }
 
-template <int STAGE, bool N1>
+// MODE 1 (last stage of the last cycle): u, v, w also go to the coupler's arrays (D13, :1929-1932: the slab holds (rho u)/rho
+// already), so that the tracer stage, which finishes D13, neither re-reads nor re-writes them.
+template <int STAGE, bool N1, int MODE>
 __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
                                                   double *__restrict__ Sout, double *__restrict__ MX, double *__restrict__ MZ,
                                                   unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                   const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
-                                                  int tiles_x) {
+                                                  int tiles_x, double *__restrict__ cu, double *__restrict__ cv, double *__restrict__ cw) {
   const XzGeom g = xz_geom<N1>(p, chunk, tiles_x);
   if (!g.valid) return;
   const int n = g.n, lane = g.lane, NXI = g.NXI, j = g.j, q = g.q, e = g.e;
@@ -487,7 +489,10 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
         else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
         else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
         if (l == idR) inv_rho_new = fast_rcp(qnew + hyc);
-        if (g.owns_cell) so[(long long)l * p.sV] = (l == idR || l == idT) ? qnew : qnew * inv_rho_new;
+        const double stored = (l == idR || l == idT) ? qnew : qnew * inv_rho_new;
+        if (g.owns_cell) so[(long long)l * p.sV] = stored;
+        if (MODE == 1 && g.owns_cell && (l == idU || l == idV || l == idW))
+          (l == idU ? cu : l == idV ? cv : cw)[cell0 + (long long)kc * planeC] = stored;
       }
     }
     // ------------------------------------------------ carries for the next level
@@ -809,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     const long long so = (long long)(kuc + p.HZ) * p.sK + so_row;
     const double hyc_u = p.hyc[kuc * p.nens + e];
     const double rho_new = Sout[so + idR * p.sV] + hyc_u;
-    double qn_[T], rho_n = 0, st_T = 0, st_U = 0, st_V = 0, st_W = 0;
+    double qn_[T], rho_n = 0, st_T = 0;
 #pragma unroll
     for (int v = 0; v < T; v++) qn_[v] = 0;
     if (STAGE != 1) {
@@ -817,7 +822,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #pragma unroll
       for (int v = 0; v < T; v++) qn_[v] = Sn[so + (5 + t0 + v) * p.sV];
     }
-    if (MODE == 1) { st_T = Sout[so + idT * p.sV]; st_U = Sout[so + idU * p.sV]; st_V = Sout[so + idV * p.sV]; st_W = Sout[so + idW * p.sV]; }
+    if (MODE == 1) st_T = Sout[so + idT * p.sV];              // (u, v, w were written to the coupler by k_xz_state<3, ., 1>)
     // nens > 1: the x-stencil neighbours of level k come from memory (issued here, with the iteration's other loads)
     double nbw2[T], nbw1[T], nbe1[T], nbe2[T];
 #pragma unroll
@@ -923,7 +928,6 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         const int hi = kuc * p.nens + e;
         double press = pressure_fast(p, st_T, p.hytc[hi], p.p0c[hi], p.ihytc[hi]);
         c.rho_d[ci] = rho_dry;
-        c.u[ci] = st_U; c.v[ci] = st_V; c.w[ci] = st_W;
         c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);
       }
     }
