@@ -187,13 +187,15 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
           weno5_edges_fast(qv[-2 * p.sJ], qv[-p.sJ], qv[0], qv[p.sJ], qv[2 * p.sJ], l_, r_); se[v] = l_; }
       }
       double Lr = cn[idR], Lu = cn[idV], Lt = cn[idT], Rr = se[idR], Ru = se[idV], Rt = se[idT];
-      if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; }
-      if (bcmode == 2) { Rr = Lr; Ru = Lu; Rt = Lt; }
+      const bool ybc = (bcmode == 1 || bcmode == 2);           // wave-uniform (j is): a branch, interior faces carry no selects
+      if (__builtin_expect(ybc, 0)) {
+        if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; } else { Rr = Lr; Ru = Lu; Rt = Lt; }
+        if (zero) { Lu = 0.0; Ru = 0.0; }                      // = the reference's zeroed normal momentum on both sides
+      }
       double f[5], fn, fT;
-      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, zero, fn, fT);
+      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, false, fn, fT);
       int up = fs.ind;
-      if (bcmode == 1) up = 1;     // both sides hold the R (cell j) values
-      if (bcmode == 2) up = 0;
+      if (__builtin_expect(ybc, 0)) up = (bcmode == 1) ? 1 : 0;   // both sides hold the R (cell j) / L values
       f[idR] = fs.m_upw; f[idV] = fn; f[idT] = fT;
       {   // scalar copies first: a select between elements of two arrays is lowered to a pointer select -> scratch memory
         const double sU = se[idU], cU = cn[idU], sW = se[idW], cW = cn[idW];
@@ -437,17 +439,17 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       const double *hp = p.hypk + (long long)(k * n + e) * 8;
       const double hyr = hp[4], hyt = hp[5], p0 = hp[6], ihyt = hp[7];
       double Lr = ct[idR], Lu = ct[idW], Lt = ct[idT], Rr = be[idR], Ru = be[idW], Rt = be[idT];
-      int bcmode = 0;
-      if (k == 0) bcmode = 1;                                  // :1020-1038 wall/open edge-value rule
-      if (top) bcmode = 2;
-      const bool zero = bcmode && (p.bc_z == MW_BC_WALL);
-      if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; }
-      if (bcmode == 2) { Rr = Lr; Ru = Lu; Rt = Lt; }
+      // :1020-1038 wall/open edge-value rule at the two boundary faces.  k is wave-uniform: a branch, so that the interior faces
+      // carry no selects (a zero normal velocity on both sides is what the reference's "zero the momentum" amounts to).
+      const bool zbc = (k == 0) || top;
+      if (__builtin_expect(zbc, 0)) {
+        if (k == 0) { Lr = Rr; Lu = Ru; Lt = Rt; } else { Rr = Lr; Ru = Lu; Rt = Lt; }
+        if (p.bc_z == MW_BC_WALL) { Lu = 0.0; Ru = 0.0; }
+      }
       double fn, fT;
-      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, zero, fn, fT);
+      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, false, fn, fT);
       int up = fs.ind;
-      if (bcmode == 1) up = 1;
-      if (bcmode == 2) up = 0;
+      if (__builtin_expect(zbc, 0)) up = (k == 0) ? 1 : 0;
       fzs[idR] = fs.m_upw; fzs[idW] = fn; fzs[idT] = fT;
       fzs[idU] = fs.m_upw * (up ? be[idU] : ct[idU]);
       fzs[idV] = fs.m_upw * (up ? be[idV] : ct[idV]);
