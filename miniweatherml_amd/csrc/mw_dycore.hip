@@ -50,6 +50,7 @@ struct DyP {                      // kernel parameter block (by value)
                                                // p0e, ihyte)[(k*nens+e)*8 + f], nz+1 rows: one pointer instead of eight in the hot kernels
   double bn[11];                               // binomial series coefficients C(gamma, n), n = 0..10
   int bn_default;                              // bn[] equals the literal table for gamma = 1003/716 bit for bit (the usual case)
+  int an_default;                              // likewise C(1/gamma, n) of the conversion's inverse series (mw_march.h)
 };
 
 struct CouplerPtrs {
@@ -755,6 +756,7 @@ struct mw_dycore_s {
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
   int chunk_y = 0, chunk_yt = 0, chunk_z = 0, chunk_f = 0;
+  bool conv_pending = false;               // time_step: the coupler -> slab conversion is still to be done by stage 1's k_y_state
   unsigned int *dirty = nullptr;           // two words: "a y face was scaled in this / the next fused tracer launch"
   unsigned long long fused_launches = 0;
   unsigned char *flags = nullptr;          // fused tracer stage: per-cell "a y face of this cell was FCT-scaled" bits
@@ -815,6 +817,13 @@ static void fill_params(mw_dycore_s *d) {
   for (int n = 1; n <= 10; n++) { bn = bn * ((long double)g.gamma_d - (n - 1)) / n; p.bn[n] = (double)bn; }
   p.bn_default = 1;
   for (int n = 0; n <= 10; n++) if (p.bn[n] != BN_DEFAULT[n]) p.bn_default = 0;
+  { static const double AN_DEFAULT[11] = {1.0, 0x1.6d7ed9f857ccfp-1, -0x1.a255770e765c3p-4, 0x1.66b0e7bdc9cadp-5, -0x1.9a025de3c9f2fp-6,
+                                         0x1.0d783d4c75011p-6, -0x1.80febd2957c9ap-7, 0x1.22bbebca1e45p-7, -0x1.c8e61cbaa3102p-8,
+                                         0x1.71e467e9895fp-8, -0x1.327f77d85aeeep-8};
+    const long double a = 1.0L / (long double)g.gamma_d;
+    long double an = 1.0L;                                  // C(1/gamma, n)
+    p.an_default = 1;
+    for (int n = 1; n <= 10; n++) { an = an * (a - (n - 1)) / n; if ((double)an != AN_DEFAULT[n]) p.an_default = 0; } }
 }
 
 static int upload_background(mw_dycore_s *d) {
@@ -932,7 +941,8 @@ static int balanced_chunk(int nz, long long base_waves, const char *env, long lo
   return (int)((nz + nch - 1) / nch);
 }
 
-static int launch_y_state(mw_dycore_s *d, const double *S, int par) {
+// conv != nullptr: the slab S is still empty -- the kernel converts the coupler's fields on the way and fills it (k_y_state<true>)
+static int launch_y_state(mw_dycore_s *d, const double *S, int par, const CouplerPtrs *conv = nullptr) {
   const DyP &p = d->p;
   if (p.sim2d) return 0;
   ProfScope ps(d, 5);
@@ -940,7 +950,10 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par) {
   // measured on 400x400x100 (625 wave columns): 8 x 50 rows for k_y_state, 14 x 29 for k_y_tracers (-5 % / -2 % vs. 32-row chunks)
   int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000));
   dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
-  hipLaunchKernelGGL(k_y_state, grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk);
+  if (conv) hipLaunchKernelGGL((k_y_state<true>), grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv,
+                               const_cast<double *>(S));
+  else      hipLaunchKernelGGL((k_y_state<false>), grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk,
+                               CouplerPtrs(), nullptr);
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -1098,7 +1111,9 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   if (d->overlap && gs >= 2) MW_HIP(hipStreamWaitEvent(ss, d->ev_tr[(gs - 2) & 7], 0));
   // ---- state pipeline
   if (halo_fill(d, Sin, 0, 5, ss, 0, true)) return 1;
-  if (launch_y_state(d, Sin, par)) return 1;                                  // y faces: m_upw, selector, y tendencies
+  const bool conv = (STAGE == 1) && d->conv_pending;            // first stage of the step: D1 + D2 inside k_y_state
+  d->conv_pending = false;
+  if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
   // previous stage, which this stream produced itself: it is issued BEFORE the wait for this stage's state kernels and so
@@ -1322,8 +1337,6 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   fill_params(d);
   const DyP &p = d->p;
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
-  { ProfScope ps(d, 4);
-    hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK(); }       // :101 (+ D2)
   const bool march = (d->strict == 0);                        // production path; strict = 1/2 use the general
                                                               // flux-materialising kernels below
   if (march && !getenv("MW_NO_WRAP")) {                       // index wrap instead of halo cells (see DyP::wrap_x)
@@ -1338,6 +1351,15 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     bool want = ov ? (atoi(ov) != 0) : (d->xchg != nullptr);
     if (getenv("MW_NO_OVERLAP")) want = false;
     d->overlap = march && d->tstream && want; }
+  // D1 + D2 (:101, :248-255).  Production path on one stream with periodic x and y owned by this rank: done inside the first
+  // k_y_state (no separate pass); otherwise a conversion kernel first (the reference's operation order on the general path).
+  d->conv_pending = march && !d->overlap && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT");
+  if (!d->conv_pending) {
+    ProfScope ps(d, 4);
+    if (march && p.nt <= 4) hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
+    else       hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
+    MW_LAUNCH_CHECK();
+  }
   if (d->overlap) { MW_HIP(hipEventRecord(d->ev_misc, d->stream)); MW_HIP(hipStreamWaitEvent(d->tstream, d->ev_misc, 0)); d->gstage = 0; }
   double dt_dyn = mw_dycore_compute_time_step(&d->g);                     // :104
   int ncycles = (int)std::ceil(dt_phys / dt_dyn);                         // :107

@@ -140,11 +140,101 @@ __device__ __forceinline__ int bc_mode_x(const DyP &p, int i) {                 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// D1 + D2 for the production path (convert_coupler_to_dynamics :1955-2015 with the stage-1 divide :248-255), fast arithmetic:
+// rho theta = (p/C0)^(1/gamma) is written as hy_rho_theta(k) (1 + delta)^(1/gamma) with delta = p/p_hy(k) - 1 -- the inverse of
+// the Riemann solver's pressure series: 10 FMAs instead of the ~230 instructions of pow, and the stored PERTURBATION
+// hyt ((1+delta)^(1/gamma) - 1) comes out without the cancellation of pow(...) - hyt.  |delta| > 0.05 or a non-default gamma: pow.
+// C(1/gamma, n), n = 10..1, for gamma = 1003/716 (the long-double recurrence of fill_params as hex literals).
+// ---------------------------------------------------------------------------------------------------------------
+// out of line (as pressure_pow): the pow body must not be inlined into k_y_state, which sits at the register limit
+__device__ __attribute__((noinline)) double rhotheta_ratio_pow(double press_over_C0, double inv_gamma, double hyt) {
+  return pow(press_over_C0, inv_gamma) / hyt - 1.0;
+}
+__device__ __forceinline__ double inv_gamma_series_default(double dl) {
+#pragma clang fp contract(fast)
+  double acc = -0x1.327f77d85aeeep-8;
+  acc = acc * dl + 0x1.71e467e9895fp-8;
+  acc = acc * dl + -0x1.c8e61cbaa3102p-8;
+  acc = acc * dl + 0x1.22bbebca1e45p-7;
+  acc = acc * dl + -0x1.80febd2957c9ap-7;
+  acc = acc * dl + 0x1.0d783d4c75011p-6;
+  acc = acc * dl + -0x1.9a025de3c9f2fp-6;
+  acc = acc * dl + 0x1.66b0e7bdc9cadp-5;
+  acc = acc * dl + -0x1.a255770e765c3p-4;
+  acc = acc * dl + 0x1.6d7ed9f857ccfp-1;
+  return acc;
+}
+// One cell of the coupler, as loaded (the marching kernel requests row j+3 at the top of iteration j and converts it at the end).
+struct CouplerCell { double rho_d, u, v, w, temp, tr[4]; };
+__device__ __forceinline__ CouplerCell load_coupler_cell(const DyP &p, const CouplerPtrs &c, long long ci) {
+  CouplerCell r;
+  r.rho_d = c.rho_d[ci]; r.u = c.u[ci]; r.v = c.v[ci]; r.w = c.w[ci]; r.temp = c.temp[ci];
+#pragma unroll
+  for (int tr = 0; tr < 4; tr++) r.tr[tr] = (tr < p.nt) ? c.tr[tr][ci] : 0.0;
+  return r;
+}
+// -> the five state variables of the slab (rho', u, v, w, (rho theta)') and 1/rho for the tracers.  hi = k*nens + e.  The last
+// operation of every result is not contractable, so that a caller that goes on computing with the values sees exactly what is stored.
+__device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCell &r, int hi, double *s5, double &inv_den) {
+  double rho, ru, rv, rw, sd, hyt, rp;
+  {
+#pragma clang fp contract(fast)
+    rho = r.rho_d;
+    double rho_v = 0;
+#pragma unroll
+    for (int tr = 0; tr < 4; tr++) {
+      if ((p.mass_mask >> tr) & 1u) rho += r.tr[tr];           // (tracers beyond nt were loaded as 0 and have no mask bit)
+      if (tr == p.idWV) rho_v = r.tr[tr];
+    }
+    const double press = r.rho_d * p.R_d * r.temp + rho_v * p.R_v * r.temp;
+    const double hyc = p.hyc[hi], p0 = p.p0c[hi];
+    hyt = p.hytc[hi];
+    const double dl = press * fast_rcp(p0) - 1.0;
+    if (fabs(dl) <= 0.05 && p.an_default) sd = inv_gamma_series_default(dl) * dl;
+    else                                  sd = rhotheta_ratio_pow(press / p.C0, 1.0 / p.gamma, hyt);
+    rp = rho - hyc;                                            // state(idR)
+    inv_den = fast_rcp(rp + hyc);                              // what D2 divides by (:249)
+    ru = rho * r.u; rv = rho * r.v; rw = rho * r.w;
+  }
+  {
+#pragma clang fp contract(off)
+    s5[idR] = rp; s5[idU] = ru * inv_den; s5[idV] = rv * inv_den; s5[idW] = rw * inv_den; s5[idT] = hyt * sd;
+  }
+}
+// the tracers of that cell: slab value = rho_t / rho
+__device__ __forceinline__ void convert_cell_tracers(const DyP &p, const CouplerCell &r, double inv_den, double *__restrict__ s) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int tr = 0; tr < 4; tr++) if (tr < p.nt) s[(long long)(5 + tr) * p.sV] = r.tr[tr] * inv_den;
+}
+// stand-alone form (2-D runs, walls / open boundaries or a neighbour exchange in y, two-stream schedule)
+__global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtrs c, double *__restrict__ S) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  const int NXI = p.nx * p.nens;
+  if (t >= (long long)p.ny * NXI) return;
+  const int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  const long long ci = ((long long)k * p.ny + j) * NXI + ie;
+  const CouplerCell r = load_coupler_cell(p, c, ci);
+  double s5[5], inv_den;
+  convert_cell_fast(p, r, k * p.nens + ie % p.nens, s5, inv_den);
+  double *s = S + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
+#pragma unroll
+  for (int v = 0; v < 5; v++) s[(long long)v * p.sV] = s5[v];
+  convert_cell_tracers(p, r, inv_den, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Y pass, state variables.  thread = (k, interior fused-x lane), marches j over [ja-1, jb] for the chunk [ja, jb).
+// CONV (first stage of a step, periodic y owned by one rank): the rows are not read from the slab but converted from the
+// coupler's arrays while they are loaded, and the chunk writes the slab rows it owns (state variables and tracers) on the way:
+// the separate conversion pass -- 16 arrays read or written -- disappears.
 // Writes FY[idR] (= m_upw), UPY (selector) for faces ja..jb and tendY (5,nz,ny,nx,nens) for rows ja..jb-1.
 // ---------------------------------------------------------------------------------------------------------------
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restrict__ S, double *__restrict__ MY,
-                                                 unsigned char *__restrict__ UPY, double *__restrict__ tendY, int chunk) {
+                                                 unsigned char *__restrict__ UPY, double *__restrict__ tendY, int chunk,
+                                                 CouplerPtrs c, double *__restrict__ Sw) {
   const int NXI = p.nx * p.nens;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
   if (t >= (long long)p.nz * NXI) return;
@@ -160,15 +250,41 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   unsigned char *upy = UPY + (long long)k * p.fyK + ie;
   double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
   double w[5][5], nxt[5], cn[5], fprev[5];
+  // CONV: row r (halo rows wrap) comes from the coupler; the rows ja..jb-1 are this chunk's to store.  The row is REQUESTED at the
+  // top of an iteration and converted at its end, when the values have arrived.
+  const int hi = k * p.nens + e;
+#define MW_ROW_CI(r) (((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
+#define MW_ROW_FINISH(raw, r, out5)                                                                                   \
+  { double inv_den_;                                                                                                  \
+    convert_cell_fast(p, raw, hi, out5, inv_den_);                                                                    \
+    if ((r) >= ja && (r) < jb) {                                                                                      \
+      double *s_ = Sw + (long long)(k + p.HZ) * p.sK + (long long)((r) + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;  \
+      s_[0] = out5[0]; s_[p.sV] = out5[1]; s_[2 * p.sV] = out5[2]; s_[3 * p.sV] = out5[3]; s_[4 * p.sV] = out5[4];    \
+      convert_cell_tracers(p, raw, inv_den_, s_);                                                                     \
+    } }
 #pragma unroll
-  for (int v = 0; v < 5; v++) {
-    cn[v] = 0; fprev[v] = 0;
+  for (int v = 0; v < 5; v++) { cn[v] = 0; fprev[v] = 0; }
+  if (CONV) {
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - 2 + s) + p.HY) * p.sJ];
+    for (int s = 0; s < 5; s++) {
+      const CouplerCell raw = load_coupler_cell(p, c, MW_ROW_CI(ja - 1 - 2 + s));
+      double r5[5];
+      MW_ROW_FINISH(raw, ja - 1 - 2 + s, r5)
+#pragma unroll
+      for (int v = 0; v < 5; v++) w[v][s] = r5[v];
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < 5; v++) {
+#pragma unroll
+      for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - 2 + s) + p.HY) * p.sJ];
+    }
   }
   for (int j = ja - 1; j <= jb; j++) {
-    {
-      const int jn = min(j + 3, p.ny + p.HY - 1);               // clamp: the last prefetch is never used
+    const int jn = min(j + 3, p.ny + p.HY - 1);                 // clamp: the last prefetch is never used
+    CouplerCell raw;
+    if (CONV) raw = load_coupler_cell(p, c, MW_ROW_CI(jn));
+    else {
 #pragma unroll
       for (int v = 0; v < 5; v++) nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
     }
@@ -210,12 +326,15 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 #pragma unroll
       for (int l = 0; l < 5; l++) fprev[l] = f[l];
     }
+    if (CONV) MW_ROW_FINISH(raw, jn, nxt)
 #pragma unroll
     for (int v = 0; v < 5; v++) {
       cn[v] = ne[v];
       w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
     }
   }
+#undef MW_ROW_CI
+#undef MW_ROW_FINISH
 }
 
 // Y pass, tracers: flux(face j) = m_upw * (up ? south edge of cell j : north edge of cell j-1)
