@@ -127,6 +127,27 @@ def test_index_wrap_is_bitwise_the_halo_fill(mw, monkeypatch):
             assert torch.equal(out[0][n], out[1][n]), (nens, n)
 
 
+def test_conversion_inside_y_state_is_bitwise_the_conversion_pass(mw, monkeypatch):
+    """One rank, periodic x/y, one stream: the first k_y_state converts the coupler rows it loads and fills the slab (default);
+    MW_NO_FUSED_CONVERT=1 runs k_coupler_to_state_fast first.  Same device function on the same inputs: identical fields, also
+    with sub-cycling (only the first cycle converts) and with a developed, perturbed state."""
+    import torch
+    from miniweatherml_amd import modules
+    out = []
+    for nofuse in (None, "1"):
+        if nofuse: monkeypatch.setenv("MW_NO_FUSED_CONVERT", nofuse)
+        else: monkeypatch.delenv("MW_NO_FUSED_CONVERT", raising=False)
+        coupler, dycore, _ = modules.make_supercell(90, 70, 30, 1, 45000., 35000., 20000.)
+        modules.perturb_temperature(coupler)
+        dt = dycore.compute_time_step(coupler)
+        for n in range(4):
+            dycore.time_step(coupler, dt * (2.5 if n == 2 else 1.0))          # step 2: three sub-cycles
+        dm = coupler.get_data_manager_readonly()
+        out.append({n: dm.get(n, True).clone() for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid")})
+    for n in out[0]:
+        assert torch.equal(out[0][n], out[1][n]), n
+
+
 def test_config4_block_per_gpu(mw):
     """BASELINE.json configs[3]: the per-GPU block of the 8-GPU supercell run, 256 x 512 x 128 with 4 ensemble members
     (6.7e7 cells, 4.3 GB per slab: byte offsets far beyond 2^32).  Members identical, mass conserved, tracers positive."""
