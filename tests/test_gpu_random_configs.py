@@ -1,6 +1,8 @@
 """Seeded random configurations of the production path against the oracle: grid shape (odd sizes, 2-D and 3-D), ensemble size,
 number of tracers and their positive / adds_mass flags, boundary conditions, z / y chunk sizes of the marching kernels, and a
 rough state (random wind, sparse tracers) that keeps the FCT limiter busy.  Complements the hand-picked cases elsewhere."""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,7 +26,7 @@ def draw(seed):
     return dict(nx=nx, ny=ny, nz=nz, nens=nens, nt=nt, pos=pos, adds=adds, bc=bc, chunks=chunks, rng=rng)
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MW_RANDOM_SEEDS", "32"))))     # MW_RANDOM_SEEDS=300: a longer sweep
 def test_random_configuration(mw, oracle, seed, monkeypatch):
     from miniweatherml_amd import modules
     c = draw(seed)
