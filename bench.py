@@ -67,16 +67,41 @@ def cpu_baseline(sample):
                       "(oracle/mw_oracle.cpp, -O2 -ffp-contract=off), %.1f s on 1 of %d host cores" % (nx, ny, nz, el, os.cpu_count())}
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, one per GPU, as a
+    `torch.distributed.run` CHILD process -- this parent never touches the GPU (no HIP call before or after; counting devices
+    does not initialise it), relays the child's output and exits with its code."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < a.gpus:
+        sys.exit("bench.py: --gpus %d requested but only %d GPU(s) are visible on this node" % (a.gpus, ndev))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL between processes needs it on this pool
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a)                                           # does not return
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if rank == 0 and world != 1:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    if world != a.gpus:                                          # a launcher started a different number of ranks than asked for
+        sys.exit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d" % (a.gpus, world))
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit("bench.py: rank %d (LOCAL_RANK %d) has no GPU: %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     if world > 1:
@@ -102,21 +127,7 @@ def main():
                                                         nranks=world, myrank=rank)
     assert coupler.get_nx() == a.nx and (coupler.get_ny() == a.ny or ny_glob == 1)
     dycore.set_strict(a.strict)
-    transport = "none"
-    if world > 1:
-        transport = a.transport
-        if transport == "rccl":
-            try:
-                modules.use_rccl_exchange(dycore, coupler)
-            except capi.MWError as e:                              # e.g. communicator creation refused: use torch's RCCL group
-                print("rank %d: built-in RCCL transport unavailable (%s); using torch.distributed p2p" % (rank, e), file=sys.stderr)
-                transport = "torch"
-            flag = torch.tensor([1 if transport == "torch" else 0], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)          # all ranks must agree on the transport
-            if int(flag.item()) == 1:
-                transport = "torch"
-        if transport == "torch":
-            modules.use_torch_distributed_exchange(dycore, coupler)
+    transport = modules.install_exchange(dycore, coupler, a.transport) if world > 1 else "none"   # all ranks agree on one
 
     dt = dycore.compute_time_step(coupler)
     V = 5 + coupler.get_num_tracers()

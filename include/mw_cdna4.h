@@ -152,6 +152,10 @@ int  mw_dycore_set_exchange(mw_dycore_t h, mw_exchange_fn fn, void *ctx);
  * unique_id: the 128-byte ncclUniqueId created on rank 0 (mw_rccl_unique_id) and broadcast by the host. */
 int  mw_rccl_unique_id(unsigned char *id128);
 int  mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, int myrank);
+/* RCCL is resolved at run time from the librccl ALREADY mapped in the process (a PyTorch host: torch's own, the one behind
+ * torch.distributed's "nccl" backend), else from the loader's search path -- never two RCCLs in one process.  Returns the
+ * path it came from ("" when none is available) and, optionally, its version code (ncclGetVersion). */
+const char *mw_rccl_library_path(int *version);
 /* Diagnostic: one rank sends 4 strips of n doubles to itself through the exchange's own ncclGroup / side stream / event
  * sequence and compares; 0 = RCCL initialises on this box and the ordering against `stream` holds. */
 int  mw_rccl_selftest(long long n, void *stream);

@@ -38,8 +38,8 @@ def build(force=False, verbose=True):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + \
-              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+        # RCCL is NOT linked: mw_rccl.cpp resolves it at run time from the librccl already mapped in the process (one RCCL)
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

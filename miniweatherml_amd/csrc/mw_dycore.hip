@@ -774,7 +774,7 @@ struct mw_dycore_s {
   int prof = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[8];
   size_t ev_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  void *rccl = nullptr;                      // mw_rccl.cpp state
+  void (*xchg_free)(void *) = nullptr;       // set when the handle owns xchg_ctx (the built-in RCCL transport, mw_rccl.cpp)
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Padding the blocks-per-plane count to a
@@ -1150,6 +1150,16 @@ static int make_coupler_ptrs(mw_dycore_s *d, const double *rho_d, const double *
   return 0;
 }
 
+// A block of a decomposed domain needs its neighbours' strips: without a transport the halo fill would wrap the block onto
+// itself and the result would be silently wrong (the reference always exchanges, :641-723).
+static int need_exchange(const mw_dycore_s *d) {
+  const mw_grid_t &g = d->g;
+  if (!d->xchg && (g.nproc_x > 1 || (g.nproc_y > 1 && g.ny_glob != 1)))
+    MW_FAIL("this handle is one block of a " + std::to_string(g.nproc_x) + " x " + std::to_string(g.nproc_y) +
+            " rank grid but no halo-exchange transport is installed (mw_dycore_use_rccl / mw_dycore_set_exchange)");
+  return 0;
+}
+
 static int validate_grid(const mw_grid_t *g) {
   if (!g) MW_FAIL("null grid");
   if (g->nz < 3 || g->nx < 3 || g->ny < 1 || g->nens < 1) MW_FAIL("grid too small (need nz,nx >= 3, ny >= 1, nens >= 1)");
@@ -1235,6 +1245,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
+  if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
   for (int w = 0; w < 8; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete d;
@@ -1298,6 +1309,11 @@ int mw_dycore_get_fluxes(mw_dycore_t d, double **out6) {
 
 int mw_dycore_set_exchange(mw_dycore_t d, mw_exchange_fn fn, void *ctx) {
   if (!d) MW_FAIL("null handle");
+  if (d->xchg_free && d->xchg_ctx && d->xchg_ctx != ctx) {     // a transport the handle owned is being replaced
+    (void)hipStreamSynchronize(d->stream); if (d->tstream) (void)hipStreamSynchronize(d->tstream);
+    d->xchg_free(d->xchg_ctx);
+  }
+  d->xchg_free = nullptr;
   d->xchg = fn; d->xchg_ctx = ctx;
   if (fn) {
     for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) {
@@ -1336,6 +1352,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   if (make_coupler_ptrs(d, rho_d, u, v, w, temp, tracers, c)) return 1;
   fill_params(d);
   const DyP &p = d->p;
+  if (need_exchange(d)) return 1;
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
   const bool march = (d->strict == 0);                        // production path; strict = 1/2 use the general
                                                               // flux-materialising kernels below
@@ -1404,6 +1421,7 @@ int mw_dycore_compute_tendencies(mw_dycore_t d, const double *rho_d, const doubl
   if (make_coupler_ptrs(d, rho_d, u, v, w, temp, tracers, c)) return 1;
   fill_params(d);
   const DyP &p = d->p;
+  if (need_exchange(d)) return 1;
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
   hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK();
   if (halo_fill(d, d->S0)) return 1;
@@ -1439,6 +1457,14 @@ int mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream) {
 }
 
 } // extern "C"
+
+namespace mw {
+int dycore_set_exchange_owned(mw_dycore_t d, mw_exchange_fn fn, void *ctx, void (*free_ctx)(void *)) {
+  if (mw_dycore_set_exchange(d, fn, ctx)) return 1;
+  d->xchg_free = free_ctx;
+  return 0;
+}
+} // namespace mw
 
 // ---- init (:1197-1683): host column profiles + device quadrature --------------------------------------
 namespace {

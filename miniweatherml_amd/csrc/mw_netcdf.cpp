@@ -48,6 +48,7 @@ struct mw_nc_s {
   std::vector<Dim> dims;
   std::vector<Var> vars;
   std::vector<unsigned char> swapbuf;
+  void *stage_dev = nullptr, *stage_host = nullptr; size_t stage_cap = 0;   // mw_output_put_field's staging pair (grow-only, freed in close)
 
   void put32(std::vector<unsigned char> &b, uint32_t v) { uint32_t x = be32(v); b.insert(b.end(), (unsigned char *)&x, (unsigned char *)&x + 4); }
   void put64(std::vector<unsigned char> &b, uint64_t v) { uint64_t x = be64(v); b.insert(b.end(), (unsigned char *)&x, (unsigned char *)&x + 8); }
@@ -101,6 +102,24 @@ static int pread_all(int fd, void *buf, size_t n, long long off) {
   }
   return 0;
 }
+
+namespace mw {
+// One device + one pinned host staging buffer per file handle for mw_output_put_field (mw_output.hip): allocating and freeing
+// a pair per field and record (hipMalloc / hipHostMalloc are device-wide synchronisation points) serialised output-heavy runs.
+int nc_staging(mw_nc_t nc, size_t bytes, double **dev, double **host) {
+  if (nc->stage_cap < bytes) {
+    if (nc->stage_dev) (void)hipFree(nc->stage_dev);
+    if (nc->stage_host) (void)hipHostFree(nc->stage_host);
+    nc->stage_dev = nc->stage_host = nullptr; nc->stage_cap = 0;
+    if (hipMalloc(&nc->stage_dev, bytes) != hipSuccess) { nc->stage_dev = nullptr; MW_FAIL("output staging: hipMalloc failed"); }
+    if (hipHostMalloc(&nc->stage_host, bytes, hipHostMallocDefault) != hipSuccess) {
+      (void)hipFree(nc->stage_dev); nc->stage_dev = nc->stage_host = nullptr; MW_FAIL("output staging: hipHostMalloc failed"); }
+    nc->stage_cap = bytes;
+  }
+  *dev = (double *)nc->stage_dev; *host = (double *)nc->stage_host;
+  return 0;
+}
+} // namespace mw
 
 extern "C" {
 
@@ -301,6 +320,8 @@ int mw_nc_set_numrecs(mw_nc_t nc, long long numrecs) {
 int mw_nc_close(mw_nc_t nc) {
   if (!nc) return 0;
   int rc = 0;
+  if (nc->stage_dev) (void)hipFree(nc->stage_dev);
+  if (nc->stage_host) (void)hipHostFree(nc->stage_host);
   if (nc->fd >= 0) { if (fsync(nc->fd) != 0) rc = 1; if (close(nc->fd) != 0) rc = 1; }
   delete nc;
   if (rc) MW_FAIL("nc_close: fsync/close failed");

@@ -134,6 +134,8 @@ static int six_ptrs(double *const *p, Six &s, const char *what) {
   return 0;
 }
 
+namespace mw { int nc_staging(mw_nc_t nc, size_t bytes, double **dev, double **host); }   // mw_netcdf.cpp
+
 extern "C" {
 
 int mw_output_put_field(mw_nc_t nc, int varid, long long record, const mw_grid_t *g, const double *field, void *stream) {
@@ -142,8 +144,7 @@ int mw_output_put_field(mw_nc_t nc, int varid, long long record, const mw_grid_t
   hipStream_t st = (hipStream_t)stream;
   const long long ncell = (long long)g->nz * g->ny * g->nx;
   double *dev = nullptr, *host = nullptr;
-  MW_HIP(hipMalloc(&dev, (size_t)ncell * sizeof(double)));
-  if (hipHostMalloc(&host, (size_t)ncell * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipFree(dev); MW_FAIL("hipHostMalloc failed"); }
+  if (nc_staging(nc, (size_t)ncell * sizeof(double), &dev, &host)) return 1;      // cached in the file handle, freed by mw_nc_close
   int rc = 0;
   hipLaunchKernelGGL(k_extract_member, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, field, ncell, g->nens, 0, dev);   // iens = 0 (:2035)
   if (hipGetLastError() != hipSuccess || hipMemcpyAsync(host, dev, (size_t)ncell * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -154,7 +155,6 @@ int mw_output_put_field(mw_nc_t nc, int varid, long long record, const mw_grid_t
     else             { const long long start[3] = {0, g->j_beg, g->i_beg}, count[3] = {g->nz, g->ny, g->nx};
                        rc = mw_nc_put_vara_double(nc, varid, start, count, host); }
   }
-  (void)hipHostFree(host); (void)hipFree(dev);
   return rc;
 }
 

@@ -10,11 +10,66 @@
 // =====================================================================================================
 #include "../../include/mw_cdna4.h"
 #include "mw_common.h"
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is NOT linked, see RcclApi below
+#include <dlfcn.h>
+#include <link.h>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
+namespace mw {   // defined in mw_dycore.hip: installs a transport whose context the handle owns (freed on replace / destroy)
+int dycore_set_exchange_owned(mw_dycore_t h, mw_exchange_fn fn, void *ctx, void (*free_ctx)(void *));
+}
+
 namespace {
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE RCCL per process.  A PyTorch host has already mapped its own librccl (torch/lib/librccl.so, the one behind
+// torch.distributed's "nccl" backend); linking libmw_cdna4.so against /opt/rocm's copy could put a second RCCL -- of another
+// version -- into the process.  The entry points are therefore resolved at run time: first from whatever librccl is already
+// mapped (dl_iterate_phdr), and only when there is none (a plain C++ host) from the loader's search path.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RcclApi {
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
+  std::string path;
+  bool ok = false;
+};
+int find_mapped_rccl(struct dl_phdr_info *info, size_t, void *out) {
+  if (info->dlpi_name && strstr(info->dlpi_name, "librccl.so")) { *(std::string *)out = info->dlpi_name; return 1; }
+  return 0;
+}
+RcclApi &rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::string mapped;
+    dl_iterate_phdr(find_mapped_rccl, &mapped);
+    void *h = nullptr;
+    if (!mapped.empty()) h = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD);
+    if (!h) for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+    if (!h) return;
+#define MW_SYM(field, name) api.field = (decltype(api.field))dlsym(h, #name); if (!api.field) return;
+    MW_SYM(GetUniqueId, ncclGetUniqueId) MW_SYM(CommInitRank, ncclCommInitRank) MW_SYM(CommDestroy, ncclCommDestroy)
+    MW_SYM(GroupStart, ncclGroupStart) MW_SYM(GroupEnd, ncclGroupEnd) MW_SYM(Send, ncclSend) MW_SYM(Recv, ncclRecv)
+    MW_SYM(GetErrorString, ncclGetErrorString) MW_SYM(GetVersion, ncclGetVersion)
+#undef MW_SYM
+    Dl_info di;
+    if (dladdr((void *)api.Send, &di) && di.dli_fname) api.path = di.dli_fname;
+    api.ok = true;
+  });
+  return api;
+}
+#define MW_NEED_RCCL()                                                                                  \
+  RcclApi &R = rccl_api();                                                                              \
+  if (!R.ok) MW_FAIL("RCCL is not available: no librccl.so is mapped in this process and none could be loaded")
+
 struct RcclCtx {
   ncclComm_t comm = nullptr;
   hipStream_t side = nullptr;
@@ -24,23 +79,35 @@ struct RcclCtx {
 
 #define MW_NCCL(call)                                                                                   \
   do { ncclResult_t r__ = (call);                                                                       \
-       if (r__ != ncclSuccess) { mw::set_error(std::string(#call) + " failed: " + ncclGetErrorString(r__)); return 1; } } while (0)
+       if (r__ != ncclSuccess) { mw::set_error(std::string(#call) + " failed: " + R.GetErrorString(r__)); return 1; } } while (0)
+
+void free_ctx(RcclCtx *c) {
+  if (!c) return;
+  RcclApi &R = rccl_api();
+  if (c->side) (void)hipStreamSynchronize(c->side);
+  if (c->comm && R.ok) (void)R.CommDestroy(c->comm);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  delete c;
+}
 
 int rccl_exchange(void *vctx, const double *sW, const double *sE, const double *sS, const double *sN, double *rW, double *rE,
                   double *rS, double *rN, long long nWE, long long nSN, void *vstream) {
   RcclCtx *c = (RcclCtx *)vctx;
+  MW_NEED_RCCL();
   hipStream_t main_stream = (hipStream_t)vstream;
   MW_HIP(hipEventRecord(c->ev_ready, main_stream));          // pack kernels done
   MW_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
   const double *sbuf[4] = {sW, sE, sS, sN};
   double *rbuf[4] = {rW, rE, rS, rN};
   const long long cnt[4] = {nWE, nWE, nSN, nSN};
-  MW_NCCL(ncclGroupStart());
+  MW_NCCL(R.GroupStart());
   for (int o = 0; o < 4; o++) { int dir = c->send_order[o];
-    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(ncclSend(sbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], c->comm, c->side)); }
+    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Send(sbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], c->comm, c->side)); }
   for (int o = 0; o < 4; o++) { int dir = c->recv_order[o];
-    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(ncclRecv(rbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], c->comm, c->side)); }
-  MW_NCCL(ncclGroupEnd());
+    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Recv(rbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], c->comm, c->side)); }
+  MW_NCCL(R.GroupEnd());
   MW_HIP(hipEventRecord(c->ev_done, c->side));
   MW_HIP(hipStreamWaitEvent(main_stream, c->ev_done, 0));    // unpack kernels wait for the strips
   return 0;
@@ -52,25 +119,38 @@ extern "C" {
 int mw_rccl_unique_id(unsigned char *id128) {
   if (!id128) MW_FAIL("null id buffer");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  MW_NEED_RCCL();
   ncclUniqueId id;
-  MW_NCCL(ncclGetUniqueId(&id));
+  MW_NCCL(R.GetUniqueId(&id));
   memcpy(id128, &id, 128);
   return 0;
 }
 
+// Which RCCL the entry points were resolved from (diagnostic: a PyTorch host must see torch's own librccl here), and its version.
+const char *mw_rccl_library_path(int *version) {
+  RcclApi &R = rccl_api();
+  if (version) { *version = 0; if (R.ok) (void)R.GetVersion(version); }
+  return R.ok ? R.path.c_str() : "";
+}
+
 int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, int myrank) {
   if (!h || !id128) MW_FAIL("null argument");
+  MW_NEED_RCCL();
   mw_grid_t g;
   if (mw_dycore_get_grid(h, &g)) return 1;
   if (nranks != g.nproc_x * g.nproc_y) MW_FAIL("nranks does not match the handle's rank grid");
+  if (myrank < 0 || myrank >= nranks) MW_FAIL("myrank out of range");
   RcclCtx *c = new RcclCtx();
+  auto fail = [&]() { free_ctx(c); return 1; };              // (the error text has been set by the failing call)
   ncclUniqueId id; memcpy(&id, id128, 128);
-  MW_NCCL(ncclCommInitRank(&c->comm, nranks, id, myrank));
-  MW_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-  MW_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-  MW_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-  if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return 1;
-  return mw_dycore_set_exchange(h, rccl_exchange, c);
+  { ncclResult_t r = R.CommInitRank(&c->comm, nranks, id, myrank);
+    if (r != ncclSuccess) { c->comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { mw::set_error("mw_dycore_use_rccl: stream/event creation failed"); return fail(); }
+  if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return fail();
+  if (mw::dycore_set_exchange_owned(h, rccl_exchange, c, [](void *p) { free_ctx((RcclCtx *)p); })) return fail();   // the handle frees it
+  return 0;
 }
 
 // Diagnostic: a 1-rank communicator that sends n doubles to itself through the same group/stream/event sequence as
@@ -78,28 +158,34 @@ int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, in
 // on the box and that the ordering against the caller's stream holds.  Returns 0 when the received data equal the sent data.
 int mw_rccl_selftest(long long n, void *vstream) {
   if (n < 1) MW_FAIL("rccl_selftest: n must be >= 1");
+  MW_NEED_RCCL();
   hipStream_t main_stream = (hipStream_t)vstream;
   ncclUniqueId id;
-  MW_NCCL(ncclGetUniqueId(&id));
-  RcclCtx c;
-  MW_NCCL(ncclCommInitRank(&c.comm, 1, id, 0));
-  MW_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
-  MW_HIP(hipEventCreateWithFlags(&c.ev_ready, hipEventDisableTiming));
-  MW_HIP(hipEventCreateWithFlags(&c.ev_done, hipEventDisableTiming));
-  for (int d = 0; d < 4; d++) { c.peers[d] = 0; c.send_order[d] = d; c.active[d] = 1; }
-  c.recv_order[0] = 1; c.recv_order[1] = 0; c.recv_order[2] = 3; c.recv_order[3] = 2;      // E,W,N,S like mw_exchange_plan
+  MW_NCCL(R.GetUniqueId(&id));
+  RcclCtx *c = new RcclCtx();
+  auto fail = [&]() { free_ctx(c); return 1; };
+  { ncclResult_t r = R.CommInitRank(&c->comm, 1, id, 0);
+    if (r != ncclSuccess) { c->comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { mw::set_error("rccl_selftest: stream/event creation failed"); return fail(); }
+  for (int d = 0; d < 4; d++) { c->peers[d] = 0; c->send_order[d] = d; c->active[d] = 1; }
+  c->recv_order[0] = 1; c->recv_order[1] = 0; c->recv_order[2] = 3; c->recv_order[3] = 2;      // E,W,N,S like mw_exchange_plan
   std::vector<double> h((size_t)4 * n), back((size_t)4 * n, -1.0);
   for (size_t i = 0; i < h.size(); i++) h[i] = 1.0 + (double)i * 0.5;
   double *src = nullptr, *dst = nullptr;
-  MW_HIP(hipMalloc(&src, h.size() * 8)); MW_HIP(hipMalloc(&dst, h.size() * 8));
-  MW_HIP(hipMemcpyAsync(src, h.data(), h.size() * 8, hipMemcpyHostToDevice, main_stream));
-  MW_HIP(hipMemsetAsync(dst, 0, h.size() * 8, main_stream));
+  if (hipMalloc(&src, h.size() * 8) != hipSuccess || hipMalloc(&dst, h.size() * 8) != hipSuccess) {
+    if (src) (void)hipFree(src);
+    mw::set_error("rccl_selftest: hipMalloc failed"); return fail(); }
+  int rc = 0;
+  if (hipMemcpyAsync(src, h.data(), h.size() * 8, hipMemcpyHostToDevice, main_stream) != hipSuccess ||
+      hipMemsetAsync(dst, 0, h.size() * 8, main_stream) != hipSuccess) { mw::set_error("rccl_selftest: upload failed"); rc = 1; }
   // strips W,E (n each) and S,N (n each); my E halo = the "peer's" W strip etc.
-  int rc = rccl_exchange(&c, src, src + n, src + 2 * n, src + 3 * n, dst, dst + n, dst + 2 * n, dst + 3 * n, n, n, main_stream);
-  if (!rc) { MW_HIP(hipMemcpyAsync(back.data(), dst, h.size() * 8, hipMemcpyDeviceToHost, main_stream)); MW_HIP(hipStreamSynchronize(main_stream)); }
+  if (!rc) rc = rccl_exchange(c, src, src + n, src + 2 * n, src + 3 * n, dst, dst + n, dst + 2 * n, dst + 3 * n, n, n, main_stream);
+  if (!rc && (hipMemcpyAsync(back.data(), dst, h.size() * 8, hipMemcpyDeviceToHost, main_stream) != hipSuccess ||
+              hipStreamSynchronize(main_stream) != hipSuccess)) { mw::set_error("rccl_selftest: download failed"); rc = 1; }
   (void)hipFree(src); (void)hipFree(dst);
-  (void)hipEventDestroy(c.ev_ready); (void)hipEventDestroy(c.ev_done); (void)hipStreamDestroy(c.side);
-  (void)ncclCommDestroy(c.comm);
+  free_ctx(c);
   if (rc) return 1;
   // receives were posted E,W,N,S against sends W,E,S,N: rE <- sW, rW <- sE, rN <- sS, rS <- sN
   const int from[4] = {1, 0, 3, 2};                                      // dst strip d holds src strip from[d]

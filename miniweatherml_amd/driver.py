@@ -80,12 +80,8 @@ def _coupler(cfg, device, nranks, myrank, yaml_path):
 
 
 def _exchange(dycore, coupler):
-    from . import capi, modules
-    if coupler.get_nranks() > 1:
-        try:
-            modules.use_rccl_exchange(dycore, coupler)
-        except capi.MWError:
-            modules.use_torch_distributed_exchange(dycore, coupler)
+    from . import modules
+    return modules.install_exchange(dycore, coupler)             # all ranks agree on one transport (RCCL, else torch p2p)
 
 
 def _time_loop(cfg, dycore, coupler, body, max_steps):

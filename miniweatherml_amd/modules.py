@@ -156,7 +156,8 @@ class Dynamics_Euler_Stratified_WenoFV:
         with torch.cuda.device(coupler.device):
             check(capi.lib().mw_dycore_time_step(self.h, *[_ptr(t) for t in self._fields], self._tracer_ptrs, float(dt_phys)))
         self.etime += dt_phys
-        if self.out_freq >= 0.0 and self.etime / self.out_freq >= self.num_out + 1:    # :183-186
+        # :183-186.  out_freq == 0: the reference's etime/0. is +inf >= num_out+1, i.e. a record after every step
+        if self.out_freq >= 0.0 and (self.out_freq == 0.0 or self.etime / self.out_freq >= self.num_out + 1):
             self.output(coupler, self.etime)
             self.num_out += 1
 
@@ -758,6 +759,41 @@ class DataGenerator:
             nc.set_numrecs(ul + n)
         nc.close()
         return n
+
+
+def install_exchange(dycore, coupler, transport="rccl", group=None):
+    """Picks the halo-exchange transport for a multi-rank run TOGETHER on all ranks: the built-in RCCL transport unless any
+    rank cannot set it up, in which case every rank switches to the torch.distributed point-to-point transport (ranks on
+    different transports would deadlock).  Returns the transport in use: "none" (one rank), "rccl" or "torch"."""
+    import torch.distributed as dist
+    if coupler.get_nranks() <= 1:
+        return "none"
+    dev = coupler.device if dist.get_backend(group) != "gloo" else "cpu"
+
+    def any_rank(failed):
+        flag = torch.tensor([1 if failed else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        return int(flag.item()) == 1
+
+    if transport == "rccl":
+        failed, why = False, ""
+        if not capi.lib().mw_rccl_library_path(None):                        # checked BEFORE the collective communicator set-up
+            failed, why = True, "no librccl available to libmw_cdna4"
+        if any_rank(failed):
+            transport = "torch"
+        else:
+            try:
+                use_rccl_exchange(dycore, coupler, group)
+            except MWError as e:
+                failed, why = True, str(e)
+            if any_rank(failed):
+                transport = "torch"
+        if failed:
+            import sys
+            print("rank %d: built-in RCCL transport unavailable (%s)" % (coupler.get_myrank(), why), file=sys.stderr)
+    if transport == "torch":
+        use_torch_distributed_exchange(dycore, coupler, group)                # replaces (and frees) a half-installed RCCL transport
+    return transport
 
 
 def use_rccl_exchange(dycore, coupler, group=None):

@@ -26,3 +26,34 @@ def mw():
     from miniweatherml_amd import capi
     capi.lib()
     return miniweatherml_amd
+
+
+def pytest_sessionstart(session):
+    from util import PARITY_LOG
+    try:
+        os.remove(PARITY_LOG)
+    except OSError:
+        pass
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Condenses the observed parity errors of this session (tests/util.py: compare_fields) into one JSON next to the log:
+    per comparison the worst relative error over the fields and whether the sensitivity fallback was needed."""
+    import json
+    from util import PARITY_LOG
+    if not os.path.exists(PARITY_LOG):
+        return
+    rows = [json.loads(ln) for ln in open(PARITY_LOG)]
+    out = {"comparisons": len(rows), "needed_fallback": sorted({r["what"] for r in rows if any(f["needed_fallback"] for f in r["fields"].values())}),
+           "worst_rel_by_tolerance": {}, "cases": []}
+    for r in rows:
+        worst_field = max(r["fields"], key=lambda k: r["fields"][k]["rel"])
+        wr = r["fields"][worst_field]["rel"]
+        key = "%g" % r["tol"]
+        if not any(f["needed_fallback"] for f in r["fields"].values()):
+            out["worst_rel_by_tolerance"][key] = max(out["worst_rel_by_tolerance"].get(key, 0.0), wr)
+        out["cases"].append({"what": r["what"], "tol": r["tol"], "passed": r["passed"], "worst_field": worst_field, "worst_rel": wr,
+                             "fallback_allowed": r["fallback_allowed"],
+                             "needed_fallback": sorted(k for k, f in r["fields"].items() if f["needed_fallback"]),
+                             "rel": {k: f["rel"] for k, f in r["fields"].items()}})
+    json.dump(out, open(os.path.join(os.path.dirname(PARITY_LOG), "parity_summary.json"), "w"), indent=1)

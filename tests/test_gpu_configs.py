@@ -1,0 +1,120 @@
+"""BASELINE.json's configurations that round 1 left without a -m gpu test, at their full single-GPU sizes:
+
+  configs[0]  supercell_example 200x200x50 nens 1: one dycore time_step of the HIP path against the CPU oracle (the oracle needs
+              ~6 s per step at this size), plain 1e-11.
+  configs[2]  supercell_kessler_surrogate 400x400x100: the surrogate loop (dycore -> MLP inference beside the true Kessler,
+              experiments/supercell_kessler_surrogate/inference_ponni.cpp:60-78) for 2 steps through the product modules; property
+              checks on the whole 1.6e7-cell state and an oracle comparison of the Kessler and MLP results on a seeded sample of
+              1000 whole columns (1e5 cells; Kessler is column-coupled) -- 1e-12 for Kessler, 1e-5 of the output range for the MLP.
+
+plus the guard that a block of a decomposed domain refuses to step without a halo-exchange transport."""
+import numpy as np
+import pytest
+import torch
+
+from util import compare_fields, gpu_fields, push_fields
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_200x200x50_one_step_vs_oracle(mw, oracle):
+    from miniweatherml_amd import modules
+    nx, ny, nz = 200, 200, 50
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 1.0e5, 1.0e5, 2.0e4)
+    odyc, of = oracle.supercell_setup(nx, ny, nz, 1, 1.0e5, 1.0e5, 2.0e4)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-13, "config1 init")
+    push_fields(coupler, of)                                       # identical inputs
+    dt = dycore.compute_time_step(coupler)
+    assert dt == odyc.compute_time_step() == 0.6 * 400.0 / 430.0   # dx = dy = 500, dz = 400
+    dycore.time_step(coupler, dt)
+    odyc.time_step(of, dt)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "config1 200x200x50, 1 step")
+
+
+def _seed_cloud_and_rain(coupler):
+    """A deterministic cloud / rain field so that every Kessler branch runs (the supercell initial state has neither): cloud in a
+    band of levels over a third of the domain, rain below it, super- and sub-saturated vapour side by side."""
+    dm = coupler.get_data_manager_readwrite()
+    rho_d = dm.get("density_dry")
+    nz, ny, nx, _ = rho_d.shape
+    k = torch.arange(nz, device=rho_d.device, dtype=torch.float64).view(nz, 1, 1, 1)
+    j = torch.arange(ny, device=rho_d.device, dtype=torch.float64).view(1, ny, 1, 1)
+    i = torch.arange(nx, device=rho_d.device, dtype=torch.float64).view(1, 1, nx, 1)
+    blob = ((torch.sin(i * 0.11) * torch.cos(j * 0.07)) > 0.3).to(torch.float64)
+    qc = 2.0e-3 * blob * ((k > 15) & (k < 45)).to(torch.float64) * (0.5 + 0.5 * torch.sin(0.3 * k + 0.05 * i) ** 2)
+    qr = 4.0e-4 * blob * (k < 30).to(torch.float64) * (0.5 + 0.5 * torch.cos(0.2 * k + 0.03 * j) ** 2)
+    dm.get("cloud_liquid").copy_(qc * rho_d)
+    dm.get("precip_liquid").copy_(qr * rho_d)
+    dm.get("water_vapor").mul_(1.0 + 0.25 * torch.sin(0.09 * i + 0.05 * j))
+
+
+def test_config3_surrogate_loop_400x400x100(mw, oracle):
+    from miniweatherml_amd import modules
+    nx, ny, nz = 400, 400, 100
+    micro = modules.Microphysics_Kessler_Surrogate()
+    coupler, dycore, micro = modules.make_supercell(nx, ny, nz, 1, 2.0e5, 2.0e5, 2.0e4, micro=micro)
+    dm = coupler.get_data_manager_readwrite()
+    dt = dycore.compute_time_step(coupler)
+    names = ("temp", "density_dry", "water_vapor", "cloud_liquid", "precip_liquid")
+    rng = np.random.default_rng(2024)
+    cols = torch.from_numpy(np.sort(rng.choice(ny * nx, 1000, replace=False))).to(coupler.device)       # 1000 columns = 1e5 cells
+
+    def sample():                                                  # (nz, 1000) per field, on the host
+        return {n: dm.get(n, True).view(nz, ny * nx)[:, cols].cpu().numpy().copy() for n in names}
+
+    for step in range(2):                                          # inference_ponni.cpp:66-78: dycore -> micro (NN beside Kessler)
+        dycore.time_step(coupler, dt)
+        if step == 1:
+            _seed_cloud_and_rain(coupler)                          # all Kessler branches, non-trivial NN inputs
+        before = sample()
+        precl0 = dm.get("precl", True).view(ny * nx)[cols].cpu().numpy().copy()
+        nn = micro.time_step(coupler, dt)
+        after = sample()
+        nn_s = [o.view(nz, ny * nx)[:, cols].cpu().numpy() for o in nn]
+        # --- the MLP on the sampled cells (inputs = the state BEFORE Kessler, :176-202): 1e-5 of each output's range
+        ref = oracle.mlp_forward(before["temp"], before["density_dry"], before["water_vapor"], before["cloud_liquid"],
+                                 before["precip_liquid"], micro.W1, micro.b1, micro.W2, micro.b2, micro.scl_in, micro.scl_out)
+        for n, (a, r) in enumerate(zip(nn_s, ref)):
+            assert np.max(np.abs(a - r)) <= 1e-5 * (micro.scl_out[n, 1] - micro.scl_out[n, 0]), ("mlp output", n, step)
+        # --- Kessler on the sampled columns (rainsplit is 1 on both sides at the CFL step: 0.8 dz / dt = 573 m/s fall speed)
+        o = {n: before[n].copy() for n in names}
+        precl = np.zeros(1000)
+        rs = oracle.kessler_time_step(coupler.get_dz(), dt, o["water_vapor"], o["cloud_liquid"], o["precip_liquid"], o["density_dry"],
+                                      o["temp"], precl)
+        assert rs == 1
+        got = {"temp": after["temp"], "tracer0": after["water_vapor"], "tracer1": after["cloud_liquid"], "tracer2": after["precip_liquid"]}
+        want = {"temp": o["temp"], "tracer0": o["water_vapor"], "tracer1": o["cloud_liquid"], "tracer2": o["precip_liquid"]}
+        compare_fields(got, want, 1e-12, "config3 kessler sample, step %d" % step)
+        got_precl = dm.get("precl", True).view(ny * nx)[cols].cpu().numpy()
+        assert np.max(np.abs(got_precl - precl)) <= 1e-12 * max(np.max(np.abs(precl)), 1e-300)
+        if step == 1:
+            assert np.max(precl) > 0 and np.max(np.abs(after["cloud_liquid"] - before["cloud_liquid"])) > 0   # the branches did run
+        # --- the NN result is returned, not written back (:271-276 commented out in the reference)
+        # (the sampled columns above already equal Kessler's result; here: no aliasing, and the fp32 network's temperature is not
+        #  what the coupler holds)
+        for x, n in zip(nn, ("temp", "water_vapor", "cloud_liquid", "precip_liquid")):
+            assert x.data_ptr() != dm.get(n, True).data_ptr()
+        assert not torch.equal(nn[0], dm.get("temp", True))
+    # --- properties of the whole state
+    for n in names + ("uvel", "vvel", "wvel"):
+        assert bool(torch.isfinite(dm.get(n, True)).all()), n
+    for n in ("density_dry", "water_vapor", "cloud_liquid", "precip_liquid"):
+        assert float(dm.get(n, True).min()) >= 0.0, n
+    for x in nn:
+        assert bool(torch.isfinite(x).all())
+    for x in nn[1:]:
+        assert float(x.min()) >= 0.0                               # NN densities are clipped at 0 (:199-201)
+    del coupler, dycore, micro
+    torch.cuda.empty_cache()
+
+
+def test_decomposed_block_without_transport_fails_loudly(mw):
+    """A handle that is one block of a 2-rank grid must not step (or compute tendencies) with a self-wrapped halo."""
+    from miniweatherml_amd import modules
+    from miniweatherml_amd.capi import MWError
+    coupler, dycore, _ = modules.make_supercell(24, 32, 12, 1, 12000., 16000., 20000., nranks=2, myrank=0)
+    dt = dycore.compute_time_step(coupler)
+    with pytest.raises(MWError, match="no halo-exchange transport"):
+        dycore.time_step(coupler, dt)
+    with pytest.raises(MWError, match="no halo-exchange transport"):
+        dycore.compute_tendencies(coupler, dt)

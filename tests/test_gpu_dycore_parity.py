@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from util import compare_fields, gpu_fields, oracle_sensitivity, push_fields
+from util import compare_fields, gpu_fields, oracle_sensitivity, push_fields, sens_allowed
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -60,7 +60,8 @@ def test_time_steps_match_oracle(mw, oracle, name, mode):
     dycore.set_strict(mode)
     dt = dycore.compute_time_step(coupler)
     assert dt == odyc.compute_time_step()
-    sens = case_sensitivity(oracle, name, (1, 10))
+    # the sensitivity fallback only for the allow-listed thermal case (tests/util.py: SENS_ALLOW); plain 1e-11 / 1e-9 elsewhere
+    sens = case_sensitivity(oracle, name, (1, 10)) if sens_allowed(name) else {1: None, 10: None}
     dycore.time_step(coupler, dt)
     odyc.time_step(of, dt)
     compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "%s mode %d, 1 step" % (name, mode), sens[1])
@@ -209,13 +210,10 @@ def test_ragged_sizes(mw, oracle, name, mode):
     dycore.set_strict(mode)
     dt = dycore.compute_time_step(coupler)
     nx, ny, nz, nens, xlen, ylen, zlen, init, nt, grav, nsteps = case
-    make = lambda: oracle.supercell_setup(nx, ny, nz, nens, xlen, ylen, zlen, init_data=init, num_tracers=nt,   # noqa: E731
-                                          enable_gravity=grav, perturb=True)
-    sens = oracle_sensitivity(oracle, name, make, (nsteps,))
     for _ in range(nsteps):
         dycore.time_step(coupler, dt)
         odyc.time_step(of, dt)
-    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-10, "%s mode %d" % (name, mode), sens[nsteps])
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-10, "%s mode %d" % (name, mode))
 
 
 def test_unsupported_options_fail_loudly(mw):

@@ -38,11 +38,10 @@ def test_full_supercell_loop(mw, oracle, shape):
     push_fields(coupler, f)
     dt = dycore.compute_time_step(coupler)
     precl = np.zeros((ny, nx, nens))
-    sens = oracle_sensitivity(oracle, ("loop",) + shape, lambda: oracle.supercell_setup(nx, ny, nz, nens, xlen, ylen, 20000.), (5,))
     for _ in range(5):
         modules.supercell_step(coupler, dycore, micro, nudger, dt)
         oracle_step(oracle, dyc, f, nud, dt, precl)
-    compare_fields(gpu_fields(coupler), f.as_dict(), 1e-10, "full loop %s" % (shape,), sens[5])
+    compare_fields(gpu_fields(coupler), f.as_dict(), 1e-10, "full loop %s" % (shape,))
 
 
 def test_sponge_layer_alone(mw, oracle):

@@ -42,3 +42,25 @@ def test_four_processes_2x2():
 def test_two_processes_full_loop_with_allreduce():
     """dycore + Kessler + sponge_layer + ColumnNudger on 2 processes: halo strips AND the horizontal-mean all-reduce."""
     run_job(2, 24, 32, 12, 3, "full")
+
+
+def _ngpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("world,nxg,nyg", [(2, 24, 32), (4, 32, 32), (8, 48, 32)])
+def test_rccl_transport_between_gpus(world, nxg, nyg):
+    """The built-in RCCL transport (mw_dycore_use_rccl: ncclSend/ncclRecv in one group on a side stream) between DISTINCT
+    GPUs, one process per GPU: gathered blocks == the single-rank run, bitwise; the worker also asserts that exactly one
+    librccl is mapped and that the library's entry points come from it.  Skipped on boxes with fewer GPUs (the development
+    box has one); the driver's multi-GPU node runs it."""
+    if _ngpus() < world:
+        pytest.skip("needs %d GPUs, %d visible" % (world, _ngpus()))
+    run_job(world, nxg, nyg, 12, 2, "rccl")
+
+
+def test_rccl_full_loop_between_gpus():
+    if _ngpus() < 2:
+        pytest.skip("needs 2 GPUs, %d visible" % _ngpus())
+    run_job(2, 24, 32, 12, 3, "rccl_full")

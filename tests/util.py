@@ -1,5 +1,24 @@
 """Shared helpers for the parity tests (tests only)."""
+import json
+import os
+
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# Every compare_fields() call appends what it OBSERVED (max|diff| / scale per field, the limit it was held to, and whether the
+# sensitivity fallback was needed) to this JSON-lines file; tests/conftest.py condenses it into parity_r<NN>.json at session end
+# and the round's copy is committed under profiles/.
+PARITY_LOG = os.environ.get("MW_PARITY_LOG", os.path.join(ROOT, "gpurun_out", "parity_observed.jsonl"))
+
+# The ONLY cases that may use the `10 x oracle 1-ulp sensitivity` fallback: the thermal bubble -- whose
+# saturated core sits on the reference algorithm's branch discontinuities (convexify's `tot > 1e-20`, the upwind selector) so
+# that the ORACLE run from inputs one ulp apart diverges by up to 1e-8 after a step -- and the wall/open boundary tests built
+# on that case.  Everything else is held to the plain 1e-11 / 1e-9 (1e-10 for 2-5 steps) of BASELINE.md section 4.
+SENS_ALLOW = ("thermal3d_16x16x16", "bc ", "zperiodic")
+
+
+def sens_allowed(what):
+    return any(what.startswith(a) for a in SENS_ALLOW)
 
 
 def rel_err(a, b):
@@ -40,16 +59,31 @@ def compare_fields(got, ref, tol, what="", sens=None):
     max(tol*scale, 10*sens): an implementation cannot be asked to track the oracle more closely than the oracle tracks
     itself across the algorithm's own branch discontinuities (`if (tot > 1.e-20)` in convexify,
     WenoLimiter_recon.h:12-15, and the upwind selector `ind = (m_L + m_R > 0) ? 0 : 1`, :408)."""
-    worst = {}
+    if sens is not None and not sens_allowed(what):
+        raise AssertionError("%s: the sensitivity fallback is reserved for the allow-listed cases %r" % (what, SENS_ALLOW))
+    worst, rec, fail = {}, {}, None
     for k in ref:
-        scale = np.max(np.abs(ref[k]))
-        d = np.max(np.abs(got[k] - ref[k]))
-        lim = tol * scale + ABS_FLOOR.get(k, 0.0) * (tol / 1e-11)
+        scale = float(np.max(np.abs(ref[k])))
+        d = float(np.max(np.abs(got[k] - ref[k])))
+        plain = tol * scale + ABS_FLOOR.get(k, 0.0) * (tol / 1e-11)
+        lim = plain
         if sens is not None:
             lim = max(lim, 10.0 * sens[k])
         worst[k] = (d, scale)
-        assert np.all(np.isfinite(got[k])), "%s: non-finite values in %s" % (what, k)
-        assert d <= lim, "%s: field %s max|diff| %.3e > %.3e (scale %.3e)" % (what, k, d, lim, scale)
+        rec[k] = {"max_abs_diff": d, "scale": scale, "rel": (d / scale if scale > 0 else d), "limit_abs": lim,
+                  "needed_fallback": bool(d > plain)}
+        if fail is None and not np.all(np.isfinite(got[k])):
+            fail = "%s: non-finite values in %s" % (what, k)
+        if fail is None and not d <= lim:
+            fail = "%s: field %s max|diff| %.3e > %.3e (scale %.3e)" % (what, k, d, lim, scale)
+    try:
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        with open(PARITY_LOG, "a") as fh:
+            fh.write(json.dumps({"what": what, "tol": tol, "fallback_allowed": sens is not None, "passed": fail is None,
+                                 "test": os.environ.get("PYTEST_CURRENT_TEST", ""), "fields": rec}) + "\n")
+    except OSError:
+        pass
+    assert fail is None, fail
     return worst
 ABS_FLOOR.update({"tracer%d" % t: 1e-14 for t in range(3, 16)})
 
