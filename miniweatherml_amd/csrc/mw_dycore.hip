@@ -152,7 +152,8 @@ __device__ __forceinline__ void halo_x_body(const DyP &p, double *__restrict__ S
   if (p.bc_x == MW_BC_PERIODIC) {
     int src = lo ? ih + p.nx : ih - p.nx;
     val = row[(long long)src * p.nens];
-  } else {                                          // :782-803 (both sides, two independent ifs)
+  } else {                                          // :782-803 (both sides, two independent ifs: `px == 0`, `px == nproc_x-1`)
+    if (lo ? (p.px != 0) : (p.px != p.nproc_x - 1)) return;   // not a domain edge: this halo holds the neighbour's strip
     if (v + p.v0 == idU && p.bc_x == MW_BC_WALL) val = 0;
     else val = row[(long long)(lo ? p.HX : p.HX + p.nx - 1) * p.nens];
   }
@@ -174,6 +175,7 @@ __device__ __forceinline__ void halo_y_body(const DyP &p, double *__restrict__ S
     int src = lo ? jh + p.ny : jh - p.ny;
     val = col[(long long)src * p.sJ];
   } else {                                          // :804-825
+    if (lo ? (p.py != 0) : (p.py != p.nproc_y - 1)) return;
     if (v + p.v0 == idV && p.bc_y == MW_BC_WALL) val = 0;
     else val = col[(long long)(lo ? p.HY : p.HY + p.ny - 1) * p.sJ];
   }
@@ -191,7 +193,8 @@ __device__ __forceinline__ void halo_z_body(const DyP &p, double *__restrict__ S
   int lo = h < p.HZ;
   int kh = lo ? h : p.nz + h;
   double val;
-  if (v + p.v0 == idW && p.bc_z == MW_BC_WALL) val = 0;
+  if (p.bc_z == MW_BC_PERIODIC) val = col[(long long)(lo ? kh + p.nz : kh - p.nz) * p.sK];     // :752-763
+  else if (v + p.v0 == idW && p.bc_z == MW_BC_WALL) val = 0;
   else val = col[(long long)(lo ? p.HZ : p.HZ + p.nz - 1) * p.sK];
   col[(long long)kh * p.sK] = val;
 }
@@ -277,18 +280,23 @@ __device__ __forceinline__ double edge_value(const double *__restrict__ q, long 
   return right ? r : l;
 }
 
+// Background values a face side adds to its reconstructed perturbations: hyr (density), hyt (rho theta), p0 = C0 hyt^gamma, 1/hyt.
+// Both sides of a face share them -- except at the two z faces of a z-PERIODIC domain, where the reference copies the finished
+// edge value of the opposite boundary face (:1008-1019), hydrostatic part of THAT level included.
+struct FaceBg { double hyr, hyt, p0, ihyt; };
+
 template <bool STRICT>
 __device__ __forceinline__ void face_flux(const DyP &p, const double *__restrict__ cL, int eL, const double *__restrict__ cR,
-                                          int eR, long long st, int nrm, double hyr, double hyt, double p0, double ihyt,
+                                          int eR, long long st, int nrm, const FaceBg &bL, const FaceBg &bR,
                                           bool zero_nrm, double *__restrict__ f, long long fV) {
   const double cs = 350;
-  double rL = edge_value<STRICT>(cL + idR * p.sV, st, eL) + hyr;
-  double rR = edge_value<STRICT>(cR + idR * p.sV, st, eR) + hyr;
+  double rL = edge_value<STRICT>(cL + idR * p.sV, st, eL) + bL.hyr;
+  double rR = edge_value<STRICT>(cR + idR * p.sV, st, eR) + bR.hyr;
   double uL = edge_value<STRICT>(cL + nrm * p.sV, st, eL);
   double uR = edge_value<STRICT>(cR + nrm * p.sV, st, eR);
   double eTL = edge_value<STRICT>(cL + idT * p.sV, st, eL), eTR = edge_value<STRICT>(cR + idT * p.sV, st, eR);
-  double tL = eTL + hyt;
-  double tR = eTR + hyt;
+  double tL = eTL + bL.hyt;
+  double tR = eTR + bR.hyt;
   if (STRICT) {
 #pragma clang fp contract(off)
     double mL = zero_nrm ? 0.0 : uL * rL;
@@ -313,7 +321,7 @@ __device__ __forceinline__ void face_flux(const DyP &p, const double *__restrict
 #pragma clang fp contract(fast)
     double mL = zero_nrm ? 0.0 : uL * rL;
     double mR = zero_nrm ? 0.0 : uR * rR;
-    double p_L = pressure_fast(p, eTL, hyt, p0, ihyt), p_R = pressure_fast(p, eTR, hyt, p0, ihyt);
+    double p_L = pressure_fast(p, eTL, bL.hyt, bL.p0, bL.ihyt), p_R = pressure_fast(p, eTR, bR.hyt, bR.p0, bR.ihyt);
     double w1 = 0.5 * (p_R - cs * mR);
     double w2 = 0.5 * (p_L + cs * mL);
     double p_upw = w1 + w2;
@@ -354,9 +362,8 @@ __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ 
         if (i == p.nx) { cR = cL; eR = eL; zero = (p.bc_x == MW_BC_WALL); }
       }
     }
-    double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
-    face_flux<STRICT>(p, cL, eL, cR, eR, p.nens, idU, hyr, hyt, p.p0c[k * p.nens + e], p.ihytc[k * p.nens + e], zero,
-                      FX + (long long)k * p.fxK + (long long)j * p.fxJ + ie, p.fxV);
+    const FaceBg bg = {p.hyc[k * p.nens + e], p.hytc[k * p.nens + e], p.p0c[k * p.nens + e], p.ihytc[k * p.nens + e]};
+    face_flux<STRICT>(p, cL, eL, cR, eR, p.nens, idU, bg, bg, zero, FX + (long long)k * p.fxK + (long long)j * p.fxJ + ie, p.fxV);
   }
   // ---------------- Y face j-1/2
   if (!p.sim2d && i < p.nx && k < p.nz) {
@@ -369,17 +376,23 @@ __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ 
         if (j == p.ny) { cR = cL; eR = eL; zero = (p.bc_y == MW_BC_WALL); }
       }
     }
-    double hyr = p.hyc[k * p.nens + e], hyt = p.hytc[k * p.nens + e];
-    face_flux<STRICT>(p, cL, eL, cR, eR, p.sJ, idV, hyr, hyt, p.p0c[k * p.nens + e], p.ihytc[k * p.nens + e], zero,
-                      FY + (long long)k * p.fyK + (long long)j * p.fyJ + ie, p.fyV);
+    const FaceBg bg = {p.hyc[k * p.nens + e], p.hytc[k * p.nens + e], p.p0c[k * p.nens + e], p.ihytc[k * p.nens + e]};
+    face_flux<STRICT>(p, cL, eL, cR, eR, p.sJ, idV, bg, bg, zero, FY + (long long)k * p.fyK + (long long)j * p.fyJ + ie, p.fyV);
   }
   // ---------------- Z face k-1/2 : wall / open edge-value rule at k = 0 and k = nz  (:1020-1038)
   if (i < p.nx && j < p.ny) {
     const double *cL = c - p.sK, *cR = c;  int eL = 1, eR = 0;  bool zero = false;
-    if (k == 0)    { cL = cR; eL = eR; zero = (p.bc_z == MW_BC_WALL); }
-    if (k == p.nz) { cR = cL; eR = eL; zero = (p.bc_z == MW_BC_WALL); }
-    double hyr = p.hye[k * p.nens + e], hyt = p.hyte[k * p.nens + e];      // edges for z (:368-377)
-    face_flux<STRICT>(p, cL, eL, cR, eR, p.sK, idW, hyr, hyt, p.p0e[k * p.nens + e], p.ihyte[k * p.nens + e], zero,
+    int kL = k, kR = k;                                      // which face's hydrostatic edge values each side carries (:368-377)
+    if (p.bc_z == MW_BC_PERIODIC) {                          // :1008-1019: slot 0 of face 0 := slot 0 of face nz, slot 1 of face nz := slot 1 of face 0
+      if (k == 0)    { cL = c + (long long)(p.nz - 1) * p.sK; kL = p.nz; }       // top edge of cell nz-1, as finished at face nz
+      if (k == p.nz) { cR = c - (long long)p.nz * p.sK;       kR = 0;    }       // bottom edge of cell 0, as finished at face 0
+    } else {                                                 // :1020-1038 wall / open
+      if (k == 0)    { cL = cR; eL = eR; zero = (p.bc_z == MW_BC_WALL); }
+      if (k == p.nz) { cR = cL; eR = eL; zero = (p.bc_z == MW_BC_WALL); }
+    }
+    const FaceBg bL = {p.hye[kL * p.nens + e], p.hyte[kL * p.nens + e], p.p0e[kL * p.nens + e], p.ihyte[kL * p.nens + e]};
+    const FaceBg bR = {p.hye[kR * p.nens + e], p.hyte[kR * p.nens + e], p.p0e[kR * p.nens + e], p.ihyte[kR * p.nens + e]};
+    face_flux<STRICT>(p, cL, eL, cR, eR, p.sK, idW, bL, bR, zero,
                       FZ + (long long)k * p.fzK + (long long)j * p.fzJ + (long long)i * p.nens + e, p.fzV);
   }
 }
@@ -883,14 +896,17 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
     if (ex_x) { hipLaunchKernelGGL(k_unpack_x, dim3((unsigned)((nWE + 255) / 256)), dim3(256), 0, st, p, S, bf[4], bf[5]); MW_LAUNCH_CHECK(); }
     if (ex_y) { hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((nSN + 255) / 256)), dim3(256), 0, st, p, S, bf[6], bf[7]); MW_LAUNCH_CHECK(); }
   }
-  // local wrap / BC:  x when this direction has one rank (periodic self-wrap) or a non-periodic BC on an edge rank
-  if (ex_x && p.bc_x != MW_BC_PERIODIC) MW_FAIL("wall/open bc_x with nproc_x > 1 is not implemented");
-  if (ex_y && !p.sim2d && p.bc_y != MW_BC_PERIODIC) MW_FAIL("wall/open bc_y with nproc_y > 1 is not implemented");
+  // local wrap / BC:  x when this direction has one rank (periodic self-wrap), or a wall / open boundary on a domain-edge rank.
+  // With several ranks in a non-periodic direction the edge ranks have just exchanged with their periodic-wrap neighbour like
+  // the reference does (:641-723 uses the periodic neighbour matrix) and the boundary rule then OVERWRITES that halo
+  // (:782-825: `px == 0` west side, `px == nproc_x-1` east side; the kernel skips the sides that are rank-interior).
+  const bool edge_x = (p.px == 0 || p.px == p.nproc_x - 1), edge_y = (p.py == 0 || p.py == p.nproc_y - 1);
+  const bool bcx_after = ex_x && p.bc_x != MW_BC_PERIODIC && edge_x, bcy_after = ex_y && p.bc_y != MW_BC_PERIODIC && edge_y;
   const long long nx_ = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens;
   const long long ny_ = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
   const long long nz_ = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
-  const unsigned nbx = (ex_x || (skip_z && p.wrap_x)) ? 0u : (unsigned)((nx_ + 255) / 256);      // skip_z = production path
-  const unsigned nby = (ex_y || p.sim2d || (skip_z && p.wrap_y)) ? 0u : (unsigned)((ny_ + 255) / 256);
+  const unsigned nbx = ((ex_x && !bcx_after) || (skip_z && p.wrap_x)) ? 0u : (unsigned)((nx_ + 255) / 256);      // skip_z = production path
+  const unsigned nby = ((ex_y && !bcy_after) || p.sim2d || (skip_z && p.wrap_y)) ? 0u : (unsigned)((ny_ + 255) / 256);
   const unsigned nbz = skip_z ? 0u : (unsigned)((nz_ + 255) / 256);      // (the marching kernels apply the z rule while loading)
   if (nbx + nby + nbz) { hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + nbz), dim3(256), 0, st, p, S, nbx, nby); MW_LAUNCH_CHECK(); }
   return 0;
@@ -1166,7 +1182,7 @@ static int validate_grid(const mw_grid_t *g) {
   if (g->ny_glob != 1 && g->ny < 3) MW_FAIL("3-D runs need ny >= 3 per rank");
   if (g->num_tracers < 1 || g->num_tracers > MW_MAX_TRACERS) MW_FAIL("num_tracers must be in [1, MW_MAX_TRACERS] (a water_vapor tracer is required, SURVEY 8(a) quirk 6)");
   if (g->idWV < 0 || g->idWV >= g->num_tracers) MW_FAIL("idWV out of range");
-  if (g->bc_z == MW_BC_PERIODIC) MW_FAIL("bc_z = periodic is not implemented (no reference test case uses it)");
+  for (int b : {g->bc_x, g->bc_y, g->bc_z}) if (b != MW_BC_PERIODIC && b != MW_BC_OPEN && b != MW_BC_WALL) MW_FAIL("bc_x / bc_y / bc_z must be 0 (periodic), 1 (open) or 2 (wall)");
   return 0;
 }
 
@@ -1257,7 +1273,7 @@ double *mw_dycore_immersed_proportion(mw_dycore_t d) { return d ? d->imm : nullp
 
 int mw_dycore_set_bc(mw_dycore_t d, int bc_x, int bc_y, int bc_z) {
   if (!d) MW_FAIL("null handle");
-  if (bc_z == MW_BC_PERIODIC) MW_FAIL("bc_z = periodic is not implemented");
+  for (int b : {bc_x, bc_y, bc_z}) if (b != MW_BC_PERIODIC && b != MW_BC_OPEN && b != MW_BC_WALL) MW_FAIL("bc_x / bc_y / bc_z must be 0 (periodic), 1 (open) or 2 (wall)");
   d->g.bc_x = bc_x; d->g.bc_y = bc_y; d->g.bc_z = bc_z;
   fill_params(d);
   return 0;
@@ -1354,8 +1370,9 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   const DyP &p = d->p;
   if (need_exchange(d)) return 1;
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
-  const bool march = (d->strict == 0);                        // production path; strict = 1/2 use the general
-                                                              // flux-materialising kernels below
+  // production path; strict = 1/2 use the general flux-materialising kernels below.  So does a z-PERIODIC domain (:752-763,
+  // :1008-1019; no shipped case): the marching kernels apply the wall / open z rule while loading and have no periodic form.
+  const bool march = (d->strict == 0) && (p.bc_z != MW_BC_PERIODIC);
   if (march && !getenv("MW_NO_WRAP")) {                       // index wrap instead of halo cells (see DyP::wrap_x)
     d->p.wrap_x = (p.bc_x == MW_BC_PERIODIC) && !(d->xchg && p.nproc_x > 1) && p.nx >= 3;
     d->p.wrap_y = !p.sim2d && (p.bc_y == MW_BC_PERIODIC) && !(d->xchg && p.nproc_y > 1) && p.ny >= 3;

@@ -44,7 +44,10 @@ def pytest_sessionfinish(session, exitstatus):
     if not os.path.exists(PARITY_LOG):
         return
     rows = [json.loads(ln) for ln in open(PARITY_LOG)]
-    out = {"comparisons": len(rows), "needed_fallback": sorted({r["what"] for r in rows if any(f["needed_fallback"] for f in r["fields"].values())}),
+    failed = [r for r in rows if not r["passed"]]          # comparisons that raised (negative controls expect to)
+    rows = [r for r in rows if r["passed"]]
+    out = {"comparisons": len(rows), "failed_comparisons (negative controls included)": sorted({r["what"] for r in failed}),
+           "needed_fallback": sorted({r["what"] for r in rows if any(f["needed_fallback"] for f in r["fields"].values())}),
            "worst_rel_by_tolerance": {}, "cases": []}
     for r in rows:
         worst_field = max(r["fields"], key=lambda k: r["fields"][k]["rel"])

@@ -142,6 +142,45 @@ def test_wall_and_open_boundaries(mw, oracle, mode, bc):
     compare_fields(gpu_fields(coupler), of.as_dict(), 1e-10, "bc %s mode %d" % (bc, mode), sens[3])
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("bc", [(0, 0, 0), (2, 1, 0)])
+def test_z_periodic(mw, oracle, mode, bc):
+    """bc_z = periodic (halo rule :752-763, edge rule :1008-1019: the boundary faces take the finished edge values of the opposite
+    boundary face, hydrostatic part of that level included).  No shipped case uses it; the thermal bubble case with its z-periodic
+    rule switched on is the test (1e-11 after 1 step, 1e-9 after 10; the thermal case is on the sensitivity allow-list)."""
+    coupler, dycore, odyc, of = setup_case(oracle, SNAP["cases"]["thermal3d_16x16x16"])
+    push_fields(coupler, of)
+    dycore.set_strict(mode)
+    dycore.set_bc(coupler, *bc)
+    odyc.p.bc_x, odyc.p.bc_y, odyc.p.bc_z = bc
+    dt = dycore.compute_time_step(coupler)
+    sens = case_sensitivity(oracle, "thermal3d_16x16x16", (1, 10))
+    dycore.time_step(coupler, dt)
+    odyc.time_step(of, dt)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "zperiodic %s mode %d, 1 step" % (bc, mode), sens[1])
+    check_fluxes(dycore, coupler, odyc, 1e-9)                 # incl. the two boundary faces, which must carry the same flux
+    fz = dycore.fluxes(coupler)["state_flux_z"]
+    assert float((fz[:, 0] - fz[:, -1]).abs().max()) == 0.0
+    for _ in range(9):
+        dycore.time_step(coupler, dt)
+        odyc.time_step(of, dt)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-9, "zperiodic %s mode %d, 10 steps" % (bc, mode), sens[10])
+
+
+def test_z_periodic_differs_from_wall(mw, oracle):
+    """Negative control: the periodic z rule is really applied (the same run with the wall rule gives a different state)."""
+    out = []
+    for bcz in (0, 2):
+        coupler, dycore, odyc, of = setup_case(oracle, SNAP["cases"]["thermal3d_16x16x16"])
+        push_fields(coupler, of)
+        dycore.set_bc(coupler, 0, 0, bcz)
+        dt = dycore.compute_time_step(coupler)
+        for _ in range(3):
+            dycore.time_step(coupler, dt)
+        out.append(gpu_fields(coupler))
+    assert np.max(np.abs(out[0]["wvel"] - out[1]["wvel"])) > 1e-6
+
+
 def test_known_answers_on_gpu(mw, oracle):
     """32x32x16 supercell + bubble, 3 dycore steps (reference-run numbers)."""
     from miniweatherml_amd import modules
@@ -220,8 +259,8 @@ def test_unsupported_options_fail_loudly(mw):
     from miniweatherml_amd import modules
     from miniweatherml_amd.capi import MWError
     coupler, dycore, _ = modules.make_supercell(8, 8, 8, 1, 4000., 4000., 20000.)
-    with pytest.raises(MWError, match="periodic"):
-        dycore.set_bc(coupler, 0, 0, 0)                       # bc_z = periodic: no reference case uses it
+    with pytest.raises(MWError, match="bc_x / bc_y / bc_z"):
+        dycore.set_bc(coupler, 0, 0, 3)                       # not a boundary type
     with pytest.raises(MWError, match="dt_phys"):
         dycore.time_step(coupler, 0.0)
 

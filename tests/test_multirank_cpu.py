@@ -20,10 +20,10 @@ def free_port():
     return port
 
 
-def run_job(world, nxg, nyg, nz, nsteps):
+def run_job(world, nxg, nyg, nz, nsteps, bc=None):
     port = free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "gloo_worker.py"), str(r), str(world), str(port), str(nxg),
-                               str(nyg), str(nz), str(nsteps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(nyg), str(nz), str(nsteps)] + (["%d,%d,%d" % bc] if bc else []), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     outs = []
     for p in procs:
@@ -50,3 +50,15 @@ def test_two_ranks_2d_west_equals_east_peer():
 
 def test_four_ranks_2x2():
     run_job(4, 16, 16, 8, 2)
+
+
+@pytest.mark.parametrize("world,bc", [(2, (2, 2, 2)), (2, (1, 0, 1)), (4, (2, 2, 2)), (4, (1, 1, 2))])
+def test_wall_and_open_boundaries_across_ranks(world, bc):
+    """Wall (2) / open (1) boundaries in decomposed directions (:782-825, :1040-1081 apply on the domain-edge ranks only): the
+    gloo job must equal, bitwise, the same decomposition run with all ranks in one process -- and, where only undecomposed
+    directions are non-periodic, the single-rank run."""
+    run_job(world, 16, 16, 8, 2, bc)
+
+
+def test_z_periodic_across_ranks():
+    run_job(2, 12, 16, 8, 2, (0, 0, 0))

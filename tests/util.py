@@ -111,3 +111,77 @@ def oracle_sensitivity(oracle, key, make, steps):
             out[s] = {k: float(np.max(np.abs(a[k] - b[k]))) for k in a}
     _SENS_CACHE[key] = out
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# In-process rank emulation (threads): R product handles on one GPU / R oracle ranks on the CPU
+# ------------------------------------------------------------------------------------------------------------------
+import ctypes as C      # noqa: E402
+import threading        # noqa: E402
+
+
+class Exchanger:
+    """All ranks live in this process; strips are copied device-to-device after a barrier."""
+
+    def __init__(self, nranks):
+        self.n = nranks
+        self.bar = threading.Barrier(nranks)
+        self.send = [None] * nranks
+        self.errors = []
+
+    def make_cb(self, rank, grid):
+        from miniweatherml_amd import capi
+        peers, so, ro, act = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+        capi.check(capi.lib().mw_exchange_plan(C.byref(grid), peers, so, ro, act))
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+        def cb(ctx, sW, sE, sS, sN, rW, rE, rS, rN, nWE, nSN, stream):
+            try:
+                hip.hipStreamSynchronize(stream)                          # my strips are packed
+                self.send[rank] = (sW, sE, sS, sN)
+                self.bar.wait(timeout=60)
+                cnt = [nWE, nWE, nSN, nSN]
+                recv = [rW, rE, rS, rN]
+                for d in range(4):                                      # my halo d comes from peer[d]'s opposite strip
+                    if recv[d] and cnt[d] and act[d]:
+                        src = self.send[peers[d]][d ^ 1]
+                        assert hip.hipMemcpy(recv[d], src, cnt[d] * 8, 3) == 0      # hipMemcpyDeviceToDevice
+                # a device-to-device hipMemcpy is not synchronous with the host, and the library's streams do not synchronise
+                # with the null stream it runs on: finish the copies before the unpack kernels are enqueued
+                assert hip.hipStreamSynchronize(None) == 0
+                self.bar.wait(timeout=60)
+                return 0
+            except Exception as e:                                      # pragma: no cover
+                self.errors.append(repr(e))
+                self.bar.abort()
+                return 1
+        return capi.EXCHANGE_FN(cb)
+
+
+
+class OracleExchanger:
+    """The oracle's halo/edge exchange callback between oracle ranks living in threads of this process."""
+
+    def __init__(self, nranks, plans):
+        self.n, self.plans = nranks, plans
+        self.bar = threading.Barrier(nranks)
+        self.send = [None] * nranks
+
+    def make_cb(self, rank):
+        peers, act = self.plans[rank]
+
+        def cb(ctx, kind, sW, sE, sS, sN, rW, rE, rS, rN, nWE, nSN):
+            cnt = [nWE, nWE, nSN, nSN]
+            sb, rb = [sW, sE, sS, sN], [rW, rE, rS, rN]
+            self.send[rank] = [np.ctypeslib.as_array(sb[d], shape=(cnt[d],)).copy() if cnt[d] else None for d in range(4)]
+            self.bar.wait(timeout=120)
+            for d in range(4):
+                if cnt[d]:
+                    src = self.send[peers[d]][d ^ 1] if act[d] else self.send[rank][d ^ 1]      # single rank in a direction: self wrap
+                    np.ctypeslib.as_array(rb[d], shape=(cnt[d],))[:] = src
+            self.bar.wait(timeout=120)
+        return cb
+
+
