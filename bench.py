@@ -11,14 +11,20 @@ workload: BASELINE.json configs[1]: supercell 400x400x100, nens 1, fp64, 3 Kessl
           region).  N > 1: weak scaling, every GPU keeps a 400x400x100 block of a (400*nproc_x) x (400*nproc_y) x 100
           grid (2-D x/y decomposition of coupler.h:127-179), 3-cell halos exchanged over RCCL once per RK stage and group.
 timing  : W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(); max over ranks.
-roofline: dominant kernel k_xz_state (x/z WENO reconstruction + Riemann + complete state tendencies + SSPRK3 combine, one
-          launch per RK stage).  achieved = algorithmic bytes per launch / average launch duration, the duration from
-          hipEvents recorded on the kernel's own stream inside the timed region (mw_dycore_profile).  Algorithmic bytes
-          per cell and launch: read 5 state + 5 y-tendencies (+ 5 q^n in stages 2,3), write 5 state
-          + 2 face mass fluxes + 2 selector bytes = 138 B (stage 1) / 178 B (stages 2,3), 164.7 B on average.
-          peak 8 TB/s HBM3E spec.  traffic = measured HBM bytes per launch from profiles/ (2 x FETCH_SIZE + WRITE_SIZE,
-          calibrated with mw_calib_copy).  SURVEY.md 8(d)'s own figures are reported beside it: roofline.pipeline (512 B per
-          cell-update) and roofline.flux_stencil_stage (256 B per cell and stage, against one third of the step).  The kernel is fp64-VALU bound: see roofline.valu_busy_frac.
+roofline: SURVEY.md 8(d)'s flux-stencil figure: 32 V = 256 B per cell and RK stage (read V, write 3 V doubles), priced against
+          everything one stage launches (k_y_state + k_xz_state + k_y_tracers + k_tracers_fused + k_tracer_patch: the reference's
+          D6 + D9 stencil split by direction and variable group, with D10-D12 fused in).  achieved = 256 B x cells / average stage
+          duration, the duration from hipEvents recorded on the handle's stream around each stage inside the timed region
+          (mw_dycore_profile class 8; N > 1 runs two streams: one third of the step instead).  roofline.dominant_kernel carries
+          k_xz_state's own numbers (its algorithmic bytes: read 5 state + 5 y-tendencies (+ 5 q^n in stages 2,3), write 5 state + 2
+          face mass fluxes + 2 selector bytes = 138 / 178 B per cell, 164.7 B on average), roofline.pipeline the 512 B per
+          cell-update figure.  peak 8 TB/s HBM3E spec.  traffic / valu_* come from the committed rocprofv3 PMC summary
+          (profiles/latest_summary.json, 2 x FETCH_SIZE + WRITE_SIZE calibrated with mw_calib_copy) and are reported ONLY while
+          the kernel sources still hash to what that profile was taken from (roofline.pmc_provenance); otherwise null.
+          The stage is fp64-VALU-issue bound, not HBM bound (roofline.binding_resource; SURVEY.md 8(d) predicts it).
+micro   : after the timed region (the headline is untouched): Kessler (two states) and the surrogate MLP on the same grid, 72 B per
+          cell each, and the dycore step on a state with cloud and rain (FCT limiter + y-face correction pass active):
+          developed_ms_per_step.
 cpu_baseline: the CPU oracle (a port: the reference itself is unbuildable here) timed on one host core
           on BASELINE.json configs[0] (supercell 200x200x50), rank 0, N = 1 only.
 """
@@ -48,7 +54,16 @@ def parse():
     ap.add_argument("--cpu-sample", type=str, default="200x200x50", help="oracle sample grid nx x ny x nz")
     ap.add_argument("--strict", type=int, default=0)
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl", help="halo-exchange transport for N > 1")
-    return ap.parse_args()
+    ap.add_argument("--workload", choices=["config2", "config4"], default="config2",
+                    help="config2 (default): BASELINE.json configs[1], 400x400x100 nens 1 per GPU, dx 500 m.  config4: configs[3]'s per-GPU "
+                         "block 256x512x128 nens 4, dx 800 m (weak-scaling series 256x512 ... 1024x1024 global for 1 ... 8 GPUs)")
+    ap.add_argument("--no-micro", action="store_true", help="skip the Kessler / MLP / developed-state section after the timed region")
+    a = ap.parse_args()
+    if a.workload == "config4":
+        a.nx, a.ny, a.nz, a.nens = 256, 512, 128, 4
+    return a
+
+
 
 
 def cpu_baseline(sample):
@@ -65,6 +80,97 @@ def cpu_baseline(sample):
     return {"value": nsteps * nx * ny * nz / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
             "sample": "2 dycore time_steps (3 RK stages each) of supercell %dx%dx%d nens=1, 3 tracers, CPU oracle "
                       "(oracle/mw_oracle.cpp, -O2 -ffp-contract=off), %.1f s on 1 of %d host cores" % (nx, ny, nz, el, os.cpu_count())}
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the HIP sources of the dycore kernels: ties counter values copied from a committed
+    rocprofv3 summary to the code they were measured on (tools/summarize_profiles.py records the same hash)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mw_march.h", "mw_weno.h", "mw_dycore.hip"):
+        h.update(open(os.path.join(ROOT, "miniweatherml_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def micro_section(torch, modules, coupler, dycore, micro, dt, a):
+    """After the timed region: Kessler and the surrogate MLP on the bench grid (72 algorithmic bytes per cell each: 5 fields read, 4
+    written) and the dycore on a state that HAS cloud and rain (the headline state has none, so its FCT limiter and y-face
+    correction pass idle).  Durations from events on torch's current stream, which is the stream these entry points launch on."""
+    dm = coupler.get_data_manager_readwrite()
+    rho_d = dm.get("density_dry")
+    nz, ny, nx, nens = rho_d.shape
+    ncell = rho_d.numel()
+
+    def timed(fn, iters=10):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    g = torch.Generator(device=rho_d.device).manual_seed(1)
+    rnd = lambda: torch.rand(rho_d.shape, generator=g, device=rho_d.device, dtype=torch.float64)        # noqa: E731
+    qc = rnd() * 2e-3 * (rnd() > 0.6)
+    qr = rnd() * 3e-4 * (rnd() > 0.6)
+    box = torch.zeros_like(rho_d)
+    box[: int(0.6 * nz), ny // 4: ny // 2, nx // 4: nx // 2] = 1.0
+    base = {n: dm.get(n).clone() for n in ("water_vapor", "cloud_liquid", "precip_liquid", "temp")}
+    states = {"one_storm": "cloud and rain inside one storm (1/16 of the columns, lower 60 % of the levels): rain-free wavefronts take "
+                           "the short cut", "scattered": "cloud / rain scattered at random over 40 % of the cells (no rain-free wavefront)"}
+    res = {"kessler": {"alg_bytes_per_cell": 72, "cells": ncell, "states": {}}}
+    saved = dict(base)
+
+    def restore():
+        for n, t in saved.items():
+            dm.get(n).copy_(t)
+
+    def kessler_once():
+        restore()
+        micro.time_step(coupler, dt)
+
+    for name, desc in states.items():
+        m = box if name == "one_storm" else 1.0
+        saved["cloud_liquid"], saved["precip_liquid"] = qc * rho_d * m, qr * rho_d * m
+        ms = timed(kessler_once) - timed(restore)
+        res["kessler"]["states"][name] = {"state": desc, "ms_per_call": ms, "cells_per_s": ncell / ms * 1e3,
+                                          "achieved_GBps": ncell * 72 / ms / 1e6, "frac": ncell * 72 / ms / 1e6 / 8000.0}
+    res["kessler"]["kernels"] = "k_kessler_prep + k_kessler_chunks (+ k_kessler_column when rainsplit > 1)"
+    restore()
+    W1, b1, W2, b2, si, so = modules.load_surrogate_weights()
+    ins = [dm.get(n) for n in ("temp", "density_dry", "water_vapor", "cloud_liquid", "precip_liquid")]
+    outs = [torch.empty_like(ins[0]) for _ in range(4)]
+    ms = timed(lambda: modules.mlp_forward(*ins, W1, b1, W2, b2, si, so, outs))
+    res["mlp"] = {"kernel": "k_mlp (v_mfma_f32_16x16x4_f32, 5 MFMAs per 16 cells)", "alg_bytes_per_cell": 72, "cells": ncell, "ms_per_call": ms,
+                  "cells_per_s": ncell / ms * 1e3, "achieved_GBps": ncell * 72 / ms / 1e6, "frac": ncell * 72 / ms / 1e6 / 8000.0,
+                  "fp32_gflops_nominal": ncell * 208 / ms / 1e6, "bound": "hbm (2.9 flop/B: MFMA utilisation is necessarily << 1 %)"}
+    # ---- the dycore on a state with cloud and rain: smooth blobs with sharp rims in the sheared wind -> FCT multipliers < 1
+    k = torch.arange(nz, device=rho_d.device, dtype=torch.float64).view(nz, 1, 1, 1)
+    j = torch.arange(ny, device=rho_d.device, dtype=torch.float64).view(1, ny, 1, 1)
+    i = torch.arange(nx, device=rho_d.device, dtype=torch.float64).view(1, 1, nx, 1)
+    blob = ((torch.sin(i * 0.11) * torch.cos(j * 0.07)) > 0.3).to(torch.float64)
+    for n, t in base.items():
+        dm.get(n).copy_(t)
+    dm.get("cloud_liquid").copy_(2.0e-3 * blob * ((k > 0.15 * nz) & (k < 0.45 * nz)) * (0.5 + 0.5 * torch.sin(0.3 * k + 0.05 * i) ** 2) * rho_d)
+    dm.get("precip_liquid").copy_(4.0e-4 * blob * (k < 0.3 * nz) * (0.5 + 0.5 * torch.cos(0.2 * k + 0.03 * j) ** 2) * rho_d)
+    for _ in range(2):
+        dycore.time_step(coupler, dt)
+    dev_ms = timed(lambda: dycore.time_step(coupler, dt), 6)       # (no per-kernel events here: they cost ~2 % of the step)
+    dycore.profile(1)
+    for _ in range(2):
+        dycore.time_step(coupler, dt)
+    patch_ms, patch_n = dycore.profile_get(1)
+    dycore.profile(0)
+    res["developed_ms_per_step"] = dev_ms
+    res["developed_state"] = {"state": "the bench state after the timed region + seeded cloud (2e-3) and rain (4e-4) blobs with sharp rims: "
+                                       "FCT multipliers < 1 and a busy y-face correction pass", "cell_updates_per_s": ncell / dev_ms * 1e3,
+                              "tracer_patch_ms_per_launch": patch_ms / max(1, patch_n),
+                              "cloud_max": float(dm.get("cloud_liquid").max()), "rain_max": float(dm.get("precip_liquid").max())}
+    return res
 
 
 def spawn_ranks(a):
@@ -117,7 +223,8 @@ def main():
     capi.check(L.mw_decompose(world, rank, a.nx * world, a.ny * world if a.ny > 1 else 1, C.byref(g0)))   # only to learn nproc_x/y
     npx, npy = g0.nproc_x, g0.nproc_y
     nx_glob, ny_glob = a.nx * npx, (a.ny * npy if a.ny > 1 else 1)
-    xlen, ylen, zlen = 500.0 * nx_glob, 500.0 * max(ny_glob, 1) if ny_glob > 1 else 500.0 * a.ny, 20000.0
+    dxy = 800.0 if a.workload == "config4" else 500.0              # input_euler3d_1024x1024x100.yaml: xlen = 819200 / 1024 cells
+    xlen, ylen, zlen = dxy * nx_glob, dxy * max(ny_glob, 1) if ny_glob > 1 else dxy * a.ny, 20000.0
     nudger = None
     if a.full_loop:
         coupler, dycore, micro, nudger = modules.make_supercell(nx_glob, ny_glob, a.nz, a.nens, xlen, ylen, zlen, "supercell", device,
@@ -156,7 +263,8 @@ def main():
     sync()
     el = time.perf_counter() - t0
     KNAMES = ["xz_state", "tracer_patch", "tracer_update_unfused", "halo", "convert", "y_state", "y_tracers", "tracers_fused"]
-    prof_dom = dycore.profile_get(0)                             # the roofline's duration: live, over the timed region
+    prof_dom = dycore.profile_get(0)                             # the dominant kernel: live, over the timed region
+    prof_stage = dycore.profile_get(8)                           # every RK stage, first to last launch: live, over the timed region
     # Outside the timed region: every kernel class bracketed by events (their markers cost ~2 % of the step), same schedule
     dycore.profile(1)
     for _ in range(3):
@@ -186,59 +294,79 @@ def main():
     wmax = float(coupler.get_data_manager_readonly().get("wvel", True).abs().max())
     assert wmax == wmax and wmax < 100.0, "unphysical state after the timed region (max|w| = %r)" % wmax
 
+    two_streams = (os.environ.get("MW_OVERLAP", "1" if world > 1 else "0") != "0") and not a.strict
     if rank == 0:
         ncycles = 1
         total_updates = float(ncells_local) * world * ncycles * a.steps
         value = total_updates / el
+        ms_per_step = el / a.steps * 1e3
+        per_gpu = value / world
+        # ---- the flux stencil of one RK stage = 32 V B per cell, against everything that stage launches
+        stage_ms_live = (prof_stage[0] / prof_stage[1]) if (prof_stage[1] and not two_streams and not a.strict) else None
+        stage_ms = stage_ms_live if stage_ms_live else ms_per_step / 3.0
+        stage_bytes = 32.0 * V * ncells_local
+        achieved = stage_bytes / (stage_ms * 1e-3) / 1e9
+        # ---- the dominant kernel on its own
         flux_ms, flux_n = prof_dom
         avg_flux_s = flux_ms / 1e3 / max(1, flux_n)
         # k_xz_state per cell and launch: read 5 (state) + 5 (y tendencies) [+ 5 q^n in stages 2,3], write 5 + 2 doubles + 2 bytes
-        alg_bytes = ((10 + 15 + 15) / 3.0 + 7) * 8.0 * ncells_local + 2.0 * ncells_local
+        dom_bytes = ((10 + 15 + 15) / 3.0 + 7) * 8.0 * ncells_local + 2.0 * ncells_local
         if a.strict:                                             # general path: k_flux reads V, writes 3V doubles per cell
-            alg_bytes = 32.0 * V * ncells_local
-        achieved = alg_bytes / avg_flux_s / 1e9 if flux_n else None
-        traffic, valu_busy, valu_instr = None, None, None
+            dom_bytes = 32.0 * V * ncells_local
+        dom_achieved = dom_bytes / avg_flux_s / 1e9 if flux_n else None
+        # ---- counters from the committed rocprofv3 summary: only while the kernel sources are the profiled ones
+        traffic, dom_traffic, valu_busy, valu_instr, prov = None, None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "latest_summary.json")
         if os.path.exists(pmc) and not a.strict:
             try:
                 pj = json.load(open(pmc))
-                if int(pj.get("cells_per_launch", 0)) == ncells_local:
-                    ks = [v for k, v in pj["kernels"].items() if k.startswith("k_xz_state")]
-                    traffic = sum(k["hbm_read_bytes"] + k["hbm_write_bytes"] for k in ks) / len(ks)
+                now = kernel_source_hash()
+                prov = {"file": "profiles/latest_summary.json", "tag": pj.get("tag"), "profiled_sources_sha16": pj.get("kernel_sources_sha16"),
+                        "current_sources_sha16": now, "valid": bool(pj.get("kernel_sources_sha16") == now and
+                                                                    int(pj.get("cells_per_launch", 0)) == ncells_local)}
+                if prov["valid"]:
+                    K = pj["kernels"]
+                    ks = [v for k, v in K.items() if k.startswith("k_xz_state")]
+                    dom_traffic = sum(k["hbm_read_bytes"] + k["hbm_write_bytes"] for k in ks) / len(ks)
                     valu_busy = sum(k["valu_busy_frac"] for k in ks) / len(ks)
                     valu_instr = sum(k["valu_instr_per_cell"] for k in ks) / len(ks)
+                    stage_k = [v for k, v in K.items() if k.startswith(("k_xz_state", "k_y_state", "k_y_tracers", "k_tracers_fused", "k_tracer_patch"))]
+                    nstages = sum(k["calls"] for k in ks)      # one k_xz_state launch per RK stage
+                    traffic = sum((k["hbm_read_bytes"] + k["hbm_write_bytes"]) * k["calls"] for k in stage_k if "hbm_read_bytes" in k) / nstages
             except Exception:
-                traffic = None
+                traffic = dom_traffic = None
+        what = "complete supercell_example loop: WENO-FV dycore + Kessler + sponge_layer + ColumnNudger" if a.full_loop else "WENO-FV dycore only"
         out = {
             "metric": "cell-updates/s" + (" (full supercell_example loop)" if a.full_loop else ""), "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "supercell %dx%dx%d nens=%d per GPU (global %dx%dx%d), WENO-FV dycore only, 3 tracers, "
-                                   "CFL dt" % (a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz),
+            "config": {"workload": "supercell %dx%dx%d nens=%d per GPU (global %dx%dx%d, dx = dy = %g m), %s, 3 tracers, "
+                                   "CFL dt" % (a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz, dxy, what),
+                       "baseline_config": "configs[3] per-GPU block" if a.workload == "config4" else "configs[1]",
                        "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict,
-                       "schedule": ("two streams (state | tracers, tracer stream at high priority)" if (os.environ.get("MW_OVERLAP", "1" if world > 1 else "0") != "0" and not a.strict) else "one stream"),
+                       "schedule": ("two streams (state | tracers, tracer stream at high priority)" if two_streams else "one stream"),
                        "alg_bytes_per_cell_update": 64 * V,
                        "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world},
-            "roofline": {"bound": "hbm", "kernel": "k_flux" if a.strict else "k_xz_state", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
-                         "avg_launch_ms": avg_flux_s * 1e3, "launches": flux_n, "alg_bytes_per_launch": alg_bytes,
-                         "avg_launch_ms_exclusive": (prof_excl["xz_state"][0] / max(1, prof_excl["xz_state"][1])) if prof_excl else None,
-                         "achieved_exclusive": (alg_bytes / (prof_excl["xz_state"][0] / max(1, prof_excl["xz_state"][1]) * 1e-3) / 1e9)
-                         if prof_excl else None,
-                         "valu_busy_frac": valu_busy, "valu_instr_per_cell": valu_instr,
-                         "note": "fp64-VALU bound kernel (SURVEY.md 8(d)): valu_busy_frac / valu_instr_per_cell from the committed "
-                                 "rocprofv3 PMC summary profiles/latest_summary.json; duration measured live with hipEvents"},
+            "roofline": {"bound": "hbm", "binding_resource": "fp64 VALU issue (SURVEY.md 8(d): ~14 kflop against 512 B per cell-update)",
+                         "kernel": "one RK stage = k_y_state + k_xz_state + k_y_tracers + k_tracers_fused + k_tracer_patch "
+                                   "(SURVEY.md 8(d) flux stencil, 32 V B per cell)" if not a.strict else "one RK stage (general path)",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "alg_bytes_per_launch": stage_bytes, "avg_launch_ms": stage_ms,
+                         "avg_launch_ms_source": "hipEvents around every RK stage on the handle's stream, timed region" if stage_ms_live
+                                                 else "ms_per_step / 3 (two-stream schedule: a stage's launches overlap the next stage's)",
+                         "launches": prof_stage[1] if stage_ms_live else 3 * a.steps,
+                         "pmc_provenance": prov,
+                         "dominant_kernel": {"kernel": "k_flux" if a.strict else "k_xz_state", "achieved": dom_achieved,
+                                             "frac": (dom_achieved / 8000.0) if dom_achieved else None, "traffic": dom_traffic,
+                                             "avg_launch_ms": avg_flux_s * 1e3, "launches": flux_n, "alg_bytes_per_launch": dom_bytes,
+                                             "avg_launch_ms_exclusive": (prof_excl["xz_state"][0] / max(1, prof_excl["xz_state"][1])) if prof_excl else None,
+                                             "valu_busy_frac": valu_busy, "valu_instr_per_cell": valu_instr},
+                         "pipeline": {"alg_bytes_per_cell_update": 64 * V, "achieved": per_gpu * 64 * V / 1e9, "frac": per_gpu * 64 * V / 8.0e12}},
             "kernel_ms_per_step": {k: v[0] / 3.0 for k, v in prof.items()},
             "kernel_ms_per_step_exclusive": ({k: v[0] / 3.0 for k, v in prof_excl.items()} if prof_excl else None),
         }
-        # SURVEY.md 8(d)'s own per-unit figures, next to the dominant kernel's: whole pipeline = 64 V B per cell-update
-        # ("roofline.achieved = cell_updates_per_s x B_alg / 8.0e12"); flux stencil of one stage = 32 V B per cell, priced
-        # against one third of the step (everything a stage does, per GPU)
-        per_gpu = value / world
-        out["roofline"]["pipeline"] = {"alg_bytes_per_cell_update": 64 * V, "achieved": per_gpu * 64 * V / 1e9,
-                                       "frac": per_gpu * 64 * V / 8.0e12}
-        out["roofline"]["flux_stencil_stage"] = {"alg_bytes_per_cell": 32 * V, "achieved": 3.0 * per_gpu * 32 * V / 1e9,
-                                                 "frac": 3.0 * per_gpu * 32 * V / 8.0e12}
+        if world == 1 and not a.no_micro and not a.strict:
+            out.update(micro_section(torch, modules, coupler, dycore, micro, dt, a))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         print(json.dumps(out))

@@ -115,7 +115,8 @@ double mw_dycore_get_etime(mw_dycore_t h);   /* member etime, :55 */
  * dominant kernel instead of two around every kernel, whose markers cost about 2 % of the step); which: 0 x/z flux stencil + state update (k_xz_state; k_flux on the
  * general path), 1 fct (general path) / y-face correction pass of the fused tracer stage, 2 update (general path; tracer update
  * of the unfused production path), 3 halo, 4 convert, 5 y stencil state, 6 y stencil tracers, 7 x/z tracer stage (fused:
- * fluxes + FCT + update). */
+ * fluxes + FCT + update), 8 one whole RK stage of the production path (first to last launch on the handle's stream; also
+ * recorded by mw_dycore_profile(h,2)). */
 int  mw_dycore_profile(mw_dycore_t h, int enable);
 int  mw_dycore_profile_get(mw_dycore_t h, int which, double *total_ms, long long *launches);
 

@@ -785,8 +785,8 @@ struct mw_dycore_s {
   long long nWE1 = 0, nSN1 = 0;                  // per variable
   // profiling
   int prof = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[8];
-  size_t ev_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[9];       // kernel classes 0..7; 8 = one whole RK stage (all its launches)
+  size_t ev_used[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   void (*xchg_free)(void *) = nullptr;       // set when the handle owns xchg_ctx (the built-in RCCL transport, mw_rccl.cpp)
 };
 
@@ -859,7 +859,7 @@ static int upload_background(mw_dycore_s *d) {
 
 struct ProfScope {
   mw_dycore_s *d; int which; size_t idx; bool on; hipStream_t st;
-  ProfScope(mw_dycore_s *d_, int w, hipStream_t st_ = nullptr) : d(d_), which(w), idx(0), on(d_->prof == 1 || (d_->prof == 2 && w == 0)), st(st_ ? st_ : d_->stream) {
+  ProfScope(mw_dycore_s *d_, int w, hipStream_t st_ = nullptr) : d(d_), which(w), idx(0), on(d_->prof == 1 || (d_->prof == 2 && (w == 0 || w == 8))), st(st_ ? st_ : d_->stream) {
     if (!on) return;
     if (d->ev_used[which] == d->ev[which].size()) {
       hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); d->ev[which].push_back({a, b});
@@ -1124,6 +1124,7 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   const int par = (int)(gs & 1), slot = (int)(gs & 7);
   hipStream_t ss = d->stream, ts = d->overlap ? d->tstream : d->stream;
   const int T = d->p.nt;
+  ProfScope stage_scope(d, 8, ss);                            // one-stream schedule: first launch to last launch of the stage
   if (d->overlap && gs >= 2) MW_HIP(hipStreamWaitEvent(ss, d->ev_tr[(gs - 2) & 7], 0));
   // ---- state pipeline
   if (halo_fill(d, Sin, 0, 5, ss, 0, true)) return 1;
@@ -1263,7 +1264,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
-  for (int w = 0; w < 8; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (int w = 0; w < 9; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   delete d;
 }
 
@@ -1346,11 +1347,11 @@ int mw_dycore_profile(mw_dycore_t d, int enable) {
   if (!d) MW_FAIL("null handle");
   MW_HIP(hipStreamSynchronize(d->stream));
   d->prof = enable;
-  for (int w = 0; w < 8; w++) d->ev_used[w] = 0;
+  for (int w = 0; w < 9; w++) d->ev_used[w] = 0;
   return 0;
 }
 int mw_dycore_profile_get(mw_dycore_t d, int which, double *total_ms, long long *launches) {
-  if (!d || which < 0 || which > 7) MW_FAIL("bad argument");
+  if (!d || which < 0 || which > 8) MW_FAIL("bad argument");
   MW_HIP(hipStreamSynchronize(d->stream));
   double tot = 0;
   for (size_t i = 0; i < d->ev_used[which]; i++) { float ms = 0; MW_HIP(hipEventElapsedTime(&ms, d->ev[which][i].first, d->ev[which][i].second)); tot += ms; }
