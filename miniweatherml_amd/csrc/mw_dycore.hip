@@ -1018,7 +1018,8 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
   ProfScope ps(d, 0);
   dim3 grid; int chunk, tiles_x;
   if (xz_grid(d, grid, chunk, tiles_x)) return 1;
-  if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true, MODE>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
+  // nens == 1: the per-level background values come through LDS (k_xz_state<.., HPL = 1>; dynamic LDS = the chunk's rows)
+  if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true, MODE, 1>), grid, dim3(256), (size_t)(chunk + 2) * 64, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
                                       d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);
   else             hipLaunchKernelGGL((k_xz_state<STAGE, false, MODE>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
                                       d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);

@@ -337,6 +337,11 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 #undef MW_ROW_FINISH
 }
 
+// (Measured dead end, round 2: the 5-row window of every variable in LDS instead of registers -- a "ring", slot = row mod 5, no
+//  per-iteration register shift (48 v_mov_b64 of 543 VALU instructions) and 50 VGPRs less.  With two waves per SIMD it was 10 %
+//  SLOWER (1.39 against 1.25 ms per step: the 25 LDS reads of an iteration sit in front of the arithmetic that needs them), and
+//  capped at 168 VGPRs for a third wave the compiler still spilled 16-52 registers and it was 5 % slower.)
+
 // Y pass, tracers: flux(face j) = m_upw * (up ? south edge of cell j : north edge of cell j-1)
 template <int T>
 __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restrict__ S, double *__restrict__ FY,
@@ -405,6 +410,13 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
 //              so the neighbours are read from global memory (the same cache lines the wave has just touched: L1 hits) and
 //              EVERY lane reconstructs; only the west neighbour's east-edge value and the east face's flux still travel
 //              by lane (ds_bpermute): 1 halo cell per side, 64 - 2n cells per wave.
+// (Measured dead ends for nens > 1, round 2 -- config 4's block runs at 87 % of the nens = 1 rate per cell:
+//   * "member waves": a wave's lanes = 64 x cells of ONE member (nens doubles apart) so that the x stencil can use the DPP shifts:
+//     bitwise the nens = 1 result, but every wave-wide access then touches nens times as many cache lines -- k_xz_state 13.7 ->
+//     15.3 ms, k_tracers_fused 9.5 -> 13.4 ms per step on 256 x 512 x 128 x 4;
+//   * the neighbour-load path for nens = 1 (62 instead of 58 cells per wave): 30 % slower than the DPP shifts.
+//   What would close the gap is a member-major layout of the handle's internal arrays (every kernel then runs its nens = 1 path per
+//   member and only the coupler-side accesses are strided) -- not done.)
 // ---------------------------------------------------------------------------------------------------------------
 struct XzGeom {
   int n, lane, NXI, j, q, qq, qa, e, i, qc, ka, kb, kstart;   // qq: index incl. halo (BC logic), qa: the index that is addressed (wrapped)
@@ -456,13 +468,23 @@ __device__ __forceinline__ void x_neighbours(double c0, const double *__restrict
 
 // MODE 1 (last stage of the last cycle): u, v, w also go to the coupler's arrays (D13, :1929-1932: the slab holds (rho u)/rho
 // already), so that the tracer stage, which finishes D13, neither re-reads nor re-writes them.
-template <int STAGE, bool N1, int MODE>
+template <int STAGE, bool N1, int MODE, int HPL = 0>
 __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
                                                   double *__restrict__ Sout, double *__restrict__ MX, double *__restrict__ MZ,
                                                   unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                   const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
                                                   int tiles_x, double *__restrict__ cu, double *__restrict__ cv, double *__restrict__ cw) {
   const XzGeom g = xz_geom<N1>(p, chunk, tiles_x);
+  // HPL (nens == 1): the eight background values of every level of this chunk (DyP::hypk rows kstart..kb) are copied to LDS once
+  // and read from there (a broadcast read, issued with the iteration's other loads).  Read as scalar loads they were placed right
+  // in front of their first use -- the kernel has no spare SGPRs to hold them any earlier -- and their latency was exposed three
+  // times per level (-1 % kernel time).  All 256 threads copy, also those of waves beyond the last row, which leave right after.
+  extern __shared__ double lds_hp[];
+  if (HPL) {
+    const int nrow = g.kb - g.kstart + 1;
+    for (int i = threadIdx.x; i < nrow * 8; i += 256) lds_hp[i] = p.hypk[(long long)g.kstart * 8 + i];     // (nens == 1: row k at k*8)
+    __syncthreads();
+  }
   if (!g.valid) return;
   const int n = g.n, lane = g.lane, NXI = g.NXI, j = g.j, q = g.q, e = g.e;
   const double *col = S + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qa;           // level k at col + (k+HZ)*sK
@@ -503,11 +525,16 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       for (int l = 0; l < 5; l++) tyv[l] = tendY[(long long)l * p.nC + cell0 + (long long)k * planeC];
     }
     if (p.use_immersed && fin) immv = p.imm[cell0 + (long long)(k - 1) * planeC];
+    double hpl[8];
+    if (HPL) {
+#pragma unroll
+      for (int f = 0; f < 8; f++) hpl[f] = lds_hp[(k - g.kstart) * 8 + f];
+    }
     // ------------------------------------------------ X direction (cell k = window centre)
     double fxs[5];
     if (xwork) {
       const double *hp = p.hypk + (long long)(k * n + e) * 8;
-      const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
+      const double hyr = HPL ? hpl[0] : hp[0], hyt = HPL ? hpl[1] : hp[1], p0 = HPL ? hpl[2] : hp[2], ihyt = HPL ? hpl[3] : hp[3];
       double we[5], ee[5];
 #pragma unroll
       for (int v = 0; v < 5; v++) {
@@ -556,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     for (int l = 0; l < 5; l++) fzs[l] = 0;
     if (zface) {
       const double *hp = p.hypk + (long long)(k * n + e) * 8;
-      const double hyr = hp[4], hyt = hp[5], p0 = hp[6], ihyt = hp[7];
+      const double hyr = HPL ? hpl[4] : hp[4], hyt = HPL ? hpl[5] : hp[5], p0 = HPL ? hpl[6] : hp[6], ihyt = HPL ? hpl[7] : hp[7];
       double Lr = ct[idR], Lu = ct[idW], Lt = ct[idT], Rr = be[idR], Ru = be[idW], Rt = be[idT];
       // :1020-1038 wall/open edge-value rule at the two boundary faces.  k is wave-uniform: a branch, so that the interior faces
       // carry no selects (a zero normal velocity on both sides is what the reference's "zero the momentum" amounts to).
@@ -580,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     // ------------------------------------------------ finalise cell k-1 (it now has its upper z face)
     if (fin) {
       const int kc = k - 1;
-      const double hyc = p.hypk[(long long)(kc * n + e) * 8];
+      const double hyc = HPL ? lds_hp[(kc - g.kstart) * 8] : p.hypk[(long long)(kc * n + e) * 8];
       const int wi = 1;                                        // window slot that holds level k-1 (window is centred on k)
       const double rho_s = w[idR][wi] + hyc;
       const double rho_n = (STAGE == 1) ? rho_s : snv[idR] + hyc;
