@@ -171,6 +171,10 @@ int  mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *
                           const double *rho_d, double *temp, double *precl, void *workspace, int *rainsplit_out,
                           void *stream);
 
+/* Diagnostic (no reference counterpart): the Kessler module's own log (fn 0), exp (1), sqrt (2) and reciprocal (3) -- short
+ * forms for positive finite arguments, see mw_kessler.hip -- on n caller-supplied DEVICE doubles. */
+int  mw_kessler_math_probe(long long n, const double *x, double *y, int fn, void *stream);
+
 /* ---- sponge layer + column nudging (the two remaining per-step modules of the supercell loop) ---- */
 /* Sums `buf` (DEVICE, n doubles) in place over all ranks, ordered on `stream` -- MPI_Allreduce(SUM) in the reference
  * (sponge_layer.h:53-63, column_nudging.h:89-99).  Pass NULL on a single rank. */

@@ -18,30 +18,92 @@
 // =====================================================================================================
 #include "../../include/mw_cdna4.h"
 #include "mw_common.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
 namespace mw {
 
-// x^a for x >= 0 as exp(a log x): device pow is ~230 fp64-VALU instructions, log + exp ~140, and the three powers of
-// r*qr in the evaporation/fall-speed formulas share one log.  |a log x| <= ~25 here, so the result is within ~3e-15 relative
-// of pow (x = 0 gives exp(-inf) = 0 = pow(0, a) for a > 0).
-__device__ __forceinline__ double pow_pos(double x, double a) { return exp(a * log(x)); }
-// 1/x to full fp64 accuracy (v_rcp_f64 + two Newton steps, 5 instructions; an IEEE division is ~25).  A rain-free cell of the
-// reference's formulas holds ~17 divisions against one exp/log pair and one exp: they dominate, so a/b is evaluated as a*rcp(b)
-// (<= 1.5 ulp from the quotient; the parity tolerance of this module is 1e-12).
-__device__ __forceinline__ double rcp64(double x) {
+// ---------------------------------------------------------------------------------------------------------------
+// log / exp / sqrt for this module.  With rain in every wavefront the sweep is fp64-transcendental bound (4 log + 6 exp +
+// 1 sqrt per cell); the device library's log is 92 VALU instructions, its exp 36, its sqrt 22 (they also serve denormals,
+// infinities and NaNs to < 1 ulp).  The arguments here are positive, finite density / pressure ratios, so:
+//   kes_log  : fdlibm's scheme -- x = 2^k m, m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1), log m = 2s + s^3 R(s^2) with the 7-term
+//              minimax R (|error| < 2^-58.45), ln 2 split in two: 36 instructions, <= 1 ulp (tests: <= 2.3e-16 relative
+//              against the host libm over 1e-130 .. 150).  x == 0 -> -inf (so that exp(a log 0) = 0 = pow(0, a)); tiny x is scaled.
+//   kes_exp  : k = rint(x / ln 2), r = x - k ln 2 (two-part), degree-13 Taylor polynomial (|r| <= 0.347: remainder 4e-18),
+//              ldexp: 21 instructions, <= 2.3e-16 relative.  The argument is clamped to [-746, 710]: -inf -> 0, overflow -> inf.
+//   kes_sqrt : v_rsq_f64 + two coupled Newton steps (arguments in [1e-3, 1e3]).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double kes_rcp(double x) {
 #pragma clang fp contract(fast)
   double r = __builtin_amdgcn_rcp(x);
   r = r + r * (1.0 - x * r);
   r = r + r * (1.0 - x * r);
   return r;
 }
+// one Newton step: 2e-15 relative (used where the quotient only feeds a rate term; the temperature <-> theta round trip and the
+// mixing ratios keep the fully rounded reciprocal)
+__device__ __forceinline__ double kes_rcp1(double x) {
+#pragma clang fp contract(fast)
+  double r = __builtin_amdgcn_rcp(x);
+  return r + r * (1.0 - x * r);
+}
+__device__ __forceinline__ double kes_log(double x) {
+#pragma clang fp contract(fast)
+  const bool zero = (x == 0.0);
+  const bool tiny = (x < 0x1p-1000);
+  const double xs = tiny ? x * 0x1p+200 : x;
+  int e = __builtin_amdgcn_frexp_exp(xs);
+  double m = __builtin_amdgcn_frexp_mant(xs);                 // [0.5, 1)
+  const bool lo = (m < 0.70710678118654752440);
+  m = lo ? m + m : m;                                         // [sqrt(1/2), sqrt(2))
+  e = (lo ? e - 1 : e) - (tiny ? 200 : 0);
+  const double f = m - 1.0;
+  const double s = f * kes_rcp(2.0 + f);
+  const double hfsq = 0.5 * f * f, z = s * s, w = z * z;
+  const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+  const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+  const double R = t2 + t1, dk = (double)e;
+  const double r = dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+  return zero ? -__builtin_huge_val() : r;
+}
+__device__ __forceinline__ double kes_exp(double x) {
+#pragma clang fp contract(fast)
+  x = fmin(fmax(x, -746.0), 710.0);
+  const double k = __builtin_rint(x * 1.44269504088896340736);
+  double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+  r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;                              // 1/13!
+  p = p * r + 1.0 / 479001600.0; p = p * r + 1.0 / 39916800.0; p = p * r + 1.0 / 3628800.0; p = p * r + 1.0 / 362880.0;
+  p = p * r + 1.0 / 40320.0;     p = p * r + 1.0 / 5040.0;     p = p * r + 1.0 / 720.0;     p = p * r + 1.0 / 120.0;
+  p = p * r + 1.0 / 24.0;        p = p * r + 1.0 / 6.0;        p = p * r + 0.5;             p = p * r + 1.0;
+  p = p * r + 1.0;
+  return __builtin_amdgcn_ldexp(p, (int)k);
+}
+__device__ __forceinline__ double kes_sqrt(double a) {
+#pragma clang fp contract(fast)
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  double r = 0.5 - h * g;
+  g = g + g * r; h = h + h * r;
+  r = 0.5 - h * g;
+  g = g + g * r; h = h + h * r;
+  return g + h * (a - g * g) * 1.0;                           // one correction of the residual (h ~ 1/(2 sqrt a))
+}
+// x^a for x >= 0 as exp(a log x): device pow is ~230 fp64-VALU instructions, kes_log + kes_exp 57, and the powers of
+// r*qr in the evaporation formula share one log.  |a log x| <= ~25 here, so the result is within ~3e-15 relative
+// of pow (x = 0 gives exp(-inf) = 0 = pow(0, a) for a > 0).
+__device__ __forceinline__ double pow_pos(double x, double a) { return kes_exp(a * kes_log(x)); }
+// 1/x to full fp64 accuracy (v_rcp_f64 + two Newton steps, 5 instructions; an IEEE division is ~25).  A rain-free cell of the
+// reference's formulas holds ~17 divisions against one exp/log pair and one exp: they dominate, so a/b is evaluated as a*rcp(b)
+// (<= 1.5 ulp from the quotient; the parity tolerance of this module is 1e-12).
+__device__ __forceinline__ double rcp64(double x) { return kes_rcp(x); }
 // The same where x is a rain quantity: rain-free wavefronts (most of the domain) skip the log/exp pair.  exp(a log 0) =
 // exp(-inf) = 0, so the short cut returns exactly what the formula returns; mixed wavefronts evaluate the formula.
 __device__ __forceinline__ double pow_rain(double x, double a) {
   if (!__any(x != 0.0)) return 0.0;
-  return exp(a * log(x));
+  return kes_exp(a * kes_log(x));
 }
 
 struct KesP {
@@ -57,37 +119,55 @@ __global__ __launch_bounds__(256) void k_kessler_init_min(unsigned long long *dt
 
 // Terminal velocity of rain, :256-260, from the density fields (one definition for the CFL pass, the chunk sweep and the
 // column sweep: the 16 bytes per cell of a stored copy cost more than recomputing it, and a rain-free wavefront skips it).
-__device__ __forceinline__ double kessler_velqr(double rho_r, double rd, double rho0) {
+__device__ __forceinline__ double kessler_velqr(double rho_r, double rd, double ird, double rho0) {      // ird = 1 / rd
 #pragma clang fp contract(off)
   if (!__any(rho_r != 0.0)) return 0.0;                       // wave-uniform; exact: 36.34 * 0^0.1364 * rhalf = 0
-  const double qr = rho_r / rd;                               // :140
+  const double qr = rho_r * ird;                              // :140
   const double r = 0.001 * rd;                                // :256
-  const double rhalf = sqrt(rho0 / rd);                       // :257  rho(0,i)/rho(k,i)
+  const double rhalf = kes_sqrt(rho0 * ird);                  // :257  rho(0,i)/rho(k,i)
   return 36.34 * pow_rain(qr * r, 0.1364) * rhalf;            // :260
 }
 
-__global__ __launch_bounds__(256) void k_kessler_prep(KesP p, const double *__restrict__ rho_v, const double *__restrict__ rho_r,
-                                                      const double *__restrict__ rho_d, const double *__restrict__ temp,
-                                                      double *__restrict__ velqr_out, double *__restrict__ flux_top, int chunk,
+// K2 + K3 (:255-279).  thread = (column i, a range of levels).  What the pass must deliver is (a) rainsplit = ceil(dt / min dt2d) and
+// (b) the pre-update rain flux of the level just above every z chunk of the sweep.  dt2d = 0.8 dz / velqr is below dt -- i.e. can
+// raise rainsplit above 1 -- only where velqr > 0.8 dz / dt (573 m/s at the dycore's CFL step: never); every other cell contributes a
+// value >= dt, and min(.., dt) gives the same rainsplit (cells without rain contribute exactly dt in the reference, :266).  A cell
+// is PROVEN harmless without any transcendental: for 0.001 rho_r <= 1 the power (qr r)^0.1364 is <= 1, so
+// velqr <= 36.34 sqrt(rho0 / rho) < limit  <=>  36.34^2 rho0 (1 + 1e-9) < limit^2 rho.  Only wavefronts with an unproven cell -- or on a
+// chunk-boundary level, whose flux the sweep needs -- evaluate the fall speed (:260).  The pass is then a stream over two fields.
+__global__ __launch_bounds__(256) void k_kessler_prep(KesP p, const double *__restrict__ rho_r, const double *__restrict__ rho_d,
+                                                      double *__restrict__ flux_top, int chunk, int klevels,
                                                       unsigned long long *dtmax_bits) {
 #pragma clang fp contract(off)
-  // grid-stride over all (k, column) cells: a few thousand workgroups -> a few thousand atomics on the one min word
-  // (62500 single-address atomics cost 0.7 ms on MI355X: ~88 per microsecond per address)
-  double dtc = __longlong_as_double(0x7FF0000000000000ll);
-  const long long n = (long long)p.nz * p.ncol;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long long)gridDim.x * 256) {
-    const int k = (int)(idx / p.ncol);
-    const long long i = idx - (long long)k * p.ncol;
-    double rd = rho_d[idx];
-    const double rr = rho_r[idx];
-    double qr = rr / rd;                                      // :140
-    double r = 0.001 * rd;                                    // :256
-    double velqr = kessler_velqr(rr, rd, rho_d[i]);           // :257-260
-    if (k > 0 && k % chunk == 0) flux_top[(long long)(k / chunk - 1) * p.ncol + i] = r * qr * velqr;   // flux entering the chunk below
-    if (k < p.nz - 1) {                                       // :262-268
-      double zk = (k + 0.5) * p.dz, zk1 = (k + 1 + 0.5) * p.dz;   // zmid, :137
-      double c = (velqr > 1.e-10) ? 0.8 * (zk1 - zk) / velqr : p.dt;
-      dtc = fmin(dtc, c);
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * klevels, k1 = min(k0 + klevels, p.nz);
+  double dtc = p.dt;                                          // every cell's contribution is capped at dt (see above)
+  if (i < p.ncol) {
+    const double rho0 = rho_d[i];
+    const double lim = 0.8 * p.dz / p.dt;
+    const double lhs = (36.34 * 36.34) * rho0 * (1.0 + 1.0e-9), lim2 = lim * lim;
+    constexpr int KL = 5;                                     // (= klevels of the launch) all loads of the thread first
+    double rdv[KL], rrv[KL];
+#pragma unroll
+    for (int m = 0; m < KL; m++) { const long long idx = (long long)min(k0 + m, p.nz - 1) * p.ncol + i; rdv[m] = rho_d[idx]; rrv[m] = rho_r[idx]; }
+#pragma unroll
+    for (int m = 0; m < KL; m++) {
+      const int k = k0 + m;
+      if (k >= k1) break;
+      const double rd = rdv[m], rr = rrv[m];
+      const bool boundary = (k > 0 && k % chunk == 0);        // block-uniform
+      const bool proven = (0.001 * rr <= 1.0) && (lhs < lim2 * rd);
+      if (boundary || __any(!proven)) {
+        const double ird = rcp64(rd);
+        const double qr = rr * ird, r = 0.001 * rd;           // :140, :256
+        const double velqr = kessler_velqr(rr, rd, ird, rho0);   // :257-260
+        if (boundary) flux_top[(long long)(k / chunk - 1) * p.ncol + i] = r * qr * velqr;   // flux entering the chunk below
+        if (k < p.nz - 1) {                                   // :262-268
+          const double zk = (k + 0.5) * p.dz, zk1 = (k + 1 + 0.5) * p.dz;   // zmid, :137
+          const double c = (velqr > 1.e-10) ? 0.8 * (zk1 - zk) / velqr : p.dt;
+          dtc = fmin(dtc, c);
+        }
+      }
     }
   }
   // block min (wave shuffle, then LDS across the 4 waves); positive doubles order like their bit patterns
@@ -98,23 +178,30 @@ __global__ __launch_bounds__(256) void k_kessler_prep(KesP p, const double *__re
   __syncthreads();
   if (threadIdx.x == 0) {
     double m = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
-    atomicMin(dtmax_bits, (unsigned long long)__double_as_longlong(m));     // :276 minval(dt2d)
+    if (m < p.dt || (blockIdx.x == 0 && blockIdx.y == 0))                    // one word, one atomic per block that has something to say
+      atomicMin(dtmax_bits, (unsigned long long)__double_as_longlong(m));     // :276 minval(dt2d), capped at dt
   }
 }
 
 // One cell of one rain sub-cycle (:288-335): sedimentation from the pre-update fluxes, then the adjustment terms.
-// In: theta, qv, qc, qr, velqr (pre-update), flux_above = r*qr*velqr of level k+1 (pre-update).  Out: updated theta..velqr;
+// In: T, qv, qc, qr, velqr (pre-update), flux_above = r*qr*velqr of level k+1 (pre-update).  Out: updated T..velqr;
 // returns this cell's pre-update flux (the next lower cell's flux_above).
-__device__ __forceinline__ double kessler_cell(const KesP &p, int k, double rd, double rho0, double pk, double pp0, double dt0, double flux_above,
-                                               double &theta, double &qv, double &qc, double &qr, double &velqr, double &precl_acc) {
+// TEMPERATURE FORM.  The reference converts temp -> theta = temp / pk with the Exner function pk = (p/p0)^(R_d/cp) (:142-143), works
+// on theta, and converts back temp = theta pk (:160).  pk is constant during the call and enters the column physics only as
+// pk * theta (= temp, :303-305) and as the latent-heating factor lv / (cp pk) on theta (:321) -- which is lv / cp on temp.  The Exner
+// function therefore cancels exactly; evaluating in temperature form drops one log, one exp and two reciprocals per cell and
+// differs from the reference's operation order by rounding only (tests: 1e-12 against the oracle, which keeps the theta form; a
+// vapour-free state now comes back bit for bit).  pc (:258) needs p/p0 itself, not pk.
+__device__ __forceinline__ double kessler_cell(const KesP &p, int k, double rd, double rho0, double pp0, double dt0, double flux_above,
+                                               double &T, double &qv, double &qc, double &qr, double &velqr, double &precl_acc) {
 #pragma clang fp contract(off)
   const double Rd = p.R_d, cp = p.cp_d;
   const double psl = p.p0 / 100;                              // :246
   const double rhoqr = 1000., lv = 2.5e6;                     // :247-248
   const int nz = p.nz;
   double r = 0.001 * rd;                                              // :256
-  double rhalf = sqrt(rho0 * rcp64(rd));                              // :257
-  double pc = 3.8 * rcp64(pp0 * psl);                                      // :258  pow(pk, cp/Rd) = pressure/p0 (pk = (pressure/p0)^(Rd/cp))
+  double rhalf = kes_sqrt(rho0 * rcp64(rd));                          // :257
+  double pc = 3.8 * kes_rcp1(pp0 * psl);                                      // :258  pow(pk, cp/Rd) = pressure/p0 (pk = (pressure/p0)^(Rd/cp))
   double zk = (k + 0.5) * p.dz;
   // sedimentation (:288-299) from pre-update values
   if (k == 0) precl_acc = precl_acc + rho0 * qr * velqr / rhoqr;      // :292 (rho(0,i) qr(0,i) velqr(0,i))
@@ -122,31 +209,31 @@ __device__ __forceinline__ double kessler_cell(const KesP &p, int k, double rd, 
   double sed;
   if (k == nz - 1) {
     double zm = (k - 1 + 0.5) * p.dz;
-    sed = -dt0 * qr * velqr * rcp64(0.5 * (zk - zm));                 // :295
+    sed = -dt0 * qr * velqr * kes_rcp1(0.5 * (zk - zm));                 // :295
   } else {
     double zp = (k + 1 + 0.5) * p.dz;
-    sed = dt0 * (flux_above - flux_here) * rcp64(r * (zp - zk));      // :297-298
+    sed = dt0 * (flux_above - flux_here) * kes_rcp1(r * (zp - zk));      // :297-298
   }
   // adjustment terms (:302-335)
-  double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.0)) * rcp64(1 + dt0 * 2.2 * pow_rain(qr, 0.875));
+  double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.0)) * kes_rcp1(1 + dt0 * 2.2 * pow_rain(qr, 0.875));
   qc = fmax(qc - qrprod, 0.0);
   qr = fmax(qr + qrprod + sed, 0.0);
-  double tmp = pk * theta - 36.;
-  const double rtmp = rcp64(tmp);
-  double qvs = pc * exp(17.27 * (pk * theta - 273.) * rtmp);
-  double prod = (qv - qvs) * rcp64(1. + qvs * (4093. * lv / cp) * (rtmp * rtmp));
+  double tmp = T - 36.;                                               // :303  pk * theta - 36
+  const double rtmp = kes_rcp1(tmp);
+  double qvs = pc * kes_exp(17.27 * (T - 273.) * rtmp);
+  double prod = (qv - qvs) * kes_rcp1(1. + qvs * (4093. * lv / cp) * (rtmp * rtmp));
   double tmp1 = 0.0;                                                   // rain-free wavefront: (1.6 + 0) * 0 / (..) * (..) = 0
   if (__any(r * qr != 0.0)) {
-    const double lrq = log(r * qr);                                    // one log for the two powers of r*qr
-    const double rqvs = rcp64(qvs);
-    tmp1 = dt0 * (((1.6 + 124.9 * exp(0.2046 * lrq)) * exp(0.525 * lrq)) * rcp64(2550000. * pc * ((1.0 / 3.8) * rqvs) + 540000.)) *
-           (fmax(qvs - qv, 0.0) * (rcp64(r) * rqvs));
+    const double lrq = kes_log(r * qr);                                // one log for the two powers of r*qr
+    const double rqvs = kes_rcp1(qvs);
+    tmp1 = dt0 * (((1.6 + 124.9 * kes_exp(0.2046 * lrq)) * kes_exp(0.525 * lrq)) * kes_rcp1(2550000. * pc * ((1.0 / 3.8) * rqvs) + 540000.)) *
+           (fmax(qvs - qv, 0.0) * (kes_rcp1(r) * rqvs));
   }
   double tmp2 = fmax(-prod - qc, 0.0);
   double tmp3 = qr;
   double ern = fmin(tmp1, fmin(tmp2, tmp3));
   double cond = fmax(prod, -qc);
-  theta = theta + lv * rcp64(cp * pk) * (cond - ern);
+  T = T + (lv / cp) * (cond - ern);                                   // :321  theta += lv / (cp pk) (..), times pk
   qv = fmax(qv - cond + ern, 0.0);
   qc = qc + cond;
   qr = qr - ern;
@@ -180,14 +267,13 @@ __global__ __launch_bounds__(256) void k_kessler_chunks(KesP p, double *__restri
     const double rd_n = rho_d[nidx], T_n = temp[nidx], rv_n = rho_v[nidx], rc_n = rho_c[nidx], rr_n = rho_r[nidx];
     double pressure = p.R_d * rd * T_in + p.R_v * rv_in * T_in;          // :141
     const double pp0 = pressure * (1.0 / p.p0);
-    double pk = pow_pos(pp0, p.R_d / p.cp_d);                            // :142 exner
     const double ird = rcp64(rd);
     double qv = rv_in * ird, qc = rc_in * ird, qr = rr_in * ird;         // :138-140
-    double theta = T_in * rcp64(pk);                                     // :143
-    double velqr = kessler_velqr(rr_in, rd, rho0);                       // :260 (as k_kessler_prep saw it)
-    flux_above = kessler_cell(p, k, rd, rho0, pk, pp0, dt0, flux_above, theta, qv, qc, qr, velqr, precl_acc);
+    double T = T_in;                                                     // (temperature form: see kessler_cell)
+    double velqr = kessler_velqr(rr_in, rd, ird, rho0);                  // :260 (as k_kessler_prep saw it)
+    flux_above = kessler_cell(p, k, rd, rho0, pp0, dt0, flux_above, T, qv, qc, qr, velqr, precl_acc);
     rho_v[idx] = qv * rd; rho_c[idx] = qc * rd; rho_r[idx] = qr * rd;    // :154-161 [K5]
-    temp[idx] = theta * pk;
+    temp[idx] = T;
     rd = rd_n; T_in = T_n; rv_in = rv_n; rc_in = rc_n; rr_in = rr_n;
   }
   if (c == 0) precl[i] = precl_acc / 1.0;                                // :332-334
@@ -217,22 +303,29 @@ __global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restri
       double rd = rho_d[idx];
       double T_in = temp[idx], rv_in = rho_v[idx];
       double pressure = p.R_d * rd * T_in + p.R_v * rv_in * T_in;        // :141
-      const double pp0 = pressure / p.p0;
-      double pk = pow_pos(pp0, p.R_d / p.cp_d);                          // :142 exner
-      double theta, qv, qc, qr, velqr;
+      const double pp0 = pressure / p.p0;                                // (of the call's input state, like the reference's pk, :141-142)
+      double T, qv, qc, qr, velqr;
       if (first) {
-        qv = rv_in / rd; qc = rho_c[idx] / rd; qr = rho_r[idx] / rd;      // :138-140
-        theta = T_in / pk;                                                // :143
-        velqr = kessler_velqr(rho_r[idx], rd, rho0);                      // :260 (as k_kessler_prep saw it)
-      } else { theta = w_theta[idx]; qv = w_qv[idx]; qc = w_qc[idx]; qr = w_qr[idx]; velqr = w_velqr[idx]; }
-      flux_above = kessler_cell(p, k, rd, rho0, pk, pp0, dt0, flux_above, theta, qv, qc, qr, velqr, precl_acc);
+        const double ird = rcp64(rd);
+        qv = rv_in * ird; qc = rho_c[idx] * ird; qr = rho_r[idx] * ird;   // :138-140
+        T = T_in;                                                         // (temperature form: see kessler_cell)
+        velqr = kessler_velqr(rho_r[idx], rd, ird, rho0);                 // :260 (as k_kessler_prep saw it)
+      } else { T = w_theta[idx]; qv = w_qv[idx]; qc = w_qc[idx]; qr = w_qr[idx]; velqr = w_velqr[idx]; }
+      flux_above = kessler_cell(p, k, rd, rho0, pp0, dt0, flux_above, T, qv, qc, qr, velqr, precl_acc);
       if (lastp) {                                                        // :154-161 [K5]
         rho_v[idx] = qv * rd; rho_c[idx] = qc * rd; rho_r[idx] = qr * rd;
-        temp[idx] = theta * pk;
-      } else { w_theta[idx] = theta; w_qv[idx] = qv; w_qc[idx] = qc; w_qr[idx] = qr; w_velqr[idx] = velqr; }
+        temp[idx] = T;
+      } else { w_theta[idx] = T; w_qv[idx] = qv; w_qc[idx] = qc; w_qr[idx] = qr; w_velqr[idx] = velqr; }
     }
   }
   precl[i] = precl_acc / (double)rainsplit;                               // :332-334
+}
+
+// diagnostic: the module's log / exp / sqrt on caller-supplied arguments (tests compare them with the host libm)
+__global__ __launch_bounds__(256) void k_kessler_math_probe(long long n, const double *__restrict__ x, double *__restrict__ y, int fn) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  y[i] = fn == 0 ? kes_log(x[i]) : fn == 1 ? kes_exp(x[i]) : fn == 2 ? kes_sqrt(x[i]) : kes_rcp(x[i]);
 }
 
 } // namespace mw
@@ -242,6 +335,14 @@ using namespace mw;
 extern "C" {
 
 long long mw_kessler_workspace_bytes(int nz, long long ncol) { return (long long)sizeof(double) * (16 + 5ll * nz * ncol + ((long long)nz / 4 + 1) * ncol); }
+
+int mw_kessler_math_probe(long long n, const double *x, double *y, int fn, void *stream) {
+  if (n < 1 || !x || !y || fn < 0 || fn > 3) MW_FAIL("kessler_math_probe: bad argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipLaunchKernelGGL(k_kessler_math_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, x, y, fn);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
 
 int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *rho_v, double *rho_c, double *rho_r,
                          const double *rho_d, double *temp, double *precl, void *workspace, int *rainsplit_out, void *stream) {
@@ -254,14 +355,14 @@ int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *r
   unsigned long long *bits = (unsigned long long *)workspace;
   double *ws = (double *)workspace + 16;
   hipLaunchKernelGGL(k_kessler_init_min, dim3(1), dim3(64), 0, st, bits); MW_LAUNCH_CHECK();
-  long long nb = ((long long)nz * ncol + 255) / 256;
-  if (nb > 4096) nb = 4096;
   // z chunks of the rainsplit == 1 path: enough (column, chunk) threads to fill the chip, at least 4 levels per chunk
   int chunk = nz;
   for (int c : {25, 20, 16, 12, 10, 8, 5, 4}) if (c < nz) { chunk = c; if (((ncol + 63) / 64) * ((nz + c - 1) / c) >= 16384) break; }
   const int nchunks = (nz + chunk - 1) / chunk;
   double *flux_top = ws + 5ll * nz * ncol;                    // (nchunks-1, ncol)
-  hipLaunchKernelGGL(k_kessler_prep, dim3((unsigned)nb), dim3(256), 0, st, p, rho_v, rho_r, rho_d, temp, ws, flux_top, chunk, bits); MW_LAUNCH_CHECK();
+  const int klevels = 5;                                        // levels per thread of the CFL pass (k_kessler_prep: KL)
+  hipLaunchKernelGGL(k_kessler_prep, dim3((unsigned)((ncol + 255) / 256), (unsigned)((nz + klevels - 1) / klevels)), dim3(256), 0, st, p,
+                     rho_r, rho_d, flux_top, chunk, klevels, bits); MW_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_kessler_chunks, dim3((unsigned)((ncol + 255) / 256), (unsigned)nchunks), dim3(256), 0, st, p, rho_v, rho_c, rho_r,
                      rho_d, temp, precl, bits, ws, flux_top, chunk); MW_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_kessler_column, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp,
