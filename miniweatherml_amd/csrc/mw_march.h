@@ -343,6 +343,10 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 //  capped at 168 VGPRs for a third wave the compiler still spilled 16-52 registers and it was 5 % slower.)
 
 // Y pass, tracers: flux(face j) = m_upw * (up ? south edge of cell j : north edge of cell j-1)
+// (Measured, round 2: a wave-uniform "all five stencil rows are exactly 0 -> edges 0" short cut for cloud and rain -- bitwise
+//  neutral -- removes 2/3 of this kernel's arithmetic on the supercell state and changes its time by 3 %: the kernel moves 57 B per
+//  cell at 4.6 TB/s and is bandwidth-bound once the arithmetic shrinks.  k_tracers_fused gained 10 %, the step 4 %; a state with
+//  cloud and rain everywhere lost 3 % to the test.  Not kept.)
 template <int T>
 __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restrict__ S, double *__restrict__ FY,
                                                    const double *__restrict__ MY, const unsigned char *__restrict__ UPY, int chunk,
