@@ -53,6 +53,7 @@ SYMBOLS = {
     "mw_dycore_get_grid": (C.c_int, [C.c_void_p, C.POINTER(Grid)]),
     "mw_dycore_set_bc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mw_dycore_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
+    "mw_dycore_set_order": (C.c_int, [C.c_void_p, C.c_int]),
     "mw_dycore_time_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_double]),
     "mw_dycore_compute_tendencies": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_double,
                                                                                C.c_void_p, C.c_void_p]),

@@ -272,11 +272,12 @@ __global__ __launch_bounds__(256) void k_unpack_y(DyP p, double *__restrict__ S,
 // The two sides of a face are described by (source cell, which edge); passive variables (transverse momenta,
 // tracers) are reconstructed on the upwind side only.
 // -----------------------------------------------------------------------------------------------------
-template <bool STRICT>
+template <bool STRICT, int ORD = 5>
 __device__ __forceinline__ double edge_value(const double *__restrict__ q, long long st, int right) {
   double l, r;
-  if (STRICT) weno5_edges_strict(q[-2 * st], q[-st], q[0], q[st], q[2 * st], l, r);
-  else        weno5_edges_fast  (q[-2 * st], q[-st], q[0], q[st], q[2 * st], l, r);
+  if (ORD == 3) { if (STRICT) weno3_edges_strict(q[-st], q[0], q[st], l, r); else weno3_edges_fast(q[-st], q[0], q[st], l, r); }
+  else if (STRICT) weno5_edges_strict(q[-2 * st], q[-st], q[0], q[st], q[2 * st], l, r);
+  else             weno5_edges_fast  (q[-2 * st], q[-st], q[0], q[st], q[2 * st], l, r);
   return right ? r : l;
 }
 
@@ -285,16 +286,16 @@ __device__ __forceinline__ double edge_value(const double *__restrict__ q, long 
 // edge value of the opposite boundary face (:1008-1019), hydrostatic part of THAT level included.
 struct FaceBg { double hyr, hyt, p0, ihyt; };
 
-template <bool STRICT>
+template <bool STRICT, int ORD>
 __device__ __forceinline__ void face_flux(const DyP &p, const double *__restrict__ cL, int eL, const double *__restrict__ cR,
                                           int eR, long long st, int nrm, const FaceBg &bL, const FaceBg &bR,
                                           bool zero_nrm, double *__restrict__ f, long long fV) {
   const double cs = 350;
-  double rL = edge_value<STRICT>(cL + idR * p.sV, st, eL) + bL.hyr;
-  double rR = edge_value<STRICT>(cR + idR * p.sV, st, eR) + bR.hyr;
-  double uL = edge_value<STRICT>(cL + nrm * p.sV, st, eL);
-  double uR = edge_value<STRICT>(cR + nrm * p.sV, st, eR);
-  double eTL = edge_value<STRICT>(cL + idT * p.sV, st, eL), eTR = edge_value<STRICT>(cR + idT * p.sV, st, eR);
+  double rL = edge_value<STRICT, ORD>(cL + idR * p.sV, st, eL) + bL.hyr;
+  double rR = edge_value<STRICT, ORD>(cR + idR * p.sV, st, eR) + bR.hyr;
+  double uL = edge_value<STRICT, ORD>(cL + nrm * p.sV, st, eL);
+  double uR = edge_value<STRICT, ORD>(cR + nrm * p.sV, st, eR);
+  double eTL = edge_value<STRICT, ORD>(cL + idT * p.sV, st, eL), eTR = edge_value<STRICT, ORD>(cR + idT * p.sV, st, eR);
   double tL = eTL + bL.hyt;
   double tR = eTR + bR.hyt;
   if (STRICT) {
@@ -314,7 +315,7 @@ __device__ __forceinline__ void face_flux(const DyP &p, const double *__restrict
     f[idT * fV] = m_upw * (ind ? tR : tL) / r_upw;
     for (int l = idU; l < p.V; l++) {
       if (l == nrm || l == idT) continue;
-      double val = edge_value<true>(cU + l * p.sV, st, eU) * r_upw;
+      double val = edge_value<true, ORD>(cU + l * p.sV, st, eU) * r_upw;
       f[l * fV] = m_upw * val / r_upw;
     }
   } else {
@@ -335,12 +336,12 @@ __device__ __forceinline__ void face_flux(const DyP &p, const double *__restrict
     f[idT * fV] = m_upw * (ind ? tR : tL) / r_upw;
     for (int l = idU; l < p.V; l++) {
       if (l == nrm || l == idT) continue;
-      f[l * fV] = m_upw * edge_value<false>(cU + l * p.sV, st, eU);
+      f[l * fV] = m_upw * edge_value<false, ORD>(cU + l * p.sV, st, eU);
     }
   }
 }
 
-template <bool STRICT>
+template <bool STRICT, int ORD>
 __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ S, double *__restrict__ FX,
                                               double *__restrict__ FY, double *__restrict__ FZ) {
   long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ 
       }
     }
     const FaceBg bg = {p.hyc[k * p.nens + e], p.hytc[k * p.nens + e], p.p0c[k * p.nens + e], p.ihytc[k * p.nens + e]};
-    face_flux<STRICT>(p, cL, eL, cR, eR, p.nens, idU, bg, bg, zero, FX + (long long)k * p.fxK + (long long)j * p.fxJ + ie, p.fxV);
+    face_flux<STRICT, ORD>(p, cL, eL, cR, eR, p.nens, idU, bg, bg, zero, FX + (long long)k * p.fxK + (long long)j * p.fxJ + ie, p.fxV);
   }
   // ---------------- Y face j-1/2
   if (!p.sim2d && i < p.nx && k < p.nz) {
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ 
       }
     }
     const FaceBg bg = {p.hyc[k * p.nens + e], p.hytc[k * p.nens + e], p.p0c[k * p.nens + e], p.ihytc[k * p.nens + e]};
-    face_flux<STRICT>(p, cL, eL, cR, eR, p.sJ, idV, bg, bg, zero, FY + (long long)k * p.fyK + (long long)j * p.fyJ + ie, p.fyV);
+    face_flux<STRICT, ORD>(p, cL, eL, cR, eR, p.sJ, idV, bg, bg, zero, FY + (long long)k * p.fyK + (long long)j * p.fyJ + ie, p.fyV);
   }
   // ---------------- Z face k-1/2 : wall / open edge-value rule at k = 0 and k = nz  (:1020-1038)
   if (i < p.nx && j < p.ny) {
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void k_flux(DyP p, const double *__restrict__ 
     }
     const FaceBg bL = {p.hye[kL * p.nens + e], p.hyte[kL * p.nens + e], p.p0e[kL * p.nens + e], p.ihyte[kL * p.nens + e]};
     const FaceBg bR = {p.hye[kR * p.nens + e], p.hyte[kR * p.nens + e], p.p0e[kR * p.nens + e], p.ihyte[kR * p.nens + e]};
-    face_flux<STRICT>(p, cL, eL, cR, eR, p.sK, idW, bL, bR, zero,
+    face_flux<STRICT, ORD>(p, cL, eL, cR, eR, p.sK, idW, bL, bR, zero,
                       FZ + (long long)k * p.fzK + (long long)j * p.fzJ + (long long)i * p.nens + e, p.fzV);
   }
 }
@@ -570,7 +571,7 @@ namespace mw {
 // (mw_init.cpp part below); the per-cell quadrature + convert_dynamics_to_coupler (:1656) runs here.
 // -----------------------------------------------------------------------------------------------------
 struct InitP {
-  int init_data;
+  int init_data, ord;
   long long i_beg, j_beg;
   double xlen, ylen, cp_d, p0;
   const double *hyDensGLL, *hyDensThetaGLL, *hyDensVapGLL;     // supercell: (nz,5) device
@@ -603,6 +604,10 @@ __constant__ double c_gll5_pts[5] = {-0.50000000000000000000000000000000000000, 
 __constant__ double c_gll5_wts[5] = {0.050000000000000000000000000000000000000, 0.27222222222222222222222222222222222222,
                                      0.35555555555555555555555555555555555556, 0.27222222222222222222222222222222222222,
                                      0.050000000000000000000000000000000000000};     // :659-665
+__constant__ double c_gll3_pts[3] = {-0.50000000000000000000000000000000000000, 0.00000000000000000000000000000000000000,
+                                     0.50000000000000000000000000000000000000};      // TransformMatrices.h:83-88 (MW_ORD = 3)
+__constant__ double c_gll3_wts[3] = {0.16666666666666666666666666666666666667, 0.66666666666666666666666666666666666667,
+                                     0.16666666666666666666666666666666666667};      // :90-95
 __constant__ double c_gll9_pts[9] = {-0.50000000000000000000000000000000000000, -0.44987899770573007865617262220916897903,
                                      -0.33859313975536887672294271354567122536, -0.18155873191308907935537603435432960651,
                                      0.00000000000000000000000000000000000000, 0.18155873191308907935537603435432960651,
@@ -629,21 +634,23 @@ __global__ __launch_bounds__(256) void k_init_cells(DyP p, InitP q, CouplerPtrs 
   long long ci = ((long long)k * p.ny + j) * NXI + ie;
   double sR = 0, sU = 0, sV = 0, sW = 0, sT = 0, sWV = 0;
   const double dx = p.dx, dy = p.dy, dz = p.dz;
-  if (q.init_data == MW_DATA_SUPERCELL) {                     // :1843-1886
-    for (int kk = 0; kk < 5; kk++) for (int jj = 0; jj < 5; jj++) for (int ii = 0; ii < 5; ii++) {
-      double zloc = (k + 0.5) * dz + c_gll5_pts[kk] * dz;
-      double dens = q.hyDensGLL[k * 5 + kk];
+  if (q.init_data == MW_DATA_SUPERCELL) {                     // :1843-1886  (ord GLL points per direction)
+    const int no = q.ord;
+    const double *gp = (no == 3) ? c_gll3_pts : c_gll5_pts, *gw = (no == 3) ? c_gll3_wts : c_gll5_wts;
+    for (int kk = 0; kk < no; kk++) for (int jj = 0; jj < no; jj++) for (int ii = 0; ii < no; ii++) {
+      double zloc = (k + 0.5) * dz + gp[kk] * dz;
+      double dens = q.hyDensGLL[k * no + kk];
       double uvel;
       const double zs = 5000, us = 30, uc = 15;
       if (zloc < zs) uvel = us * (zloc / zs) - uc; else uvel = us - uc;
       double vvel = 0, wvel = 0;
-      double dens_vap = q.hyDensVapGLL[k * 5 + kk], dens_theta = q.hyDensThetaGLL[k * 5 + kk];
-      double factor = c_gll5_wts[ii] * c_gll5_wts[jj] * c_gll5_wts[kk];
-      sR += (dens - q.hyDensGLL[k * 5 + kk]) * factor;
+      double dens_vap = q.hyDensVapGLL[k * no + kk], dens_theta = q.hyDensThetaGLL[k * no + kk];
+      double factor = gw[ii] * gw[jj] * gw[kk];
+      sR += (dens - q.hyDensGLL[k * no + kk]) * factor;
       sU += dens * uvel * factor;
       sV += dens * vvel * factor;
       sW += dens * wvel * factor;
-      sT += (dens_theta - q.hyDensThetaGLL[k * 5 + kk]) * factor;
+      sT += (dens_theta - q.hyDensThetaGLL[k * no + kk]) * factor;
       sWV += dens_vap * factor;
     }
   } else {                                                     // thermal :1361-1392 ; city :1463-1503 ; building :1566-1607
@@ -779,6 +786,7 @@ struct mw_dycore_s {
   std::vector<double> hy_host;               // same packing (the last four are derived in upload_background)
   double etime = 0;
   int strict = 0;
+  int ord = 5;                               // WENO order (3: the reference's -DMW_ORD=3 build; runs on the general kernels)
   // halo exchange
   mw_exchange_fn xchg = nullptr; void *xchg_ctx = nullptr;
   double *bufs[2][8] = {{nullptr}, {nullptr}};   // [group: 0 state (or all), 1 tracers][sW sE sS sN rW rE rS rN]
@@ -917,8 +925,13 @@ static int launch_flux(mw_dycore_s *d, const double *S) {
   const DyP &p = d->p;
   long long per_plane = (long long)(p.sim2d ? p.ny : p.ny + 1) * (p.nx + 1) * p.nens;
   dim3 grid = plane_grid(per_plane, p.nz + 1);
-  if (d->strict == 1) hipLaunchKernelGGL(k_flux<true>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
-  else           hipLaunchKernelGGL(k_flux<false>, grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+  if (d->ord == 3) {
+    if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 3>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    else                hipLaunchKernelGGL((k_flux<false, 3>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+  } else {
+    if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 5>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    else                hipLaunchKernelGGL((k_flux<false, 5>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+  }
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -1281,6 +1294,12 @@ int mw_dycore_set_bc(mw_dycore_t d, int bc_x, int bc_y, int bc_z) {
   return 0;
 }
 int mw_dycore_set_strict(mw_dycore_t d, int strict) { if (!d) MW_FAIL("null handle"); d->strict = strict; return 0; }
+int mw_dycore_set_order(mw_dycore_t d, int ord) {
+  if (!d) MW_FAIL("null handle");
+  if (ord != 3 && ord != 5) MW_FAIL("WENO order must be 3 or 5 (MW_ORD 7 and 9 are not built)");
+  d->ord = ord;
+  return 0;
+}
 
 int mw_dycore_set_background(mw_dycore_t d, const double *hyc, const double *hytc, const double *hye, const double *hyte,
                              const double *immersed_proportion) {
@@ -1374,7 +1393,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
   // production path; strict = 1/2 use the general flux-materialising kernels below.  So does a z-PERIODIC domain (:752-763,
   // :1008-1019; no shipped case): the marching kernels apply the wall / open z rule while loading and have no periodic form.
-  const bool march = (d->strict == 0) && (p.bc_z != MW_BC_PERIODIC);
+  const bool march = (d->strict == 0) && (p.bc_z != MW_BC_PERIODIC) && (d->ord == 5);
   if (march && !getenv("MW_NO_WRAP")) {                       // index wrap instead of halo cells (see DyP::wrap_x)
     d->p.wrap_x = (p.bc_x == MW_BC_PERIODIC) && !(d->xchg && p.nproc_x > 1) && p.nx >= 3;
     d->p.wrap_y = !p.sim2d && (p.bc_y == MW_BC_PERIODIC) && !(d->xchg && p.nproc_y > 1) && p.ny >= 3;
@@ -1556,14 +1575,17 @@ extern "C" int mw_dycore_init(mw_dycore_t d, int init_data, double *rho_d, doubl
   g.bc_x = MW_BC_PERIODIC; g.bc_y = MW_BC_PERIODIC; g.bc_z = MW_BC_WALL;         // :1332-1334, 1340-1342, 1423-1425, 1551-1553
   g.use_immersed = (init_data == MW_DATA_CITY || init_data == MW_DATA_BUILDING); // :1312, 1426, 1554
   d->etime = 0;                                                                  // :1317
-  const int nz = g.nz, nens = g.nens, ord = 5;
+  const int nz = g.nz, nens = g.nens, ord = d->ord;               // `ord` GLL points per cell (:1725-1727)
   const double dz = g.zlen / g.nz, dx = g.xlen / g.nx_glob;
+  const double h_gll3_pts[3] = {-0.50000000000000000000000000000000000000, 0.00000000000000000000000000000000000000, 0.50000000000000000000000000000000000000};   // TransformMatrices.h:83-88
+  const double h_gll3_wts[3] = {0.16666666666666666666666666666666666667, 0.66666666666666666666666666666666666667, 0.16666666666666666666666666666666666667};   // :90-95
+  const double *h_gllN_pts = (ord == 3) ? h_gll3_pts : h_gll5_pts, *h_gllN_wts = (ord == 3) ? h_gll3_wts : h_gll5_wts;
   size_t nzc = (size_t)nz * nens, nze = (size_t)(nz + 1) * nens;
   double *hyc = d->hy_host.data(), *hytc = hyc + nzc, *hye = hyc + 2 * nzc, *hyte = hye + nze;
   std::vector<double> gllcols;     // supercell: hyDensGLL | hyDensThetaGLL | hyDensVapGLL, each (nz,5)
   InitP q;  memset(&q, 0, sizeof(q));
   q.init_data = init_data; q.i_beg = g.i_beg; q.j_beg = g.j_beg; q.xlen = g.xlen; q.ylen = g.ylen; q.cp_d = g.cp_d; q.p0 = g.p0;
-  q.nx_glob = g.nx_glob; q.ny_glob = g.ny_glob;
+  q.nx_glob = g.nx_glob; q.ny_glob = g.ny_glob; q.ord = ord;
   std::vector<double> bheights;
   if (init_data == MW_DATA_SUPERCELL) {                                          // init_supercell, :1687-1840
     const double z_0 = 0, z_trop = 12000, T_0 = 300, T_trop = 213, T_top = 213, p_0 = 100000;
@@ -1573,10 +1595,10 @@ extern "C" int mw_dycore_init(mw_dycore_t d, int init_data, double *rho_d, doubl
     double *hyDensGLL = gllcols.data(), *hyDensThetaGLL = hyDensGLL + (size_t)nz * ord, *hyDensVapGLL = hyDensThetaGLL + (size_t)nz * ord;
     for (int k = 0; k < nz; k++) for (int kk = 0; kk < ord - 1; kk++) for (int kkk = 0; kkk < ord; kkk++) {       // :1736-1756
       double cellmid = (k + 0.5) * dz;
-      double ord_b = cellmid + h_gll5_pts[kk] * dz, ord_t = cellmid + h_gll5_pts[kk + 1] * dz;
+      double ord_b = cellmid + h_gllN_pts[kk] * dz, ord_t = cellmid + h_gllN_pts[kk + 1] * dz;
       double ord_m = 0.5 * (ord_b + ord_t);
-      double ord_dz = dz * (h_gll5_pts[kk + 1] - h_gll5_pts[kk]);
-      double zloc = ord_m + ord_dz * h_gll5_pts[kkk];
+      double ord_dz = dz * (h_gllN_pts[kk + 1] - h_gllN_pts[kk]);
+      double zloc = ord_m + ord_dz * h_gllN_pts[kkk];
       double T = h_supercell_temperature(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top);
       double press_dry = h_supercell_pressure_dry(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top, p_0, R_d, grav);
       double qvs = h_supercell_sat_mix_dry(press_dry, T);
@@ -1588,13 +1610,13 @@ extern "C" int mw_dycore_init(mw_dycore_t d, int init_data, double *rho_d, doubl
     hyP[0] = p_0;                                                                                                   // :1759-1774
     for (int k = 0; k < nz; k++) for (int kk = 0; kk < ord - 1; kk++) {
       double tot = 0;
-      for (int kkk = 0; kkk < ord; kkk++) tot += quad_temp[((size_t)k * (ord - 1) + kk) * ord + kkk] * h_gll5_wts[kkk];
-      tot *= dz * (h_gll5_pts[kk + 1] - h_gll5_pts[kk]);
+      for (int kkk = 0; kkk < ord; kkk++) tot += quad_temp[((size_t)k * (ord - 1) + kk) * ord + kkk] * h_gllN_wts[kkk];
+      tot *= dz * (h_gllN_pts[kk + 1] - h_gllN_pts[kk]);
       hyP[(size_t)k * ord + kk + 1] = hyP[(size_t)k * ord + kk] * exp(tot);
       if (kk == ord - 2 && k < nz - 1) hyP[(size_t)(k + 1) * ord] = hyP[(size_t)k * ord + ord - 1];
     }
     for (int k = 0; k < nz; k++) for (int kk = 0; kk < ord; kk++) {                                               // :1777-1805
-      double zloc = (k + 0.5) * dz + h_gll5_pts[kk] * dz;
+      double zloc = (k + 0.5) * dz + h_gllN_pts[kk] * dz;
       double T = h_supercell_temperature(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top);
       double press_tmp = h_supercell_pressure_dry(zloc, z_0, z_trop, ztop, T_0, T_trop, T_top, p_0, R_d, grav);
       double qvs = h_supercell_sat_mix_dry(press_tmp, T);
@@ -1612,8 +1634,8 @@ extern "C" int mw_dycore_init(mw_dycore_t d, int init_data, double *rho_d, doubl
     }
     for (int k = 0; k < nz; k++) {                                                                                  // :1808-1840
       double dens_tot = 0, dens_theta_tot = 0;
-      for (int kk = 0; kk < ord; kk++) { dens_tot += hyDensGLL[(size_t)k * ord + kk] * h_gll5_wts[kk];
-                                         dens_theta_tot += hyDensThetaGLL[(size_t)k * ord + kk] * h_gll5_wts[kk]; }
+      for (int kk = 0; kk < ord; kk++) { dens_tot += hyDensGLL[(size_t)k * ord + kk] * h_gllN_wts[kk];
+                                         dens_theta_tot += hyDensThetaGLL[(size_t)k * ord + kk] * h_gllN_wts[kk]; }
       for (int e = 0; e < nens; e++) { hyc[(size_t)k * nens + e] = dens_tot; hytc[(size_t)k * nens + e] = dens_theta_tot; }
     }
   } else {

@@ -203,7 +203,12 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
   std::vector<double *> tracer_ptrs;
   double *f_rho = nullptr, *f_u = nullptr, *f_v = nullptr, *f_w = nullptr, *f_T = nullptr;
  public:
-  int static constexpr ord = 5, hs = 2, num_state = 5;
+#ifndef MW_ORD
+  int static constexpr ord = 5;                                       // :24-28 (compile with -DMW_ORD=3 for the reference's order-3 build)
+#else
+  int static constexpr ord = MW_ORD;
+#endif
+  int static constexpr hs = (ord - 1) / 2, num_state = 5;             // :29
   int static constexpr idR = 0, idU = 1, idV = 2, idW = 3, idT = 4;
   real etime = 0, out_freq = -1;  int num_out = 0, idWV = 0;
   std::vector<real> hy_dens_cells, hy_dens_theta_cells, hy_dens_edges, hy_dens_theta_edges;     // (nz[,+1],nens), host copies
@@ -250,6 +255,7 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
     g.enable_gravity = coupler.get_option<bool>("enable_gravity", true);
     g.bc_x = g.bc_y = MW_BC_PERIODIC; g.bc_z = MW_BC_WALL; g.use_immersed = 0;
     mw_check(mw_dycore_create(&h, &g, pos.data(), adds.data(), nullptr));
+    if (ord != 5) mw_check(mw_dycore_set_order(h, ord));                                                        // before init (:1725-1727)
     bind(coupler);
     mw_check(mw_dycore_init(h, init_id, f_rho, f_u, f_v, f_w, f_T, tracer_ptrs.data()));
     mw_check(mw_dycore_get_grid(h, &g));

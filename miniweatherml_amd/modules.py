@@ -32,12 +32,15 @@ def _stream_ptr(device):
 
 
 class Dynamics_Euler_Stratified_WenoFV:
-    ord = 5
+    ord = 5               # the reference's compile-time MW_ORD (:24-29); Dynamics_Euler_Stratified_WenoFV(ord=3) = its -DMW_ORD=3 build
     hs = 2
     num_state = 5
     idR, idU, idV, idW, idT = 0, 1, 2, 3, 4
 
-    def __init__(self):
+    def __init__(self, ord=5):
+        if ord not in (3, 5):
+            endrun("ERROR: WENO order must be 3 or 5")
+        self.ord, self.hs = ord, (ord - 1) // 2
         self.h = C.c_void_p(None)
         self.etime = 0.0
         self._tracer_ptrs = None
@@ -109,6 +112,8 @@ class Dynamics_Euler_Stratified_WenoFV:
         g.bc_x, g.bc_y, g.bc_z, g.use_immersed = capi.BC_PERIODIC, capi.BC_PERIODIC, capi.BC_WALL, 0
         with torch.cuda.device(coupler.device):
             check(L.mw_dycore_create(C.byref(self.h), C.byref(g), pos, adds, _stream_ptr(coupler.device)))
+            if self.ord != 5:
+                check(L.mw_dycore_set_order(self.h, self.ord))              # before init: the supercell data uses `ord` GLL points
             self._bind(coupler)
             check(L.mw_dycore_init(self.h, capi.INIT_IDS[init_data], *[_ptr(t) for t in self._fields], self._tracer_ptrs))
         check(L.mw_dycore_get_grid(self.h, C.byref(g)))
@@ -868,7 +873,7 @@ def use_torch_distributed_exchange(dycore, coupler, group=None, host_staged=Fals
 
 
 def make_supercell(nx_glob, ny_glob, nz, nens=1, xlen=1.0e5, ylen=1.0e5, zlen=2.0e4, init_data="supercell", device="cuda:0",
-                   nranks=1, myrank=0, micro=None, enable_gravity=None, perturb=True, with_nudger=False):
+                   nranks=1, myrank=0, micro=None, enable_gravity=None, perturb=True, with_nudger=False, ord=5):
     """The set-up sequence of experiments/supercell_example/driver.cpp:41-61 (column nudger excluded)."""
     coupler = Coupler(device)
     coupler.set_option("out_prefix", "test")
@@ -879,7 +884,7 @@ def make_supercell(nx_glob, ny_glob, nz, nens=1, xlen=1.0e5, ylen=1.0e5, zlen=2.
     coupler.distribute_mpi_and_allocate_coupled_state(nz, ny_glob, nx_glob, nens, nranks, myrank)
     coupler.set_grid(xlen, ylen, zlen)
     micro = micro or Microphysics_Kessler()
-    dycore = Dynamics_Euler_Stratified_WenoFV()
+    dycore = Dynamics_Euler_Stratified_WenoFV(ord)
     micro.init(coupler)
     dycore.init(coupler)
     if with_nudger:

@@ -38,8 +38,15 @@
 
 typedef double real;
 
-static const int hs  = 2;   // dynamics_euler_stratified_wenofv.h:29  (ord = 5)
-static const int ord = 5;   // :25
+// The reference selects the reconstruction order at COMPILE time (-DMW_ORD=3 in build/machines/aws/aws_a100_gpu.env:21; default 5,
+// dynamics_euler_stratified_wenofv.h:24-28).  So does this restatement: oracle/Makefile builds libmw_oracle.so (ord 5) and
+// libmw_oracle_ord3.so (-DMW_ORD=3).
+#ifndef MW_ORD
+#define MW_ORD 5
+#endif
+static_assert(MW_ORD == 3 || MW_ORD == 5, "restated orders: 3 and 5");
+static const int ord = MW_ORD;          // dynamics_euler_stratified_wenofv.h:24-28
+static const int hs  = (MW_ORD-1)/2;    // :29
 static const int num_state = 5;          // :31
 enum { idR = 0, idU = 1, idV = 2, idW = 3, idT = 4 };       // :34-38
 enum { DATA_THERMAL = 0, DATA_SUPERCELL = 1, DATA_CITY = 2, DATA_BUILDING = 3 };  // :41-44
@@ -118,6 +125,44 @@ static inline void coefs5_shift3(real *c, real v0, real v1, real v2, real v3, re
   c[4]=FP(0.041666666666666666666666666666666666667)*v0-FP(0.16666666666666666666666666666666666667)*v1+FP(0.25000000000000000000000000000000000000)*v2-FP(0.16666666666666666666666666666666666667)*v3+FP(0.041666666666666666666666666666666666667)*v4;
 }
 
+static inline void convexify3(real &w1, real &w2, real &w3) {             // WenoLimiter_recon.h:5-8
+  real tot = w1 + w2 + w3;
+  if (tot > 1.e-20) { w1 /= tot;   w2 /= tot;   w3 /= tot; }
+}
+static inline real TV2(const real *a) { return FP(1.0000000000000000000000000000000000000)*(a[1]*a[1]); }   // WenoLimiter_recon.h:29-34
+static inline void coefs2_shift1(real *c, real v0, real v1) {             // WenoLimiter_recon.h:72-76
+  c[0]=FP(1.0000000000000000000000000000000000000)*v1;
+  c[1]=-FP(1.0000000000000000000000000000000000000)*v0+FP(1.0000000000000000000000000000000000000)*v1;
+}
+static inline void coefs2_shift2(real *c, real v0, real v1) {             // WenoLimiter_recon.h:78-82
+  c[0]=FP(1.0000000000000000000000000000000000000)*v0;
+  c[1]=-FP(1.0000000000000000000000000000000000000)*v0+FP(1.0000000000000000000000000000000000000)*v1;
+}
+struct Weno3 {   // WenoLimiter.h:12-50: default ctor arguments cutoff 0, idl 1,1,5e2, convexified
+  real cutoff, idl_L, idl_R, idl_H;
+  Weno3() { cutoff = 0; idl_L = 1; idl_R = 1; idl_H = 5.e2; convexify3(idl_L, idl_R, idl_H); }
+  void compute_limited_coefs(const real *s, real *coefs_H) const {   // WenoLimiter.h:28-49
+    real coefs_L[2], coefs_R[2];
+    coefs2_shift1( coefs_L , s[0] , s[1] );
+    coefs2_shift2( coefs_R , s[1] , s[2] );
+    coefs3_shift2( coefs_H , s[0] , s[1] , s[2] );
+    real w_L = TV2( coefs_L );
+    real w_R = TV2( coefs_R );
+    real w_H = TV3( coefs_H );
+    convexify3( w_L , w_R , w_H );
+    w_L = idl_L / (w_L*w_L + 1.e-20);
+    w_R = idl_R / (w_R*w_R + 1.e-20);
+    w_H = idl_H / (w_H*w_H + 1.e-20);
+    convexify3( w_L , w_R , w_H );
+    if (w_L <= cutoff) w_L = 0;
+    if (w_R <= cutoff) w_R = 0;
+    convexify3( w_L , w_R , w_H );
+    coefs_H[0] = coefs_H[0]*w_H + coefs_L[0]*w_L + coefs_R[0]*w_R;
+    coefs_H[1] = coefs_H[1]*w_H + coefs_L[1]*w_L + coefs_R[1]*w_R;
+    coefs_H[2] = coefs_H[2]*w_H;
+  }
+};
+
 struct Weno5 {   // WenoLimiter.h:53-66: default ctor arguments cutoff 0, idl 1,2,1,1e3, convexified
   real cutoff, idl_L, idl_C, idl_R, idl_H;
   Weno5() { cutoff = 0; idl_L = 1; idl_C = 2; idl_R = 1; idl_H = 1.e3; convexify4(idl_L, idl_C, idl_R, idl_H); }
@@ -149,6 +194,15 @@ struct Weno5 {   // WenoLimiter.h:53-66: default ctor arguments cutoff 0, idl 1,
   }
 };
 
+#if MW_ORD == 3
+typedef Weno3 WenoLim;
+// TransformMatrices.h:300-308  coefs_to_gll_lower(SArray<FP,2,3,2>);  :83-95  get_gll_points / get_gll_weights (SArray<FP,1,3>)
+static const real coefs_to_gll[3][2] = { {1,1}, {-0.50000000000000000000000000000000000000,0.50000000000000000000000000000000000000},
+                                         {0.25000000000000000000000000000000000000,0.25000000000000000000000000000000000000} };
+static const real gll_pts[3] = { -0.50000000000000000000000000000000000000, 0.00000000000000000000000000000000000000, 0.50000000000000000000000000000000000000 };
+static const real gll_wts[3] = { 0.16666666666666666666666666666666666667, 0.66666666666666666666666666666666666667, 0.16666666666666666666666666666666666667 };
+#else
+typedef Weno5 WenoLim;
 // TransformMatrices.h:1132-1144  coefs_to_gll_lower(SArray<FP,2,5,2>)  (c2g[s][ii])
 static const real coefs_to_gll[5][2] = { {1,1}, {-0.5,0.5}, {0.25,0.25}, {-0.125,0.125}, {0.0625,0.0625} };
 // TransformMatrices.h:650-665  get_gll_points / get_gll_weights (SArray<FP,1,5>) -- plain double literals
@@ -158,6 +212,7 @@ static const real gll_pts[5] = { -0.50000000000000000000000000000000000000, -0.3
 static const real gll_wts[5] = { 0.050000000000000000000000000000000000000, 0.27222222222222222222222222222222222222,
                                  0.35555555555555555555555555555555555556, 0.27222222222222222222222222222222222222,
                                  0.050000000000000000000000000000000000000 };
+#endif
 // TransformMatrices.h:4113-4137  9-point GLL rule (city / building init)
 static const real gll_pts9[9] = { -0.50000000000000000000000000000000000000, -0.44987899770573007865617262220916897903,
   -0.33859313975536887672294271354567122536, -0.18155873191308907935537603435432960651, 0.00000000000000000000000000000000000000,
@@ -169,8 +224,8 @@ static const real gll_wts9[9] = { 0.013888888888888888888888888888888888889, 0.0
    0.013888888888888888888888888888888888889 };
 
 // dynamics_euler_stratified_wenofv.h:556-571
-static inline void reconstruct_gll_values(const real *stencil, real *gll, const Weno5 &limiter) {
-  real wenoCoefs[5];
+static inline void reconstruct_gll_values(const real *stencil, real *gll, const WenoLim &limiter) {
+  real wenoCoefs[ord];
   limiter.compute_limited_coefs( stencil , wenoCoefs );
   for (int ii=0; ii<2; ii++) {
     real tmp = 0;
@@ -535,13 +590,13 @@ static void compute_tendencies(const mwo_dycore *d, real *state, real *state_ten
   real *tracers_limits_y = (real*)malloc(8*nly*(num_tracers>0?num_tracers:1));
   real *tracers_limits_z = (real*)malloc(8*nlz*(num_tracers>0?num_tracers:1));
 
-  Weno5 limiter;    // :267
+  WenoLim limiter;    // :267
 
   // :271-388  [D6]
   for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) for (int iens=0;iens<nens;iens++) {
     // X-direction  :276-305
     for (int l=0; l < num_state; l++) {
-      real stencil[5], gll[2];
+      real stencil[ord], gll[2];
       for (int s=0; s < ord; s++) { stencil[s] = state[D.H(l,hs+k,hs+j,i+s,iens)]; }
       reconstruct_gll_values(stencil,gll,limiter);
       state_limits_x[D.LX(l,1,k,j,i  ,iens)] = gll[0];
@@ -558,7 +613,7 @@ static void compute_tendencies(const mwo_dycore *d, real *state, real *state_ten
     state_limits_x[D.LX(idT,1,k,j,i  ,iens)] += HYTC(k,iens);
     state_limits_x[D.LX(idT,0,k,j,i+1,iens)] += HYTC(k,iens);
     for (int l=0; l < num_tracers; l++) {
-      real stencil[5], gll[2];
+      real stencil[ord], gll[2];
       for (int s=0; s < ord; s++) { stencil[s] = tracers[D.H(l,hs+k,hs+j,i+s,iens)]; }
       reconstruct_gll_values(stencil,gll,limiter);
       tracers_limits_x[D.LX(l,1,k,j,i  ,iens)] = gll[0] * state_limits_x[D.LX(idR,1,k,j,i  ,iens)];
@@ -567,7 +622,7 @@ static void compute_tendencies(const mwo_dycore *d, real *state, real *state_ten
     // Y-direction  :311-352
     if (!sim2d) {
       for (int l=0; l < num_state; l++) {
-        real stencil[5], gll[2];
+        real stencil[ord], gll[2];
         for (int s=0; s < ord; s++) { stencil[s] = state[D.H(l,hs+k,j+s,hs+i,iens)]; }
         reconstruct_gll_values(stencil,gll,limiter);
         state_limits_y[D.LY(l,1,k,j  ,i,iens)] = gll[0];
@@ -584,7 +639,7 @@ static void compute_tendencies(const mwo_dycore *d, real *state, real *state_ten
       state_limits_y[D.LY(idT,1,k,j  ,i,iens)] += HYTC(k,iens);
       state_limits_y[D.LY(idT,0,k,j+1,i,iens)] += HYTC(k,iens);
       for (int l=0; l < num_tracers; l++) {
-        real stencil[5], gll[2];
+        real stencil[ord], gll[2];
         for (int s=0; s < ord; s++) { stencil[s] = tracers[D.H(l,hs+k,j+s,hs+i,iens)]; }
         reconstruct_gll_values(stencil,gll,limiter);
         tracers_limits_y[D.LY(l,1,k,j  ,i,iens)] = gll[0] * state_limits_y[D.LY(idR,1,k,j  ,i,iens)];
@@ -602,7 +657,7 @@ static void compute_tendencies(const mwo_dycore *d, real *state, real *state_ten
     }
     // Z-direction  :358-387
     for (int l=0; l < num_state; l++) {
-      real stencil[5], gll[2];
+      real stencil[ord], gll[2];
       for (int s=0; s < ord; s++) { stencil[s] = state[D.H(l,k+s,hs+j,hs+i,iens)]; }
       reconstruct_gll_values(stencil,gll,limiter);
       state_limits_z[D.LZ(l,1,k  ,j,i,iens)] = gll[0];
@@ -619,7 +674,7 @@ static void compute_tendencies(const mwo_dycore *d, real *state, real *state_ten
     state_limits_z[D.LZ(idT,1,k  ,j,i,iens)] += HYTE(k  ,iens);
     state_limits_z[D.LZ(idT,0,k+1,j,i,iens)] += HYTE(k+1,iens);
     for (int l=0; l < num_tracers; l++) {
-      real stencil[5], gll[2];
+      real stencil[ord], gll[2];
       for (int s=0; s < ord; s++) { stencil[s] = tracers[D.H(l,k+s,hs+j,hs+i,iens)]; }
       reconstruct_gll_values(stencil,gll,limiter);
       tracers_limits_z[D.LZ(l,1,k  ,j,i,iens)] = gll[0] * state_limits_z[D.LZ(idR,1,k  ,j,i,iens)];
@@ -1131,11 +1186,12 @@ static void init_quadrature_case(mwo_dycore *d, int init_data_int, real *state, 
 extern "C" {
 
 // ---- WENO unit entry (tests) -------------------------------------------------------------------------
-void mwo_weno5(const double *stencil, double *limited_coefs, double *gll) {
-  Weno5 lim;
+void mwo_weno5(const double *stencil, double *limited_coefs, double *gll) {      // the build's order: `ord` stencil values and coefficients
+  WenoLim lim;
   lim.compute_limited_coefs(stencil, limited_coefs);
   reconstruct_gll_values(stencil, gll, lim);
 }
+int mwo_order(void) { return ord; }
 void mwo_weno5_ideal_weights(double *w4) { Weno5 l; w4[0]=l.idl_L; w4[1]=l.idl_C; w4[2]=l.idl_R; w4[3]=l.idl_H; }
 
 // C0 as dycore.init computes it   :1247

@@ -9,7 +9,29 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmw_oracle.so")
+# The reconstruction order is a COMPILE-time choice in the reference (-DMW_ORD) and in this restatement: libmw_oracle.so is the
+# ord-5 build; `with_order(3)` returns a second instance of this module bound to libmw_oracle_ord3.so.
+_LIB_PATH = os.path.join(_HERE, globals().get("_MW_ORACLE_LIB_NAME", "libmw_oracle.so"))
+
+
+def with_order(order):
+    """This module bound to the oracle build of the given WENO order (3 or 5)."""
+    import importlib.util
+    import sys
+    if order == 5:
+        return sys.modules[__name__]
+    if order != 3:
+        raise ValueError("oracle builds exist for WENO orders 3 and 5")
+    name = __name__ + "_ord3"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.abspath(__file__))
+    mod = importlib.util.module_from_spec(spec)
+    mod._MW_ORACLE_LIB_NAME = "libmw_oracle_ord3.so"
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    assert mod.lib().mwo_order() == 3
+    return mod
 
 DATA_THERMAL, DATA_SUPERCELL, DATA_CITY, DATA_BUILDING = 0, 1, 2, 3
 BC_PERIODIC, BC_OPEN, BC_WALL = 0, 1, 2
@@ -43,8 +65,9 @@ _lib = None
 
 def build(force=False):
     """Compile oracle/libmw_oracle.so with the committed Makefile (g++, seconds)."""
-    if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "mw_oracle.cpp")):
+    src = os.path.join(_HERE, "mw_oracle.cpp")
+    libs = [os.path.join(_HERE, n) for n in ("libmw_oracle.so", "libmw_oracle_ord3.so")]
+    if force or any(not os.path.exists(l) or os.path.getmtime(l) < os.path.getmtime(src) for l in libs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
@@ -57,6 +80,7 @@ def lib():
     L = C.CDLL(_LIB_PATH)
     dp = C.POINTER(C.c_double)
     L.mwo_weno5.argtypes = [dp, dp, dp]
+    L.mwo_order.restype = C.c_int
     L.mwo_weno5_ideal_weights.argtypes = [dp]
     L.mwo_compute_C0.restype = C.c_double
     L.mwo_compute_C0.argtypes = [C.c_double] * 4
@@ -238,8 +262,8 @@ def perturb_temperature(p, temp):
 
 
 def weno5(stencil):
-    s = np.ascontiguousarray(stencil, dtype=np.float64)
-    coefs = np.zeros(5)
+    s = np.ascontiguousarray(stencil, dtype=np.float64)          # `ord` values (the bound build's order)
+    coefs = np.zeros(lib().mwo_order())
     gll = np.zeros(2)
     lib().mwo_weno5(_dp(s), _dp(coefs), _dp(gll))
     return coefs, gll

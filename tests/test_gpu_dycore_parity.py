@@ -368,3 +368,55 @@ def test_non_default_gamma_uses_the_generic_pressure(mw, oracle):
         dycore.time_step(coupler, dt)
         odyc.time_step(of, dt)
         compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11 if step == 0 else 1e-10, "cp_d = 1010, step %d" % (step + 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# WENO order 3: the reference's -DMW_ORD=3 build (the only order its GPU benchmark environment compiles,
+# build/machines/aws/aws_a100_gpu.env:21).  Oracle = the same restatement compiled with -DMW_ORD=3 (WenoLimiter<3>, hs = 1,
+# 3-point GLL initial data); device = mw_dycore_set_order(h, 3) -> general kernels with weno3_edges_*.
+# ---------------------------------------------------------------------------------------------------------------------
+ORD3_CASES = {
+    "supercell3d_16x16x8": (16, 16, 8, 1, 16000., 16000., 20000., "supercell", 3, True),
+    "supercell2d_64x1x32": (64, 1, 32, 1, 100000., 100000., 20000., "supercell", 3, True),
+    "supercell3d_nens2_12x10x8": (12, 10, 8, 2, 6000., 5000., 20000., "supercell", 3, True),
+    "city_48x48x12_nograv": (48, 48, 12, 1, 2400., 2400., 120., "city", 1, False),
+}
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("name", sorted(ORD3_CASES))
+def test_weno_order_3(mw, oracle, name, mode):
+    from miniweatherml_amd import modules
+    O3 = oracle.with_order(3)
+    nx, ny, nz, nens, xlen, ylen, zlen, init, nt, grav = ORD3_CASES[name]
+    micro = None
+    if nt == 1:
+        class OneTracer(modules.Microphysics_Kessler):
+            def init(self, coupler):
+                coupler.add_tracer("water_vapor", "Water Vapor", True, True)
+        micro = OneTracer()
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, zlen, init, micro=micro, enable_gravity=grav,
+                                                perturb=(init == "supercell"), ord=3)
+    odyc, of = O3.supercell_setup(nx, ny, nz, nens, xlen, ylen, zlen, init_data=init, num_tracers=nt, enable_gravity=grav,
+                                  perturb=(init == "supercell"))
+    assert dycore.ord == 3 and dycore.hs == 1
+    hy = odyc.hy()
+    for k in ("hy_dens_cells", "hy_dens_theta_cells", "hy_dens_edges", "hy_dens_theta_edges"):
+        assert np.array_equal(getattr(dycore, k), hy[k]), k          # `ord`-point GLL columns on the host: bitwise
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-13, "ord3 init " + name)
+    push_fields(coupler, of)
+    dycore.set_strict(mode)
+    dt = dycore.compute_time_step(coupler)
+    dycore.time_step(coupler, dt)
+    odyc.time_step(of, dt)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "ord3 %s mode %d, 1 step" % (name, mode))
+    for _ in range(9):
+        dycore.time_step(coupler, dt)
+        odyc.time_step(of, dt)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-9, "ord3 %s mode %d, 10 steps" % (name, mode))
+    # and it is not the order-5 scheme
+    o5, f5 = oracle.supercell_setup(nx, ny, nz, nens, xlen, ylen, zlen, init_data=init, num_tracers=nt, enable_gravity=grav,
+                                    perturb=(init == "supercell"))
+    for _ in range(10):
+        o5.time_step(f5, dt)
+    assert np.max(np.abs(f5.uvel - of.uvel)) > 1e-6

@@ -100,3 +100,20 @@ def test_fp_literals_are_double_rounding_safe():
         pytest.skip("no 80-bit long double on this host")
     for l in lits:
         assert float(np.longdouble(l)) == float(l), l
+
+
+def test_weno3_limiter_properties(oracle):
+    """WenoLimiter<3> of the -DMW_ORD=3 oracle build: ideal weights (1, 1, 500)/502, exact for polynomials of degree <= 1 ... the
+    high-order candidate reproduces a parabola's edge values when the data are smooth, and a step keeps the edges between the
+    neighbouring cell values."""
+    import numpy as np
+    O3 = oracle.with_order(3)
+    assert O3.lib().mwo_order() == 3 and oracle.lib().mwo_order() == 5
+    coefs, gll = O3.weno5(np.array([2.0, 2.0, 2.0]))
+    assert np.allclose(coefs, [2.0, 0.0, 0.0]) and np.allclose(gll, [2.0, 2.0])
+    # cell averages of a straight line: the edge values are exact
+    coefs, gll = O3.weno5(np.array([1.0, 2.0, 3.0]))
+    assert np.allclose(gll, [1.5, 2.5], atol=1e-12)
+    # a step: no new extrema
+    coefs, gll = O3.weno5(np.array([0.0, 0.0, 1.0]))
+    assert -1e-12 <= gll[0] <= 1.0 and -1e-12 <= gll[1] <= 1.0
