@@ -1669,4 +1669,102 @@ void mwo_mlp_forward(long long ncells, const double *temp, const double *rho_d, 
   }
 }
 
+
+// =====================================================================================================================
+// Surrogate data workflow: StatisticsGatherer and DataGenerator of
+// experiments/supercell_kessler_surrogate/custom_modules/{gather_micro_statistics,generate_micro_surrogate_data}.h
+// Fields are the (nz,ny,nx,nens) coupler arrays; only member 0 takes part, like the reference (index (k,j,i,0)).
+// =====================================================================================================================
+// StatisticsGatherer::is_active   gather_micro_statistics.h:61-74
+static inline bool micro_is_active(real temp_in, real temp_out, real rho_v_in, real rho_v_out, real rho_c_in, real rho_c_out,
+                                   real rho_p_in, real rho_p_out) {
+  real tol = 1.e-10;
+  real temp_diff  = std::abs( temp_out  - temp_in  );
+  real rho_v_diff = std::abs( rho_v_out - rho_v_in );
+  real rho_c_diff = std::abs( rho_c_out - rho_c_in );
+  real rho_p_diff = std::abs( rho_p_out - rho_p_in );
+  if (temp_diff > tol || rho_v_diff > tol || rho_c_diff > tol || rho_p_diff > tol) {  return true;  }
+  return false;
+}
+// gather_micro_statistics   :19-58: active(k,j,i) and its sum (numer += sum, denom += size).  in4 / out4 = temp, water_vapor,
+// cloud_liquid, precip_liquid before / after the microphysics.
+long long mwo_micro_active(int nz, int ny, int nx, int nens, const double *const *in4, const double *const *out4, int *active) {
+  long long sum = 0;
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) {
+    size_t c = ((((size_t)k*ny+j)*nx+i)*nens);
+    int a = micro_is_active( in4[0][c] , out4[0][c] , in4[1][c] , out4[1][c] , in4[2][c] , out4[2][c] , in4[3][c] , out4[3][c] ) ? 1 : 0;
+    if (active) active[((size_t)k*ny+j)*nx+i] = a;
+    sum += a;
+  }
+  return sum;
+}
+// generate_samples_stencil   generate_micro_surrogate_data.h:47-62: the two sampling thresholds
+void mwo_micro_sample_thresholds(int nz, int ny, int nx, int nranks, double desired_samples_per_time_step, double *active_threshold,
+                                 double *inactive_threshold) {
+  double ratio_active = 0.4;
+  double expected_num_active   =    ratio_active  * nx*ny*nz;
+  double expected_num_inactive = (1-ratio_active) * nx*ny*nz;
+  double desired_ratio_active = 0.5;
+  double desired_samples_active   =    desired_ratio_active  * desired_samples_per_time_step / nranks;
+  double desired_samples_inactive = (1-desired_ratio_active) * desired_samples_per_time_step / nranks;
+  *active_threshold   = desired_samples_active   / expected_num_active;
+  *inactive_threshold = desired_samples_inactive / expected_num_inactive;
+}
+// The reference draws yakl::Random(key).genFP<double>() (:95); yakl::Random lives in the ABSENT YAKL submodule (version unpinned), so
+// this draw is PINNED BY DEFINITION, not by the reference: the same key through the splitmix64 finaliser, top 53 bits -> [0,1).
+static inline double micro_u01_from_key(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+// :83-101  do_sample(k,j,i); key = (seed+myrank)*nz*ny*nx + k*ny*nx + j*nx + i  (key0 = (seed+myrank)*nz*ny*nx from the caller)
+long long mwo_micro_sample_mask(int nz, int ny, int nx, int nens, const double *const *in4, const double *const *out4,
+                                unsigned long long key0, double active_threshold, double inactive_threshold, int *do_sample) {
+  long long n = 0;
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) {
+    size_t c = ((((size_t)k*ny+j)*nx+i)*nens);
+    double thresh;
+    if ( micro_is_active( in4[0][c] , out4[0][c] , in4[1][c] , out4[1][c] , in4[2][c] , out4[2][c] , in4[3][c] , out4[3][c] ) ) {
+      thresh = active_threshold;
+    } else {
+      thresh = inactive_threshold;
+    }
+    double rand_num = micro_u01_from_key( key0 + (unsigned long long)k*ny*nx + (unsigned long long)j*nx + (unsigned long long)i );
+    do_sample[((size_t)k*ny+j)*nx+i] = (rand_num < thresh) ? 1 : 0;
+    n += do_sample[((size_t)k*ny+j)*nx+i];
+  }
+  return n;
+}
+// :135-158  the samples in the reference's (k,j,i) loop order: gen_input(5,2) [variable][stencil slot] and gen_output(4), 32-bit.
+// Slot 1 holds level min(nz-1,k+1) of temp, rho_v, rho_c, rho_p in rows 0..3 (:147-150, the reference's own row assignment);
+// gen_input(4,1) is never assigned by the reference (uninitialised host memory) and is written as 0 here.
+long long mwo_micro_gather_samples(int nz, int ny, int nx, int nens, const double *rho_d, const double *const *in4,
+                                   const double *const *out4, const int *do_sample, float *inputs, float *outputs) {
+  long long ul = 0;
+  for (int k=0;k<nz;k++) for (int j=0;j<ny;j++) for (int i=0;i<nx;i++) {
+    if (!do_sample[((size_t)k*ny+j)*nx+i]) continue;
+    size_t c  = ((((size_t)k*ny+j)*nx+i)*nens);
+    size_t cu = ((((size_t)std::min(nz-1,k+1)*ny+j)*nx+i)*nens);
+    float *gi = inputs + ul*10, *go = outputs + ul*4;
+    gi[0*2+0] = (float) in4[0][c];   // temp_in
+    gi[1*2+0] = (float) rho_d[c];
+    gi[2*2+0] = (float) in4[1][c];   // rho_v_in
+    gi[3*2+0] = (float) in4[2][c];   // rho_c_in
+    gi[4*2+0] = (float) in4[3][c];   // rho_p_in
+    gi[0*2+1] = (float) in4[0][cu];
+    gi[1*2+1] = (float) in4[1][cu];
+    gi[2*2+1] = (float) in4[2][cu];
+    gi[3*2+1] = (float) in4[3][cu];
+    gi[4*2+1] = 0.f;
+    go[0] = (float) out4[0][c];
+    go[1] = (float) out4[1][c];
+    go[2] = (float) out4[2][c];
+    go[3] = (float) out4[3][c];
+    ul++;
+  }
+  return ul;
+}
+
 } // extern "C"

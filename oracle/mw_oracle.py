@@ -114,6 +114,14 @@ def lib():
     L.mwo_nudge_to_column.argtypes = [C.POINTER(Params), pdp, dp, C.c_double, ALLREDUCE_FN, C.c_void_p]
     L.mwo_horizontal_sponge_apply.argtypes = [C.POINTER(Params), pdp, dp, C.c_int, C.c_double, C.c_double] + [C.c_int] * 4
     L.mwo_time_average_accumulate.argtypes = [C.POINTER(Params), pdp, pdp, C.c_double, C.c_double]
+    ip = C.POINTER(C.c_int)
+    L.mwo_micro_active.restype = C.c_longlong
+    L.mwo_micro_active.argtypes = [C.c_int] * 4 + [pdp, pdp, ip]
+    L.mwo_micro_sample_thresholds.argtypes = [C.c_int] * 4 + [C.c_double, dp, dp]
+    L.mwo_micro_sample_mask.restype = C.c_longlong
+    L.mwo_micro_sample_mask.argtypes = [C.c_int] * 4 + [pdp, pdp, C.c_ulonglong, C.c_double, C.c_double, ip]
+    L.mwo_micro_gather_samples.restype = C.c_longlong
+    L.mwo_micro_gather_samples.argtypes = [C.c_int] * 4 + [dp, pdp, pdp, ip, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     fp = C.POINTER(C.c_float)
     L.mwo_mlp_forward.argtypes = [C.c_longlong, dp, dp, dp, dp, dp, fp, fp, fp, fp, dp, dp, dp, dp, dp, dp]
     _lib = L
@@ -289,6 +297,34 @@ def mlp_forward(temp, rho_d, rho_v, rho_c, rho_r, W1, b1, W2, b2, scl_in, scl_ou
     lib().mwo_mlp_forward(n, _dp(temp), _dp(rho_d), _dp(rho_v), _dp(rho_c), _dp(rho_r), _fp(W1), _fp(b1), _fp(W2), _fp(b2),
                           _dp(scl_in), _dp(scl_out), *[_dp(o) for o in outs])
     return outs
+
+
+def micro_active(in4, out4):
+    """StatisticsGatherer: (count, active mask (nz,ny,nx)) from the four fields before / after the microphysics (nz,ny,nx,nens)."""
+    nz, ny, nx, nens = in4[0].shape
+    act = np.zeros((nz, ny, nx), dtype=np.int32)
+    n = lib().mwo_micro_active(nz, ny, nx, nens, _ptr_array(in4), _ptr_array(out4), act.ctypes.data_as(C.POINTER(C.c_int)))
+    return int(n), act
+
+
+def micro_sample_thresholds(nz, ny, nx, nranks, desired_samples_per_time_step=50.0):
+    a, b = C.c_double(), C.c_double()
+    lib().mwo_micro_sample_thresholds(nz, ny, nx, nranks, float(desired_samples_per_time_step), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def micro_samples(rho_d, in4, out4, key0, thr_active, thr_inactive):
+    """DataGenerator: (do_sample mask (nz,ny,nx), inputs (n,5,2) float32, outputs (n,4) float32) in the reference's loop order."""
+    nz, ny, nx, nens = in4[0].shape
+    mask = np.zeros((nz, ny, nx), dtype=np.int32)
+    ip = C.POINTER(C.c_int)
+    n = lib().mwo_micro_sample_mask(nz, ny, nx, nens, _ptr_array(in4), _ptr_array(out4), C.c_ulonglong(key0 % 2 ** 64), thr_active,
+                                    thr_inactive, mask.ctypes.data_as(ip))
+    ins, outs = np.zeros((max(n, 1), 5, 2), dtype=np.float32), np.zeros((max(n, 1), 4), dtype=np.float32)
+    m = lib().mwo_micro_gather_samples(nz, ny, nx, nens, _dp(rho_d), _ptr_array(in4), _ptr_array(out4), mask.ctypes.data_as(ip),
+                                       ins.ctypes.data_as(C.POINTER(C.c_float)), outs.ctypes.data_as(C.POINTER(C.c_float)))
+    assert m == n
+    return mask, ins[:n], outs[:n]
 
 
 def _ptr_array(arrs):
