@@ -175,6 +175,10 @@ int  mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *
                           const double *rho_d, double *temp, double *precl, void *workspace, int *rainsplit_out,
                           void *stream);
 
+/* mean(a - b) over n DEVICE doubles -- the surrogate module's "Relative diff" prints, microphysics_kessler_ponni.h:266-269
+ * (yakl::intrinsics::sum(a - b) / size there).  Deterministic order.  workspace1024: DEVICE scratch of 1024 doubles; mean_out: HOST. */
+int  mw_mean_diff(long long n, const double *a, const double *b, double *workspace1024, double *mean_out, void *stream);
+
 /* Diagnostic (no reference counterpart): the Kessler module's own log (fn 0), exp (1), sqrt (2) and reciprocal (3) -- short
  * forms for positive finite arguments, see mw_kessler.hip -- on n caller-supplied DEVICE doubles. */
 int  mw_kessler_math_probe(long long n, const double *x, double *y, int fn, void *stream);

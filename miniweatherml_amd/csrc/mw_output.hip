@@ -8,6 +8,7 @@
 // =====================================================================================================
 #include "../../include/mw_cdna4.h"
 #include "mw_common.h"
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -124,6 +125,30 @@ __global__ __launch_bounds__(256) void k_gather_samples(const double *__restrict
   for (int v = 0; v < 4; v++) out[v] = (float)f.a[4 + v][c * nens];
 }
 
+// mean(a - b) over n doubles, deterministic: 1024 workgroups each sum a fixed, interleaved share in a fixed order; one workgroup
+// then adds the 1024 partial sums as a fixed tree (the "Relative diff" prints of the surrogate module, microphysics_kessler_ponni.h:266-269,
+// are yakl::intrinsics::sum(a - b) / size in the reference).
+__global__ __launch_bounds__(256) void k_diff_partial(long long n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ part) {
+#pragma clang fp contract(off)
+  double s = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += a[i] - b[i];
+  __shared__ double sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+__global__ __launch_bounds__(256) void k_diff_final(double *__restrict__ part, int np) {
+#pragma clang fp contract(off)
+  __shared__ double sm[256];
+  double s = 0;
+  for (int i = threadIdx.x; i < np; i += 256) s += part[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w]; __syncthreads(); }
+  if (threadIdx.x == 0) part[0] = sm[0];
+}
+
 } // namespace mw
 
 using namespace mw;
@@ -230,6 +255,20 @@ int mw_micro_gather_samples(const mw_grid_t *g, const double *rho_d, const doubl
   hipLaunchKernelGGL(k_gather_samples, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rho_d, f, cells, n, g->nz,
                      (long long)g->ny * g->nx, g->nens, inputs, outputs);
   MW_LAUNCH_CHECK();
+  return 0;
+}
+
+int mw_mean_diff(long long n, const double *a, const double *b, double *workspace1024, double *mean_out, void *stream) {
+  if (n < 1 || !a || !b || !workspace1024 || !mean_out) MW_FAIL("mean_diff: bad argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)std::min<long long>(1024, (n + 255) / 256);
+  hipLaunchKernelGGL(k_diff_partial, dim3((unsigned)nb), dim3(256), 0, st, n, a, b, workspace1024); MW_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_diff_final, dim3(1), dim3(256), 0, st, workspace1024, nb); MW_LAUNCH_CHECK();
+  double sum = 0;
+  MW_HIP(hipMemcpyAsync(&sum, workspace1024, sizeof(double), hipMemcpyDeviceToHost, st));
+  MW_HIP(hipStreamSynchronize(st));
+  *mean_out = sum / (double)n;
   return 0;
 }
 

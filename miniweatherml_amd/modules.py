@@ -297,8 +297,16 @@ class Microphysics_Kessler_Surrogate(Microphysics_Kessler):
         """The four 'Relative diff' prints (:266-269): mean(NN - Kessler)."""
         dm = coupler.get_data_manager_readonly()
         t, v, c, r = self._nn_out
-        return dict(rho_v=float((v - dm.get("water_vapor", True)).mean()), rho_c=float((c - dm.get("cloud_liquid", True)).mean()),
-                    rho_r=float((r - dm.get("precip_liquid", True)).mean()), temp=float((t - dm.get("temp", True)).mean()))
+        if getattr(self, "_ws_mean", None) is None:
+            self._ws_mean = torch.empty(1024, dtype=torch.float64, device=coupler.device)
+        out = {}
+        with torch.cuda.device(coupler.device):
+            for key, nn, name in (("rho_v", v, "water_vapor"), ("rho_c", c, "cloud_liquid"), ("rho_r", r, "precip_liquid"), ("temp", t, "temp")):
+                m = C.c_double(0.0)
+                check(capi.lib().mw_mean_diff(nn.numel(), _ptr(nn), _ptr(dm.get(name, True)), _ptr(self._ws_mean), C.byref(m),
+                                              _stream_ptr(coupler.device)))
+                out[key] = m.value
+        return out
 
 
 def perturb_temperature(coupler, thermal=True, random=False):                   # perturb_temperature.h:8-67

@@ -126,8 +126,12 @@ def test_surrogate_module_runs_beside_kessler(mw, oracle):
     precl = np.zeros((16, 16, 1))
     oracle.kessler_time_step(coupler.get_dz(), dt, f.tracers[0], f.tracers[1], f.tracers[2], f.rho_d, f.temp, precl)
     compare_fields(gpu_fields(coupler), f.as_dict(), 1e-12, "surrogate module leaves Kessler result in the coupler")
-    d = micro.mean_diffs(coupler)
+    d = micro.mean_diffs(coupler)                                # the "Relative diff" prints (:266-269): mean(NN - Kessler), on the device
     assert set(d) == {"rho_v", "rho_c", "rho_r", "temp"} and all(np.isfinite(v) for v in d.values())
+    g = gpu_fields(coupler)
+    for key, x, name in (("temp", nn[0], "temp"), ("rho_v", nn[1], "tracer0"), ("rho_c", nn[2], "tracer1"), ("rho_r", nn[3], "tracer2")):
+        ref = float(np.mean(x.cpu().numpy() - g[name]))
+        assert abs(d[key] - ref) <= 1e-12 * max(abs(ref), float(np.max(np.abs(g[name]))))
     assert len(nn) == 4
 
 
