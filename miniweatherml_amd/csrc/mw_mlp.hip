@@ -16,6 +16,7 @@
 // =====================================================================================================
 #include "../../include/mw_cdna4.h"
 #include "mw_common.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace mw {
@@ -84,6 +85,61 @@ __global__ __launch_bounds__(256) void k_mlp(MlpP P, long long ncells, const dou
   }
 }
 
+// The same with 16-byte accesses: a lane owns the cell PAIR (2c, 2c+1) of a 32-cell span, loaded / stored as one double2 -- every
+// lane group then moves 256 contiguous bytes per instruction and the wave issues half as many memory instructions.  The even
+// cells of the span form one MFMA tile, the odd cells the next (a tile is any 16 cells).  ncells must be a multiple of 32 here;
+// the launcher hands the remainder to k_mlp.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <int PAIRS>
+__global__ __launch_bounds__(256) void k_mlp_x2(MlpP P, long long ncells, const double *__restrict__ temp,
+                                                const double *__restrict__ rho_d, const double *__restrict__ rho_v,
+                                                const double *__restrict__ rho_c, const double *__restrict__ rho_r,
+                                                double *__restrict__ o_temp, double *__restrict__ o_rv,
+                                                double *__restrict__ o_rc, double *__restrict__ o_rr) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, cidx = lane & 15;
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * 256) >> 6;
+  const double *in_g = (g == 0) ? temp : (g == 1) ? rho_d : (g == 2) ? rho_v : rho_c;
+  double *out_g = (g == 0) ? o_temp : (g == 1) ? o_rv : (g == 2) ? o_rc : o_rr;
+  const double imin = P.in_min[g], irng = 1.0 / P.in_rng[g], imin4 = P.in_min[4], irng4 = 1.0 / P.in_rng[4];
+  const double omin = P.out_min[g], orng = P.out_rng[g];
+  const float a10 = P.a1[0][lane], a11 = P.a1[1][lane];
+  const float a20 = P.a2[0][lane], a21 = P.a2[1][lane], a22 = P.a2[2][lane];
+  const f32x4 c1 = {P.c1[g][0], P.c1[g][1], P.c1[g][2], P.c1[g][3]};
+  const f32x4 c2 = {P.c2[g], 0.f, 0.f, 0.f};
+  const long long nspans = ncells / 32;
+  for (long long s0 = wave * PAIRS; s0 < nspans; s0 += nwaves * PAIRS) {
+    f64x2 xin[PAIRS], xin4[PAIRS];
+#pragma unroll
+    for (int u = 0; u < PAIRS; u++) {
+      const long long cell = min(s0 + u, nspans - 1) * 32 + 2 * cidx;          // (clamped: the tail spans are recomputed, not stored)
+      xin[u] = *(const f64x2 *)(in_g + cell);
+      xin4[u] = (g == 0) ? *(const f64x2 *)(rho_r + cell) : (f64x2){imin4, imin4};
+    }
+#pragma unroll
+    for (int u = 0; u < PAIRS; u++) {
+      f64x2 y2;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        float b0 = (float)((xin[u][h] - imin) * irng);                    // :182-186 (fp64 math, stored as float)
+        float b1 = (g == 0) ? (float)((xin4[u][h] - imin4) * irng4) : 0.f;
+        f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10, b0, c1, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11, b1, d1, 0, 0, 0);
+        float h0 = leaky(d1[0]), h1 = leaky(d1[1]), h2 = leaky(d1[2]);    // Relu(negative_slope = 0.1), :105
+        f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a20, h0, c2, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a21, h1, d2, 0, 0, 0);
+        d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a22, h2, d2, 0, 0, 0);
+        double y = (double)d2[0] * orng + omin;                           // :198-201
+        if (g != 0) y = fmax(0.0, y);
+        y2[h] = y;
+      }
+      if (s0 + u < nspans) *(f64x2 *)(out_g + (s0 + u) * 32 + 2 * cidx) = y2;
+    }
+  }
+}
+
 } // namespace mw
 
 using namespace mw;
@@ -118,14 +174,31 @@ extern "C" int mw_mlp_forward(long long ncells, const double *temp, const double
   }
   for (int i = 0; i < 5; i++) { P.in_min[i] = scl_in[i * 2 + 0]; P.in_rng[i] = scl_in[i * 2 + 1] - scl_in[i * 2 + 0]; }
   for (int i = 0; i < 4; i++) { P.out_min[i] = scl_out[i * 2 + 0]; P.out_rng[i] = scl_out[i * 2 + 1] - scl_out[i * 2 + 0]; }
-  constexpr int TILES = 4;
-  long long ntiles = (ncells + 15) / 16;
-  long long waves_needed = (ntiles + TILES - 1) / TILES;
-  long long blocks = (waves_needed + 3) / 4;
-  if (blocks > 256 * 16) blocks = 256 * 16;                     // grid-stride beyond 16 blocks per CU
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_mlp<TILES>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, ncells, temp, rho_d, rho_v, rho_c,
-                     rho_r, temp_out, rho_v_out, rho_c_out, rho_r_out);
-  MW_LAUNCH_CHECK();
+  constexpr int TILES = 4, PAIRS = 2;
+  // bulk: spans of 32 cells with 16-byte accesses (needs 16-byte aligned arrays); remainder (and unaligned callers): k_mlp
+  bool aligned = true;
+  for (const void *q : {(const void *)temp, (const void *)rho_d, (const void *)rho_v, (const void *)rho_c, (const void *)rho_r, (const void *)temp_out,
+                        (const void *)rho_v_out, (const void *)rho_c_out, (const void *)rho_r_out}) aligned = aligned && (((size_t)q & 15) == 0);
+  static const bool x2 = !(getenv("MW_MLP_X2") && getenv("MW_MLP_X2")[0] == '0');
+  const long long bulk = (aligned && x2) ? (ncells / 32) * 32 : 0;
+  if (bulk > 0) {
+    long long waves_needed = (bulk / 32 + PAIRS - 1) / PAIRS;
+    long long blocks = (waves_needed + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;                   // grid-stride beyond 16 blocks per CU
+    hipLaunchKernelGGL(k_mlp_x2<PAIRS>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, bulk, temp, rho_d, rho_v, rho_c,
+                       rho_r, temp_out, rho_v_out, rho_c_out, rho_r_out);
+    MW_LAUNCH_CHECK();
+  }
+  const long long rest = ncells - bulk;
+  if (rest > 0) {
+    long long ntiles = (rest + 15) / 16;
+    long long waves_needed = (ntiles + TILES - 1) / TILES;
+    long long blocks = (waves_needed + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_mlp<TILES>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, P, rest, temp + bulk, rho_d + bulk, rho_v + bulk,
+                       rho_c + bulk, rho_r + bulk, temp_out + bulk, rho_v_out + bulk, rho_c_out + bulk, rho_r_out + bulk);
+    MW_LAUNCH_CHECK();
+  }
   return 0;
 }
