@@ -38,6 +38,7 @@ struct DyP {                      // kernel parameter block (by value)
   long long fxJ, fxK, fxV, fyJ, fyK, fyV, fzJ, fzK, fzV;   // flux strides
   int sim2d, bc_x, bc_y, bc_z, px, py, nproc_x, nproc_y;
   int v0;                         // halo/pack kernels: index of the first variable of the group being processed
+  int cst, ce;                    // coupler-side stride / member offset (1, 0; member-major mode: nens, member) -- see cpl() in mw_march.h
   int wrap_x, wrap_y;             // production path, periodic direction owned by one rank: the marching kernels wrap their x / row index
                                   // instead of reading halo cells, and that halo is not filled
   int enable_gravity, use_immersed, idWV;
@@ -748,6 +749,17 @@ __global__ __launch_bounds__(256) void k_weno5_edges(const double *__restrict__ 
   out[t * 2] = l; out[t * 2 + 1] = r;
 }
 
+// member-major slab (nens, V, nz+2HZ, ny+2HY, nx+2HX) -> the fused layout (V, nz+2HZ, ny+2HY, (nx+2HX)*nens), halos included.
+// p = the FUSED parameter block.  Used when the public flux arrays are rebuilt from a stage input of the production path.
+__global__ __launch_bounds__(256) void k_member_to_fused(DyP p, const double *__restrict__ src, double *__restrict__ dst) {
+  const long long n = (long long)p.V * p.sV;                  // fused elements
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int e = (int)(t % p.nens);
+  const long long r = t / p.nens;                             // (v, k, j, i) with the member-major strides
+  dst[t] = src[(long long)e * (n / p.nens) + r];
+}
+
 __global__ __launch_bounds__(256) void k_calib_copy(const double *__restrict__ in, double *__restrict__ out, long long n) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = in[i];
@@ -786,6 +798,7 @@ struct mw_dycore_s {
   std::vector<double> hy_host;               // same packing (the last four are derived in upload_background)
   double etime = 0;
   int strict = 0;
+  int member_major = 0;                      // production path with nens > 1: the handle's arrays hold one member after the other (View)
   int ord = 5;                               // WENO order (3: the reference's -DMW_ORD=3 build; runs on the general kernels)
   // halo exchange
   mw_exchange_fn xchg = nullptr; void *xchg_ctx = nullptr;
@@ -818,7 +831,7 @@ static void fill_params(mw_dycore_s *d) {
   p.fxJ = (long long)(g.nx + 1) * g.nens; p.fxK = (long long)g.ny * p.fxJ;       p.fxV = (long long)g.nz * p.fxK;
   p.fyJ = (long long)g.nx * g.nens;       p.fyK = (long long)(g.ny + 1) * p.fyJ; p.fyV = (long long)g.nz * p.fyK;
   p.fzJ = (long long)g.nx * g.nens;       p.fzK = (long long)g.ny * p.fzJ;       p.fzV = (long long)(g.nz + 1) * p.fzK;
-  p.v0 = 0; p.wrap_x = 0; p.wrap_y = 0;
+  p.v0 = 0; p.wrap_x = 0; p.wrap_y = 0; p.cst = 1; p.ce = 0;
   p.bc_x = g.bc_x; p.bc_y = g.bc_y; p.bc_z = g.bc_z; p.px = g.px; p.py = g.py; p.nproc_x = g.nproc_x; p.nproc_y = g.nproc_y;
   p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
   p.pos_mask = 0; p.mass_mask = 0;
@@ -859,6 +872,16 @@ static int upload_background(mw_dycore_s *d) {
     double *pk = h + 4 * nzc + 4 * nze;                      // packed rows
     const double *src[8] = {h, h + nzc, ext, ext + nzc, h + 2 * nzc, h + 2 * nzc + nze, ext + 2 * nzc, ext + 2 * nzc + nze};
     for (size_t n = 0; n < nze; n++) for (int f = 0; f < 8; f++) pk[n * 8 + f] = (f < 4 && n >= nzc) ? 0.0 : src[f][n];
+    // member-major copies (View): member e's columns contiguous, so that the nens = 1 kernels index them with k alone
+    double *mm = pk + 8 * nze;
+    const size_t per = 4 * (size_t)g.nz + 8 * (size_t)(g.nz + 1);
+    for (int e = 0; e < g.nens; e++) {
+      double *m = mm + (size_t)e * per;
+      for (int k = 0; k < g.nz; k++) { const size_t n = (size_t)k * g.nens + e;
+        m[k] = h[n]; m[g.nz + k] = hytc[n]; m[2 * g.nz + k] = ext[n]; m[3 * g.nz + k] = ext[nzc + n]; }
+      double *mpk = m + 4 * g.nz;
+      for (int k = 0; k <= g.nz; k++) for (int f = 0; f < 8; f++) mpk[(size_t)k * 8 + f] = pk[((size_t)k * g.nens + e) * 8 + f];
+    }
   }
   MW_HIP(hipMemcpyAsync(d->hy_dev, d->hy_host.data(), d->hy_host.size() * sizeof(double), hipMemcpyHostToDevice, d->stream));
   MW_HIP(hipStreamSynchronize(d->stream));
@@ -878,6 +901,45 @@ struct ProfScope {
   ~ProfScope() { if (on) (void)hipEventRecord(d->ev[which][idx].second, st); }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Member-major mode (production path, nens > 1).  With the coupler's member-fastest layout the x stencil of a wave cannot use
+// the DPP lane shifts (x neighbours are nens lanes apart) and the marching kernels fall back to neighbour loads + ds_bpermute:
+// k_xz_state is 36 % slower per cell at nens = 4.  The handle's INTERNAL arrays (slabs, tendY, M/UP, FY, side arrays, flags) are
+// ours to lay out, so with nens > 1 they hold one member after the other and every production kernel is launched once per member
+// in its nens = 1 form (View: the member's parameter block and base pointers); only the coupler-side accesses -- conversion in,
+// D13 out, immersed proportion -- are strided (DyP::cst / ce, cpl() in mw_march.h).  The general kernels keep the fused layout in
+// the same allocations (a handle runs one path or the other within a time_step; get_fluxes transposes the retained stage input).
+// ---------------------------------------------------------------------------------------------------------------------
+struct View {
+  DyP p;
+  long long slab, tend, m[3], f[3], cells;          // member e's offsets = e * these (doubles; UP / flags: bytes = the same counts)
+  int e;
+  template <class T> T *S(T *base) const { return base ? base + e * slab : base; }
+};
+static int n_views(const mw_dycore_s *d) { return d->member_major ? d->p.nens : 1; }
+static View view(const mw_dycore_s *d, int e) {
+  View v; v.e = e; v.p = d->p;
+  v.slab = v.tend = v.cells = 0; for (int a = 0; a < 3; a++) v.m[a] = v.f[a] = 0;
+  if (!d->member_major) { v.e = 0; return v; }
+  DyP &q = v.p;
+  const int n = d->p.nens;
+  q.nens = 1; q.cst = n; q.ce = e;
+  q.NXE = q.nx + 2 * q.HX;
+  q.sJ = q.NXE; q.sK = (long long)(q.ny + 2 * q.HY) * q.sJ; q.sV = (long long)(q.nz + 2 * q.HZ) * q.sK;
+  q.nC = (long long)q.nz * q.ny * q.nx;
+  q.fxJ = q.nx + 1; q.fxK = (long long)q.ny * q.fxJ;       q.fxV = (long long)q.nz * q.fxK;
+  q.fyJ = q.nx;     q.fyK = (long long)(q.ny + 1) * q.fyJ; q.fyV = (long long)q.nz * q.fyK;
+  q.fzJ = q.nx;     q.fzK = (long long)q.ny * q.fzJ;       q.fzV = (long long)(q.nz + 1) * q.fzK;
+  const size_t nzc = (size_t)q.nz * n, nze = (size_t)(q.nz + 1) * n, per = 4 * (size_t)q.nz + 8 * (size_t)(q.nz + 1);
+  const double *m = d->hy_dev + 4 * nzc + 4 * nze + 8 * nze + (size_t)e * per;
+  q.hyc = m; q.hytc = m + q.nz; q.p0c = m + 2 * q.nz; q.ihytc = m + 3 * q.nz; q.hypk = m + 4 * q.nz;
+  q.hye = q.hyte = q.p0e = q.ihyte = nullptr;              // (edge tables: only through hypk on this path)
+  v.slab = (long long)q.V * q.sV; v.tend = 5 * q.nC; v.cells = q.nC;
+  v.m[0] = q.fxV; v.m[1] = q.fyV; v.m[2] = q.fzV;
+  v.f[0] = (long long)q.V * q.fxV; v.f[1] = (long long)q.V * q.fyV; v.f[2] = (long long)q.V * q.fzV;
+  return v;
+}
+
 // halo fill of variables [v0, v0+nv) of one slab: neighbour exchange (or self wrap) in x/y, then BCs -- replaces
 // halo_exchange (:574-827).  `grp` selects the pack-buffer set (0: state or all variables, 1: tracers).
 static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hipStream_t st = nullptr, int grp = 0, bool skip_z = false) {
@@ -885,38 +947,54 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
   if (nv < 0) nv = d->p.V;
   if (nv == 0) return 0;
   ProfScope ps(d, 3, st);
-  DyP q = d->p;
-  q.v0 = v0; q.V = nv;
-  double *S = Sbase + (long long)v0 * q.sV;
-  const DyP &p = q;
-  bool ex_x = d->xchg && (p.nproc_x > 1), ex_y = d->xchg && (p.nproc_y > 1) && !p.sim2d;
-  long long nWE = d->nWE1 * nv, nSN = d->nSN1 * nv;
+  // skip_z = production path; with a member-major handle the slab holds one member after the other: every kernel below runs once
+  // per member on its nens = 1 view, and the strips of member e sit at e * (strip size / nens) in the exchange buffers
+  const int nv_views = (skip_z && d->member_major) ? d->p.nens : 1;
+  const DyP &pf = d->p;
+  bool ex_x = d->xchg && (pf.nproc_x > 1), ex_y = d->xchg && (pf.nproc_y > 1) && !pf.sim2d;
+  long long nWE = d->nWE1 * nv, nSN = d->nSN1 * nv;              // all members
+  const long long mWE = nWE / nv_views, mSN = nSN / nv_views;    // one view
   double **bf = d->bufs[grp];
+  auto member = [&](int e, DyP &q, double *&S) {
+    View v; if (nv_views > 1) v = view(d, e); else { v.p = d->p; v.e = 0; v.slab = 0; }
+    q = v.p; q.v0 = v0; q.V = nv;
+    S = Sbase + e * v.slab + (long long)v0 * q.sV;
+  };
   if (ex_x || ex_y) {
     // a rank grid with more than one rank in a direction: ship 3-cell strips to the face neighbours.
     // Directions with a single rank still wrap locally below.
-    if (ex_x) { hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((nWE + 255) / 256)), dim3(256), 0, st, p, S, bf[0], bf[1]); MW_LAUNCH_CHECK(); }
-    if (ex_y) { hipLaunchKernelGGL(k_pack_y, dim3((unsigned)((nSN + 255) / 256)), dim3(256), 0, st, p, S, bf[2], bf[3]); MW_LAUNCH_CHECK(); }
+    for (int e = 0; e < nv_views; e++) {
+      DyP q; double *S; member(e, q, S);
+      if (ex_x) { hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((mWE + 255) / 256)), dim3(256), 0, st, q, S, bf[0] + e * mWE, bf[1] + e * mWE); MW_LAUNCH_CHECK(); }
+      if (ex_y) { hipLaunchKernelGGL(k_pack_y, dim3((unsigned)((mSN + 255) / 256)), dim3(256), 0, st, q, S, bf[2] + e * mSN, bf[3] + e * mSN); MW_LAUNCH_CHECK(); }
+    }
     int rc = d->xchg(d->xchg_ctx, ex_x ? bf[0] : nullptr, ex_x ? bf[1] : nullptr, ex_y ? bf[2] : nullptr, ex_y ? bf[3] : nullptr,
                      ex_x ? bf[4] : nullptr, ex_x ? bf[5] : nullptr, ex_y ? bf[6] : nullptr, ex_y ? bf[7] : nullptr, ex_x ? nWE : 0,
                      ex_y ? nSN : 0, st);
     if (rc) MW_FAIL("halo exchange callback failed");
-    if (ex_x) { hipLaunchKernelGGL(k_unpack_x, dim3((unsigned)((nWE + 255) / 256)), dim3(256), 0, st, p, S, bf[4], bf[5]); MW_LAUNCH_CHECK(); }
-    if (ex_y) { hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((nSN + 255) / 256)), dim3(256), 0, st, p, S, bf[6], bf[7]); MW_LAUNCH_CHECK(); }
+    for (int e = 0; e < nv_views; e++) {
+      DyP q; double *S; member(e, q, S);
+      if (ex_x) { hipLaunchKernelGGL(k_unpack_x, dim3((unsigned)((mWE + 255) / 256)), dim3(256), 0, st, q, S, bf[4] + e * mWE, bf[5] + e * mWE); MW_LAUNCH_CHECK(); }
+      if (ex_y) { hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((mSN + 255) / 256)), dim3(256), 0, st, q, S, bf[6] + e * mSN, bf[7] + e * mSN); MW_LAUNCH_CHECK(); }
+    }
   }
   // local wrap / BC:  x when this direction has one rank (periodic self-wrap), or a wall / open boundary on a domain-edge rank.
   // With several ranks in a non-periodic direction the edge ranks have just exchanged with their periodic-wrap neighbour like
   // the reference does (:641-723 uses the periodic neighbour matrix) and the boundary rule then OVERWRITES that halo
   // (:782-825: `px == 0` west side, `px == nproc_x-1` east side; the kernel skips the sides that are rank-interior).
-  const bool edge_x = (p.px == 0 || p.px == p.nproc_x - 1), edge_y = (p.py == 0 || p.py == p.nproc_y - 1);
-  const bool bcx_after = ex_x && p.bc_x != MW_BC_PERIODIC && edge_x, bcy_after = ex_y && p.bc_y != MW_BC_PERIODIC && edge_y;
-  const long long nx_ = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens;
-  const long long ny_ = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
-  const long long nz_ = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
-  const unsigned nbx = ((ex_x && !bcx_after) || (skip_z && p.wrap_x)) ? 0u : (unsigned)((nx_ + 255) / 256);      // skip_z = production path
-  const unsigned nby = ((ex_y && !bcy_after) || p.sim2d || (skip_z && p.wrap_y)) ? 0u : (unsigned)((ny_ + 255) / 256);
-  const unsigned nbz = skip_z ? 0u : (unsigned)((nz_ + 255) / 256);      // (the marching kernels apply the z rule while loading)
-  if (nbx + nby + nbz) { hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + nbz), dim3(256), 0, st, p, S, nbx, nby); MW_LAUNCH_CHECK(); }
+  for (int e = 0; e < nv_views; e++) {
+    DyP q; double *S; member(e, q, S);
+    const DyP &p = q;
+    const bool edge_x = (p.px == 0 || p.px == p.nproc_x - 1), edge_y = (p.py == 0 || p.py == p.nproc_y - 1);
+    const bool bcx_after = ex_x && p.bc_x != MW_BC_PERIODIC && edge_x, bcy_after = ex_y && p.bc_y != MW_BC_PERIODIC && edge_y;
+    const long long nx_ = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens;
+    const long long ny_ = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
+    const long long nz_ = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
+    const unsigned nbx = ((ex_x && !bcx_after) || (skip_z && p.wrap_x)) ? 0u : (unsigned)((nx_ + 255) / 256);      // skip_z = production path
+    const unsigned nby = ((ex_y && !bcy_after) || p.sim2d || (skip_z && p.wrap_y)) ? 0u : (unsigned)((ny_ + 255) / 256);
+    const unsigned nbz = skip_z ? 0u : (unsigned)((nz_ + 255) / 256);      // (the marching kernels apply the z rule while loading)
+    if (nbx + nby + nbz) { hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + nbz), dim3(256), 0, st, p, S, nbx, nby); MW_LAUNCH_CHECK(); }
+  }
   return 0;
 }
 
@@ -972,44 +1050,51 @@ static int balanced_chunk(int nz, long long base_waves, const char *env, long lo
 
 // conv != nullptr: the slab S is still empty -- the kernel converts the coupler's fields on the way and fills it (k_y_state<true>)
 static int launch_y_state(mw_dycore_s *d, const double *S, int par, const CouplerPtrs *conv = nullptr) {
-  const DyP &p = d->p;
-  if (p.sim2d) return 0;
+  if (d->p.sim2d) return 0;
   ProfScope ps(d, 5);
-  long long threads = (long long)p.nz * p.nx * p.nens;
-  // measured on 400x400x100 (625 wave columns): 8 x 50 rows for k_y_state, 14 x 29 for k_y_tracers (-5 % / -2 % vs. 32-row chunks)
-  int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000));
-  dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
-  if (conv) hipLaunchKernelGGL((k_y_state<true>), grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv,
-                               const_cast<double *>(S));
-  else      hipLaunchKernelGGL((k_y_state<false>), grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk,
-                               CouplerPtrs(), nullptr);
-  MW_LAUNCH_CHECK();
-  return 0;
-}
-
-static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_t st) {
-  const DyP &p = d->p;
-  if (p.sim2d) return 0;
-  ProfScope ps(d, 6, st);
-  long long threads = (long long)p.nz * p.nx * p.nens;
-  int chunk = d->chunk_yt ? d->chunk_yt : (d->chunk_yt = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_YT", 8400));
-  dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
-  for (int t0 = 0; t0 < p.nt; t0 += 4) {
-    int cnt = std::min(4, p.nt - t0);
-    const double *M = d->M[par][1]; const unsigned char *U = d->UP[par][1];
-    switch (cnt) {
-      case 1: hipLaunchKernelGGL((k_y_tracers<1>), grid, dim3(256), 0, st, p, S, d->FY, M, U, chunk, t0); break;
-      case 2: hipLaunchKernelGGL((k_y_tracers<2>), grid, dim3(256), 0, st, p, S, d->FY, M, U, chunk, t0); break;
-      case 3: hipLaunchKernelGGL((k_y_tracers<3>), grid, dim3(256), 0, st, p, S, d->FY, M, U, chunk, t0); break;
-      default: hipLaunchKernelGGL((k_y_tracers<4>), grid, dim3(256), 0, st, p, S, d->FY, M, U, chunk, t0); break;
-    }
+  for (int e = 0; e < n_views(d); e++) {
+    const View v = view(d, e);
+    const DyP &p = v.p;
+    long long threads = (long long)p.nz * p.nx * p.nens;
+    // measured on 400x400x100 (625 wave columns): 8 x 50 rows for k_y_state, 14 x 29 for k_y_tracers (-5 % / -2 % vs. 32-row chunks)
+    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000));
+    dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
+    double *MY = d->M[par][1] + e * v.m[1]; unsigned char *UY = d->UP[par][1] + e * v.m[1];
+    if (conv) hipLaunchKernelGGL((k_y_state<true>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, *conv,
+                                 const_cast<double *>(v.S(S)));
+    else      hipLaunchKernelGGL((k_y_state<false>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk,
+                                 CouplerPtrs(), nullptr);
     MW_LAUNCH_CHECK();
   }
   return 0;
 }
 
-static int xz_grid(mw_dycore_s *d, dim3 &grid, int &chunk, int &tiles_x) {
-  const DyP &p = d->p;
+static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_t st) {
+  if (d->p.sim2d) return 0;
+  ProfScope ps(d, 6, st);
+  for (int e = 0; e < n_views(d); e++) {
+    const View v = view(d, e);
+    const DyP &p = v.p;
+    long long threads = (long long)p.nz * p.nx * p.nens;
+    int chunk = d->chunk_yt ? d->chunk_yt : (d->chunk_yt = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_YT", 8400));
+    dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
+    double *FY = d->FY + e * v.f[1];
+    for (int t0 = 0; t0 < p.nt; t0 += 4) {
+      int cnt = std::min(4, p.nt - t0);
+      const double *M = d->M[par][1] + e * v.m[1]; const unsigned char *U = d->UP[par][1] + e * v.m[1];
+      switch (cnt) {
+        case 1: hipLaunchKernelGGL((k_y_tracers<1>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); break;
+        case 2: hipLaunchKernelGGL((k_y_tracers<2>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); break;
+        case 3: hipLaunchKernelGGL((k_y_tracers<3>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); break;
+        default: hipLaunchKernelGGL((k_y_tracers<4>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); break;
+      }
+      MW_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+static int xz_grid(mw_dycore_s *d, const DyP &p, dim3 &grid, int &chunk, int &tiles_x) {
   int U = xz_cells_per_wave(p.nens);
   if (U < 4) MW_FAIL("nens too large for the 64-lane x tiling (need nens <= 30)");
   tiles_x = (p.nx * p.nens + U - 1) / U;
@@ -1027,16 +1112,22 @@ static int xz_grid(mw_dycore_s *d, dim3 &grid, int &chunk, int &tiles_x) {
 template <int STAGE, int MODE>
 static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn, int par,
                            const CouplerPtrs &c) {
-  const DyP &p = d->p;
   ProfScope ps(d, 0);
-  dim3 grid; int chunk, tiles_x;
-  if (xz_grid(d, grid, chunk, tiles_x)) return 1;
-  // nens == 1: the per-level background values come through LDS (k_xz_state<.., HPL = 1>; dynamic LDS = the chunk's rows)
-  if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true, MODE, 1>), grid, dim3(256), (size_t)(chunk + 2) * 64, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
-                                      d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);
-  else             hipLaunchKernelGGL((k_xz_state<STAGE, false, MODE>), grid, dim3(256), 0, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2],
-                                      d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);
-  MW_LAUNCH_CHECK();
+  for (int e = 0; e < n_views(d); e++) {
+    const View v = view(d, e);
+    const DyP &p = v.p;
+    dim3 grid; int chunk, tiles_x;
+    if (xz_grid(d, p, grid, chunk, tiles_x)) return 1;
+    double *MX = d->M[par][0] + e * v.m[0], *MZ = d->M[par][2] + e * v.m[2], *tY = d->tendY + e * v.tend;
+    unsigned char *UX = d->UP[par][0] + e * v.m[0], *UZ = d->UP[par][2] + e * v.m[2];
+    // nens == 1 (also: one member of a member-major handle): the per-level background values come through LDS
+    // (k_xz_state<.., HPL = 1>; dynamic LDS = the chunk's rows)
+    if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true, MODE, 1>), grid, dim3(256), (size_t)(chunk + 2) * 64, d->stream, p, v.S(S), v.S(Sn), v.S(Sout),
+                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);
+    else             hipLaunchKernelGGL((k_xz_state<STAGE, false, MODE>), grid, dim3(256), 0, d->stream, p, v.S(S), v.S(Sn), v.S(Sout),
+                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);
+    MW_LAUNCH_CHECK();
+  }
   return 0;
 }
 
@@ -1052,7 +1143,7 @@ static int launch_xz_tracers(mw_dycore_s *d, const double *S, int par, double dt
   const DyP &p = d->p;
   ProfScope ps(d, 7, st);
   dim3 grid; int chunk, tiles_x;
-  if (xz_grid(d, grid, chunk, tiles_x)) return 1;
+  if (xz_grid(d, p, grid, chunk, tiles_x)) return 1;
   const int rows4 = p.ny >= 4 ? 1 : 0;                         // block = 4 rows of one x tile (shares the FY rows)
   if (rows4) grid.x = (unsigned)(((p.ny + 3) / 4) * tiles_x);
   for (int t0 = 0; t0 < p.nt; t0 += 4) {
@@ -1085,36 +1176,48 @@ static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const doubl
 }
 
 template <int STAGE, int MODE, int T, bool N1>
-static void launch_tracers_fused_t(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
+static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
-  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1>), grid, dim3(256), 0, st, d->p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2],
-                     d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4);
+  const int e = v.e;
+  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1>), grid, dim3(256), 0, st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
+                     d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
+                     d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4);
 }
 // x/z tracer fluxes + FCT + update in one kernel, then the (normally empty) y-face correction
 template <int STAGE, int MODE>
 static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, int par, double dt, double dt_dyn,
                                 const CouplerPtrs &c, hipStream_t st) {
-  const DyP &p = d->p;
   {
     ProfScope ps(d, 7, st);
-    const int U = p.nens == 1 ? 58 : 64 - 4 * p.nens;   // 3 / 2 halo cells per side (k_tracers_fused)
-    const int tiles_x = (p.nx * p.nens + U - 1) / U;
-    const int rows4 = p.ny >= 4 ? 1 : 0;
-    const long long waves = (long long)p.ny * tiles_x;
-    const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F"));
-    dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
+    for (int e = 0; e < n_views(d); e++) {
+      const View v = view(d, e);
+      const DyP &p = v.p;
+      const int U = p.nens == 1 ? 58 : 64 - 4 * p.nens;   // 3 / 2 halo cells per side (k_tracers_fused)
+      const int tiles_x = (p.nx * p.nens + U - 1) / U;
+      const int rows4 = p.ny >= 4 ? 1 : 0;
+      const long long waves = (long long)p.ny * tiles_x;
+      const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F"));
+      dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
 #define MW_FUSED_CASE(TT) \
-    case TT: if (p.nens == 1) launch_tracers_fused_t<STAGE, MODE, TT, true>(d, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); \
-             else             launch_tracers_fused_t<STAGE, MODE, TT, false>(d, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); break;
-    switch (p.nt) { MW_FUSED_CASE(1) MW_FUSED_CASE(2) MW_FUSED_CASE(3) MW_FUSED_CASE(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
+      case TT: if (p.nens == 1) launch_tracers_fused_t<STAGE, MODE, TT, true>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); \
+               else             launch_tracers_fused_t<STAGE, MODE, TT, false>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); break;
+      switch (p.nt) { MW_FUSED_CASE(1) MW_FUSED_CASE(2) MW_FUSED_CASE(3) MW_FUSED_CASE(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
 #undef MW_FUSED_CASE
-    MW_LAUNCH_CHECK();
+      MW_LAUNCH_CHECK();
+    }
   }
+  const DyP &p = d->p;
   if (!p.sim2d && p.pos_mask && !getenv("MW_DEBUG_NO_PATCH")) {   // (the switch exists for the negative control in tests/)
     ProfScope ps(d, 1, st);
-    hipLaunchKernelGGL((k_tracer_patch<STAGE, MODE>), plane_grid((long long)p.ny * p.nx * p.nens, (p.nz + MW_PATCH_LEVELS - 1) / MW_PATCH_LEVELS), dim3(256), 0, st, p, Sout, d->flags,
-                       d->FX, d->FZ, dt_dyn, c, d->dirty + (d->fused_launches & 1), d->dirty + ((d->fused_launches + 1) & 1));
-    MW_LAUNCH_CHECK();
+    for (int e = 0; e < n_views(d); e++) {
+      const View v = view(d, e);
+      const DyP &q = v.p;
+      // (member-major: every member's launch reads the same `dirty` word; only the last one may clear the next stage's word)
+      unsigned int *next = (e == n_views(d) - 1) ? d->dirty + ((d->fused_launches + 1) & 1) : d->dirty + 2;
+      hipLaunchKernelGGL((k_tracer_patch<STAGE, MODE>), plane_grid((long long)q.ny * q.nx * q.nens, (q.nz + MW_PATCH_LEVELS - 1) / MW_PATCH_LEVELS), dim3(256), 0, st, q,
+                         v.S(Sout), d->flags + e * v.cells, d->FX + e * v.f[0], d->FZ + e * v.f[2], dt_dyn, c, d->dirty + (d->fused_launches & 1), next);
+      MW_LAUNCH_CHECK();
+    }
   } else if (!p.sim2d && p.pos_mask) {                          // (negative-control switch) nobody else clears the next word
     (void)hipMemsetAsync(d->dirty + ((d->fused_launches + 1) & 1), 0, sizeof(unsigned int), st);
   }
@@ -1166,8 +1269,17 @@ static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, 
   const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
   if (rk_stage_march<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;                        // stage 1 (:119-132)
   if (rk_stage_march<2, 0>(d, Q[1], Q[0], Q[2], dt2, dt_dyn, c)) return 1;                           // stage 2 (:136-153)
-  if (last) { if (rk_stage_march<3, 1>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }             // stage 3 (:157-174) + :178
-  else      { if (rk_stage_march<3, 0>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }
+  if (last && !d->member_major) { if (rk_stage_march<3, 1>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }   // stage 3 (:157-174) + :178
+  else                          { if (rk_stage_march<3, 0>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }
+  if (last && d->member_major) {                              // D13 (:178) as one coalesced pass over the result slab
+    hipStream_t ts = d->overlap ? d->tstream : d->stream;     // the tracer pipeline finishes the stage
+    ProfScope ps(d, 4, ts);
+    const View v = view(d, 0);
+    const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
+    hipLaunchKernelGGL(k_member_to_coupler, plane_grid((long long)d->p.ny * d->p.nx * d->p.nens, d->p.nz), dim3(256), 0, ts, d->p, Q[3], c, ms);
+    MW_LAUNCH_CHECK();
+    if (d->overlap) MW_HIP(hipEventRecord(d->ev_tr[(d->gstage - 1) & 7], ts));     // the step's join waits for this event
+  }
   d->flux_src = Q[2]; d->flux_dt = dt3;
   return 0;
 }
@@ -1216,7 +1328,8 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
   const char *s = getenv("MW_STRICT");
   d->strict = (s && s[0] == '1');
   size_t nzc = (size_t)g->nz * g->nens, nze = (size_t)(g->nz + 1) * g->nens;
-  d->hy_host.assign(4 * nzc + 4 * nze + 8 * nze, 0.0);
+  // fused tables (hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows), then per member: hyc | hytc | p0c | ihytc | packed rows
+  d->hy_host.assign(4 * nzc + 4 * nze + 8 * nze + (size_t)g->nens * (4 * (size_t)g->nz + 8 * (size_t)(g->nz + 1)), 0.0);
   auto fail = [&](void) { mw_dycore_destroy(d); return 1; };
   if (hipMalloc(&d->hy_dev, d->hy_host.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(hy) failed"); return fail(); }
   fill_params(d);
@@ -1228,10 +1341,10 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
       hipMalloc(&d->tendY, (size_t)5 * p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->FX, fxb) != hipSuccess ||
       hipMalloc(&d->FY, fyb) != hipSuccess || hipMalloc(&d->FZ, fzb) != hipSuccess ||
       hipMalloc(&d->imm, (size_t)p.nC * sizeof(double)) != hipSuccess || hipMalloc(&d->flags, (size_t)p.nC) != hipSuccess ||
-      hipMalloc(&d->dirty, 2 * sizeof(unsigned int)) != hipSuccess) {
+      hipMalloc(&d->dirty, 4 * sizeof(unsigned int)) != hipSuccess) {
     set_error("hipMalloc(workspace) failed"); return fail(); }
   (void)hipMemsetAsync(d->flags, 0, (size_t)p.nC, d->stream);
-  (void)hipMemsetAsync(d->dirty, 0, 2 * sizeof(unsigned int), d->stream);
+  (void)hipMemsetAsync(d->dirty, 0, 4 * sizeof(unsigned int), d->stream);
   { const char *f = getenv("MW_FUSED_TRACERS");
     d->fused = (g->num_tracers <= 4 && g->nens <= 12 && !(f && f[0] == '0')) ? 1 : 0; }
   // zero everything once: halo corners are never written and the flux arrays start at 0 (:1677-1682)
@@ -1326,6 +1439,12 @@ int mw_dycore_get_background(mw_dycore_t d, double *hyc, double *hytc, double *h
 int mw_dycore_get_fluxes(mw_dycore_t d, double **out6) {
   if (!d || !out6) MW_FAIL("null argument");
   if (d->flux_src) {     // production path: the state-variable fluxes of the last stage were never written; rebuild all six
+    if (d->member_major) {   // the retained stage input is member-major: bring it into the fused layout the general kernels read (S1 is free)
+      const long long n = (long long)d->p.V * d->p.sV;
+      hipLaunchKernelGGL(k_member_to_fused, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, d->p, d->flux_src, d->S1);
+      MW_LAUNCH_CHECK();
+      d->flux_src = d->S1;
+    }
     { // the marching kernels apply the z boundary rule (and, in a periodic direction owned by one rank, the wrap) while
       // loading and leave those halos of the slab unfilled: fill them for k_flux
       DyP p = d->p; p.v0 = 0;
@@ -1406,12 +1525,18 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     bool want = ov ? (atoi(ov) != 0) : (d->xchg != nullptr);
     if (getenv("MW_NO_OVERLAP")) want = false;
     d->overlap = march && d->tstream && want; }
+  // nens > 1 on the production path: member-major internal layout (see View)
+  d->member_major = march && d->fused && p.nens > 1 && !getenv("MW_NO_MEMBER_MAJOR");
   // D1 + D2 (:101, :248-255).  Production path on one stream with periodic x and y owned by this rank: done inside the first
   // k_y_state (no separate pass); otherwise a conversion kernel first (the reference's operation order on the general path).
-  d->conv_pending = march && !d->overlap && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT");
+  d->conv_pending = march && !d->member_major && !d->overlap && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT");
   if (!d->conv_pending) {
     ProfScope ps(d, 4);
-    if (march && p.nt <= 4) hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
+    if (d->member_major) {      // one coalesced pass in the coupler's order (see k_coupler_to_member)
+      const View v = view(d, 0);
+      const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
+      hipLaunchKernelGGL(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms);
+    } else if (march && p.nt <= 4) hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
     else       hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
     MW_LAUNCH_CHECK();
   }
