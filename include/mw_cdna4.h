@@ -175,6 +175,12 @@ int  mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *
                           const double *rho_d, double *temp, double *precl, void *workspace, int *rainsplit_out,
                           void *stream);
 
+/* ponni::load_h5_weights<N>(file, group, dataset), microphysics_kessler_ponni.h:103-107: one 32-bit float dataset of an HDF5 file
+ * (the Keras weight file `keras_weights_h5`: "/dense_6/dense_6" "kernel:0" (5,10), "bias:0" (10), "/dense_7/dense_7" ...), read by a
+ * dependency-free HOST reader (old-style groups, contiguous / compact little-endian float data; anything else is refused).
+ * out == NULL: shape query.  dims: up to 8 extents, ndims: rank.  capacity: number of floats `out` holds. */
+int  mw_h5_read_f32(const char *file, const char *group, const char *dataset, float *out, long long capacity, long long *dims, int *ndims);
+
 /* mean(a - b) over n DEVICE doubles -- the surrogate module's "Relative diff" prints, microphysics_kessler_ponni.h:266-269
  * (yakl::intrinsics::sum(a - b) / size there).  Deterministic order.  workspace1024: DEVICE scratch of 1024 doubles; mean_out: HOST. */
 int  mw_mean_diff(long long n, const double *a, const double *b, double *workspace1024, double *mean_out, void *stream);

@@ -13,8 +13,9 @@ generate_micro_data   experiments/supercell_kessler_surrogate/generate_micro_dat
 
 The YAML keys are the reference's (sim_time, nens, nx_glob, ny_glob, nz, xlen, ylen, zlen, dt_phys, out_prefix, init_data,
 out_freq, enable_gravity, file_per_process; keras_weights_h5 / nn_input_scaling / nn_output_scaling for the surrogate).  The
-Keras HDF5 file cannot be read here (no HDF5 library): `keras_weights_txt` names its text export (tools/export_mlp_weights.sh);
-without it the export of the reference's shipped weights (miniweatherml_amd/data/) is used.
+Keras HDF5 file named by `keras_weights_h5` is read by the library's own reader (mw_h5.cpp = ponni::load_h5_weights); a text export
+(`keras_weights_txt`, tools/export_mlp_weights.sh) is accepted too; without either, the reference's shipped weight file
+(miniweatherml_amd/data/) is used.
 """
 import argparse
 import os
@@ -135,7 +136,8 @@ def run(experiment, yaml_path, max_steps=None, device="cuda:0", quiet=False):
 
             def rel(p):
                 return p if p is None or os.path.isabs(p) else os.path.normpath(os.path.join(os.getcwd(), p))
-            kw = dict(weights_txt=rel(cfg.get("keras_weights_txt")))
+            h5 = rel(cfg.get("keras_weights_h5"))
+            kw = dict(weights_txt=rel(cfg.get("keras_weights_txt")), weights_h5=h5 if h5 and os.path.exists(h5) else None)
             for k_yaml, k_arg in (("nn_input_scaling", "in_scaling_txt"), ("nn_output_scaling", "out_scaling_txt")):
                 p = rel(cfg.get(k_yaml))
                 kw[k_arg] = p if p and os.path.exists(p) else None             # else: the shipped tables

@@ -242,13 +242,38 @@ class Microphysics_Kessler:
         return rs.value if return_rainsplit else None
 
 
-def load_surrogate_weights(weights_txt=None, in_scaling_txt=None, out_scaling_txt=None):
-    """The shipped Keras weights (exported to text by tools/export_mlp_weights.sh) + min/max scaling tables
-    (microphysics_kessler_ponni.h:97-135)."""
-    w = np.loadtxt(weights_txt or os.path.join(_DATA, "kessler_surrogate_weights.txt"), dtype=np.float64, comments="#").astype(np.float32)
-    if w.size != 104:
-        endrun("surrogate weight file must hold 104 values")
-    W1, b1, W2, b2 = w[:50].reshape(5, 10).copy(), w[50:60].copy(), w[60:100].reshape(10, 4).copy(), w[100:104].copy()
+def load_h5_weights(fname, group, dataset):
+    """ponni::load_h5_weights<N> (microphysics_kessler_ponni.h:103-107): one float32 dataset of a Keras HDF5 weight file, through the
+    library's dependency-free reader (mw_h5.cpp)."""
+    L = capi.lib()
+    dims, nd = (C.c_longlong * 8)(), C.c_int(0)
+    fb, gb, db = str(fname).encode(), group.encode(), dataset.encode()
+    check(L.mw_h5_read_f32(fb, gb, db, None, 0, dims, C.byref(nd)))
+    shape = tuple(int(dims[i]) for i in range(nd.value))
+    out = np.empty(shape, dtype=np.float32)
+    check(L.mw_h5_read_f32(fb, gb, db, out.ctypes.data_as(C.POINTER(C.c_float)), out.size, dims, C.byref(nd)))
+    return out
+
+
+def load_surrogate_weights(weights_txt=None, in_scaling_txt=None, out_scaling_txt=None, weights_h5=None):
+    """The Keras weights + min/max scaling tables (microphysics_kessler_ponni.h:97-135).  weights_h5: the reference's
+    `keras_weights_h5` file, read like ponni::load_h5_weights does (:103-107); weights_txt: a text export of the 104 values
+    (tools/export_mlp_weights.sh).  Default: the reference's shipped weight file (miniweatherml_amd/data/)."""
+    if weights_txt is None and weights_h5 is None:
+        weights_h5 = os.path.join(_DATA, "supercell_kessler_singlecell_model_weights.h5")
+    if weights_h5 is not None:
+        W1 = load_h5_weights(weights_h5, "/dense_6/dense_6", "kernel:0")       # Matvec 1   (in, out) = (5, 10)
+        b1 = load_h5_weights(weights_h5, "/dense_6/dense_6", "bias:0")
+        W2 = load_h5_weights(weights_h5, "/dense_7/dense_7", "kernel:0")       # Matvec 2   (10, 4)
+        b2 = load_h5_weights(weights_h5, "/dense_7/dense_7", "bias:0")
+        if W1.shape != (5, 10) or b1.shape != (10,) or W2.shape != (10, 4) or b2.shape != (4,):
+            endrun("surrogate weight file: expected Dense(5->10) and Dense(10->4)")
+        w = None
+    else:
+        w = np.loadtxt(weights_txt, dtype=np.float64, comments="#").astype(np.float32)
+        if w.size != 104:
+            endrun("surrogate weight file must hold 104 values")
+        W1, b1, W2, b2 = w[:50].reshape(5, 10).copy(), w[50:60].copy(), w[60:100].reshape(10, 4).copy(), w[100:104].copy()
     scl_in = np.loadtxt(in_scaling_txt or os.path.join(_DATA, "kessler_surrogate_input_scaling.txt")).reshape(5, 2)
     scl_out = np.loadtxt(out_scaling_txt or os.path.join(_DATA, "kessler_surrogate_output_scaling.txt")).reshape(4, 2)
     return W1, b1, W2, b2, np.ascontiguousarray(scl_in), np.ascontiguousarray(scl_out)
@@ -274,10 +299,10 @@ class Microphysics_Kessler_Surrogate(Microphysics_Kessler):
 
     online = False        # True = the four deep_copy_to lines :273-276 un-commented: the NN result replaces Kessler's
 
-    def init(self, coupler, weights_txt=None, in_scaling_txt=None, out_scaling_txt=None):
+    def init(self, coupler, weights_txt=None, in_scaling_txt=None, out_scaling_txt=None, weights_h5=None):
         super().init(coupler)
         self.W1, self.b1, self.W2, self.b2, self.scl_in, self.scl_out = load_surrogate_weights(weights_txt, in_scaling_txt,
-                                                                                              out_scaling_txt)
+                                                                                              out_scaling_txt, weights_h5)
         self._nn_out = None
 
     def time_step(self, coupler, dt):

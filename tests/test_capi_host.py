@@ -130,3 +130,27 @@ def test_create_rejects_bad_grids(mw):
     h = C.c_void_p()
     assert L.mw_dycore_create(C.byref(h), C.byref(g), None, None, None) != 0
     assert b"water_vapor" in L.mw_last_error()
+
+
+def test_h5_weight_reader_matches_the_text_export(mw):
+    """mw_h5_read_f32 (= ponni::load_h5_weights, microphysics_kessler_ponni.h:103-107) on the reference's shipped Keras weight file:
+    shapes (in, out) = (5, 10), (10), (10, 4), (4) and values identical to the h5dump text export of the same file; errors are loud."""
+    import numpy as np
+    from miniweatherml_amd import modules
+    from miniweatherml_amd.capi import MWError
+    data = os.path.join(ROOT, "miniweatherml_amd", "data")
+    h5 = os.path.join(data, "supercell_kessler_singlecell_model_weights.h5")
+    a = modules.load_surrogate_weights(weights_h5=h5)
+    b = modules.load_surrogate_weights(weights_txt=os.path.join(data, "kessler_surrogate_weights.txt"))
+    assert [x.shape for x in a[:4]] == [(5, 10), (10,), (10, 4), (4,)]
+    for x, y in zip(a, b):
+        assert x.dtype == y.dtype and np.array_equal(x, y)
+    assert all(np.array_equal(x, y) for x, y in zip(modules.load_surrogate_weights(), a))       # the default is the .h5
+    with pytest.raises(MWError, match="no object named"):
+        modules.load_h5_weights(h5, "/dense_6/dense_6", "kernel:1")
+    with pytest.raises(MWError, match="not an old-style group|no object named"):
+        modules.load_h5_weights(h5, "/dense_6/dense_6/kernel:0", "x")
+    with pytest.raises(MWError, match="not an HDF5 file"):
+        modules.load_h5_weights(os.path.join(ROOT, "README.md"), "/a", "b")
+    with pytest.raises(MWError, match="cannot open"):
+        modules.load_h5_weights(os.path.join(ROOT, "no_such_file.h5"), "/a", "b")
