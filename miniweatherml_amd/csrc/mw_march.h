@@ -938,6 +938,9 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
 //   receiver-centred k_tracer_patch then subtracts the recorded change from the two neighbours' new values (exact up to
 //   rounding: the provisional value over-estimates the inflow, so a clipped provisional value stays clipped).
 //   FY itself is never modified here, so what a receiver used is always the unscaled flux (no race).
+//   (Measured, round 2: wave-uniform branches that let the four ghost iterations of a chunk skip the stages nobody reads -- the x
+//   reconstructions at k = ka-2 and kb+1, S2 / S3 before their first cell -- save 1 % at run time but cost 30-40 VGPRs (spills in
+//   the MODE 1 variant) and the kernel as a whole became 15 % slower.  The loop body stays branch-free.)
 // ---------------------------------------------------------------------------------------------------------------
 template <int STAGE, int MODE, int T, bool N1>
 __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *__restrict__ S, const double *__restrict__ Sn, double *Sout,
