@@ -1174,10 +1174,25 @@ __global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const
   const int NXI = p.nx * p.nens;
   if (t >= (long long)p.ny * NXI) return;
   const int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
-  for (int k = blockIdx.y * MW_PATCH_LEVELS; k < min(p.nz, (int)(blockIdx.y + 1) * MW_PATCH_LEVELS); k++) {   // (few, fat blocks: the launch
-  const long long ci = ((long long)k * p.ny + j) * NXI + ie;                                                // is normally a no-op)
-  const unsigned fN = (j + 1 < p.ny) ? flags[ci + NXI] : 0u;      // northern neighbour scaled its south face = my north face
-  const unsigned fS = (j >= 1) ? flags[ci - NXI] : 0u;            // southern neighbour scaled its north face = my south face
+  // Busy case (some y face WAS scaled somewhere: any developed storm): the two flag bytes of all of this thread's levels are
+  // requested together -- one memory latency instead of one per level -- and a thread without a flagged neighbour leaves at once.
+  const int kb0 = blockIdx.y * MW_PATCH_LEVELS, kb1 = min(p.nz, kb0 + MW_PATCH_LEVELS);
+  unsigned fNv[MW_PATCH_LEVELS], fSv[MW_PATCH_LEVELS], anyf = 0u;
+#pragma unroll
+  for (int m = 0; m < MW_PATCH_LEVELS; m++) {
+    const long long cim = ((long long)min(kb0 + m, p.nz - 1) * p.ny + j) * NXI + ie;
+    fNv[m] = (j + 1 < p.ny) ? flags[cim + NXI] : 0u;            // northern neighbour scaled its south face = my north face
+    fSv[m] = (j >= 1) ? flags[cim - NXI] : 0u;                  // southern neighbour scaled its north face = my south face
+  }
+#pragma unroll
+  for (int m = 0; m < MW_PATCH_LEVELS; m++) anyf |= (kb0 + m < kb1) ? ((fNv[m] & 0x55u) | (fSv[m] & 0xAAu)) : 0u;
+  if (anyf == 0u) return;
+#pragma unroll
+  for (int m = 0; m < MW_PATCH_LEVELS; m++) {
+  const int k = kb0 + m;
+  if (k >= kb1) break;
+  const long long ci = ((long long)k * p.ny + j) * NXI + ie;
+  const unsigned fN = fNv[m], fS = fSv[m];
   if (((fN & 0x55u) | (fS & 0xAAu)) == 0u) continue;
   const int e = ie % p.nens;
   const long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
