@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmw_cdna4.so")
+LIB_PATH = os.environ.get("MW_LIB_PATH") or os.path.join(_HERE, "libmw_cdna4.so")      # (MW_LIB_PATH: compiler-flag experiments)
 
 MW_MAX_TRACERS = 16
 DATA_THERMAL, DATA_SUPERCELL, DATA_CITY, DATA_BUILDING = 0, 1, 2, 3
