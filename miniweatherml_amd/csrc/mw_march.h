@@ -33,6 +33,18 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
+// vmcnt counts loads AND stores on gfx9-family parts and retires them in issue order, and the compiler's counted waits assume the
+// fewest stores on any path (stores sit in divergent blocks that a wave may skip).  A load waited for AFTER a store therefore
+// waits for that store's write acknowledgement.  The marching kernels issue a level's loads at the top of the iteration and its
+// stores at the bottom; landed() names the loaded values in front of the first store, which puts the (by then free) wait
+// there, and in front of the loop for the prologue's loads, whose pending state would otherwise leak into every iteration.
+template <int N>
+__device__ __forceinline__ void landed(double (&a)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; i++) asm volatile("" : "+v"(a[i]));
+}
+__device__ __forceinline__ void landed(double &a) { asm volatile("" : "+v"(a)); }
+
 // Whole-wavefront shifts by one lane as DPP moves (v_mov_b32_dpp wave_shr:1 / wave_shl:1, gfx9 family): two full-rate
 // VALU moves per double and no LDS round trip.  Used when nens == 1 (x neighbours are adjacent lanes).
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
@@ -342,6 +354,8 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
       for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - 2 + s) + p.HY) * p.sJ];
     }
   }
+#pragma unroll
+  for (int v = 0; v < 5; v++) landed(w[v]);
   for (int j = ja - 1; j <= jb; j++) {
     const int jn = min(j + 3, p.ny + p.HY - 1);                 // clamp: the last prefetch is never used
     CouplerCell raw;
@@ -380,6 +394,8 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
         f[idU] = fs.m_upw * (up ? sU : cU);
         f[idW] = fs.m_upw * (up ? sW : cW);
       }
+      if (CONV) { landed(raw.rho_d); landed(raw.u); landed(raw.v); landed(raw.w); landed(raw.temp); landed(raw.tr); }
+      else landed(nxt);                                        // the iteration's loads, in front of its stores (see landed())
       if (face) { fy[(long long)j * p.fyJ] = fs.m_upw; upy[(long long)j * p.fyJ] = (unsigned char)up; }
       if (j > ja) {
 #pragma unroll
@@ -435,6 +451,9 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
   }
   double m_n = MY[(long long)k * p.fyK + ie + (long long)ja * p.fyJ];
   int up_n = upy[(long long)ja * p.fyJ];
+#pragma unroll
+  for (int v = 0; v < T; v++) landed(w[v]);
+  landed(nxt); landed(m_n); asm volatile("" : "+v"(up_n));
   for (int j = ja - 1; j <= jb; j++) {
     const int jn = min(j + 4, p.ny + p.HY - 1);
 #pragma unroll
@@ -447,6 +466,7 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
     double se[T], ne[T];
 #pragma unroll
     for (int v = 0; v < T; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
+    landed(nxt2); landed(m_n); asm volatile("" : "+v"(up_n));  // the iteration's loads, in front of its stores (see landed())
     if (j >= ja) {
       if (__builtin_expect(bc_mode_y(p, j) == 3, 0)) {
 #pragma unroll
@@ -568,6 +588,8 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
 #pragma unroll
     for (int s = 0; s < 5; s++) w[v][s] = load_zlevel(p, col + (long long)v * p.sV, g.kstart - 2 + s, v == idW);
   }
+#pragma unroll
+  for (int v = 0; v < 5; v++) landed(w[v]);
   for (int k = g.kstart; k <= g.kb; k++) {
     const bool top = (k == p.nz);                              // only the boundary face nz, no cell to reconstruct
     const bool xwork = (k >= g.ka) && (k < g.kb);              // cells of this chunk (ghost levels only do z)
@@ -598,6 +620,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     }
     // ------------------------------------------------ X direction (cell k = window centre)
     double fxs[5];
+    int upx = 0;
     if (xwork) {
       const double *hp = p.hypk + (long long)(k * n + e) * 8;
       const double hyr = HPL ? hpl[0] : hp[0], hyt = HPL ? hpl[1] : hp[1], p0 = HPL ? hpl[2] : hp[2], ihyt = HPL ? hpl[3] : hp[3];
@@ -630,10 +653,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       fxs[idR] = fs.m_upw; fxs[idU] = fn; fxs[idT] = fT;
       fxs[idV] = fs.m_upw * (up ? we[idV] : Lv[idV]);
       fxs[idW] = fs.m_upw * (up ? we[idW] : Lv[idW]);
-      if (g.owns_face && (g.owns_cell || q >= NXI)) {
-        const long long fo = (long long)k * p.fxK + (long long)j * p.fxJ + q;
-        MX[fo] = fs.m_upw;  UPX[fo] = (unsigned char)up;
-      }
+      upx = up;                                                // (stored below, behind landed())
     }
     // ------------------------------------------------ Z direction: reconstruct cell k, solve face k
     double be[5], te[5];
@@ -647,6 +667,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     double fzs[5];
 #pragma unroll
     for (int l = 0; l < 5; l++) fzs[l] = 0;
+    int upz = 0;
     if (zface) {
       const double *hp = p.hypk + (long long)(k * n + e) * 8;
       const double hyr = HPL ? hpl[4] : hp[4], hyt = HPL ? hpl[5] : hp[5], p0 = HPL ? hpl[6] : hp[6], ihyt = HPL ? hpl[7] : hp[7];
@@ -665,10 +686,17 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       fzs[idR] = fs.m_upw; fzs[idW] = fn; fzs[idT] = fT;
       fzs[idU] = fs.m_upw * (up ? be[idU] : ct[idU]);
       fzs[idV] = fs.m_upw * (up ? be[idV] : ct[idV]);
-      if (g.owns_cell) {
-        const long long fo = (long long)k * p.fzK + (long long)j * p.fzJ + q;
-        MZ[fo] = fs.m_upw;  UPZ[fo] = (unsigned char)up;
-      }
+      upz = up;
+    }
+    // ------------------------------------------------ all loads of this iteration have landed (see landed()); its stores follow
+    landed(nxt); landed(snv); landed(tyv); landed(immv);
+    if (xwork && g.owns_face && (g.owns_cell || q >= NXI)) {
+      const long long fo = (long long)k * p.fxK + (long long)j * p.fxJ + q;
+      MX[fo] = fxs[idR];  UPX[fo] = (unsigned char)upx;
+    }
+    if (zface && g.owns_cell) {
+      const long long fo = (long long)k * p.fzK + (long long)j * p.fzJ + q;
+      MZ[fo] = fzs[idR];  UPZ[fo] = (unsigned char)upz;
     }
     // ------------------------------------------------ finalise cell k-1 (it now has its upper z face)
     if (fin) {
@@ -1000,6 +1028,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #pragma unroll
     for (int s = 0; s < 5; s++) w[v][s] = load_zlevel(p, col + (long long)v * p.sV, kstart - 2 + s, false);
   }
+#pragma unroll
+  for (int v = 0; v < T; v++) landed(w[v]);
   // The loop body is branch-free apart from predicated stores and the rare limiter paths: every load uses a clamped
   // (always valid) address and is issued at the top, the z reconstruction (registers only) runs while they are in flight.
   // Iterations outside a quantity's range compute values that are never stored or carried into a used result.
@@ -1030,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     }
     const long long so = (long long)(kuc + p.HZ) * p.sK + so_row;
     const double hyc_u = p.hyc[kuc * p.nens + e];
-    const double rho_new = Sout[so + idR * p.sV] + hyc_u;
+    double rho_new = Sout[so + idR * p.sV] + hyc_u;
     double qn_[T], rho_n = 0, st_T = 0;
 #pragma unroll
     for (int v = 0; v < T; v++) qn_[v] = 0;
@@ -1112,6 +1142,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         }
         multp[v] = mult;
       }
+      landed(nxt); landed(qn_); landed(rho_new); landed(rho_n); landed(st_T);               // in front of the iteration's stores (see landed())
       if (rec && do_y) flags[((long long)kp * p.ny + j) * NXI + q] = (unsigned char)fl;     // 2 bits per tracer: (south, north) face scaled
       if (__builtin_expect(fl != 0u, 0)) *dirty = 1u;           // (only set inside `rec`) lets k_tracer_patch return at once when nothing was scaled
     }
