@@ -1028,8 +1028,14 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #pragma unroll
     for (int s = 0; s < 5; s++) w[v][s] = load_zlevel(p, col + (long long)v * p.sV, kstart - 2 + s, false);
   }
+  // The patch cell (beyond lane 0 / lane 63) of a level is requested one iteration ahead: the x reconstruction is the first
+  // consumer of an iteration, and vmcnt retires in order -- waiting for it would wait for everything requested before it.
+  double xpn[T];
+#pragma unroll
+  for (int v = 0; v < T; v++) xpn[v] = N1 ? col[(long long)v * p.sV + (long long)(min(kstart, p.nz - 1) + p.HZ) * p.sK + opatch] : 0.0;
 #pragma unroll
   for (int v = 0; v < T; v++) landed(w[v]);
+  landed(xpn);
   // The loop body is branch-free apart from predicated stores and the rare limiter paths: every load uses a clamped
   // (always valid) address and is issued at the top, the z reconstruction (registers only) runs while they are in flight.
   // Iterations outside a quantity's range compute values that are never stored or carried into a used result.
@@ -1042,9 +1048,11 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     const int kpc = min(max(kp, 0), p.nz - 1), kuc = min(max(ku, 0), p.nz - 1);
     // ------------------------------------------------ loads of this iteration
     const int kn = min(k + 3, p.nz + p.HZ - 1);
-    double xpatch[T];                                            // level k, the cell beyond lane 0 / lane 63 (first: needed first)
+    double xpatch[T];                                            // level k, the cell beyond lane 0 / lane 63
 #pragma unroll
-    for (int v = 0; v < T; v++) xpatch[v] = N1 ? col[(long long)v * p.sV + (long long)(kx + p.HZ) * p.sK + opatch] : 0.0;
+    for (int v = 0; v < T; v++) xpatch[v] = xpn[v];
+#pragma unroll
+    for (int v = 0; v < T; v++) xpn[v] = N1 ? col[(long long)v * p.sV + (long long)(min(k + 1, p.nz - 1) + p.HZ) * p.sK + opatch] : 0.0;
 #pragma unroll
     for (int v = 0; v < T; v++) nxt[v] = load_zlevel(p, col + (long long)v * p.sV, kn, false);
     const double mx = MX[(long long)kx * p.fxK + fxo];
@@ -1142,7 +1150,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         }
         multp[v] = mult;
       }
-      landed(nxt); landed(qn_); landed(rho_new); landed(rho_n); landed(st_T);               // in front of the iteration's stores (see landed())
+      landed(nxt); landed(xpn); landed(qn_); landed(rho_new); landed(rho_n); landed(st_T);  // in front of the iteration's stores (see landed())
       if (rec && do_y) flags[((long long)kp * p.ny + j) * NXI + q] = (unsigned char)fl;     // 2 bits per tracer: (south, north) face scaled
       if (__builtin_expect(fl != 0u, 0)) *dirty = 1u;           // (only set inside `rec`) lets k_tracer_patch return at once when nothing was scaled
     }
