@@ -192,8 +192,9 @@ __device__ __forceinline__ CouplerCell load_coupler_cell(const DyP &p, const Cou
 }
 // -> the five state variables of the slab (rho', u, v, w, (rho theta)') and 1/rho for the tracers.  hi = k*nens + e.  The last
 // operation of every result is not contractable, so that a caller that goes on computing with the values sees exactly what is stored.
-__device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCell &r, int hi, double *s5, double &inv_den) {
-  double rho, ru, rv, rw, sd, hyt, rp;
+// (hyc, hyt, p0: the cell's background density, rho*theta and pressure = DyP::hyc / hytc / p0c [hi] = the first three of hypk's row)
+__device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCell &r, double hyc, double hyt, double p0, double *s5, double &inv_den) {
+  double rho, ru, rv, rw, sd, rp;
   {
 #pragma clang fp contract(fast)
     rho = r.rho_d;
@@ -204,8 +205,6 @@ __device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCel
       if (tr == p.idWV) rho_v = r.tr[tr];
     }
     const double press = r.rho_d * p.R_d * r.temp + rho_v * p.R_v * r.temp;
-    const double hyc = p.hyc[hi], p0 = p.p0c[hi];
-    hyt = p.hytc[hi];
     const double dl = press * fast_rcp(p0) - 1.0;
     if (fabs(dl) <= 0.05 && p.an_default) sd = inv_gamma_series_default(dl) * dl;
     else                                  sd = rhotheta_ratio_pow(press / p.C0, 1.0 / p.gamma, hyt);
@@ -217,6 +216,9 @@ __device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCel
 #pragma clang fp contract(off)
     s5[idR] = rp; s5[idU] = ru * inv_den; s5[idV] = rv * inv_den; s5[idW] = rw * inv_den; s5[idT] = hyt * sd;
   }
+}
+__device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCell &r, int hi, double *s5, double &inv_den) {
+  convert_cell_fast(p, r, p.hyc[hi], p.hytc[hi], p.p0c[hi], s5, inv_den);
 }
 // the tracers of that cell: slab value = rho_t / rho
 __device__ __forceinline__ void convert_cell_tracers(const DyP &p, const CouplerCell &r, double inv_den, double *__restrict__ s) {
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 #define MW_ROW_CI(r) cpl(p, ((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
 #define MW_ROW_FINISH(raw, r, out5)                                                                                   \
   { double inv_den_;                                                                                                  \
-    convert_cell_fast(p, raw, hi, out5, inv_den_);                                                                    \
+    convert_cell_fast(p, raw, hyr, hyt, p0, out5, inv_den_);   /* (the row's background values are in registers already) */ \
     if ((r) >= ja && (r) < jb) {                                                                                      \
       double *s_ = Sw + (long long)(k + p.HZ) * p.sK + (long long)((r) + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;  \
       s_[0] = out5[0]; s_[p.sV] = out5[1]; s_[2 * p.sV] = out5[2]; s_[3 * p.sV] = out5[3]; s_[4 * p.sV] = out5[4];    \
@@ -991,6 +993,19 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const BlockXY blk = xcd_block();
   if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
   else       { const long long wid = (long long)blk.x * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
+  // MODE 1: D13's three background values (hytc, p0c, ihytc) of the levels this block finishes go through LDS.  As global loads
+  // they sat behind the tracer stores, each waited for at once -- and a vmcnt wait behind a store waits for the store (see landed());
+  // requested at the top of the iteration they cost 6 VGPRs the kernel does not have.  (dynamic LDS: (chunk + 4) * nens * 3 doubles)
+  extern __shared__ double lds_bg[];
+  const int bg_l0 = max((int)blk.y * chunk - 4, 0);
+  if (MODE == 1) {
+    const int cnt = (min((int)blk.y * chunk + chunk, p.nz) - bg_l0) * p.nens;
+    for (int i3 = threadIdx.x; i3 < cnt * 3; i3 += 256) {
+      const int i = i3 / 3, f = i3 - i * 3;
+      lds_bg[i3] = (f == 0 ? p.hytc : f == 1 ? p.p0c : p.ihytc)[bg_l0 * p.nens + i];
+    }
+    __syncthreads();
+  }
   if (j >= p.ny) return;
   const int q = tx * U - hw * n + lane;                       // fused-x index of this lane's cell (halo lanes included)
   const int qq = min(max(q, -3 * n), NXI + 3 * n - 1);        // clamped into the 3-cell halo for addressing
@@ -1181,8 +1196,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       if (MODE == 1 && st) {
         // D13 (:1929-1935): p = C0 (rho theta)^gamma with rho theta = hy + (rho theta)' -- the same series around the hydrostatic
         // state as in the Riemann solver (device pow for large perturbations); rho*(rho theta / rho) differs from rho theta by rounding
-        const int hi = kuc * p.nens + e;
-        double press = pressure_fast(p, st_T, p.hytc[hi], p.p0c[hi], p.ihytc[hi]);
+        const double *bg = lds_bg + ((kuc - bg_l0) * p.nens + e) * 3;
+        double press = pressure_fast(p, st_T, bg[0], bg[1], bg[2]);
         c.rho_d[cpl(p, ci)] = rho_dry;
         c.temp[cpl(p, ci)] = press / (rho_dry * p.R_d + rho_v * p.R_v);
       }
