@@ -442,7 +442,10 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
   double *fy = FY + (long long)k * p.fyK + ie;
   const unsigned char *upy = UPY + (long long)k * p.fyK + ie;
   // Loads run two rows ahead of their use (row j+4 and the face data of row j+1 are requested in iteration j): with ~75 VALU
-  // instructions per tracer and row, one iteration is shorter than the memory latency.
+  // instructions per tracer and row, one iteration is shorter than the memory latency.  (The copy nxt = nxt2 at the end of the
+  // iteration still waits for the row just requested.  Measured, round 2: two register sets taking turns in a loop unrolled by
+  // two, so that a set is only waited for two iterations after its request, need 236 instead of 154 VGPRs for three tracers --
+  // two waves per SIMD instead of three -- and the kernel was 10 % slower.)
   double w[T][5], nxt[T], nxt2[T], cn[T];
 #pragma unroll
   for (int v = 0; v < T; v++) {
