@@ -1527,9 +1527,10 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     d->overlap = march && d->tstream && want; }
   // nens > 1 on the production path: member-major internal layout (see View)
   d->member_major = march && d->fused && p.nens > 1 && !getenv("MW_NO_MEMBER_MAJOR");
-  // D1 + D2 (:101, :248-255).  Production path on one stream with periodic x and y owned by this rank: done inside the first
-  // k_y_state (no separate pass); otherwise a conversion kernel first (the reference's operation order on the general path).
-  d->conv_pending = march && !d->member_major && !d->overlap && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT");
+  // D1 + D2 (:101, :248-255).  Production path with periodic x and y owned by this rank (either schedule: the tracer stream waits
+  // for the stage's state kernels anyway): done inside the first k_y_state (no separate pass); otherwise a conversion kernel first
+  // (the reference's operation order on the general path).
+  d->conv_pending = march && !d->member_major && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT");
   if (!d->conv_pending) {
     ProfScope ps(d, 4);
     if (d->member_major) {      // one coalesced pass in the coupler's order (see k_coupler_to_member)
