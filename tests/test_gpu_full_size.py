@@ -184,3 +184,36 @@ def test_config5_city_block(mw):
     assert 15.0 < float(u.max()) < 40.0 and float(u[imm > 0.5].abs().max()) < float(u.max())   # the flow is being braked inside the buildings
     del coupler, dycore, hs, ta
     torch.cuda.empty_cache()
+
+
+def test_member_major_layout_agrees_with_the_member_fastest_kernels(mw, monkeypatch):
+    """nens > 1: the default keeps the handle's arrays member after member and runs the nens = 1 kernels per member (DPP shifts);
+    MW_NO_MEMBER_MAJOR=1 keeps the coupler's member-fastest order inside and fetches the x neighbours by loads.  The stencil
+    arithmetic is the same; the conversions at the coupler boundary are not (the member-major handle stores q / rho in its slab and
+    multiplies back in k_member_to_coupler, the other writes rho q straight from the last stage): agreement to a few ulp, with
+    members that differ from each other and chunks that do not divide nz."""
+    import torch
+    from miniweatherml_amd import modules
+    monkeypatch.setenv("MW_CHUNK_Z", "7"); monkeypatch.setenv("MW_CHUNK_F", "9")
+    out = []
+    for legacy in (None, "1"):
+        if legacy: monkeypatch.setenv("MW_NO_MEMBER_MAJOR", legacy)
+        else: monkeypatch.delenv("MW_NO_MEMBER_MAJOR", raising=False)
+        coupler, dycore, _ = modules.make_supercell(70, 45, 26, 3, 35000., 22500., 20000.)
+        modules.perturb_temperature(coupler)
+        dm = coupler.get_data_manager_readwrite()
+        t = dm.get("temp", True)
+        t += 0.05 * torch.arange(3, device=t.device, dtype=t.dtype)          # members differ
+        dt = dycore.compute_time_step(coupler)
+        for n in range(3):
+            dycore.time_step(coupler, dt * (2.2 if n == 1 else 1.0))            # step 1: three sub-cycles
+        fl = dycore.fluxes(coupler)
+        dmr = coupler.get_data_manager_readonly()
+        out.append({n: dmr.get(n, True).clone() for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid")})
+        out[-1].update({k: v.clone() for k, v in fl.items()})
+    for n in out[0]:
+        scale = float(out[1][n].abs().max())
+        floor = 1e-11 if n in ("uvel", "vvel", "wvel") else 1e-18          # (v starts at 0 and grows from rounding-level seeds)
+        assert float((out[0][n] - out[1][n]).abs().max()) <= 1e-12 * scale + floor, n
+    a = out[0]["temp"]
+    assert not torch.equal(a[..., 0], a[..., 1])
