@@ -1,0 +1,41 @@
+"""Per-class kernel times of the dycore step on bench.py's headline state and on its seeded 'developed' state (cloud / rain blobs
+with sharp rims: busy FCT).  python tools/developed_classes.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from miniweatherml_amd import modules
+
+NAMES = ["xz_state", "patch", "upd", "halo", "convert", "y_state", "y_tracers", "fused"]
+nx, ny, nz = 400, 400, 100
+coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 2e5, 2e5, 2e4)
+modules.perturb_temperature(coupler)
+dt = dycore.compute_time_step(coupler)
+dm = coupler.get_data_manager_readwrite()
+
+
+def classes(tag):
+    for _ in range(3): dycore.time_step(coupler, dt)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10): dycore.time_step(coupler, dt)
+    b.record(); torch.cuda.synchronize()
+    dycore.profile(1)
+    for _ in range(5): dycore.time_step(coupler, dt)
+    out = {n: round(dycore.profile_get(i)[0] / 5, 3) for i, n in enumerate(NAMES)}
+    dycore.profile(0)
+    print(tag, "step %.3f ms" % (a.elapsed_time(b) / 10), out, flush=True)
+
+
+classes("headline ")
+rho_d = dm.get("density_dry")
+k = torch.arange(nz, device=rho_d.device, dtype=torch.float64).view(nz, 1, 1, 1)
+j = torch.arange(ny, device=rho_d.device, dtype=torch.float64).view(1, ny, 1, 1)
+i = torch.arange(nx, device=rho_d.device, dtype=torch.float64).view(1, 1, nx, 1)
+blob = ((torch.sin(i * 0.11) * torch.cos(j * 0.07)) > 0.3).to(torch.float64)
+dm.get("cloud_liquid").copy_(2.0e-3 * blob * ((k > 0.15 * nz) & (k < 0.45 * nz)) * (0.5 + 0.5 * torch.sin(0.3 * k + 0.05 * i) ** 2) * rho_d)
+dm.get("precip_liquid").copy_(4.0e-4 * blob * (k < 0.3 * nz) * (0.5 + 0.5 * torch.cos(0.2 * k + 0.03 * j) ** 2) * rho_d)
+classes("developed")
