@@ -1175,11 +1175,13 @@ static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const doubl
   return 0;
 }
 
+// dynamic LDS of k_tracers_fused<., MODE 1>: D13's background table of the block's levels
+static size_t fused_bg_bytes(int mode, int chunk, int nens) { return mode == 1 ? (size_t)(chunk + 4) * nens * 24 : 0; }
 template <int STAGE, int MODE, int T, bool N1>
 static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
   const int e = v.e;
-  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1>), grid, dim3(256), MODE == 1 ? (size_t)(chunk + 4) * v.p.nens * 24 : 0, st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
+  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1>), grid, dim3(256), fused_bg_bytes(MODE, chunk, v.p.nens), st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
                      d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
                      d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4);
 }
@@ -1198,6 +1200,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const long long waves = (long long)p.ny * tiles_x;
       const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F"));
       dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
+      if (fused_bg_bytes(MODE, chunk, p.nens) > 60000) MW_FAIL("fused tracer stage: nens x chunk too large for its LDS table (use the member-major layout or a smaller MW_CHUNK_F)");
 #define MW_FUSED_CASE(TT) \
       case TT: if (p.nens == 1) launch_tracers_fused_t<STAGE, MODE, TT, true>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); \
                else             launch_tracers_fused_t<STAGE, MODE, TT, false>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); break;

@@ -1635,7 +1635,11 @@ void mwo_time_average_accumulate(const mwo_params *pp, const double *const *fiel
 // Surrogate NN block   experiments/supercell_kessler_surrogate/custom_modules/microphysics_kessler_ponni.h:176-202
 // ponni source is absent (empty submodule): layers restated from the call sites :103-110 and Keras Dense
 // semantics (kernel stored (in,out); y = x.W + b; LeakyReLU alpha = 0.1), fp32, accumulation in index order
-// with the bias added after the matvec (Matvec layer then Bias layer).   PARITY UNPINNED.
+// with the bias added after the matvec (Matvec layer then Bias layer).   PARITY UNPINNED at the bit level; ANCHORED on reference-made
+// artefacts: the architecture is the one the reference's training notebook builds and saves into the shipped .h5
+// (jupyter_notebooks/kessler_singlecell_train_example.ipynb: Dense(10) -> LeakyReLU(alpha=0.1) -> Dense(4)), and with the shipped
+// weights + scaling files this function reproduces the Kessler step within the test error that notebook recorded
+// (tests/test_oracle_mlp_anchor.py, with negative controls for slope, scaling orientation and weight layout).
 // W1 (5,10) row-major, b1 (10), W2 (10,4) row-major, b2 (4); scl_in (5,2), scl_out (4,2) as [min,max] rows.
 // -----------------------------------------------------------------------------------------------------
 void mwo_mlp_forward(long long ncells, const double *temp, const double *rho_d, const double *rho_v, const double *rho_c,
