@@ -315,7 +315,7 @@ def main():
             dom_bytes = 32.0 * V * ncells_local
         dom_achieved = dom_bytes / avg_flux_s / 1e9 if flux_n else None
         # ---- counters from the committed rocprofv3 summary: only while the kernel sources are the profiled ones
-        traffic, dom_traffic, valu_busy, valu_instr, prov = None, None, None, None, None
+        traffic, dom_traffic, valu_busy, valu_instr, prov, valu_side = None, None, None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "latest_summary.json")
         if os.path.exists(pmc) and not a.strict:
             try:
@@ -333,8 +333,14 @@ def main():
                     stage_k = [v for k, v in K.items() if k.startswith(("k_xz_state", "k_y_state", "k_y_tracers", "k_tracers_fused", "k_tracer_patch"))]
                     nstages = sum(k["calls"] for k in ks)      # one k_xz_state launch per RK stage
                     traffic = sum((k["hbm_read_bytes"] + k["hbm_write_bytes"]) * k["calls"] for k in stage_k if "hbm_read_bytes" in k) / nstages
+                    # fp64-VALU side of the roofline (the binding one): counted VALU instructions of one cell-update against the
+                    # chip's issue rate (1024 SIMDs, one wave64 instruction per 4 cycles, 2.4 GHz peak engine clock)
+                    instr_cu = sum(k["valu_instr_per_cell"] * k["calls"] for k in stage_k if "valu_instr_per_cell" in k) / nstages * 3.0
+                    valu_side = {"instr_per_cell_update": instr_cu, "achieved_wave_instr_per_s": per_gpu * instr_cu / 64.0,
+                                 "peak_wave_instr_per_s": 1024 * 2.4e9 / 4.0, "frac": per_gpu * instr_cu / 64.0 / (1024 * 2.4e9 / 4.0),
+                                 "source": "SQ_INSTS_VALU of profiles/latest_summary.json x live cell-updates/s"}
             except Exception:
-                traffic = dom_traffic = None
+                traffic = dom_traffic = valu_side = None
         what = "complete supercell_example loop: WENO-FV dycore + Kessler + sponge_layer + ColumnNudger" if a.full_loop else "WENO-FV dycore only"
         out = {
             "metric": "cell-updates/s" + (" (full supercell_example loop)" if a.full_loop else ""), "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
@@ -361,6 +367,7 @@ def main():
                                              "avg_launch_ms": avg_flux_s * 1e3, "launches": flux_n, "alg_bytes_per_launch": dom_bytes,
                                              "avg_launch_ms_exclusive": (prof_excl["xz_state"][0] / max(1, prof_excl["xz_state"][1])) if prof_excl else None,
                                              "valu_busy_frac": valu_busy, "valu_instr_per_cell": valu_instr},
+                         "fp64_valu": valu_side,
                          "pipeline": {"alg_bytes_per_cell_update": 64 * V, "achieved": per_gpu * 64 * V / 1e9, "frac": per_gpu * 64 * V / 8.0e12}},
             "kernel_ms_per_step": {k: v[0] / 3.0 for k, v in prof.items()},
             "kernel_ms_per_step_exclusive": ({k: v[0] / 3.0 for k, v in prof_excl.items()} if prof_excl else None),
