@@ -1040,12 +1040,41 @@ static int launch_update(mw_dycore_s *d, const double *Sstar, const double *Sn, 
 
 // Equal chunks along the marching direction: enough of them for `target` waves (x/z kernels: ~5 rounds of 2 waves/SIMD over
 // the 1024 SIMDs), none shorter than 8 cells (every chunk re-primes its pipeline).
-static int balanced_chunk(int nz, long long base_waves, const char *env, long long target = 10000) {
+// The count of chunks decides how many workgroups a CU holds at once, and that quantises the run time -- measured on 100 x 100 x 50:
+// 0.37 ms per step with 10 chunks of 5 levels (250 workgroups: one per CU, every wave alone on its SIMD), 0.47 ms with 6 chunks of
+// 9 (300 workgroups: 44 CUs hold two).  Model: duration = t(B) * (chunk + o) * (1 + chunk / 1000) with B workgroups on 256 CUs that
+// hold `bpc` of them each; a CU's last, partly filled round costs less than a full one (a wave that has its SIMD to itself runs
+// ~1.7 x faster); o = cells of work a chunk adds (ghost levels, pipeline priming); the last factor is what long chunks lose in
+// cache locality.  Fitted to chunk sweeps on 100 x 100 x 50, 200 x 200 x 50, 256 x 256 x 64, 300 x 300 x 80 and 400 x 400 x 100
+// (tools/tail_probe.py); `model` = false keeps the older rule (enough chunks for `target` waves, none under 8 cells).
+static int balanced_chunk(int nz, long long base_waves, const char *env, long long target, int bpc, double o, bool model) {
   const char *s = getenv(env);
   if (s && atoi(s) > 0) return std::min(nz, atoi(s));
   long long nch = std::max(1ll, (target + base_waves - 1) / base_waves);
   nch = std::min<long long>(nch, std::max(1, nz / 8));
-  return (int)((nz + nch - 1) / nch);
+  const long long cap = 256ll * bpc;
+  if (!model || getenv("MW_NO_CHUNK_MODEL")) return (int)((nz + nch - 1) / nch);
+  auto t_of = [&](long long B) {
+    const long long full = B / cap, rem = B - full * cap;
+    if (rem == 0) return (double)full;
+    const long long m = (rem + 255) / 256;                     // workgroups per CU in the last round
+    const double part = (bpc == 2) ? (m == 1 ? 0.6 : 1.0) : (m == 1 ? 0.45 : m == 2 ? 0.75 : 1.0);
+    return (double)full + part;
+  };
+  auto cost_of = [&](int chunk) {
+    const int neff = (nz + chunk - 1) / chunk;                 // the chunk length decides; neff chunks result
+    return t_of(((base_waves + 3) / 4) * neff) * (chunk + o) * (1.0 + 0.001 * chunk);
+  };
+  const int old_chunk = (int)((nz + nch - 1) / nch);
+  double best = 1e300; int best_chunk = nz;
+  for (int n = 1; n <= std::max(1, nz / 4); n++) {
+    const int chunk = (nz + n - 1) / n;
+    const double cost = cost_of(chunk);
+    if (cost < best * (1.0 - 1e-9)) { best = cost; best_chunk = chunk; }
+  }
+  // the model is crude: it overrides the older rule only where it promises more than 3 % (small and odd-sized launches: 9-26 %
+  // measured; the tuned large grids keep their chunks)
+  return (best < 0.97 * cost_of(old_chunk)) ? best_chunk : old_chunk;
 }
 
 // conv != nullptr: the slab S is still empty -- the kernel converts the coupler's fields on the way and fills it (k_y_state<true>)
@@ -1057,7 +1086,7 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     const DyP &p = v.p;
     long long threads = (long long)p.nz * p.nx * p.nens;
     // measured on 400x400x100 (625 wave columns): 8 x 50 rows for k_y_state, 14 x 29 for k_y_tracers (-5 % / -2 % vs. 32-row chunks)
-    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000));
+    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     double *MY = d->M[par][1] + e * v.m[1]; unsigned char *UY = d->UP[par][1] + e * v.m[1];
     if (conv) hipLaunchKernelGGL((k_y_state<true>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, *conv,
@@ -1076,7 +1105,7 @@ static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_
     const View v = view(d, e);
     const DyP &p = v.p;
     long long threads = (long long)p.nz * p.nx * p.nens;
-    int chunk = d->chunk_yt ? d->chunk_yt : (d->chunk_yt = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_YT", 8400));
+    int chunk = d->chunk_yt ? d->chunk_yt : (d->chunk_yt = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_YT", 8400, 3, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     double *FY = d->FY + e * v.f[1];
     for (int t0 = 0; t0 < p.nt; t0 += 4) {
@@ -1102,7 +1131,7 @@ static int xz_grid(mw_dycore_s *d, const DyP &p, dim3 &grid, int &chunk, int &ti
   if (!d->chunk_z) {
     // k_xz_state: equal chunks, enough of them for ~5 rounds of 2 waves/SIMD over the 1024 SIMDs (measured on 400x400x100:
     // 4 x 25 levels beats 32,32,32,4 by 4 %)
-    d->chunk_z = balanced_chunk(p.nz, waves, "MW_CHUNK_Z");
+    d->chunk_z = balanced_chunk(p.nz, waves, "MW_CHUNK_Z", 10000, 2, 2.5, true);
   }
   chunk = d->chunk_z;
   grid = dim3((unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
@@ -1198,7 +1227,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const int tiles_x = (p.nx * p.nens + U - 1) / U;
       const int rows4 = p.ny >= 4 ? 1 : 0;
       const long long waves = (long long)p.ny * tiles_x;
-      const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F"));
+      const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F", 10000, 2, 4.5, true));
       dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
       if (fused_bg_bytes(MODE, chunk, p.nens) > 60000) MW_FAIL("fused tracer stage: nens x chunk too large for its LDS table (use the member-major layout or a smaller MW_CHUNK_F)");
 #define MW_FUSED_CASE(TT) \

@@ -36,7 +36,17 @@ def run(ny, nz=100, nx=400, env=None):
     torch.cuda.empty_cache()
 
 
-for ny in (292, 293, 300, 340, 365, 366, 380, 400, 420, 438, 439, 512):
-    run(ny)
-for cz in (13, 17, 20, 25, 34, 50, 100):
-    run(400, env={"MW_CHUNK_Z": str(cz), "MW_CHUNK_F": str(cz)})
+what = sys.argv[1] if len(sys.argv) > 1 else "xz"
+if what == "xz":
+    for ny in (292, 293, 300, 340, 365, 366, 380, 400, 420, 438, 439, 512):
+        run(ny)
+    for cz in (13, 17, 20, 25, 34, 50, 100):
+        run(400, env={"MW_CHUNK_Z": str(cz), "MW_CHUNK_F": str(cz)})
+elif what == "y":                                               # y chunk sizes on the headline grid
+    for cy in (25, 29, 34, 40, 45, 50, 58, 67, 80, 100, 134, 200):
+        run(400, env={"MW_CHUNK_Y": str(cy), "MW_CHUNK_YT": str(cy)})
+elif what == "small":                                           # z chunk counts on small grids
+    for n in (200, 100):
+        for cz in (5, 7, 9, 10, 13, 17, 25, 50):
+            run(n, nz=50, nx=n, env={"MW_CHUNK_Z": str(cz), "MW_CHUNK_F": str(cz)})
+        run(n, nz=50, nx=n)
