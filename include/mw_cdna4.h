@@ -135,6 +135,10 @@ int  mw_calib_copy(const double *in, double *out, long long n, void *stream);
 
 /* modules::perturb_temperature(coupler, thermal=true, random=false), perturb_temperature.h:41-66 */
 int  mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream);
+/* the random = true branch, perturb_temperature.h:25-39 (applied BEFORE the thermal, as there): +-3 K uniform noise on the lowest
+ * nz/4 levels, fading linearly; one draw per (level, column) from the key myrank*nz*nx*ny*nens + k*ncol + i.  yakl::Random is
+ * unavailable: the key goes through the splitmix64 finaliser ("Substitutions"). */
+int  mw_perturb_temperature_random(const mw_grid_t *g, double *temp, void *stream);
 
 /* ---- multi-GPU halo exchange ---------------------------------------------------------------------- */
 /* halo_exchange, :574-747 (MPI_Isend/Irecv W/E/S/N, tags 0-3).  The native design ships a 3-cell halo once

@@ -63,6 +63,7 @@ SYMBOLS = {
     "mw_dycore_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "mw_calib_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "mw_perturb_temperature": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p]),
+    "mw_perturb_temperature_random": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.c_void_p]),
     "mw_exchange_plan": (C.c_int, [C.POINTER(Grid)] + [C.POINTER(C.c_int)] * 4),
     "mw_dycore_set_exchange": (C.c_int, [C.c_void_p, EXCHANGE_FN, C.c_void_p]),
     "mw_rccl_unique_id": (C.c_int, [C.c_char_p]),

@@ -736,6 +736,26 @@ __global__ __launch_bounds__(256) void k_perturb_temperature(int nz, int ny, int
   if (rad < 1) temp[t] += amp * pow(cos(M_PI * rad / 2), 2.0);
 }
 
+// modules::perturb_temperature(random=true)   perturb_temperature.h:25-39: the lowest nz/4 levels get uniform noise in [-1, 1] * 3 K,
+// fading linearly with height; every (level, column) draws from its own generator seeded with a globally unique key
+// (myrank*nz*nx*ny*nens + k*ncol + i).  yakl::Random is not available (empty submodule): the same key goes through the splitmix64
+// finaliser (53 random bits -> [0, 1)), the substitution the surrogate-data sampler uses (mw_output.hip); INTEGRATION.md says so.
+__global__ __launch_bounds__(256) void k_perturb_temperature_random(int num_levels, long long ncol, unsigned long long seed,
+                                                                    double *__restrict__ temp) {
+#pragma clang fp contract(off)
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)num_levels * ncol) return;
+  const int k = (int)(t / ncol);
+  unsigned long long z = seed + (unsigned long long)t + 0x9E3779B97F4A7C15ull;              // t = k*ncol + i
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const double u01 = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+  const double rnd = u01 * 2.0 - 1.0;
+  const double scaling = (num_levels - (double)k) / num_levels;
+  temp[t] += rnd * 3.0 * scaling;                               // (levels are the slowest index: t addresses temp(k, column) directly)
+}
+
 // Streaming copy with this library's access shape (8 bytes per lane, consecutive lanes consecutive doubles): the known-byte
 // workload used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on gfx950 (MI355X_MICROARCH.md, HBM section).
 // Diagnostic: the device WENO-5 routines on caller-supplied stencils (unit test of the core arithmetic against the golden vectors)
@@ -1648,6 +1668,19 @@ int mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream) {
   long long n = (long long)g->nz * g->ny * g->nx * g->nens;
   hipLaunchKernelGGL(k_perturb_temperature, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g->nz, g->ny, g->nx,
                      g->nens, g->i_beg, g->j_beg, g->xlen / g->nx_glob, g->ylen / g->ny_glob, g->zlen / g->nz, g->xlen, g->ylen, temp);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+int mw_perturb_temperature_random(const mw_grid_t *g, double *temp, void *stream) {
+  if (!g || !temp) MW_FAIL("null argument");
+  const int num_levels = g->nz / 4;
+  const long long ncol = (long long)g->ny * g->nx * g->nens;
+  if (num_levels < 1) return 0;
+  const unsigned long long myrank = (unsigned long long)g->py * g->nproc_x + g->px;
+  const unsigned long long seed = myrank * (unsigned long long)g->nz * g->nx * g->ny * g->nens;
+  const long long n = (long long)num_levels * ncol;
+  hipLaunchKernelGGL(k_perturb_temperature_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, num_levels, ncol, seed, temp);
   MW_LAUNCH_CHECK();
   return 0;
 }

@@ -371,7 +371,7 @@ class ColumnNudger {                                                  // model/m
 };
 
 inline void perturb_temperature(core::Coupler &coupler, bool thermal = true, bool random = false) {   // perturb_temperature.h:8-67
-  if (random) endrun("perturb_temperature(random=true) needs yakl::Random and is not on the hot path");
+  if (random) mw_check(mw_perturb_temperature_random(&coupler.grid, coupler.get_data_manager_readwrite().get<real>("temp").data(), nullptr));
   if (thermal) mw_check(mw_perturb_temperature(&coupler.grid, coupler.get_data_manager_readwrite().get<real>("temp").data(), nullptr));
 }
 

@@ -335,11 +335,11 @@ class Microphysics_Kessler_Surrogate(Microphysics_Kessler):
 
 
 def perturb_temperature(coupler, thermal=True, random=False):                   # perturb_temperature.h:8-67
-    if random:
-        endrun("perturb_temperature(random=true) needs yakl::Random and is not on the hot path")
-    if thermal:
-        temp = coupler.get_data_manager_readwrite().get("temp")
-        with torch.cuda.device(coupler.device):
+    temp = coupler.get_data_manager_readwrite().get("temp")
+    with torch.cuda.device(coupler.device):
+        if random:      # :25-39 (splitmix64 in place of the unavailable yakl::Random, see include/mw_cdna4.h)
+            check(capi.lib().mw_perturb_temperature_random(C.byref(coupler.grid), _ptr(temp), _stream_ptr(coupler.device)))
+        if thermal:     # :41-66
             check(capi.lib().mw_perturb_temperature(C.byref(coupler.grid), _ptr(temp), _stream_ptr(coupler.device)))
 
 

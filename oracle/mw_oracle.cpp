@@ -1327,6 +1327,26 @@ void mwo_init(mwo_dycore *d, int init_data_int, double *dm_rho_d, double *dm_uve
 }
 
 // perturb_temperature(coupler, thermal=true, random=false)    perturb_temperature.h:41-66
+// modules::perturb_temperature, random = true   perturb_temperature.h:25-39.  yakl::Random (empty submodule) is replaced by the
+// splitmix64 finaliser of the SAME key (seed + k*ncol + i), as in mwo_sample_mask: PINNED BY DEFINITION, not by the reference.
+void mwo_perturb_temperature_random(const mwo_params *pp, double *temp, int myrank) {
+  const mwo_params &p = *pp;
+  int  num_levels = p.nz / 4;
+  real magnitude  = 3.;
+  size_t seed = (size_t)myrank*p.nz*p.nx*p.ny*p.nens;
+  size_t ncol = (size_t)p.ny*p.nx*p.nens;
+  for (int k=0;k<num_levels;k++) for (size_t i=0;i<ncol;i++) {
+    unsigned long long z = (unsigned long long)(seed+k*ncol+i) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    real u01 = (real)(z >> 11) * (FP(1.0) / FP(9007199254740992.0));
+    real rand = u01*FP(2.) - FP(1.);
+    real scaling = ( num_levels - (real)k ) / num_levels;
+    temp[k*ncol+i] += rand * magnitude * scaling;
+  }
+}
+
 void mwo_perturb_temperature(const mwo_params *pp, double *temp) {
   const mwo_params &p = *pp;  Dims D(p);
   real dx=get_dx(p), dy=get_dy(p), dz=get_dz(p), xlen=p.xlen, ylen=p.ylen;

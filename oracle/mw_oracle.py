@@ -105,6 +105,7 @@ def lib():
     pdp = C.POINTER(dp)
     L.mwo_init.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, dp, dp, pdp]
     L.mwo_perturb_temperature.argtypes = [C.POINTER(Params), dp]
+    L.mwo_perturb_temperature_random.argtypes = [C.POINTER(Params), dp, C.c_int]
     L.mwo_stage_tendencies.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, pdp, C.c_double, dp, dp]
     L.mwo_time_step.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, pdp, C.c_double]
     L.mwo_kessler_time_step.restype = C.c_int
@@ -265,8 +266,11 @@ class OracleDycore:
         return self.L.mwo_compute_time_step(self.L.mwo_params_ptr(self.h))
 
 
-def perturb_temperature(p, temp):
-    lib().mwo_perturb_temperature(C.byref(p), _dp(temp))
+def perturb_temperature(p, temp, thermal=True, random=False, myrank=0):
+    if random:
+        lib().mwo_perturb_temperature_random(C.byref(p), _dp(temp), int(myrank))
+    if thermal:
+        lib().mwo_perturb_temperature(C.byref(p), _dp(temp))
 
 
 def weno5(stencil):

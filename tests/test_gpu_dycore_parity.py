@@ -8,6 +8,7 @@ import json
 import os
 
 import numpy as np
+import torch
 import pytest
 
 from util import compare_fields, gpu_fields, oracle_sensitivity, push_fields, sens_allowed
@@ -420,3 +421,37 @@ def test_weno_order_3(mw, oracle, name, mode):
     for _ in range(10):
         o5.time_step(f5, dt)
     assert np.max(np.abs(f5.uvel - of.uvel)) > 1e-6
+
+
+@pytest.mark.parametrize("nranks,rank", [(1, 0), (4, 3)])
+def test_random_temperature_perturbation_is_bitwise_the_oracles(mw, oracle, nranks, rank):
+    """perturb_temperature(random = true) (perturb_temperature.h:25-39): +-3 K noise on the lowest nz/4 levels, one draw per (level,
+    column) from a globally unique key -- with splitmix64 standing in for yakl::Random on both sides, so the two must agree bit for
+    bit, also on a rank of a decomposition (the key starts at myrank * nz*nx*ny*nens) and with the thermal applied afterwards."""
+    from miniweatherml_amd import modules
+    nx, ny, nz, nens = 24, 20, 16, 2
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 12000., 10000., 20000., nranks=nranks, myrank=rank, perturb=False)
+    odyc, of = oracle.supercell_setup(nx, ny, nz, nens, 12000., 10000., 20000., nranks=nranks, rank=rank, perturb=False)
+    push_fields(coupler, of)                                      # same starting temperature on both sides
+    t0 = of.temp.copy()
+    modules.perturb_temperature(coupler, thermal=False, random=True)
+    oracle.perturb_temperature(odyc.p, of.temp, thermal=False, random=True, myrank=rank)
+    got = coupler.get_data_manager_readonly().get("temp", True).cpu().numpy()
+    assert np.array_equal(got, of.temp)                           # the noise: bit for bit
+    push_fields(coupler, of)
+    of.temp[...] = t0
+    coupler.get_data_manager_readwrite().get("temp", True).copy_(torch.as_tensor(t0, device="cuda"))
+    modules.perturb_temperature(coupler, thermal=True, random=True)
+    oracle.perturb_temperature(odyc.p, of.temp, thermal=True, random=True, myrank=rank)
+    got = coupler.get_data_manager_readonly().get("temp", True).cpu().numpy()
+    assert np.max(np.abs(got - of.temp)) <= 1e-13 * 300.0         # + the thermal (device pow / cos: rounding level)
+    lev = nz // 4
+    d = of.temp - t0
+    assert np.all(np.abs(d[:lev]) <= 3.0 + 5.0) and np.abs(d[:lev]).max() > 1.0       # noise (<= 3 K) + bubble (<= 5 K)
+    only_noise = oracle.Fields(odyc.p).temp * 0
+    oracle.perturb_temperature(odyc.p, only_noise, thermal=False, random=True, myrank=rank)
+    assert np.all(only_noise[lev:] == 0) and np.abs(only_noise[:lev]).max() <= 3.0 and abs(only_noise[:lev].mean()) < 0.1
+    if nranks > 1:                                                # another rank draws other numbers
+        other = only_noise * 0
+        oracle.perturb_temperature(odyc.p, other, thermal=False, random=True, myrank=0)
+        assert not np.array_equal(other, only_noise)

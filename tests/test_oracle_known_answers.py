@@ -117,3 +117,26 @@ def test_weno3_limiter_properties(oracle):
     # a step: no new extrema
     coefs, gll = O3.weno5(np.array([0.0, 0.0, 1.0]))
     assert -1e-12 <= gll[0] <= 1.0 and -1e-12 <= gll[1] <= 1.0
+
+
+def test_random_temperature_perturbation_of_the_oracle(oracle):
+    """perturb_temperature(random = true), perturb_temperature.h:25-39, with splitmix64 for yakl::Random (pinned by definition):
+    lowest nz/4 levels only, |noise| <= 3 K fading linearly with height, reproducible, different on another rank."""
+    import numpy as np
+    dyc, f = oracle.supercell_setup(10, 8, 16, 2, 5000., 4000., 20000., perturb=False)
+    a = np.zeros_like(f.temp); b = np.zeros_like(f.temp); c = np.zeros_like(f.temp)
+    oracle.perturb_temperature(dyc.p, a, thermal=False, random=True)
+    oracle.perturb_temperature(dyc.p, b, thermal=False, random=True)
+    oracle.perturb_temperature(dyc.p, c, thermal=False, random=True, myrank=2)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.all(a[4:] == 0)
+    for k in range(4):
+        lim = 3.0 * (4 - k) / 4
+        assert np.abs(a[k]).max() <= lim and np.abs(a[k]).max() > 0.5 * lim
+    # the first draw, by hand: key 0 through the splitmix64 finaliser
+    z = (0 + 0x9E3779B97F4A7C15) & (2**64 - 1)
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+    z = z ^ (z >> 31)
+    u01 = (z >> 11) / 9007199254740992.0
+    assert a.reshape(16, -1)[0, 0] == (u01 * 2.0 - 1.0) * 3.0 * 1.0
