@@ -96,8 +96,9 @@ int  mw_dycore_set_bc(mw_dycore_t h, int bc_x, int bc_y, int bc_z);
  * create).  2: the general flux-materialising kernels with the fast arithmetic (A/B of the two kernel structures). */
 int  mw_dycore_set_strict(mw_dycore_t h, int strict);
 /* WENO order, the reference's compile-time -DMW_ORD (dynamics_euler_stratified_wenofv.h:24-29; 3 in build/machines/aws/aws_a100_gpu.env:21):
- * 5 (default) or 3.  Call before mw_dycore_init (the supercell initial data uses `ord` GLL points, :1725-1886).  Order 3 runs on the
- * general flux-materialising kernels. */
+ * 5 (default), 3, 7 or 9.  Call before mw_dycore_init (the supercell initial data uses `ord` GLL points, :1725-1886).  Orders 3, 7
+ * and 9 run on the general flux-materialising kernels; 7 and 9 (WenoLimiter<7> / <9>, hs = 3 / 4) re-allocate the handle's slabs
+ * with 4- / 5-cell x, y halos and 3 / 4 z levels and exchange strips of that depth. */
 int  mw_dycore_set_order(mw_dycore_t h, int ord);
 
 /* Dynamics_Euler_Stratified_WenoFV::time_step(coupler, dt_phys), :81-198: convert-in, ncycles x SSPRK3,

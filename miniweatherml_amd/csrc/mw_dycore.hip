@@ -276,7 +276,14 @@ __global__ __launch_bounds__(256) void k_unpack_y(DyP p, double *__restrict__ S,
 template <bool STRICT, int ORD = 5>
 __device__ __forceinline__ double edge_value(const double *__restrict__ q, long long st, int right) {
   double l, r;
-  if (ORD == 3) { if (STRICT) weno3_edges_strict(q[-st], q[0], q[st], l, r); else weno3_edges_fast(q[-st], q[0], q[st], l, r); }
+  if (ORD == 7 || ORD == 9) {
+    constexpr int h = (ORD - 1) / 2;
+    double s[ORD];
+#pragma unroll
+    for (int m = 0; m < ORD; m++) s[m] = q[(long long)(m - h) * st];
+    if (STRICT) weno79_edges_strict<ORD>(s, l, r); else weno79_edges_fast<ORD>(s, l, r);
+  }
+  else if (ORD == 3) { if (STRICT) weno3_edges_strict(q[-st], q[0], q[st], l, r); else weno3_edges_fast(q[-st], q[0], q[st], l, r); }
   else if (STRICT) weno5_edges_strict(q[-2 * st], q[-st], q[0], q[st], q[2 * st], l, r);
   else             weno5_edges_fast  (q[-2 * st], q[-st], q[0], q[st], q[2 * st], l, r);
   return right ? r : l;
@@ -619,6 +626,8 @@ __constant__ double c_gll9_wts[9] = {0.013888888888888888888888888888888888889, 
                                      0.18575963718820861678004535147392290249, 0.17321425548652317255756576606985914397,
                                      0.13726935625008086764035280928968636297, 0.082747680780402762523169860014604152919,
                                      0.013888888888888888888888888888888888889};     // :4126-4137
+__constant__ double c_gll7_pts[7] = MW_GLL7_PTS;                                    // get_gll_points / _weights(SArray<FP,1,7>): mw_weno79.h
+__constant__ double c_gll7_wts[7] = MW_GLL7_WTS;
 __constant__ double c_gl3_pts[3] = {0.112701665379258311482073460022, 0.500000000000000000000000000000,
                                     0.887298334620741688517926539980};                // :1349-1351
 __constant__ double c_gl3_wts[3] = {0.277777777777777777777777777779, 0.444444444444444444444444444444,
@@ -637,7 +646,8 @@ __global__ __launch_bounds__(256) void k_init_cells(DyP p, InitP q, CouplerPtrs 
   const double dx = p.dx, dy = p.dy, dz = p.dz;
   if (q.init_data == MW_DATA_SUPERCELL) {                     // :1843-1886  (ord GLL points per direction)
     const int no = q.ord;
-    const double *gp = (no == 3) ? c_gll3_pts : c_gll5_pts, *gw = (no == 3) ? c_gll3_wts : c_gll5_wts;
+    const double *gp = (no == 3) ? c_gll3_pts : (no == 7) ? c_gll7_pts : (no == 9) ? c_gll9_pts : c_gll5_pts;
+    const double *gw = (no == 3) ? c_gll3_wts : (no == 7) ? c_gll7_wts : (no == 9) ? c_gll9_wts : c_gll5_wts;
     for (int kk = 0; kk < no; kk++) for (int jj = 0; jj < no; jj++) for (int ii = 0; ii < no; ii++) {
       double zloc = (k + 0.5) * dz + gp[kk] * dz;
       double dens = q.hyDensGLL[k * no + kk];
@@ -819,7 +829,8 @@ struct mw_dycore_s {
   double etime = 0;
   int strict = 0;
   int member_major = 0;                      // production path with nens > 1: the handle's arrays hold one member after the other (View)
-  int ord = 5;                               // WENO order (3: the reference's -DMW_ORD=3 build; runs on the general kernels)
+  int ord = 5;                               // WENO order (3, 7, 9: the reference's -DMW_ORD builds; they run on the general kernels)
+  int hxw = HXc, hzw = HZc;                  // halo widths of the slabs: hs + 1 in x / y, hs in z (3 / 2 up to order 5)
   // halo exchange
   mw_exchange_fn xchg = nullptr; void *xchg_ctx = nullptr;
   double *bufs[2][8] = {{nullptr}, {nullptr}};   // [group: 0 state (or all), 1 tracers][sW sE sS sN rW rE rS rN]
@@ -844,7 +855,7 @@ static void fill_params(mw_dycore_s *d) {
   const mw_grid_t &g = d->g;  DyP &p = d->p;
   p.nz = g.nz; p.ny = g.ny; p.nx = g.nx; p.nens = g.nens; p.nt = g.num_tracers; p.V = 5 + g.num_tracers;
   p.sim2d = (g.ny_glob == 1);
-  p.HX = HXc; p.HY = p.sim2d ? 0 : HXc; p.HZ = HZc;
+  p.HX = d->hxw; p.HY = p.sim2d ? 0 : d->hxw; p.HZ = d->hzw;
   p.NXE = (g.nx + 2 * p.HX) * g.nens;
   p.sJ = p.NXE; p.sK = (long long)(g.ny + 2 * p.HY) * p.sJ; p.sV = (long long)(g.nz + 2 * p.HZ) * p.sK;
   p.nC = (long long)g.nz * g.ny * g.nx * g.nens;
@@ -1026,6 +1037,12 @@ static int launch_flux(mw_dycore_s *d, const double *S) {
   if (d->ord == 3) {
     if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 3>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
     else                hipLaunchKernelGGL((k_flux<false, 3>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+  } else if (d->ord == 7) {
+    if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 7>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    else                hipLaunchKernelGGL((k_flux<false, 7>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+  } else if (d->ord == 9) {
+    if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 9>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    else                hipLaunchKernelGGL((k_flux<false, 9>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
   } else {
     if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 5>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
     else                hipLaunchKernelGGL((k_flux<false, 5>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
@@ -1461,8 +1478,29 @@ int mw_dycore_set_bc(mw_dycore_t d, int bc_x, int bc_y, int bc_z) {
 int mw_dycore_set_strict(mw_dycore_t d, int strict) { if (!d) MW_FAIL("null handle"); d->strict = strict; return 0; }
 int mw_dycore_set_order(mw_dycore_t d, int ord) {
   if (!d) MW_FAIL("null handle");
-  if (ord != 3 && ord != 5) MW_FAIL("WENO order must be 3 or 5 (MW_ORD 7 and 9 are not built)");
+  if (ord != 3 && ord != 5 && ord != 7 && ord != 9) MW_FAIL("WENO order must be 3, 5, 7 or 9");
   d->ord = ord;
+  // orders 7 and 9 reach further: x / y halo hs + 1 (the neighbour's edge value is rebuilt locally), z halo hs
+  const int hs = (ord - 1) / 2, hx = std::max(HXc, hs + 1), hz = std::max(HZc, hs);
+  if (hx != d->hxw || hz != d->hzw) {
+    MW_HIP(hipStreamSynchronize(d->stream));
+    if (d->tstream) MW_HIP(hipStreamSynchronize(d->tstream));
+    d->hxw = hx; d->hzw = hz;
+    fill_params(d);
+    const size_t slab = (size_t)d->p.V * d->p.sV * sizeof(double);
+    for (double **S : {&d->S0, &d->S1, &d->S2, &d->S3}) {
+      if (*S) (void)hipFree(*S);
+      *S = nullptr;
+      MW_HIP(hipMalloc(S, slab));
+      MW_HIP(hipMemsetAsync(*S, 0, slab, d->stream));           // halo corners are never written (as in create)
+    }
+    d->nWE1 = (long long)d->p.nz * d->p.ny * d->p.HX * d->p.nens;
+    d->nSN1 = (long long)d->p.nz * d->p.HY * d->p.nx * d->p.nens;
+    bool had = false;
+    for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) { (void)hipFree(d->bufs[g][b]); d->bufs[g][b] = nullptr; had = true; }
+    if (had && mw_dycore_set_exchange(d, d->xchg, d->xchg_ctx)) return 1;   // strips are HX / HY cells deep: re-allocate
+    MW_HIP(hipStreamSynchronize(d->stream));
+  }
   return 0;
 }
 
@@ -1770,7 +1808,9 @@ extern "C" int mw_dycore_init(mw_dycore_t d, int init_data, double *rho_d, doubl
   const double dz = g.zlen / g.nz, dx = g.xlen / g.nx_glob;
   const double h_gll3_pts[3] = {-0.50000000000000000000000000000000000000, 0.00000000000000000000000000000000000000, 0.50000000000000000000000000000000000000};   // TransformMatrices.h:83-88
   const double h_gll3_wts[3] = {0.16666666666666666666666666666666666667, 0.66666666666666666666666666666666666667, 0.16666666666666666666666666666666666667};   // :90-95
-  const double *h_gllN_pts = (ord == 3) ? h_gll3_pts : h_gll5_pts, *h_gllN_wts = (ord == 3) ? h_gll3_wts : h_gll5_wts;
+  const double h_gll7_pts[7] = MW_GLL7_PTS, h_gll7_wts[7] = MW_GLL7_WTS;
+  const double *h_gllN_pts = (ord == 3) ? h_gll3_pts : (ord == 7) ? h_gll7_pts : (ord == 9) ? h_gll9_pts : h_gll5_pts;
+  const double *h_gllN_wts = (ord == 3) ? h_gll3_wts : (ord == 7) ? h_gll7_wts : (ord == 9) ? h_gll9_wts : h_gll5_wts;
   size_t nzc = (size_t)nz * nens, nze = (size_t)(nz + 1) * nens;
   double *hyc = d->hy_host.data(), *hytc = hyc + nzc, *hye = hyc + 2 * nzc, *hyte = hye + nze;
   std::vector<double> gllcols;     // supercell: hyDensGLL | hyDensThetaGLL | hyDensVapGLL, each (nz,5)

@@ -174,4 +174,78 @@ __device__ __forceinline__ void weno3_edges_fast(double s0, double s1, double s2
   weno3_edges_body<false>(s0, s1, s2, left, right);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// WENO-7 and WENO-9 (MW_ORD = 7 / 9, dynamics_euler_stratified_wenofv.h:24-28): weno::WenoLimiter<7> / <9>::compute_limited_coefs
+// (helpers/WenoLimiter.h:95-137, :141-194) -- the three 3-cell candidates around the centre as in WENO-5, the high-order
+// candidate over all N cells, ideal weights 1, 2, 1, 1e5 (1e8) convexified -- + coefs_to_gll_lower<N,2>.  The polynomial-fit and
+// total-variation constants come from mw_weno79.h, which tools/gen_weno_tables.py derives from their definitions.
+// Always the reference's operation order with contraction off (see weno79_edges_fast).
+// ---------------------------------------------------------------------------------------------------------------------
+} // namespace mw
+#include "mw_weno79.h"
+namespace mw {
+
+template <int N, bool STRICT>
+__device__ __forceinline__ void weno79_edges_body(const double *s, double &left, double &right) {
+#pragma clang fp contract(off)
+  constexpr int c = (N - 1) / 2;                                               // centre cell of the stencil
+  const double s0 = s[c - 1], s1 = s[c], s2 = s[c + 1];
+  // coefs3_shift1(s[c-2], s[c-1], s[c]), coefs3_shift2(s[c-1], s[c], s[c+1]), coefs3_shift3(s[c], s[c+1], s[c+2]) (WenoLimiter_recon.h:84-103)
+  const double m2 = s[c - 2], p2 = s[c + 2];
+  double L[3], C[3], R[3], H[N];
+  L[0] = -MW_C(0.041666666666666666666666666666666666667)*m2+MW_C(0.083333333333333333333333333333333333333)*s0+MW_C(0.95833333333333333333333333333333333333)*s1;
+  L[1] = MW_C(0.5)*m2-MW_C(2.0)*s0+MW_C(1.5)*s1;
+  L[2] = MW_C(0.5)*m2-MW_C(1.0)*s0+MW_C(0.5)*s1;
+  C[0] = -MW_C(0.041666666666666666666666666666666666667)*s0+MW_C(1.0833333333333333333333333333333333333)*s1-MW_C(0.041666666666666666666666666666666666667)*s2;
+  C[1] = -MW_C(0.5)*s0+MW_C(0.5)*s2;
+  C[2] = MW_C(0.5)*s0-MW_C(1.0)*s1+MW_C(0.5)*s2;
+  R[0] = MW_C(0.95833333333333333333333333333333333333)*s1+MW_C(0.083333333333333333333333333333333333333)*s2-MW_C(0.041666666666666666666666666666666666667)*p2;
+  R[1] = -MW_C(1.5)*s1+MW_C(2.0)*s2-MW_C(0.5)*p2;
+  R[2] = MW_C(0.5)*s1-MW_C(1.0)*s2+MW_C(0.5)*p2;
+  if (N == 7) mw_coefs7(H, s[0], s[1], s[2], s[3], s[4], s[5], s[6]);
+  else        mw_coefs9(H, s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[N - 1]);
+  double wL = MW_C(1.0)*(L[1]*L[1])+MW_C(4.3333333333333333333333333333333333333)*(L[2]*L[2]);
+  double wC = MW_C(1.0)*(C[1]*C[1])+MW_C(4.3333333333333333333333333333333333333)*(C[2]*C[2]);
+  double wR = MW_C(1.0)*(R[1]*R[1])+MW_C(4.3333333333333333333333333333333333333)*(R[2]*R[2]);
+  double wH = (N == 7) ? mw_tv7(H) : mw_tv9(H);
+  double tot = wL + wC + wR + wH;
+  if (tot > 1.e-20) { wL /= tot; wC /= tot; wR /= tot; wH /= tot; }
+  double iL = 1.0, iC = 2.0, iR = 1.0, iH = (N == 7) ? 1.e5 : 1.e8;             // ctor: convexify(1, 2, 1, 1e5 | 1e8)
+  { const double it = iL + iC + iR + iH; iL /= it; iC /= it; iR /= it; iH /= it; }
+  wL = iL / (wL*wL + 1.e-20);
+  wC = iC / (wC*wC + 1.e-20);
+  wR = iR / (wR*wR + 1.e-20);
+  wH = iH / (wH*wH + 1.e-20);
+  tot = wL + wC + wR + wH;
+  if (tot > 1.e-20) { wL /= tot; wC /= tot; wR /= tot; wH /= tot; }
+  if (wL <= 0.0) wL = 0;                                                        // cutoff == 0
+  if (wC <= 0.0) wC = 0;
+  if (wR <= 0.0) wR = 0;
+  tot = wL + wC + wR + wH;
+  if (tot > 1.e-20) { wL /= tot; wC /= tot; wR /= tot; wH /= tot; }
+  H[0] = H[0]*wH + L[0]*wL + C[0]*wC + R[0]*wR;
+  H[1] = H[1]*wH + L[1]*wL + C[1]*wC + R[1]*wR;
+  H[2] = H[2]*wH + L[2]*wL + C[2]*wC + R[2]*wR;
+#pragma unroll
+  for (int m = 3; m < N; m++) H[m] = H[m]*wH;
+  // coefs_to_gll_lower<N,2>: tmp = 0 + sum_s (-+1/2)^s * coef_s, in that order
+  double lo = H[0], hi = H[0], pw = 1.0;
+#pragma unroll
+  for (int m = 1; m < N; m++) { pw *= 0.5; lo = lo + ((m & 1) ? -pw : pw) * H[m]; hi = hi + pw * H[m]; }
+  left = lo; right = hi;
+}
+template <int N>
+__device__ __forceinline__ void weno79_edges_strict(const double *s, double &left, double &right) {
+#pragma clang fp contract(off)
+  weno79_edges_body<N, true>(s, left, right);
+}
+// (No contracted variant: the 9-cell fit and its total variation cancel over constants up to 1.8e9 with an ideal weight of 1e8, and
+//  FMA contraction alone moved a supercell step by 1.3e-11 of the field's scale -- more than the 1e-11 the parity tests allow.
+//  These orders are not a performance path; both run-time modes use the reference's operation order.)
+template <int N>
+__device__ __forceinline__ void weno79_edges_fast(const double *s, double &left, double &right) {
+#pragma clang fp contract(off)
+  weno79_edges_body<N, false>(s, left, right);
+}
+
 } // namespace mw

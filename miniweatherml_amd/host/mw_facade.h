@@ -204,7 +204,7 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
   double *f_rho = nullptr, *f_u = nullptr, *f_v = nullptr, *f_w = nullptr, *f_T = nullptr;
  public:
 #ifndef MW_ORD
-  int static constexpr ord = 5;                                       // :24-28 (compile with -DMW_ORD=3 for the reference's order-3 build)
+  int static constexpr ord = 5;                                       // :24-28 (compile with -DMW_ORD=3 | 7 | 9 for the reference's other orders)
 #else
   int static constexpr ord = MW_ORD;
 #endif

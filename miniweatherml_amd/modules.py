@@ -38,8 +38,8 @@ class Dynamics_Euler_Stratified_WenoFV:
     idR, idU, idV, idW, idT = 0, 1, 2, 3, 4
 
     def __init__(self, ord=5):
-        if ord not in (3, 5):
-            endrun("ERROR: WENO order must be 3 or 5")
+        if ord not in (3, 5, 7, 9):
+            endrun("ERROR: WENO order must be 3, 5, 7 or 9")
         self.ord, self.hs = ord, (ord - 1) // 2
         self.h = C.c_void_p(None)
         self.etime = 0.0

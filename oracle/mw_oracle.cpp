@@ -40,11 +40,11 @@ typedef double real;
 
 // The reference selects the reconstruction order at COMPILE time (-DMW_ORD=3 in build/machines/aws/aws_a100_gpu.env:21; default 5,
 // dynamics_euler_stratified_wenofv.h:24-28).  So does this restatement: oracle/Makefile builds libmw_oracle.so (ord 5) and
-// libmw_oracle_ord3.so (-DMW_ORD=3).
+// libmw_oracle_ord{3,7,9}.so (-DMW_ORD=3 / 7 / 9).
 #ifndef MW_ORD
 #define MW_ORD 5
 #endif
-static_assert(MW_ORD == 3 || MW_ORD == 5, "restated orders: 3 and 5");
+static_assert(MW_ORD == 3 || MW_ORD == 5 || MW_ORD == 7 || MW_ORD == 9, "restated orders: 3, 5, 7 and 9");
 static const int ord = MW_ORD;          // dynamics_euler_stratified_wenofv.h:24-28
 static const int hs  = (MW_ORD-1)/2;    // :29
 static const int num_state = 5;          // :31
@@ -194,7 +194,82 @@ struct Weno5 {   // WenoLimiter.h:53-66: default ctor arguments cutoff 0, idl 1,
   }
 };
 
-#if MW_ORD == 3
+// Orders 7 and 9.  The polynomial-fit and total-variation constants (WenoLimiter_recon.h:58-70, :182-205) and the Gauss-Lobatto
+// rules are DERIVED, not transcribed: tools/gen_weno_tables.py computes them from their definitions in exact arithmetic, rounds
+// them the way the reference's `_fp` literals are rounded, and writes weno79.inc; tools/check_weno_tables.py found all 155 + 32
+// constants, and the order of the terms, identical to the reference's (in the container that holds it).
+#define REAL real
+#include "weno79.inc"
+struct Weno7 {   // WenoLimiter.h:95-137: default ctor arguments cutoff 0, idl 1,2,1,1e5, convexified
+  real cutoff, idl_L, idl_C, idl_R, idl_H;
+  Weno7() { cutoff = 0; idl_L = 1; idl_C = 2; idl_R = 1; idl_H = 1.e5; convexify4(idl_L, idl_C, idl_R, idl_H); }
+  void compute_limited_coefs(const real *s, real *coefs_H) const {   // WenoLimiter.h:112-136
+    real coefs_L[3], coefs_C[3], coefs_R[3];
+    coefs3_shift1( coefs_L , s[1] , s[2] , s[3] );
+    coefs3_shift2( coefs_C , s[2] , s[3] , s[4] );
+    coefs3_shift3( coefs_R , s[3] , s[4] , s[5] );
+    mw_coefs7    ( coefs_H , s[0] , s[1] , s[2] , s[3] , s[4] , s[5] , s[6] );
+    real w_L = TV3( coefs_L );
+    real w_C = TV3( coefs_C );
+    real w_R = TV3( coefs_R );
+    real w_H = mw_tv7( coefs_H );
+    convexify4( w_L , w_C , w_R , w_H );
+    w_L = idl_L / (w_L*w_L + 1.e-20);
+    w_C = idl_C / (w_C*w_C + 1.e-20);
+    w_R = idl_R / (w_R*w_R + 1.e-20);
+    w_H = idl_H / (w_H*w_H + 1.e-20);
+    convexify4( w_L , w_C , w_R , w_H );
+    if (w_L <= cutoff) w_L = 0;
+    if (w_C <= cutoff) w_C = 0;
+    if (w_R <= cutoff) w_R = 0;
+    convexify4( w_L , w_C , w_R , w_H );
+    coefs_H[0] = coefs_H[0]*w_H + coefs_L[0]*w_L + coefs_C[0]*w_C + coefs_R[0]*w_R;
+    coefs_H[1] = coefs_H[1]*w_H + coefs_L[1]*w_L + coefs_C[1]*w_C + coefs_R[1]*w_R;
+    coefs_H[2] = coefs_H[2]*w_H + coefs_L[2]*w_L + coefs_C[2]*w_C + coefs_R[2]*w_R;
+    for (int m = 3; m < 7; m++) coefs_H[m] = coefs_H[m]*w_H;
+  }
+};
+struct Weno9 {   // WenoLimiter.h:141-194: default ctor arguments cutoff 0, idl 1,2,1,1e8, convexified
+  real cutoff, idl_L, idl_C, idl_R, idl_H;
+  Weno9() { cutoff = 0; idl_L = 1; idl_C = 2; idl_R = 1; idl_H = 1.e8; convexify4(idl_L, idl_C, idl_R, idl_H); }
+  void compute_limited_coefs(const real *s, real *coefs_H) const {   // WenoLimiter.h:158-193
+    real coefs_L[3], coefs_C[3], coefs_R[3];
+    coefs3_shift1( coefs_L , s[2] , s[3] , s[4] );
+    coefs3_shift2( coefs_C , s[3] , s[4] , s[5] );
+    coefs3_shift3( coefs_R , s[4] , s[5] , s[6] );
+    mw_coefs9    ( coefs_H , s[0] , s[1] , s[2] , s[3] , s[4] , s[5] , s[6] , s[7] , s[8] );
+    real w_L = TV3( coefs_L );
+    real w_C = TV3( coefs_C );
+    real w_R = TV3( coefs_R );
+    real w_H = mw_tv9( coefs_H );
+    convexify4( w_L , w_C , w_R , w_H );
+    w_L = idl_L / (w_L*w_L + 1.e-20);
+    w_C = idl_C / (w_C*w_C + 1.e-20);
+    w_R = idl_R / (w_R*w_R + 1.e-20);
+    w_H = idl_H / (w_H*w_H + 1.e-20);
+    convexify4( w_L , w_C , w_R , w_H );
+    if (w_L <= cutoff) w_L = 0;
+    if (w_C <= cutoff) w_C = 0;
+    if (w_R <= cutoff) w_R = 0;
+    convexify4( w_L , w_C , w_R , w_H );
+    coefs_H[0] = coefs_H[0]*w_H + coefs_L[0]*w_L + coefs_C[0]*w_C + coefs_R[0]*w_R;
+    coefs_H[1] = coefs_H[1]*w_H + coefs_L[1]*w_L + coefs_C[1]*w_C + coefs_R[1]*w_R;
+    coefs_H[2] = coefs_H[2]*w_H + coefs_L[2]*w_L + coefs_C[2]*w_C + coefs_R[2]*w_R;
+    for (int m = 3; m < 9; m++) coefs_H[m] = coefs_H[m]*w_H;
+  }
+};
+
+#if MW_ORD == 7
+typedef Weno7 WenoLim;
+static const real coefs_to_gll[7][2] = MW_C2G7;          // TransformMatrices.h coefs_to_gll_lower(SArray<FP,2,7,2>): (-+1/2)^s
+static const real gll_pts[7] = MW_GLL7_PTS;               // get_gll_points / get_gll_weights (SArray<FP,1,7>)
+static const real gll_wts[7] = MW_GLL7_WTS;
+#elif MW_ORD == 9
+typedef Weno9 WenoLim;
+static const real coefs_to_gll[9][2] = MW_C2G9;
+static const real gll_pts[9] = MW_GLL9_PTS;
+static const real gll_wts[9] = MW_GLL9_WTS;
+#elif MW_ORD == 3
 typedef Weno3 WenoLim;
 // TransformMatrices.h:300-308  coefs_to_gll_lower(SArray<FP,2,3,2>);  :83-95  get_gll_points / get_gll_weights (SArray<FP,1,3>)
 static const real coefs_to_gll[3][2] = { {1,1}, {-0.50000000000000000000000000000000000000,0.50000000000000000000000000000000000000},

@@ -15,22 +15,22 @@ _LIB_PATH = os.path.join(_HERE, globals().get("_MW_ORACLE_LIB_NAME", "libmw_orac
 
 
 def with_order(order):
-    """This module bound to the oracle build of the given WENO order (3 or 5)."""
+    """This module bound to the oracle build of the given WENO order (3, 5, 7 or 9)."""
     import importlib.util
     import sys
     if order == 5:
         return sys.modules[__name__]
-    if order != 3:
-        raise ValueError("oracle builds exist for WENO orders 3 and 5")
-    name = __name__ + "_ord3"
+    if order not in (3, 7, 9):
+        raise ValueError("oracle builds exist for WENO orders 3, 5, 7 and 9")
+    name = __name__ + "_ord%d" % order
     if name in sys.modules:
         return sys.modules[name]
     spec = importlib.util.spec_from_file_location(name, os.path.abspath(__file__))
     mod = importlib.util.module_from_spec(spec)
-    mod._MW_ORACLE_LIB_NAME = "libmw_oracle_ord3.so"
+    mod._MW_ORACLE_LIB_NAME = "libmw_oracle_ord%d.so" % order
     sys.modules[name] = mod
     spec.loader.exec_module(mod)
-    assert mod.lib().mwo_order() == 3
+    assert mod.lib().mwo_order() == order
     return mod
 
 DATA_THERMAL, DATA_SUPERCELL, DATA_CITY, DATA_BUILDING = 0, 1, 2, 3
@@ -66,8 +66,9 @@ _lib = None
 def build(force=False):
     """Compile oracle/libmw_oracle.so with the committed Makefile (g++, seconds)."""
     src = os.path.join(_HERE, "mw_oracle.cpp")
-    libs = [os.path.join(_HERE, n) for n in ("libmw_oracle.so", "libmw_oracle_ord3.so")]
-    if force or any(not os.path.exists(l) or os.path.getmtime(l) < os.path.getmtime(src) for l in libs):
+    libs = [os.path.join(_HERE, n) for n in ("libmw_oracle.so", "libmw_oracle_ord3.so", "libmw_oracle_ord7.so", "libmw_oracle_ord9.so")]
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "weno79.inc")))
+    if force or any(not os.path.exists(l) or os.path.getmtime(l) < newest for l in libs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 

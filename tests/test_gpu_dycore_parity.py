@@ -386,9 +386,12 @@ ORD3_CASES = {
 
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("name", sorted(ORD3_CASES))
-def test_weno_order_3(mw, oracle, name, mode):
+@pytest.mark.parametrize("order", [3, 7, 9])
+def test_weno_orders_3_7_9(mw, oracle, name, mode, order):
+    """MW_ORD = 3, 7, 9 (dynamics_euler_stratified_wenofv.h:24-28).  Orders 7 / 9: WenoLimiter<7> / <9> (hs = 3 / 4: the slabs get
+    4- / 5-cell x, y halos and 3 / 4 z levels), `ord`-point GLL initial data; oracle = the restatement compiled with -DMW_ORD."""
     from miniweatherml_amd import modules
-    O3 = oracle.with_order(3)
+    O3 = oracle.with_order(order)
     nx, ny, nz, nens, xlen, ylen, zlen, init, nt, grav = ORD3_CASES[name]
     micro = None
     if nt == 1:
@@ -397,24 +400,28 @@ def test_weno_order_3(mw, oracle, name, mode):
                 coupler.add_tracer("water_vapor", "Water Vapor", True, True)
         micro = OneTracer()
     coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, zlen, init, micro=micro, enable_gravity=grav,
-                                                perturb=(init == "supercell"), ord=3)
+                                                perturb=(init == "supercell"), ord=order)
     odyc, of = O3.supercell_setup(nx, ny, nz, nens, xlen, ylen, zlen, init_data=init, num_tracers=nt, enable_gravity=grav,
                                   perturb=(init == "supercell"))
-    assert dycore.ord == 3 and dycore.hs == 1
+    assert dycore.ord == order and dycore.hs == (order - 1) // 2
     hy = odyc.hy()
     for k in ("hy_dens_cells", "hy_dens_theta_cells", "hy_dens_edges", "hy_dens_theta_edges"):
         assert np.array_equal(getattr(dycore, k), hy[k]), k          # `ord`-point GLL columns on the host: bitwise
-    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-13, "ord3 init " + name)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-13, "ord%d init %s" % (order, name))
     push_fields(coupler, of)
     dycore.set_strict(mode)
     dt = dycore.compute_time_step(coupler)
     dycore.time_step(coupler, dt)
     odyc.time_step(of, dt)
-    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "ord3 %s mode %d, 1 step" % (name, mode))
+    # Order 9: at the rim of the warm bubble the candidates' total variations sit at the 1e-20 switch of `convexify` (normalise or
+    # not, WenoLimiter_recon.h:12-15) -- a discontinuity of the scheme: last-bit differences of stage 1 (device pow / exp) flip it
+    # in ~20 cells of the 2-D case and move them by up to 1.3e-11 of the field's scale (order 7 and every other order-9 case: 1e-13).
+    tol1 = 1e-10 if order == 9 else 1e-11
+    compare_fields(gpu_fields(coupler), of.as_dict(), tol1, "ord%d %s mode %d, 1 step" % (order, name, mode))
     for _ in range(9):
         dycore.time_step(coupler, dt)
         odyc.time_step(of, dt)
-    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-9, "ord3 %s mode %d, 10 steps" % (name, mode))
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-9, "ord%d %s mode %d, 10 steps" % (order, name, mode))
     # and it is not the order-5 scheme
     o5, f5 = oracle.supercell_setup(nx, ny, nz, nens, xlen, ylen, zlen, init_data=init, num_tracers=nt, enable_gravity=grav,
                                     perturb=(init == "supercell"))

@@ -15,7 +15,7 @@ from util import Exchanger, OracleExchanger, compare_fields, gpu_fields, push_fi
 pytestmark = pytest.mark.gpu
 
 
-def run_ranks(nranks, nxg, nyg, nz, nens, nsteps):
+def run_ranks(nranks, nxg, nyg, nz, nens, nsteps, ord=5):
     from miniweatherml_amd import capi, modules
     xlen, ylen = 500.0 * nxg, (500.0 * nyg if nyg > 1 else 1.0e5)
     ex = Exchanger(nranks)
@@ -24,7 +24,7 @@ def run_ranks(nranks, nxg, nyg, nz, nens, nsteps):
 
     def worker(rank):
         try:
-            coupler, dycore, _ = modules.make_supercell(nxg, nyg, nz, nens, xlen, ylen, 20000., nranks=nranks, myrank=rank)
+            coupler, dycore, _ = modules.make_supercell(nxg, nyg, nz, nens, xlen, ylen, 20000., nranks=nranks, myrank=rank, ord=ord)
             cb = ex.make_cb(rank, coupler.grid)
             keep.append(cb)
             capi.check(capi.lib().mw_dycore_set_exchange(dycore.h, cb, None))
@@ -44,7 +44,7 @@ def run_ranks(nranks, nxg, nyg, nz, nens, nsteps):
         t.join(300)
     assert not ex.errors, ex.errors
     # single-rank reference on the same GPU
-    coupler, dycore, _ = modules.make_supercell(nxg, nyg, nz, nens, xlen, ylen, 20000.)
+    coupler, dycore, _ = modules.make_supercell(nxg, nyg, nz, nens, xlen, ylen, 20000., ord=ord)
     dt = dycore.compute_time_step(coupler)
     for _ in range(nsteps):
         dycore.time_step(coupler, dt)
@@ -65,6 +65,13 @@ def test_four_ranks_2x2(mw):
 
 def test_eight_ranks_4x2_nens2(mw):
     run_ranks(8, 48, 24, 8, 2, 2)
+
+
+@pytest.mark.parametrize("ord", [3, 7, 9])
+def test_four_ranks_other_weno_orders(mw, ord):
+    """Orders 7 / 9 exchange 4- / 5-cell strips (hs + 1); the exchange is installed AFTER the order is set here, and the
+    buffers follow the halo width either way (mw_dycore_set_order re-allocates them)."""
+    run_ranks(4, 24, 20, 10, 1, 2, ord=ord)
 
 
 def test_two_ranks_2d(mw):

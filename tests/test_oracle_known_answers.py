@@ -140,3 +140,49 @@ def test_random_temperature_perturbation_of_the_oracle(oracle):
     z = z ^ (z >> 31)
     u01 = (z >> 11) / 9007199254740992.0
     assert a.reshape(16, -1)[0, 0] == (u01 * 2.0 - 1.0) * 3.0 * 1.0
+
+
+@pytest.mark.parametrize("order", [7, 9])
+def test_weno_7_and_9_limiter_properties(oracle, order):
+    """WenoLimiter<7> / <9> of the -DMW_ORD=7 / 9 oracle builds.  Independent of the reference: constants, cell averages of a
+    polynomial of degree <= 2 are reproduced exactly at both edges (all four candidates agree, whatever the weights), smooth data give
+    the full-order edge values (the high-order candidate carries ~1 of the weight), a step creates no new extremum."""
+    import numpy as np
+    from numpy.polynomial import polynomial as P
+    Oo = oracle.with_order(order)
+    assert Oo.lib().mwo_order() == order
+    h = (order - 1) // 2
+    xs = np.arange(-h, h + 1, dtype=np.float64)
+
+    def averages(c):                                            # cell averages of sum c_m x^m over the unit cells centred at xs
+        ci = P.polyint(c)
+        return P.polyval(xs + 0.5, ci) - P.polyval(xs - 0.5, ci)
+
+    coefs, gll = Oo.weno5(np.full(order, 3.0))
+    assert np.allclose(coefs, [3.0] + [0.0] * (order - 1), atol=1e-14) and np.allclose(gll, [3.0, 3.0], atol=1e-14)
+    c = np.array([0.7, -1.3, 0.4])
+    coefs, gll = Oo.weno5(averages(c))
+    assert np.allclose(gll, [P.polyval(-0.5, c), P.polyval(0.5, c)], rtol=0, atol=1e-12)
+    c = np.array([1.0, 0.3, -0.02, 0.003, 5e-4, -2e-4, 1e-4, 3e-5, -1e-5][:order])            # smooth: the curvature terms are small
+    coefs, gll = Oo.weno5(averages(c))
+    assert np.allclose(gll, [P.polyval(-0.5, c), P.polyval(0.5, c)], rtol=0, atol=1e-7)     # limited: next to, not at, full order
+    low = Oo.weno5(averages(np.concatenate([c[:3], np.zeros(order - 3)])))[1]                # what a parabola alone would give
+    assert np.max(np.abs(low - [P.polyval(-0.5, c), P.polyval(0.5, c)])) > 1e-4
+    s = np.zeros(order); s[h + 1:] = 1.0
+    coefs, gll = Oo.weno5(s)
+    assert -1e-10 <= gll[0] <= 1.0 + 1e-10 and -1e-10 <= gll[1] <= 1.0 + 1e-10
+
+
+def test_weno_7_9_tables_equal_the_reference_literals():
+    """tools/gen_weno_tables.py derives the 155 fit / total-variation constants and the 7- and 9-point Gauss-Lobatto rules; where the
+    reference tree is at hand (this container, not the GPU box) every one of them -- and the order of the terms -- is compared with the
+    reference's `_fp` literals as doubles."""
+    import os
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/model/modules/helpers"):
+        pytest.skip("reference tree not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_weno_tables.py")], capture_output=True, text=True)
+    assert r.returncode == 0 and "DIFFERENT" not in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("identical") == 8
