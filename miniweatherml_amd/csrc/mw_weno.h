@@ -137,42 +137,43 @@ __device__ __forceinline__ void weno5_edges_fast(double s0, double s1, double s2
 // WenoLimiter_recon.h:72-96; TV :29-42) + coefs_to_gll_lower<3,2> (TransformMatrices.h:300-308).  STRICT: the reference's
 // operation order, contraction off; otherwise the same statements with FMA contraction.
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool STRICT>
-__device__ __forceinline__ void weno3_edges_body(double s0, double s1, double s2, double &left, double &right) {
-  const double L0 = 1.0 * s1, L1 = -1.0 * s0 + 1.0 * s1;                        // coefs2_shift1(s0, s1)
-  const double R0 = 1.0 * s1, R1 = -1.0 * s1 + 1.0 * s2;                        // coefs2_shift2(s1, s2)
-  const double H0 = -MW_C(0.041666666666666666666666666666666666667)*s0+MW_C(1.0833333333333333333333333333333333333)*s1-MW_C(0.041666666666666666666666666666666666667)*s2;
-  const double H1 = -MW_C(0.5)*s0+MW_C(0.5)*s2;
-  const double H2 = MW_C(0.5)*s0-MW_C(1.0)*s1+MW_C(0.5)*s2;
-  double wL = 1.0 * (L1 * L1), wR = 1.0 * (R1 * R1);
-  double wH = 1.0 * (H1 * H1) + MW_C(4.3333333333333333333333333333333333333) * (H2 * H2);
-  double tot = wL + wR + wH;
-  if (tot > 1.e-20) { wL /= tot; wR /= tot; wH /= tot; }
-  const double itot = 1.0 + 1.0 + 5.e2;                                          // ctor: convexify(1, 1, 5e2)
-  const double iL = 1.0 / itot, iR = 1.0 / itot, iH = 5.e2 / itot;
-  wL = iL / (wL * wL + 1.e-20);
-  wR = iR / (wR * wR + 1.e-20);
-  wH = iH / (wH * wH + 1.e-20);
-  tot = wL + wR + wH;
-  if (tot > 1.e-20) { wL /= tot; wR /= tot; wH /= tot; }
-  if (wL <= 0.0) wL = 0;                                                         // cutoff == 0
-  if (wR <= 0.0) wR = 0;
-  tot = wL + wR + wH;
-  if (tot > 1.e-20) { wL /= tot; wR /= tot; wH /= tot; }
-  const double c0 = H0 * wH + L0 * wL + R0 * wR;
-  const double c1 = H1 * wH + L1 * wL + R1 * wR;
-  const double c2 = H2 * wH;
-  left  = (c0 + (-0.5) * c1) + 0.25 * c2;
+// (The statements live in a macro and are expanded inside both functions: a `#pragma clang fp contract` binds lexically, it does
+//  not follow a call into a helper.)
+#define MW_WENO3_STATEMENTS(s0, s1, s2, left, right)                                                                          \
+  const double L0 = 1.0 * s1, L1 = -1.0 * s0 + 1.0 * s1;                        /* coefs2_shift1(s0, s1) */                     \
+  const double R0 = 1.0 * s1, R1 = -1.0 * s1 + 1.0 * s2;                        /* coefs2_shift2(s1, s2) */                     \
+  const double H0 = -MW_C(0.041666666666666666666666666666666666667)*s0+MW_C(1.0833333333333333333333333333333333333)*s1-MW_C(0.041666666666666666666666666666666666667)*s2; \
+  const double H1 = -MW_C(0.5)*s0+MW_C(0.5)*s2;                                                                                \
+  const double H2 = MW_C(0.5)*s0-MW_C(1.0)*s1+MW_C(0.5)*s2;                                                                    \
+  double wL = 1.0 * (L1 * L1), wR = 1.0 * (R1 * R1);                                                                           \
+  double wH = 1.0 * (H1 * H1) + MW_C(4.3333333333333333333333333333333333333) * (H2 * H2);                                     \
+  double tot = wL + wR + wH;                                                                                                   \
+  if (tot > 1.e-20) { wL /= tot; wR /= tot; wH /= tot; }                                                                       \
+  const double itot = 1.0 + 1.0 + 5.e2;                                          /* ctor: convexify(1, 1, 5e2) */               \
+  const double iL = 1.0 / itot, iR = 1.0 / itot, iH = 5.e2 / itot;                                                             \
+  wL = iL / (wL * wL + 1.e-20);                                                                                                \
+  wR = iR / (wR * wR + 1.e-20);                                                                                                \
+  wH = iH / (wH * wH + 1.e-20);                                                                                                \
+  tot = wL + wR + wH;                                                                                                          \
+  if (tot > 1.e-20) { wL /= tot; wR /= tot; wH /= tot; }                                                                       \
+  if (wL <= 0.0) wL = 0;                                                         /* cutoff == 0 */                              \
+  if (wR <= 0.0) wR = 0;                                                                                                       \
+  tot = wL + wR + wH;                                                                                                          \
+  if (tot > 1.e-20) { wL /= tot; wR /= tot; wH /= tot; }                                                                       \
+  const double c0 = H0 * wH + L0 * wL + R0 * wR;                                                                               \
+  const double c1 = H1 * wH + L1 * wL + R1 * wR;                                                                               \
+  const double c2 = H2 * wH;                                                                                                   \
+  left  = (c0 + (-0.5) * c1) + 0.25 * c2;                                                                                      \
   right = (c0 + ( 0.5) * c1) + 0.25 * c2;
-}
 __device__ __forceinline__ void weno3_edges_strict(double s0, double s1, double s2, double &left, double &right) {
 #pragma clang fp contract(off)
-  weno3_edges_body<true>(s0, s1, s2, left, right);
+  MW_WENO3_STATEMENTS(s0, s1, s2, left, right)
 }
 __device__ __forceinline__ void weno3_edges_fast(double s0, double s1, double s2, double &left, double &right) {
 #pragma clang fp contract(fast)
-  weno3_edges_body<false>(s0, s1, s2, left, right);
+  MW_WENO3_STATEMENTS(s0, s1, s2, left, right)
 }
+#undef MW_WENO3_STATEMENTS
 
 // ---------------------------------------------------------------------------------------------------------------------
 // WENO-7 and WENO-9 (MW_ORD = 7 / 9, dynamics_euler_stratified_wenofv.h:24-28): weno::WenoLimiter<7> / <9>::compute_limited_coefs
