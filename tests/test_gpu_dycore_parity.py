@@ -413,9 +413,11 @@ def test_weno_orders_3_7_9(mw, oracle, name, mode, order):
     dt = dycore.compute_time_step(coupler)
     dycore.time_step(coupler, dt)
     odyc.time_step(of, dt)
-    # Order 9: at the rim of the warm bubble the candidates' total variations sit at the 1e-20 switch of `convexify` (normalise or
-    # not, WenoLimiter_recon.h:12-15) -- a discontinuity of the scheme: last-bit differences of stage 1 (device pow / exp) flip it
-    # in ~20 cells of the 2-D case and move them by up to 1.3e-11 of the field's scale (order 7 and every other order-9 case: 1e-13).
+    # Order 9: in the 2-D case ~20 cells at the rim of the warm bubble differ by up to 1.3e-11 of the field's scale after one step, in
+    # both run-time modes (order 7 and every other order-9 case: <= 1e-13).  The scheme itself is that touchy there: the ORACLE run
+    # from inputs with every field perturbed by one ulp (random signs) moves by 1.7e-10 of the scale in one step at order 9 and by
+    # 4e-11 at orders 5 and 7 (horizontally uniform data: the candidates' total variations sit at the 1e-20 switches of `convexify`,
+    # WenoLimiter_recon.h:12-15) -- the device's last-bit differences in stage 1 (pow, exp) are such a perturbation.
     tol1 = 1e-10 if order == 9 else 1e-11
     compare_fields(gpu_fields(coupler), of.as_dict(), tol1, "ord%d %s mode %d, 1 step" % (order, name, mode))
     for _ in range(9):
