@@ -1498,7 +1498,11 @@ int mw_dycore_set_order(mw_dycore_t d, int ord) {
     d->nSN1 = (long long)d->p.nz * d->p.HY * d->p.nx * d->p.nens;
     bool had = false;
     for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) { (void)hipFree(d->bufs[g][b]); d->bufs[g][b] = nullptr; had = true; }
-    if (had && mw_dycore_set_exchange(d, d->xchg, d->xchg_ctx)) return 1;   // strips are HX / HY cells deep: re-allocate
+    if (had) {                                                  // strips are HX / HY cells deep: re-allocate (the transport and its owner stay)
+      auto owner = d->xchg_free;
+      if (mw_dycore_set_exchange(d, d->xchg, d->xchg_ctx)) return 1;
+      d->xchg_free = owner;
+    }
     MW_HIP(hipStreamSynchronize(d->stream));
   }
   return 0;
