@@ -59,6 +59,34 @@ struct CouplerPtrs {
   double *tr[MW_MAX_TRACERS];
 };
 
+// Compile-time configuration of the marching kernels (mw_march.h).  The run-time switches of DyP that are wave-uniform and fixed
+// for a whole run cost SGPRs (the marching kernels have none to spare: every SGPR spilled to a VGPR lane comes back as a
+// v_readlane, a VALU instruction) and selects (v_cndmask pairs per double).  K = 0 keeps every switch at run time (any
+// configuration).  K = 1 / 2 are the shipped experiments' configurations with the switches folded:
+//   both: nens == 1 (or one member of a member-major handle), 3-D, periodic x and y (any rank count: the index wrap stays a
+//         run-time switch), wall in z, no Coriolis term (latitude is forced to 0 at init, :1249), the default gamma (series
+//         coefficients as literals), every tracer positive and mass-adding with water vapour first (idWV == 0);
+//   K = 1 (supercell_example, supercell_kessler_surrogate, community_benchmark): gravity on, no immersed boundaries, the three
+//         Kessler tracers;
+//   K = 2 (simple_city): immersed boundaries, gravity off, water vapour only.
+// marching_config() in the host part decides; anything else runs K = 0.
+template <int K> struct Cf {
+  static constexpr bool spec = (K != 0);
+  static __device__ __forceinline__ bool x_periodic(const DyP &p) { return spec || p.bc_x == MW_BC_PERIODIC; }
+  static __device__ __forceinline__ bool y_periodic(const DyP &p) { return spec || p.bc_y == MW_BC_PERIODIC; }
+  static __device__ __forceinline__ bool z_wall(const DyP &p) { return spec || p.bc_z == MW_BC_WALL; }
+  static __device__ __forceinline__ bool sim2d(const DyP &p) { return !spec && p.sim2d; }
+  static __device__ __forceinline__ bool immersed(const DyP &p) { return K == 2 || (!spec && p.use_immersed); }
+  static __device__ __forceinline__ bool gravity(const DyP &p) { return K == 1 || (!spec && p.enable_gravity); }
+  static __device__ __forceinline__ bool coriolis(const DyP &p) { return !spec; }
+  static __device__ __forceinline__ bool bn_default(const DyP &p) { return spec || p.bn_default; }
+  static __device__ __forceinline__ bool an_default(const DyP &p) { return spec || p.an_default; }
+  static __device__ __forceinline__ bool positive(const DyP &p, int t) { return spec || ((p.pos_mask >> t) & 1u); }
+  static __device__ __forceinline__ bool adds_mass(const DyP &p, int t) { return spec || ((p.mass_mask >> t) & 1u); }
+  static __device__ __forceinline__ bool is_wv(const DyP &p, int t) { return spec ? (t == 0) : (t == p.idWV); }
+  static __device__ __forceinline__ int ntr(const DyP &p) { return K == 1 ? 3 : K == 2 ? 1 : p.nt; }   // K = 1: the three Kessler tracers; K = 2: water vapour
+};
+
 // -----------------------------------------------------------------------------------------------------
 // pow(x, gamma): strict = device libm pow; fast = same for now (kept separate so it can be specialised)
 // -----------------------------------------------------------------------------------------------------
@@ -94,11 +122,50 @@ static const double BN_DEFAULT[11] = {1.0, 0x1.669d5185016e2p+0, 0x1.1f7e1e502b5
                                       -0x1.7dda38e0cc64cp-7, 0x1.ca1dc2cec496fp-8, -0x1.2cfe340a81e1p-8, 0x1.a553bdf108378p-9,
                                       -0x1.34ef19ee96d45p-9, 0x1.d587239f51368p-10};
 
+template <int K = 0>
 __device__ __forceinline__ double pressure_fast(const DyP &p, double e, double hyt, double p0, double ihyt) {
 #pragma clang fp contract(fast)
   double dl = e * ihyt;
-  if (fabs(dl) <= 0.05 && p.bn_default) return p0 + p0 * (pressure_series_default(dl) * dl);
+  if (fabs(dl) <= 0.05 && Cf<K>::bn_default(p)) return p0 + p0 * (pressure_series_default(dl) * dl);
   return pressure_pow(p.C0, hyt + e, p.gamma);                  // large perturbation, or a non-default gamma
+}
+// The two sides of a face at once (the Riemann solver needs both, :401): the same two Horner chains as pressure_series_default,
+// as three-address v_fma_f64 interleaved in ONE asm statement.  Left to the compiler, the chain of a polynomial whose coefficients
+// it keeps in registers becomes v_mov_b64 (coefficient -> accumulator) + v_fmac_f64 (two-address) per step -- nine extra VALU
+// instructions per evaluation, four evaluations per level in k_xz_state (seen in round 2's gfx950 code, tools/isa_histogram.py) --
+// inside one divergent block per side.  Here: two independent dependency chains in one block, no moves.  (The coefficients are
+// "v" operands: twenty VGPRs for the whole kernel.  The single evaluations of D1 / D13 keep the compiler's form: k_tracers_fused
+// <3, 1> has no registers for them.)
+__device__ __forceinline__ void pressure_series_pair(double dlL, double dlR, double &sL, double &sR) {
+  double aL, aR;
+  asm("v_fma_f64 %0, %4, %2, %5\n\tv_fma_f64 %1, %4, %3, %5\n\t"
+      "v_fma_f64 %0, %0, %2, %6\n\tv_fma_f64 %1, %1, %3, %6\n\t"
+      "v_fma_f64 %0, %0, %2, %7\n\tv_fma_f64 %1, %1, %3, %7\n\t"
+      "v_fma_f64 %0, %0, %2, %8\n\tv_fma_f64 %1, %1, %3, %8\n\t"
+      "v_fma_f64 %0, %0, %2, %9\n\tv_fma_f64 %1, %1, %3, %9\n\t"
+      "v_fma_f64 %0, %0, %2, %10\n\tv_fma_f64 %1, %1, %3, %10\n\t"
+      "v_fma_f64 %0, %0, %2, %11\n\tv_fma_f64 %1, %1, %3, %11\n\t"
+      "v_fma_f64 %0, %0, %2, %12\n\tv_fma_f64 %1, %1, %3, %12\n\t"
+      "v_fma_f64 %0, %0, %2, %13\n\tv_fma_f64 %1, %1, %3, %13"
+      : "=&v"(aL), "=&v"(aR)
+      : "v"(dlL), "v"(dlR), "v"(0x1.d587239f51368p-10), "v"(-0x1.34ef19ee96d45p-9), "v"(0x1.a553bdf108378p-9), "v"(-0x1.2cfe340a81e1p-8),
+        "v"(0x1.ca1dc2cec496fp-8), "v"(-0x1.7dda38e0cc64cp-7), "v"(0x1.6f48bfb7e5329p-6), "v"(-0x1.cb58863e4dd29p-5),
+        "v"(0x1.1f7e1e502b562p-2), "v"(0x1.669d5185016e2p+0));
+  sL = aL; sR = aR;
+}
+template <int K = 0>
+__device__ __forceinline__ void pressure_fast_pair(const DyP &p, double eL, double eR, double hyt, double p0, double ihyt, double &pL, double &pR) {
+#pragma clang fp contract(fast)
+  const double dL = eL * ihyt, dR = eR * ihyt;
+  if (__builtin_expect(fabs(dL) <= 0.05 && fabs(dR) <= 0.05 && Cf<K>::bn_default(p), 1)) {
+    double sL, sR;
+    pressure_series_pair(dL, dR, sL, sR);
+    pL = p0 + p0 * (sL * dL);
+    pR = p0 + p0 * (sR * dR);
+  } else {                                                      // a large perturbation on either side, or a non-default gamma
+    pL = pressure_fast<K>(p, eL, hyt, p0, ihyt);
+    pR = pressure_fast<K>(p, eR, hyt, p0, ihyt);
+  }
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -811,7 +878,8 @@ struct mw_dycore_s {
   double *M[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};          // upwind mass flux of every x/y/z face,
   unsigned char *UP[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // upwind selector; double-buffered by stage parity
   hipStream_t tstream = nullptr;                        // tracer pipeline (runs one stage behind / beside the state pipeline)
-  hipEvent_t ev_state[8] = {nullptr}, ev_tr[8] = {nullptr}, ev_misc = nullptr;
+  hipEvent_t ev_state[8] = {nullptr}, ev_tr[8] = {nullptr}, ev_ystate[8] = {nullptr}, ev_misc = nullptr;
+  int early_yt = 0;                                     // two-stream schedule: k_y_tracers starts behind k_y_state, beside k_xz_state
   long long gstage = 0;                                 // global stage counter (event ring index, buffer parity)
   int overlap = 1;
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
@@ -1114,6 +1182,19 @@ static int balanced_chunk(int nz, long long base_waves, const char *env, long lo
   return (best < 0.97 * cost_of(old_chunk)) ? best_chunk : old_chunk;
 }
 
+// Which compile-time configuration of the marching kernels (Cf<K>) fits this view of the handle: 1 / 2 = the shipped supercell /
+// simple_city set-ups with their run-time switches folded, 0 = everything at run time.  MW_NO_SPEC=1 forces 0 (A/B timing, tests).
+static int marching_config(const DyP &p) {
+  static const bool off = getenv("MW_NO_SPEC") != nullptr;
+  if (off) return 0;
+  const unsigned all = (1u << p.nt) - 1u;
+  if (p.nens != 1 || p.sim2d || p.bc_x != MW_BC_PERIODIC || p.bc_y != MW_BC_PERIODIC || p.bc_z != MW_BC_WALL || p.fcor != 0.0 ||
+      !p.bn_default || !p.an_default || p.pos_mask != all || p.mass_mask != all || p.idWV != 0) return 0;
+  if (p.nt == 3 && !p.use_immersed && p.enable_gravity) return 1;
+  if (p.nt == 1 && p.use_immersed && !p.enable_gravity) return 2;
+  return 0;
+}
+
 // conv != nullptr: the slab S is still empty -- the kernel converts the coupler's fields on the way and fills it (k_y_state<true>)
 static int launch_y_state(mw_dycore_s *d, const double *S, int par, const CouplerPtrs *conv = nullptr) {
   if (d->p.sim2d) return 0;
@@ -1126,10 +1207,14 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     double *MY = d->M[par][1] + e * v.m[1]; unsigned char *UY = d->UP[par][1] + e * v.m[1];
-    if (conv) hipLaunchKernelGGL((k_y_state<true>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, *conv,
-                                 const_cast<double *>(v.S(S)));
-    else      hipLaunchKernelGGL((k_y_state<false>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk,
-                                 CouplerPtrs(), nullptr);
+#define MW_YS(CONV_, K_, cp, sw) hipLaunchKernelGGL((k_y_state<CONV_, K_>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw)
+    double *Sw = const_cast<double *>(v.S(S));
+    switch (marching_config(p)) {
+      case 1:  if (conv) MW_YS(true, 1, *conv, Sw); else MW_YS(false, 1, CouplerPtrs(), nullptr); break;
+      case 2:  if (conv) MW_YS(true, 2, *conv, Sw); else MW_YS(false, 2, CouplerPtrs(), nullptr); break;
+      default: if (conv) MW_YS(true, 0, *conv, Sw); else MW_YS(false, 0, CouplerPtrs(), nullptr); break;
+    }
+#undef MW_YS
     MW_LAUNCH_CHECK();
   }
   return 0;
@@ -1188,10 +1273,13 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
     unsigned char *UX = d->UP[par][0] + e * v.m[0], *UZ = d->UP[par][2] + e * v.m[2];
     // nens == 1 (also: one member of a member-major handle): the per-level background values come through LDS
     // (k_xz_state<.., HPL = 1>; dynamic LDS = the chunk's rows)
-    if (p.nens == 1) hipLaunchKernelGGL((k_xz_state<STAGE, true, MODE, 1>), grid, dim3(256), (size_t)(chunk + 2) * 64, d->stream, p, v.S(S), v.S(Sn), v.S(Sout),
-                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);
-    else             hipLaunchKernelGGL((k_xz_state<STAGE, false, MODE>), grid, dim3(256), 0, d->stream, p, v.S(S), v.S(Sn), v.S(Sout),
-                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w);
+#define MW_XZ(N1_, HPL_, K_, lds) hipLaunchKernelGGL((k_xz_state<STAGE, N1_, MODE, HPL_, K_>), grid, dim3(256), lds, d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
+                                                    MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
+    const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
+    if (p.nens == 1) {
+      switch (marching_config(p)) { case 1: MW_XZ(true, 1, 1, hpl_bytes); break; case 2: MW_XZ(true, 1, 2, hpl_bytes); break; default: MW_XZ(true, 1, 0, hpl_bytes); break; }
+    } else MW_XZ(false, 0, 0, 0);
+#undef MW_XZ
     MW_LAUNCH_CHECK();
   }
   return 0;
@@ -1243,11 +1331,11 @@ static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const doubl
 
 // dynamic LDS of k_tracers_fused<., MODE 1>: D13's background table of the block's levels
 static size_t fused_bg_bytes(int mode, int chunk, int nens) { return mode == 1 ? (size_t)(chunk + 4) * nens * 24 : 0; }
-template <int STAGE, int MODE, int T, bool N1>
+template <int STAGE, int MODE, int T, bool N1, int K>
 static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
   const int e = v.e;
-  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1>), grid, dim3(256), fused_bg_bytes(MODE, chunk, v.p.nens), st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
+  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1, K>), grid, dim3(256), fused_bg_bytes(MODE, chunk, v.p.nens), st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
                      d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
                      d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4);
 }
@@ -1268,9 +1356,14 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
       if (fused_bg_bytes(MODE, chunk, p.nens) > 60000) MW_FAIL("fused tracer stage: nens x chunk too large for its LDS table (use the member-major layout or a smaller MW_CHUNK_F)");
 #define MW_FUSED_CASE(TT) \
-      case TT: if (p.nens == 1) launch_tracers_fused_t<STAGE, MODE, TT, true>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); \
-               else             launch_tracers_fused_t<STAGE, MODE, TT, false>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); break;
-      switch (p.nt) { MW_FUSED_CASE(1) MW_FUSED_CASE(2) MW_FUSED_CASE(3) MW_FUSED_CASE(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
+      case TT: if (p.nens == 1) launch_tracers_fused_t<STAGE, MODE, TT, true, 0>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); \
+               else             launch_tracers_fused_t<STAGE, MODE, TT, false, 0>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); break;
+      // (the D13 variant <3, 1> with three tracers sits at the register limit: with the switches folded the compiler spills VGPRs to
+      //  scratch, with the run-time switches it does not -- it keeps K = 0; one launch per time step)
+      const int K = (MODE == 1 && p.nt == 3) ? 0 : marching_config(p);
+      if (K == 1)      launch_tracers_fused_t<STAGE, MODE, 3, true, 1>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st);
+      else if (K == 2) launch_tracers_fused_t<STAGE, MODE, 1, true, 2>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st);
+      else switch (p.nt) { MW_FUSED_CASE(1) MW_FUSED_CASE(2) MW_FUSED_CASE(3) MW_FUSED_CASE(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
 #undef MW_FUSED_CASE
       MW_LAUNCH_CHECK();
     }
@@ -1317,13 +1410,23 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   const bool conv = (STAGE == 1) && d->conv_pending;            // first stage of the step: D1 + D2 inside k_y_state
   d->conv_pending = false;
   if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
+  // (k_y_tracers only needs this stage's y faces: it may run BESIDE k_xz_state -- an HBM-bound launch beside a VALU-bound one)
+  const bool early_yt = d->overlap && d->early_yt;
+  if (early_yt) MW_HIP(hipEventRecord(d->ev_ystate[slot], ss));
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
   // previous stage, which this stream produced itself: it is issued BEFORE the wait for this stage's state kernels and so
   // runs beside them; the state stream's exchange for stage s+1 in turn runs beside this stage's tracer kernels.
   if (halo_fill(d, Sin, 5, T, ts, 1, true)) return 1;
-  if (d->overlap) { MW_HIP(hipEventRecord(d->ev_state[slot], ss)); MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0)); }
-  if (launch_y_tracers(d, Sin, par, ts)) return 1;                            // tracer fluxes (public arrays)
+  if (d->overlap) MW_HIP(hipEventRecord(d->ev_state[slot], ss));
+  if (early_yt) {
+    MW_HIP(hipStreamWaitEvent(ts, d->ev_ystate[slot], 0));
+    if (launch_y_tracers(d, Sin, par, ts)) return 1;
+    MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0));
+  } else {
+    if (d->overlap) MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0));
+    if (launch_y_tracers(d, Sin, par, ts)) return 1;                          // tracer fluxes (public arrays)
+  }
   if (d->fused) {
     if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ts)) return 1;   // x/z fluxes + D10 + D11/D12 (+ D13)
   } else {
@@ -1438,7 +1541,9 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
                                 : hipStreamCreateWithPriority(&d->tstream, hipStreamNonBlocking, pm == 1 ? least : greatest);
       if (er != hipSuccess) { set_error("hipStreamCreate failed"); return fail(); } }
     for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
+                                    hipEventCreateWithFlags(&d->ev_ystate[i], hipEventDisableTiming) != hipSuccess ||
                                     hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
+    { const char *ey = getenv("MW_EARLY_YT"); d->early_yt = ey ? atoi(ey) : 0; }
     if (hipEventCreateWithFlags(&d->ev_misc, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
   }
   fill_params(d);
@@ -1455,7 +1560,8 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->flags) (void)hipFree(d->flags);
   if (d->dirty) (void)hipFree(d->dirty);
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
-  for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
+  for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]);
+                                if (d->ev_ystate[i]) (void)hipEventDestroy(d->ev_ystate[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);

@@ -38,6 +38,12 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // waits for that store's write acknowledgement.  The marching kernels issue a level's loads at the top of the iteration and its
 // stores at the bottom; landed() names the loaded values in front of the first store, which puts the (by then free) wait
 // there, and in front of the loop for the prologue's loads, whose pending state would otherwise leak into every iteration.
+// A fence for the instruction scheduler.  With its run-time switches folded (Cf<K>, K != 0) a marching loop body loses the rare
+// branches that used to cut it into basic blocks and becomes one block of ~500 instructions, which the scheduler then re-orders
+// as a whole -- it sank the loads of k_tracers_fused towards their uses and the kernel became 8 % SLOWER than the unspecialised
+// one (measured, round 3).  The fences restore the intended order: all loads of a level first, register-only arithmetic behind.
+#define MW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 template <int N>
 __device__ __forceinline__ void landed(double (&a)[N]) {
 #pragma unroll
@@ -93,10 +99,11 @@ __device__ __forceinline__ int wrap_row(const DyP &p, int j) { return p.wrap_y ?
 // Level kl of a marching column (kl may lie in the z halo, -3..nz+2) with the z boundary rule (:752-781) applied on the fly: halo
 // levels repeat the nearest interior level, w is 0 behind a wall.  The marching kernels therefore never read the slab's z halo
 // and the production path does not fill it (k is wave-uniform: the clamp is scalar work).
+template <int K = 0>
 __device__ __forceinline__ double load_zlevel(const DyP &p, const double *__restrict__ colv, int kl, bool is_w) {
   const int kc = min(max(kl, 0), p.nz - 1);
   double val = colv[(long long)(kc + p.HZ) * p.sK];
-  if (is_w && kc != kl && p.bc_z == MW_BC_WALL) val = 0.0;
+  if (is_w && kc != kl && Cf<K>::z_wall(p)) val = 0.0;
   return val;
 }
 
@@ -108,6 +115,7 @@ struct FaceState {   // what the passive variables need from the Riemann solve o
 // Acoustic-upwind Riemann solve for the three primary variables of one face (:399-414).  Edge values:
 // rX = rho edge (perturbation + hy), uX = normal velocity edge, eTX = (rho theta)' edge (perturbation only).
 // Returns the fluxes of idR, the normal momentum and idT, plus the upwind selector.
+template <int K = 0>
 __device__ __forceinline__ FaceState riemann_primary(const DyP &p, double rL, double rR, double uL, double uR, double eTL,
                                                      double eTR, double hyt, double p0, double ihyt, bool zero_nrm,
                                                      double &f_nrm, double &f_T) {
@@ -115,7 +123,8 @@ __device__ __forceinline__ FaceState riemann_primary(const DyP &p, double rL, do
   const double cs = 350;
   double mL = zero_nrm ? 0.0 : uL * rL;
   double mR = zero_nrm ? 0.0 : uR * rR;
-  double p_L = pressure_fast(p, eTL, hyt, p0, ihyt), p_R = pressure_fast(p, eTR, hyt, p0, ihyt);
+  double p_L, p_R;
+  pressure_fast_pair<K>(p, eTL, eTR, hyt, p0, ihyt, p_L, p_R);
   double w1 = 0.5 * (p_R - cs * mR);
   double w2 = 0.5 * (p_L + cs * mL);
   double p_upw = w1 + w2;
@@ -138,14 +147,16 @@ __device__ __forceinline__ FaceState riemann_primary(const DyP &p, double rL, do
 // ---------------------------------------------------------------------------------------------------------------
 
 // y boundary rule (:1061-1081): 0 none, 1: L := R (low wall/open), 2: R := L (high), 3: quirk 1 (R = row 0's south edge)
+template <int K = 0>
 __device__ __forceinline__ int bc_mode_y(const DyP &p, int j) {
-  if (p.bc_y == MW_BC_PERIODIC) return 0;
+  if (Cf<K>::y_periodic(p)) return 0;
   if (p.py == 0) { if (j == 0) return 1; if (j == p.ny && p.nproc_y == 1) return 3; return 0; }
   if (p.py == p.nproc_y - 1 && j == p.ny) return 2;
   return 0;
 }
+template <int K = 0>
 __device__ __forceinline__ int bc_mode_x(const DyP &p, int i) {                      // :1040-1060
-  if (p.bc_x == MW_BC_PERIODIC) return 0;
+  if (Cf<K>::x_periodic(p)) return 0;
   if (p.px == 0) { if (i == 0) return 1; if (i == p.nx && p.nproc_x == 1) return 3; return 0; }
   if (p.px == p.nproc_x - 1 && i == p.nx) return 2;
   return 0;
@@ -183,16 +194,18 @@ __device__ __forceinline__ long long cpl(const DyP &p, long long ci) { return ci
 
 // One cell of the coupler, as loaded (the marching kernel requests row j+3 at the top of iteration j and converts it at the end).
 struct CouplerCell { double rho_d, u, v, w, temp, tr[4]; };
+template <int K = 0>
 __device__ __forceinline__ CouplerCell load_coupler_cell(const DyP &p, const CouplerPtrs &c, long long ci) {
   CouplerCell r;
   r.rho_d = c.rho_d[ci]; r.u = c.u[ci]; r.v = c.v[ci]; r.w = c.w[ci]; r.temp = c.temp[ci];
 #pragma unroll
-  for (int tr = 0; tr < 4; tr++) r.tr[tr] = (tr < p.nt) ? c.tr[tr][ci] : 0.0;
+  for (int tr = 0; tr < 4; tr++) r.tr[tr] = (tr < Cf<K>::ntr(p)) ? c.tr[tr][ci] : 0.0;
   return r;
 }
 // -> the five state variables of the slab (rho', u, v, w, (rho theta)') and 1/rho for the tracers.  hi = k*nens + e.  The last
 // operation of every result is not contractable, so that a caller that goes on computing with the values sees exactly what is stored.
 // (hyc, hyt, p0: the cell's background density, rho*theta and pressure = DyP::hyc / hytc / p0c [hi] = the first three of hypk's row)
+template <int K = 0>
 __device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCell &r, double hyc, double hyt, double p0, double *s5, double &inv_den) {
   double rho, ru, rv, rw, sd, rp;
   {
@@ -201,12 +214,12 @@ __device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCel
     double rho_v = 0;
 #pragma unroll
     for (int tr = 0; tr < 4; tr++) {
-      if ((p.mass_mask >> tr) & 1u) rho += r.tr[tr];           // (tracers beyond nt were loaded as 0 and have no mask bit)
-      if (tr == p.idWV) rho_v = r.tr[tr];
+      if (tr < Cf<K>::ntr(p) && Cf<K>::adds_mass(p, tr)) rho += r.tr[tr];
+      if (Cf<K>::is_wv(p, tr)) rho_v = r.tr[tr];
     }
     const double press = r.rho_d * p.R_d * r.temp + rho_v * p.R_v * r.temp;
     const double dl = press * fast_rcp(p0) - 1.0;
-    if (fabs(dl) <= 0.05 && p.an_default) sd = inv_gamma_series_default(dl) * dl;
+    if (fabs(dl) <= 0.05 && Cf<K>::an_default(p)) sd = inv_gamma_series_default(dl) * dl;
     else                                  sd = rhotheta_ratio_pow(press / p.C0, 1.0 / p.gamma, hyt);
     rp = rho - hyc;                                            // state(idR)
     inv_den = fast_rcp(rp + hyc);                              // what D2 divides by (:249)
@@ -218,13 +231,14 @@ __device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCel
   }
 }
 __device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCell &r, int hi, double *s5, double &inv_den) {
-  convert_cell_fast(p, r, p.hyc[hi], p.hytc[hi], p.p0c[hi], s5, inv_den);
+  convert_cell_fast<0>(p, r, p.hyc[hi], p.hytc[hi], p.p0c[hi], s5, inv_den);
 }
 // the tracers of that cell: slab value = rho_t / rho
+template <int K = 0>
 __device__ __forceinline__ void convert_cell_tracers(const DyP &p, const CouplerCell &r, double inv_den, double *__restrict__ s) {
 #pragma clang fp contract(off)
 #pragma unroll
-  for (int tr = 0; tr < 4; tr++) if (tr < p.nt) s[(long long)(5 + tr) * p.sV] = r.tr[tr] * inv_den;
+  for (int tr = 0; tr < 4; tr++) if (tr < Cf<K>::ntr(p)) s[(long long)(5 + tr) * p.sV] = r.tr[tr] * inv_den;
 }
 // stand-alone form (2-D runs, walls / open boundaries or a neighbour exchange in y, two-stream schedule)
 __global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtrs c, double *__restrict__ S) {
@@ -307,7 +321,9 @@ __global__ __launch_bounds__(256) void k_member_to_coupler(DyP p, const double *
 // the separate conversion pass -- 16 arrays read or written -- disappears.
 // Writes FY[idR] (= m_upw), UPY (selector) for faces ja..jb and tendY (5,nz,ny,nx,nens) for rows ja..jb-1.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool CONV>
+// (Measured, round 3: with the switches folded the non-converting variant needs 192 VGPRs; capped at 168 for a third wave per SIMD
+//  it spills 24 of them.)
+template <bool CONV, int K>
 __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restrict__ S, double *__restrict__ MY,
                                                  unsigned char *__restrict__ UPY, double *__restrict__ tendY, int chunk,
                                                  CouplerPtrs c, double *__restrict__ Sw) {
@@ -332,18 +348,18 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 #define MW_ROW_CI(r) cpl(p, ((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
 #define MW_ROW_FINISH(raw, r, out5)                                                                                   \
   { double inv_den_;                                                                                                  \
-    convert_cell_fast(p, raw, hyr, hyt, p0, out5, inv_den_);   /* (the row's background values are in registers already) */ \
+    convert_cell_fast<K>(p, raw, hyr, hyt, p0, out5, inv_den_);   /* (the row's background values are in registers already) */ \
     if ((r) >= ja && (r) < jb) {                                                                                      \
       double *s_ = Sw + (long long)(k + p.HZ) * p.sK + (long long)((r) + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;  \
       s_[0] = out5[0]; s_[p.sV] = out5[1]; s_[2 * p.sV] = out5[2]; s_[3 * p.sV] = out5[3]; s_[4 * p.sV] = out5[4];    \
-      convert_cell_tracers(p, raw, inv_den_, s_);                                                                     \
+      convert_cell_tracers<K>(p, raw, inv_den_, s_);                                                                     \
     } }
 #pragma unroll
   for (int v = 0; v < 5; v++) { cn[v] = 0; fprev[v] = 0; }
   if (CONV) {
 #pragma unroll
     for (int s = 0; s < 5; s++) {
-      const CouplerCell raw = load_coupler_cell(p, c, MW_ROW_CI(ja - 1 - 2 + s));
+      const CouplerCell raw = load_coupler_cell<K>(p, c, MW_ROW_CI(ja - 1 - 2 + s));
       double r5[5];
       MW_ROW_FINISH(raw, ja - 1 - 2 + s, r5)
 #pragma unroll
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   for (int j = ja - 1; j <= jb; j++) {
     const int jn = min(j + 3, p.ny + p.HY - 1);                 // clamp: the last prefetch is never used
     CouplerCell raw;
-    if (CONV) raw = load_coupler_cell(p, c, MW_ROW_CI(jn));
+    if (CONV) raw = load_coupler_cell<K>(p, c, MW_ROW_CI(jn));
     else {
 #pragma unroll
       for (int v = 0; v < 5; v++) nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
       const bool face = (j >= ja);
       const int jc = max(j, 0);
       // face j: L = north edge of cell j-1 (cn), R = south edge of cell j (se)
-      const int bcmode = bc_mode_y(p, jc);
+      const int bcmode = bc_mode_y<K>(p, jc);
       const bool zero = (bcmode == 1 || bcmode == 2) && (p.bc_y == MW_BC_WALL);
       if (__builtin_expect(bcmode == 3, 0)) {
 #pragma unroll
@@ -387,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
         if (zero) { Lu = 0.0; Ru = 0.0; }                      // = the reference's zeroed normal momentum on both sides
       }
       double f[5], fn, fT;
-      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, false, fn, fT);
+      FaceState fs = riemann_primary<K>(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, false, fn, fT);
       int up = fs.ind;
       if (__builtin_expect(ybc, 0)) up = (bcmode == 1) ? 1 : 0;   // both sides hold the R (cell j) / L values
       f[idR] = fs.m_upw; f[idV] = fn; f[idT] = fT;
@@ -396,7 +412,11 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
         f[idU] = fs.m_upw * (up ? sU : cU);
         f[idW] = fs.m_upw * (up ? sW : cW);
       }
-      if (CONV) { landed(raw.rho_d); landed(raw.u); landed(raw.v); landed(raw.w); landed(raw.temp); landed(raw.tr); }
+      if (CONV) {
+        landed(raw.rho_d); landed(raw.u); landed(raw.v); landed(raw.w); landed(raw.temp);
+#pragma unroll
+        for (int tr = 0; tr < 4; tr++) if (!Cf<K>::spec || tr < Cf<K>::ntr(p)) landed(raw.tr[tr]);
+      }
       else landed(nxt);                                        // the iteration's loads, in front of its stores (see landed())
       if (face) { fy[(long long)j * p.fyJ] = fs.m_upw; upy[(long long)j * p.fyJ] = (unsigned char)up; }
       if (j > ja) {
@@ -427,6 +447,8 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 //  neutral -- removes 2/3 of this kernel's arithmetic on the supercell state and changes its time by 3 %: the kernel moves 57 B per
 //  cell at 4.6 TB/s and is bandwidth-bound once the arithmetic shrinks.  k_tracers_fused gained 10 %, the step 4 %; a state with
 //  cloud and rain everywhere lost 3 % to the test.  Not kept.)
+// (No Cf<K> form: measured in round 3, the folded variant needs 112 instead of 154 VGPRs for three tracers, runs 4 instead of 3 waves
+//  per SIMD and is 4-6 % SLOWER -- the kernel is bound by HBM, and more resident waves only interleave more rows' streams.)
 template <int T>
 __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restrict__ S, double *__restrict__ FY,
                                                    const double *__restrict__ MY, const unsigned char *__restrict__ UPY, int chunk,
@@ -473,7 +495,7 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
     for (int v = 0; v < T; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
     landed(nxt2); landed(m_n); asm volatile("" : "+v"(up_n));  // the iteration's loads, in front of its stores (see landed())
     if (j >= ja) {
-      if (__builtin_expect(bc_mode_y(p, j) == 3, 0)) {
+      if (__builtin_expect(bc_mode_y<0>(p, j) == 3, 0)) {
 #pragma unroll
         for (int v = 0; v < T; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_;
           weno5_edges_fast(qv[-2 * p.sJ], qv[-p.sJ], qv[0], qv[p.sJ], qv[2 * p.sJ], l_, r_); se[v] = l_; }
@@ -559,7 +581,7 @@ __device__ __forceinline__ void x_neighbours(double c0, const double *__restrict
 
 // MODE 1 (last stage of the last cycle): u, v, w also go to the coupler's arrays (D13, :1929-1932: the slab holds (rho u)/rho
 // already), so that the tracer stage, which finishes D13, neither re-reads nor re-writes them.
-template <int STAGE, bool N1, int MODE, int HPL = 0>
+template <int STAGE, bool N1, int MODE, int HPL, int K>
 __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
                                                   double *__restrict__ Sout, double *__restrict__ MX, double *__restrict__ MZ,
                                                   unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
@@ -591,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   for (int v = 0; v < 5; v++) {
     ct[v] = 0; lds_fzprev[v][threadIdx.x] = 0; lds_xpart[v][threadIdx.x] = 0;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = load_zlevel(p, col + (long long)v * p.sV, g.kstart - 2 + s, v == idW);
+    for (int s = 0; s < 5; s++) w[v][s] = load_zlevel<K>(p, col + (long long)v * p.sV, g.kstart - 2 + s, v == idW);
   }
 #pragma unroll
   for (int v = 0; v < 5; v++) landed(w[v]);
@@ -604,20 +626,23 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     {
       const int kn = min(k + 3, p.nz + p.HZ - 1);
 #pragma unroll
-      for (int v = 0; v < 5; v++) nxt[v] = load_zlevel(p, col + (long long)v * p.sV, kn, v == idW);
+      for (int v = 0; v < 5; v++) nxt[v] = load_zlevel<K>(p, col + (long long)v * p.sV, kn, v == idW);
     }
+    // (unconditional, at levels clamped into the chunk: a ghost iteration loads values nobody uses, and no default values have to be
+    //  materialised for a skipped load -- ten v_mov_b64 per level)
     double snv[5], tyv[5], immv = 0;
+    const int kfc = max(k - 1, g.ka), kxc = min(max(k, g.ka), g.kb - 1);       // the level that is finalised / reconstructed in x
 #pragma unroll
     for (int l = 0; l < 5; l++) { snv[l] = 0; tyv[l] = 0; }
-    if (STAGE != 1 && fin) {
+    if (STAGE != 1) {
 #pragma unroll
-      for (int l = 0; l < 5; l++) snv[l] = Sn[(long long)l * p.sV + slab0 + (long long)(k - 1 + p.HZ) * p.sK];
+      for (int l = 0; l < 5; l++) snv[l] = Sn[(long long)l * p.sV + slab0 + (long long)(kfc + p.HZ) * p.sK];
     }
-    if (xwork && !p.sim2d) {
+    if (!Cf<K>::sim2d(p)) {
 #pragma unroll
-      for (int l = 0; l < 5; l++) tyv[l] = tendY[(long long)l * p.nC + cell0 + (long long)k * planeC];
+      for (int l = 0; l < 5; l++) tyv[l] = tendY[(long long)l * p.nC + cell0 + (long long)kxc * planeC];
     }
-    if (p.use_immersed && fin) immv = p.imm[cpl(p, cell0 + (long long)(k - 1) * planeC)];
+    if (Cf<K>::immersed(p)) immv = p.imm[cpl(p, cell0 + (long long)kfc * planeC)];
     double hpl[8];
     if (HPL) {
 #pragma unroll
@@ -636,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
         x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK, g.om2, g.om1, g.op1, g.op2, lane, n, m2, m1, p1, p2);
         weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
       }
-      const int bcmode = bc_mode_x(p, g.i);
+      const int bcmode = bc_mode_x<K>(p, g.i);
       const bool zero = (bcmode == 1 || bcmode == 2) && (p.bc_x == MW_BC_WALL);
       if (__builtin_expect(bcmode == 3, 0)) {                  // quirk 1: slot 1 at face nx keeps cell 0's west edge (:985)
         const double *c0p = col + (long long)(k + p.HZ) * p.sK - (long long)p.nx * n;
@@ -651,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; }
       if (bcmode == 2) { Rr = Lr; Ru = Lu; Rt = Lt; }
       double fn, fT;
-      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, zero, fn, fT);
+      FaceState fs = riemann_primary<K>(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, zero, fn, fT);
       int up = fs.ind;
       if (bcmode == 1) up = 1;
       if (bcmode == 2) up = 0;
@@ -661,19 +686,16 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       upx = up;                                                // (stored below, behind landed())
     }
     // ------------------------------------------------ Z direction: reconstruct cell k, solve face k
+    // (also on the boundary face nz, where there is no cell: the window then holds clamped levels, the edge values are finite and
+    //  nobody reads them -- a branch here would need ten default values materialised in every iteration)
     double be[5], te[5];
-    if (!top) {
 #pragma unroll
-      for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be[v], te[v]);
-    } else {
-#pragma unroll
-      for (int v = 0; v < 5; v++) { be[v] = 0; te[v] = 0; }
-    }
+    for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be[v], te[v]);
+    // (also on the ghost iteration below the chunk, whose face belongs to the chunk underneath: its flux is never stored and never
+    //  enters a tendency -- the first cell that is finalised is ka, with the faces ka and ka + 1)
     double fzs[5];
-#pragma unroll
-    for (int l = 0; l < 5; l++) fzs[l] = 0;
     int upz = 0;
-    if (zface) {
+    {
       const double *hp = p.hypk + (long long)(k * n + e) * 8;
       const double hyr = HPL ? hpl[4] : hp[4], hyt = HPL ? hpl[5] : hp[5], p0 = HPL ? hpl[6] : hp[6], ihyt = HPL ? hpl[7] : hp[7];
       double Lr = ct[idR], Lu = ct[idW], Lt = ct[idT], Rr = be[idR], Ru = be[idW], Rt = be[idT];
@@ -682,10 +704,10 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       const bool zbc = (k == 0) || top;
       if (__builtin_expect(zbc, 0)) {
         if (k == 0) { Lr = Rr; Lu = Ru; Lt = Rt; } else { Rr = Lr; Ru = Lu; Rt = Lt; }
-        if (p.bc_z == MW_BC_WALL) { Lu = 0.0; Ru = 0.0; }
+        if (Cf<K>::z_wall(p)) { Lu = 0.0; Ru = 0.0; }
       }
       double fn, fT;
-      FaceState fs = riemann_primary(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, false, fn, fT);
+      FaceState fs = riemann_primary<K>(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, false, fn, fT);
       int up = fs.ind;
       if (__builtin_expect(zbc, 0)) up = (k == 0) ? 1 : 0;
       fzs[idR] = fs.m_upw; fzs[idW] = fn; fzs[idT] = fT;
@@ -711,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       const double rho_s = w[idR][wi] + hyc;
       const double rho_n = (STAGE == 1) ? rho_s : snv[idR] + hyc;
       double imm_coef = 0;
-      if (p.use_immersed) { double tau = 1.e3 * dt_stage; imm_coef = -fmin(1.0, dt_stage / tau); }
+      if (Cf<K>::immersed(p)) { double tau = 1.e3 * dt_stage; imm_coef = -fmin(1.0, dt_stage / tau); }
       const double ru_s = w[idU][wi] * rho_s, rv_s = w[idV][wi] * rho_s;
       double inv_rho_new = 1.0;
       double *so = Sout + slab0 + (long long)(kc + p.HZ) * p.sK;
@@ -726,11 +748,11 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
         if (STAGE == 1) q_n = q_s;
         else q_n = (l == idR || l == idT) ? snv[l] : snv[l] * rho_n;
         double tend = xpart[l] - (fzs[l] - fzprev[l]) * p.rdz;
-        if (l == idW && p.enable_gravity) tend += -p.grav * rho_s;
-        if (l == idU) tend += p.fcor * rv_s;
-        if (l == idV) tend -= p.fcor * ru_s;
-        if (l == idV && p.sim2d) tend = 0;
-        if (p.use_immersed) { double imm_tend = imm_coef * q_s / dt_stage; tend = immv * imm_tend + (1 - immv) * tend; }
+        if (l == idW && Cf<K>::gravity(p)) tend += -p.grav * rho_s;
+        if (l == idU && Cf<K>::coriolis(p)) tend += p.fcor * rv_s;
+        if (l == idV && Cf<K>::coriolis(p)) tend -= p.fcor * ru_s;
+        if (l == idV && Cf<K>::sim2d(p)) tend = 0;
+        if (Cf<K>::immersed(p)) { double imm_tend = imm_coef * q_s / dt_stage; tend = immv * imm_tend + (1 - immv) * tend; }
         double qnew;
         if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
         else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
@@ -975,7 +997,7 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
 //   reconstructions at k = ka-2 and kb+1, S2 / S3 before their first cell -- save 1 % at run time but cost 30-40 VGPRs (spills in
 //   the MODE 1 variant) and the kernel as a whole became 15 % slower.  The loop body stays branch-free.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int STAGE, int MODE, int T, bool N1>
+template <int STAGE, int MODE, int T, bool N1, int K>
 __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *__restrict__ S, const double *__restrict__ Sn, double *Sout,
                                                        const double *__restrict__ FY, const double *__restrict__ MX,
                                                        const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
@@ -984,6 +1006,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
                                                        double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4) {
   const int n = N1 ? 1 : p.nens;
   constexpr int t0 = 0;                                       // one group: all (<= 4) tracers of the cell
+  constexpr bool MW_FENCED = Cf<K>::spec;                     // (see MW_SCHED_FENCE)
   const int lane = threadIdx.x & 63;
   const int NXI = p.nx * n;
   // halo cells per side.  nens == 1 (DPP shifts): the multiplier of the cell next to the updated range needs the x flux of
@@ -1032,7 +1055,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const long long fxo = (long long)j * p.fxJ + qf;
   const long long fzo = (long long)j * p.fzJ + qm;
   const long long fyo = (long long)j * p.fyJ + qm;
-  const bool do_y = !p.sim2d;
+  const bool do_y = !Cf<K>::sim2d(p);
   const int ka = blk.y * chunk, kb = min(ka + chunk, p.nz);
   const int k_lo = max(ka - 1, 0);                            // cells k_lo .. k_hi get all six fluxes (FCT multiplier)
   const int k_hi = min(kb, p.nz - 1);
@@ -1077,7 +1100,9 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     const int upx = UPX[(long long)kx * p.fxK + fxo];
     const double mz = MZ[(long long)kz * p.fzK + fzo];
     const int upz = UPZ[(long long)kz * p.fzK + fzo];
-    const double rhop = S[(long long)idR * p.sV + (long long)(kpc + p.HZ) * p.sK + so_row] + p.hyc[kpc * p.nens + e];
+    // (loaded values are only NAMED in this section; the first arithmetic on them -- "+ hyc" -- comes behind the reconstructions:
+    //  an add in here waits for its operands in the middle of the loads that are still to be issued)
+    const double rhop_raw = S[(long long)idR * p.sV + (long long)(kpc + p.HZ) * p.sK + so_row], hyc_p = p.hyc[kpc * p.nens + e];
     double fys[T], fyn[T];
 #pragma unroll
     for (int v = 0; v < T; v++) {
@@ -1086,12 +1111,12 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     }
     const long long so = (long long)(kuc + p.HZ) * p.sK + so_row;
     const double hyc_u = p.hyc[kuc * p.nens + e];
-    double rho_new = Sout[so + idR * p.sV] + hyc_u;
-    double qn_[T], rho_n = 0, st_T = 0;
+    const double rho_new_raw = Sout[so + idR * p.sV];
+    double qn_[T], rho_n_raw = 0, st_T = 0;
 #pragma unroll
     for (int v = 0; v < T; v++) qn_[v] = 0;
     if (STAGE != 1) {
-      rho_n = Sn[so + idR * p.sV] + hyc_u;
+      rho_n_raw = Sn[so + idR * p.sV];
 #pragma unroll
       for (int v = 0; v < T; v++) qn_[v] = Sn[so + (5 + t0 + v) * p.sV];
     }
@@ -1105,14 +1130,16 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       if (!N1) { nbw2[v] = lvl[om2]; nbw1[v] = lvl[om1]; nbe1[v] = lvl[op1]; nbe2[v] = lvl[op2]; }
     }
     // ------------------------------------------------ S1: z reconstruction (registers only), then the fluxes of level k
+    if (MW_FENCED) MW_SCHED_FENCE();
     double te[T], fxn[T], fzn[T], be_[T], xe_[T];
 #pragma unroll
     for (int v = 0; v < T; v++) {                                // all reconstructions first: they need no loaded operand
       weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be_[v], te[v]);
       if (!cell) be_[v] = 0;
+      if (MW_FENCED) MW_SCHED_FENCE();
     }
     {
-      const bool quirk = bc_mode_x(p, i) == 3;
+      const bool quirk = bc_mode_x<K>(p, i) == 3;
 #pragma unroll
       for (int v = 0; v < T; v++) {
         double c0 = w[v][2], m2 = nbw2[v], m1 = nbw1[v], p1 = nbe1[v], p2 = nbe2[v];
@@ -1129,11 +1156,14 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         double Lq = from_west<N1>(ee, lane, n);
         be_[v] = upz ? be_[v] : ct[v];
         xe_[v] = upx ? we : Lq;
+        if (MW_FENCED) MW_SCHED_FENCE();
       }
     }
 #pragma unroll
     for (int v = 0; v < T; v++) { fzn[v] = mz * be_[v]; fxn[v] = mx * xe_[v]; }
     // ------------------------------------------------ S2: cell k-1 -> multiplier, scaled faces, partial tendency
+    const double rhop = rhop_raw + hyc_p;
+    double rho_new = rho_new_raw + hyc_u, rho_n = (STAGE != 1) ? rho_n_raw + hyc_u : 0.0;
     double szn[T], Pn[T];
     {
       const bool rec = upd && s2cell && (kp >= ka) && (kp < kb);           // the unique owner of cell (kp, j, q)
@@ -1150,7 +1180,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
           const double out_y = (fmax(fyn[v], 0.0) - fmin(fys[v], 0.0)) * p.rdy;
           const double out_z = (fmax(fzn[v], 0.0) - fmin(fzp[v], 0.0)) * p.rdz;
           const double mass_out = (out_x + out_y + out_z) * dt;
-          if (__builtin_expect(s2cell && has_mult && ((p.pos_mask >> (t0 + v)) & 1u) && mass_out > mass_available, 0))
+          if (__builtin_expect(s2cell && has_mult && Cf<K>::positive(p, t0 + v) && mass_out > mass_available, 0))
             mult = mass_available / mass_out;
         }
         const double mult_w = from_west<N1>(mult, lane, n);
@@ -1188,19 +1218,19 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
         else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
         else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
-        if ((p.pos_mask >> (t0 + v)) & 1u) qnew = fmax(0.0, qnew);
+        if (Cf<K>::positive(p, t0 + v)) qnew = fmax(0.0, qnew);
         if (MODE == 0) { if (st) Sout[so + (5 + t0 + v) * p.sV] = qnew * inv_rho_new; }
         else {
           if (st) c.tr[v][cpl(p, ci)] = qnew;
-          if (v == p.idWV) rho_v = qnew;
-          if ((p.mass_mask >> v) & 1u) rho_dry -= qnew;
+          if (Cf<K>::is_wv(p, v)) rho_v = qnew;
+          if (Cf<K>::adds_mass(p, v)) rho_dry -= qnew;
         }
       }
       if (MODE == 1 && st) {
         // D13 (:1929-1935): p = C0 (rho theta)^gamma with rho theta = hy + (rho theta)' -- the same series around the hydrostatic
         // state as in the Riemann solver (device pow for large perturbations); rho*(rho theta / rho) differs from rho theta by rounding
         const double *bg = lds_bg + ((kuc - bg_l0) * p.nens + e) * 3;
-        double press = pressure_fast(p, st_T, bg[0], bg[1], bg[2]);
+        double press = pressure_fast<K>(p, st_T, bg[0], bg[1], bg[2]);
         c.rho_d[cpl(p, ci)] = rho_dry;
         c.temp[cpl(p, ci)] = press / (rho_dry * p.R_d + rho_v * p.R_v);
       }

@@ -4,7 +4,7 @@
 set -e
 name=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
-C=$R/miniweatherml_amd/csrc
+C=${MW_SRC_DIR:-$R/miniweatherml_amd/csrc}     # MW_SRC_DIR: another checkout's csrc (e.g. `git archive <rev>` for a same-box baseline)
 mkdir -p $R/miniweatherml_amd/variants /tmp/mwvar_$name
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function -Wno-unused-variable -ffp-contract=on -I/opt/rocm/include"
 objs=""
