@@ -878,8 +878,7 @@ struct mw_dycore_s {
   double *M[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};          // upwind mass flux of every x/y/z face,
   unsigned char *UP[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // upwind selector; double-buffered by stage parity
   hipStream_t tstream = nullptr;                        // tracer pipeline (runs one stage behind / beside the state pipeline)
-  hipEvent_t ev_state[8] = {nullptr}, ev_tr[8] = {nullptr}, ev_ystate[8] = {nullptr}, ev_misc = nullptr;
-  int early_yt = 0;                                     // two-stream schedule: k_y_tracers starts behind k_y_state, beside k_xz_state
+  hipEvent_t ev_state[8] = {nullptr}, ev_tr[8] = {nullptr}, ev_misc = nullptr;
   long long gstage = 0;                                 // global stage counter (event ring index, buffer parity)
   int overlap = 1;
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
@@ -1410,23 +1409,16 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   const bool conv = (STAGE == 1) && d->conv_pending;            // first stage of the step: D1 + D2 inside k_y_state
   d->conv_pending = false;
   if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
-  // (k_y_tracers only needs this stage's y faces: it may run BESIDE k_xz_state -- an HBM-bound launch beside a VALU-bound one)
-  const bool early_yt = d->overlap && d->early_yt;
-  if (early_yt) MW_HIP(hipEventRecord(d->ev_ystate[slot], ss));
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
   // previous stage, which this stream produced itself: it is issued BEFORE the wait for this stage's state kernels and so
   // runs beside them; the state stream's exchange for stage s+1 in turn runs beside this stage's tracer kernels.
+  // (Measured, round 3 -- profiles/r03_ab_two_stream_yt_beside_xz.txt: letting k_y_tracers start right behind k_y_state, BESIDE
+  //  k_xz_state (an HBM-bound launch beside a VALU-bound one), stretches both and leaves the step where it was: 5.62-5.74 ms against
+  //  5.51-5.70 on one stream.  The step as a whole moves 26 GB at 4.8 TB/s: there is no idle HBM time for a second kernel to use.)
   if (halo_fill(d, Sin, 5, T, ts, 1, true)) return 1;
-  if (d->overlap) MW_HIP(hipEventRecord(d->ev_state[slot], ss));
-  if (early_yt) {
-    MW_HIP(hipStreamWaitEvent(ts, d->ev_ystate[slot], 0));
-    if (launch_y_tracers(d, Sin, par, ts)) return 1;
-    MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0));
-  } else {
-    if (d->overlap) MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0));
-    if (launch_y_tracers(d, Sin, par, ts)) return 1;                          // tracer fluxes (public arrays)
-  }
+  if (d->overlap) { MW_HIP(hipEventRecord(d->ev_state[slot], ss)); MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0)); }
+  if (launch_y_tracers(d, Sin, par, ts)) return 1;                            // tracer fluxes (public arrays)
   if (d->fused) {
     if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ts)) return 1;   // x/z fluxes + D10 + D11/D12 (+ D13)
   } else {
@@ -1541,9 +1533,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
                                 : hipStreamCreateWithPriority(&d->tstream, hipStreamNonBlocking, pm == 1 ? least : greatest);
       if (er != hipSuccess) { set_error("hipStreamCreate failed"); return fail(); } }
     for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
-                                    hipEventCreateWithFlags(&d->ev_ystate[i], hipEventDisableTiming) != hipSuccess ||
                                     hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
-    { const char *ey = getenv("MW_EARLY_YT"); d->early_yt = ey ? atoi(ey) : 0; }
     if (hipEventCreateWithFlags(&d->ev_misc, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
   }
   fill_params(d);
@@ -1560,8 +1550,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->flags) (void)hipFree(d->flags);
   if (d->dirty) (void)hipFree(d->dirty);
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
-  for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]);
-                                if (d->ev_ystate[i]) (void)hipEventDestroy(d->ev_ystate[i]); }
+  for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
