@@ -169,6 +169,9 @@ const char *mw_rccl_library_path(int *version);
 /* Diagnostic: one rank sends 4 strips of n doubles to itself through the exchange's own ncclGroup / side stream / event
  * sequence and compares; 0 = RCCL initialises on this box and the ordering against `stream` holds. */
 int  mw_rccl_selftest(long long n, void *stream);
+/* Number of exchange lanes (side stream + communicator each; one per pipeline of the two-stream schedule) that the last
+ * mw_rccl_selftest drove: 2 when the process's RCCL provides ncclCommSplit, else 1. */
+int  mw_rccl_selftest_lanes(void);
 
 /* ---- Kessler microphysics ------------------------------------------------------------------------- */
 /* Microphysics_Kessler::time_step(coupler, dt), microphysics_kessler.h:99-162 + kessler() :234-339.

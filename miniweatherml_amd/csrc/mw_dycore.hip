@@ -1253,6 +1253,8 @@ static int xz_grid(mw_dycore_s *d, const DyP &p, dim3 &grid, int &chunk, int &ti
     // k_xz_state: equal chunks, enough of them for ~5 rounds of 2 waves/SIMD over the 1024 SIMDs (measured on 400x400x100:
     // 4 x 25 levels beats 32,32,32,4 by 4 %)
     d->chunk_z = balanced_chunk(p.nz, waves, "MW_CHUNK_Z", 10000, 2, 2.5, true);
+    // k_xz_state<.., HPL = 1> keeps (chunk + 2) rows of 64 bytes in dynamic LDS: stay well inside the 64 KB a workgroup may have
+    d->chunk_z = std::min(d->chunk_z, 900);
   }
   chunk = d->chunk_z;
   grid = dim3((unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
@@ -1477,6 +1479,17 @@ static int validate_grid(const mw_grid_t *g) {
   return 0;
 }
 
+// The halo kernels fill a periodic halo from the interior of the SAME block (halo_x_body: src = ih + nx) and the pack kernels read
+// HX / HY interior cells per side: a block narrower than its halo would read halo cells that are not filled yet and give silently
+// wrong results.  (3 cells up to WENO-5; 4 / 5 for orders 7 / 9; z only when bc_z is periodic -- wall / open copy one level.)
+static int check_halo_fit(const mw_dycore_s *d) {
+  const DyP &p = d->p;
+  if (p.nx < p.HX) MW_FAIL("nx = " + std::to_string(p.nx) + " per rank is narrower than the x halo of WENO order " + std::to_string(d->ord) + " (" + std::to_string(p.HX) + " cells)");
+  if (!p.sim2d && p.ny < p.HY) MW_FAIL("ny = " + std::to_string(p.ny) + " per rank is narrower than the y halo of WENO order " + std::to_string(d->ord) + " (" + std::to_string(p.HY) + " cells)");
+  if (p.bc_z == MW_BC_PERIODIC && p.nz < p.HZ) MW_FAIL("nz = " + std::to_string(p.nz) + " is smaller than the z halo of WENO order " + std::to_string(d->ord) + " (" + std::to_string(p.HZ) + " levels) with bc_z = periodic");
+  return 0;
+}
+
 extern "C" {
 
 int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tracer_positive,
@@ -1566,36 +1579,48 @@ double *mw_dycore_immersed_proportion(mw_dycore_t d) { return d ? d->imm : nullp
 int mw_dycore_set_bc(mw_dycore_t d, int bc_x, int bc_y, int bc_z) {
   if (!d) MW_FAIL("null handle");
   for (int b : {bc_x, bc_y, bc_z}) if (b != MW_BC_PERIODIC && b != MW_BC_OPEN && b != MW_BC_WALL) MW_FAIL("bc_x / bc_y / bc_z must be 0 (periodic), 1 (open) or 2 (wall)");
+  const int old[3] = {d->g.bc_x, d->g.bc_y, d->g.bc_z};
   d->g.bc_x = bc_x; d->g.bc_y = bc_y; d->g.bc_z = bc_z;
   fill_params(d);
+  if (check_halo_fit(d)) { d->g.bc_x = old[0]; d->g.bc_y = old[1]; d->g.bc_z = old[2]; fill_params(d); return 1; }
   return 0;
 }
 int mw_dycore_set_strict(mw_dycore_t d, int strict) { if (!d) MW_FAIL("null handle"); d->strict = strict; return 0; }
 int mw_dycore_set_order(mw_dycore_t d, int ord) {
   if (!d) MW_FAIL("null handle");
   if (ord != 3 && ord != 5 && ord != 7 && ord != 9) MW_FAIL("WENO order must be 3, 5, 7 or 9");
-  d->ord = ord;
   // orders 7 and 9 reach further: x / y halo hs + 1 (the neighbour's edge value is rebuilt locally), z halo hs
   const int hs = (ord - 1) / 2, hx = std::max(HXc, hs + 1), hz = std::max(HZc, hs);
-  if (hx != d->hxw || hz != d->hzw) {
+  const int old_ord = d->ord, old_hx = d->hxw, old_hz = d->hzw;
+  auto rollback = [&]() { d->ord = old_ord; d->hxw = old_hx; d->hzw = old_hz; fill_params(d); return 1; };
+  d->ord = ord; d->hxw = hx; d->hzw = hz;
+  fill_params(d);
+  if (check_halo_fit(d)) return rollback();
+  if (hx != old_hx || hz != old_hz) {
     MW_HIP(hipStreamSynchronize(d->stream));
     if (d->tstream) MW_HIP(hipStreamSynchronize(d->tstream));
-    d->hxw = hx; d->hzw = hz;
-    fill_params(d);
+    // the four slabs in their new size first; the handle only changes once all of them exist
     const size_t slab = (size_t)d->p.V * d->p.sV * sizeof(double);
-    for (double **S : {&d->S0, &d->S1, &d->S2, &d->S3}) {
-      if (*S) (void)hipFree(*S);
-      *S = nullptr;
-      MW_HIP(hipMalloc(S, slab));
-      MW_HIP(hipMemsetAsync(*S, 0, slab, d->stream));           // halo corners are never written (as in create)
+    double *fresh[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; i++) {
+      if (hipMalloc(&fresh[i], slab) != hipSuccess || hipMemsetAsync(fresh[i], 0, slab, d->stream) != hipSuccess) {   // halo corners are never written (as in create)
+        for (int j = 0; j <= i; j++) if (fresh[j]) (void)hipFree(fresh[j]);
+        set_error("mw_dycore_set_order: hipMalloc of the wider slabs failed (the handle keeps its previous order)");
+        return rollback();
+      }
     }
+    double **S[4] = {&d->S0, &d->S1, &d->S2, &d->S3};
+    for (int i = 0; i < 4; i++) { if (*S[i]) (void)hipFree(*S[i]); *S[i] = fresh[i]; }
+    d->flux_src = nullptr;                                      // pointed into a slab that no longer exists
+    d->chunk_y = d->chunk_yt = d->chunk_z = d->chunk_f = 0;
     d->nWE1 = (long long)d->p.nz * d->p.ny * d->p.HX * d->p.nens;
     d->nSN1 = (long long)d->p.nz * d->p.HY * d->p.nx * d->p.nens;
     bool had = false;
     for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) { (void)hipFree(d->bufs[g][b]); d->bufs[g][b] = nullptr; had = true; }
     if (had) {                                                  // strips are HX / HY cells deep: re-allocate (the transport and its owner stay)
-      auto owner = d->xchg_free;
-      if (mw_dycore_set_exchange(d, d->xchg, d->xchg_ctx)) return 1;
+      auto owner = d->xchg_free; auto fn = d->xchg; void *ctx = d->xchg_ctx;
+      d->xchg_free = nullptr;                                   // (set_exchange must not free the context it is about to re-install)
+      if (mw_dycore_set_exchange(d, fn, ctx)) { d->xchg_free = owner; d->xchg = fn; d->xchg_ctx = ctx; return 1; }
       d->xchg_free = owner;
     }
     MW_HIP(hipStreamSynchronize(d->stream));
@@ -1659,8 +1684,8 @@ int mw_dycore_set_exchange(mw_dycore_t d, mw_exchange_fn fn, void *ctx) {
     d->xchg_free(d->xchg_ctx);
   }
   d->xchg_free = nullptr;
-  d->xchg = fn; d->xchg_ctx = ctx;
-  if (fn) {
+  d->xchg = nullptr; d->xchg_ctx = nullptr;                    // committed below, once the strip buffers exist: a failed allocation
+  if (fn) {                                                    // must not leave a transport (and a context its owner then frees) behind
     for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) {
       if (d->bufs[g][b]) continue;
       long long n = ((b % 4 < 2) ? d->nWE1 : d->nSN1) * d->p.V;          // sized for all V variables
@@ -1668,6 +1693,7 @@ int mw_dycore_set_exchange(mw_dycore_t d, mw_exchange_fn fn, void *ctx) {
       MW_HIP(hipMalloc(&d->bufs[g][b], (size_t)n * sizeof(double)));
     }
   }
+  d->xchg = fn; d->xchg_ctx = ctx;
   return 0;
 }
 
@@ -1697,7 +1723,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   if (make_coupler_ptrs(d, rho_d, u, v, w, temp, tracers, c)) return 1;
   fill_params(d);
   const DyP &p = d->p;
-  if (need_exchange(d)) return 1;
+  if (need_exchange(d) || check_halo_fit(d)) return 1;
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
   // production path; strict = 1/2 use the general flux-materialising kernels below.  So does a z-PERIODIC domain (:752-763,
   // :1008-1019; no shipped case): the marching kernels apply the wall / open z rule while loading and have no periodic form.
@@ -1774,7 +1800,7 @@ int mw_dycore_compute_tendencies(mw_dycore_t d, const double *rho_d, const doubl
   if (make_coupler_ptrs(d, rho_d, u, v, w, temp, tracers, c)) return 1;
   fill_params(d);
   const DyP &p = d->p;
-  if (need_exchange(d)) return 1;
+  if (need_exchange(d) || check_halo_fit(d)) return 1;
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
   hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK();
   if (halo_fill(d, d->S0)) return 1;

@@ -34,6 +34,7 @@ struct H5File {
     for (int i = n - 1; i >= 0; i--) v = (v << 8) | b[off + i];
     return v;
   }
+  int byte(uint64_t off) { return (int)u(off, 1); }          // one byte, bounds-checked like everything that comes from the file
   bool sig(uint64_t off, const char *s4) { return in(off, 4) && memcmp(&b[off], s4, 4) == 0; }
 };
 
@@ -48,7 +49,7 @@ bool parse_messages(H5File &f, uint64_t off, uint64_t len, int &remaining, ObjIn
 
 bool parse_header(H5File &f, uint64_t addr, ObjInfo &o) {
   if (!f.in(addr, 16)) return f.fail("h5: object header address beyond the end of the file");
-  if (f.b[addr] != 1) return f.fail("h5: only version-1 object headers are supported (this file uses a newer object header)");
+  if (f.byte(addr) != 1) return f.fail("h5: only version-1 object headers are supported (this file uses a newer object header)");
   int nmsg = (int)f.u(addr + 2, 2);
   uint64_t hsize = f.u(addr + 8, 4);
   return parse_messages(f, addr + 16, hsize, nmsg, o, 0);
@@ -64,36 +65,46 @@ bool parse_messages(H5File &f, uint64_t off, uint64_t len, int &remaining, ObjIn
     if (!f.in(d, size)) return f.fail("h5: header message beyond the end of the file");
     remaining--;
     if (type == 0x0011) {                                    // symbol table message: this object is an old-style group
+      if (size < 16) return f.fail("h5: symbol table message too short");
       o.has_symtab = true; o.btree = f.u(d, 8); o.heap = f.u(d + 8, 8);
     } else if (type == 0x0001) {                             // dataspace
-      const int ver = f.b[d], rank = f.b[d + 1];
+      if (size < 4) return f.fail("h5: dataspace message too short");
+      const int ver = f.byte(d), rank = f.byte(d + 1);
       uint64_t p = (ver == 1) ? d + 8 : d + 4;
       if (ver != 1 && ver != 2) return f.fail("h5: unsupported dataspace message version");
-      if (ver == 2 && f.b[d + 3] == 2) return f.fail("h5: null dataspace");
+      if (ver == 2 && f.byte(d + 3) == 2) return f.fail("h5: null dataspace");
+      if (rank > 8 || !f.in(p, 8 * (uint64_t)rank)) return f.fail("h5: dataspace rank / extent beyond the message");
       o.dims.clear();
       for (int r = 0; r < rank; r++) o.dims.push_back((long long)f.u(p + 8 * (uint64_t)r, 8));
       o.has_space = true;
     } else if (type == 0x0003) {                             // datatype
-      const int cls = f.b[d] & 0x0F;
-      const int bits0 = f.b[d + 1];
+      if (size < 8) return f.fail("h5: datatype message too short");
+      const int cls = f.byte(d) & 0x0F;
+      const int bits0 = f.byte(d + 1);
       const uint64_t tsize = f.u(d + 4, 4);
       o.has_type = true;
       o.type_ok = (cls == 1 && tsize == 4 && (bits0 & 1) == 0);       // floating point, 4 bytes, little-endian
       o.type_desc = "class " + std::to_string(cls) + ", " + std::to_string(tsize) + " bytes" + ((bits0 & 1) ? ", big-endian" : "");
     } else if (type == 0x0008) {                             // data layout
-      const int ver = f.b[d];
+      if (size < 4) return f.fail("h5: data layout message too short");
+      const int ver = f.byte(d);
       o.has_layout = true;
       if (ver == 3) {
-        o.layout_class = f.b[d + 1];
+        o.layout_class = f.byte(d + 1);
         if (o.layout_class == 0) { o.data_size = f.u(d + 2, 2); o.data_addr = d + 4; }
         else if (o.layout_class == 1) { o.data_addr = f.u(d + 2, 8); o.data_size = f.u(d + 10, 8); }
       } else if (ver == 1 || ver == 2) {
-        const int rank = f.b[d + 1];
-        o.layout_class = f.b[d + 2];
+        const int rank = f.byte(d + 1);
+        o.layout_class = f.byte(d + 2);
+        if (rank > 9) return f.fail("h5: data layout rank out of range");
         if (o.layout_class == 1) {                           // contiguous: address, then `rank` 4-byte dimension sizes (bytes = their product)
           o.data_addr = f.u(d + 8, 8);
           uint64_t n = 1;
-          for (int r = 0; r < rank; r++) n *= f.u(d + 16 + 4 * (uint64_t)r, 4);
+          for (int r = 0; r < rank; r++) {
+            const uint64_t e = f.u(d + 16 + 4 * (uint64_t)r, 4);
+            if (e != 0 && n > (uint64_t)f.b.size() / e) return f.fail("h5: data layout larger than the file");
+            n *= e;
+          }
           o.data_size = n;
         } else if (o.layout_class == 0) {                    // compact: dimension sizes, then the size of the data and the data
           const uint64_t q = d + 8 + 4 * (uint64_t)rank;
@@ -101,7 +112,9 @@ bool parse_messages(H5File &f, uint64_t off, uint64_t len, int &remaining, ObjIn
         }
       } else return f.fail("h5: unsupported data layout message version " + std::to_string(ver));
     } else if (type == 0x0010) {                             // continuation: more messages elsewhere
+      if (size < 16) return f.fail("h5: continuation message too short");
       const uint64_t coff = f.u(d, 8), clen = f.u(d + 8, 8);
+      if (!f.in(coff, clen)) return f.fail("h5: continuation block beyond the end of the file");
       if (!parse_messages(f, coff, clen, remaining, o, depth + 1)) return false;
     }
     off = d + size;
@@ -114,13 +127,14 @@ bool parse_messages(H5File &f, uint64_t off, uint64_t len, int &remaining, ObjIn
 bool find_child(H5File &f, uint64_t btree, uint64_t heap, const std::string &name, uint64_t &obj_addr) {
   if (!f.sig(heap, "HEAP")) return f.fail("h5: local heap signature not found");
   const uint64_t heap_data = f.u(heap + 24, 8), heap_size = f.u(heap + 8, 8);
+  if (!f.err.empty() || !f.in(heap_data, heap_size)) return f.fail("h5: local heap data segment beyond the end of the file");
   std::vector<uint64_t> stack{btree};
   int guard = 0;
   while (!stack.empty()) {
     if (++guard > 100000) return f.fail("h5: group B-tree does not terminate");
     const uint64_t node = stack.back(); stack.pop_back();
     if (f.sig(node, "TREE")) {
-      if (f.b[node + 4] != 0) return f.fail("h5: unexpected B-tree node type in a group");
+      if (f.byte(node + 4) != 0) return f.fail("h5: unexpected B-tree node type in a group");
       const int used = (int)f.u(node + 6, 2);
       uint64_t p = node + 24;                                // key 0
       for (int e = 0; e < used; e++) { stack.push_back(f.u(p + 8, 8)); p += 16; }      // (key, child) pairs: child after each key
@@ -186,9 +200,13 @@ extern "C" int mw_h5_read_f32(const char *file, const char *group, const char *d
   if (!o.has_space || !o.has_type || !o.has_layout) return bad("h5_read_f32: " + path + " is not a dataset");
   if (!o.type_ok) return bad("h5_read_f32: " + path + " is not little-endian 32-bit float (" + o.type_desc + ")");
   if (o.layout_class != 0 && o.layout_class != 1) return bad("h5_read_f32: " + path + " is stored chunked; only contiguous / compact data are supported");
-  long long n = 1;
-  for (long long d : o.dims) n *= d;
   if ((int)o.dims.size() > 8) return bad("h5_read_f32: rank > 8");
+  long long n = 1;
+  for (long long d : o.dims) {                               // untrusted: positive, and the product no larger than the file could hold
+    if (d <= 0) return bad("h5_read_f32: " + path + " has a non-positive dimension");
+    if (n > (long long)(f.b.size() / 4) / d) return bad("h5_read_f32: " + path + ": shape larger than the file");
+    n *= d;
+  }
   if (ndims) *ndims = (int)o.dims.size();
   if (dims) for (size_t r = 0; r < o.dims.size(); r++) dims[r] = o.dims[r];
   if (!out) return 0;                                        // shape query only

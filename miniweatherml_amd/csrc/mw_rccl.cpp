@@ -38,6 +38,7 @@ struct RcclApi {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;
+  decltype(&ncclCommSplit) CommSplit = nullptr;           // optional (NCCL >= 2.18): the second lane's communicator
   std::string path;
   bool ok = false;
 };
@@ -60,6 +61,7 @@ RcclApi &rccl_api() {
     MW_SYM(GroupStart, ncclGroupStart) MW_SYM(GroupEnd, ncclGroupEnd) MW_SYM(Send, ncclSend) MW_SYM(Recv, ncclRecv)
     MW_SYM(GetErrorString, ncclGetErrorString) MW_SYM(GetVersion, ncclGetVersion)
 #undef MW_SYM
+    api.CommSplit = (decltype(api.CommSplit))dlsym(h, "ncclCommSplit");
     Dl_info di;
     if (dladdr((void *)api.Send, &di) && di.dli_fname) api.path = di.dli_fname;
     api.ok = true;
@@ -70,10 +72,21 @@ RcclApi &rccl_api() {
   RcclApi &R = rccl_api();                                                                              \
   if (!R.ok) MW_FAIL("RCCL is not available: no librccl.so is mapped in this process and none could be loaded")
 
-struct RcclCtx {
+// Two LANES: the dycore's state and tracer pipelines (rk_stage_march in mw_dycore.hip) exchange their strips from two different
+// streams, each hiding the other's transfer.  With one side stream and one communicator the two exchanges would queue behind each
+// other; each lane therefore has its own side stream, event pair and communicator (lane 1's is split off lane 0's with
+// ncclCommSplit: same ranks, same order, no second unique id in the ABI).  A lane belongs to the first caller stream that uses
+// it; a third stream -- or an RCCL without ncclCommSplit -- shares lane 0.  Every rank issues the same calls in the same order on
+// every lane (the schedule is a function of the stage counter alone), which is what a communicator requires.
+struct RcclLane {
   ncclComm_t comm = nullptr;
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr, owner = nullptr;
+  bool owned = false;                                           // `owner` has been assigned
   hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+};
+struct RcclCtx {
+  RcclLane lane[2];
+  int nlanes = 1;
   int peers[4], send_order[4], recv_order[4], active[4];        // mw_exchange_plan
 };
 
@@ -84,12 +97,36 @@ struct RcclCtx {
 void free_ctx(RcclCtx *c) {
   if (!c) return;
   RcclApi &R = rccl_api();
-  if (c->side) (void)hipStreamSynchronize(c->side);
-  if (c->comm && R.ok) (void)R.CommDestroy(c->comm);
-  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
-  if (c->side) (void)hipStreamDestroy(c->side);
+  for (int l = 1; l >= 0; l--) {                                // the split communicator before its parent
+    RcclLane &L = c->lane[l];
+    if (L.side) (void)hipStreamSynchronize(L.side);
+    if (L.comm && R.ok) (void)R.CommDestroy(L.comm);
+    if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
+    if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+    if (L.side) (void)hipStreamDestroy(L.side);
+  }
   delete c;
+}
+// streams and events of the lanes; lane 1 only when a second communicator can be split off
+int init_lanes(RcclCtx *c, RcclApi &R, int nranks, int myrank) {
+  c->nlanes = 1;
+  if (R.CommSplit && !getenv("MW_RCCL_ONE_LANE")) {
+    ncclResult_t r = R.CommSplit(c->lane[0].comm, 0, myrank, &c->lane[1].comm, nullptr);
+    if (r == ncclSuccess && c->lane[1].comm) c->nlanes = 2; else c->lane[1].comm = nullptr;
+  }
+  for (int l = 0; l < c->nlanes; l++) {
+    RcclLane &L = c->lane[l];
+    if (hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&L.ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess) { mw::set_error("mw_rccl: stream/event creation failed"); return 1; }
+  }
+  (void)nranks;
+  return 0;
+}
+RcclLane &lane_of(RcclCtx *c, hipStream_t caller) {
+  for (int l = 0; l < c->nlanes; l++) if (c->lane[l].owned && c->lane[l].owner == caller) return c->lane[l];
+  for (int l = 0; l < c->nlanes; l++) if (!c->lane[l].owned) { c->lane[l].owned = true; c->lane[l].owner = caller; return c->lane[l]; }
+  return c->lane[0];
 }
 
 int rccl_exchange(void *vctx, const double *sW, const double *sE, const double *sS, const double *sN, double *rW, double *rE,
@@ -97,19 +134,20 @@ int rccl_exchange(void *vctx, const double *sW, const double *sE, const double *
   RcclCtx *c = (RcclCtx *)vctx;
   MW_NEED_RCCL();
   hipStream_t main_stream = (hipStream_t)vstream;
-  MW_HIP(hipEventRecord(c->ev_ready, main_stream));          // pack kernels done
-  MW_HIP(hipStreamWaitEvent(c->side, c->ev_ready, 0));
+  RcclLane &L = lane_of(c, main_stream);
+  MW_HIP(hipEventRecord(L.ev_ready, main_stream));           // pack kernels done
+  MW_HIP(hipStreamWaitEvent(L.side, L.ev_ready, 0));
   const double *sbuf[4] = {sW, sE, sS, sN};
   double *rbuf[4] = {rW, rE, rS, rN};
   const long long cnt[4] = {nWE, nWE, nSN, nSN};
   MW_NCCL(R.GroupStart());
   for (int o = 0; o < 4; o++) { int dir = c->send_order[o];
-    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Send(sbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], c->comm, c->side)); }
+    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Send(sbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], L.comm, L.side)); }
   for (int o = 0; o < 4; o++) { int dir = c->recv_order[o];
-    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Recv(rbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], c->comm, c->side)); }
+    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Recv(rbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], L.comm, L.side)); }
   MW_NCCL(R.GroupEnd());
-  MW_HIP(hipEventRecord(c->ev_done, c->side));
-  MW_HIP(hipStreamWaitEvent(main_stream, c->ev_done, 0));    // unpack kernels wait for the strips
+  MW_HIP(hipEventRecord(L.ev_done, L.side));
+  MW_HIP(hipStreamWaitEvent(main_stream, L.ev_done, 0));     // unpack kernels wait for the strips
   return 0;
 }
 } // namespace
@@ -143,15 +181,17 @@ int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, in
   RcclCtx *c = new RcclCtx();
   auto fail = [&]() { free_ctx(c); return 1; };              // (the error text has been set by the failing call)
   ncclUniqueId id; memcpy(&id, id128, 128);
-  { ncclResult_t r = R.CommInitRank(&c->comm, nranks, id, myrank);
-    if (r != ncclSuccess) { c->comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
-  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { mw::set_error("mw_dycore_use_rccl: stream/event creation failed"); return fail(); }
+  { ncclResult_t r = R.CommInitRank(&c->lane[0].comm, nranks, id, myrank);
+    if (r != ncclSuccess) { c->lane[0].comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
+  if (init_lanes(c, R, nranks, myrank)) return fail();
   if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return fail();
   if (mw::dycore_set_exchange_owned(h, rccl_exchange, c, [](void *p) { free_ctx((RcclCtx *)p); })) return fail();   // the handle frees it
   return 0;
 }
+
+static int g_selftest_lanes = 0;
+// How many lanes (side stream + communicator) the last mw_rccl_selftest drove: 2 when this RCCL can split a communicator.
+int mw_rccl_selftest_lanes(void) { return g_selftest_lanes; }
 
 // Diagnostic: a 1-rank communicator that sends n doubles to itself through the same group/stream/event sequence as
 // rccl_exchange (two sends + two receives in one ncclGroup on a side stream).  Checks, on a single GPU, that RCCL initialises
@@ -164,11 +204,9 @@ int mw_rccl_selftest(long long n, void *vstream) {
   MW_NCCL(R.GetUniqueId(&id));
   RcclCtx *c = new RcclCtx();
   auto fail = [&]() { free_ctx(c); return 1; };
-  { ncclResult_t r = R.CommInitRank(&c->comm, 1, id, 0);
-    if (r != ncclSuccess) { c->comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
-  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) { mw::set_error("rccl_selftest: stream/event creation failed"); return fail(); }
+  { ncclResult_t r = R.CommInitRank(&c->lane[0].comm, 1, id, 0);
+    if (r != ncclSuccess) { c->lane[0].comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
+  if (init_lanes(c, R, 1, 0)) return fail();
   for (int d = 0; d < 4; d++) { c->peers[d] = 0; c->send_order[d] = d; c->active[d] = 1; }
   c->recv_order[0] = 1; c->recv_order[1] = 0; c->recv_order[2] = 3; c->recv_order[3] = 2;      // E,W,N,S like mw_exchange_plan
   std::vector<double> h((size_t)4 * n), back((size_t)4 * n, -1.0);
@@ -182,15 +220,30 @@ int mw_rccl_selftest(long long n, void *vstream) {
       hipMemsetAsync(dst, 0, h.size() * 8, main_stream) != hipSuccess) { mw::set_error("rccl_selftest: upload failed"); rc = 1; }
   // strips W,E (n each) and S,N (n each); my E halo = the "peer's" W strip etc.
   if (!rc) rc = rccl_exchange(c, src, src + n, src + 2 * n, src + 3 * n, dst, dst + n, dst + 2 * n, dst + 3 * n, n, n, main_stream);
+  // the second lane (the tracer pipeline's): the same exchange from a second caller stream, in flight together with the first
+  std::vector<double> back2((size_t)4 * n, -1.0);
+  double *dst2 = nullptr; hipStream_t s2 = nullptr; hipEvent_t up = nullptr;
+  if (!rc && (hipMalloc(&dst2, h.size() * 8) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess ||
+              hipEventCreateWithFlags(&up, hipEventDisableTiming) != hipSuccess)) { mw::set_error("rccl_selftest: second lane set-up failed"); rc = 1; }
+  if (!rc && (hipEventRecord(up, main_stream) != hipSuccess || hipStreamWaitEvent(s2, up, 0) != hipSuccess ||      // src is uploaded
+              hipMemsetAsync(dst2, 0, h.size() * 8, s2) != hipSuccess)) { mw::set_error("rccl_selftest: second lane set-up failed"); rc = 1; }
+  if (!rc) rc = rccl_exchange(c, src, src + n, src + 2 * n, src + 3 * n, dst2, dst2 + n, dst2 + 2 * n, dst2 + 3 * n, n, n, s2);
+  g_selftest_lanes = (c->lane[0].owned ? 1 : 0) + (c->nlanes > 1 && c->lane[1].owned ? 1 : 0);
   if (!rc && (hipMemcpyAsync(back.data(), dst, h.size() * 8, hipMemcpyDeviceToHost, main_stream) != hipSuccess ||
               hipStreamSynchronize(main_stream) != hipSuccess)) { mw::set_error("rccl_selftest: download failed"); rc = 1; }
-  (void)hipFree(src); (void)hipFree(dst);
+  if (!rc && (hipMemcpyAsync(back2.data(), dst2, h.size() * 8, hipMemcpyDeviceToHost, s2) != hipSuccess ||
+              hipStreamSynchronize(s2) != hipSuccess)) { mw::set_error("rccl_selftest: download (second lane) failed"); rc = 1; }
+  (void)hipFree(src); (void)hipFree(dst); if (dst2) (void)hipFree(dst2);
   free_ctx(c);
+  if (s2) (void)hipStreamDestroy(s2);
+  if (up) (void)hipEventDestroy(up);
   if (rc) return 1;
   // receives were posted E,W,N,S against sends W,E,S,N: rE <- sW, rW <- sE, rN <- sS, rS <- sN
   const int from[4] = {1, 0, 3, 2};                                      // dst strip d holds src strip from[d]
-  for (int d = 0; d < 4; d++) for (long long i = 0; i < n; i++)
+  for (int d = 0; d < 4; d++) for (long long i = 0; i < n; i++) {
     if (back[(size_t)d * n + i] != h[(size_t)from[d] * n + i]) MW_FAIL("rccl_selftest: received data differ from the sent data");
+    if (back2[(size_t)d * n + i] != h[(size_t)from[d] * n + i]) MW_FAIL("rccl_selftest: received data differ from the sent data (second lane)");
+  }
   return 0;
 }
 

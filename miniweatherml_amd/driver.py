@@ -56,6 +56,9 @@ def _distributed(device):
     if world == 1:
         return 1, 0, device
     import torch.distributed as dist
+    # dmabuf IPC (the host driver of this pool supports nothing else: without it RCCL between processes fails with
+    # "hipIpcGetMemHandle: invalid argument").  The HSA runtime reads it when it initialises -- at the first GPU call, below.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if device.startswith("cuda"):
         device = "cuda:%d" % local

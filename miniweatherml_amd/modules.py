@@ -840,14 +840,23 @@ def use_rccl_exchange(dycore, coupler, group=None):
     import torch.distributed as dist
     L = capi.lib()
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    ident = torch.zeros(128, dtype=torch.uint8, device=coupler.device)
+    # 128 id bytes + 1 status byte.  Rank 0 ALWAYS reaches the broadcast -- with status 1 and a zero id when it could not create the
+    # id -- and every rank raises only after it: a rank that left before the collective would leave the others waiting in it.
+    ident = torch.zeros(129, dtype=torch.uint8, device=coupler.device)
+    why = ""
     if rank == 0:
         buf = C.create_string_buffer(128)
-        check(L.mw_rccl_unique_id(buf))
-        ident.copy_(torch.tensor(list(buf.raw), dtype=torch.uint8))
+        if L.mw_rccl_unique_id(buf) != 0:
+            why = L.mw_last_error().decode(errors="replace")
+            ident[128] = 1
+        else:
+            ident[:128].copy_(torch.tensor(list(buf.raw), dtype=torch.uint8))
     dist.broadcast(ident, 0, group=group)
+    host = ident.cpu().tolist()
+    if host[128]:
+        raise MWError("rank 0 could not create the ncclUniqueId" + (": " + why if why else ""))
     with torch.cuda.device(coupler.device):
-        check(L.mw_dycore_use_rccl(dycore.h, bytes(ident.cpu().tolist()), world, rank))
+        check(L.mw_dycore_use_rccl(dycore.h, bytes(host[:128]), world, rank))
 
 
 def use_torch_distributed_exchange(dycore, coupler, group=None, host_staged=False):

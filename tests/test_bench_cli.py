@@ -25,3 +25,35 @@ def test_launcher_world_size_mismatch_is_refused():
     r = run(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0
     assert "WORLD_SIZE=2" in r.stderr
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_bench_config4_block_under_the_torchrun_launcher():
+    """The launch line the driver uses for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with N = 1 on the one GPU of the development box: RANK / LOCAL_RANK / WORLD_SIZE come
+    from the launcher, the workload is config 4's per-GPU block (256 x 512 x 128, nens 4: the member-major path), and rank 0 prints
+    ONE JSON line with the contract's keys."""
+    import json
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "config4", "--steps", "2", "--warmup", "1",
+           "--no-micro", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64"
+    assert "256x512x128 nens=4" in d["config"]["workload"] and d["config"]["baseline_config"] == "configs[3] per-GPU block"
+    assert d["value"] > 1e8                                     # a real run (the block takes ~28 ms per step)

@@ -464,3 +464,25 @@ def test_random_temperature_perturbation_is_bitwise_the_oracles(mw, oracle, nran
         other = only_noise * 0
         oracle.perturb_temperature(odyc.p, other, thermal=False, random=True, myrank=0)
         assert not np.array_equal(other, only_noise)
+
+
+def test_block_narrower_than_its_halo_is_refused(mw):
+    """A periodic halo is filled from the interior of the same block and the strips of an exchange are HX / HY cells deep: a block
+    narrower than the halo of its WENO order (3 cells up to order 5, 4 / 5 for orders 7 / 9) would read cells that are not filled
+    yet.  The handle refuses instead of computing silently wrong values, and keeps its previous order."""
+    from miniweatherml_amd import capi, modules
+    from miniweatherml_amd.capi import MWError
+    L = capi.lib()
+    coupler, dycore, micro = modules.make_supercell(4, 4, 8, 1, 2000.0, 2000.0, 20000.0, "thermal", perturb=False)
+    assert L.mw_dycore_set_order(dycore.h, 9) != 0 and b"narrower than the x halo" in L.mw_last_error()
+    assert L.mw_dycore_set_order(dycore.h, 7) == 0            # 4 cells wide: just fits the 4-cell halo of order 7
+    dt = dycore.compute_time_step(coupler)
+    dycore.time_step(coupler, dt)                             # still a working handle
+    assert L.mw_dycore_set_order(dycore.h, 5) == 0
+    assert L.mw_dycore_set_bc(dycore.h, 0, 0, 0) == 0         # z periodic: nz = 8 >= 2
+    coupler2, dycore2, _ = modules.make_supercell(6, 6, 3, 1, 3000.0, 3000.0, 20000.0, "thermal", perturb=False)
+    capi.check(L.mw_dycore_set_order(dycore2.h, 9))           # z halo 4 > nz = 3: fine with a wall ...
+    assert L.mw_dycore_set_bc(dycore2.h, 0, 0, 0) != 0 and b"bc_z = periodic" in L.mw_last_error()      # ... refused with a periodic z
+    with pytest.raises(MWError):
+        c3, d3, _ = modules.make_supercell(6, 6, 3, 1, 3000.0, 3000.0, 20000.0, "thermal", perturb=False, ord=9)
+        d3.set_bc(c3, 0, 0, 0)

@@ -15,8 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def run_job(world, nxg, nyg, nz, nsteps, mode="dycore"):
     port = free_port()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL / device-memory sharing between processes needs it on this pool (as bench.py sets it)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "gpu_dist_worker.py"), str(r), str(world), str(port), str(nxg),
-                               str(nyg), str(nz), str(nsteps), mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                               str(nyg), str(nz), str(nsteps), mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
              for r in range(world)]
     outs = []
     for p in procs:

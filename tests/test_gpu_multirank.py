@@ -87,6 +87,9 @@ def test_rccl_transport_selftest(mw):
         st = torch.cuda.current_stream().cuda_stream
         capi.check(capi.lib().mw_rccl_selftest(3 * 100 * 400 * 5, C.c_void_p(st)))          # one state strip of config 2
         capi.check(capi.lib().mw_rccl_selftest(7, C.c_void_p(st)))
+        # both lanes -- the state pipeline's and the tracer pipeline's side stream + communicator -- were driven, from two caller
+        # streams, with both exchanges in flight together (torch's RCCL 2.26 provides ncclCommSplit for the second communicator)
+        assert capi.lib().mw_rccl_selftest_lanes() == 2
 
 
 @pytest.mark.parametrize("layout", [(2, 20, 24, 10), (4, 32, 28, 8)])

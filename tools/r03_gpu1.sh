@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-bash tools/ab_bench.sh "MW_X=1" "MW_OVERLAP=1" "MW_OVERLAP=1 MW_EARLY_YT=1" "MW_OVERLAP=1 MW_EARLY_YT=1 MW_TSTREAM_PRIO=0" > gpurun_out/r03_ab4.txt 2>&1
-cat gpurun_out/r03_ab4.txt
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r03_t2.txt 2>&1
+tail -15 gpurun_out/r03_t2.txt
