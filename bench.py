@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--workload", choices=["config2", "config4"], default="config2",
                     help="config2 (default): BASELINE.json configs[1], 400x400x100 nens 1 per GPU, dx 500 m.  config4: configs[3]'s per-GPU "
                          "block 256x512x128 nens 4, dx 800 m (weak-scaling series 256x512 ... 1024x1024 global for 1 ... 8 GPUs)")
+    ap.add_argument("--ord", type=int, default=5, choices=[3, 5, 7, 9], help="WENO order (the reference's -DMW_ORD; 5 = its default and the headline; "
+                    "3 = the order its GPU benchmark environment builds, build/machines/aws/aws_a100_gpu.env:21)")
     ap.add_argument("--no-micro", action="store_true", help="skip the Kessler / MLP / developed-state section after the timed region")
     a = ap.parse_args()
     if a.workload == "config4":
@@ -229,10 +231,10 @@ def main():
     nudger = None
     if a.full_loop:
         coupler, dycore, micro, nudger = modules.make_supercell(nx_glob, ny_glob, a.nz, a.nens, xlen, ylen, zlen, "supercell", device,
-                                                                nranks=world, myrank=rank, with_nudger=True)
+                                                                nranks=world, myrank=rank, with_nudger=True, ord=a.ord)
     else:
         coupler, dycore, micro = modules.make_supercell(nx_glob, ny_glob, a.nz, a.nens, xlen, ylen, zlen, "supercell", device,
-                                                        nranks=world, myrank=rank)
+                                                        nranks=world, myrank=rank, ord=a.ord)
     assert coupler.get_nx() == a.nx and (coupler.get_ny() == a.ny or ny_glob == 1)
     dycore.set_strict(a.strict)
     transport = modules.install_exchange(dycore, coupler, a.transport) if world > 1 else "none"   # all ranks agree on one
@@ -325,6 +327,8 @@ def main():
                 prov = {"file": "profiles/latest_summary.json", "tag": pj.get("tag"), "profiled_sources_sha16": pj.get("kernel_sources_sha16"),
                         "current_sources_sha16": now, "valid": bool(pj.get("kernel_sources_sha16") == now and
                                                                     int(pj.get("cells_per_launch", 0)) == ncells_local)}
+                if a.ord != 5:
+                    prov["valid"] = False                      # the committed counters are the WENO-5 kernels'
                 if prov["valid"]:
                     K = pj["kernels"]
                     ks = [v for k, v in K.items() if k.startswith("k_xz_state")]
@@ -344,13 +348,13 @@ def main():
                 traffic = dom_traffic = valu_side = None
         what = "complete supercell_example loop: WENO-FV dycore + Kessler + sponge_layer + ColumnNudger" if a.full_loop else "WENO-FV dycore only"
         out = {
-            "metric": "cell-updates/s" + (" (full supercell_example loop)" if a.full_loop else ""), "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
+            "metric": "cell-updates/s" + (" (full supercell_example loop)" if a.full_loop else "") + (" (MW_ORD = %d)" % a.ord if a.ord != 5 else ""), "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "supercell %dx%dx%d nens=%d per GPU (global %dx%dx%d, dx = dy = %g m), %s, 3 tracers, "
                                    "CFL dt" % (a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz, dxy, what),
                        "baseline_config": "configs[3] per-GPU block" if a.workload == "config4" else "configs[1]",
-                       "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict,
+                       "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict, "weno_order": a.ord,
                        "schedule": ("two streams (state | tracers, tracer stream at high priority)" if two_streams else "one stream"),
                        "alg_bytes_per_cell_update": 64 * V,
                        "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world},

@@ -1206,13 +1206,12 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     double *MY = d->M[par][1] + e * v.m[1]; unsigned char *UY = d->UP[par][1] + e * v.m[1];
-#define MW_YS(CONV_, K_, cp, sw) hipLaunchKernelGGL((k_y_state<CONV_, K_>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw)
+#define MW_YS(CONV_, K_, O_, cp, sw) hipLaunchKernelGGL((k_y_state<CONV_, K_, O_>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw)
+#define MW_YS_K(K_) { if (d->ord == 3) { if (conv) MW_YS(true, K_, 3, *conv, Sw); else MW_YS(false, K_, 3, CouplerPtrs(), nullptr); } \
+                      else             { if (conv) MW_YS(true, K_, 5, *conv, Sw); else MW_YS(false, K_, 5, CouplerPtrs(), nullptr); } }
     double *Sw = const_cast<double *>(v.S(S));
-    switch (marching_config(p)) {
-      case 1:  if (conv) MW_YS(true, 1, *conv, Sw); else MW_YS(false, 1, CouplerPtrs(), nullptr); break;
-      case 2:  if (conv) MW_YS(true, 2, *conv, Sw); else MW_YS(false, 2, CouplerPtrs(), nullptr); break;
-      default: if (conv) MW_YS(true, 0, *conv, Sw); else MW_YS(false, 0, CouplerPtrs(), nullptr); break;
-    }
+    switch (marching_config(p)) { case 1: MW_YS_K(1) break; case 2: MW_YS_K(2) break; default: MW_YS_K(0) break; }
+#undef MW_YS_K
 #undef MW_YS
     MW_LAUNCH_CHECK();
   }
@@ -1232,12 +1231,10 @@ static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_
     for (int t0 = 0; t0 < p.nt; t0 += 4) {
       int cnt = std::min(4, p.nt - t0);
       const double *M = d->M[par][1] + e * v.m[1]; const unsigned char *U = d->UP[par][1] + e * v.m[1];
-      switch (cnt) {
-        case 1: hipLaunchKernelGGL((k_y_tracers<1>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); break;
-        case 2: hipLaunchKernelGGL((k_y_tracers<2>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); break;
-        case 3: hipLaunchKernelGGL((k_y_tracers<3>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); break;
-        default: hipLaunchKernelGGL((k_y_tracers<4>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); break;
-      }
+#define MW_YT(T_) { if (d->ord == 3) hipLaunchKernelGGL((k_y_tracers<T_, 3>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); \
+                    else             hipLaunchKernelGGL((k_y_tracers<T_, 5>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); }
+      switch (cnt) { case 1: MW_YT(1) break; case 2: MW_YT(2) break; case 3: MW_YT(3) break; default: MW_YT(4) break; }
+#undef MW_YT
       MW_LAUNCH_CHECK();
     }
   }
@@ -1245,7 +1242,7 @@ static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_
 }
 
 static int xz_grid(mw_dycore_s *d, const DyP &p, dim3 &grid, int &chunk, int &tiles_x) {
-  int U = xz_cells_per_wave(p.nens);
+  int U = xz_cells_per_wave(p.nens, d->ord);
   if (U < 4) MW_FAIL("nens too large for the 64-lane x tiling (need nens <= 30)");
   tiles_x = (p.nx * p.nens + U - 1) / U;
   long long waves = (long long)p.ny * tiles_x;
@@ -1274,12 +1271,14 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
     unsigned char *UX = d->UP[par][0] + e * v.m[0], *UZ = d->UP[par][2] + e * v.m[2];
     // nens == 1 (also: one member of a member-major handle): the per-level background values come through LDS
     // (k_xz_state<.., HPL = 1>; dynamic LDS = the chunk's rows)
-#define MW_XZ(N1_, HPL_, K_, lds) hipLaunchKernelGGL((k_xz_state<STAGE, N1_, MODE, HPL_, K_>), grid, dim3(256), lds, d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
-                                                    MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
+#define MW_XZ(N1_, HPL_, K_, O_, lds) hipLaunchKernelGGL((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), grid, dim3(256), lds, d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
+                                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
+#define MW_XZ_K(K_) { if (d->ord == 3) MW_XZ(true, 1, K_, 3, hpl_bytes); else MW_XZ(true, 1, K_, 5, hpl_bytes); }
     const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
     if (p.nens == 1) {
-      switch (marching_config(p)) { case 1: MW_XZ(true, 1, 1, hpl_bytes); break; case 2: MW_XZ(true, 1, 2, hpl_bytes); break; default: MW_XZ(true, 1, 0, hpl_bytes); break; }
-    } else MW_XZ(false, 0, 0, 0);
+      switch (marching_config(p)) { case 1: MW_XZ_K(1) break; case 2: MW_XZ_K(2) break; default: MW_XZ_K(0) break; }
+    } else MW_XZ(false, 0, 0, 5, 0);                          // (the fused-layout form for nens > 1: WENO-5 only, see time_step)
+#undef MW_XZ_K
 #undef MW_XZ
     MW_LAUNCH_CHECK();
   }
@@ -1332,11 +1331,11 @@ static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const doubl
 
 // dynamic LDS of k_tracers_fused<., MODE 1>: D13's background table of the block's levels
 static size_t fused_bg_bytes(int mode, int chunk, int nens) { return mode == 1 ? (size_t)(chunk + 4) * nens * 24 : 0; }
-template <int STAGE, int MODE, int T, bool N1, int K>
+template <int STAGE, int MODE, int T, bool N1, int K, int ORD = 5>
 static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
   const int e = v.e;
-  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1, K>), grid, dim3(256), fused_bg_bytes(MODE, chunk, v.p.nens), st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
+  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1, K, ORD>), grid, dim3(256), fused_bg_bytes(MODE, chunk, v.p.nens), st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
                      d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
                      d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4);
 }
@@ -1349,23 +1348,26 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
     for (int e = 0; e < n_views(d); e++) {
       const View v = view(d, e);
       const DyP &p = v.p;
-      const int U = p.nens == 1 ? 58 : 64 - 4 * p.nens;   // 3 / 2 halo cells per side (k_tracers_fused)
+      const int U = p.nens == 1 ? 64 - 2 * ((d->ord - 1) / 2 + 1) : 64 - 4 * p.nens;   // hs + 1 / 2 halo cells per side (k_tracers_fused)
       const int tiles_x = (p.nx * p.nens + U - 1) / U;
       const int rows4 = p.ny >= 4 ? 1 : 0;
       const long long waves = (long long)p.ny * tiles_x;
       const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F", 10000, 2, 4.5, true));
       dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
       if (fused_bg_bytes(MODE, chunk, p.nens) > 60000) MW_FAIL("fused tracer stage: nens x chunk too large for its LDS table (use the member-major layout or a smaller MW_CHUNK_F)");
+#define MW_FUSED_ARGS d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st
 #define MW_FUSED_CASE(TT) \
-      case TT: if (p.nens == 1) launch_tracers_fused_t<STAGE, MODE, TT, true, 0>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); \
-               else             launch_tracers_fused_t<STAGE, MODE, TT, false, 0>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st); break;
+      case TT: if (p.nens != 1)     launch_tracers_fused_t<STAGE, MODE, TT, false, 0>(MW_FUSED_ARGS); \
+               else if (d->ord == 3) launch_tracers_fused_t<STAGE, MODE, TT, true, 0, 3>(MW_FUSED_ARGS); \
+               else                  launch_tracers_fused_t<STAGE, MODE, TT, true, 0>(MW_FUSED_ARGS); break;
       // (the D13 variant <3, 1> with three tracers sits at the register limit: with the switches folded the compiler spills VGPRs to
       //  scratch, with the run-time switches it does not -- it keeps K = 0; one launch per time step)
       const int K = (MODE == 1 && p.nt == 3) ? 0 : marching_config(p);
-      if (K == 1)      launch_tracers_fused_t<STAGE, MODE, 3, true, 1>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st);
-      else if (K == 2) launch_tracers_fused_t<STAGE, MODE, 1, true, 2>(d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st);
+      if (K == 1)      { if (d->ord == 3) launch_tracers_fused_t<STAGE, MODE, 3, true, 1, 3>(MW_FUSED_ARGS); else launch_tracers_fused_t<STAGE, MODE, 3, true, 1>(MW_FUSED_ARGS); }
+      else if (K == 2) { if (d->ord == 3) launch_tracers_fused_t<STAGE, MODE, 1, true, 2, 3>(MW_FUSED_ARGS); else launch_tracers_fused_t<STAGE, MODE, 1, true, 2>(MW_FUSED_ARGS); }
       else switch (p.nt) { MW_FUSED_CASE(1) MW_FUSED_CASE(2) MW_FUSED_CASE(3) MW_FUSED_CASE(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
 #undef MW_FUSED_CASE
+#undef MW_FUSED_ARGS
       MW_LAUNCH_CHECK();
     }
   }
@@ -1727,7 +1729,10 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
   // production path; strict = 1/2 use the general flux-materialising kernels below.  So does a z-PERIODIC domain (:752-763,
   // :1008-1019; no shipped case): the marching kernels apply the wall / open z rule while loading and have no periodic form.
-  const bool march = (d->strict == 0) && (p.bc_z != MW_BC_PERIODIC) && (d->ord == 5);
+  // WENO-3 (the reference's GPU-benchmark build, -DMW_ORD=3) marches too, in the forms that exist for it: fused tracer stage, and
+  // nens == 1 or the member-major layout.  Orders 7 / 9 run on the general kernels.
+  const bool ord3_ok = d->fused && (p.nens == 1 || !getenv("MW_NO_MEMBER_MAJOR"));
+  const bool march = (d->strict == 0) && (p.bc_z != MW_BC_PERIODIC) && (d->ord == 5 || (d->ord == 3 && ord3_ok));
   if (march && !getenv("MW_NO_WRAP")) {                       // index wrap instead of halo cells (see DyP::wrap_x)
     d->p.wrap_x = (p.bc_x == MW_BC_PERIODIC) && !(d->xchg && p.nproc_x > 1) && p.nx >= 3;
     d->p.wrap_y = !p.sim2d && (p.bc_y == MW_BC_PERIODIC) && !(d->xchg && p.nproc_y > 1) && p.ny >= 3;

@@ -43,6 +43,8 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // as a whole -- it sank the loads of k_tracers_fused towards their uses and the kernel became 8 % SLOWER than the unspecialised
 // one (measured, round 3).  The fences restore the intended order: all loads of a level first, register-only arithmetic behind.
 #define MW_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// (Measured, round 3: non-temporal stores / loads (__builtin_nontemporal_*) for the write-once / read-once intermediates between two
+//  launches -- y tendencies, face mass fluxes, tracer y fluxes, q^n -- change nothing: 5.55-5.70 ms either way.)
 
 template <int N>
 __device__ __forceinline__ void landed(double (&a)[N]) {
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void k_member_to_coupler(DyP p, const double *
 // ---------------------------------------------------------------------------------------------------------------
 // (Measured, round 3: with the switches folded the non-converting variant needs 192 VGPRs; capped at 168 for a third wave per SIMD
 //  it spills 24 of them.)
-template <bool CONV, int K>
+template <bool CONV, int K, int ORD>
 __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restrict__ S, double *__restrict__ MY,
                                                  unsigned char *__restrict__ UPY, double *__restrict__ tendY, int chunk,
                                                  CouplerPtrs c, double *__restrict__ Sw) {
@@ -341,7 +343,8 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   double *fy = MY + (long long)k * p.fyK + ie;                                               // face j at fy + j*fyJ
   unsigned char *upy = UPY + (long long)k * p.fyK + ie;
   double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
-  double w[5][5], nxt[5], cn[5], fprev[5];
+  constexpr int HS = (ORD - 1) / 2;                           // stencil half width; the window holds rows j-HS .. j+HS
+  double w[5][ORD], nxt[5], cn[5], fprev[5];
   // CONV: row r (halo rows wrap) comes from the coupler; the rows ja..jb-1 are this chunk's to store.  The row is REQUESTED at the
   // top of an iteration and converted at its end, when the values have arrived.
   const int hi = k * p.nens + e;
@@ -358,10 +361,10 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   for (int v = 0; v < 5; v++) { cn[v] = 0; fprev[v] = 0; }
   if (CONV) {
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-      const CouplerCell raw = load_coupler_cell<K>(p, c, MW_ROW_CI(ja - 1 - 2 + s));
+    for (int s = 0; s < ORD; s++) {
+      const CouplerCell raw = load_coupler_cell<K>(p, c, MW_ROW_CI(ja - 1 - HS + s));
       double r5[5];
-      MW_ROW_FINISH(raw, ja - 1 - 2 + s, r5)
+      MW_ROW_FINISH(raw, ja - 1 - HS + s, r5)
 #pragma unroll
       for (int v = 0; v < 5; v++) w[v][s] = r5[v];
     }
@@ -369,13 +372,13 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 #pragma unroll
     for (int v = 0; v < 5; v++) {
 #pragma unroll
-      for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - 2 + s) + p.HY) * p.sJ];
+      for (int s = 0; s < ORD; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - HS + s) + p.HY) * p.sJ];
     }
   }
 #pragma unroll
   for (int v = 0; v < 5; v++) landed(w[v]);
   for (int j = ja - 1; j <= jb; j++) {
-    const int jn = min(j + 3, p.ny + p.HY - 1);                 // clamp: the last prefetch is never used
+    const int jn = min(j + HS + 1, p.ny + p.HY - 1);            // clamp: the last prefetch is never used
     CouplerCell raw;
     if (CONV) raw = load_coupler_cell<K>(p, c, MW_ROW_CI(jn));
     else {
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
     }
     double se[5], ne[5];
 #pragma unroll
-    for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
+    for (int v = 0; v < 5; v++) weno_window_edges<ORD>(w[v], se[v], ne[v]);
     {                                                          // (computed on the ghost iteration j = ja-1 too: only the stores are predicated)
       const bool face = (j >= ja);
       const int jc = max(j, 0);
@@ -393,8 +396,10 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
       const bool zero = (bcmode == 1 || bcmode == 2) && (p.bc_y == MW_BC_WALL);
       if (__builtin_expect(bcmode == 3, 0)) {
 #pragma unroll
-        for (int v = 0; v < 5; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_;
-          weno5_edges_fast(qv[-2 * p.sJ], qv[-p.sJ], qv[0], qv[p.sJ], qv[2 * p.sJ], l_, r_); se[v] = l_; }
+        for (int v = 0; v < 5; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_, q_[ORD];
+#pragma unroll
+          for (int s = 0; s < ORD; s++) q_[s] = qv[(long long)(s - HS) * p.sJ];
+          weno_window_edges<ORD>(q_, l_, r_); se[v] = l_; }
       }
       double Lr = cn[idR], Lu = cn[idV], Lt = cn[idT], Rr = se[idR], Ru = se[idV], Rt = se[idT];
       const bool ybc = (bcmode == 1 || bcmode == 2);           // wave-uniform (j is): a branch, interior faces carry no selects
@@ -430,7 +435,9 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 #pragma unroll
     for (int v = 0; v < 5; v++) {
       cn[v] = ne[v];
-      w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
+#pragma unroll
+      for (int s = 0; s + 1 < ORD; s++) w[v][s] = w[v][s + 1];
+      w[v][ORD - 1] = nxt[v];
     }
   }
 #undef MW_ROW_CI
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
 //  cloud and rain everywhere lost 3 % to the test.  Not kept.)
 // (No Cf<K> form: measured in round 3, the folded variant needs 112 instead of 154 VGPRs for three tracers, runs 4 instead of 3 waves
 //  per SIMD and is 4-6 % SLOWER -- the kernel is bound by HBM, and more resident waves only interleave more rows' streams.)
-template <int T>
+template <int T, int ORD>
 __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restrict__ S, double *__restrict__ FY,
                                                    const double *__restrict__ MY, const unsigned char *__restrict__ UPY, int chunk,
                                                    int t0) {
@@ -468,13 +475,14 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
   // iteration still waits for the row just requested.  Measured, round 2: two register sets taking turns in a loop unrolled by
   // two, so that a set is only waited for two iterations after its request, need 236 instead of 154 VGPRs for three tracers --
   // two waves per SIMD instead of three -- and the kernel was 10 % slower.)
-  double w[T][5], nxt[T], nxt2[T], cn[T];
+  constexpr int HS = (ORD - 1) / 2;
+  double w[T][ORD], nxt[T], nxt2[T], cn[T];
 #pragma unroll
   for (int v = 0; v < T; v++) {
     cn[v] = 0;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - 2 + s) + p.HY) * p.sJ];
-    nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, min(ja - 1 + 3, p.ny + p.HY - 1)) + p.HY) * p.sJ];
+    for (int s = 0; s < ORD; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - HS + s) + p.HY) * p.sJ];
+    nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, min(ja - 1 + HS + 1, p.ny + p.HY - 1)) + p.HY) * p.sJ];
   }
   double m_n = MY[(long long)k * p.fyK + ie + (long long)ja * p.fyJ];
   int up_n = upy[(long long)ja * p.fyJ];
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
   for (int v = 0; v < T; v++) landed(w[v]);
   landed(nxt); landed(m_n); asm volatile("" : "+v"(up_n));
   for (int j = ja - 1; j <= jb; j++) {
-    const int jn = min(j + 4, p.ny + p.HY - 1);
+    const int jn = min(j + HS + 2, p.ny + p.HY - 1);
 #pragma unroll
     for (int v = 0; v < T; v++) nxt2[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
     const int jl = min(max(j + 1, ja), jb);                     // unconditional loads (clamped row): nothing waits inside a branch
@@ -492,13 +500,15 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
     up_n = upy[(long long)jl * p.fyJ];
     double se[T], ne[T];
 #pragma unroll
-    for (int v = 0; v < T; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], se[v], ne[v]);
+    for (int v = 0; v < T; v++) weno_window_edges<ORD>(w[v], se[v], ne[v]);
     landed(nxt2); landed(m_n); asm volatile("" : "+v"(up_n));  // the iteration's loads, in front of its stores (see landed())
     if (j >= ja) {
       if (__builtin_expect(bc_mode_y<0>(p, j) == 3, 0)) {
 #pragma unroll
-        for (int v = 0; v < T; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_;
-          weno5_edges_fast(qv[-2 * p.sJ], qv[-p.sJ], qv[0], qv[p.sJ], qv[2 * p.sJ], l_, r_); se[v] = l_; }
+        for (int v = 0; v < T; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_, q_[ORD];
+#pragma unroll
+          for (int s = 0; s < ORD; s++) q_[s] = qv[(long long)(s - HS) * p.sJ];
+          weno_window_edges<ORD>(q_, l_, r_); se[v] = l_; }
       }
 #pragma unroll
       for (int v = 0; v < T; v++) {   // scalar copies first (a select between two arrays' elements would go through scratch)
@@ -509,7 +519,9 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
 #pragma unroll
     for (int v = 0; v < T; v++) {
       cn[v] = ne[v];
-      w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v]; nxt[v] = nxt2[v];
+#pragma unroll
+      for (int s = 0; s + 1 < ORD; s++) w[v][s] = w[v][s + 1];
+      w[v][ORD - 1] = nxt[v]; nxt[v] = nxt2[v];
     }
   }
 }
@@ -537,16 +549,20 @@ struct XzGeom {
   int om2, om1, op1, op2;                                     // nens > 1: offsets (doubles) of the x neighbours from the lane's own cell
   bool owns_face, owns_cell, valid;
 };
-__host__ __device__ __forceinline__ int xz_cells_per_wave(int nens) { return nens == 1 ? 58 : 64 - 2 * nens; }
-template <bool N1>
+// (nens == 1: hs + 1 halo lanes per side -- hs stencil cells and one more so that the west neighbour's east-edge value is rebuilt in
+//  the wave: 58 cells per wave for WENO-5, 60 for WENO-3)
+__host__ __device__ __forceinline__ int xz_cells_per_wave(int nens, int ord = 5) { return nens == 1 ? 64 - 2 * ((ord - 1) / 2 + 1) : 64 - 2 * nens; }
+template <bool N1, int ORD = 5>
 __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, int rows4 = 0) {
+  static_assert(N1 || ORD == 5, "the neighbour-load form (nens > 1 in the fused layout) exists for WENO-5 only");
+  constexpr int HS = (ORD - 1) / 2;
   XzGeom g;
   g.n = N1 ? 1 : p.nens;
   g.lane = threadIdx.x & 63;
   g.NXI = p.nx * g.n;
-  const int hw = N1 ? 3 : 1;                                  // halo cells per side
+  const int hw = N1 ? HS + 1 : 1;                             // halo cells per side
   const int U = 64 - 2 * hw * g.n;                            // cells (fused) a wave completes
-  g.cell_lo = hw * g.n; g.cell_hi = 64 - hw * g.n; g.face_hi = N1 ? 64 - 2 * g.n : 64;
+  g.cell_lo = hw * g.n; g.cell_hi = 64 - hw * g.n; g.face_hi = N1 ? 64 - HS * g.n : 64;
   const BlockXY blk = xcd_block();
   const long long wid = (long long)blk.x * 4 + (threadIdx.x >> 6);           // wave id -> (row j, x tile)
   int tx;
@@ -581,13 +597,14 @@ __device__ __forceinline__ void x_neighbours(double c0, const double *__restrict
 
 // MODE 1 (last stage of the last cycle): u, v, w also go to the coupler's arrays (D13, :1929-1932: the slab holds (rho u)/rho
 // already), so that the tracer stage, which finishes D13, neither re-reads nor re-writes them.
-template <int STAGE, bool N1, int MODE, int HPL, int K>
+template <int STAGE, bool N1, int MODE, int HPL, int K, int ORD>
 __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
                                                   double *__restrict__ Sout, double *__restrict__ MX, double *__restrict__ MZ,
                                                   unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                   const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
                                                   int tiles_x, double *__restrict__ cu, double *__restrict__ cv, double *__restrict__ cw) {
-  const XzGeom g = xz_geom<N1>(p, chunk, tiles_x);
+  constexpr int HS = (ORD - 1) / 2;
+  const XzGeom g = xz_geom<N1, ORD>(p, chunk, tiles_x);
   // HPL (nens == 1): the eight background values of every level of this chunk (DyP::hypk rows kstart..kb) are copied to LDS once
   // and read from there (a broadcast read, issued with the iteration's other loads).  Read as scalar loads they were placed right
   // in front of their first use -- the kernel has no spare SGPRs to hold them any earlier -- and their latency was exposed three
@@ -608,12 +625,12 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   // flux) live in LDS, one private slot per thread: 20 VGPRs less in a kernel that sits at the 256-register limit (measured:
   // -5 % run time; moving more carries there, or doing the same in k_y_state / k_tracers_fused, was slower).
   __shared__ double lds_xpart[5][256], lds_fzprev[5][256];
-  double w[5][5], nxt[5], ct[5];
+  double w[5][ORD], nxt[5], ct[5];
 #pragma unroll
   for (int v = 0; v < 5; v++) {
     ct[v] = 0; lds_fzprev[v][threadIdx.x] = 0; lds_xpart[v][threadIdx.x] = 0;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = load_zlevel<K>(p, col + (long long)v * p.sV, g.kstart - 2 + s, v == idW);
+    for (int s = 0; s < ORD; s++) w[v][s] = load_zlevel<K>(p, col + (long long)v * p.sV, g.kstart - HS + s, v == idW);
   }
 #pragma unroll
   for (int v = 0; v < 5; v++) landed(w[v]);
@@ -624,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     const bool fin = (k > g.ka);                               // cell k-1 gets finalised in this iteration
     // ---------------- issue this iteration's global loads
     {
-      const int kn = min(k + 3, p.nz + p.HZ - 1);
+      const int kn = min(k + HS + 1, p.nz + p.HZ - 1);
 #pragma unroll
       for (int v = 0; v < 5; v++) nxt[v] = load_zlevel<K>(p, col + (long long)v * p.sV, kn, v == idW);
     }
@@ -657,17 +674,22 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       double we[5], ee[5];
 #pragma unroll
       for (int v = 0; v < 5; v++) {
-        double c0 = w[v][2], m2, m1, p1, p2;
-        x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK, g.om2, g.om1, g.op1, g.op2, lane, n, m2, m1, p1, p2);
-        weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
+        double c0 = w[v][HS], m2, m1, p1, p2;
+        if (ORD == 3) { m1 = from_west<true>(c0, lane, n); p1 = from_east<true>(c0, lane, n); weno3_edges_fast(m1, c0, p1, we[v], ee[v]); }
+        else {
+          x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK, g.om2, g.om1, g.op1, g.op2, lane, n, m2, m1, p1, p2);
+          weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
+        }
       }
       const int bcmode = bc_mode_x<K>(p, g.i);
       const bool zero = (bcmode == 1 || bcmode == 2) && (p.bc_x == MW_BC_WALL);
       if (__builtin_expect(bcmode == 3, 0)) {                  // quirk 1: slot 1 at face nx keeps cell 0's west edge (:985)
         const double *c0p = col + (long long)(k + p.HZ) * p.sK - (long long)p.nx * n;
 #pragma unroll
-        for (int v = 0; v < 5; v++) { const double *qv = c0p + (long long)v * p.sV; double l_, r_;
-          weno5_edges_fast(qv[-2 * n], qv[-n], qv[0], qv[n], qv[2 * n], l_, r_); we[v] = l_; }
+        for (int v = 0; v < 5; v++) { const double *qv = c0p + (long long)v * p.sV; double l_, r_, q_[ORD];
+#pragma unroll
+          for (int s = 0; s < ORD; s++) q_[s] = qv[(s - HS) * n];
+          weno_window_edges<ORD>(q_, l_, r_); we[v] = l_; }
       }
       double Lv[5];
 #pragma unroll
@@ -690,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     //  nobody reads them -- a branch here would need ten default values materialised in every iteration)
     double be[5], te[5];
 #pragma unroll
-    for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be[v], te[v]);
+    for (int v = 0; v < 5; v++) weno_window_edges<ORD>(w[v], be[v], te[v]);
     // (also on the ghost iteration below the chunk, whose face belongs to the chunk underneath: its flux is never stored and never
     //  enters a tendency -- the first cell that is finalised is ka, with the faces ka and ka + 1)
     double fzs[5];
@@ -729,7 +751,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     if (fin) {
       const int kc = k - 1;
       const double hyc = HPL ? lds_hp[(kc - g.kstart) * 8] : p.hypk[(long long)(kc * n + e) * 8];
-      const int wi = 1;                                        // window slot that holds level k-1 (window is centred on k)
+      constexpr int wi = HS - 1;                               // window slot that holds level k-1 (window is centred on k)
       const double rho_s = w[idR][wi] + hyc;
       const double rho_n = (STAGE == 1) ? rho_s : snv[idR] + hyc;
       double imm_coef = 0;
@@ -778,7 +800,9 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
 #pragma unroll
       for (int v = 0; v < 5; v++) {
         ct[v] = te[v];
-        w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
+#pragma unroll
+        for (int s = 0; s + 1 < ORD; s++) w[v][s] = w[v][s + 1];
+        w[v][ORD - 1] = nxt[v];
       }
     }
   }
@@ -997,13 +1021,15 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
 //   reconstructions at k = ka-2 and kb+1, S2 / S3 before their first cell -- save 1 % at run time but cost 30-40 VGPRs (spills in
 //   the MODE 1 variant) and the kernel as a whole became 15 % slower.  The loop body stays branch-free.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int STAGE, int MODE, int T, bool N1, int K>
+template <int STAGE, int MODE, int T, bool N1, int K, int ORD>
 __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *__restrict__ S, const double *__restrict__ Sn, double *Sout,
                                                        const double *__restrict__ FY, const double *__restrict__ MX,
                                                        const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
                                                        const unsigned char *__restrict__ UPZ, double *__restrict__ DS,
                                                        double *__restrict__ DN, unsigned char *__restrict__ flags, unsigned int *__restrict__ dirty,
                                                        double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4) {
+  static_assert(N1 || ORD == 5, "the neighbour-load form exists for WENO-5 only");
+  constexpr int HS = (ORD - 1) / 2;
   const int n = N1 ? 1 : p.nens;
   constexpr int t0 = 0;                                       // one group: all (<= 4) tracers of the cell
   constexpr bool MW_FENCED = Cf<K>::spec;                     // (see MW_SCHED_FENCE)
@@ -1013,7 +1039,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   // its outer face, whose upwind reconstruction reaches a 4th cell -- lanes 0 and 63 load that cell (a clamped all-lane load
   // issued first in the iteration) and the DPP shift hands it on as its edge fill, so 3 lanes per side are enough
   // (58 cells per wave: 7 instead of 8 waves per 400-cell row).  nens > 1: neighbour loads, 2 cells per side.
-  const int hw = N1 ? 3 : 2;
+  const int hw = N1 ? HS + 1 : 2;                             // (WENO-3: 2 lanes per side, 60 cells per wave)
   const int U = 64 - 2 * hw * n;
   int j, tx;
   const BlockXY blk = xcd_block();
@@ -1060,14 +1086,15 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const int k_lo = max(ka - 1, 0);                            // cells k_lo .. k_hi get all six fluxes (FCT multiplier)
   const int k_hi = min(kb, p.nz - 1);
   const int kstart = max(ka - 2, 0);
-  double w[T][5], nxt[T], ct[T];
+  double w[T][ORD], nxt[T], ct[T];
   double fxp[T], fzp[T], multp[T], szf[T], P[T];
+  double wkm2[T];                                             // WENO-3: level k-2 has left the 3-level window and is carried instead
   double rhos2 = 0;
 #pragma unroll
   for (int v = 0; v < T; v++) {
-    ct[v] = 0; fxp[v] = fzp[v] = szf[v] = P[v] = 0; multp[v] = 1;
+    ct[v] = 0; fxp[v] = fzp[v] = szf[v] = P[v] = 0; multp[v] = 1; wkm2[v] = 0;
 #pragma unroll
-    for (int s = 0; s < 5; s++) w[v][s] = load_zlevel(p, col + (long long)v * p.sV, kstart - 2 + s, false);
+    for (int s = 0; s < ORD; s++) w[v][s] = load_zlevel(p, col + (long long)v * p.sV, kstart - HS + s, false);
   }
   // The patch cell (beyond lane 0 / lane 63) of a level is requested one iteration ahead: the x reconstruction is the first
   // consumer of an iteration, and vmcnt retires in order -- waiting for it would wait for everything requested before it.
@@ -1088,7 +1115,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     const int kx = min(k, p.nz - 1), kz = min(k, p.nz);
     const int kpc = min(max(kp, 0), p.nz - 1), kuc = min(max(ku, 0), p.nz - 1);
     // ------------------------------------------------ loads of this iteration
-    const int kn = min(k + 3, p.nz + p.HZ - 1);
+    const int kn = min(k + HS + 1, p.nz + p.HZ - 1);
     double xpatch[T];                                            // level k, the cell beyond lane 0 / lane 63
 #pragma unroll
     for (int v = 0; v < T; v++) xpatch[v] = xpn[v];
@@ -1134,7 +1161,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     double te[T], fxn[T], fzn[T], be_[T], xe_[T];
 #pragma unroll
     for (int v = 0; v < T; v++) {                                // all reconstructions first: they need no loaded operand
-      weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be_[v], te[v]);
+      weno_window_edges<ORD>(w[v], be_[v], te[v]);
       if (!cell) be_[v] = 0;
       if (MW_FENCED) MW_SCHED_FENCE();
     }
@@ -1142,16 +1169,19 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       const bool quirk = bc_mode_x<K>(p, i) == 3;
 #pragma unroll
       for (int v = 0; v < T; v++) {
-        double c0 = w[v][2], m2 = nbw2[v], m1 = nbw1[v], p1 = nbe1[v], p2 = nbe2[v];
+        double c0 = w[v][HS], m2 = nbw2[v], m1 = nbw1[v], p1 = nbe1[v], p2 = nbe2[v];
         if (N1) {                                              // whole-wave DPP shifts
           m1 = dpp_mov_old<0x138>(xpatch[v], c0); p1 = dpp_mov_old<0x130>(xpatch[v], c0);   // lanes 0 / 63 keep the loaded cell
-          m2 = from_west<true>(m1, lane, 1); p2 = from_east<true>(p1, lane, 1);
+          if (ORD == 5) { m2 = from_west<true>(m1, lane, 1); p2 = from_east<true>(p1, lane, 1); }
         }
         double we, ee;
-        weno5_edges_fast(m2, m1, c0, p1, p2, we, ee);
+        if (ORD == 3) weno3_edges_fast(m1, c0, p1, we, ee);
+        else          weno5_edges_fast(m2, m1, c0, p1, p2, we, ee);
         if (__builtin_expect(quirk, 0)) {
-          const double *qv = col + (long long)v * p.sV + (long long)(kx + p.HZ) * p.sK - (long long)p.nx * n; double r_;
-          weno5_edges_fast(qv[-2 * n], qv[-n], qv[0], qv[n], qv[2 * n], we, r_);
+          const double *qv = col + (long long)v * p.sV + (long long)(kx + p.HZ) * p.sK - (long long)p.nx * n; double r_, q_[ORD];
+#pragma unroll
+          for (int s = 0; s < ORD; s++) q_[s] = qv[(s - HS) * n];
+          weno_window_edges<ORD>(q_, we, r_);
         }
         double Lq = from_west<N1>(ee, lane, n);
         be_[v] = upz ? be_[v] : ct[v];
@@ -1175,7 +1205,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         double mult = 1.0;
         {
           // the cell volume dx dy dz multiplies both sides of the reference's test (:506-511) and cancels in the multiplier
-          const double mass_available = fmax(w[v][1] * rhop, 0.0);
+          const double mass_available = fmax(w[v][HS - 1] * rhop, 0.0);      // (window slot HS - 1 = level k-1)
           const double out_x = (fmax(fe, 0.0) - fmin(fxp[v], 0.0)) * p.rdx;
           const double out_y = (fmax(fyn[v], 0.0) - fmin(fys[v], 0.0)) * p.rdy;
           const double out_z = (fmax(fzn[v], 0.0) - fmin(fzp[v], 0.0)) * p.rdz;
@@ -1211,7 +1241,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       double rho_dry = rho_new, rho_v = 0;
 #pragma unroll
       for (int v = 0; v < T; v++) {
-        const double q_s = w[v][0] * rhos2;
+        const double q_s = (ORD == 3 ? wkm2[v] : w[v][0]) * rhos2;           // level k-2
         const double q_n = (STAGE == 1) ? q_s : qn_[v] * rho_n;
         const double tend = P[v] - (szn[v] - szf[v]) * p.rdz;
         double qnew;
@@ -1241,7 +1271,10 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     for (int v = 0; v < T; v++) {
       fxp[v] = fxn[v]; fzp[v] = fzn[v]; szf[v] = szn[v]; P[v] = Pn[v];
       ct[v] = te[v];
-      w[v][0] = w[v][1]; w[v][1] = w[v][2]; w[v][2] = w[v][3]; w[v][3] = w[v][4]; w[v][4] = nxt[v];
+      if (ORD == 3) wkm2[v] = w[v][0];                         // level k-1 is level (k+1)-2 of the next iteration
+#pragma unroll
+      for (int s = 0; s + 1 < ORD; s++) w[v][s] = w[v][s + 1];
+      w[v][ORD - 1] = nxt[v];
     }
   }
 }

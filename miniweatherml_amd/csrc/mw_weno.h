@@ -169,11 +169,39 @@ __device__ __forceinline__ void weno3_edges_strict(double s0, double s1, double 
 #pragma clang fp contract(off)
   MW_WENO3_STATEMENTS(s0, s1, s2, left, right)
 }
+#undef MW_WENO3_STATEMENTS
+// The same mathematics re-associated like weno5_edges_fast (one reciprocal instead of nine divisions, no constant coefficients:
+// every candidate preserves the cell mean): 38 VALU instructions.
+//   a = s1 - s0, b = s2 - s1;  L1 = a, R1 = b, H1 = (a + b)/2, H2 = (b - a)/2
+//   t_L = a^2, t_R = b^2, t_H = H1^2 + 13/3 H2^2;  S = sum t;  d_i = t_i^2 + 1e-20 S^2 (convexify #1 folded in, as in WENO-5)
+//   normalised weights = idl_i prod_{j != i} d_j / N  (idl = 1, 1, 500; the /502 cancels)
+//   edge values = s1 + (c2/6 -+ c1/2) with c1 = H1 w_H + a w_L + b w_R, c2 = H2 w_H   (1/4 - 1/12 = 1/6)
 __device__ __forceinline__ void weno3_edges_fast(double s0, double s1, double s2, double &left, double &right) {
 #pragma clang fp contract(fast)
-  MW_WENO3_STATEMENTS(s0, s1, s2, left, right)
+  const double a = s1 - s0, b = s2 - s1;
+  const double C1p = a + b, H2p = b - a;                    // 2 H1, 2 H2
+  const double hC = 0.5 * C1p;
+  const double tL = a * a, tR = b * b;
+  const double tH = hC * hC + 1.0833333333333333333333333333333333333 * (H2p * H2p);      // (13/3)/4
+  const double S = (tL + tR) + tH;
+  const double eS = (S > 1.e-20) ? (1.e-20 * S) * S : 1.e-20;
+  const double dL = tL * tL + eS, dR = tR * tR + eS, dH = tH * tH + eS;
+  const double nL = dR * dH, nR = dL * dH, nH = (5.e2 * dL) * dR;
+  const double N = (nL + nR) + nH;
+  double rN = __builtin_amdgcn_rcp(N);
+  rN = rN + rN * (1.0 - N * rN);                            // (one Newton step: see weno5_edges_fast)
+  const double od = 0.5 * (hC * nH + (a * nL + b * nR));
+  const double ev = (1.0 / 12.0) * (H2p * nH);              // c2/6 = H2p/12
+  left  = s1 + (ev - od) * rN;
+  right = s1 + (ev + od) * rN;
 }
-#undef MW_WENO3_STATEMENTS
+// A marching kernel's register window of ORD cells (centre ORD/2) -> the centre cell's two edge values
+template <int ORD>
+__device__ __forceinline__ void weno_window_edges(const double (&w)[ORD], double &left, double &right) {
+  static_assert(ORD == 3 || ORD == 5, "the marching kernels exist for WENO orders 3 and 5");
+  if (ORD == 3) weno3_edges_fast(w[0], w[1], w[ORD - 1], left, right);
+  else          weno5_edges_fast(w[0], w[1], w[ORD / 2], w[ORD - 2], w[ORD - 1], left, right);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // WENO-7 and WENO-9 (MW_ORD = 7 / 9, dynamics_euler_stratified_wenofv.h:24-28): weno::WenoLimiter<7> / <9>::compute_limited_coefs

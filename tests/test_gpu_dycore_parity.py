@@ -374,7 +374,8 @@ def test_non_default_gamma_uses_the_generic_pressure(mw, oracle):
 # ---------------------------------------------------------------------------------------------------------------------
 # WENO order 3: the reference's -DMW_ORD=3 build (the only order its GPU benchmark environment compiles,
 # build/machines/aws/aws_a100_gpu.env:21).  Oracle = the same restatement compiled with -DMW_ORD=3 (WenoLimiter<3>, hs = 1,
-# 3-point GLL initial data); device = mw_dycore_set_order(h, 3) -> general kernels with weno3_edges_*.
+# 3-point GLL initial data); device = mw_dycore_set_order(h, 3) -> the marching kernels' ORD = 3 forms (production) or the general
+# kernels with weno3_edges_* (strict / mode 2).
 # ---------------------------------------------------------------------------------------------------------------------
 ORD3_CASES = {
     "supercell3d_16x16x8": (16, 16, 8, 1, 16000., 16000., 20000., "supercell", 3, True),
@@ -384,12 +385,16 @@ ORD3_CASES = {
 }
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("name", sorted(ORD3_CASES))
 @pytest.mark.parametrize("order", [3, 7, 9])
 def test_weno_orders_3_7_9(mw, oracle, name, mode, order):
     """MW_ORD = 3, 7, 9 (dynamics_euler_stratified_wenofv.h:24-28).  Orders 7 / 9: WenoLimiter<7> / <9> (hs = 3 / 4: the slabs get
-    4- / 5-cell x, y halos and 3 / 4 z levels), `ord`-point GLL initial data; oracle = the restatement compiled with -DMW_ORD."""
+    4- / 5-cell x, y halos and 3 / 4 z levels), `ord`-point GLL initial data; oracle = the restatement compiled with -DMW_ORD.
+    Modes: 0 = production (order 3: the marching kernels -- 2-D, member-major nens = 2 and the immersed city configuration included;
+    orders 7 / 9: the general kernels), 1 = strict (the reference's operation order), 2 = the general kernels with fast arithmetic."""
+    if mode == 2 and order != 3:
+        pytest.skip("orders 7 / 9: mode 0 already runs the general kernels")
     from miniweatherml_amd import modules
     O3 = oracle.with_order(order)
     nx, ny, nz, nens, xlen, ylen, zlen, init, nt, grav = ORD3_CASES[name]

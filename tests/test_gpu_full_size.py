@@ -66,13 +66,15 @@ def test_two_d_keeps_v_zero(mw):
     assert float(fl["state_flux_y"].abs().max()) == 0.0 and float(fl["tracers_flux_y"].abs().max()) == 0.0
 
 
-def test_production_path_equals_general_path_at_size(mw):
+@pytest.mark.parametrize("order", [5, 3])
+def test_production_path_equals_general_path_at_size(mw, order):
     """The marching production kernels and the general flux-materialising kernels (same fast arithmetic) are two
-    independent implementations of one stage; they must agree to rounding on a mid-size grid after 5 steps."""
+    independent implementations of one stage; they must agree to rounding on a mid-size grid after 5 steps.  Order 3 = the
+    reference's GPU-benchmark build (-DMW_ORD=3): 3-level windows, 60 cells per wave."""
     from miniweatherml_amd import modules
     out = []
     for mode in (0, 2):
-        coupler, dycore, _ = modules.make_supercell(160, 120, 60, 1, 80000., 60000., 20000.)
+        coupler, dycore, _ = modules.make_supercell(160, 120, 60, 1, 80000., 60000., 20000., ord=order)
         dycore.set_strict(mode)
         dt = dycore.compute_time_step(coupler)
         for _ in range(5):

@@ -1,5 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r03_t2.txt 2>&1
-tail -15 gpurun_out/r03_t2.txt
+bash tools/ab_bench.sh "MW_X=1" "MW_LIB_PATH=$GRAFT_REPO_ROOT/miniweatherml_amd/variants/libmw_nt.so" > gpurun_out/r03_ab5.txt 2>&1
+cat gpurun_out/r03_ab5.txt
