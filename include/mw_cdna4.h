@@ -129,6 +129,12 @@ int  mw_dycore_profile_get(mw_dycore_t h, int which, double *total_ms, long long
  * on n caller-supplied 5-cell stencils (DEVICE (n,5)) -> the two edge values (DEVICE (n,2)); strict = 1: the reference's operation
  * order with contraction off, 0: the production arithmetic (mw_weno.h). */
 int  mw_weno5_edges(long long n, const double *stencils, double *edges, int strict, void *stream);
+/* Diagnostic: out[i] = pow(x[i], y[i]) as the kernels that keep the reference's operation order compute it (strict path, init,
+ * D1 / D13 passes): glibc's algorithm and tables (csrc/mw_glibc_pow.h), i.e. the bits of the host libm's pow that the reference
+ * built with the YAKL serial backend gets (dynamics_euler_stratified_wenofv.h:401, :1935, :2009).  main_path (device, n bytes,
+ * may be NULL): 1 where the restated main path applied, 0 where the device library's pow was used (arguments the dycore never
+ * produces: x <= 0 or subnormal, |y| < 2^-65 or >= 2^63, over- / underflowing results). */
+int  mw_strict_pow(long long n, const double *x, const double *y, double *out, unsigned char *main_path, void *stream);
 
 /* Measurement aid (no reference counterpart): copies n doubles with this library's access shape (8 B per lane).  A launch
  * moves exactly 8n bytes each way, which calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE counters (tools/calib_pmc.py). */

@@ -70,6 +70,7 @@ SYMBOLS = {
     "mw_dycore_use_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "mw_rccl_selftest": (C.c_int, [C.c_longlong, C.c_void_p]),
     "mw_rccl_selftest_lanes": (C.c_int, []),
+    "mw_strict_pow": (C.c_int, [C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mw_rccl_library_path": (C.c_char_p, [C.POINTER(C.c_int)]),
     "mw_weno5_edges": (C.c_int, [C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mw_kessler_workspace_bytes": (C.c_longlong, [C.c_int, C.c_longlong]),

@@ -17,6 +17,7 @@
 #include "../../include/mw_cdna4.h"
 #include "mw_common.h"
 #include "mw_weno.h"
+#include "mw_glibc_pow.h"
 #include <vector>
 #include <cmath>
 #include <cstring>
@@ -90,7 +91,15 @@ template <int K> struct Cf {
 // -----------------------------------------------------------------------------------------------------
 // pow(x, gamma): strict = device libm pow; fast = same for now (kept separate so it can be specialised)
 // -----------------------------------------------------------------------------------------------------
-template <bool STRICT> __device__ __forceinline__ double pow_gamma(double x, double g) { return pow(x, g); }
+// pow of the kernels that keep the reference's operation order (general path: strict and fast arithmetic; init; D1 / D13 passes):
+// the bits of the host's glibc (mw_glibc_pow.h), so that the strict path equals the CPU oracle bit for bit.  Arguments outside the
+// restated main path -- nothing the dycore produces -- take the device library's pow.
+__device__ __forceinline__ double pow_ref(double x, double y) {
+  double r;
+  if (__builtin_expect(glibc_pow_main(x, y, &r), 1)) return r;
+  return pow(x, y);
+}
+template <bool STRICT> __device__ __forceinline__ double pow_gamma(double x, double g) { return pow_ref(x, g); }
 
 // p = C0 (hyt + e)^gamma for the fast path.  The Riemann solver needs two of these per face (6 per cell and stage,
 // :401,:426,:457); the device-libm pow costs ~230 fp64-VALU instructions.  Writing (hyt + e)^gamma =
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(256) void k_coupler_to_state(DyP p, CouplerPtrs c, 
   double press = rho_d * p.R_d * temp + rho_v * p.R_v * temp;
   double rho = rho_d;
   for (int tr = 0; tr < p.nt; tr++) if ((p.mass_mask >> tr) & 1u) rho += c.tr[tr][ci];
-  double theta = pow(press / p.C0, 1.0 / p.gamma) / rho;
+  double theta = pow_ref(press / p.C0, 1.0 / p.gamma) / rho;
   double hyc = p.hyc[k * p.nens + e], hytc = p.hytc[k * p.nens + e];
   double *s = S + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
   double rp = rho - hyc;                                  // state(idR)
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(256) void k_update(DyP p, const double *Sstar, cons
     }
   }
   if (MODE == 1) {
-    double press = p.C0 * pow(press_arg, p.gamma);
+    double press = p.C0 * pow_ref(press_arg, p.gamma);
     double temp = press / (rho_dry_acc * p.R_d + rho_v_new * p.R_v);
     c.rho_d[ci] = rho_dry_acc;  c.u[ci] = unew;  c.v[ci] = vnew;  c.w[ci] = wnew;  c.temp[ci] = temp;
   }
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(256) void k_state_to_coupler(DyP p, const double *_
   double rho = S[so + idR * p.sV] + hyc;
   double u = (S[so + idU * p.sV] * rho) / rho, v = (S[so + idV * p.sV] * rho) / rho, w = (S[so + idW * p.sV] * rho) / rho;
   double theta = (S[so + idT * p.sV] + hytc) / rho;
-  double press = p.C0 * pow(rho * theta, p.gamma);
+  double press = p.C0 * pow_ref(rho * theta, p.gamma);
   double rho_d = rho, rho_v = 0;
   for (int tr = 0; tr < p.nt; tr++) {
     double q = S[so + (5 + tr) * p.sV] * rho;
@@ -660,8 +669,8 @@ __device__ __forceinline__ void d_hydro_const_theta(double z, double grav, doubl
   const double theta0 = 300., exner0 = 1.;
   t = theta0;
   double exner = exner0 - grav * z / (cp * theta0);
-  double pr = p0 * pow(exner, (cp / rd));
-  double rt = pow((pr / C0), (1.0 / gamma));
+  double pr = p0 * pow_ref(exner, (cp / rd));
+  double rt = pow_ref((pr / C0), (1.0 / gamma));
   r = rt / t;
 }
 __device__ __forceinline__ double d_sample_ellipse_cosine(double amp, double x, double y, double z, double x0, double y0,
@@ -669,7 +678,7 @@ __device__ __forceinline__ double d_sample_ellipse_cosine(double amp, double x, 
 #pragma clang fp contract(off)
   double dist = sqrt(((x - x0) / xrad) * ((x - x0) / xrad) + ((y - y0) / yrad) * ((y - y0) / yrad) +
                      ((z - z0) / zrad) * ((z - z0) / zrad)) * M_PI / 2.;
-  if (dist <= M_PI / 2.) return amp * pow(cos(dist), 2.0);
+  if (dist <= M_PI / 2.) return amp * pow_ref(cos(dist), 2.0);
   return 0.;
 }
 
@@ -745,7 +754,7 @@ __global__ __launch_bounds__(256) void k_init_cells(DyP p, InitP q, CouplerPtrs 
         double rho_d = hr;
         u = 0.; v = 0.; w = 0.;
         double theta_d = ht + d_sample_ellipse_cosine(2.0, x, y, z, q.xlen / 2, q.ylen / 2, 2000., 2000., 2000., 2000.);
-        double p_d = p.C0 * pow(rho_d * theta_d, p.gamma);
+        double p_d = p.C0 * pow_ref(rho_d * theta_d, p.gamma);
         double temp = p_d / rho_d / p.R_d;
         double tc = temp - 273.15;                             // saturation_vapor_pressure, :1137-1140
         double sat_pv = 610.94 * exp(17.625 * tc / (243.04 + tc));
@@ -753,7 +762,7 @@ __global__ __launch_bounds__(256) void k_init_cells(DyP p, InitP q, CouplerPtrs 
         rho_v = d_sample_ellipse_cosine(0.8, x, y, z, q.xlen / 2, q.ylen / 2, 2000., 2000., 2000., 2000.) * sat_rv;
         double pr = rho_d * p.R_d * temp + rho_v * p.R_v * temp;
         rho = rho_d + rho_v;
-        theta = pow(pr / p.C0, 1.0 / p.gamma) / rho;
+        theta = pow_ref(pr / p.C0, 1.0 / p.gamma) / rho;
       } else {
         if (p.enable_gravity) d_hydro_const_theta(z, p.grav, p.C0, q.cp_d, q.p0, p.gamma, p.R_d, hr, ht);
         else { hr = 1.15; ht = 300; }
@@ -784,7 +793,7 @@ __global__ __launch_bounds__(256) void k_init_cells(DyP p, InitP q, CouplerPtrs 
   double rho = sR + hyc;
   double u = sU / rho, v = sV / rho, w = sW / rho;
   double theta = (sT + hytc) / rho;
-  double press = p.C0 * pow(rho * theta, p.gamma);
+  double press = p.C0 * pow_ref(rho * theta, p.gamma);
   double rho_d = rho;
   for (int tr = 0; tr < p.nt; tr++) {
     double val = (tr == p.idWV) ? sWV : 0.0;
@@ -810,7 +819,7 @@ __global__ __launch_bounds__(256) void k_perturb_temperature(int nz, int ny, int
   double x0 = xlen / 2, y0 = ylen / 2, z0 = 1500, radx = 10000, rady = 10000, radz = 1500, amp = 5;
   double xn = (xloc - x0) / radx, yn = (yloc - y0) / rady, zn = (zloc - z0) / radz;
   double rad = sqrt(xn * xn + yn * yn + zn * zn);
-  if (rad < 1) temp[t] += amp * pow(cos(M_PI * rad / 2), 2.0);
+  if (rad < 1) temp[t] += amp * pow_ref(cos(M_PI * rad / 2), 2.0);
 }
 
 // modules::perturb_temperature(random=true)   perturb_temperature.h:25-39: the lowest nz/4 levels get uniform noise in [-1, 1] * 3 K,
@@ -844,6 +853,17 @@ __global__ __launch_bounds__(256) void k_weno5_edges(const double *__restrict__ 
   if (strict) weno5_edges_strict(s[0], s[1], s[2], s[3], s[4], l, r);
   else        weno5_edges_fast(s[0], s[1], s[2], s[3], s[4], l, r);
   out[t * 2] = l; out[t * 2 + 1] = r;
+}
+
+// Diagnostic: the strict path's pow (mw_glibc_pow.h) on caller-supplied arguments; main[i] = 1 where the restated main path applied
+__global__ __launch_bounds__(256) void k_strict_pow(const double *__restrict__ x, const double *__restrict__ y, double *__restrict__ out,
+                                                    unsigned char *__restrict__ main_path, long long n) {
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  double r;
+  const bool m = glibc_pow_main(x[t], y[t], &r);
+  out[t] = m ? r : pow(x[t], y[t]);
+  if (main_path) main_path[t] = m ? 1 : 0;
 }
 
 // member-major slab (nens, V, nz+2HZ, ny+2HY, nx+2HX) -> the fused layout (V, nz+2HZ, ny+2HY, (nx+2HX)*nens), halos included.
@@ -1820,6 +1840,14 @@ int mw_weno5_edges(long long n, const double *stencils, double *edges, int stric
   if (n < 1 || !stencils || !edges) MW_FAIL("weno5_edges: bad argument");
   if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
   hipLaunchKernelGGL(k_weno5_edges, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stencils, edges, n, strict);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
+int mw_strict_pow(long long n, const double *x, const double *y, double *out, unsigned char *main_path, void *stream) {
+  if (n < 1 || !x || !y || !out) MW_FAIL("strict_pow: bad argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipLaunchKernelGGL(k_strict_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, out, main_path, n);
   MW_LAUNCH_CHECK();
   return 0;
 }

@@ -996,7 +996,7 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
   if (MODE == 1) {
     // the slab holds u = (rho u)/rho etc. -- exactly what convert_dynamics_to_coupler computes (:1929-1932)
     double theta = (Sout[so + idT * p.sV] + hytc) / rho_new;
-    double press = p.C0 * pow(rho_new * theta, p.gamma);
+    double press = p.C0 * pow_ref(rho_new * theta, p.gamma);
     c.rho_d[ci] = rho_dry;
     c.u[ci] = Sout[so + idU * p.sV]; c.v[ci] = Sout[so + idV * p.sV]; c.w[ci] = Sout[so + idW * p.sV];
     c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);

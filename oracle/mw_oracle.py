@@ -66,11 +66,38 @@ _lib = None
 def build(force=False):
     """Compile oracle/libmw_oracle.so with the committed Makefile (g++, seconds)."""
     src = os.path.join(_HERE, "mw_oracle.cpp")
-    libs = [os.path.join(_HERE, n) for n in ("libmw_oracle.so", "libmw_oracle_ord3.so", "libmw_oracle_ord7.so", "libmw_oracle_ord9.so")]
-    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "weno79.inc")))
+    libs = [os.path.join(_HERE, n) for n in ("libmw_oracle.so", "libmw_oracle_ord3.so", "libmw_oracle_ord7.so", "libmw_oracle_ord9.so",
+                                              "libmw_powcheck.so")]
+    csrc = os.path.join(os.path.dirname(_HERE), "miniweatherml_amd", "csrc")
+    newest = max(os.path.getmtime(f) for f in (src, os.path.join(_HERE, "weno79.inc"), os.path.join(_HERE, "pow_check.cpp"),
+                                               os.path.join(csrc, "mw_glibc_pow.h"), os.path.join(csrc, "mw_glibc_pow_tables.h")))
     if force or any(not os.path.exists(l) or os.path.getmtime(l) < newest for l in libs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
+
+
+def powcheck():
+    """(libm_pow, glibc_pow_restated) on numpy arrays: std::pow of the host's C library and the product's restatement of it
+    (miniweatherml_amd/csrc/mw_glibc_pow.h compiled for the host) -- see oracle/pow_check.cpp."""
+    build()
+    L = C.CDLL(os.path.join(_HERE, "libmw_powcheck.so"))
+    dp = C.POINTER(C.c_double)
+    L.mwo_libm_pow.argtypes = [C.c_longlong, dp, dp, dp]
+    L.mwo_glibc_pow_restated.argtypes = [C.c_longlong, dp, dp, dp, C.POINTER(C.c_ubyte)]
+    L.mwo_glibc_pow_restated.restype = C.c_longlong
+
+    def libm_pow(x, y):
+        x, y = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64)
+        out = np.empty_like(x)
+        L.mwo_libm_pow(x.size, x.ctypes.data_as(dp), y.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        return out
+
+    def restated(x, y):
+        x, y = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(y, dtype=np.float64)
+        out, ok = np.empty_like(x), np.empty(x.size, dtype=np.uint8)
+        L.mwo_glibc_pow_restated(x.size, x.ctypes.data_as(dp), y.ctypes.data_as(dp), out.ctypes.data_as(dp), ok.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        return out, ok.astype(bool)
+    return libm_pow, restated
 
 
 def lib():

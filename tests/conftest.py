@@ -50,6 +50,8 @@ def pytest_sessionfinish(session, exitstatus):
            "needed_fallback": sorted({r["what"] for r in rows if any(f["needed_fallback"] for f in r["fields"].values())}),
            "worst_rel_by_tolerance": {}, "cases": []}
     out["worst_fraction_of_limit_by_tolerance"] = {}
+    # comparisons held to bit-equality (the strict kernel path, "mode 1": tolerance 0) that passed
+    out["bitwise_equal_to_the_oracle"] = sorted({r["what"] for r in rows if r.get("bitwise")})
     out["note"] = ("rel = max|diff| / max|field|.  The limit of a field is tol * max|field| plus an absolute floor for fields that are "
                    "identically ~0 in the oracle (tests/util.py: ABS_FLOOR, e.g. vvel in a y-symmetric run), so a large `rel` of such a "
                    "field is not a violation; worst_fraction_of_limit = max|diff| / limit is the number to read (<= 1 passes).  Cases in "
@@ -63,7 +65,7 @@ def pytest_sessionfinish(session, exitstatus):
             rels = [f["rel"] for f in r["fields"].values() if f["scale"] > 0 and f["limit_abs"] <= 1.0000001 * r["tol"] * f["scale"]]
             if rels:
                 out["worst_rel_by_tolerance"][key] = max(out["worst_rel_by_tolerance"].get(key, 0.0), max(rels))
-            frac = max((f["max_abs_diff"] / f["limit_abs"]) for f in r["fields"].values() if f["limit_abs"] > 0)
+            frac = max(((f["max_abs_diff"] / f["limit_abs"]) for f in r["fields"].values() if f["limit_abs"] > 0), default=0.0)
             out["worst_fraction_of_limit_by_tolerance"][key] = max(out["worst_fraction_of_limit_by_tolerance"].get(key, 0.0), frac)
         out["cases"].append({"what": r["what"], "tol": r["tol"], "passed": r["passed"], "worst_field": worst_field, "worst_rel": wr,
                              "fallback_allowed": r["fallback_allowed"],

@@ -61,14 +61,21 @@ def compare_fields(got, ref, tol, what="", sens=None):
     WenoLimiter_recon.h:12-15, and the upwind selector `ind = (m_L + m_R > 0) ? 0 : 1`, :408)."""
     if sens is not None and not sens_allowed(what):
         raise AssertionError("%s: the sensitivity fallback is reserved for the allow-listed cases %r" % (what, SENS_ALLOW))
+    # The STRICT kernel path ("mode 1": the reference's operation order, contraction off, glibc's pow -- csrc/mw_glibc_pow.h) is held
+    # to BIT-EQUALITY with the oracle: no tolerance, no floor, no sensitivity fallback (round 3).
+    bitwise = " mode 1" in what
+    if bitwise:
+        sens = None
     worst, rec, fail = {}, {}, None
     for k in ref:
         scale = float(np.max(np.abs(ref[k])))
         d = float(np.max(np.abs(got[k] - ref[k])))
-        plain = tol * scale + ABS_FLOOR.get(k, 0.0) * (tol / 1e-11)
+        plain = 0.0 if bitwise else tol * scale + ABS_FLOOR.get(k, 0.0) * (tol / 1e-11)
         lim = plain
         if sens is not None:
             lim = max(lim, 10.0 * sens[k])
+        if bitwise and fail is None and not np.array_equal(got[k], ref[k]):
+            fail = "%s: field %s is not bit-identical to the oracle (max|diff| %.3e, scale %.3e)" % (what, k, d, scale)
         worst[k] = (d, scale)
         rec[k] = {"max_abs_diff": d, "scale": scale, "rel": (d / scale if scale > 0 else d), "limit_abs": lim,
                   "needed_fallback": bool(d > plain)}
@@ -79,7 +86,7 @@ def compare_fields(got, ref, tol, what="", sens=None):
     try:
         os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
         with open(PARITY_LOG, "a") as fh:
-            fh.write(json.dumps({"what": what, "tol": tol, "fallback_allowed": sens is not None, "passed": fail is None,
+            fh.write(json.dumps({"what": what, "tol": 0.0 if bitwise else tol, "bitwise": bitwise, "fallback_allowed": sens is not None, "passed": fail is None,
                                  "test": os.environ.get("PYTEST_CURRENT_TEST", ""), "fields": rec}) + "\n")
     except OSError:
         pass

@@ -1,4 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-bash tools/ab_bench.sh "MW_X=1" "MW_LIB_PATH=$GRAFT_REPO_ROOT/miniweatherml_amd/variants/libmw_nt.so" > gpurun_out/r03_ab5.txt 2>&1
-cat gpurun_out/r03_ab5.txt
+mkdir -p gpurun_out
+timeout 1800 python -m pytest tests -q -m gpu > gpurun_out/r03_t4.txt 2>&1
+grep -E "^FAILED|passed|failed" gpurun_out/r03_t4.txt | head -60
