@@ -1,6 +1,6 @@
 """Static instruction-class histogram of the gfx950 code of selected kernels (no GPU needed).
 
-    python tools/isa_histogram.py [--src mw_dycore.hip] [--md] <kernel-substring> [...]     (-- extra hipcc flags)
+    python tools/isa_histogram.py [--src mw_dycore.hip] [--csrc DIR] [--md] <kernel-substring> [...]     (-- extra hipcc flags)
 
 Compiles the source to device assembly (hipcc -S --offload-device-only) and, per kernel whose demangled name contains one of the
 substrings, counts instructions by class -- for the whole kernel and for its largest loop (the marching loop: the basic blocks
@@ -121,19 +121,22 @@ def main():
     if "--" in args:
         i = args.index("--"); extra = args[i + 1:]; args = args[:i]
     src = "mw_dycore.hip"
+    csrc = os.path.join(ROOT, "miniweatherml_amd", "csrc")
     md = False
     filt = []
     it = iter(args)
     for a in it:
         if a == "--src":
             src = next(it)
+        elif a == "--csrc":                      # another checkout's csrc directory (e.g. `git archive <rev>` for a before / after table)
+            csrc = next(it)
         elif a == "--md":
             md = True
         else:
             filt.append(a)
     os.makedirs("/tmp/rr", exist_ok=True)
     out = "/tmp/rr/isa_%s.s" % os.path.splitext(src)[0]
-    cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-x", "hip", "--offload-device-only", "-S", os.path.join(ROOT, "miniweatherml_amd", "csrc", src), "-o", out] + extra
+    cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-x", "hip", "--offload-device-only", "-S", os.path.join(csrc, src), "-o", out] + extra
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         print(r.stderr); sys.exit(1)
