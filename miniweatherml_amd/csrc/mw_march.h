@@ -781,7 +781,10 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
         else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
         if (l == idR) inv_rho_new = fast_rcp(qnew + hyc);
         const double stored = (l == idR || l == idT) ? qnew : qnew * inv_rho_new;
-        if (g.owns_cell) so[(long long)l * p.sV] = stored;
+        // (MODE 1, the last stage of a time step: u, v, w go to the coupler's arrays only.  Nobody reads the result slab's velocities
+        //  any more -- the tracer stage of this stage needs rho' and (rho theta)', and the next time_step starts from the coupler's
+        //  fields (D1) -- so three of the five slab stores are dropped: 24 B per cell and step.)
+        if (g.owns_cell && !(MODE == 1 && (l == idU || l == idV || l == idW))) so[(long long)l * p.sV] = stored;
         if (MODE == 1 && g.owns_cell && (l == idU || l == idV || l == idW))
           (l == idU ? cu : l == idV ? cv : cw)[cpl(p, cell0 + (long long)kc * planeC)] = stored;
       }
@@ -997,8 +1000,7 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
     // the slab holds u = (rho u)/rho etc. -- exactly what convert_dynamics_to_coupler computes (:1929-1932)
     double theta = (Sout[so + idT * p.sV] + hytc) / rho_new;
     double press = p.C0 * pow_ref(rho_new * theta, p.gamma);
-    c.rho_d[ci] = rho_dry;
-    c.u[ci] = Sout[so + idU * p.sV]; c.v[ci] = Sout[so + idV * p.sV]; c.w[ci] = Sout[so + idW * p.sV];
+    c.rho_d[ci] = rho_dry;                                     // (u, v, w: written to the coupler by k_xz_state<3, ., 1>, like on the fused path)
     c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);
   }
 }
