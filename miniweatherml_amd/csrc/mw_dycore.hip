@@ -1766,6 +1766,10 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     if (getenv("MW_NO_OVERLAP")) want = false;
     d->overlap = march && d->tstream && want; }
   // nens > 1 on the production path: member-major internal layout (see View)
+  // (Measured, round 3, config 4's block 256 x 512 x 128 x 4: the members' coupler-touching launches -- D1 inside k_y_state, D13 inside the
+  //  last stage -- issued SIDE BY SIDE on one stream per member, hoping that the quarter lines the four members read / write would
+  //  meet in L2: they do not.  27.3 ms per step with the two coalesced conversion passes; 33.2 with D13 inside the member launches
+  //  (k_tracers_fused 7.6 -> 12.0 ms, k_xz_state 9.4 -> 11.7), 30.3 with D1 inside (k_y_state 3.8 -> 7.7), 34.3 with both.)
   d->member_major = march && d->fused && p.nens > 1 && !getenv("MW_NO_MEMBER_MAJOR");
   // D1 + D2 (:101, :248-255).  Production path with periodic x and y owned by this rank (either schedule: the tracer stream waits
   // for the stage's state kernels anyway): done inside the first k_y_state (no separate pass); otherwise a conversion kernel first

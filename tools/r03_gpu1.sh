@@ -1,5 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1800 python -m pytest tests -x -q -m gpu > gpurun_out/r03_t5.txt 2>&1
-grep -E "passed|failed" gpurun_out/r03_t5.txt | tail -2
+for v in 0 1 2 3; do
+  MW_MEMBER_DIRECT=$v python bench.py --workload config4 --no-micro --no-cpu-baseline --steps 10 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('direct=$v', '%.4g'%d['value'], '%.2f ms'%d['ms_per_step'], {k:round(x,2) for k,x in d['kernel_ms_per_step'].items() if x>0.01})"
+done
+MW_MEMBER_DIRECT=3 timeout 900 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_dycore_parity.py tests/test_gpu_random_configs.py -x -q -m gpu 2>&1 | tail -2
