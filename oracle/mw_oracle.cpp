@@ -12,13 +12,17 @@
 //     Fortran + (P)NetCDF, and the build rules forbid writing stand-ins for absent headers.  There is
 //     therefore no oracle/_ref.
 //   * The reference ships no tests, golden vectors or fixtures.
-//   * Dycore + init + perturb_temperature: pinned against the reference-run known answers the survey
-//     recorded in BASELINE.md section 2 (32x32x16 supercell + bubble, 3 dycore steps: wvel max/min,
-//     temp max, sum(density_dry) before/after, all 18 significant digits) and the WenoLimiter<5> facts in
-//     SURVEY.md section 4 (convexified ideal weights, degree<=2 exactness, step-stencil behaviour).
-//     See tests/test_oracle_known_answers.py.
-//   * Kessler: PARITY UNPINNED (no reference output of the isolated module is recorded anywhere).
-//   * MLP (ponni source absent): PARITY UNPINNED; restated from the call sites and Keras Dense semantics.
+//   * PARITY UNPINNED (all of it, under the rule that only the reference's own golden vectors / fixtures or outputs of the
+//     reference built here without stand-ins pin an oracle).  What exists instead, as evidence and not as a pin:
+//     - dycore + init + perturb_temperature reproduce, to all 18 significant digits, the numbers the survey session
+//       recorded from the reference's own headers run against a YAKL stand-in (32x32x16 supercell +
+//       bubble, 3 dycore steps: wvel max/min, temp max, sum(density_dry) before/after), the two CFL steps, and the
+//       WenoLimiter<5> facts of SURVEY.md section 4 (tests/test_oracle_known_answers.py);
+//     - the 155 + 32 derived WENO-7/9 and GLL constants equal the reference's literals (tools/check_weno_tables.py);
+//     - the MLP reproduces the test errors the reference's training notebook recorded (tests/test_oracle_mlp_anchor.py);
+//     - the full loop reaches the value ranges recorded at step 800 of the default 2-D run (tests/test_oracle_full_loop.py).
+//   * Kessler: no reference output of the isolated module is recorded anywhere.
+//   * MLP (ponni source absent): restated from the call sites and Keras Dense semantics.
 //
 // Every function cites the reference file:line it follows (paths relative to /root/reference/).
 // All arithmetic is IEEE fp64 in the reference's operation order; compile with -O2 -ffp-contract=off

@@ -1,8 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-for v in 0 1 2 3; do
-  MW_MEMBER_DIRECT=$v python bench.py --workload config4 --no-micro --no-cpu-baseline --steps 10 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('direct=$v', '%.4g'%d['value'], '%.2f ms'%d['ms_per_step'], {k:round(x,2) for k,x in d['kernel_ms_per_step'].items() if x>0.01})"
-done
-MW_MEMBER_DIRECT=3 timeout 900 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_dycore_parity.py tests/test_gpu_random_configs.py -x -q -m gpu 2>&1 | tail -2
+bash tools/ab_bench.sh "MW_X=1" "MW_CHUNK_Z=20" "MW_CHUNK_F=20" "MW_CHUNK_Z=17" "MW_CHUNK_F=17" "MW_CHUNK_Y=40" "MW_CHUNK_Y=45" "MW_CHUNK_YT=25" "MW_CHUNK_YT=34" 2>&1 | grep -v rep3 > gpurun_out/r03_ab8.txt
+cat gpurun_out/r03_ab8.txt
