@@ -21,7 +21,9 @@ roofline: SURVEY.md 8(d)'s flux-stencil figure: 32 V = 256 B per cell and RK sta
           cell-update figure.  peak 8 TB/s HBM3E spec.  traffic / valu_* come from the committed rocprofv3 PMC summary
           (profiles/latest_summary.json, 2 x FETCH_SIZE + WRITE_SIZE calibrated with mw_calib_copy) and are reported ONLY while
           the kernel sources still hash to what that profile was taken from (roofline.pmc_provenance); otherwise null.
-          The stage is fp64-VALU-issue bound, not HBM bound (roofline.binding_resource; SURVEY.md 8(d) predicts it).
+          The stage is bound by its COUNTED HBM traffic (the intermediates between its four launches make it ~2.1 x the algorithmic
+          bytes) with the fp64 instruction stream at 0.80-0.87 VALU busy right under it (roofline.binding_resource, roofline.traffic_frac,
+          roofline.fp64_valu; DESIGN.md 0b: the WENO-3 build runs half the arithmetic in 93 % of the time).
 micro   : after the timed region (the headline is untouched): Kessler (two states) and the surrogate MLP on the same grid, 72 B per
           cell each, and the dycore step on a state with cloud and rain (FCT limiter + y-face correction pass active):
           developed_ms_per_step.
@@ -358,13 +360,19 @@ def main():
                        "schedule": ("two streams (state | tracers, tracer stream at high priority)" if two_streams else "one stream"),
                        "alg_bytes_per_cell_update": 64 * V,
                        "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world},
-            # bound: the resource that binds the stage.  achieved / peak / frac stay SURVEY.md 8(d)'s HBM figure (32 V B per cell against
-            # 8 TB/s: the number the north star's 60 % target is quoted in); roofline.fp64_valu carries the binding side's own fraction.
-            "roofline": {"bound": "fp64_valu" if not a.strict else "hbm",
-                         "binding_resource": "fp64 VALU issue (SURVEY.md 8(d): ~14 kflop against 512 B per cell-update)",
+            # bound: the resource that binds the stage: its COUNTED HBM traffic -- 2.1 x the algorithmic bytes: y tendencies,
+            # face mass fluxes, tracer y fluxes written by one launch and read by the next -- moving at 4.6-5.6 TB/s, with the fp64
+            # instruction stream at 0.80-0.87 VALU busy right under it (the WENO-3 build, half the arithmetic, takes 93 % of the time).
+            # achieved / peak / frac are SURVEY.md 8(d)'s algorithmic figure (32 V B per cell against 8 TB/s: what the north star's 60 %
+            # target is quoted in); traffic / traffic_frac the counted bytes; roofline.fp64_valu the instruction side.
+            "roofline": {"bound": "hbm",
+                         "binding_resource": "HBM traffic of the stage's four launches (counted bytes: roofline.traffic, ~2.1 x algorithmic; "
+                                             "4.6-5.6 TB/s per kernel = 85-100 % of what a streaming copy reaches on this part), "
+                                             "fp64 VALU issue co-limiting at 0.80-0.87 busy",
                          "kernel": "one RK stage = k_y_state + k_xz_state + k_y_tracers + k_tracers_fused + k_tracer_patch "
                                    "(SURVEY.md 8(d) flux stencil, 32 V B per cell)" if not a.strict else "one RK stage (general path)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_frac": (traffic / (stage_ms * 1e-3) / 8.0e12) if traffic else None,
                          "alg_bytes_per_launch": stage_bytes, "avg_launch_ms": stage_ms,
                          "avg_launch_ms_source": "hipEvents around every RK stage on the handle's stream, timed region" if stage_ms_live
                                                  else "ms_per_step / 3 (two-stream schedule: a stage's launches overlap the next stage's)",

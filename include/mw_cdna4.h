@@ -188,6 +188,10 @@ long long mw_kessler_workspace_bytes(int nz, long long ncol);
 int  mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *rho_v, double *rho_c, double *rho_r,
                           const double *rho_d, double *temp, double *precl, void *workspace, int *rainsplit_out,
                           void *stream);
+/* 1: the STRICT Kessler path -- the reference's formulas in the reference's operation order (theta form, IEEE divisions, no
+ * contraction) with glibc's pow and exp (csrc/mw_glibc_pow.h): the bits microphysics_kessler.h:99-162, :234-339 produces on a glibc
+ * host (YAKL serial backend).  0 (default): the production kernels (1e-12 from it).  Process-wide, like the module's constants. */
+int  mw_kessler_set_strict(int strict);
 
 /* ponni::load_h5_weights<N>(file, group, dataset), microphysics_kessler_ponni.h:103-107: one 32-bit float dataset of an HDF5 file
  * (the Keras weight file `keras_weights_h5`: "/dense_6/dense_6" "kernel:0" (5,10), "bias:0" (10), "/dense_7/dense_7" ...), read by a

@@ -105,4 +105,29 @@ MW_GP_HD bool glibc_pow_main(double x, double y, double *res) {
   return true;
 }
 
+// exp(x) with the bits of glibc's exp (e_exp.c, the x86-64 FMA build `__exp_fma`): the same table and polynomial as pow's last step.
+// Main path: 2^-54 <= |x| < 512.  (Used by the strict Kessler path: the saturation vapour pressure, microphysics_kessler.h:304.)
+MW_GP_HD bool glibc_exp_main(double x, double *res) {
+#pragma clang fp contract(off)
+  const uint32_t abstop = (uint32_t)(gp_bits(x) >> 52) & 0x7ffu;
+  if (abstop - 0x3c9u > 0x3eu) return false;
+  const double kdS = __builtin_fma(x, MW_GP_INVLN2N, MW_GP_SHIFT);
+  const uint64_t ki = gp_bits(kdS);
+  const double kd = kdS - MW_GP_SHIFT;
+  double r = __builtin_fma(kd, MW_GP_NEGLN2HIN, x);
+  r = __builtin_fma(kd, MW_GP_NEGLN2LON, r);
+  const uint64_t idx = 2 * (ki & 127);
+  const uint64_t sbits = gp_exp_tab[idx + 1] + (ki << 45);
+  const double c23 = __builtin_fma(r, MW_GP_C3, MW_GP_C2);
+  const double tr = r + gp_double(gp_exp_tab[idx]);
+  const double r2 = r * r;
+  const double c45 = __builtin_fma(r, MW_GP_C5, MW_GP_C4);
+  const double q1 = __builtin_fma(c23, r2, tr);
+  const double r4 = r2 * r2;
+  const double q2 = __builtin_fma(r4, c45, q1);
+  const double scale = gp_double(sbits);
+  *res = __builtin_fma(scale, q2, scale);
+  return true;
+}
+
 } // namespace mw

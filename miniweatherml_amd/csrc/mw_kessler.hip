@@ -18,6 +18,7 @@
 // =====================================================================================================
 #include "../../include/mw_cdna4.h"
 #include "mw_common.h"
+#include "mw_glibc_pow.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -321,6 +322,117 @@ __global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restri
   precl[i] = precl_acc / (double)rainsplit;                               // :332-334
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// STRICT path (mw_kessler_set_strict(1)): the reference's formulas in the reference's operation order -- theta form, IEEE divisions,
+// no contraction -- with glibc's pow and exp (mw_glibc_pow.h): BIT-identical to the CPU oracle (and, with it, to the reference on a
+// glibc host).  Not a performance path: two launches, thread = cell for K1-K3 and thread = column for the sub-cycles.
+//   workspace: w_velqr | w_theta | w_qv | w_qc | w_qr, (nz, ncol) each.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double kes_pow_ref(double x, double y) { double r; if (glibc_pow_main(x, y, &r)) return r; return pow(x, y); }
+__device__ __forceinline__ double kes_exp_ref(double x) { double r; if (glibc_exp_main(x, &r)) return r; return exp(x); }
+
+// K1 (:136-144), K2 (:255-273), K3's minimum (:276)
+__global__ __launch_bounds__(256) void k_kessler_strict_prep(KesP p, const double *__restrict__ rho_v, const double *__restrict__ rho_c,
+                                                             const double *__restrict__ rho_r, const double *__restrict__ rho_d,
+                                                             const double *__restrict__ temp, double *__restrict__ ws,
+                                                             unsigned long long *dtmax_bits) {
+#pragma clang fp contract(off)
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n = (long long)p.nz * p.ncol;
+  double dtc = __builtin_huge_val();
+  if (t < n) {
+    const int k = (int)(t / p.ncol);
+    const long long i = t - (long long)k * p.ncol;
+    double *w_velqr = ws, *w_theta = ws + n, *w_qv = ws + 2 * n, *w_qc = ws + 3 * n, *w_qr = ws + 4 * n;
+    const double rho = rho_d[t];
+    const double qv = rho_v[t] / rho, qc = rho_c[t] / rho, qr = rho_r[t] / rho;                    // :138-140
+    const double pressure = p.R_d * rho * temp[t] + p.R_v * rho_v[t] * temp[t];                     // :141
+    const double exner = kes_pow_ref(pressure / p.p0, p.R_d / p.cp_d);                              // :142
+    const double theta = temp[t] / exner;                                                           // :143
+    const double r = 0.001 * rho;                                                                   // :256
+    const double rhalf = sqrt(rho_d[i] / rho);                                                      // :257
+    const double velqr = 36.34 * kes_pow_ref(qr * r, 0.1364) * rhalf;                               // :260
+    w_velqr[t] = velqr; w_theta[t] = theta; w_qv[t] = qv; w_qc[t] = qc; w_qr[t] = qr;
+    if (k < p.nz - 1) {                                                                             // :262-268
+      const double zk = (k + 0.5) * p.dz, zk1 = (k + 1 + 0.5) * p.dz;
+      dtc = (velqr > 1.e-10) ? 0.8 * (zk1 - zk) / velqr : p.dt;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { double o = __shfl_down(dtc, off, 64); dtc = fmin(dtc, o); }
+  __shared__ double smin[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) smin[wv] = dtc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double m = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+    if (m < __builtin_huge_val()) atomicMin(dtmax_bits, (unsigned long long)__double_as_longlong(m));   // positive doubles order like their bits
+  }
+}
+
+// K4 (:285-335) + K5 (:154-161): thread = column, all sub-cycles, top-down (sed(k) needs the pre-update flux of level k+1 only)
+__global__ __launch_bounds__(256) void k_kessler_strict_column(KesP p, double *__restrict__ rho_v, double *__restrict__ rho_c,
+                                                               double *__restrict__ rho_r, const double *__restrict__ rho_d,
+                                                               double *__restrict__ temp, double *__restrict__ precl,
+                                                               const unsigned long long *dtmax_bits, double *__restrict__ ws) {
+#pragma clang fp contract(off)
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.ncol) return;
+  const long long n = (long long)p.nz * p.ncol;
+  double *w_velqr = ws, *w_theta = ws + n, *w_qv = ws + 2 * n, *w_qc = ws + 3 * n, *w_qr = ws + 4 * n;
+  const double dt_max = __longlong_as_double((long long)*dtmax_bits);
+  const int rainsplit = (int)ceil(p.dt / dt_max);                                                   // :279
+  const double dt0 = p.dt / (double)rainsplit;                                                      // :280
+  const int nz = p.nz;
+  const double Rd = p.R_d, cp = p.cp_d;
+  const double psl = p.p0 / 100, rhoqr = 1000., lv = 2.5e6;                                          // :246-248
+  const double rho0 = rho_d[i];
+  double pr = 0;                                                                                    // precl(i), :270-272
+  for (int nt = 0; nt < rainsplit; nt++) {
+    double flux_above = 0;                                  // r(k+1) qr(k+1) velqr(k+1), pre-update
+    for (int k = nz - 1; k >= 0; k--) {
+      const long long idx = (long long)k * p.ncol + i;
+      const double rho = rho_d[idx];
+      // exner of the call's INPUT state (:141-142; temp / rho_v of this level are only overwritten below, in the last sub-cycle)
+      const double pressure = Rd * rho * temp[idx] + p.R_v * rho_v[idx] * temp[idx];
+      const double pk = kes_pow_ref(pressure / p.p0, Rd / cp);
+      const double r = 0.001 * rho;                                                                 // :256
+      const double rhalf = sqrt(rho0 / rho);                                                        // :257
+      const double pc = 3.8 / (kes_pow_ref(pk, cp / Rd) * psl);                                     // :258
+      double theta = w_theta[idx], qv = w_qv[idx], qc = w_qc[idx], qr = w_qr[idx];
+      const double velqr = w_velqr[idx];
+      const double zk = (k + 0.5) * p.dz;
+      if (k == 0) pr = pr + rho0 * qr * velqr / rhoqr;                                              // :292
+      const double flux_here = r * qr * velqr;
+      double sed;
+      if (k == nz - 1) { const double zm = (k - 1 + 0.5) * p.dz; sed = -dt0 * qr * velqr / (0.5 * (zk - zm)); }       // :295
+      else             { const double zp = (k + 1 + 0.5) * p.dz; sed = dt0 * (flux_above - flux_here) / (r * (zp - zk)); }   // :297-298
+      flux_above = flux_here;
+      // :302-335
+      const double qrprod = qc - (qc - dt0 * fmax(0.001 * (qc - 0.001), 0.)) / (1 + dt0 * 2.2 * kes_pow_ref(qr, 0.875));
+      qc = fmax(qc - qrprod, 0.);
+      qr = fmax(qr + qrprod + sed, 0.);
+      const double tmp = pk * theta - 36.;
+      const double qvs = pc * kes_exp_ref(17.27 * (pk * theta - 273.) / tmp);
+      const double prod = (qv - qvs) / (1. + qvs * (4093. * lv / cp) / (tmp * tmp));
+      const double tmp1 = dt0 * (((1.6 + 124.9 * kes_pow_ref(r * qr, 0.2046)) * kes_pow_ref(r * qr, 0.525)) /
+                                 (2550000. * pc / (3.8 * qvs) + 540000.)) * (fmax(qvs - qv, 0.) / (r * qvs));
+      const double tmp2 = fmax(-prod - qc, 0.);
+      const double tmp3 = qr;
+      const double ern = fmin(tmp1, fmin(tmp2, tmp3));
+      theta = theta + lv / (cp * pk) * (fmax(prod, -qc) - ern);
+      qv = fmax(qv - fmax(prod, -qc) + ern, 0.);
+      qc = qc + fmax(prod, -qc);
+      qr = qr - ern;
+      const double velqr_new = 36.34 * kes_pow_ref(qr * r, 0.1364) * rhalf;                         // :331
+      if (nt == rainsplit - 1) {                                                                    // :154-161 [K5]
+        rho_v[idx] = qv * rho; rho_c[idx] = qc * rho; rho_r[idx] = qr * rho;
+        temp[idx] = theta * pk;
+      } else { w_theta[idx] = theta; w_qv[idx] = qv; w_qc[idx] = qc; w_qr[idx] = qr; w_velqr[idx] = velqr_new; }
+    }
+  }
+  precl[i] = pr / (double)rainsplit;                                                                // :332-334
+}
+
 // diagnostic: the module's log / exp / sqrt on caller-supplied arguments (tests compare them with the host libm)
 __global__ __launch_bounds__(256) void k_kessler_math_probe(long long n, const double *__restrict__ x, double *__restrict__ y, int fn) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -344,6 +456,10 @@ int mw_kessler_math_probe(long long n, const double *x, double *y, int fn, void 
   return 0;
 }
 
+static int g_kessler_strict = 0;
+// 1: the strict path (reference operation order, glibc's pow / exp: bit-identical to the CPU oracle); 0: the production kernels
+int mw_kessler_set_strict(int strict) { g_kessler_strict = strict ? 1 : 0; return 0; }
+
 int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *rho_v, double *rho_c, double *rho_r,
                          const double *rho_d, double *temp, double *precl, void *workspace, int *rainsplit_out, void *stream) {
   if (nz < 2 || ncol < 1) MW_FAIL("kessler: need nz >= 2 and ncol >= 1");
@@ -355,6 +471,20 @@ int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *r
   unsigned long long *bits = (unsigned long long *)workspace;
   double *ws = (double *)workspace + 16;
   hipLaunchKernelGGL(k_kessler_init_min, dim3(1), dim3(64), 0, st, bits); MW_LAUNCH_CHECK();
+  if (g_kessler_strict) {
+    const long long n = (long long)nz * ncol;
+    hipLaunchKernelGGL(k_kessler_strict_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp, ws, bits); MW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_kessler_strict_column, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp,
+                       precl, bits, ws); MW_LAUNCH_CHECK();
+    if (rainsplit_out) {
+      unsigned long long hb = 0;
+      MW_HIP(hipMemcpyAsync(&hb, bits, 8, hipMemcpyDeviceToHost, st));
+      MW_HIP(hipStreamSynchronize(st));
+      double dt_max; memcpy(&dt_max, &hb, 8);
+      *rainsplit_out = (int)std::ceil(dt / dt_max);
+    }
+    return 0;
+  }
   // z chunks of the rainsplit == 1 path: enough (column, chunk) threads to fill the chip, at least 4 levels per chunk
   int chunk = nz;
   for (int c : {25, 20, 16, 12, 10, 8, 5, 4}) if (c < nz) { chunk = c; if (((ncol + 63) / 64) * ((nz + c - 1) / c) >= 16384) break; }

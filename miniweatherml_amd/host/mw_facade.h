@@ -166,6 +166,7 @@ class Microphysics_Kessler {                                          // model/m
   void *ws = nullptr; long long ws_bytes = 0;
  public:
   int static constexpr num_tracers = 3;
+  void set_strict(int strict) { mw_check(mw_kessler_set_strict(strict)); }   // 1: reference operation order + glibc's pow / exp (bit-identical to the CPU restatement)
   real R_d, cp_d, cv_d, gamma_d, kappa_d, R_v, cp_v, cv_v, p0, grav;
   Microphysics_Kessler() { R_d = 287.; cp_d = 1003.; cv_d = cp_d - R_d; gamma_d = cp_d / cv_d; kappa_d = R_d / cp_d; R_v = 461.;
                            cp_v = 1859; cv_v = R_v - cp_v; p0 = 1.e5; grav = 9.81; }                             // :29-41

@@ -205,6 +205,10 @@ class Microphysics_Kessler:
         self.cv_v = self.R_v - self.cp_v
         self.p0, self.grav = 1.e5, 9.81
         self._ws = None
+        self.strict = 0          # 1: the strict path (reference operation order, glibc's pow / exp): bit-identical to the CPU oracle
+
+    def set_strict(self, strict):
+        self.strict = int(bool(strict))
 
     @staticmethod
     def get_num_tracers():
@@ -235,6 +239,7 @@ class Microphysics_Kessler:
         if self._ws is None or self._ws.numel() * 8 < nbytes:
             self._ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=coupler.device)
         rs = C.c_int(0)
+        check(L.mw_kessler_set_strict(self.strict))
         with torch.cuda.device(coupler.device):
             check(L.mw_kessler_time_step(nz, ncol, coupler.get_dz(), float(dt), _ptr(rho_v), _ptr(rho_c), _ptr(rho_r), _ptr(rho_d),
                                          _ptr(temp), _ptr(precl), _ptr(self._ws), C.byref(rs) if return_rainsplit else None,

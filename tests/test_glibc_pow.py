@@ -50,6 +50,22 @@ def test_host_build_of_the_restatement_is_bit_identical_to_libm(oracle):
     assert total > 7_000_000
 
 
+def test_host_build_of_the_exp_restatement_is_bit_identical_to_libm(oracle):
+    """glibc's exp (the strict Kessler path's saturation vapour pressure, microphysics_kessler.h:304): same table, same polynomial."""
+    libm_exp, restated = oracle.expcheck()
+    rng = np.random.default_rng(21)
+    for name, x in (("17.27 (T - 273) / (T - 36)", rng.uniform(-45.0, 12.0, 2_000_000)), ("wide", rng.uniform(-720.0, 720.0, 2_000_000)),
+                    ("small", rng.uniform(-1e-3, 1e-3, 1_000_000) * rng.uniform(0.0, 1.0, 1_000_000))):
+        ref = libm_exp(x)
+        got, main = restated(x)
+        bad = (bits(ref) != bits(got)) & main
+        assert not bad.any(), "%s: %d results differ from libm" % (name, int(bad.sum()))
+        if name != "wide":
+            assert main.mean() > 0.999, name
+    _, main = restated(np.array([0.0, 1e-300, 600.0, -800.0, np.inf, np.nan]))
+    assert not main.any()
+
+
 def test_arguments_outside_the_main_path_are_declined(oracle):
     _, restated = oracle.powcheck()
     x = np.array([0.0, -1.0, np.inf, np.nan, 5e-324, 1e-310, 2.0, 2.0, 2.0, 2.0, 1e300, 1e-300])

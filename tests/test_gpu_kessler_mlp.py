@@ -42,6 +42,31 @@ def test_kessler_matches_oracle(mw, oracle, shape, heavy):
     assert np.max(precl) > 0
 
 
+@pytest.mark.parametrize("heavy", [False, True])
+@pytest.mark.parametrize("shape", [(16, 12, 20), (40, 1, 40)])
+def test_strict_kessler_is_bit_identical_to_the_oracle(mw, oracle, shape, heavy):
+    """The strict Kessler path (mw_kessler_set_strict(1): reference operation order, theta form, IEEE divisions, glibc's pow and exp,
+    csrc/mw_glibc_pow.h) against the oracle's restatement of microphysics_kessler.h:99-162, :234-339: every field and the precipitation
+    rate bit for bit, with rainsplit 1 and > 1, over two consecutive calls."""
+    from miniweatherml_amd import modules
+    nx, ny, nz = shape
+    dyc, f = rainy_state(oracle, nx, ny, nz, heavy)
+    coupler, dycore, micro = modules.make_supercell(nx, ny, nz, 1, 500.0 * nx, 500.0 * ny if ny > 1 else 1e5, 20000.)
+    push_fields(coupler, f)
+    micro.set_strict(1)
+    dt = 90.0 if heavy else dycore.compute_time_step(coupler)
+    for call in range(2):
+        precl = np.zeros((ny, nx, 1))
+        rs_ref = oracle.kessler_time_step(coupler.get_dz(), dt, f.tracers[0], f.tracers[1], f.tracers[2], f.rho_d, f.temp, precl)
+        rs = micro.time_step(coupler, dt, return_rainsplit=True)
+        assert rs == rs_ref and (rs > 1) == heavy
+        compare_fields(gpu_fields(coupler), f.as_dict(), 0.0, "kessler strict mode 1 heavy=%s call %d" % (heavy, call))
+        got_precl = coupler.get_data_manager_readonly().get("precl", True).cpu().numpy()
+        assert np.array_equal(got_precl, precl)
+    micro.set_strict(0)
+    micro.time_step(coupler, dt)                                  # (and the process-wide switch is back on the production kernels)
+
+
 def test_kessler_dry_state_is_identity_on_vapor_free_air(mw, oracle):
     from miniweatherml_amd import modules
     coupler, dycore, micro = modules.make_supercell(12, 12, 10, 1, 6000., 6000., 20000.)

@@ -1,4 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-bash tools/ab_bench.sh "MW_X=1" "MW_CHUNK_Z=20" "MW_CHUNK_F=20" "MW_CHUNK_Z=17" "MW_CHUNK_F=17" "MW_CHUNK_Y=40" "MW_CHUNK_Y=45" "MW_CHUNK_YT=25" "MW_CHUNK_YT=34" 2>&1 | grep -v rep3 > gpurun_out/r03_ab8.txt
-cat gpurun_out/r03_ab8.txt
+timeout 900 python -m pytest tests/test_gpu_kessler_mlp.py tests/test_glibc_pow.py tests/test_gpu_cpp_facade.py -x -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -12
