@@ -236,6 +236,9 @@ int  mw_mlp_forward(long long ncells, const double *temp, const double *rho_d, c
                     const double *rho_c, const double *rho_r, const float *W1, const float *b1, const float *W2,
                     const float *b2, const double *scl_in, const double *scl_out, double *temp_out,
                     double *rho_v_out, double *rho_c_out, double *rho_r_out, void *stream);
+/* 1: the strict form -- thread per cell, fp32 accumulation in index order, no contraction (the order in which the layers are defined,
+ * microphysics_kessler_ponni.h:103-110); 0 (default): the MFMA kernels (the same products summed in the matrix cores' order). */
+int  mw_mlp_set_strict(int strict);
 
 /* ---- file output ------------------------------------------------------------ */
 /* A minimal netCDF *classic* writer (mw_netcdf.cpp): the reference writes through PnetCDF with NC_CLOBBER | NC_64BIT_DATA,

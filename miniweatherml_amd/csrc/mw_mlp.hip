@@ -144,6 +144,44 @@ __global__ __launch_bounds__(256) void k_mlp_x2(MlpP P, long long ncells, const 
 
 using namespace mw;
 
+// STRICT form (mw_mlp_set_strict(1)): thread = cell, plain fp32 loops in INDEX ORDER, no contraction -- the order in which the layers
+// are defined (Matvec, Bias, Relu, Matvec, Bias; microphysics_kessler_ponni.h:103-110) and in which the CPU restatement accumulates:
+// bit-identical to it.  (The MFMA kernels sum the same products in the matrix cores' order: 1e-5 on the fp32 outputs.)
+struct MlpRef { float W1[50], b1[10], W2[40], b2[4]; double in_min[5], in_rng[5], out_min[4], out_rng[4]; };
+__global__ __launch_bounds__(256) void k_mlp_strict(MlpRef P, long long n, const double *__restrict__ temp, const double *__restrict__ rho_d,
+                                                    const double *__restrict__ rho_v, const double *__restrict__ rho_c, const double *__restrict__ rho_r,
+                                                    double *__restrict__ temp_out, double *__restrict__ rho_v_out, double *__restrict__ rho_c_out,
+                                                    double *__restrict__ rho_r_out) {
+#pragma clang fp contract(off)
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  const double in[5] = {temp[c], rho_d[c], rho_v[c], rho_c[c], rho_r[c]};
+  float x[5], h[10], y[4];
+#pragma unroll
+  for (int i = 0; i < 5; i++) x[i] = (float)((in[i] - P.in_min[i]) / P.in_rng[i]);                 // :182-186 (fp64, stored to float)
+#pragma unroll
+  for (int o = 0; o < 10; o++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) acc += x[i] * P.W1[i * 10 + o];
+    acc = acc + P.b1[o];
+    h[o] = acc > 0.f ? acc : 0.1f * acc;
+  }
+#pragma unroll
+  for (int o = 0; o < 4; o++) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 10; i++) acc += h[i] * P.W2[i * 4 + o];
+    y[o] = acc + P.b2[o];
+  }
+  temp_out[c]  =           y[0] * P.out_rng[0] + P.out_min[0];                                      // :198-201
+  rho_v_out[c] = fmax(0.0, y[1] * P.out_rng[1] + P.out_min[1]);
+  rho_c_out[c] = fmax(0.0, y[2] * P.out_rng[2] + P.out_min[2]);
+  rho_r_out[c] = fmax(0.0, y[3] * P.out_rng[3] + P.out_min[3]);
+}
+static int g_mlp_strict = 0;
+extern "C" int mw_mlp_set_strict(int strict) { g_mlp_strict = strict ? 1 : 0; return 0; }
+
 extern "C" int mw_mlp_forward(long long ncells, const double *temp, const double *rho_d, const double *rho_v, const double *rho_c,
                               const double *rho_r, const float *W1, const float *b1, const float *W2, const float *b2,
                               const double *scl_in, const double *scl_out, double *temp_out, double *rho_v_out,
@@ -152,6 +190,16 @@ extern "C" int mw_mlp_forward(long long ncells, const double *temp, const double
   if (!temp || !rho_d || !rho_v || !rho_c || !rho_r || !W1 || !b1 || !W2 || !b2 || !scl_in || !scl_out || !temp_out ||
       !rho_v_out || !rho_c_out || !rho_r_out) MW_FAIL("mlp: null pointer");
   if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  if (g_mlp_strict) {
+    MlpRef R;
+    memcpy(R.W1, W1, sizeof(R.W1)); memcpy(R.b1, b1, sizeof(R.b1)); memcpy(R.W2, W2, sizeof(R.W2)); memcpy(R.b2, b2, sizeof(R.b2));
+    for (int i = 0; i < 5; i++) { R.in_min[i] = scl_in[i * 2 + 0]; R.in_rng[i] = scl_in[i * 2 + 1] - scl_in[i * 2 + 0]; }
+    for (int i = 0; i < 4; i++) { R.out_min[i] = scl_out[i * 2 + 0]; R.out_rng[i] = scl_out[i * 2 + 1] - scl_out[i * 2 + 0]; }
+    hipLaunchKernelGGL(k_mlp_strict, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, (hipStream_t)stream, R, ncells, temp, rho_d, rho_v, rho_c,
+                       rho_r, temp_out, rho_v_out, rho_c_out, rho_r_out);
+    MW_LAUNCH_CHECK();
+    return 0;
+  }
   MlpP P;          // operand images built per call (cheap: 104 weights)
   memset(&P, 0, sizeof(P));
   auto rho = [](int u) { return (u / 3) * 4 + (u % 3); };      // hidden unit u -> D1 row with row % 4 < 3

@@ -284,11 +284,13 @@ def load_surrogate_weights(weights_txt=None, in_scaling_txt=None, out_scaling_tx
     return W1, b1, W2, b2, np.ascontiguousarray(scl_in), np.ascontiguousarray(scl_out)
 
 
-def mlp_forward(temp, rho_d, rho_v, rho_c, rho_r, W1, b1, W2, b2, scl_in, scl_out, outs=None):
-    """model.forward_batch_parallel with the fused scaling (microphysics_kessler_ponni.h:176-202)."""
+def mlp_forward(temp, rho_d, rho_v, rho_c, rho_r, W1, b1, W2, b2, scl_in, scl_out, outs=None, strict=0):
+    """model.forward_batch_parallel with the fused scaling (microphysics_kessler_ponni.h:176-202).  strict = 1: the thread-per-cell
+    form that accumulates in index order (bit-identical to the CPU restatement) instead of the MFMA kernels."""
     fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
     if outs is None:
         outs = [torch.empty_like(temp) for _ in range(4)]
+    check(capi.lib().mw_mlp_set_strict(int(bool(strict))))
     with torch.cuda.device(temp.device):
         check(capi.lib().mw_mlp_forward(temp.numel(), _ptr(temp), _ptr(rho_d), _ptr(rho_v), _ptr(rho_c), _ptr(rho_r),
                                         W1.ctypes.data_as(fp), b1.ctypes.data_as(fp), W2.ctypes.data_as(fp), b2.ctypes.data_as(fp),

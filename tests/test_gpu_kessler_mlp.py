@@ -105,6 +105,25 @@ def test_mlp_matches_oracle_on_supercell_state(mw, oracle):
         assert float(o.min()) >= 0.0                                 # densities clipped at 0 (:199-201)
 
 
+def test_strict_mlp_is_bit_identical_to_the_oracle(mw, oracle):
+    """mw_mlp_set_strict(1): fp32 accumulation in index order, no contraction -- the CPU restatement's order -- on a rainy supercell
+    state and on inputs drawn over (and beyond) the scaling ranges; the MFMA kernels stay within 1e-5 of it."""
+    from miniweatherml_amd import modules
+    W1, b1, W2, b2, si, so = modules.load_surrogate_weights()
+    dyc, f = rainy_state(oracle, 20, 16, 24, False)
+    rng = np.random.default_rng(3)
+    wide = [rng.uniform(si[i, 0] - 0.2 * (si[i, 1] - si[i, 0]), si[i, 1] + 0.2 * (si[i, 1] - si[i, 0]), 50_001) for i in range(5)]
+    for ins in ([f.temp, f.rho_d, f.tracers[0], f.tracers[1], f.tracers[2]], wide):
+        ref = oracle.mlp_forward(*ins, W1, b1, W2, b2, si, so)
+        t = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in ins]
+        outs = modules.mlp_forward(*t, W1, b1, W2, b2, si, so, strict=1)
+        for n, (o, r) in enumerate(zip(outs, ref)):
+            assert np.array_equal(o.cpu().numpy(), r), n
+        fast = modules.mlp_forward(*t, W1, b1, W2, b2, si, so)              # (and the switch is back on the MFMA kernels)
+        for n, (o, r) in enumerate(zip(fast, ref)):
+            assert np.max(np.abs(o.cpu().numpy() - r)) <= mlp_tol(so, n), n
+
+
 @pytest.mark.parametrize("ncells", [1, 15, 16, 17, 63, 64, 65, 1000, 4097])
 def test_mlp_ragged_sizes(mw, oracle, ncells):
     from miniweatherml_amd import modules
