@@ -99,6 +99,11 @@ __device__ __forceinline__ double pow_ref(double x, double y) {
   if (__builtin_expect(glibc_pow_main(x, y, &r), 1)) return r;
   return pow(x, y);
 }
+__device__ __forceinline__ double exp_ref(double x) {       // likewise exp (the thermal initial state's saturation vapour pressure, :1139)
+  double r;
+  if (__builtin_expect(glibc_exp_main(x, &r), 1)) return r;
+  return exp(x);
+}
 template <bool STRICT> __device__ __forceinline__ double pow_gamma(double x, double g) { return pow_ref(x, g); }
 
 // p = C0 (hyt + e)^gamma for the fast path.  The Riemann solver needs two of these per face (6 per cell and stage,
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(256) void k_init_cells(DyP p, InitP q, CouplerPtrs 
         double p_d = p.C0 * pow_ref(rho_d * theta_d, p.gamma);
         double temp = p_d / rho_d / p.R_d;
         double tc = temp - 273.15;                             // saturation_vapor_pressure, :1137-1140
-        double sat_pv = 610.94 * exp(17.625 * tc / (243.04 + tc));
+        double sat_pv = 610.94 * exp_ref(17.625 * tc / (243.04 + tc));
         double sat_rv = sat_pv / p.R_v / temp;
         rho_v = d_sample_ellipse_cosine(0.8, x, y, z, q.xlen / 2, q.ylen / 2, 2000., 2000., 2000., 2000.) * sat_rv;
         double pr = rho_d * p.R_d * temp + rho_v * p.R_v * temp;

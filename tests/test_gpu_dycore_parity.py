@@ -48,7 +48,12 @@ def test_init_matches_oracle(mw, oracle, name):
     hy = odyc.hy()
     for k in ("hy_dens_cells", "hy_dens_theta_cells", "hy_dens_edges", "hy_dens_theta_edges"):
         assert np.array_equal(getattr(dycore, k), hy[k]), k          # host column code, same libm -> bitwise
-    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-13, "init " + name)
+    # init + perturb_temperature: supercell, city, building -- their device code needs pow only, and that has glibc's bits
+    # (csrc/mw_glibc_pow.h) -- are BIT-identical to the oracle; the thermal case also calls cos on the device: 1e-13
+    if name.startswith("thermal"):
+        compare_fields(gpu_fields(coupler), of.as_dict(), 1e-13, "init " + name)
+    else:
+        compare_fields(gpu_fields(coupler), of.as_dict(), 0.0, "init %s, strict arithmetic: mode 1" % name)
     assert np.array_equal(dycore.immersed_proportion(coupler).cpu().numpy(), odyc.immersed_proportion())
     assert coupler.get_option("use_immersed_boundaries") == bool(odyc.p.use_immersed)
 
