@@ -175,8 +175,9 @@ const char *mw_rccl_library_path(int *version);
 /* Diagnostic: one rank sends 4 strips of n doubles to itself through the exchange's own ncclGroup / side stream / event
  * sequence and compares; 0 = RCCL initialises on this box and the ordering against `stream` holds. */
 int  mw_rccl_selftest(long long n, void *stream);
-/* Number of exchange lanes (side stream + communicator each; one per pipeline of the two-stream schedule) that the last
- * mw_rccl_selftest drove: 2 when the process's RCCL provides ncclCommSplit, else 1. */
+/* What the last mw_rccl_selftest drove: 10 x the number of exchange lanes (side stream + event pair each; one per pipeline of the
+ * two-stream schedule) + the number of communicators behind them: 21 = two lanes on one communicator (default), 22 = a communicator
+ * per lane (MW_RCCL_TWO_COMMS=1, split with ncclCommSplit). */
 int  mw_rccl_selftest_lanes(void);
 
 /* ---- Kessler microphysics ------------------------------------------------------------------------- */

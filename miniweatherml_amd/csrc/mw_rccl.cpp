@@ -73,11 +73,15 @@ RcclApi &rccl_api() {
   if (!R.ok) MW_FAIL("RCCL is not available: no librccl.so is mapped in this process and none could be loaded")
 
 // Two LANES: the dycore's state and tracer pipelines (rk_stage_march in mw_dycore.hip) exchange their strips from two different
-// streams, each hiding the other's transfer.  With one side stream and one communicator the two exchanges would queue behind each
-// other; each lane therefore has its own side stream, event pair and communicator (lane 1's is split off lane 0's with
-// ncclCommSplit: same ranks, same order, no second unique id in the ABI).  A lane belongs to the first caller stream that uses
-// it; a third stream -- or an RCCL without ncclCommSplit -- shares lane 0.  Every rank issues the same calls in the same order on
-// every lane (the schedule is a function of the stage counter alone), which is what a communicator requires.
+// streams, each hiding the other's transfer.  Each lane has its own side stream and event pair, so that an exchange only waits for
+// the pack kernels of ITS pipeline and only its pipeline's unpack kernels wait for it.  A lane belongs to the first caller stream
+// that uses it; a third stream shares lane 0.
+// Communicators: by default both lanes use the ONE communicator of the handle -- RCCL then runs the two groups in the order they
+// were issued, which is the same on every rank (the schedule is a function of the stage counter alone).  MW_RCCL_TWO_COMMS=1 gives
+// lane 1 its own communicator (split off lane 0's with ncclCommSplit: no second unique id in the ABI), so that the two transfers
+// can also overlap each other; NCCL's documentation warns that kernels of two communicators may dead-lock each other if the
+// device cannot hold both at once, and this path could not be run between distinct GPUs on the one-GPU development box, so it is
+// opt-in (mw_rccl_selftest exercises both forms on one GPU).
 struct RcclLane {
   ncclComm_t comm = nullptr;
   hipStream_t side = nullptr, owner = nullptr;
@@ -87,6 +91,7 @@ struct RcclLane {
 struct RcclCtx {
   RcclLane lane[2];
   int nlanes = 1;
+  bool own_comm1 = false;                                       // lane 1 has a communicator of its own (MW_RCCL_TWO_COMMS=1)
   int peers[4], send_order[4], recv_order[4], active[4];        // mw_exchange_plan
 };
 
@@ -100,7 +105,7 @@ void free_ctx(RcclCtx *c) {
   for (int l = 1; l >= 0; l--) {                                // the split communicator before its parent
     RcclLane &L = c->lane[l];
     if (L.side) (void)hipStreamSynchronize(L.side);
-    if (L.comm && R.ok) (void)R.CommDestroy(L.comm);
+    if (L.comm && R.ok && (l == 0 || c->own_comm1)) (void)R.CommDestroy(L.comm);
     if (L.ev_ready) (void)hipEventDestroy(L.ev_ready);
     if (L.ev_done) (void)hipEventDestroy(L.ev_done);
     if (L.side) (void)hipStreamDestroy(L.side);
@@ -110,10 +115,14 @@ void free_ctx(RcclCtx *c) {
 // streams and events of the lanes; lane 1 only when a second communicator can be split off
 int init_lanes(RcclCtx *c, RcclApi &R, int nranks, int myrank) {
   c->nlanes = 1;
-  if (R.CommSplit && !getenv("MW_RCCL_ONE_LANE")) {
-    ncclResult_t r = R.CommSplit(c->lane[0].comm, 0, myrank, &c->lane[1].comm, nullptr);
-    if (r == ncclSuccess && c->lane[1].comm) c->nlanes = 2; else c->lane[1].comm = nullptr;
-  }
+  c->nlanes = getenv("MW_RCCL_ONE_LANE") ? 1 : 2;
+  c->lane[1].comm = c->lane[0].comm; c->own_comm1 = false;     // shared communicator (default)
+  { const char *tc = getenv("MW_RCCL_TWO_COMMS");
+    if (c->nlanes == 2 && tc && tc[0] == '1' && R.CommSplit) {
+      ncclComm_t split = nullptr;
+      ncclResult_t r = R.CommSplit(c->lane[0].comm, 0, myrank, &split, nullptr);
+      if (r == ncclSuccess && split) { c->lane[1].comm = split; c->own_comm1 = true; }
+    } }
   for (int l = 0; l < c->nlanes; l++) {
     RcclLane &L = c->lane[l];
     if (hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess ||
@@ -189,9 +198,10 @@ int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, in
   return 0;
 }
 
-static int g_selftest_lanes = 0;
-// How many lanes (side stream + communicator) the last mw_rccl_selftest drove: 2 when this RCCL can split a communicator.
-int mw_rccl_selftest_lanes(void) { return g_selftest_lanes; }
+static int g_selftest_lanes = 0, g_selftest_comms = 0;
+// How many lanes (side stream + event pair) the last mw_rccl_selftest drove, times 10, plus the number of communicators behind them:
+// 21 = two lanes on the handle's one communicator (default), 22 = two lanes with a communicator each (MW_RCCL_TWO_COMMS=1).
+int mw_rccl_selftest_lanes(void) { return g_selftest_lanes * 10 + g_selftest_comms; }
 
 // Diagnostic: a 1-rank communicator that sends n doubles to itself through the same group/stream/event sequence as
 // rccl_exchange (two sends + two receives in one ncclGroup on a side stream).  Checks, on a single GPU, that RCCL initialises
@@ -229,6 +239,7 @@ int mw_rccl_selftest(long long n, void *vstream) {
               hipMemsetAsync(dst2, 0, h.size() * 8, s2) != hipSuccess)) { mw::set_error("rccl_selftest: second lane set-up failed"); rc = 1; }
   if (!rc) rc = rccl_exchange(c, src, src + n, src + 2 * n, src + 3 * n, dst2, dst2 + n, dst2 + 2 * n, dst2 + 3 * n, n, n, s2);
   g_selftest_lanes = (c->lane[0].owned ? 1 : 0) + (c->nlanes > 1 && c->lane[1].owned ? 1 : 0);
+  g_selftest_comms = c->own_comm1 ? 2 : 1;
   if (!rc && (hipMemcpyAsync(back.data(), dst, h.size() * 8, hipMemcpyDeviceToHost, main_stream) != hipSuccess ||
               hipStreamSynchronize(main_stream) != hipSuccess)) { mw::set_error("rccl_selftest: download failed"); rc = 1; }
   if (!rc && (hipMemcpyAsync(back2.data(), dst2, h.size() * 8, hipMemcpyDeviceToHost, s2) != hipSuccess ||

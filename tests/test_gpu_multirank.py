@@ -78,7 +78,7 @@ def test_two_ranks_2d(mw):
     run_ranks(2, 64, 1, 16, 1, 3)           # 2x1: west == east peer
 
 
-def test_rccl_transport_selftest(mw):
+def test_rccl_transport_selftest(mw, monkeypatch):
     """The RCCL transport itself (mw_rccl.cpp) on one GPU: a 1-rank communicator sends the four strips to itself through the
     exchange's own ncclGroup / side-stream / event sequence (receives posted E,W,N,S against sends W,E,S,N)."""
     import torch
@@ -87,9 +87,13 @@ def test_rccl_transport_selftest(mw):
         st = torch.cuda.current_stream().cuda_stream
         capi.check(capi.lib().mw_rccl_selftest(3 * 100 * 400 * 5, C.c_void_p(st)))          # one state strip of config 2
         capi.check(capi.lib().mw_rccl_selftest(7, C.c_void_p(st)))
-        # both lanes -- the state pipeline's and the tracer pipeline's side stream + communicator -- were driven, from two caller
-        # streams, with both exchanges in flight together (torch's RCCL 2.26 provides ncclCommSplit for the second communicator)
-        assert capi.lib().mw_rccl_selftest_lanes() == 2
+        # both lanes -- the state pipeline's and the tracer pipeline's side stream + event pair -- were driven, from two caller streams:
+        # on the handle's one communicator (default) ...
+        assert capi.lib().mw_rccl_selftest_lanes() == 21
+        # ... and with a communicator per lane (opt-in; torch's RCCL 2.26 provides ncclCommSplit)
+        monkeypatch.setenv("MW_RCCL_TWO_COMMS", "1")
+        capi.check(capi.lib().mw_rccl_selftest(4096, C.c_void_p(st)))
+        assert capi.lib().mw_rccl_selftest_lanes() == 22
 
 
 @pytest.mark.parametrize("layout", [(2, 20, 24, 10), (4, 32, 28, 8)])
