@@ -1,0 +1,23 @@
+"""The dycore step on bench.py's seeded 'developed' state only (for a rocprofv3 pass): python tools/developed_only.py [steps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from miniweatherml_amd import modules
+
+nx, ny, nz = 400, 400, 100
+coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 2e5, 2e5, 2e4)
+dt = dycore.compute_time_step(coupler)
+dm = coupler.get_data_manager_readwrite()
+rho_d = dm.get("density_dry")
+k = torch.arange(nz, device=rho_d.device, dtype=torch.float64).view(nz, 1, 1, 1)
+j = torch.arange(ny, device=rho_d.device, dtype=torch.float64).view(1, ny, 1, 1)
+i = torch.arange(nx, device=rho_d.device, dtype=torch.float64).view(1, 1, nx, 1)
+blob = ((torch.sin(i * 0.11) * torch.cos(j * 0.07)) > 0.3).to(torch.float64)
+dm.get("cloud_liquid").copy_(2.0e-3 * blob * ((k > 0.15 * nz) & (k < 0.45 * nz)) * (0.5 + 0.5 * torch.sin(0.3 * k + 0.05 * i) ** 2) * rho_d)
+dm.get("precip_liquid").copy_(4.0e-4 * blob * (k < 0.3 * nz) * (0.5 + 0.5 * torch.cos(0.2 * k + 0.03 * j) ** 2) * rho_d)
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
+    dycore.time_step(coupler, dt)
+torch.cuda.synchronize()
