@@ -1,11 +1,10 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT
-cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dev_stats -- python3 $R/tools/developed_only.py 6 > /dev/null 2> $R/gpurun_out/prof_dev_stats.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $R/gpurun_out/prof_dev_sq -- python3 $R/tools/developed_only.py 2 > /dev/null 2> $R/gpurun_out/prof_dev_sq.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_dev_f -- python3 $R/tools/developed_only.py 2 > /dev/null 2> $R/gpurun_out/prof_dev_f.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_dev_w -- python3 $R/tools/developed_only.py 2 > /dev/null 2> $R/gpurun_out/prof_dev_w.err
-cd $R
-python3 tools/summarize_profiles.py r03_developed gpurun_out/prof_dev_stats gpurun_out/prof_dev_f gpurun_out/prof_dev_w gpurun_out/prof_dev_sq 2>&1 | tail -16
-cp profiles/r03_developed_summary.json gpurun_out/
-find gpurun_out/prof_dev_f gpurun_out/prof_dev_w gpurun_out/prof_dev_sq -name "*counter_collection.csv" -size +8M -delete
+cd $GRAFT_REPO_ROOT
+python tools/city_timing.py 2>&1 | grep -v amdgpu.ids | tail -2
+MW_NO_SPEC=1 python tools/city_timing.py 2>&1 | grep -v amdgpu.ids | tail -2 | sed 's/^/nospec /'
+for g in "200 200 50" "1024 1024 100"; do set -- $g; python bench.py --nx $1 --ny $2 --nz $3 --no-micro --no-cpu-baseline --steps 10 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('$g', '%.4g'%d['value'], '%.3f ms'%d['ms_per_step'])"; done
+python bench.py --full-loop --no-micro --no-cpu-baseline 2>/dev/null > gpurun_out/bench_r03_full_loop.json; python -c "
+import json; d=json.loads(open('gpurun_out/bench_r03_full_loop.json').read()); print('full loop', '%.4g'%d['value'], '%.3f ms'%d['ms_per_step'])"
+python bench.py --workload config4 --no-micro --no-cpu-baseline --steps 10 2>/dev/null > gpurun_out/bench_r03_config4_block.json; python -c "
+import json; d=json.loads(open('gpurun_out/bench_r03_config4_block.json').read()); print('config4 block', '%.4g'%d['value'], '%.3f ms'%d['ms_per_step'])"
