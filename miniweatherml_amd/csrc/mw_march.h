@@ -610,9 +610,17 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   // in front of their first use -- the kernel has no spare SGPRs to hold them any earlier -- and their latency was exposed three
   // times per level (-1 % kernel time).  All 256 threads copy, also those of waves beyond the last row, which leave right after.
   extern __shared__ double lds_hp[];
+  // ... and so do the few uniform doubles of the finalisation (grid spacings, the stage's time-step factors, gravity): as kernel
+  // arguments they occupy 12 SGPRs for the whole loop in a kernel that spills SGPRs to VGPR lanes (every spilled one comes back as a
+  // v_readlane, a VALU instruction); as broadcast LDS reads they are VGPR operands where they are used.
+  __shared__ double lds_c[8];
   if (HPL) {
     const int nrow = g.kb - g.kstart + 1;
     for (int i = threadIdx.x; i < nrow * 8; i += 256) lds_hp[i] = p.hypk[(long long)g.kstart * 8 + i];     // (nens == 1: row k at k*8)
+    if (threadIdx.x < 8) {
+      const double cdt = (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;
+      lds_c[threadIdx.x] = threadIdx.x == 0 ? p.rdx : threadIdx.x == 1 ? p.rdz : threadIdx.x == 2 ? cdt : threadIdx.x == 3 ? -p.grav : 0.0;
+    }
     __syncthreads();
   }
   if (!g.valid) return;
@@ -769,16 +777,17 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
         double q_n;
         if (STAGE == 1) q_n = q_s;
         else q_n = (l == idR || l == idT) ? snv[l] : snv[l] * rho_n;
-        double tend = xpart[l] - (fzs[l] - fzprev[l]) * p.rdz;
-        if (l == idW && Cf<K>::gravity(p)) tend += -p.grav * rho_s;
+        double tend = xpart[l] - (fzs[l] - fzprev[l]) * (HPL ? lds_c[1] : p.rdz);
+        if (l == idW && Cf<K>::gravity(p)) tend += (HPL ? lds_c[3] : -p.grav) * rho_s;
         if (l == idU && Cf<K>::coriolis(p)) tend += p.fcor * rv_s;
         if (l == idV && Cf<K>::coriolis(p)) tend -= p.fcor * ru_s;
         if (l == idV && Cf<K>::sim2d(p)) tend = 0;
         if (Cf<K>::immersed(p)) { double imm_tend = imm_coef * q_s / dt_stage; tend = immv * imm_tend + (1 - immv) * tend; }
         double qnew;
-        if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
-        else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
-        else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
+        const double cdt = HPL ? lds_c[2] : (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;   // (one product, as before)
+        if (STAGE == 1)      qnew = q_n + cdt * tend;
+        else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + cdt * tend;
+        else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + cdt * tend;
         if (l == idR) inv_rho_new = fast_rcp(qnew + hyc);
         const double stored = (l == idR || l == idT) ? qnew : qnew * inv_rho_new;
         // (MODE 1, the last stage of a time step: u, v, w go to the coupler's arrays only.  Nobody reads the result slab's velocities
@@ -794,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
 #pragma unroll
       for (int l = 0; l < 5; l++) {
         double fe = from_east<N1>(fxs[l], lane, n);
-        lds_xpart[l][threadIdx.x] = -(fe - fxs[l]) * p.rdx + tyv[l];
+        lds_xpart[l][threadIdx.x] = -(fe - fxs[l]) * (HPL ? lds_c[0] : p.rdx) + tyv[l];
       }
     }
 #pragma unroll
