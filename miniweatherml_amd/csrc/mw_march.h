@@ -1061,6 +1061,16 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   // requested at the top of the iteration they cost 6 VGPRs the kernel does not have.  (dynamic LDS: (chunk + 4) * nens * 3 doubles)
   extern __shared__ double lds_bg[];
   const int bg_l0 = max((int)blk.y * chunk - 4, 0);
+  // the uniform doubles of the loop (reciprocal grid spacings, time-step factors) as broadcast LDS reads instead of resident SGPRs
+  // (as in k_xz_state: the kernel spills SGPRs to VGPR lanes)
+  // (not in the D13 variant, MODE 1: it sits at the VGPR limit and the values read from LDS live in VGPRs)
+  constexpr bool LC = (MODE == 0);
+  __shared__ double lds_c[8];
+  if (LC && threadIdx.x < 8) {
+    const double cdt = (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;
+    lds_c[threadIdx.x] = threadIdx.x == 0 ? p.rdx : threadIdx.x == 1 ? p.rdy : threadIdx.x == 2 ? p.rdz : threadIdx.x == 3 ? dt : threadIdx.x == 4 ? cdt : 0.0;
+  }
+  if (LC) __syncthreads();
   if (MODE == 1) {
     const int cnt = (min((int)blk.y * chunk + chunk, p.nz) - bg_l0) * p.nens;
     for (int i3 = threadIdx.x; i3 < cnt * 3; i3 += 256) {
@@ -1217,10 +1227,10 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         {
           // the cell volume dx dy dz multiplies both sides of the reference's test (:506-511) and cancels in the multiplier
           const double mass_available = fmax(w[v][HS - 1] * rhop, 0.0);      // (window slot HS - 1 = level k-1)
-          const double out_x = (fmax(fe, 0.0) - fmin(fxp[v], 0.0)) * p.rdx;
-          const double out_y = (fmax(fyn[v], 0.0) - fmin(fys[v], 0.0)) * p.rdy;
-          const double out_z = (fmax(fzn[v], 0.0) - fmin(fzp[v], 0.0)) * p.rdz;
-          const double mass_out = (out_x + out_y + out_z) * dt;
+          const double out_x = (fmax(fe, 0.0) - fmin(fxp[v], 0.0)) * (LC ? lds_c[0] : p.rdx);
+          const double out_y = (fmax(fyn[v], 0.0) - fmin(fys[v], 0.0)) * (LC ? lds_c[1] : p.rdy);
+          const double out_z = (fmax(fzn[v], 0.0) - fmin(fzp[v], 0.0)) * (LC ? lds_c[2] : p.rdz);
+          const double mass_out = (out_x + out_y + out_z) * (LC ? lds_c[3] : dt);
           if (__builtin_expect(s2cell && has_mult && Cf<K>::positive(p, t0 + v) && mass_out > mass_available, 0))
             mult = mass_available / mass_out;
         }
@@ -1232,7 +1242,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         szn[v] = (G > 0) ? G * multp[v] : G * mult;                          // z face kp, scaled by its donor
         const double ys = (fys[v] < 0) ? fys[v] * mult : fys[v];             // outgoing y faces scaled, incoming provisional
         const double yn = (fyn[v] > 0) ? fyn[v] * mult : fyn[v];
-        Pn[v] = -(sFe - sFw) * p.rdx - (yn - ys) * p.rdy;
+        Pn[v] = -(sFe - sFw) * (LC ? lds_c[0] : p.rdx) - (yn - ys) * (LC ? lds_c[1] : p.rdy);
         if (__builtin_expect(rec && mult < 1.0, 0)) {
           if (fys[v] < 0) { DS[(long long)(5 + t0 + v) * p.fxV + (long long)kp * p.fxK + (long long)j * p.fxJ + q] = ys - fys[v]; fl |= 1u << (2 * v); }
           if (fyn[v] > 0) { DN[(long long)(5 + t0 + v) * p.fzV + (long long)kp * p.fzK + (long long)j * p.fzJ + q] = yn - fyn[v]; fl |= 2u << (2 * v); }
@@ -1254,11 +1264,12 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       for (int v = 0; v < T; v++) {
         const double q_s = (ORD == 3 ? wkm2[v] : w[v][0]) * rhos2;           // level k-2
         const double q_n = (STAGE == 1) ? q_s : qn_[v] * rho_n;
-        const double tend = P[v] - (szn[v] - szf[v]) * p.rdz;
+        const double tend = P[v] - (szn[v] - szf[v]) * (LC ? lds_c[2] : p.rdz);
         double qnew;
-        if (STAGE == 1)      qnew = q_n + dt_dyn * tend;
-        else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + (1.0 / 4.0) * dt_dyn * tend;
-        else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + (2.0 / 3.0) * dt_dyn * tend;
+        const double cdt = LC ? lds_c[4] : (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;   // (one product, as before)
+        if (STAGE == 1)      qnew = q_n + cdt * tend;
+        else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + cdt * tend;
+        else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + cdt * tend;
         if (Cf<K>::positive(p, t0 + v)) qnew = fmax(0.0, qnew);
         if (MODE == 0) { if (st) Sout[so + (5 + t0 + v) * p.sV] = qnew * inv_rho_new; }
         else {
