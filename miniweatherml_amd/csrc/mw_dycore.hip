@@ -1209,8 +1209,7 @@ static int balanced_chunk(int nz, long long base_waves, const char *env, long lo
 // Which compile-time configuration of the marching kernels (Cf<K>) fits this view of the handle: 1 / 2 = the shipped supercell /
 // simple_city set-ups with their run-time switches folded, 0 = everything at run time.  MW_NO_SPEC=1 forces 0 (A/B timing, tests).
 static int marching_config(const DyP &p) {
-  static const bool off = getenv("MW_NO_SPEC") != nullptr;
-  if (off) return 0;
+  if (getenv("MW_NO_SPEC")) return 0;                          // (read per launch: tests switch it inside one process)
   const unsigned all = (1u << p.nt) - 1u;
   if (p.nens != 1 || p.sim2d || p.bc_x != MW_BC_PERIODIC || p.bc_y != MW_BC_PERIODIC || p.bc_z != MW_BC_WALL || p.fcor != 0.0 ||
       !p.bn_default || !p.an_default || p.pos_mask != all || p.mass_mask != all || p.idWV != 0) return 0;
