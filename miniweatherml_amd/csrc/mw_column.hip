@@ -9,9 +9,14 @@
 // =====================================================================================================
 #include "../../include/mw_cdna4.h"
 #include "mw_common.h"
+#include "mw_glibc_pow.h"
 #include <cmath>
 
 namespace mw {
+
+// cos with the bits of the host's glibc where its main path applies (|x| < 2.4263; mw_glibc_pow.h), else the device library's
+__device__ __forceinline__ double cos_glibc(double x) { double r; if (glibc_cos_main(x, &r)) return r; return cos(x); }
+
 
 struct FieldPtrs { double *f[5 + MW_MAX_TRACERS]; };
 
@@ -54,7 +59,7 @@ __global__ __launch_bounds__(256) void k_sponge_apply(FieldPtrs fp, int num_fiel
   const int k = nz - 1 - kloc;
   double z = (k + 0.5) * dz;
   double rel_dist = (zlen - z) / (num_layers * dz);
-  double space_factor = (cos(M_PI * rel_dist) + 1) / 2;
+  double space_factor = (cos_glibc(M_PI * rel_dist) + 1) / 2;
   double factor = space_factor * time_factor;
   double *q = fp.f[ifld] + (long long)k * ncell_lev * nens + t;
   double v = *q;

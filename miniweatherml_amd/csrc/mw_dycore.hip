@@ -104,6 +104,11 @@ __device__ __forceinline__ double exp_ref(double x) {       // likewise exp (the
   if (__builtin_expect(glibc_exp_main(x, &r), 1)) return r;
   return exp(x);
 }
+__device__ __forceinline__ double cos_ref(double x) {       // likewise cos (the cosine bells of the initial states, :1131, perturb_temperature.h:63)
+  double r;
+  if (__builtin_expect(glibc_cos_main(x, &r), 1)) return r;
+  return cos(x);
+}
 template <bool STRICT> __device__ __forceinline__ double pow_gamma(double x, double g) { return pow_ref(x, g); }
 
 // p = C0 (hyt + e)^gamma for the fast path.  The Riemann solver needs two of these per face (6 per cell and stage,
@@ -683,7 +688,7 @@ __device__ __forceinline__ double d_sample_ellipse_cosine(double amp, double x, 
 #pragma clang fp contract(off)
   double dist = sqrt(((x - x0) / xrad) * ((x - x0) / xrad) + ((y - y0) / yrad) * ((y - y0) / yrad) +
                      ((z - z0) / zrad) * ((z - z0) / zrad)) * M_PI / 2.;
-  if (dist <= M_PI / 2.) return amp * pow_ref(cos(dist), 2.0);
+  if (dist <= M_PI / 2.) return amp * pow_ref(cos_ref(dist), 2.0);
   return 0.;
 }
 
@@ -824,7 +829,7 @@ __global__ __launch_bounds__(256) void k_perturb_temperature(int nz, int ny, int
   double x0 = xlen / 2, y0 = ylen / 2, z0 = 1500, radx = 10000, rady = 10000, radz = 1500, amp = 5;
   double xn = (xloc - x0) / radx, yn = (yloc - y0) / rady, zn = (zloc - z0) / radz;
   double rad = sqrt(xn * xn + yn * yn + zn * zn);
-  if (rad < 1) temp[t] += amp * pow_ref(cos(M_PI * rad / 2), 2.0);
+  if (rad < 1) temp[t] += amp * pow_ref(cos_ref(M_PI * rad / 2), 2.0);
 }
 
 // modules::perturb_temperature(random=true)   perturb_temperature.h:25-39: the lowest nz/4 levels get uniform noise in [-1, 1] * 3 K,

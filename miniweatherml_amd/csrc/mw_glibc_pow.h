@@ -32,9 +32,11 @@ struct GpLogEntry { double invc, logc, logctail; };
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ const GpLogEntry gp_log_tab[128] = MW_GP_LOG_TABLE;
 __device__ const unsigned long long gp_exp_tab[256] = MW_GP_EXP_TABLE;
+__device__ const double gp_sincos_tab[440] = MW_GP_SINCOS_TABLE;
 #else
 static const GpLogEntry gp_log_tab[128] = MW_GP_LOG_TABLE;
 static const unsigned long long gp_exp_tab[256] = MW_GP_EXP_TABLE;
+static const double gp_sincos_tab[440] = MW_GP_SINCOS_TABLE;
 #endif
 
 MW_GP_HD uint64_t gp_bits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
@@ -127,6 +129,80 @@ MW_GP_HD bool glibc_exp_main(double x, double *res) {
   const double q2 = __builtin_fma(r4, c45, q1);
   const double scale = gp_double(sbits);
   *res = __builtin_fma(scale, q2, scale);
+  return true;
+}
+
+// cos(x) with the bits of glibc's cos (sysdeps/ieee754/dbl-64/s_sin.c, the x86-64 FMA build `__cos_fma`), for 2^-27 < |x| < 2.4263
+// except a measure-zero set (below).  |x| < 0.855469: do_cos -- |x| = k/128 + d, cos from the table entry k and short polynomials of
+// d.  0.855469 <= |x| < 2.426265: cos x = sin(pi/2 - |x|) with pi/2 as hp0 + hp1: a Taylor polynomial for |a| < 0.126, else do_sin
+// with the table.  (The initial states' cosine bells -- perturb_temperature.h:63, dynamics_euler_stratified_wenofv.h:1131 -- take
+// arguments in [0, pi/2].)  The polynomial constants are usncs.h's; the table is the library's (mw_glibc_pow_tables.h).
+MW_GP_HD bool glibc_cos_main(double xin, double *res) {
+#pragma clang fp contract(off)
+  const double sn3 = -0x1.5555555555515p-3, sn5 = 0x1.11110e829872fp-7;
+  const double cs2 = 0.5, cs4 = -0x1.5555555555535p-5, cs6 = 0x1.6c16bedd9e239p-10;
+  const double big = 0x1.8p45;
+  const uint32_t kx = (uint32_t)(gp_bits(xin) >> 32) & 0x7fffffffu;
+  if (kx <= 0x3e3fffffu || kx > 0x400368fcu) return false;                // |x| < 2^-27 (result 1) or the range-reduction paths
+  const double ax = gp_double(gp_bits(xin) & 0x7fffffffffffffffull);
+  if (kx <= 0x3feb5fffu) {                                                // do_cos(|x|, +-0)
+    const double dx = (xin >= 0.0) ? 0.0 : -0.0;
+    const double u = ax + big;
+    const int k = (int)(uint32_t)gp_bits(u) << 2;
+    double d = ax - (u - big);
+    const double cs = gp_sincos_tab[k + 2];
+    d = d + dx;
+    const double xx = d * d;
+    const double ps = __builtin_fma(xx, sn5, sn3);
+    const double x3 = d * xx;
+    const double s = __builtin_fma(x3, ps, d);
+    double pc = __builtin_fma(xx, cs6, cs4);
+    pc = __builtin_fma(xx, pc, cs2);
+    const double c = xx * pc;
+    double cor = __builtin_fma(-s, gp_sincos_tab[k + 1], gp_sincos_tab[k + 3]);      // ccs - s * ssn
+    cor = __builtin_fma(-c, cs, cor);                                                  // ... - cs * c
+    cor = __builtin_fma(-s, gp_sincos_tab[k], cor);                                    // ... - sn * s
+    *res = cs + cor;
+    return true;
+  }
+  const double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+  const double y = hp0 - ax;
+  const double a = y + hp1;
+  const double da = (y - a) + hp1;
+  const double aa = gp_double(gp_bits(a) & 0x7fffffffffffffffull);
+  if (aa < 0x1.020c49ba5e354p-3) {                                        // TAYLOR_SIN(a * a, a, da)
+    const double s1 = -0x1.5555555555555p-3, s2 = 0x1.1111111110ecep-7, s3 = -0x1.a01a019db08b8p-13, s4 = 0x1.71de27b9a7ed9p-19,
+                 s5 = -0x1.addffc2fcdf59p-26;
+    const double xx = a * a;
+    double t = __builtin_fma(xx, s5, s4);
+    t = __builtin_fma(xx, t, s3);
+    t = __builtin_fma(xx, t, s2);
+    t = __builtin_fma(xx, t, s1);
+    const double hd = da * cs2;
+    t = __builtin_fma(t, a, -hd);
+    const double r = __builtin_fma(xx, t, da);
+    *res = a + r;
+    return true;
+  }
+  if (!(a > 0.0)) return false;                                           // (a <= 0: |x| at or beyond pi/2 -- the mirrored form; not restated)
+  const double u = aa + big;
+  const int k = (int)(uint32_t)gp_bits(u) << 2;
+  const double x = aa - (u - big);
+  const double xx = x * x;
+  const double ps = __builtin_fma(xx, sn5, sn3);
+  const double x3 = x * xx;
+  const double sd = __builtin_fma(x3, ps, da);
+  double pc = __builtin_fma(xx, cs6, cs4);
+  pc = __builtin_fma(xx, pc, cs2);
+  const double s = x + sd;
+  const double c0 = xx * pc;
+  const double c = __builtin_fma(x, da, c0);
+  const double sn = gp_sincos_tab[k];
+  double cor = __builtin_fma(s, gp_sincos_tab[k + 3], gp_sincos_tab[k + 1]);           // ssn + s * ccs
+  cor = __builtin_fma(-c, sn, cor);                                                    // ... - sn * c
+  const double t = __builtin_fma(s, gp_sincos_tab[k + 2], cor);                       // cs * s + cor
+  const double r = sn + t;
+  *res = gp_double((gp_bits(r) & 0x7fffffffffffffffull) | (gp_bits(a) & 0x8000000000000000ull));
   return true;
 }
 

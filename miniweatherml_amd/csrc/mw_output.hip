@@ -8,11 +8,16 @@
 // =====================================================================================================
 #include "../../include/mw_cdna4.h"
 #include "mw_common.h"
+#include "mw_glibc_pow.h"
 #include <algorithm>
 #include <cmath>
 #include <vector>
 
 namespace mw {
+
+// cos with the bits of the host's glibc where its main path applies (|x| < 2.4263; mw_glibc_pow.h), else the device library's
+__device__ __forceinline__ double cos_glibc(double x) { double r; if (glibc_cos_main(x, &r)) return r; return cos(x); }
+
 
 struct Six { double *f[6]; };
 
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(256) void k_hsponge_apply(Six f, int nz, int ny, in
   for (int s = 0; s < 4; s++) {
     if (!on[s]) continue;
     double loc = d[s] / (sponge_cells - 1.0);
-    double weight = d[s] < sponge_cells ? (cos(M_PI * loc) + 1) / 2 : 0;
+    double weight = d[s] < sponge_cells ? (cos_glibc(M_PI * loc) + 1) / 2 : 0;
     weight *= time_factor;
     v = weight * c + (1 - weight) * v;
   }

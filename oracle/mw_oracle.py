@@ -100,27 +100,28 @@ def powcheck():
     return libm_pow, restated
 
 
-def expcheck():
-    """(libm_exp, glibc_exp_restated): std::exp of the host's C library and the product's restatement of it (mw_glibc_pow.h)."""
+def expcheck(fn="exp"):
+    """(libm_fn, restated_fn) for fn = "exp" or "cos": the host C library's function and the product's restatement of it (mw_glibc_pow.h)."""
     build()
     L = C.CDLL(os.path.join(_HERE, "libmw_powcheck.so"))
     dp = C.POINTER(C.c_double)
-    L.mwo_libm_exp.argtypes = [C.c_longlong, dp, dp]
-    L.mwo_glibc_exp_restated.argtypes = [C.c_longlong, dp, dp, C.POINTER(C.c_ubyte)]
-    L.mwo_glibc_exp_restated.restype = C.c_longlong
+    f_ref, f_re = getattr(L, "mwo_libm_" + fn), getattr(L, "mwo_glibc_%s_restated" % fn)
+    f_ref.argtypes = [C.c_longlong, dp, dp]
+    f_re.argtypes = [C.c_longlong, dp, dp, C.POINTER(C.c_ubyte)]
+    f_re.restype = C.c_longlong
 
-    def libm_exp(x):
+    def libm_fn(x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         out = np.empty_like(x)
-        L.mwo_libm_exp(x.size, x.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        f_ref(x.size, x.ctypes.data_as(dp), out.ctypes.data_as(dp))
         return out
 
     def restated(x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         out, ok = np.empty_like(x), np.empty(x.size, dtype=np.uint8)
-        L.mwo_glibc_exp_restated(x.size, x.ctypes.data_as(dp), out.ctypes.data_as(dp), ok.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        f_re(x.size, x.ctypes.data_as(dp), out.ctypes.data_as(dp), ok.ctypes.data_as(C.POINTER(C.c_ubyte)))
         return out, ok.astype(bool)
-    return libm_exp, restated
+    return libm_fn, restated
 
 
 def lib():

@@ -40,4 +40,18 @@ long long mwo_glibc_exp_restated(long long n, const double *x, double *out, unsi
   return cnt;
 }
 
+
+void mwo_libm_cos(long long n, const double *x, double *out) {
+  for (long long i = 0; i < n; i++) out[i] = std::cos(x[i]);
+}
+long long mwo_glibc_cos_restated(long long n, const double *x, double *out, unsigned char *ok) {
+  long long cnt = 0;
+  for (long long i = 0; i < n; i++) {
+    double r = 0;
+    const bool m = mw::glibc_cos_main(x[i], &r);
+    ok[i] = m ? 1 : 0; out[i] = r; cnt += m;
+  }
+  return cnt;
+}
+
 }

@@ -66,6 +66,21 @@ def test_host_build_of_the_exp_restatement_is_bit_identical_to_libm(oracle):
     assert not main.any()
 
 
+def test_host_build_of_the_cos_restatement_is_bit_identical_to_libm(oracle):
+    """glibc's cos on [0, pi/2] (the cosine bells of the initial states) and on the rest of its two table / Taylor paths."""
+    libm_cos, restated = oracle.expcheck("cos")
+    rng = np.random.default_rng(31)
+    for name, x, full in (("[0, pi/2]", rng.uniform(0.0, np.pi / 2, 3_000_000), True),
+                          ("towards pi/2", np.pi / 2 - rng.uniform(0.0, 0.2, 1_000_000) * rng.uniform(0.0, 1.0, 1_000_000), True),
+                          ("[-2.42, 2.42]", rng.uniform(-2.42, 2.42, 3_000_000), False), ("wide", rng.uniform(-60.0, 60.0, 500_000), False)):
+        ref = libm_cos(x)
+        got, main = restated(x)
+        bad = (bits(ref) != bits(got)) & main
+        assert not bad.any(), "%s: %d results differ from libm" % (name, int(bad.sum()))
+        if full:
+            assert main.mean() > 0.9999, name
+
+
 def test_arguments_outside_the_main_path_are_declined(oracle):
     _, restated = oracle.powcheck()
     x = np.array([0.0, -1.0, np.inf, np.nan, 5e-324, 1e-310, 2.0, 2.0, 2.0, 2.0, 1e300, 1e-300])

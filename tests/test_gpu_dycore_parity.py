@@ -48,12 +48,9 @@ def test_init_matches_oracle(mw, oracle, name):
     hy = odyc.hy()
     for k in ("hy_dens_cells", "hy_dens_theta_cells", "hy_dens_edges", "hy_dens_theta_edges"):
         assert np.array_equal(getattr(dycore, k), hy[k]), k          # host column code, same libm -> bitwise
-    # init + perturb_temperature: supercell, city, building -- their device code needs pow only, and that has glibc's bits
-    # (csrc/mw_glibc_pow.h) -- are BIT-identical to the oracle; the thermal case also calls cos on the device: 1e-13
-    if name.startswith("thermal"):
-        compare_fields(gpu_fields(coupler), of.as_dict(), 1e-13, "init " + name)
-    else:
-        compare_fields(gpu_fields(coupler), of.as_dict(), 0.0, "init %s, strict arithmetic: mode 1" % name)
+    # init + perturb_temperature: the device code keeps the reference's operation order, and its pow, exp and cos have glibc's bits
+    # (csrc/mw_glibc_pow.h): BIT-identical to the oracle, all four initial states
+    compare_fields(gpu_fields(coupler), of.as_dict(), 0.0, "init %s, strict arithmetic: mode 1" % name)
     assert np.array_equal(dycore.immersed_proportion(coupler).cpu().numpy(), odyc.immersed_proportion())
     assert coupler.get_option("use_immersed_boundaries") == bool(odyc.p.use_immersed)
 
