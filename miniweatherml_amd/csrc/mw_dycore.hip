@@ -1227,6 +1227,25 @@ static int marching_config(const DyP &p) {
 static int launch_y_state(mw_dycore_s *d, const double *S, int par, const CouplerPtrs *conv = nullptr) {
   if (d->p.sim2d) return 0;
   ProfScope ps(d, 5);
+  if (conv && d->member_major) {
+    // D1 inside the launch, member-major handle: ONE launch over the fused lanes (k_y_state<.., MM>): unit-stride reads of the
+    // coupler's arrays, outputs into the members' arrays.  The folded configuration is decided on a member's view (nens = 1 there).
+    const View v0 = view(d, 0);
+    const DyP &p = d->p;
+    const long long threads = (long long)p.nz * p.nx * p.nens;
+    const long long mthreads = (long long)p.nz * p.nx;                                   // one member's: the chunk rule of the per-member launches
+    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (mthreads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
+    dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
+    const YMember mm = {v0.p.sJ, v0.p.sK, v0.p.sV, v0.slab, v0.p.fyJ, v0.p.fyK, v0.m[1], v0.p.nC, v0.tend, p.nx};
+    double *Sw = const_cast<double *>(S);
+#define MW_YSM(K_, O_) hipLaunchKernelGGL((k_y_state<true, K_, O_, true>), grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
+    const int K = marching_config(v0.p);
+    if (d->ord == 3) { if (K == 1) MW_YSM(1, 3); else if (K == 2) MW_YSM(2, 3); else MW_YSM(0, 3); }
+    else             { if (K == 1) MW_YSM(1, 5); else if (K == 2) MW_YSM(2, 5); else MW_YSM(0, 5); }
+#undef MW_YSM
+    MW_LAUNCH_CHECK();
+    return 0;
+  }
   for (int e = 0; e < n_views(d); e++) {
     const View v = view(d, e);
     const DyP &p = v.p;
@@ -1235,7 +1254,7 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     double *MY = d->M[par][1] + e * v.m[1]; unsigned char *UY = d->UP[par][1] + e * v.m[1];
-#define MW_YS(CONV_, K_, O_, cp, sw) hipLaunchKernelGGL((k_y_state<CONV_, K_, O_>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw)
+#define MW_YS(CONV_, K_, O_, cp, sw) hipLaunchKernelGGL((k_y_state<CONV_, K_, O_>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw, YMember())
 #define MW_YS_K(K_) { if (d->ord == 3) { if (conv) MW_YS(true, K_, 3, *conv, Sw); else MW_YS(false, K_, 3, CouplerPtrs(), nullptr); } \
                       else             { if (conv) MW_YS(true, K_, 5, *conv, Sw); else MW_YS(false, K_, 5, CouplerPtrs(), nullptr); } }
     double *Sw = const_cast<double *>(v.S(S));
@@ -1783,7 +1802,8 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   // D1 + D2 (:101, :248-255).  Production path with periodic x and y owned by this rank (either schedule: the tracer stream waits
   // for the stage's state kernels anyway): done inside the first k_y_state (no separate pass); otherwise a conversion kernel first
   // (the reference's operation order on the general path).
-  d->conv_pending = march && !d->member_major && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT");
+  d->conv_pending = march && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT") &&
+                    (!d->member_major || !getenv("MW_NO_FUSED_CONVERT_MM"));
   if (!d->conv_pending) {
     ProfScope ps(d, 4);
     if (d->member_major) {      // one coalesced pass in the coupler's order (see k_coupler_to_member)

@@ -237,10 +237,10 @@ __device__ __forceinline__ void convert_cell_fast(const DyP &p, const CouplerCel
 }
 // the tracers of that cell: slab value = rho_t / rho
 template <int K = 0>
-__device__ __forceinline__ void convert_cell_tracers(const DyP &p, const CouplerCell &r, double inv_den, double *__restrict__ s) {
+__device__ __forceinline__ void convert_cell_tracers(const DyP &p, const CouplerCell &r, double inv_den, double *__restrict__ s, long long sV) {
 #pragma clang fp contract(off)
 #pragma unroll
-  for (int tr = 0; tr < 4; tr++) if (tr < Cf<K>::ntr(p)) s[(long long)(5 + tr) * p.sV] = r.tr[tr] * inv_den;
+  for (int tr = 0; tr < 4; tr++) if (tr < Cf<K>::ntr(p)) s[(long long)(5 + tr) * sV] = r.tr[tr] * inv_den;
 }
 // stand-alone form (2-D runs, walls / open boundaries or a neighbour exchange in y, two-stream schedule)
 __global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtrs c, double *__restrict__ S) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtr
   double *s = S + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
 #pragma unroll
   for (int v = 0; v < 5; v++) s[(long long)v * p.sV] = s5[v];
-  convert_cell_tracers(p, r, inv_den, s);
+  convert_cell_tracers(p, r, inv_den, s, p.sV);
 }
 
 // Member-major handles (nens > 1, see View in mw_dycore.hip): the two conversions between the coupler's member-fastest arrays and
@@ -325,10 +325,16 @@ __global__ __launch_bounds__(256) void k_member_to_coupler(DyP p, const double *
 // ---------------------------------------------------------------------------------------------------------------
 // (Measured, round 3: with the switches folded the non-converting variant needs 192 VGPRs; capped at 168 for a third wave per SIMD
 //  it spills 24 of them.)
-template <bool CONV, int K, int ORD>
+// MM (member-major handles, nens > 1; CONV only): ONE launch over the FUSED lanes (lane = (x, member), the coupler's order) reads the
+// coupler's arrays as unit-stride streams, and writes its outputs -- slab rows, y tendencies, face mass fluxes -- into the handle's
+// member-after-member arrays (16-lane segments of nens different members: whole 128-byte lines at nens = 4).  The y direction does not
+// care which lane holds which x cell, so this replaces the separate k_coupler_to_member pass and the members' first k_y_state.
+struct YMember { long long sJ, sK, sV, slab, fyJ, fyK, mfy, nC, tend; int nx; };
+template <bool CONV, int K, int ORD, bool MM = false>
 __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restrict__ S, double *__restrict__ MY,
                                                  unsigned char *__restrict__ UPY, double *__restrict__ tendY, int chunk,
-                                                 CouplerPtrs c, double *__restrict__ Sw) {
+                                                 CouplerPtrs c, double *__restrict__ Sw, YMember mm) {
+  static_assert(!MM || CONV, "the fused-lane form exists for the converting launch only");
   const int NXI = p.nx * p.nens;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
   if (t >= (long long)p.nz * NXI) return;
@@ -340,9 +346,15 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   const double *hp = p.hypk + (long long)(k * p.nens + e) * 8;
   const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
   const double *col = S + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;      // row j at col + (j+HY)*sJ
-  double *fy = MY + (long long)k * p.fyK + ie;                                               // face j at fy + j*fyJ
-  unsigned char *upy = UPY + (long long)k * p.fyK + ie;
-  double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
+  // where the outputs go: the parameter block's own (fused or one-member) layout, or member e's part of a member-major handle
+  const int io = MM ? ie / p.nens : ie;
+  const long long o_fyJ = MM ? mm.fyJ : p.fyJ, o_fyK = MM ? mm.fyK : p.fyK, o_row = MM ? mm.nx : NXI, o_nC = MM ? mm.nC : p.nC;
+  const long long o_sJ = MM ? mm.sJ : p.sJ, o_sK = MM ? mm.sK : p.sK, o_sV = MM ? mm.sV : p.sV;
+  const long long o_x0 = MM ? p.HX + io : (long long)p.HX * p.nens + ie;
+  double *fy = MY + (MM ? e * mm.mfy : 0) + (long long)k * o_fyK + io;                        // face j at fy + j*o_fyJ
+  unsigned char *upy = UPY + (MM ? e * mm.mfy : 0) + (long long)k * o_fyK + io;
+  double *ty = tendY + (MM ? e * mm.tend : 0) + ((long long)k * p.ny) * o_row + io;           // row j at ty + j*o_row (+ l*o_nC)
+  double *Swm = MM ? Sw + e * mm.slab : Sw;
   constexpr int HS = (ORD - 1) / 2;                           // stencil half width; the window holds rows j-HS .. j+HS
   double w[5][ORD], nxt[5], cn[5], fprev[5];
   // CONV: row r (halo rows wrap) comes from the coupler; the rows ja..jb-1 are this chunk's to store.  The row is REQUESTED at the
@@ -353,9 +365,9 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   { double inv_den_;                                                                                                  \
     convert_cell_fast<K>(p, raw, hyr, hyt, p0, out5, inv_den_);   /* (the row's background values are in registers already) */ \
     if ((r) >= ja && (r) < jb) {                                                                                      \
-      double *s_ = Sw + (long long)(k + p.HZ) * p.sK + (long long)((r) + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;  \
-      s_[0] = out5[0]; s_[p.sV] = out5[1]; s_[2 * p.sV] = out5[2]; s_[3 * p.sV] = out5[3]; s_[4 * p.sV] = out5[4];    \
-      convert_cell_tracers<K>(p, raw, inv_den_, s_);                                                                     \
+      double *s_ = Swm + (long long)(k + p.HZ) * o_sK + (long long)((r) + p.HY) * o_sJ + o_x0;                        \
+      s_[0] = out5[0]; s_[o_sV] = out5[1]; s_[2 * o_sV] = out5[2]; s_[3 * o_sV] = out5[3]; s_[4 * o_sV] = out5[4];    \
+      convert_cell_tracers<K>(p, raw, inv_den_, s_, o_sV);                                                               \
     } }
 #pragma unroll
   for (int v = 0; v < 5; v++) { cn[v] = 0; fprev[v] = 0; }
@@ -423,10 +435,10 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
         for (int tr = 0; tr < 4; tr++) if (!Cf<K>::spec || tr < Cf<K>::ntr(p)) landed(raw.tr[tr]);
       }
       else landed(nxt);                                        // the iteration's loads, in front of its stores (see landed())
-      if (face) { fy[(long long)j * p.fyJ] = fs.m_upw; upy[(long long)j * p.fyJ] = (unsigned char)up; }
+      if (face) { fy[(long long)j * o_fyJ] = fs.m_upw; upy[(long long)j * o_fyJ] = (unsigned char)up; }
       if (j > ja) {
 #pragma unroll
-        for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fprev[l]) * p.rdy;
+        for (int l = 0; l < 5; l++) ty[(long long)l * o_nC + (long long)(j - 1) * o_row] = -(f[l] - fprev[l]) * p.rdy;
       }
 #pragma unroll
       for (int l = 0; l < 5; l++) fprev[l] = f[l];
