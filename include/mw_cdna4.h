@@ -217,6 +217,10 @@ long long mw_column_workspace_bytes(const mw_grid_t *g, int num_fields);
 /* modules::sponge_layer(coupler, dt, time_scale = 60), sponge_layer.h:8-77: relax the top 10 levels of every field to the
  * horizontal mean (w to zero).  fields: HOST array of num_fields DEVICE pointers in the reference's MultiField order
  * (density_dry, uvel, vvel, wvel, temp, tracers...).  Horizontal sums are deterministic (no atomics). */
+/* 1: the horizontal sums of mw_sponge_layer / mw_column_average / mw_nudge_to_column are added in the reference's SERIAL order
+ * (j, then i: sponge_layer.h:44-51, column_nudging.h:80-87 on the YAKL serial backend) by one thread per (field, level, member), which
+ * makes the two modules bit-identical to that backend; 0 (default): deterministic fixed-slice tree sums.  Process-wide. */
+int  mw_column_set_strict(int strict);
 int  mw_sponge_layer(const mw_grid_t *g, double *const *fields, int num_fields, double dt, double time_scale, void *workspace,
                      mw_allreduce_fn allreduce, void *ctx, void *stream);
 /* ColumnNudger::get_column_average, column_nudging.h:69-106: state5 = density_dry, uvel, vvel, temp, water_vapor;

@@ -76,6 +76,7 @@ SYMBOLS = {
     "mw_kessler_workspace_bytes": (C.c_longlong, [C.c_int, C.c_longlong]),
     "mw_kessler_set_strict": (C.c_int, [C.c_int]),
     "mw_mlp_set_strict": (C.c_int, [C.c_int]),
+    "mw_column_set_strict": (C.c_int, [C.c_int]),
     "mw_kessler_time_step": (C.c_int, [C.c_int, C.c_longlong, C.c_double, C.c_double] + [C.c_void_p] * 7 +
                              [C.POINTER(C.c_int), C.c_void_p]),
     "mw_h5_read_f32": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_float), C.c_longlong, C.POINTER(C.c_longlong),

@@ -14,7 +14,7 @@
 
 namespace mw {
 
-// cos with the bits of the host's glibc where its main path applies (|x| < 2.4263; mw_glibc_pow.h), else the device library's
+// cos with the bits of the host's glibc (mw_glibc_pow.h; the device library's beyond |x| = 1e8)
 __device__ __forceinline__ double cos_glibc(double x) { double r; if (glibc_cos_main(x, &r)) return r; return cos(x); }
 
 
@@ -38,6 +38,24 @@ __global__ __launch_bounds__(256) void k_hsum_partial(FieldPtrs fp, int nlev, in
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) partial[((long long)(fld * nlev + lev) * nens + e) * S + s] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// STRICT form (mw_column_set_strict(1)): one thread per (field, level, member) adds the level's cells in the reference's serial
+// order (j, then i; sponge_layer.h:44-51, column_nudging.h:80-87 on the serial backend) -- the sums, and with them the two modules,
+// are then bit-identical to the CPU restatement.  Not a performance path (ny * nx dependent additions per thread).
+__global__ __launch_bounds__(64) void k_hsum_serial(FieldPtrs fp, int nlev, int lev0, int dir, long long ncell_lev, int nens, int nf,
+                                                    int skip_field, double *__restrict__ out) {
+#pragma clang fp contract(off)
+  const long long t = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (t >= (long long)nf * nlev * nens) return;
+  const int e = (int)(t % nens);
+  const int lev = (int)((t / nens) % nlev);
+  const int fld = (int)(t / ((long long)nens * nlev));
+  double acc = 0;
+  if (fld != skip_field) {
+    const double *src = fp.f[fld] + (long long)(lev0 + dir * lev) * ncell_lev * nens + e;
+    for (long long c = 0; c < ncell_lev; c++) acc += src[c * nens];
+  }
+  out[t] = acc;
 }
 __global__ __launch_bounds__(256) void k_hsum_finish(const double *__restrict__ partial, long long n, int S, double *__restrict__ out) {
   long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -89,17 +107,27 @@ __global__ __launch_bounds__(256) void k_nudge_apply(FieldPtrs fp, int nz, long 
 
 using namespace mw;
 
+static int g_column_strict = 0;
+// 1: the horizontal sums of sponge_layer / ColumnNudger in the reference's serial order (bit-identical to the serial backend);
+// 0 (default): fixed-slice tree sums.  Process-wide.
+extern "C" int mw_column_set_strict(int strict) { g_column_strict = strict ? 1 : 0; return 0; }
+
 // horizontal sums of `nf` fields over levels lev0, lev0+dir, ... (nlev of them) -> out (nf, nlev, nens), all ranks combined
 static int hsum(const mw_grid_t *g, const FieldPtrs &fp, int nf, int nlev, int lev0, int dir, int skip_field, double *out, double *partial,
                 mw_allreduce_fn ar, void *ctx, hipStream_t st) {
   const long long ncell_lev = (long long)g->ny * g->nx;
   const int S = (int)((ncell_lev + SLICE - 1) / SLICE);
-  dim3 grid((unsigned)S, (unsigned)nlev, (unsigned)(nf * g->nens));
-  hipLaunchKernelGGL(k_hsum_partial, grid, dim3(256), 0, st, fp, nlev, lev0, dir, ncell_lev, g->nens, S, skip_field, partial);
-  MW_LAUNCH_CHECK();
   const long long n = (long long)nf * nlev * g->nens;
-  hipLaunchKernelGGL(k_hsum_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, n, S, out);
-  MW_LAUNCH_CHECK();
+  if (g_column_strict) {
+    hipLaunchKernelGGL(k_hsum_serial, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, fp, nlev, lev0, dir, ncell_lev, g->nens, nf, skip_field, out);
+    MW_LAUNCH_CHECK();
+  } else {
+    dim3 grid((unsigned)S, (unsigned)nlev, (unsigned)(nf * g->nens));
+    hipLaunchKernelGGL(k_hsum_partial, grid, dim3(256), 0, st, fp, nlev, lev0, dir, ncell_lev, g->nens, S, skip_field, partial);
+    MW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_hsum_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, n, S, out);
+    MW_LAUNCH_CHECK();
+  }
   if (ar && g->nproc_x * g->nproc_y > 1) { if (ar(ctx, out, n, st)) MW_FAIL("all-reduce callback failed"); }
   return 0;
 }

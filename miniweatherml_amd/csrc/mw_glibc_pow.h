@@ -132,45 +132,42 @@ MW_GP_HD bool glibc_exp_main(double x, double *res) {
   return true;
 }
 
-// cos(x) with the bits of glibc's cos (sysdeps/ieee754/dbl-64/s_sin.c, the x86-64 FMA build `__cos_fma`), for 2^-27 < |x| < 2.4263
-// except a measure-zero set (below).  |x| < 0.855469: do_cos -- |x| = k/128 + d, cos from the table entry k and short polynomials of
-// d.  0.855469 <= |x| < 2.426265: cos x = sin(pi/2 - |x|) with pi/2 as hp0 + hp1: a Taylor polynomial for |a| < 0.126, else do_sin
-// with the table.  (The initial states' cosine bells -- perturb_temperature.h:63, dynamics_euler_stratified_wenofv.h:1131 -- take
-// arguments in [0, pi/2].)  The polynomial constants are usncs.h's; the table is the library's (mw_glibc_pow_tables.h).
-MW_GP_HD bool glibc_cos_main(double xin, double *res) {
+// cos(x) with the bits of glibc's cos (sysdeps/ieee754/dbl-64/s_sin.c, the x86-64 FMA build `__cos_fma`) for |x| < 105414350:
+//   |x| < 2^-27: 1;   |x| < 0.855469: do_cos -- |x| = k/128 + d, cos from table entry k and short polynomials of d;
+//   |x| < 2.426265: cos x = sin(pi/2 - |x|) with pi/2 as hp0 + hp1;   else reduce_sincos (x = n pi/2 + a + da, four-part pi/2) and
+//   do_cos / do_sin by quadrant.  do_sin: a Taylor polynomial for |a| < 0.126, else the table.
+// (The cosine bells of the initial states -- perturb_temperature.h:63, dynamics_euler_stratified_wenofv.h:1131 -- take arguments in
+// [0, pi/2]; the sponges -- sponge_layer.h:70, horizontal_sponge.h -- in [0, pi].)  The polynomial constants are usncs.h's, the
+// table is the library's (mw_glibc_pow_tables.h).  Larger arguments (the multi-precision reductions) return false.
+MW_GP_HD double gp_do_cos(double a, double da) {                            // do_cos(a, da): a = |.| k/128 + d
 #pragma clang fp contract(off)
   const double sn3 = -0x1.5555555555515p-3, sn5 = 0x1.11110e829872fp-7;
-  const double cs2 = 0.5, cs4 = -0x1.5555555555535p-5, cs6 = 0x1.6c16bedd9e239p-10;
-  const double big = 0x1.8p45;
-  const uint32_t kx = (uint32_t)(gp_bits(xin) >> 32) & 0x7fffffffu;
-  if (kx <= 0x3e3fffffu || kx > 0x400368fcu) return false;                // |x| < 2^-27 (result 1) or the range-reduction paths
-  const double ax = gp_double(gp_bits(xin) & 0x7fffffffffffffffull);
-  if (kx <= 0x3feb5fffu) {                                                // do_cos(|x|, +-0)
-    const double dx = (xin >= 0.0) ? 0.0 : -0.0;
-    const double u = ax + big;
-    const int k = (int)(uint32_t)gp_bits(u) << 2;
-    double d = ax - (u - big);
-    const double cs = gp_sincos_tab[k + 2];
-    d = d + dx;
-    const double xx = d * d;
-    const double ps = __builtin_fma(xx, sn5, sn3);
-    const double x3 = d * xx;
-    const double s = __builtin_fma(x3, ps, d);
-    double pc = __builtin_fma(xx, cs6, cs4);
-    pc = __builtin_fma(xx, pc, cs2);
-    const double c = xx * pc;
-    double cor = __builtin_fma(-s, gp_sincos_tab[k + 1], gp_sincos_tab[k + 3]);      // ccs - s * ssn
-    cor = __builtin_fma(-c, cs, cor);                                                  // ... - cs * c
-    cor = __builtin_fma(-s, gp_sincos_tab[k], cor);                                    // ... - sn * s
-    *res = cs + cor;
-    return true;
-  }
-  const double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
-  const double y = hp0 - ax;
-  const double a = y + hp1;
-  const double da = (y - a) + hp1;
+  const double cs2 = 0.5, cs4 = -0x1.5555555555535p-5, cs6 = 0x1.6c16bedd9e239p-10, big = 0x1.8p45;
   const double aa = gp_double(gp_bits(a) & 0x7fffffffffffffffull);
-  if (aa < 0x1.020c49ba5e354p-3) {                                        // TAYLOR_SIN(a * a, a, da)
+  const double dx = (a < 0.0) ? -da : da;
+  const double u = aa + big;
+  const int k = (int)(uint32_t)gp_bits(u) << 2;
+  double d = aa - (u - big);
+  const double cs = gp_sincos_tab[k + 2];
+  d = d + dx;
+  const double xx = d * d;
+  const double ps = __builtin_fma(xx, sn5, sn3);
+  const double x3 = d * xx;
+  const double s = __builtin_fma(x3, ps, d);
+  double pc = __builtin_fma(xx, cs6, cs4);
+  pc = __builtin_fma(xx, pc, cs2);
+  const double c = xx * pc;
+  double cor = __builtin_fma(-s, gp_sincos_tab[k + 1], gp_sincos_tab[k + 3]);        // ccs - s * ssn
+  cor = __builtin_fma(-c, cs, cor);                                                    // ... - cs * c
+  cor = __builtin_fma(-s, gp_sincos_tab[k], cor);                                      // ... - sn * s
+  return cs + cor;
+}
+MW_GP_HD double gp_do_sin(double a, double da) {                            // sin(a + da): TAYLOR_SIN for |a| < 0.126, else do_sin
+#pragma clang fp contract(off)
+  const double sn3 = -0x1.5555555555515p-3, sn5 = 0x1.11110e829872fp-7;
+  const double cs2 = 0.5, cs4 = -0x1.5555555555535p-5, cs6 = 0x1.6c16bedd9e239p-10, big = 0x1.8p45;
+  const double aa = gp_double(gp_bits(a) & 0x7fffffffffffffffull);
+  if (aa < 0x1.020c49ba5e354p-3) {
     const double s1 = -0x1.5555555555555p-3, s2 = 0x1.1111111110ecep-7, s3 = -0x1.a01a019db08b8p-13, s4 = 0x1.71de27b9a7ed9p-19,
                  s5 = -0x1.addffc2fcdf59p-26;
     const double xx = a * a;
@@ -181,10 +178,9 @@ MW_GP_HD bool glibc_cos_main(double xin, double *res) {
     const double hd = da * cs2;
     t = __builtin_fma(t, a, -hd);
     const double r = __builtin_fma(xx, t, da);
-    *res = a + r;
-    return true;
+    return a + r;
   }
-  if (!(a > 0.0)) return false;                                           // (a <= 0: |x| at or beyond pi/2 -- the mirrored form; not restated)
+  if (!(0.0 < a)) da = -da;
   const double u = aa + big;
   const int k = (int)(uint32_t)gp_bits(u) << 2;
   const double x = aa - (u - big);
@@ -202,7 +198,41 @@ MW_GP_HD bool glibc_cos_main(double xin, double *res) {
   cor = __builtin_fma(-c, sn, cor);                                                    // ... - sn * c
   const double t = __builtin_fma(s, gp_sincos_tab[k + 2], cor);                       // cs * s + cor
   const double r = sn + t;
-  *res = gp_double((gp_bits(r) & 0x7fffffffffffffffull) | (gp_bits(a) & 0x8000000000000000ull));
+  return gp_double((gp_bits(r) & 0x7fffffffffffffffull) | (gp_bits(a) & 0x8000000000000000ull));
+}
+MW_GP_HD bool glibc_cos_main(double xin, double *res) {
+#pragma clang fp contract(off)
+  const uint32_t kx = (uint32_t)(gp_bits(xin) >> 32) & 0x7fffffffu;
+  if (kx > 0x419921fau) return false;                                     // |x| >= 105414350 (or inf / nan): the multi-precision reductions
+  if (kx <= 0x3e3fffffu) { *res = 1.0; return true; }                     // |x| < 2^-27
+  const double ax = gp_double(gp_bits(xin) & 0x7fffffffffffffffull);
+  if (kx <= 0x3feb5fffu) { *res = gp_do_cos(ax, (xin >= 0.0) ? 0.0 : -0.0); return true; }
+  if (kx <= 0x400368fcu) {                                                // cos x = sin(pi/2 - |x|)
+    const double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+    const double y = hp0 - ax;
+    const double a = y + hp1;
+    const double da = (y - a) + hp1;
+    *res = gp_do_sin(a, da);
+    return true;
+  }
+  // reduce_sincos: x = n pi/2 + a + da, pi/2 = mp1 + mp2 + pp3 + pp4
+  const double hpinv = 0x1.45f306dc9c883p-1, toint = 0x1.8p52;
+  const double mp1 = 0x1.921fb58000000p+0, mp2 = -0x1.dde973c000000p-27, pp3 = -0x1.cb3b398000000p-55, pp4 = -0x1.d747f23e32ed7p-83;
+  const double t = __builtin_fma(xin, hpinv, toint);
+  const double xn = t - toint;
+  const int n = (int)(gp_bits(t) & 3);
+  double y = __builtin_fma(-xn, mp1, xin);
+  y = __builtin_fma(-xn, mp2, y);
+  const double t2 = __builtin_fma(-xn, pp3, y);
+  double db = y - t2;
+  db = __builtin_fma(-pp3, xn, db);
+  const double a = __builtin_fma(-xn, pp4, t2);
+  double e = t2 - a;
+  e = __builtin_fma(-xn, pp4, e);
+  const double da = db + e;
+  const int m = n + 1;
+  const double r = (m & 1) ? gp_do_cos(a, da) : gp_do_sin(a, da);
+  *res = (m & 2) ? -r : r;
   return true;
 }
 

@@ -395,6 +395,12 @@ def _column_ws(coupler, nf, holder):
     return ws
 
 
+def set_column_strict(strict):
+    """1: sponge_layer / ColumnNudger add their horizontal sums in the reference's serial order (bit-identical to the CPU restatement);
+    0: the deterministic tree sums (default).  Process-wide (mw_column_set_strict)."""
+    check(capi.lib().mw_column_set_strict(int(bool(strict))))
+
+
 def sponge_layer(coupler, dt, time_scale=60.0):
     """modules::sponge_layer(coupler, dt, time_scale), model/modules/sponge_layer.h:8-77."""
     dm = coupler.get_data_manager_readwrite()

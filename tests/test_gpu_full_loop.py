@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import compare_fields, gpu_fields, oracle_sensitivity, push_fields
+from util import compare_fields, gpu_fields, host_libm_matches_restatement, oracle_sensitivity, push_fields
 
 pytestmark = pytest.mark.gpu
 
@@ -42,6 +42,38 @@ def test_full_supercell_loop(mw, oracle, shape):
         modules.supercell_step(coupler, dycore, micro, nudger, dt)
         oracle_step(oracle, dyc, f, nud, dt, precl)
     compare_fields(gpu_fields(coupler), f.as_dict(), 1e-10, "full loop %s" % (shape,))
+
+
+@pytest.mark.parametrize("shape", [(24, 20, 16, 1), (64, 1, 24, 1), (12, 10, 12, 2)])
+def test_strict_full_supercell_loop_is_bit_identical_to_the_oracle(mw, oracle, shape):
+    """The COMPLETE time loop of supercell_example (driver.cpp:66-79: dycore -> Kessler -> sponge_layer -> ColumnNudger) in its strict
+    forms -- reference operation order everywhere, glibc's pow / exp / cos (csrc/mw_glibc_pow.h), the horizontal sums in the serial
+    backend's order -- against the oracle's loop: every field bit for bit after 1, 5 and 20 steps, 3-D, 2-D and two members, with the
+    set-up (init, the nudger's column, perturb_temperature) made on the device."""
+    from miniweatherml_amd import modules
+    nx, ny, nz, nens = shape
+    xlen, ylen = 500.0 * nx, (500.0 * ny if ny > 1 else 1.0e5)
+    modules.set_column_strict(1)
+    try:
+        coupler, dycore, micro, nudger = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000., with_nudger=True)
+        dyc, f, nud = oracle_loop_setup(oracle, nx, ny, nz, nens, xlen, ylen, 20000.)
+        if host_libm_matches_restatement():
+            assert np.array_equal(nudger.column.cpu().numpy().ravel(), np.asarray(nud.column).ravel())
+        compare_fields(gpu_fields(coupler), f.as_dict(), 0.0, "full loop set-up %s strict mode 1" % (shape,))     # no push: the device's own state
+        dycore.set_strict(1)
+        micro.set_strict(1)
+        dt = dycore.compute_time_step(coupler)
+        precl = np.zeros((ny, nx, nens))
+        for step in range(1, 21):
+            modules.supercell_step(coupler, dycore, micro, nudger, dt)
+            oracle_step(oracle, dyc, f, nud, dt, precl)
+            if step in (1, 5, 20):
+                compare_fields(gpu_fields(coupler), f.as_dict(), 0.0, "full loop %s strict mode 1, %d steps" % (shape, step))
+    finally:
+        modules.set_column_strict(0)
+        modules.Microphysics_Kessler().set_strict(0)
+        from miniweatherml_amd import capi
+        capi.check(capi.lib().mw_kessler_set_strict(0))
 
 
 def test_sponge_layer_alone(mw, oracle):
