@@ -925,6 +925,7 @@ struct mw_dycore_s {
   std::vector<double> hy_host;               // same packing (the last four are derived in upload_background)
   double etime = 0;
   int strict = 0;
+  int mm_direct = 0;                         // ... and D13 written from the last stage's kernels (MemberOff: 2 or 4 members per workgroup, WENO-5), no k_member_to_coupler pass
   int member_major = 0;                      // production path with nens > 1: the handle's arrays hold one member after the other (View)
   int ord = 5;                               // WENO order (3, 7, 9: the reference's -DMW_ORD builds; they run on the general kernels)
   int hxw = HXc, hzw = HZc;                  // halo widths of the slabs: hs + 1 in x / y, hs in z (3 / 2 up to order 5)
@@ -1066,6 +1067,16 @@ static View view(const mw_dycore_s *d, int e) {
   v.m[0] = q.fxV; v.m[1] = q.fyV; v.m[2] = q.fzV;
   v.f[0] = (long long)q.V * q.fxV; v.f[1] = (long long)q.V * q.fyV; v.f[2] = (long long)q.V * q.fzV;
   return v;
+}
+
+// the member-to-member strides of a member-major handle, for the member-transposing kernels (MemberOff, mw_march.h)
+static MemberOff member_off(const mw_dycore_s *d) {
+  const View v = view(d, 0);
+  MemberOff mo;
+  mo.slab = v.slab; mo.tend = v.tend; mo.mx = v.m[0]; mo.my = v.m[1]; mo.mz = v.m[2]; mo.fx = v.f[0]; mo.fy = v.f[1]; mo.fz = v.f[2];
+  mo.cells = v.cells; mo.per = 4 * (long long)v.p.nz + 8 * (long long)(v.p.nz + 1);
+  mo.n = d->p.nens; mo.sh = d->p.nens == 4 ? 2 : 1;
+  return mo;
 }
 
 // halo fill of variables [v0, v0+nv) of one slab: neighbour exchange (or self wrap) in x/y, then BCs -- replaces
@@ -1236,10 +1247,19 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     const long long mthreads = (long long)p.nz * p.nx;                                   // one member's: the chunk rule of the per-member launches
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (mthreads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
-    const YMember mm = {v0.p.sJ, v0.p.sK, v0.p.sV, v0.slab, v0.p.fyJ, v0.p.fyK, v0.m[1], v0.p.nC, v0.tend, p.nx};
+    const MemberOff mo = member_off(d);
+    const YMember mm = {v0.p.sJ, v0.p.sK, v0.p.sV, v0.slab, v0.p.fyJ, v0.p.fyK, v0.m[1], v0.p.nC, v0.tend, p.nx, mo.per, mo.n, mo.sh};
     double *Sw = const_cast<double *>(S);
-#define MW_YSM(K_, O_) hipLaunchKernelGGL((k_y_state<true, K_, O_, true>), grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
     const int K = marching_config(v0.p);
+    if (d->mm_direct && d->ord == 5 && !getenv("MW_NO_MM_CONV")) {      // the members of the same cells in one workgroup (k_y_state<.., MM = 2>)
+      grid.x = (unsigned)((mthreads + 64 * (4 / mo.n) - 1) / (64 * (4 / mo.n)));
+#define MW_YSM2(K_) hipLaunchKernelGGL((k_y_state<true, K_, 5, 2>), grid, dim3(256), 0, d->stream, v0.p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
+      if (K == 1) MW_YSM2(1); else if (K == 2) MW_YSM2(2); else MW_YSM2(0);
+#undef MW_YSM2
+      MW_LAUNCH_CHECK();
+      return 0;
+    }
+#define MW_YSM(K_, O_) hipLaunchKernelGGL((k_y_state<true, K_, O_, 1>), grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
     if (d->ord == 3) { if (K == 1) MW_YSM(1, 3); else if (K == 2) MW_YSM(2, 3); else MW_YSM(0, 3); }
     else             { if (K == 1) MW_YSM(1, 5); else if (K == 2) MW_YSM(2, 5); else MW_YSM(0, 5); }
 #undef MW_YSM
@@ -1310,6 +1330,24 @@ template <int STAGE, int MODE>
 static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn, int par,
                            const CouplerPtrs &c) {
   ProfScope ps(d, 0);
+  if constexpr (STAGE == 3 && MODE == 1) {
+    if (d->mm_direct) {                                         // all members in one launch: workgroup = the nens members of 4 / nens tiles
+      const View v = view(d, 0);
+      const DyP &p = v.p;
+      dim3 grid; int chunk, tiles_x;
+      if (xz_grid(d, p, grid, chunk, tiles_x)) return 1;
+      const MemberOff mo = member_off(d);
+      const int wpb = 4 / mo.n;
+      grid.x = (unsigned)(((long long)p.ny * tiles_x + wpb - 1) / wpb);
+      const size_t lds = (size_t)(chunk + 2) * 64 * 4;
+#define MW_XZ_MT(K_) hipLaunchKernelGGL((k_xz_state<3, true, 1, 1, K_, 5, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
+                                        d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo)
+      if (marching_config(p) == 1) { MW_XZ_MT(1); } else { MW_XZ_MT(0); }
+#undef MW_XZ_MT
+      MW_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   for (int e = 0; e < n_views(d); e++) {
     const View v = view(d, e);
     const DyP &p = v.p;
@@ -1320,7 +1358,7 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
     // nens == 1 (also: one member of a member-major handle): the per-level background values come through LDS
     // (k_xz_state<.., HPL = 1>; dynamic LDS = the chunk's rows)
 #define MW_XZ(N1_, HPL_, K_, O_, lds) hipLaunchKernelGGL((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), grid, dim3(256), lds, d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
-                                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
+                                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, MemberOff())
 #define MW_XZ_K(K_) { if (d->ord == 3) MW_XZ(true, 1, K_, 3, hpl_bytes); else MW_XZ(true, 1, K_, 5, hpl_bytes); }
     const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
     if (p.nens == 1) {
@@ -1385,7 +1423,7 @@ static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *
   const int e = v.e;
   hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1, K, ORD>), grid, dim3(256), fused_bg_bytes(MODE, chunk, v.p.nens), st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
                      d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
-                     d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4);
+                     d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4, MemberOff());
 }
 // x/z tracer fluxes + FCT + update in one kernel, then the (normally empty) y-face correction
 template <int STAGE, int MODE>
@@ -1393,7 +1431,25 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
                                 const CouplerPtrs &c, hipStream_t st) {
   {
     ProfScope ps(d, 7, st);
-    for (int e = 0; e < n_views(d); e++) {
+    bool direct = false;
+    if constexpr (STAGE == 3 && MODE == 1) direct = d->mm_direct;
+    if constexpr (STAGE == 3 && MODE == 1) if (direct) {            // all members in one launch (MemberOff): workgroup = nens members x 4 / nens rows of a tile
+      const View v = view(d, 0);
+      const DyP &p = v.p;
+      const MemberOff mo = member_off(d);
+      const int U = 64 - 2 * 3, tiles_x = (p.nx + U - 1) / U, rpb = 4 / mo.n;
+      const long long waves = (long long)p.ny * tiles_x;
+      const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F", 10000, 2, 4.5, true));
+      dim3 grid((unsigned)(((p.ny + rpb - 1) / rpb) * tiles_x), (unsigned)((p.nz + chunk - 1) / chunk));
+      const size_t lds = (size_t)(chunk + 4) * 24 * 4;
+      if (lds > 60000) MW_FAIL("fused tracer stage: chunk too large for its LDS table (use a smaller MW_CHUNK_F)");
+#define MW_FUSED_MT(TT) case TT: hipLaunchKernelGGL((k_tracers_fused<3, 1, TT, true, 0, 5, true>), grid, dim3(256), lds, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
+                                 d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo); break;
+      switch (p.nt) { MW_FUSED_MT(1) MW_FUSED_MT(2) MW_FUSED_MT(3) MW_FUSED_MT(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
+#undef MW_FUSED_MT
+      MW_LAUNCH_CHECK();
+    }
+    for (int e = 0; e < (direct ? 0 : n_views(d)); e++) {
       const View v = view(d, e);
       const DyP &p = v.p;
       const int U = p.nens == 1 ? 64 - 2 * ((d->ord - 1) / 2 + 1) : 64 - 4 * p.nens;   // hs + 1 / 2 halo cells per side (k_tracers_fused)
@@ -1485,9 +1541,10 @@ static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, 
   const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
   if (rk_stage_march<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;                        // stage 1 (:119-132)
   if (rk_stage_march<2, 0>(d, Q[1], Q[0], Q[2], dt2, dt_dyn, c)) return 1;                           // stage 2 (:136-153)
-  if (last && !d->member_major) { if (rk_stage_march<3, 1>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }   // stage 3 (:157-174) + :178
-  else                          { if (rk_stage_march<3, 0>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }
-  if (last && d->member_major) {                              // D13 (:178) as one coalesced pass over the result slab
+  const bool pass13 = d->member_major && !d->mm_direct;        // D13 as a pass over the result slab
+  if (last && !pass13) { if (rk_stage_march<3, 1>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }   // stage 3 (:157-174) + :178
+  else                 { if (rk_stage_march<3, 0>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }
+  if (last && pass13) {                              // D13 (:178) as one coalesced pass over the result slab
     hipStream_t ts = d->overlap ? d->tstream : d->stream;     // the tracer pipeline finishes the stage
     ProfScope ps(d, 4, ts);
     const View v = view(d, 0);
@@ -1799,6 +1856,9 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   //  meet in L2: they do not.  27.3 ms per step with the two coalesced conversion passes; 33.2 with D13 inside the member launches
   //  (k_tracers_fused 7.6 -> 12.0 ms, k_xz_state 9.4 -> 11.7), 30.3 with D1 inside (k_y_state 3.8 -> 7.7), 34.3 with both.)
   d->member_major = march && d->fused && p.nens > 1 && !getenv("MW_NO_MEMBER_MAJOR");
+  // ... with D13 written by the last stage's kernels themselves and D1 read by the first k_y_state, the members of a tile in one
+  // workgroup so that their quarter-sector accesses meet in L1 / L2 (MemberOff, mw_march.h): 2 or 4 members, WENO-5
+  d->mm_direct = d->member_major && (p.nens == 2 || p.nens == 4) && d->ord == 5 && !getenv("MW_NO_MM_DIRECT");
   // D1 + D2 (:101, :248-255).  Production path with periodic x and y owned by this rank (either schedule: the tracer stream waits
   // for the stage's state kernels anyway): done inside the first k_y_state (no separate pass); otherwise a conversion kernel first
   // (the reference's operation order on the general path).

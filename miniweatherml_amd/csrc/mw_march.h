@@ -329,14 +329,22 @@ __global__ __launch_bounds__(256) void k_member_to_coupler(DyP p, const double *
 // coupler's arrays as unit-stride streams, and writes its outputs -- slab rows, y tendencies, face mass fluxes -- into the handle's
 // member-after-member arrays (16-lane segments of nens different members: whole 128-byte lines at nens = 4).  The y direction does not
 // care which lane holds which x cell, so this replaces the separate k_coupler_to_member pass and the members' first k_y_state.
-struct YMember { long long sJ, sK, sV, slab, fyJ, fyK, mfy, nC, tend; int nx; };
-template <bool CONV, int K, int ORD, bool MM = false>
+// MM = 2 (2 or 4 members): the per-member form of the launch -- wave = one member's 64 x cells, coalesced stores into that member's
+// arrays -- with the nens members of the same cells in ONE workgroup: their 8-byte reads of the coupler's member-fastest arrays, nens
+// doubles apart, then meet in the CU's L1 / the XCD's L2 (the same idea as MemberOff below for the way out).
+struct YMember { long long sJ, sK, sV, slab, fyJ, fyK, mfy, nC, tend; int nx; long long per; int n, sh; };
+template <bool CONV, int K, int ORD, int MM = 0>
 __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restrict__ S, double *__restrict__ MY,
                                                  unsigned char *__restrict__ UPY, double *__restrict__ tendY, int chunk,
                                                  CouplerPtrs c, double *__restrict__ Sw, YMember mm) {
   static_assert(!MM || CONV, "the fused-lane form exists for the converting launch only");
   const int NXI = p.nx * p.nens;
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
+  if (MM == 2) {                                                 // (p = one member's view: nens = 1, cst = the member count)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), em = wv & (mm.n - 1);
+    t = ((long long)blockIdx.x * (4 >> mm.sh) + (wv >> mm.sh)) * 64 + (threadIdx.x & 63);
+    MY += em * mm.mfy; UPY += em * mm.mfy; tendY += em * mm.tend; Sw += em * mm.slab; S += em * mm.slab; p.hypk += em * mm.per; p.ce = em;
+  }
   if (t >= (long long)p.nz * NXI) return;
   const int k = (int)(t / NXI);
   const int ie = (int)(t - (long long)k * NXI);
@@ -347,14 +355,14 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
   const double *col = S + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;      // row j at col + (j+HY)*sJ
   // where the outputs go: the parameter block's own (fused or one-member) layout, or member e's part of a member-major handle
-  const int io = MM ? ie / p.nens : ie;
-  const long long o_fyJ = MM ? mm.fyJ : p.fyJ, o_fyK = MM ? mm.fyK : p.fyK, o_row = MM ? mm.nx : NXI, o_nC = MM ? mm.nC : p.nC;
-  const long long o_sJ = MM ? mm.sJ : p.sJ, o_sK = MM ? mm.sK : p.sK, o_sV = MM ? mm.sV : p.sV;
-  const long long o_x0 = MM ? p.HX + io : (long long)p.HX * p.nens + ie;
-  double *fy = MY + (MM ? e * mm.mfy : 0) + (long long)k * o_fyK + io;                        // face j at fy + j*o_fyJ
-  unsigned char *upy = UPY + (MM ? e * mm.mfy : 0) + (long long)k * o_fyK + io;
-  double *ty = tendY + (MM ? e * mm.tend : 0) + ((long long)k * p.ny) * o_row + io;           // row j at ty + j*o_row (+ l*o_nC)
-  double *Swm = MM ? Sw + e * mm.slab : Sw;
+  const int io = MM == 1 ? ie / p.nens : ie;
+  const long long o_fyJ = MM == 1 ? mm.fyJ : p.fyJ, o_fyK = MM == 1 ? mm.fyK : p.fyK, o_row = MM == 1 ? mm.nx : NXI, o_nC = MM == 1 ? mm.nC : p.nC;
+  const long long o_sJ = MM == 1 ? mm.sJ : p.sJ, o_sK = MM == 1 ? mm.sK : p.sK, o_sV = MM == 1 ? mm.sV : p.sV;
+  const long long o_x0 = MM == 1 ? p.HX + io : (long long)p.HX * p.nens + ie;
+  double *fy = MY + (MM == 1 ? e * mm.mfy : 0) + (long long)k * o_fyK + io;                        // face j at fy + j*o_fyJ
+  unsigned char *upy = UPY + (MM == 1 ? e * mm.mfy : 0) + (long long)k * o_fyK + io;
+  double *ty = tendY + (MM == 1 ? e * mm.tend : 0) + ((long long)k * p.ny) * o_row + io;           // row j at ty + j*o_row (+ l*o_nC)
+  double *Swm = MM == 1 ? Sw + e * mm.slab : Sw;
   constexpr int HS = (ORD - 1) / 2;                           // stencil half width; the window holds rows j-HS .. j+HS
   double w[5][ORD], nxt[5], cn[5], fprev[5];
   // CONV: row r (halo rows wrap) comes from the coupler; the rows ja..jb-1 are this chunk's to store.  The row is REQUESTED at the
@@ -565,7 +573,7 @@ struct XzGeom {
 //  the wave: 58 cells per wave for WENO-5, 60 for WENO-3)
 __host__ __device__ __forceinline__ int xz_cells_per_wave(int nens, int ord = 5) { return nens == 1 ? 64 - 2 * ((ord - 1) / 2 + 1) : 64 - 2 * nens; }
 template <bool N1, int ORD = 5>
-__device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, int rows4 = 0) {
+__device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, int rows4 = 0, int wslot = -1, int wpb = 4) {
   static_assert(N1 || ORD == 5, "the neighbour-load form (nens > 1 in the fused layout) exists for WENO-5 only");
   constexpr int HS = (ORD - 1) / 2;
   XzGeom g;
@@ -576,7 +584,8 @@ __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, 
   const int U = 64 - 2 * hw * g.n;                            // cells (fused) a wave completes
   g.cell_lo = hw * g.n; g.cell_hi = 64 - hw * g.n; g.face_hi = N1 ? 64 - HS * g.n : 64;
   const BlockXY blk = xcd_block();
-  const long long wid = (long long)blk.x * 4 + (threadIdx.x >> 6);           // wave id -> (row j, x tile)
+  // (wslot / wpb: a block of the member-transposing form holds the nens members of 4 / nens tiles -- MemberOff below)
+  const long long wid = (long long)blk.x * wpb + (wslot < 0 ? (int)(threadIdx.x >> 6) : wslot);   // wave id -> (row j, x tile)
   int tx;
   if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); g.j = jg * 4 + (threadIdx.x >> 6); }
   else       { g.j = (int)(wid / tiles_x); tx = (int)(wid - (long long)g.j * tiles_x); }
@@ -607,28 +616,55 @@ __device__ __forceinline__ void x_neighbours(double c0, const double *__restrict
   } else { m2 = lvl[om2]; m1 = lvl[om1]; p1 = lvl[op1]; p2 = lvl[op2]; }
 }
 
+// Member-co-located form (MT) of the two kernels that write the coupler's arrays in the last stage of a time step (D13), for a
+// member-major handle with 2 or 4 members.  The coupler keeps the ensemble index fastest, a marching wave holds ONE member's x row:
+// its D13 values go out as 8-byte stores nens doubles apart.  Issued from one launch per member those quarter sectors never met in
+// L2 (measured, round 3: +20 % step time).  Here ONE launch holds all members and a workgroup = the nens members of the same tile
+// (wave w = member w % nens of tile slot w / nens): the members' stores to a line leave the same CU within a level or two of each
+// other and are merged in the XCD's L2 before the line is written back.  That replaces the k_member_to_coupler pass (8 doubles
+// read + 8 written per cell and time step): config 4's block 26.5 -> 25.5 ms with the same treatment of D1 (k_y_state<.., MM = 2>).
+// Everything per member -- slabs, face arrays, background tables -- is one stride away.
+// (Also measured: the level's values transposed through LDS, one s_barrier per level, 64 consecutive doubles stored per wave --
+//  fully coalesced, and SLOWER than the pass it replaces: k_tracers_fused<3, 1> 3.7 instead of 3.3 ms, k_xz_state<3, 1> +0.5 ms;
+//  the lock step costs more than the quarter-sector stores.)
+struct MemberOff {
+  long long slab, tend, mx, my, mz, fx, fy, fz, cells, per;    // doubles (selectors / flags: bytes) from member e to member e + 1
+  int n, sh;                                                   // members per workgroup (2 or 4) and log2 of it
+};
+
 // MODE 1 (last stage of the last cycle): u, v, w also go to the coupler's arrays (D13, :1929-1932: the slab holds (rho u)/rho
 // already), so that the tracer stage, which finishes D13, neither re-reads nor re-writes them.
-template <int STAGE, bool N1, int MODE, int HPL, int K, int ORD>
+template <int STAGE, bool N1, int MODE, int HPL, int K, int ORD, bool MT = false>
 __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
                                                   double *__restrict__ Sout, double *__restrict__ MX, double *__restrict__ MZ,
                                                   unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                   const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
-                                                  int tiles_x, double *__restrict__ cu, double *__restrict__ cv, double *__restrict__ cw) {
+                                                  int tiles_x, double *__restrict__ cu, double *__restrict__ cv, double *__restrict__ cw,
+                                                  MemberOff mo) {
+  static_assert(!MT || (N1 && HPL && MODE == 1), "the member-co-located form is the D13 variant of the nens == 1 kernel");
   constexpr int HS = (ORD - 1) / 2;
-  const XzGeom g = xz_geom<N1, ORD>(p, chunk, tiles_x);
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int mt_e = 0, mt_sub = 0;
+  if (MT) {
+    mt_e = wv & (mo.n - 1); mt_sub = wv >> mo.sh;
+    S += mt_e * mo.slab; Sn += mt_e * mo.slab; Sout += mt_e * mo.slab; MX += mt_e * mo.mx; UPX += mt_e * mo.mx; MZ += mt_e * mo.mz; UPZ += mt_e * mo.mz;
+    tendY += mt_e * mo.tend; p.hypk += mt_e * mo.per; p.ce = mt_e;
+  }
+  const XzGeom g = xz_geom<N1, ORD>(p, chunk, tiles_x, 0, MT ? mt_sub : -1, MT ? 4 >> mo.sh : 4);
   // HPL (nens == 1): the eight background values of every level of this chunk (DyP::hypk rows kstart..kb) are copied to LDS once
   // and read from there (a broadcast read, issued with the iteration's other loads).  Read as scalar loads they were placed right
   // in front of their first use -- the kernel has no spare SGPRs to hold them any earlier -- and their latency was exposed three
   // times per level (-1 % kernel time).  All 256 threads copy, also those of waves beyond the last row, which leave right after.
-  extern __shared__ double lds_hp[];
+  extern __shared__ double lds_hp_all[];
+  double *lds_hp = lds_hp_all + (MT ? wv * (chunk + 2) * 8 : 0);     // (MT: one table per wave -- the members' backgrounds differ)
   // ... and so do the few uniform doubles of the finalisation (grid spacings, the stage's time-step factors, gravity): as kernel
   // arguments they occupy 12 SGPRs for the whole loop in a kernel that spills SGPRs to VGPR lanes (every spilled one comes back as a
   // v_readlane, a VALU instruction); as broadcast LDS reads they are VGPR operands where they are used.
   __shared__ double lds_c[8];
   if (HPL) {
     const int nrow = g.kb - g.kstart + 1;
-    for (int i = threadIdx.x; i < nrow * 8; i += 256) lds_hp[i] = p.hypk[(long long)g.kstart * 8 + i];     // (nens == 1: row k at k*8)
+    if (MT) { for (int i = g.lane; i < nrow * 8; i += 64) lds_hp[i] = p.hypk[(long long)g.kstart * 8 + i]; }
+    else for (int i = threadIdx.x; i < nrow * 8; i += 256) lds_hp[i] = p.hypk[(long long)g.kstart * 8 + i];     // (nens == 1: row k at k*8)
     if (threadIdx.x < 8) {
       const double cdt = (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;
       lds_c[threadIdx.x] = threadIdx.x == 0 ? p.rdx : threadIdx.x == 1 ? p.rdz : threadIdx.x == 2 ? cdt : threadIdx.x == 3 ? -p.grav : 0.0;
@@ -1044,15 +1080,24 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
 //   reconstructions at k = ka-2 and kb+1, S2 / S3 before their first cell -- save 1 % at run time but cost 30-40 VGPRs (spills in
 //   the MODE 1 variant) and the kernel as a whole became 15 % slower.  The loop body stays branch-free.)
 // ---------------------------------------------------------------------------------------------------------------
-template <int STAGE, int MODE, int T, bool N1, int K, int ORD>
+template <int STAGE, int MODE, int T, bool N1, int K, int ORD, bool MT = false>
 __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *__restrict__ S, const double *__restrict__ Sn, double *Sout,
                                                        const double *__restrict__ FY, const double *__restrict__ MX,
                                                        const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
                                                        const unsigned char *__restrict__ UPZ, double *__restrict__ DS,
                                                        double *__restrict__ DN, unsigned char *__restrict__ flags, unsigned int *__restrict__ dirty,
-                                                       double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4) {
+                                                       double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4, MemberOff mo) {
   static_assert(N1 || ORD == 5, "the neighbour-load form exists for WENO-5 only");
+  static_assert(!MT || (N1 && MODE == 1), "the member-co-located form (see MemberOff) is the D13 variant of the nens == 1 kernel");
   constexpr int HS = (ORD - 1) / 2;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int mt_e = 0, mt_sub = 0;
+  if (MT) {                                                    // wave = member mt_e of tile slot mt_sub: everything per member is one stride away
+    mt_e = wv & (mo.n - 1); mt_sub = wv >> mo.sh;
+    S += mt_e * mo.slab; Sn += mt_e * mo.slab; Sout += mt_e * mo.slab; FY += mt_e * mo.fy; MX += mt_e * mo.mx; UPX += mt_e * mo.mx;
+    MZ += mt_e * mo.mz; UPZ += mt_e * mo.mz; DS += mt_e * mo.fx; DN += mt_e * mo.fz; flags += mt_e * mo.cells;
+    p.hyc += mt_e * mo.per; p.hytc += mt_e * mo.per; p.p0c += mt_e * mo.per; p.ihytc += mt_e * mo.per; p.ce = mt_e;
+  }
   const int n = N1 ? 1 : p.nens;
   constexpr int t0 = 0;                                       // one group: all (<= 4) tracers of the cell
   constexpr bool MW_FENCED = Cf<K>::spec;                     // (see MW_SCHED_FENCE)
@@ -1066,12 +1111,14 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const int U = 64 - 2 * hw * n;
   int j, tx;
   const BlockXY blk = xcd_block();
-  if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
-  else       { const long long wid = (long long)blk.x * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
+  if (MT)         { const int rpb = 4 >> mo.sh, jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); j = jg * rpb + mt_sub; }   // rows of one tile
+  else if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
+  else            { const long long wid = (long long)blk.x * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
   // MODE 1: D13's three background values (hytc, p0c, ihytc) of the levels this block finishes go through LDS.  As global loads
   // they sat behind the tracer stores, each waited for at once -- and a vmcnt wait behind a store waits for the store (see landed());
   // requested at the top of the iteration they cost 6 VGPRs the kernel does not have.  (dynamic LDS: (chunk + 4) * nens * 3 doubles)
-  extern __shared__ double lds_bg[];
+  extern __shared__ double lds_bg_all[];
+  double *lds_bg = lds_bg_all + (MT ? wv * (chunk + 4) * 3 : 0);      // (MT: one table per wave -- the members' backgrounds differ)
   const int bg_l0 = max((int)blk.y * chunk - 4, 0);
   // the uniform doubles of the loop (reciprocal grid spacings, time-step factors) as broadcast LDS reads instead of resident SGPRs
   // (as in k_xz_state: the kernel spills SGPRs to VGPR lanes)
@@ -1085,7 +1132,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   if (LC) __syncthreads();
   if (MODE == 1) {
     const int cnt = (min((int)blk.y * chunk + chunk, p.nz) - bg_l0) * p.nens;
-    for (int i3 = threadIdx.x; i3 < cnt * 3; i3 += 256) {
+    for (int i3 = MT ? lane : (int)threadIdx.x; i3 < cnt * 3; i3 += MT ? 64 : 256) {
       const int i = i3 / 3, f = i3 - i * 3;
       lds_bg[i3] = (f == 0 ? p.hytc : f == 1 ? p.p0c : p.ihytc)[bg_l0 * p.nens + i];
     }
@@ -1123,6 +1170,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   double fxp[T], fzp[T], multp[T], szf[T], P[T];
   double wkm2[T];                                             // WENO-3: level k-2 has left the 3-level window and is carried instead
   double rhos2 = 0;
+
 #pragma unroll
   for (int v = 0; v < T; v++) {
     ct[v] = 0; fxp[v] = fzp[v] = szf[v] = P[v] = 0; multp[v] = 1; wkm2[v] = 0;

@@ -251,3 +251,49 @@ def test_member_major_layout_agrees_with_the_member_fastest_kernels(mw, monkeypa
         assert float((out[0][n] - out[1][n]).abs().max()) <= 1e-12 * scale + floor, n
     a = out[0]["temp"]
     assert not torch.equal(a[..., 0], a[..., 1])
+
+
+@pytest.mark.parametrize("nens,nx,ny,nz", [(4, 70, 45, 26), (2, 131, 9, 26), (4, 24, 6, 12), (2, 58, 4, 14)])
+def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracle(mw, oracle, monkeypatch, nens, nx, ny, nz):
+    """Member-major handles with 2 or 4 members read D1 in the first k_y_state and write D13 from the last stage's kernels, with the
+    members of the same cells in ONE workgroup (MemberOff / k_y_state<.., MM = 2>, mw_march.h) so that their accesses to the coupler's
+    member-fastest arrays meet in L1 / L2.  MW_NO_MM_DIRECT=1 keeps the k_member_to_coupler pass (q / rho in the slab, multiplied
+    back: a few ulp apart) and the fused-lane D1 launch.  Members that differ, several tiles per row with a ragged last one, an odd row
+    count (nens = 2: a workgroup's second row does not exist), chunks that do not divide nz, a sub-cycled step.  Then the same path
+    against the CPU oracle (tolerance of BASELINE.md section 4)."""
+    import torch
+    from miniweatherml_amd import modules
+    from util import compare_fields, gpu_fields, push_fields
+    monkeypatch.setenv("MW_CHUNK_Z", "7"); monkeypatch.setenv("MW_CHUNK_F", "9")
+    out = []
+    for pass13 in (None, "1"):
+        if pass13: monkeypatch.setenv("MW_NO_MM_DIRECT", pass13)
+        else: monkeypatch.delenv("MW_NO_MM_DIRECT", raising=False)
+        coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
+        modules.perturb_temperature(coupler)
+        dm = coupler.get_data_manager_readwrite()
+        t = dm.get("temp", True)
+        t += 0.05 * torch.arange(nens, device=t.device, dtype=t.dtype)          # members differ
+        dm.get("cloud_liquid", True).fill_(2.0e-4)                            # (all D13 outputs non-trivial)
+        dt = dycore.compute_time_step(coupler)
+        for n in range(3):
+            dycore.time_step(coupler, dt * (2.2 if n == 1 else 1.0))            # step 1: three sub-cycles
+        dmr = coupler.get_data_manager_readonly()
+        out.append({n: dmr.get(n, True).clone() for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid", "precip_liquid")})
+    for n in out[0]:
+        scale = float(out[1][n].abs().max())
+        floor = 1e-11 if n in ("uvel", "vvel", "wvel") else 1e-18
+        assert float((out[0][n] - out[1][n]).abs().max()) <= 1e-12 * scale + floor, n
+    a = out[0]["temp"]
+    assert not torch.equal(a[..., 0], a[..., 1])
+    # --- against the oracle, production arithmetic
+    monkeypatch.delenv("MW_NO_MM_DIRECT", raising=False)
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
+    odyc, of = oracle.supercell_setup(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
+    of.temp += 0.05 * np.arange(nens)
+    push_fields(coupler, of)
+    dt = dycore.compute_time_step(coupler)
+    for _ in range(2):
+        dycore.time_step(coupler, dt)
+        odyc.time_step(of, dt)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "members in one workgroup (D1 / D13), nens %d %dx%dx%d, 2 steps" % (nens, nx, ny, nz))
