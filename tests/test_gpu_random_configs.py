@@ -17,7 +17,7 @@ def draw(seed):
     nx = int(rng.integers(5, 75))
     ny = 1 if two_d else int(rng.integers(3, 18))
     nz = int(rng.integers(4, 26))
-    nens = int(rng.choice([1, 1, 2, 3]))
+    nens = int(rng.choice([1, 1, 2, 3, 4]))
     nt = int(rng.integers(1, 5))
     pos = [1] + [int(rng.uniform() < 0.7) for _ in range(nt - 1)]
     adds = [1] + [int(rng.uniform() < 0.5) for _ in range(nt - 1)]
