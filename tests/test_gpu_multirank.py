@@ -67,6 +67,12 @@ def test_eight_ranks_4x2_nens2(mw):
     run_ranks(8, 48, 24, 8, 2, 2)
 
 
+def test_four_ranks_2x2_nens4(mw):
+    """config 4's shape in small: four members per block, the blocks of a 2 x 2 decomposition exchanging strips (the members of a tile
+    share a workgroup in the last stage's kernels -- MemberOff, mw_march.h -- here with filled halos instead of the index wrap)."""
+    run_ranks(4, 140, 24, 9, 4, 2)
+
+
 @pytest.mark.parametrize("ord", [3, 7, 9])
 def test_four_ranks_other_weno_orders(mw, ord):
     """Orders 7 / 9 exchange 4- / 5-cell strips (hs + 1); the exchange is installed AFTER the order is set here, and the
