@@ -1415,13 +1415,11 @@ static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const doubl
   return 0;
 }
 
-// dynamic LDS of k_tracers_fused<., MODE 1>: D13's background table of the block's levels
-static size_t fused_bg_bytes(int mode, int chunk, int nens) { return mode == 1 ? (size_t)(chunk + 4) * nens * 24 : 0; }
 template <int STAGE, int MODE, int T, bool N1, int K, int ORD = 5>
 static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
   const int e = v.e;
-  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1, K, ORD>), grid, dim3(256), fused_bg_bytes(MODE, chunk, v.p.nens), st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
+  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1, K, ORD>), grid, dim3(256), 0, st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
                      d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
                      d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4, MemberOff());
 }
@@ -1441,12 +1439,13 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const long long waves = (long long)p.ny * tiles_x;
       const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F", 10000, 2, 4.5, true));
       dim3 grid((unsigned)(((p.ny + rpb - 1) / rpb) * tiles_x), (unsigned)((p.nz + chunk - 1) / chunk));
-      const size_t lds = (size_t)(chunk + 4) * 24 * 4;
-      if (lds > 60000) MW_FAIL("fused tracer stage: chunk too large for its LDS table (use a smaller MW_CHUNK_F)");
-#define MW_FUSED_MT(TT) case TT: hipLaunchKernelGGL((k_tracers_fused<3, 1, TT, true, 0, 5, true>), grid, dim3(256), lds, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
-                                 d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo); break;
-      switch (p.nt) { MW_FUSED_MT(1) MW_FUSED_MT(2) MW_FUSED_MT(3) MW_FUSED_MT(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
+#define MW_FUSED_MT(TT) case TT: MW_FUSED_MTK(TT, 0); break;
+#define MW_FUSED_MTK(TT, K_) hipLaunchKernelGGL((k_tracers_fused<3, 1, TT, true, K_, 5, true>), grid, dim3(256), 0, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
+                                 d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo)
+      if (marching_config(p) == 1) MW_FUSED_MTK(3, 1);
+      else switch (p.nt) { MW_FUSED_MT(1) MW_FUSED_MT(2) MW_FUSED_MT(3) MW_FUSED_MT(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
 #undef MW_FUSED_MT
+#undef MW_FUSED_MTK
       MW_LAUNCH_CHECK();
     }
     for (int e = 0; e < (direct ? 0 : n_views(d)); e++) {
@@ -1458,15 +1457,12 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const long long waves = (long long)p.ny * tiles_x;
       const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F", 10000, 2, 4.5, true));
       dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
-      if (fused_bg_bytes(MODE, chunk, p.nens) > 60000) MW_FAIL("fused tracer stage: nens x chunk too large for its LDS table (use the member-major layout or a smaller MW_CHUNK_F)");
 #define MW_FUSED_ARGS d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st
 #define MW_FUSED_CASE(TT) \
       case TT: if (p.nens != 1)     launch_tracers_fused_t<STAGE, MODE, TT, false, 0>(MW_FUSED_ARGS); \
                else if (d->ord == 3) launch_tracers_fused_t<STAGE, MODE, TT, true, 0, 3>(MW_FUSED_ARGS); \
                else                  launch_tracers_fused_t<STAGE, MODE, TT, true, 0>(MW_FUSED_ARGS); break;
-      // (the D13 variant <3, 1> with three tracers sits at the register limit: with the switches folded the compiler spills VGPRs to
-      //  scratch, with the run-time switches it does not -- it keeps K = 0; one launch per time step)
-      const int K = (MODE == 1 && p.nt == 3) ? 0 : marching_config(p);
+      const int K = marching_config(p);
       if (K == 1)      { if (d->ord == 3) launch_tracers_fused_t<STAGE, MODE, 3, true, 1, 3>(MW_FUSED_ARGS); else launch_tracers_fused_t<STAGE, MODE, 3, true, 1>(MW_FUSED_ARGS); }
       else if (K == 2) { if (d->ord == 3) launch_tracers_fused_t<STAGE, MODE, 1, true, 2, 3>(MW_FUSED_ARGS); else launch_tracers_fused_t<STAGE, MODE, 1, true, 2>(MW_FUSED_ARGS); }
       else switch (p.nt) { MW_FUSED_CASE(1) MW_FUSED_CASE(2) MW_FUSED_CASE(3) MW_FUSED_CASE(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }

@@ -837,7 +837,15 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
         else if (STAGE == 2) qnew = (3.0 / 4.0) * q_n + (1.0 / 4.0) * q_s + cdt * tend;
         else                 qnew = (1.0 / 3.0) * q_n + (2.0 / 3.0) * q_s + cdt * tend;
         if (l == idR) inv_rho_new = fast_rcp(qnew + hyc);
-        const double stored = (l == idR || l == idT) ? qnew : qnew * inv_rho_new;
+        double stored = (l == idR || l == idT) ? qnew : qnew * inv_rho_new;
+        // (MODE 1: what the result slab's (rho theta)' slot is read for afterwards is D13's pressure, :1935 -- by the tracer stage of
+        //  this stage and its correction pass; the next time_step starts from the coupler's fields.  The series is evaluated HERE,
+        //  where the level's background values are at hand, and the slot holds p: the tracer stage's D13 variant is the kernel at
+        //  the register limit, this one is not.)
+        if (MODE == 1 && l == idT) {
+          const double *hq = HPL ? lds_hp + (kc - g.kstart) * 8 : p.hypk + (long long)(kc * n + e) * 8;
+          stored = pressure_fast<K>(p, qnew, hq[1], hq[2], hq[3]);
+        }
         // (MODE 1, the last stage of a time step: u, v, w go to the coupler's arrays only.  Nobody reads the result slab's velocities
         //  any more -- the tracer stage of this stage needs rho' and (rho theta)', and the next time_step starts from the coupler's
         //  fields (D1) -- so three of the five slab stores are dropped: 24 B per cell and step.)
@@ -1055,8 +1063,7 @@ __global__ __launch_bounds__(256) void k_tracer_update(DyP p, const double *Ssta
   }
   if (MODE == 1) {
     // the slab holds u = (rho u)/rho etc. -- exactly what convert_dynamics_to_coupler computes (:1929-1932)
-    double theta = (Sout[so + idT * p.sV] + hytc) / rho_new;
-    double press = p.C0 * pow_ref(rho_new * theta, p.gamma);
+    const double press = Sout[so + idT * p.sV];                   // (k_xz_state<3, ., 1> left D13's pressure in the (rho theta)' slot)
     c.rho_d[ci] = rho_dry;                                     // (u, v, w: written to the coupler by k_xz_state<3, ., 1>, like on the fused path)
     c.temp[ci] = press / (rho_dry * p.R_d + rho_v * p.R_v);
   }
@@ -1096,7 +1103,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     mt_e = wv & (mo.n - 1); mt_sub = wv >> mo.sh;
     S += mt_e * mo.slab; Sn += mt_e * mo.slab; Sout += mt_e * mo.slab; FY += mt_e * mo.fy; MX += mt_e * mo.mx; UPX += mt_e * mo.mx;
     MZ += mt_e * mo.mz; UPZ += mt_e * mo.mz; DS += mt_e * mo.fx; DN += mt_e * mo.fz; flags += mt_e * mo.cells;
-    p.hyc += mt_e * mo.per; p.hytc += mt_e * mo.per; p.p0c += mt_e * mo.per; p.ihytc += mt_e * mo.per; p.ce = mt_e;
+    p.hyc += mt_e * mo.per; p.ce = mt_e;
   }
   const int n = N1 ? 1 : p.nens;
   constexpr int t0 = 0;                                       // one group: all (<= 4) tracers of the cell
@@ -1114,30 +1121,17 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   if (MT)         { const int rpb = 4 >> mo.sh, jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); j = jg * rpb + mt_sub; }   // rows of one tile
   else if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
   else            { const long long wid = (long long)blk.x * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
-  // MODE 1: D13's three background values (hytc, p0c, ihytc) of the levels this block finishes go through LDS.  As global loads
-  // they sat behind the tracer stores, each waited for at once -- and a vmcnt wait behind a store waits for the store (see landed());
-  // requested at the top of the iteration they cost 6 VGPRs the kernel does not have.  (dynamic LDS: (chunk + 4) * nens * 3 doubles)
-  extern __shared__ double lds_bg_all[];
-  double *lds_bg = lds_bg_all + (MT ? wv * (chunk + 4) * 3 : 0);      // (MT: one table per wave -- the members' backgrounds differ)
-  const int bg_l0 = max((int)blk.y * chunk - 4, 0);
+  // (MODE 1: D13's pressure comes out of the result slab -- k_xz_state<3, ., 1> evaluated the series and left p in the (rho theta)'
+  //  slot -- so this kernel needs neither the series nor its three background values per level.)
   // the uniform doubles of the loop (reciprocal grid spacings, time-step factors) as broadcast LDS reads instead of resident SGPRs
   // (as in k_xz_state: the kernel spills SGPRs to VGPR lanes)
-  // (not in the D13 variant, MODE 1: it sits at the VGPR limit and the values read from LDS live in VGPRs)
-  constexpr bool LC = (MODE == 0);
+  constexpr bool LC = true;
   __shared__ double lds_c[8];
   if (LC && threadIdx.x < 8) {
     const double cdt = (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;
     lds_c[threadIdx.x] = threadIdx.x == 0 ? p.rdx : threadIdx.x == 1 ? p.rdy : threadIdx.x == 2 ? p.rdz : threadIdx.x == 3 ? dt : threadIdx.x == 4 ? cdt : 0.0;
   }
   if (LC) __syncthreads();
-  if (MODE == 1) {
-    const int cnt = (min((int)blk.y * chunk + chunk, p.nz) - bg_l0) * p.nens;
-    for (int i3 = MT ? lane : (int)threadIdx.x; i3 < cnt * 3; i3 += MT ? 64 : 256) {
-      const int i = i3 / 3, f = i3 - i * 3;
-      lds_bg[i3] = (f == 0 ? p.hytc : f == 1 ? p.p0c : p.ihytc)[bg_l0 * p.nens + i];
-    }
-    __syncthreads();
-  }
   if (j >= p.ny) return;
   const int q = tx * U - hw * n + lane;                       // fused-x index of this lane's cell (halo lanes included)
   const int qq = min(max(q, -3 * n), NXI + 3 * n - 1);        // clamped into the 3-cell halo for addressing
@@ -1341,8 +1335,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       if (MODE == 1 && st) {
         // D13 (:1929-1935): p = C0 (rho theta)^gamma with rho theta = hy + (rho theta)' -- the same series around the hydrostatic
         // state as in the Riemann solver (device pow for large perturbations); rho*(rho theta / rho) differs from rho theta by rounding
-        const double *bg = lds_bg + ((kuc - bg_l0) * p.nens + e) * 3;
-        double press = pressure_fast<K>(p, st_T, bg[0], bg[1], bg[2]);
+        const double press = st_T;                             // (k_xz_state<3, ., 1> left p in the (rho theta)' slot)
         c.rho_d[cpl(p, ci)] = rho_dry;
         c.temp[cpl(p, ci)] = press / (rho_dry * p.R_d + rho_v * p.R_v);
       }
@@ -1421,8 +1414,7 @@ __global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const
       if (v == p.idWV) rho_v = qv;
       if ((p.mass_mask >> v) & 1u) rho_dry -= qv;
     }
-    const int hi = k * p.nens + e;                                // the same pressure evaluation as k_tracers_fused (D13)
-    const double press = pressure_fast(p, Sout[so + idT * p.sV], p.hytc[hi], p.p0c[hi], p.ihytc[hi]);
+    const double press = Sout[so + idT * p.sV];                   // (k_xz_state<3, ., 1> left D13's pressure in the (rho theta)' slot)
     c.rho_d[cpl(p, ci)] = rho_dry;
     c.temp[cpl(p, ci)] = press / (rho_dry * p.R_d + rho_v * p.R_v);
   }
