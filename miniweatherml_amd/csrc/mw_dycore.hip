@@ -925,7 +925,7 @@ struct mw_dycore_s {
   std::vector<double> hy_host;               // same packing (the last four are derived in upload_background)
   double etime = 0;
   int strict = 0;
-  int mm_direct = 0;                         // ... and D13 written from the last stage's kernels (MemberOff: 2 or 4 members per workgroup, WENO-5), no k_member_to_coupler pass
+  int mm_direct = 0;                         // ... and D13 written from the last stage's kernels (MemberOff: 2 or 4 members per workgroup), no k_member_to_coupler pass
   int member_major = 0;                      // production path with nens > 1: the handle's arrays hold one member after the other (View)
   int ord = 5;                               // WENO order (3, 7, 9: the reference's -DMW_ORD builds; they run on the general kernels)
   int hxw = HXc, hzw = HZc;                  // halo widths of the slabs: hs + 1 in x / y, hs in z (3 / 2 up to order 5)
@@ -1251,11 +1251,13 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     const YMember mm = {v0.p.sJ, v0.p.sK, v0.p.sV, v0.slab, v0.p.fyJ, v0.p.fyK, v0.m[1], v0.p.nC, v0.tend, p.nx, mo.per, mo.n, mo.sh};
     double *Sw = const_cast<double *>(S);
     const int K = marching_config(v0.p);
-    if (d->mm_direct && d->ord == 5 && !getenv("MW_NO_MM_CONV")) {      // the members of the same cells in one workgroup (k_y_state<.., MM = 2>)
+    if (d->mm_direct && !getenv("MW_NO_MM_CONV")) {      // the members of the same cells in one workgroup (k_y_state<.., MM = 2>)
       grid.x = (unsigned)((mthreads + 64 * (4 / mo.n) - 1) / (64 * (4 / mo.n)));
-#define MW_YSM2(K_) hipLaunchKernelGGL((k_y_state<true, K_, 5, 2>), grid, dim3(256), 0, d->stream, v0.p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
-      if (K == 1) MW_YSM2(1); else if (K == 2) MW_YSM2(2); else MW_YSM2(0);
+#define MW_YSM2(K_) { if (d->ord == 3) MW_YSM2O(K_, 3); else MW_YSM2O(K_, 5); }
+#define MW_YSM2O(K_, O_) hipLaunchKernelGGL((k_y_state<true, K_, O_, 2>), grid, dim3(256), 0, d->stream, v0.p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
+      if (K == 1) MW_YSM2(1) else if (K == 2) MW_YSM2(2) else MW_YSM2(0)
 #undef MW_YSM2
+#undef MW_YSM2O
       MW_LAUNCH_CHECK();
       return 0;
     }
@@ -1340,10 +1342,12 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
       const int wpb = 4 / mo.n;
       grid.x = (unsigned)(((long long)p.ny * tiles_x + wpb - 1) / wpb);
       const size_t lds = (size_t)(chunk + 2) * 64 * 4;
-#define MW_XZ_MT(K_) hipLaunchKernelGGL((k_xz_state<3, true, 1, 1, K_, 5, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
+#define MW_XZ_MT(K_) { if (d->ord == 3) MW_XZ_MTO(K_, 3); else MW_XZ_MTO(K_, 5); }
+#define MW_XZ_MTO(K_, O_) hipLaunchKernelGGL((k_xz_state<3, true, 1, 1, K_, O_, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
                                         d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo)
-      if (marching_config(p) == 1) { MW_XZ_MT(1); } else { MW_XZ_MT(0); }
+      if (marching_config(p) == 1) MW_XZ_MT(1) else MW_XZ_MT(0)
 #undef MW_XZ_MT
+#undef MW_XZ_MTO
       MW_LAUNCH_CHECK();
       return 0;
     }
@@ -1435,17 +1439,19 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const View v = view(d, 0);
       const DyP &p = v.p;
       const MemberOff mo = member_off(d);
-      const int U = 64 - 2 * 3, tiles_x = (p.nx + U - 1) / U, rpb = 4 / mo.n;
+      const int U = 64 - 2 * ((d->ord - 1) / 2 + 1), tiles_x = (p.nx + U - 1) / U, rpb = 4 / mo.n;
       const long long waves = (long long)p.ny * tiles_x;
       const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F", 10000, 2, 4.5, true));
       dim3 grid((unsigned)(((p.ny + rpb - 1) / rpb) * tiles_x), (unsigned)((p.nz + chunk - 1) / chunk));
-#define MW_FUSED_MT(TT) case TT: MW_FUSED_MTK(TT, 0); break;
-#define MW_FUSED_MTK(TT, K_) hipLaunchKernelGGL((k_tracers_fused<3, 1, TT, true, K_, 5, true>), grid, dim3(256), 0, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
+#define MW_FUSED_MT(TT) case TT: MW_FUSED_MTK(TT, 0) break;
+#define MW_FUSED_MTK(TT, K_) { if (d->ord == 3) MW_FUSED_MTO(TT, K_, 3); else MW_FUSED_MTO(TT, K_, 5); }
+#define MW_FUSED_MTO(TT, K_, O_) hipLaunchKernelGGL((k_tracers_fused<3, 1, TT, true, K_, O_, true>), grid, dim3(256), 0, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
                                  d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo)
-      if (marching_config(p) == 1) MW_FUSED_MTK(3, 1);
+      if (marching_config(p) == 1) MW_FUSED_MTK(3, 1)
       else switch (p.nt) { MW_FUSED_MT(1) MW_FUSED_MT(2) MW_FUSED_MT(3) MW_FUSED_MT(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
 #undef MW_FUSED_MT
 #undef MW_FUSED_MTK
+#undef MW_FUSED_MTO
       MW_LAUNCH_CHECK();
     }
     for (int e = 0; e < (direct ? 0 : n_views(d)); e++) {
@@ -1853,8 +1859,8 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   //  (k_tracers_fused 7.6 -> 12.0 ms, k_xz_state 9.4 -> 11.7), 30.3 with D1 inside (k_y_state 3.8 -> 7.7), 34.3 with both.)
   d->member_major = march && d->fused && p.nens > 1 && !getenv("MW_NO_MEMBER_MAJOR");
   // ... with D13 written by the last stage's kernels themselves and D1 read by the first k_y_state, the members of a tile in one
-  // workgroup so that their quarter-sector accesses meet in L1 / L2 (MemberOff, mw_march.h): 2 or 4 members, WENO-5
-  d->mm_direct = d->member_major && (p.nens == 2 || p.nens == 4) && d->ord == 5 && !getenv("MW_NO_MM_DIRECT");
+  // workgroup so that their quarter-sector accesses meet in L1 / L2 (MemberOff, mw_march.h): 2 or 4 members
+  d->mm_direct = d->member_major && (p.nens == 2 || p.nens == 4) && !getenv("MW_NO_MM_DIRECT");
   // D1 + D2 (:101, :248-255).  Production path with periodic x and y owned by this rank (either schedule: the tracer stream waits
   // for the stage's state kernels anyway): done inside the first k_y_state (no separate pass); otherwise a conversion kernel first
   // (the reference's operation order on the general path).

@@ -253,14 +253,14 @@ def test_member_major_layout_agrees_with_the_member_fastest_kernels(mw, monkeypa
     assert not torch.equal(a[..., 0], a[..., 1])
 
 
-@pytest.mark.parametrize("nens,nx,ny,nz", [(4, 70, 45, 26), (2, 131, 9, 26), (4, 24, 6, 12), (2, 58, 4, 14)])
-def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracle(mw, oracle, monkeypatch, nens, nx, ny, nz):
+@pytest.mark.parametrize("nens,nx,ny,nz,order", [(4, 70, 45, 26, 5), (2, 131, 9, 26, 5), (4, 24, 6, 12, 5), (2, 58, 4, 14, 5), (4, 70, 11, 26, 3), (2, 125, 7, 13, 3)])
+def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracle(mw, oracle, monkeypatch, nens, nx, ny, nz, order):
     """Member-major handles with 2 or 4 members read D1 in the first k_y_state and write D13 from the last stage's kernels, with the
     members of the same cells in ONE workgroup (MemberOff / k_y_state<.., MM = 2>, mw_march.h) so that their accesses to the coupler's
     member-fastest arrays meet in L1 / L2.  MW_NO_MM_DIRECT=1 keeps the k_member_to_coupler pass (q / rho in the slab, multiplied
     back: a few ulp apart) and the fused-lane D1 launch.  Members that differ, several tiles per row with a ragged last one, an odd row
     count (nens = 2: a workgroup's second row does not exist), chunks that do not divide nz, a sub-cycled step.  Then the same path
-    against the CPU oracle (tolerance of BASELINE.md section 4)."""
+    against the CPU oracle (tolerance of BASELINE.md section 4); WENO-5 and WENO-3."""
     import torch
     from miniweatherml_amd import modules
     from util import compare_fields, gpu_fields, push_fields
@@ -269,7 +269,7 @@ def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracl
     for pass13 in (None, "1"):
         if pass13: monkeypatch.setenv("MW_NO_MM_DIRECT", pass13)
         else: monkeypatch.delenv("MW_NO_MM_DIRECT", raising=False)
-        coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
+        coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000., ord=order)
         modules.perturb_temperature(coupler)
         dm = coupler.get_data_manager_readwrite()
         t = dm.get("temp", True)
@@ -288,12 +288,12 @@ def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracl
     assert not torch.equal(a[..., 0], a[..., 1])
     # --- against the oracle, production arithmetic
     monkeypatch.delenv("MW_NO_MM_DIRECT", raising=False)
-    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
-    odyc, of = oracle.supercell_setup(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000., ord=order)
+    odyc, of = (oracle if order == 5 else oracle.with_order(order)).supercell_setup(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
     of.temp += 0.05 * np.arange(nens)
     push_fields(coupler, of)
     dt = dycore.compute_time_step(coupler)
     for _ in range(2):
         dycore.time_step(coupler, dt)
         odyc.time_step(of, dt)
-    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "members in one workgroup (D1 / D13), nens %d %dx%dx%d, 2 steps" % (nens, nx, ny, nz))
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "members in one workgroup (D1 / D13), nens %d %dx%dx%d WENO-%d, 2 steps" % (nens, nx, ny, nz, order))
