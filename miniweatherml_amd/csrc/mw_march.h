@@ -1187,8 +1187,11 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     const int kp = k - 1, ku = k - 2;
     const bool s2cell = (kp >= k_lo) && (kp <= k_hi);          // cell kp has all six fluxes (kp == nz: only the top face is scaled)
     const bool s3 = (ku >= ka) && (ku < kb);
-    const int kx = min(k, p.nz - 1), kz = min(k, p.nz);
-    const int kpc = min(max(kp, 0), p.nz - 1), kuc = min(max(ku, 0), p.nz - 1);
+    // (addresses of iterations outside a quantity's range are clamped INTO the range the chunk needs anyway -- x faces and cells
+    //  k_lo .. k_hi, updated cells ka .. kb-1 -- so that a ghost iteration re-reads a line the neighbouring iteration uses, not a
+    //  level of the chunk below or above: those lines would come from HBM for nothing)
+    const int kx = min(max(k, k_lo), p.nz - 1), kz = min(max(k, k_lo), p.nz);
+    const int kpc = min(max(kp, k_lo), k_hi), kuc = min(max(ku, ka), kb - 1);
     // ------------------------------------------------ loads of this iteration
     const int kn = min(k + HS + 1, p.nz + p.HZ - 1);
     double xpatch[T];                                            // level k, the cell beyond lane 0 / lane 63
