@@ -1288,6 +1288,31 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
   return 0;
 }
 
+// y faces of all variables in one launch (k_y_all): one-stream schedule, no conversion, the folded configurations (with the
+// switches at run time the 8 register windows do not fit: 20-88 VGPRs spilled)
+static bool y_all_ok(const mw_dycore_s *d) {
+  return !d->overlap && d->fused && !d->p.sim2d && marching_config(view(d, 0).p) != 0 && !getenv("MW_NO_Y_ALL");
+}
+static int launch_y_all(mw_dycore_s *d, const double *S) {
+  ProfScope ps(d, 5);
+  for (int e = 0; e < n_views(d); e++) {
+    const View v = view(d, e);
+    const DyP &p = v.p;
+    long long threads = (long long)p.nz * p.nx * p.nens;
+    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
+    dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
+#define MW_YA(K_, O_, T_) hipLaunchKernelGGL((k_y_all<K_, O_, T_>), grid, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk)
+#define MW_YA_O(K_, T_) { if (d->ord == 3) MW_YA(K_, 3, T_); else MW_YA(K_, 5, T_); }
+    const int K = marching_config(p);
+    if (K == 1) MW_YA_O(1, 3)
+    else MW_YA_O(2, 1)
+#undef MW_YA_O
+#undef MW_YA
+    MW_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_t st) {
   if (d->p.sim2d) return 0;
   ProfScope ps(d, 6, st);
@@ -1518,7 +1543,9 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   if (halo_fill(d, Sin, 0, 5, ss, 0, true)) return 1;
   const bool conv = (STAGE == 1) && d->conv_pending;            // first stage of the step: D1 + D2 inside k_y_state
   d->conv_pending = false;
-  if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
+  const bool yall = !conv && y_all_ok(d);                       // y faces of state variables and tracers in one launch
+  if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin)) return 1; }
+  else if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
   // previous stage, which this stream produced itself: it is issued BEFORE the wait for this stage's state kernels and so
@@ -1526,9 +1553,9 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   // (Measured, round 3 -- profiles/r03_ab_two_stream_yt_beside_xz.txt: letting k_y_tracers start right behind k_y_state, BESIDE
   //  k_xz_state (an HBM-bound launch beside a VALU-bound one), stretches both and leaves the step where it was: 5.62-5.74 ms against
   //  5.51-5.70 on one stream.  The step as a whole moves 26 GB at 4.8 TB/s: there is no idle HBM time for a second kernel to use.)
-  if (halo_fill(d, Sin, 5, T, ts, 1, true)) return 1;
+  if (!yall && halo_fill(d, Sin, 5, T, ts, 1, true)) return 1;
   if (d->overlap) { MW_HIP(hipEventRecord(d->ev_state[slot], ss)); MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0)); }
-  if (launch_y_tracers(d, Sin, par, ts)) return 1;                            // tracer fluxes (public arrays)
+  if (!yall && launch_y_tracers(d, Sin, par, ts)) return 1;                   // tracer fluxes (public arrays)
   if (d->fused) {
     if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ts)) return 1;   // x/z fluxes + D10 + D11/D12 (+ D13)
   } else {

@@ -546,6 +546,97 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
   }
 }
 
+// Y pass, state variables AND tracers in one launch (one-stream schedule, stages that do not convert): the face's upwind mass flux
+// and selector go from the Riemann solve straight into the tracer fluxes -- they are neither written nor read back (17 of 146 bytes
+// per cell of the two launches), and the launch boundary between them is gone.  Same arithmetic as k_y_state / k_y_tracers.
+template <int K, int ORD, int T>
+__global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk) {
+  constexpr int NV = 5 + T;
+  const int NXI = p.nx * p.nens;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
+  if (t >= (long long)p.nz * NXI) return;
+  const int k = (int)(t / NXI);
+  const int ie = (int)(t - (long long)k * NXI);
+  const int ja = blockIdx.y * chunk;
+  const int jb = min(ja + chunk, p.ny);
+  const int e = ie % p.nens;
+  const double *hp = p.hypk + (long long)(k * p.nens + e) * 8;
+  const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
+  const double *col = S + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;      // row j at col + (j+HY)*sJ
+  double *fy = FY + (long long)k * p.fyK + ie;                                                // tracer v, face j at fy + (5+v)*fyV + j*fyJ
+  double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
+  constexpr int HS = (ORD - 1) / 2;
+  double w[NV][ORD], nxt[NV], cn[NV], fprev[5];
+#pragma unroll
+  for (int v = 0; v < NV; v++) {
+    cn[v] = 0;
+#pragma unroll
+    for (int s = 0; s < ORD; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - HS + s) + p.HY) * p.sJ];
+  }
+#pragma unroll
+  for (int v = 0; v < 5; v++) fprev[v] = 0;
+#pragma unroll
+  for (int v = 0; v < NV; v++) landed(w[v]);
+  for (int j = ja - 1; j <= jb; j++) {
+    const int jn = min(j + HS + 1, p.ny + p.HY - 1);            // clamp: the last prefetch is never used
+#pragma unroll
+    for (int v = 0; v < NV; v++) nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
+    double se[NV], ne[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) weno_window_edges<ORD>(w[v], se[v], ne[v]);
+    {
+      const bool face = (j >= ja);
+      const int jc = max(j, 0);
+      const int bcmode = bc_mode_y<K>(p, jc);
+      const bool zero = (bcmode == 1 || bcmode == 2) && (p.bc_y == MW_BC_WALL);
+      if (__builtin_expect(bcmode == 3, 0)) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) { const double *qv = col + (long long)v * p.sV + (long long)p.HY * p.sJ; double l_, r_, q_[ORD];
+#pragma unroll
+          for (int s = 0; s < ORD; s++) q_[s] = qv[(long long)(s - HS) * p.sJ];
+          weno_window_edges<ORD>(q_, l_, r_); se[v] = l_; }
+      }
+      double Lr = cn[idR], Lu = cn[idV], Lt = cn[idT], Rr = se[idR], Ru = se[idV], Rt = se[idT];
+      const bool ybc = (bcmode == 1 || bcmode == 2);
+      if (__builtin_expect(ybc, 0)) {
+        if (bcmode == 1) { Lr = Rr; Lu = Ru; Lt = Rt; } else { Rr = Lr; Ru = Lu; Rt = Lt; }
+        if (zero) { Lu = 0.0; Ru = 0.0; }
+      }
+      double f[5], fn, fT;
+      FaceState fs = riemann_primary<K>(p, Lr + hyr, Rr + hyr, Lu, Ru, Lt, Rt, hyt, p0, ihyt, false, fn, fT);
+      int up = fs.ind;
+      if (__builtin_expect(ybc, 0)) up = (bcmode == 1) ? 1 : 0;
+      f[idR] = fs.m_upw; f[idV] = fn; f[idT] = fT;
+      {
+        const double sU = se[idU], cU = cn[idU], sW = se[idW], cW = cn[idW];
+        f[idU] = fs.m_upw * (up ? sU : cU);
+        f[idW] = fs.m_upw * (up ? sW : cW);
+      }
+      landed(nxt);                                             // the iteration's loads, in front of its stores (see landed())
+      if (face) {
+#pragma unroll
+        for (int v = 0; v < T; v++) {                          // scalar copies first (a select between two arrays' elements would go through scratch)
+          const double sv = se[5 + v], cv = cn[5 + v];
+          fy[(long long)(5 + v) * p.fyV + (long long)j * p.fyJ] = fs.m_upw * (up ? sv : cv);
+        }
+      }
+      if (j > ja) {
+#pragma unroll
+        for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fprev[l]) * p.rdy;
+      }
+#pragma unroll
+      for (int l = 0; l < 5; l++) fprev[l] = f[l];
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      cn[v] = ne[v];
+#pragma unroll
+      for (int s = 0; s + 1 < ORD; s++) w[v][s] = w[v][s + 1];
+      w[v][ORD - 1] = nxt[v];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // XZ pass.  wave = 64 fused-x lanes of one row j (n = nens lanes per x cell).  Marches k over [ka-1, kb] for the chunk
 // [ka, kb).  Two ways to get a cell's four x-stencil neighbours:
