@@ -1293,7 +1293,7 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
 static bool y_all_ok(const mw_dycore_s *d) {
   return !d->overlap && d->fused && !d->p.sim2d && marching_config(view(d, 0).p) != 0 && !getenv("MW_NO_Y_ALL");
 }
-static int launch_y_all(mw_dycore_s *d, const double *S) {
+static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv) {
   ProfScope ps(d, 5);
   for (int e = 0; e < n_views(d); e++) {
     const View v = view(d, e);
@@ -1301,8 +1301,10 @@ static int launch_y_all(mw_dycore_s *d, const double *S) {
     long long threads = (long long)p.nz * p.nx * p.nens;
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
-#define MW_YA(K_, O_, T_) hipLaunchKernelGGL((k_y_all<K_, O_, T_>), grid, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk)
-#define MW_YA_O(K_, T_) { if (d->ord == 3) MW_YA(K_, 3, T_); else MW_YA(K_, 5, T_); }
+#define MW_YA(C_, K_, O_, T_) hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), grid, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
+                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)))
+#define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
+                          else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
     const int K = marching_config(p);
     if (K == 1) MW_YA_O(1, 3)
     else MW_YA_O(2, 1)
@@ -1543,8 +1545,8 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   if (halo_fill(d, Sin, 0, 5, ss, 0, true)) return 1;
   const bool conv = (STAGE == 1) && d->conv_pending;            // first stage of the step: D1 + D2 inside k_y_state
   d->conv_pending = false;
-  const bool yall = !conv && y_all_ok(d);                       // y faces of state variables and tracers in one launch
-  if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin)) return 1; }
+  const bool yall = y_all_ok(d) && !(conv && (d->member_major || getenv("MW_NO_Y_ALL_CONV")));   // y faces of state variables and tracers in one launch
+  if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin, conv ? &c : nullptr)) return 1; }
   else if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the

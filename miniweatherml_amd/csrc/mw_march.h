@@ -546,11 +546,20 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
   }
 }
 
-// Y pass, state variables AND tracers in one launch (one-stream schedule, stages that do not convert): the face's upwind mass flux
-// and selector go from the Riemann solve straight into the tracer fluxes -- they are neither written nor read back (17 of 146 bytes
+// Y pass, state variables AND tracers in one launch (one-stream schedule, folded configurations): the face's upwind mass flux and
+// selector go from the Riemann solve straight into the tracer fluxes -- they are neither written nor read back (17 of 146 bytes
 // per cell of the two launches), and the launch boundary between them is gone.  Same arithmetic as k_y_state / k_y_tracers.
-template <int K, int ORD, int T>
-__global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk) {
+// CONV (first stage of a step): rows come from the coupler's arrays and are converted on the way, as in k_y_state<true>; the
+// tracers' slab values (rho_t / rho) then enter their windows from registers instead of being read back (24 more bytes per cell).
+// The face-flux carry of the five state variables lives in LDS there (one private slot per thread): the eight windows plus the
+// row in flight leave no registers for it.
+__device__ __forceinline__ double tracer_slab_value(double rho_t, double inv_den) {
+#pragma clang fp contract(off)
+  return rho_t * inv_den;                                      // (= convert_cell_tracers)
+}
+template <bool CONV, int K, int ORD, int T>
+__global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk,
+                                               CouplerPtrs c, double *__restrict__ Sw) {
   constexpr int NV = 5 + T;
   const int NXI = p.nx * p.nens;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
@@ -566,21 +575,49 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   double *fy = FY + (long long)k * p.fyK + ie;                                                // tracer v, face j at fy + (5+v)*fyV + j*fyJ
   double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
   constexpr int HS = (ORD - 1) / 2;
-  double w[NV][ORD], nxt[NV], cn[NV], fprev[5];
+  double w[NV][ORD], nxt[NV], cn[NV], fprev_r[CONV ? 1 : 5];
+  __shared__ double lds_fprev[CONV ? 5 : 1][CONV ? 256 : 1];
+#define MW_ROW_CI(r) cpl(p, ((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
+#define MW_ROW_FINISH(raw, r, out)                                                                                    \
+  { double inv_den_;                                                                                                  \
+    convert_cell_fast<K>(p, raw, hyr, hyt, p0, out, inv_den_);                                                        \
+    _Pragma("unroll") for (int v_ = 0; v_ < T; v_++) out[5 + v_] = tracer_slab_value(raw.tr[v_], inv_den_);          \
+    if ((r) >= ja && (r) < jb) {                                                                                      \
+      double *s_ = Sw + (long long)(k + p.HZ) * p.sK + (long long)((r) + p.HY) * p.sJ + (long long)p.HX * p.nens + ie; \
+      _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++) s_[(long long)v_ * p.sV] = out[v_];                           \
+    } }
 #pragma unroll
-  for (int v = 0; v < NV; v++) {
-    cn[v] = 0;
+  for (int v = 0; v < NV; v++) cn[v] = 0;
+  if (CONV) {
 #pragma unroll
-    for (int s = 0; s < ORD; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - HS + s) + p.HY) * p.sJ];
+    for (int l = 0; l < 5; l++) lds_fprev[l][threadIdx.x] = 0;
+#pragma unroll
+    for (int s = 0; s < ORD; s++) {
+      const CouplerCell raw = load_coupler_cell<K>(p, c, MW_ROW_CI(ja - 1 - HS + s));
+      double r8[NV];
+      MW_ROW_FINISH(raw, ja - 1 - HS + s, r8)
+#pragma unroll
+      for (int v = 0; v < NV; v++) w[v][s] = r8[v];
+    }
+  } else {
+#pragma unroll
+    for (int l = 0; l < 5; l++) fprev_r[l] = 0;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+#pragma unroll
+      for (int s = 0; s < ORD; s++) w[v][s] = col[(long long)v * p.sV + (long long)(wrap_row(p, ja - 1 - HS + s) + p.HY) * p.sJ];
+    }
   }
-#pragma unroll
-  for (int v = 0; v < 5; v++) fprev[v] = 0;
 #pragma unroll
   for (int v = 0; v < NV; v++) landed(w[v]);
   for (int j = ja - 1; j <= jb; j++) {
     const int jn = min(j + HS + 1, p.ny + p.HY - 1);            // clamp: the last prefetch is never used
+    CouplerCell raw;
+    if (CONV) raw = load_coupler_cell<K>(p, c, MW_ROW_CI(jn));
+    else {
 #pragma unroll
-    for (int v = 0; v < NV; v++) nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
+      for (int v = 0; v < NV; v++) nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
+    }
     double se[NV], ne[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) weno_window_edges<ORD>(w[v], se[v], ne[v]);
@@ -612,7 +649,12 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
         f[idU] = fs.m_upw * (up ? sU : cU);
         f[idW] = fs.m_upw * (up ? sW : cW);
       }
-      landed(nxt);                                             // the iteration's loads, in front of its stores (see landed())
+      if (CONV) {
+        landed(raw.rho_d); landed(raw.u); landed(raw.v); landed(raw.w); landed(raw.temp);
+#pragma unroll
+        for (int tr = 0; tr < T; tr++) landed(raw.tr[tr]);
+      }
+      else landed(nxt);                                        // the iteration's loads, in front of its stores (see landed())
       if (face) {
 #pragma unroll
         for (int v = 0; v < T; v++) {                          // scalar copies first (a select between two arrays' elements would go through scratch)
@@ -620,13 +662,17 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
           fy[(long long)(5 + v) * p.fyV + (long long)j * p.fyJ] = fs.m_upw * (up ? sv : cv);
         }
       }
+      double fp[5];
+#pragma unroll
+      for (int l = 0; l < 5; l++) fp[l] = CONV ? lds_fprev[l][threadIdx.x] : fprev_r[l];
       if (j > ja) {
 #pragma unroll
-        for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fprev[l]) * p.rdy;
+        for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fp[l]) * p.rdy;
       }
 #pragma unroll
-      for (int l = 0; l < 5; l++) fprev[l] = f[l];
+      for (int l = 0; l < 5; l++) { if (CONV) lds_fprev[l][threadIdx.x] = f[l]; else fprev_r[l] = f[l]; }
     }
+    if (CONV) MW_ROW_FINISH(raw, jn, nxt)
 #pragma unroll
     for (int v = 0; v < NV; v++) {
       cn[v] = ne[v];
@@ -635,6 +681,8 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
       w[v][ORD - 1] = nxt[v];
     }
   }
+#undef MW_ROW_CI
+#undef MW_ROW_FINISH
 }
 
 // ---------------------------------------------------------------------------------------------------------------
