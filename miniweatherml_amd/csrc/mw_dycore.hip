@@ -1295,6 +1295,21 @@ static bool y_all_ok(const mw_dycore_s *d) {
 }
 static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv) {
   ProfScope ps(d, 5);
+  if (conv && d->member_major) {                                // mm_direct: all members in one launch, the members of the same cells in one workgroup
+    const View v = view(d, 0);
+    const DyP &p = v.p;
+    const MemberOff mo = member_off(d);
+    const long long mthreads = (long long)p.nz * p.nx;
+    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (mthreads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
+    dim3 grid((unsigned)((mthreads + 64 * (4 / mo.n) - 1) / (64 * (4 / mo.n))), (unsigned)((p.ny + chunk - 1) / chunk));
+#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo)
+#define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
+    if (marching_config(p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
+#undef MW_YAM_O
+#undef MW_YAM
+    MW_LAUNCH_CHECK();
+    return 0;
+  }
   for (int e = 0; e < n_views(d); e++) {
     const View v = view(d, e);
     const DyP &p = v.p;
@@ -1302,7 +1317,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
 #define MW_YA(C_, K_, O_, T_) hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), grid, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
-                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)))
+                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff())
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
     const int K = marching_config(p);
@@ -1545,7 +1560,7 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   if (halo_fill(d, Sin, 0, 5, ss, 0, true)) return 1;
   const bool conv = (STAGE == 1) && d->conv_pending;            // first stage of the step: D1 + D2 inside k_y_state
   d->conv_pending = false;
-  const bool yall = y_all_ok(d) && !(conv && (d->member_major || getenv("MW_NO_Y_ALL_CONV")));   // y faces of state variables and tracers in one launch
+  const bool yall = y_all_ok(d) && !(conv && ((d->member_major && !(d->mm_direct && !getenv("MW_NO_MM_CONV"))) || getenv("MW_NO_Y_ALL_CONV")));   // y faces of state variables and tracers in one launch
   if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin, conv ? &c : nullptr)) return 1; }
   else if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables

@@ -332,6 +332,10 @@ __global__ __launch_bounds__(256) void k_member_to_coupler(DyP p, const double *
 // MM = 2 (2 or 4 members): the per-member form of the launch -- wave = one member's 64 x cells, coalesced stores into that member's
 // arrays -- with the nens members of the same cells in ONE workgroup: their 8-byte reads of the coupler's member-fastest arrays, nens
 // doubles apart, then meet in the CU's L1 / the XCD's L2 (the same idea as MemberOff below for the way out).
+struct MemberOff {
+  long long slab, tend, mx, my, mz, fx, fy, fz, cells, per;    // doubles (selectors / flags: bytes) from member e to member e + 1
+  int n, sh;                                                   // members per workgroup (2 or 4) and log2 of it
+};
 struct YMember { long long sJ, sK, sV, slab, fyJ, fyK, mfy, nC, tend; int nx; long long per; int n, sh; };
 template <bool CONV, int K, int ORD, int MM = 0>
 __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restrict__ S, double *__restrict__ MY,
@@ -557,12 +561,20 @@ __device__ __forceinline__ double tracer_slab_value(double rho_t, double inv_den
 #pragma clang fp contract(off)
   return rho_t * inv_den;                                      // (= convert_cell_tracers)
 }
-template <bool CONV, int K, int ORD, int T>
+// MT (member-major handles with 2 or 4 members, CONV): one launch for all members, the members of the same cells in one workgroup
+// (see MemberOff) -- the converting launch of such a handle.
+template <bool CONV, int K, int ORD, int T, bool MT = false>
 __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk,
-                                               CouplerPtrs c, double *__restrict__ Sw) {
+                                               CouplerPtrs c, double *__restrict__ Sw, MemberOff mo) {
+  static_assert(!MT || CONV, "the member-co-located form exists for the converting launch only");
   constexpr int NV = 5 + T;
   const int NXI = p.nx * p.nens;
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
+  if (MT) {                                                      // (p = one member's view: nens = 1, cst = the member count)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), em = wv & (mo.n - 1);
+    t = ((long long)blockIdx.x * (4 >> mo.sh) + (wv >> mo.sh)) * 64 + (threadIdx.x & 63);
+    FY += em * mo.fy; tendY += em * mo.tend; Sw += em * mo.slab; S += em * mo.slab; p.hypk += em * mo.per; p.ce = em;
+  }
   if (t >= (long long)p.nz * NXI) return;
   const int k = (int)(t / NXI);
   const int ie = (int)(t - (long long)k * NXI);
@@ -766,10 +778,6 @@ __device__ __forceinline__ void x_neighbours(double c0, const double *__restrict
 // (Also measured: the level's values transposed through LDS, one s_barrier per level, 64 consecutive doubles stored per wave --
 //  fully coalesced, and SLOWER than the pass it replaces: k_tracers_fused<3, 1> 3.7 instead of 3.3 ms, k_xz_state<3, 1> +0.5 ms;
 //  the lock step costs more than the quarter-sector stores.)
-struct MemberOff {
-  long long slab, tend, mx, my, mz, fx, fy, fz, cells, per;    // doubles (selectors / flags: bytes) from member e to member e + 1
-  int n, sh;                                                   // members per workgroup (2 or 4) and log2 of it
-};
 
 // MODE 1 (last stage of the last cycle): u, v, w also go to the coupler's arrays (D13, :1929-1932: the slab holds (rho u)/rho
 // already), so that the tracer stage, which finishes D13, neither re-reads nor re-writes them.
