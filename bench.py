@@ -12,7 +12,7 @@ workload: BASELINE.json configs[1]: supercell 400x400x100, nens 1, fp64, 3 Kessl
           grid (2-D x/y decomposition of coupler.h:127-179), 3-cell halos exchanged over RCCL once per RK stage and group.
 timing  : W untimed warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(); max over ranks.
 roofline: SURVEY.md 8(d)'s flux-stencil figure: 32 V = 256 B per cell and RK stage (read V, write 3 V doubles), priced against
-          everything one stage launches (k_y_state + k_xz_state + k_y_tracers + k_tracers_fused + k_tracer_patch: the reference's
+          everything one stage launches (k_y_all + k_xz_state + k_tracers_fused + k_tracer_patch -- two streams: k_y_state + k_y_tracers instead of k_y_all; the reference's
           D6 + D9 stencil split by direction and variable group, with D10-D12 fused in).  achieved = 256 B x cells / average stage
           duration, the duration from hipEvents recorded on the handle's stream around each stage inside the timed region
           (mw_dycore_profile class 8; N > 1 runs two streams: one third of the step instead).  roofline.dominant_kernel carries
@@ -21,7 +21,7 @@ roofline: SURVEY.md 8(d)'s flux-stencil figure: 32 V = 256 B per cell and RK sta
           cell-update figure.  peak 8 TB/s HBM3E spec.  traffic / valu_* come from the committed rocprofv3 PMC summary
           (profiles/latest_summary.json, 2 x FETCH_SIZE + WRITE_SIZE calibrated with mw_calib_copy) and are reported ONLY while
           the kernel sources still hash to what that profile was taken from (roofline.pmc_provenance); otherwise null.
-          The stage is bound by its COUNTED HBM traffic (the intermediates between its four launches make it ~2.1 x the algorithmic
+          The stage is bound by its COUNTED HBM traffic (the intermediates between its three launches make it ~2.1 x the algorithmic
           bytes) with the fp64 instruction stream at 0.80-0.87 VALU busy right under it (roofline.binding_resource, roofline.traffic_frac,
           roofline.fp64_valu; DESIGN.md 0b: the WENO-3 build runs half the arithmetic in 93 % of the time).
 micro   : after the timed region (the headline is untouched): Kessler (two states) and the surrogate MLP on the same grid, 72 B per
@@ -337,7 +337,7 @@ def main():
                     dom_traffic = sum(k["hbm_read_bytes"] + k["hbm_write_bytes"] for k in ks) / len(ks)
                     valu_busy = sum(k["valu_busy_frac"] for k in ks) / len(ks)
                     valu_instr = sum(k["valu_instr_per_cell"] for k in ks) / len(ks)
-                    stage_k = [v for k, v in K.items() if k.startswith(("k_xz_state", "k_y_state", "k_y_tracers", "k_tracers_fused", "k_tracer_patch"))]
+                    stage_k = [v for k, v in K.items() if k.startswith(("k_xz_state", "k_y_all", "k_y_state", "k_y_tracers", "k_tracers_fused", "k_tracer_patch"))]
                     nstages = sum(k["calls"] for k in ks)      # one k_xz_state launch per RK stage
                     traffic = sum((k["hbm_read_bytes"] + k["hbm_write_bytes"]) * k["calls"] for k in stage_k if "hbm_read_bytes" in k) / nstages
                     # fp64-VALU side of the roofline (the binding one): counted VALU instructions of one cell-update against the
@@ -366,10 +366,10 @@ def main():
             # achieved / peak / frac are SURVEY.md 8(d)'s algorithmic figure (32 V B per cell against 8 TB/s: what the north star's 60 %
             # target is quoted in); traffic / traffic_frac the counted bytes; roofline.fp64_valu the instruction side.
             "roofline": {"bound": "hbm",
-                         "binding_resource": "HBM traffic of the stage's four launches (counted bytes: roofline.traffic, ~2.1 x algorithmic; "
+                         "binding_resource": "HBM traffic of the stage's three launches (counted bytes: roofline.traffic, ~2.1 x algorithmic; "
                                              "4.6-5.6 TB/s per kernel = 85-100 % of what a streaming copy reaches on this part), "
                                              "fp64 VALU issue co-limiting at 0.80-0.87 busy",
-                         "kernel": "one RK stage = k_y_state + k_xz_state + k_y_tracers + k_tracers_fused + k_tracer_patch "
+                         "kernel": "one RK stage = k_y_all (y faces of all variables) + k_xz_state + k_tracers_fused + k_tracer_patch "
                                    "(SURVEY.md 8(d) flux stencil, 32 V B per cell)" if not a.strict else "one RK stage (general path)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_frac": (traffic / (stage_ms * 1e-3) / 8.0e12) if traffic else None,
