@@ -299,7 +299,12 @@ def main():
     wmax = float(coupler.get_data_manager_readonly().get("wvel", True).abs().max())
     assert wmax == wmax and wmax < 100.0, "unphysical state after the timed region (max|w| = %r)" % wmax
 
-    two_streams = (os.environ.get("MW_OVERLAP", "1" if world > 1 else "0") != "0") and not a.strict
+    # N > 1: the pipelined one-stream schedule (rk_stage_pipe) unless MW_OVERLAP / MW_NO_PIPE select the two-stream one
+    if "MW_OVERLAP" in os.environ:
+        two_streams = os.environ["MW_OVERLAP"] != "0" and not a.strict
+    else:
+        two_streams = world > 1 and bool(os.environ.get("MW_NO_PIPE")) and not a.strict
+    pipelined = world > 1 and not two_streams and "MW_OVERLAP" not in os.environ and not a.strict
     if rank == 0:
         ncycles = 1
         total_updates = float(ncells_local) * world * ncycles * a.steps
@@ -357,7 +362,8 @@ def main():
                                    "CFL dt" % (a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz, dxy, what),
                        "baseline_config": "configs[3] per-GPU block" if a.workload == "config4" else "configs[1]",
                        "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict, "weno_order": a.ord,
-                       "schedule": ("two streams (state | tracers, tracer stream at high priority)" if two_streams else "one stream"),
+                       "schedule": ("two streams (state | tracers, tracer stream at high priority)" if two_streams else
+                                    "one compute stream, strip exchange on a side stream beside the inner y chunks / the tracer stage" if pipelined else "one stream"),
                        "alg_bytes_per_cell_update": 64 * V,
                        "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world},
             # bound: the resource that binds the stage: its COUNTED HBM traffic -- 2.1 x the algorithmic bytes: y tendencies,

@@ -911,6 +911,9 @@ struct mw_dycore_s {
   hipEvent_t ev_state[8] = {nullptr}, ev_tr[8] = {nullptr}, ev_misc = nullptr;
   long long gstage = 0;                                 // global stage counter (event ring index, buffer parity)
   int overlap = 1;
+  int pipe = 0;                              // blocks of a decomposed domain: pipelined one-stream schedule (rk_stage_pipe)
+  bool pipe_ready = false;                   // ... the next stage's input strips are already on their way (event ev_pipe[2])
+  hipEvent_t ev_pipe[3] = {nullptr, nullptr, nullptr};
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
@@ -1293,7 +1296,10 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
 static bool y_all_ok(const mw_dycore_s *d) {
   return !d->overlap && d->fused && !d->p.sim2d && marching_config(view(d, 0).p) != 0 && !getenv("MW_NO_Y_ALL");
 }
-static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv) {
+// part: 0 = all rows; 1 = the rows whose chunks read no halo row (all of them with the row wrap), 2 = the two edge strips of
+// MW_Y_EDGE rows (short chunks: their launch runs between the exchange and k_xz_state, with a quarter of the wavefronts)
+#define MW_Y_EDGE 8
+static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv, int part = 0) {
   ProfScope ps(d, 5);
   if (conv && d->member_major) {                                // mm_direct: all members in one launch, the members of the same cells in one workgroup
     const View v = view(d, 0);
@@ -1302,7 +1308,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     const long long mthreads = (long long)p.nz * p.nx;
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (mthreads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
     dim3 grid((unsigned)((mthreads + 64 * (4 / mo.n) - 1) / (64 * (4 / mo.n))), (unsigned)((p.ny + chunk - 1) / chunk));
-#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo)
+#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, 0, chunk, p.ny)
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
     if (marching_config(p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
@@ -1316,8 +1322,21 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     long long threads = (long long)p.nz * p.nx * p.nens;
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
+    int row0 = 0, rstride = chunk, row_end = p.ny;
+    if (part) {
+      const int n = (int)grid.y;
+      const bool edges = !p.wrap_y;                             // the first / last rows read halo rows of the slab
+      const bool split = p.ny >= 4 * MW_Y_EDGE;                 // (an inner chunk reads up to 3 rows beyond its own: MW_Y_EDGE >= 3)
+      if (part == 1) {
+        if (edges) { if (!split) continue; row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; rstride = chunk;
+                     grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk); }
+      } else {
+        if (!edges) continue;
+        if (split) { chunk = MW_Y_EDGE; rstride = p.ny - MW_Y_EDGE; grid.y = 2u; }
+      }
+    }
 #define MW_YA(C_, K_, O_, T_) hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), grid, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
-                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff())
+                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end)
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
     const int K = marching_config(p);
@@ -1582,9 +1601,70 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   if (d->overlap) MW_HIP(hipEventRecord(d->ev_tr[slot], ts));
   return 0;
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// One RK stage of a block of a decomposed domain, PIPELINED schedule (the default with a neighbour exchange when k_y_all applies):
+// one compute stream, and the strip exchange of a stage on the side stream BESIDE interior work that does not need it:
+//   compute : k_y_all(chunks without halo rows) | wait | k_y_all(first + last chunk) -> k_xz_state -> k_tracers_fused (+ patch)
+//   exchange:   [strips of this stage's input ]         after k_xz_state: state strips of the NEXT stage's input (beside
+//                                                       k_tracers_fused); after k_tracers_fused: its tracer strips (beside the next
+//                                                       stage's interior k_y_all)
+// The y marching kernel reads no x halo at all and y halo rows only in its first and last chunk, so six of eight chunks start at
+// once.  The first stage of a cycle exchanges all variables at its start (its input comes from the conversion pass / the previous
+// cycle).  Compared with the two-stream schedule of rk_stage_march (each pipeline hides the other's exchange behind whole kernels)
+// this one keeps k_y_all -- 5 % of the step -- and needs less machinery; the transfer must fit beside ~0.3-0.5 ms of kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int STAGE, int MODE>
+static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *Sout, double dt_stage, double dt_dyn, const CouplerPtrs &c) {
+  const long long gs = d->gstage++;
+  const int par = (int)(gs & 1);
+  hipStream_t ss = d->stream, xs = d->tstream;
+  const int T = d->p.nt;
+  ProfScope stage_scope(d, 8, ss);
+  d->conv_pending = false;
+  if (!d->pipe_ready) {                                       // this stage's input has not been exchanged yet
+    MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
+    if (halo_fill(d, Sin, 0, -1, xs, 0, true)) return 1;
+    MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
+  }
+  d->pipe_ready = false;
+  if (launch_y_all(d, Sin, nullptr, 1)) return 1;             // chunks that read no halo row
+  MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));
+  if (launch_y_all(d, Sin, nullptr, 2)) return 1;             // first and last chunk
+  if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;
+  const bool early = (STAGE < 3);                             // the next stage of this cycle reads Sout
+  if (early) {
+    MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
+    if (halo_fill(d, Sout, 0, 5, xs, 0, true)) return 1;      // state strips, beside the tracer stage
+  }
+  if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ss)) return 1;
+  if (early) {
+    MW_HIP(hipEventRecord(d->ev_pipe[1], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[1], 0));
+    if (halo_fill(d, Sout, 5, T, xs, 1, true)) return 1;      // tracer strips, beside the next stage's interior y chunks
+    MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
+    d->pipe_ready = true;
+  }
+  return 0;
+}
 // One SSPRK3 sub-cycle.  Slabs: Q[0] = q^n, Q[1..3] scratch; on return the new q^n is in Q[3] (caller rotates).
 static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, const CouplerPtrs &c) {
   const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
+  if (d->pipe) {                                              // blocks of a decomposed domain, pipelined schedule
+    d->pipe_ready = false;
+    if (rk_stage_pipe<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;
+    if (rk_stage_pipe<2, 0>(d, Q[1], Q[0], Q[2], dt2, dt_dyn, c)) return 1;
+    const bool pass13p = d->member_major && !d->mm_direct;
+    if (last && !pass13p) { if (rk_stage_pipe<3, 1>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }
+    else                  { if (rk_stage_pipe<3, 0>(d, Q[2], Q[0], Q[3], dt3, dt_dyn, c)) return 1; }
+    if (last && pass13p) {
+      ProfScope ps(d, 4, d->stream);
+      const View v = view(d, 0);
+      const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
+      hipLaunchKernelGGL(k_member_to_coupler, plane_grid((long long)d->p.ny * d->p.nx * d->p.nens, d->p.nz), dim3(256), 0, d->stream, d->p, Q[3], c, ms);
+      MW_LAUNCH_CHECK();
+    }
+    d->flux_src = Q[2]; d->flux_dt = dt3;
+    return 0;
+  }
   if (rk_stage_march<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;                        // stage 1 (:119-132)
   if (rk_stage_march<2, 0>(d, Q[1], Q[0], Q[2], dt2, dt_dyn, c)) return 1;                           // stage 2 (:136-153)
   const bool pass13 = d->member_major && !d->mm_direct;        // D13 as a pass over the result slab
@@ -1701,6 +1781,8 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
     for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
                                     hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
     if (hipEventCreateWithFlags(&d->ev_misc, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
+    for (int i = 0; i < 3; i++)
+      if (hipEventCreateWithFlags(&d->ev_pipe[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
   }
   fill_params(d);
   if (hipStreamSynchronize(d->stream) != hipSuccess) { set_error("stream sync failed in create"); return fail(); }
@@ -1718,6 +1800,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
+  for (int i = 0; i < 3; i++) if (d->ev_pipe[i]) (void)hipEventDestroy(d->ev_pipe[i]);
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
@@ -1895,7 +1978,13 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   { const char *ov = getenv("MW_OVERLAP");
     bool want = ov ? (atoi(ov) != 0) : (d->xchg != nullptr);
     if (getenv("MW_NO_OVERLAP")) want = false;
-    d->overlap = march && d->tstream && want; }
+    d->overlap = march && d->tstream && want;
+    // ... unless k_y_all applies: then the pipelined one-stream schedule (rk_stage_pipe) is the default with an exchange
+    d->pipe = 0;
+    if (d->overlap && d->xchg && !ov && !getenv("MW_NO_PIPE")) {
+      d->overlap = 0;
+      if (y_all_ok(d) && d->ev_pipe[0]) d->pipe = 1; else d->overlap = 1;
+    } }
   // nens > 1 on the production path: member-major internal layout (see View)
   // (Measured, round 3, config 4's block 256 x 512 x 128 x 4: the members' coupler-touching launches -- D1 inside k_y_state, D13 inside the
   //  last stage -- issued SIDE BY SIDE on one stream per member, hoping that the quarter lines the four members read / write would

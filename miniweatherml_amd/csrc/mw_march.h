@@ -565,7 +565,7 @@ __device__ __forceinline__ double tracer_slab_value(double rho_t, double inv_den
 // (see MemberOff) -- the converting launch of such a handle.
 template <bool CONV, int K, int ORD, int T, bool MT = false>
 __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk,
-                                               CouplerPtrs c, double *__restrict__ Sw, MemberOff mo) {
+                                               CouplerPtrs c, double *__restrict__ Sw, MemberOff mo, int row0, int rstride, int row_end) {
   static_assert(!MT || CONV, "the member-co-located form exists for the converting launch only");
   constexpr int NV = 5 + T;
   const int NXI = p.nx * p.nens;
@@ -578,8 +578,8 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   if (t >= (long long)p.nz * NXI) return;
   const int k = (int)(t / NXI);
   const int ie = (int)(t - (long long)k * NXI);
-  const int ja = blockIdx.y * chunk;
-  const int jb = min(ja + chunk, p.ny);
+  const int ja = row0 + (int)blockIdx.y * rstride;               // (a launch covers the rows [row0, row_end) in chunks `rstride` rows apart: all of them, the inner ones, or the two edge strips)
+  const int jb = min(ja + chunk, row_end);
   const int e = ie % p.nens;
   const double *hp = p.hypk + (long long)(k * p.nens + e) * 8;
   const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];

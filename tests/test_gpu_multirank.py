@@ -80,6 +80,19 @@ def test_four_ranks_other_weno_orders(mw, ord):
     run_ranks(4, 24, 20, 10, 1, 2, ord=ord)
 
 
+def test_four_ranks_two_stream_schedule(mw, monkeypatch):
+    """The default with an exchange is the pipelined one-stream schedule (rk_stage_pipe: k_y_all on the rows that read no halo row while
+    the strips travel, then the two 8-row edge strips).  MW_NO_PIPE=1 selects the two-stream schedule (state | tracer pipelines,
+    k_y_state + k_y_tracers): same bits."""
+    monkeypatch.setenv("MW_NO_PIPE", "1")
+    run_ranks(4, 32, 72, 10, 1, 2)
+
+
+def test_four_ranks_pipelined_with_edge_strips(mw):
+    """Blocks of 36 rows: the y launch is split into the inner rows and the two MW_Y_EDGE-row strips (ny >= 4 * MW_Y_EDGE)."""
+    run_ranks(4, 32, 72, 10, 1, 3)
+
+
 def test_two_ranks_2d(mw):
     run_ranks(2, 64, 1, 16, 1, 3)           # 2x1: west == east peer
 
