@@ -70,7 +70,7 @@ def test_eight_ranks_4x2_nens2(mw):
 def test_four_ranks_2x2_nens4(mw):
     """config 4's shape in small: four members per block, the blocks of a 2 x 2 decomposition exchanging strips (the members of a tile
     share a workgroup in the last stage's kernels -- MemberOff, mw_march.h -- here with filled halos instead of the index wrap)."""
-    run_ranks(4, 140, 24, 9, 4, 2)
+    run_ranks(4, 140, 72, 9, 4, 2)           # (36-row blocks: the pipelined schedule splits the y launch)
 
 
 @pytest.mark.parametrize("ord", [3, 7, 9])
