@@ -1620,6 +1620,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   hipStream_t ss = d->stream, xs = d->tstream;
   const int T = d->p.nt;
   ProfScope stage_scope(d, 8, ss);
+  const bool conv = (STAGE == 1) && d->conv_pending;            // the inner rows come from the coupler's arrays (see time_step)
   d->conv_pending = false;
   if (!d->pipe_ready) {                                       // this stage's input has not been exchanged yet
     MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
@@ -1627,7 +1628,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
     MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
   }
   d->pipe_ready = false;
-  if (launch_y_all(d, Sin, nullptr, 1)) return 1;             // chunks that read no halo row
+  if (launch_y_all(d, Sin, conv ? &c : nullptr, 1)) return 1;  // rows whose chunks read no halo row
   MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));
   if (launch_y_all(d, Sin, nullptr, 2)) return 1;             // first and last chunk
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;
@@ -1999,13 +2000,24 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   // (the reference's operation order on the general path).
   d->conv_pending = march && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT") &&
                     (!d->member_major || !getenv("MW_NO_FUSED_CONVERT_MM"));
+  // Pipelined schedule of a decomposed block (rk_stage_pipe): only the strips that are packed for the neighbours and the rows the
+  // edge-strip y launch reads are converted up front; the inner rows are converted by the first k_y_all<true> while the strips travel.
+  const bool pipe_conv = d->pipe && !d->member_major && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT") && !getenv("MW_NO_PIPE_CONVERT") &&
+                         (d->p.wrap_y || p.ny >= 4 * MW_Y_EDGE);
+  if (pipe_conv) {
+    ProfScope ps(d, 4);
+    const int ylo = d->p.wrap_y ? 0 : MW_Y_EDGE + 3, yhi = d->p.wrap_y ? p.ny : p.ny - MW_Y_EDGE - 3;
+    hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ylo, yhi);
+    MW_LAUNCH_CHECK();
+    d->conv_pending = true;
+  }
   if (!d->conv_pending) {
     ProfScope ps(d, 4);
     if (d->member_major) {      // one coalesced pass in the coupler's order (see k_coupler_to_member)
       const View v = view(d, 0);
       const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
       hipLaunchKernelGGL(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms);
-    } else if (march && p.nt <= 4) hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
+    } else if (march && p.nt <= 4) hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, p.ny, p.ny);
     else       hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
     MW_LAUNCH_CHECK();
   }

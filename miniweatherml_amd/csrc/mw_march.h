@@ -243,12 +243,15 @@ __device__ __forceinline__ void convert_cell_tracers(const DyP &p, const Coupler
   for (int tr = 0; tr < 4; tr++) if (tr < Cf<K>::ntr(p)) s[(long long)(5 + tr) * sV] = r.tr[tr] * inv_den;
 }
 // stand-alone form (2-D runs, walls / open boundaries or a neighbour exchange in y, two-stream schedule)
-__global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtrs c, double *__restrict__ S) {
+// (ylo, yhi: only the cells with j < ylo, j >= yhi or within HX cells of the block's west / east edge -- the strips that the pipelined
+//  multi-rank schedule packs and the rows its edge-strip y launch reads; the rest is converted inside k_y_all<true>.  ylo >= ny: all.)
+__global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtrs c, double *__restrict__ S, int ylo, int yhi) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int k = blockIdx.y;
   const int NXI = p.nx * p.nens;
   if (t >= (long long)p.ny * NXI) return;
   const int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  if (j >= ylo && j < yhi && ie >= p.HX * p.nens && ie < NXI - p.HX * p.nens) return;
   const long long ci = ((long long)k * p.ny + j) * NXI + ie;
   const CouplerCell r = load_coupler_cell(p, c, cpl(p, ci));
   double s5[5], inv_den;
