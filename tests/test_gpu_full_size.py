@@ -297,3 +297,37 @@ def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracl
         dycore.time_step(coupler, dt)
         odyc.time_step(of, dt)
     compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "members in one workgroup (D1 / D13), nens %d %dx%dx%d WENO-%d, 2 steps" % (nens, nx, ny, nz, order))
+
+
+@pytest.mark.parametrize("nx,ny,nz,order", [(61, 23, 17, 5), (130, 9, 26, 5), (64, 37, 12, 3)])
+def test_y_faces_of_all_variables_in_one_launch_equal_the_two_launches(mw, oracle, monkeypatch, nx, ny, nz, order):
+    """k_y_all (state variables and tracers in one y march; the converting first stage included) against k_y_state + k_y_tracers
+    (MW_NO_Y_ALL=1): the same arithmetic, so the same bits -- odd sizes, y chunks that do not divide ny, a sub-cycled step, cloud
+    and rain present.  Then against the CPU oracle (tolerance of BASELINE.md section 4)."""
+    from miniweatherml_amd import modules
+    from util import compare_fields, gpu_fields, push_fields
+    monkeypatch.setenv("MW_CHUNK_Y", "7")
+    out = []
+    for two in (None, "1"):
+        if two: monkeypatch.setenv("MW_NO_Y_ALL", two)
+        else: monkeypatch.delenv("MW_NO_Y_ALL", raising=False)
+        coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 500. * nx, 500. * ny, 20000., ord=order)
+        dm = coupler.get_data_manager_readwrite()
+        dm.get("cloud_liquid", True).fill_(3.0e-4); dm.get("precip_liquid", True).fill_(1.0e-4)
+        dt = dycore.compute_time_step(coupler)
+        for n in range(3):
+            dycore.time_step(coupler, dt * (2.2 if n == 1 else 1.0))
+        out.append(gpu_fields(coupler))
+    for n in out[0]:
+        assert np.array_equal(out[0][n], out[1][n]), n
+    monkeypatch.delenv("MW_NO_Y_ALL", raising=False)
+    O = oracle if order == 5 else oracle.with_order(order)
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 500. * nx, 500. * ny, 20000., ord=order)
+    odyc, of = O.supercell_setup(nx, ny, nz, 1, 500. * nx, 500. * ny, 20000.)
+    of.tracers[1][...] = 3.0e-4 * of.rho_d; of.tracers[2][...] = 1.0e-4 * of.rho_d
+    push_fields(coupler, of)
+    dt = dycore.compute_time_step(coupler)
+    for _ in range(2):
+        dycore.time_step(coupler, dt)
+        odyc.time_step(of, dt)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "k_y_all %dx%dx%d WENO-%d, 2 steps" % (nx, ny, nz, order))
