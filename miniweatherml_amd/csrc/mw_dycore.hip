@@ -1298,7 +1298,7 @@ static bool y_all_ok(const mw_dycore_s *d) {
 }
 // part: 0 = all rows; 1 = the rows whose chunks read no halo row (all of them with the row wrap), 2 = the two edge strips of
 // MW_Y_EDGE rows (short chunks: their launch runs between the exchange and k_xz_state, with a quarter of the wavefronts)
-#define MW_Y_EDGE 8
+#define MW_Y_EDGE 4                                            // (>= 4: the converting inner launch requests coupler rows up to row_end + 3 < ny)
 static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv, int part = 0) {
   ProfScope ps(d, 5);
   if (conv && d->member_major) {                                // mm_direct: all members in one launch, the members of the same cells in one workgroup

@@ -82,7 +82,7 @@ def test_four_ranks_other_weno_orders(mw, ord):
 
 def test_four_ranks_two_stream_schedule(mw, monkeypatch):
     """The default with an exchange is the pipelined one-stream schedule (rk_stage_pipe: k_y_all on the rows that read no halo row while
-    the strips travel, then the two 8-row edge strips).  MW_NO_PIPE=1 selects the two-stream schedule (state | tracer pipelines,
+    the strips travel, then the two 4-row edge strips).  MW_NO_PIPE=1 selects the two-stream schedule (state | tracer pipelines,
     k_y_state + k_y_tracers): same bits."""
     monkeypatch.setenv("MW_NO_PIPE", "1")
     run_ranks(4, 32, 72, 10, 1, 2)
