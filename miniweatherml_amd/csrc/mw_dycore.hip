@@ -1308,7 +1308,12 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     const long long mthreads = (long long)p.nz * p.nx;
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (mthreads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
     dim3 grid((unsigned)((mthreads + 64 * (4 / mo.n) - 1) / (64 * (4 / mo.n))), (unsigned)((p.ny + chunk - 1) / chunk));
-#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, 0, chunk, p.ny)
+    int row0 = 0, row_end = p.ny;
+    if (part == 1 && !p.wrap_y) {                               // (pipelined schedule: the inner rows; the edge strips come from the slab later)
+      const int n = (int)grid.y;
+      row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk);
+    }
+#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end)
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
     if (marching_config(p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
@@ -2002,11 +2007,16 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
                     (!d->member_major || !getenv("MW_NO_FUSED_CONVERT_MM"));
   // Pipelined schedule of a decomposed block (rk_stage_pipe): only the strips that are packed for the neighbours and the rows the
   // edge-strip y launch reads are converted up front; the inner rows are converted by the first k_y_all<true> while the strips travel.
-  const bool pipe_conv = d->pipe && !d->member_major && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT") && !getenv("MW_NO_PIPE_CONVERT") &&
-                         (d->p.wrap_y || p.ny >= 4 * MW_Y_EDGE);
+  const bool pipe_conv = d->pipe && (!d->member_major || (d->mm_direct && !getenv("MW_NO_MM_CONV"))) && p.nt <= 4 &&
+                         !getenv("MW_NO_FUSED_CONVERT") && !getenv("MW_NO_PIPE_CONVERT") && (d->p.wrap_y || p.ny >= 4 * MW_Y_EDGE);
   if (pipe_conv) {
     ProfScope ps(d, 4);
     const int ylo = d->p.wrap_y ? 0 : MW_Y_EDGE + 3, yhi = d->p.wrap_y ? p.ny : p.ny - MW_Y_EDGE - 3;
+    if (d->member_major) {
+      const View v = view(d, 0);
+      const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
+      hipLaunchKernelGGL(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms, ylo, yhi);
+    } else
     hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ylo, yhi);
     MW_LAUNCH_CHECK();
     d->conv_pending = true;
@@ -2016,7 +2026,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     if (d->member_major) {      // one coalesced pass in the coupler's order (see k_coupler_to_member)
       const View v = view(d, 0);
       const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
-      hipLaunchKernelGGL(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms);
+      hipLaunchKernelGGL(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms, p.ny, p.ny);
     } else if (march && p.nt <= 4) hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, p.ny, p.ny);
     else       hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
     MW_LAUNCH_CHECK();

@@ -269,12 +269,14 @@ __global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtr
 // arrays, and the partial lines of the four launches do not meet in L2: measured +65 % on k_y_state, +20 % on k_tracers_fused.)
 // p = the FUSED parameter block; msV .. mslab = the member view's strides.
 struct MemberStrides { long long sJ, sK, sV, slab; };
-__global__ __launch_bounds__(256) void k_coupler_to_member(DyP p, CouplerPtrs c, double *__restrict__ S, MemberStrides m) {
+// (ylo, yhi: as in k_coupler_to_state_fast -- only the strips the pipelined multi-rank schedule needs up front; ylo >= ny: all cells)
+__global__ __launch_bounds__(256) void k_coupler_to_member(DyP p, CouplerPtrs c, double *__restrict__ S, MemberStrides m, int ylo, int yhi) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int k = blockIdx.y;
   const int NXI = p.nx * p.nens;
   if (t >= (long long)p.ny * NXI) return;
   const int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  if (j >= ylo && j < yhi && ie >= p.HX * p.nens && ie < NXI - p.HX * p.nens) return;
   const int i = ie / p.nens, e = ie - i * p.nens;
   const long long ci = ((long long)k * p.ny + j) * NXI + ie;
   const CouplerCell r = load_coupler_cell(p, c, ci);
