@@ -1072,7 +1072,7 @@ static View view(const mw_dycore_s *d, int e) {
   return v;
 }
 
-// the member-to-member strides of a member-major handle, for the member-co-located kernels (MemberOff, mw_march.h)
+// the member-to-member strides of a member-major handle, for the member-transposing kernels (MemberOff, mw_march.h)
 static MemberOff member_off(const mw_dycore_s *d) {
   const View v = view(d, 0);
   MemberOff mo;

@@ -740,7 +740,7 @@ __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, 
   const int U = 64 - 2 * hw * g.n;                            // cells (fused) a wave completes
   g.cell_lo = hw * g.n; g.cell_hi = 64 - hw * g.n; g.face_hi = N1 ? 64 - HS * g.n : 64;
   const BlockXY blk = xcd_block();
-  // (wslot / wpb: a block of the member-co-located form holds the nens members of 4 / nens tiles -- MemberOff)
+  // (wslot / wpb: a block of the member-transposing form holds the nens members of 4 / nens tiles -- MemberOff below)
   const long long wid = (long long)blk.x * wpb + (wslot < 0 ? (int)(threadIdx.x >> 6) : wslot);   // wave id -> (row j, x tile)
   int tx;
   if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); g.j = jg * 4 + (threadIdx.x >> 6); }
