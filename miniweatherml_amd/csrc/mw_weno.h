@@ -123,12 +123,15 @@ __device__ __forceinline__ void weno5_edges_fast(double s0, double s1, double s2
   //   s2 N + (1/4 - 1/12) c2 + (1/16 - 1/80) c4  =  s2 N + c2/6 + c4/20
   // and the constant coefficients never have to be formed.
   // The 5th-order candidate's odd (c1/2 + c3/8) and even (c2/6 + c4/20) parts are combined before the weighting:
-  const double oH = 0.5*H1 + (0.125/12.0)*H3p;
-  const double eH = (0.125/12.0)*H2p + (1.0/480.0)*H4p;                    // H2 = H2p/16 -> c2/6 = H2p/96;  c4/20 = H4p/480
-  const double od = oH*nH + 0.5*(L1*nL + hC*nC + R1*nR);
-  const double ev = eH*nH + (1.0/12.0)*(L2p*nL + C2p*nC + R2p*nR);         // even part minus s2 N   (c2 = coefs3(2) = X2p/2)
-  left  = s2 + (ev - od)*rN;
-  right = s2 + (ev + od)*rN;
+  // (the factors 1/2 and 1/12 of the two sums are applied once, to the normalised sums, instead of inside them: od2 = 2 od, ev12 = 12 ev)
+  const double oH2 = H1 + (0.25/12.0)*H3p;
+  const double eH12 = 0.125*H2p + (1.0/40.0)*H4p;                          // H2 = H2p/16 -> c2/6 = H2p/96;  c4/20 = H4p/480
+  const double od2 = oH2*nH + (L1*nL + hC*nC + R1*nR);
+  const double ev12 = eH12*nH + (L2p*nL + C2p*nC + R2p*nR);                // even part minus s2 N   (c2 = coefs3(2) = X2p/2)
+  const double r12 = (1.0/12.0)*rN, rh = 0.5*rN;
+  const double base = fma(ev12, r12, s2);                                  // (explicit: every instantiation contracts the same way)
+  left  = fma(-od2, rh, base);
+  right = fma(od2, rh, base);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
