@@ -83,26 +83,28 @@ __device__ __forceinline__ void weno5_edges_fast(double s0, double s1, double s2
   const double a = s1 - s0, b = s2 - s1, c = s3 - s2, d = s4 - s3;
   const double L2p = b - a, C2p = c - b, R2p = d - c;       // 2*coefs3_shift{1,2,3}(2)
   const double C1p = b + c;                                 // 2*coefs3_shift2(1) = s3 - s1
-  const double L1 = b + 0.5*L2p;                            // coefs3_shift1(1) =  0.5 s0 - 2 s1 + 1.5 s2
-  const double R1 = c - 0.5*R2p;                            // coefs3_shift3(1) = -1.5 s2 + 2 s3 - 0.5 s4
+  // (the odd coefficients are carried DOUBLED and the four total variations times 4: powers of two, so every value below is the
+  //  exact multiple of its plain form and the edge values come out bit for bit the same -- the halvings are simply never executed)
+  const double L1d = 2.0*b + L2p;                           // 2 coefs3_shift1(1) =  s0 - 4 s1 + 3 s2
+  const double R1d = 2.0*c - R2p;                           // 2 coefs3_shift3(1) = -3 s2 + 4 s3 - s4
   const double e = s4 - s0;
   const double sLR = L2p + R2p;
   const double H4p = sLR - 2.0*C2p;                         // 24*coefs5_shift3(4)
   const double H3p = e - 2.0*C1p;                           // 12*coefs5_shift3(3)
   const double H2p = 10.0*C2p - sLR;                        // 16*coefs5_shift3(2)
-  const double H1 = 0.70833333333333333333333333333333333333*C1p - 0.10416666666666666666666666666666666667*e;  // coefs5_shift3(1)
-  // TV (WenoLimiter_recon.h:37-56) with the scale factors folded into the constants
-  const double k1312 = 1.0833333333333333333333333333333333333;             // (13/3)/4
-  const double tL = L1*L1 + k1312*(L2p*L2p);
-  const double hC = 0.5*C1p;                                // coefs3_shift2(1)
-  const double tC = hC*hC + k1312*(C2p*C2p);
-  const double tR = R1*R1 + k1312*(R2p*R2p);
-  const double tH = H1*(H1 + (0.5/12.0)*H3p) + H2p*((4.3333333333333333333333333333333333333/256.0)*H2p + (4.2/384.0)*H4p)
-                  + (39.1125/144.0)*(H3p*H3p) + (625.83571428571428571428571428571428571/576.0)*(H4p*H4p);
+  const double H1d = (2.0*0.70833333333333333333333333333333333333)*C1p - (2.0*0.10416666666666666666666666666666666667)*e;  // 2 coefs5_shift3(1)
+  // TV (WenoLimiter_recon.h:37-56) with the scale factors folded into the constants; all four times 4
+  const double k133 = 4.3333333333333333333333333333333333333;              // 13/3
+  const double tL = L1d*L1d + k133*(L2p*L2p);
+  const double tC = C1p*C1p + k133*(C2p*C2p);               // (C1p = 2 coefs3_shift2(1))
+  const double tR = R1d*R1d + k133*(R2p*R2p);
+  const double tH = H1d*(H1d + (1.0/12.0)*H3p) + H2p*((4.3333333333333333333333333333333333333/64.0)*H2p + (4.2/96.0)*H4p)
+                  + (39.1125/36.0)*(H3p*H3p) + (625.83571428571428571428571428571428571/144.0)*(H4p*H4p);
   // convexify #1 divides every t by S = sum(t) (when S > 1e-20); then w_i = idl_i / (t_i^2 + 1e-20).  Scaling all
   // four denominators by S^2 leaves the normalised weights unchanged:  d_i = t_i^2 + 1e-20 S^2   (no division).
+  // (with the t_i carried times 4: S is 4 x the reference's sum -- its threshold 1e-20 becomes 4e-20 -- and the d_i are 16 x)
   const double S = (tL + tC) + (tR + tH);
-  const double eS = (S > 1.e-20) ? (1.e-20*S)*S : 1.e-20;
+  const double eS = (S > 4.0*1.e-20) ? (1.e-20*S)*S : 16.0*1.e-20;
   const double dL = tL*tL + eS, dC = tC*tC + eS, dR = tR*tR + eS, dH = tH*tH + eS;
   // normalised w_i = (idl_i / d_i) / sum_j (idl_j / d_j)  =  idl_i prod_{j != i} d_j / N   (idl = 1,2,1,1000; /1004 cancels)
   const double dLC = dL*dC, dRH = dR*dH;
@@ -124,11 +126,11 @@ __device__ __forceinline__ void weno5_edges_fast(double s0, double s1, double s2
   // and the constant coefficients never have to be formed.
   // The 5th-order candidate's odd (c1/2 + c3/8) and even (c2/6 + c4/20) parts are combined before the weighting:
   // (the factors 1/2 and 1/12 of the two sums are applied once, to the normalised sums, instead of inside them: od2 = 2 od, ev12 = 12 ev)
-  const double oH2 = H1 + (0.25/12.0)*H3p;
+  const double oH2 = H1d + (0.5/12.0)*H3p;                                 // (odd part, times 4 with the doubled coefficients)
   const double eH12 = 0.125*H2p + (1.0/40.0)*H4p;                          // H2 = H2p/16 -> c2/6 = H2p/96;  c4/20 = H4p/480
-  const double od2 = oH2*nH + (L1*nL + hC*nC + R1*nR);
+  const double od2 = oH2*nH + (L1d*nL + C1p*nC + R1d*nR);
   const double ev12 = eH12*nH + (L2p*nL + C2p*nC + R2p*nR);                // even part minus s2 N   (c2 = coefs3(2) = X2p/2)
-  const double r12 = (1.0/12.0)*rN, rh = 0.5*rN;
+  const double r12 = (1.0/12.0)*rN, rh = 0.25*rN;
   const double base = fma(ev12, r12, s2);                                  // (explicit: every instantiation contracts the same way)
   left  = fma(-od2, rh, base);
   right = fma(od2, rh, base);
