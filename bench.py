@@ -26,7 +26,8 @@ roofline: SURVEY.md 8(d)'s flux-stencil figure: 32 V = 256 B per cell and RK sta
           roofline.fp64_valu; DESIGN.md 0b: the WENO-3 build runs half the arithmetic in 93 % of the time).
 micro   : after the timed region (the headline is untouched): Kessler (two states) and the surrogate MLP on the same grid, 72 B per
           cell each, and the dycore step on a state with cloud and rain (FCT limiter + y-face correction pass active):
-          developed_ms_per_step.
+          developed_ms_per_step (a seeded stress state: rims everywhere) and storm.ms_per_step / value_storm (the real storm after
+          --storm-steps steps of the complete supercell_example loop).
 cpu_baseline: the CPU oracle (a port: the reference itself is unbuildable here) timed on one host core
           on BASELINE.json configs[0] (supercell 200x200x50), rank 0, N = 1 only.
 """
@@ -61,6 +62,8 @@ def parse():
                          "block 256x512x128 nens 4, dx 800 m (weak-scaling series 256x512 ... 1024x1024 global for 1 ... 8 GPUs)")
     ap.add_argument("--ord", type=int, default=5, choices=[3, 5, 7, 9], help="WENO order (the reference's -DMW_ORD; 5 = its default and the headline; "
                     "3 = the order its GPU benchmark environment builds, build/machines/aws/aws_a100_gpu.env:21)")
+    ap.add_argument("--storm-steps", type=int, default=2600, help="steps of the complete supercell loop before the 'storm' dycore timing of the "
+                    "micro section (0 = skip)")
     ap.add_argument("--no-micro", action="store_true", help="skip the Kessler / MLP / developed-state section after the timed region")
     a = ap.parse_args()
     if a.workload == "config4":
@@ -175,6 +178,22 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
                                        "FCT multipliers < 1 and a busy y-face correction pass", "cell_updates_per_s": ncell / dev_ms * 1e3,
                               "tracer_patch_ms_per_launch": patch_ms / max(1, patch_n),
                               "cloud_max": float(dm.get("cloud_liquid").max()), "rain_max": float(dm.get("precip_liquid").max())}
+    # ---- ... and on a REAL developed storm: the complete supercell_example loop (dycore, Kessler, sponge layer, column nudger,
+    # experiments/supercell_example/driver.cpp:66-79) run for a.storm_steps steps from the initial state (2600 steps of the
+    # 400 x 400 x 100 configuration: 18 m/s updraft, cloud and rain confined to the storm), then the dycore step alone.
+    if a.storm_steps > 0 and nens == 1:
+        xlen, ylen = float(coupler.get_xlen()), float(coupler.get_ylen())
+        c2, d2, m2, n2 = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000.0, "supercell", rho_d.device, with_nudger=True, ord=a.ord)
+        dt2 = d2.compute_time_step(c2)
+        for _ in range(a.storm_steps):
+            modules.supercell_step(c2, d2, m2, n2, dt2)
+        storm_ms = timed(lambda: d2.time_step(c2, dt2), 10)
+        f2 = c2.get_data_manager_readonly()
+        res["storm"] = {"state": "after %d steps of the complete supercell_example loop from the initial state" % a.storm_steps,
+                        "ms_per_step": storm_ms, "cell_updates_per_s": ncell / storm_ms * 1e3,
+                        "max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()),
+                        "rain_max": float(f2.get("precip_liquid").max())}
+        res["value_storm"] = ncell / storm_ms * 1e3
     return res
 
 
