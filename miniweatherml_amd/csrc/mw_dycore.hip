@@ -1291,10 +1291,11 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
   return 0;
 }
 
-// y faces of all variables in one launch (k_y_all): one-stream schedule, no conversion, the folded configurations (with the
-// switches at run time the 8 register windows do not fit: 20-88 VGPRs spilled)
+// y faces of all variables in one launch (k_y_all): one-stream schedule, up to three tracers.  (With the switches at run time, K = 0,
+// the eight register windows do not fit -- 90-96 VGPRs go to scratch -- and the one launch is still 2.5 % of the step faster than
+// k_y_state + k_y_tracers: 5.44-5.49 against 5.57-5.62 ms on the supercell grid with MW_NO_SPEC=1.)
 static bool y_all_ok(const mw_dycore_s *d) {
-  return !d->overlap && d->fused && !d->p.sim2d && marching_config(view(d, 0).p) != 0 && !getenv("MW_NO_Y_ALL");
+  return !d->overlap && d->fused && !d->p.sim2d && d->p.nt <= 3 && !getenv("MW_NO_Y_ALL");
 }
 // part: 0 = all rows; 1 = the rows whose chunks read no halo row (all of them with the row wrap), 2 = the two edge strips of
 // MW_Y_EDGE rows (short chunks: their launch runs between the exchange and k_xz_state, with a quarter of the wavefronts)
@@ -1346,7 +1347,10 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
     const int K = marching_config(p);
     if (K == 1) MW_YA_O(1, 3)
-    else MW_YA_O(2, 1)
+    else if (K == 2) MW_YA_O(2, 1)
+    else if (p.nt == 1) MW_YA_O(0, 1)
+    else if (p.nt == 2) MW_YA_O(0, 2)
+    else MW_YA_O(0, 3)
 #undef MW_YA_O
 #undef MW_YA
     MW_LAUNCH_CHECK();
@@ -1584,7 +1588,9 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   if (halo_fill(d, Sin, 0, 5, ss, 0, true)) return 1;
   const bool conv = (STAGE == 1) && d->conv_pending;            // first stage of the step: D1 + D2 inside k_y_state
   d->conv_pending = false;
-  const bool yall = y_all_ok(d) && !(conv && ((d->member_major && !(d->mm_direct && !getenv("MW_NO_MM_CONV"))) || getenv("MW_NO_Y_ALL_CONV")));   // y faces of state variables and tracers in one launch
+  // (the converting launch of a member-major handle exists in the members-in-one-workgroup form of the folded configurations only)
+  const bool mm_conv_ok = d->mm_direct && !getenv("MW_NO_MM_CONV") && marching_config(view(d, 0).p) != 0;
+  const bool yall = y_all_ok(d) && !(conv && ((d->member_major && !mm_conv_ok) || getenv("MW_NO_Y_ALL_CONV")));   // y faces of state variables and tracers in one launch
   if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin, conv ? &c : nullptr)) return 1; }
   else if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
@@ -2007,7 +2013,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
                     (!d->member_major || !getenv("MW_NO_FUSED_CONVERT_MM"));
   // Pipelined schedule of a decomposed block (rk_stage_pipe): only the strips that are packed for the neighbours and the rows the
   // edge-strip y launch reads are converted up front; the inner rows are converted by the first k_y_all<true> while the strips travel.
-  const bool pipe_conv = d->pipe && (!d->member_major || (d->mm_direct && !getenv("MW_NO_MM_CONV"))) && p.nt <= 4 &&
+  const bool pipe_conv = d->pipe && (!d->member_major || (d->mm_direct && !getenv("MW_NO_MM_CONV") && marching_config(view(d, 0).p) != 0)) && p.nt <= 3 &&
                          !getenv("MW_NO_FUSED_CONVERT") && !getenv("MW_NO_PIPE_CONVERT") && (d->p.wrap_y || p.ny >= 4 * MW_Y_EDGE);
   if (pipe_conv) {
     ProfScope ps(d, 4);
