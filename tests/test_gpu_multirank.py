@@ -93,6 +93,49 @@ def test_four_ranks_pipelined_with_edge_strips(mw):
     run_ranks(4, 32, 72, 10, 1, 3)
 
 
+def test_four_ranks_simple_city(mw):
+    """BASELINE.json configs[4] in small: the simple_city configuration (immersed buildings, gravity off, water vapour only -- the
+    folded configuration K = 2) on a 2 x 2 decomposition, pipelined schedule with the split y launch, bitwise against one rank."""
+    from miniweatherml_amd import capi, modules
+    nranks, nxg, nyg, nz, nsteps = 4, 64, 72, 12, 3
+    xlen, ylen, zlen = 50.0 * nxg, 50.0 * nyg, 120.0
+    ex = Exchanger(nranks)
+    results = [None] * nranks
+    keep = []
+
+    def worker(rank):
+        try:
+            coupler, dycore, _, _ = modules.make_simple_city(nxg, nyg, nz, 1, xlen, ylen, zlen, "city", nranks=nranks, myrank=rank)
+            cb = ex.make_cb(rank, coupler.grid)
+            keep.append(cb)
+            capi.check(capi.lib().mw_dycore_set_exchange(dycore.h, cb, None))
+            dt = dycore.compute_time_step(coupler)
+            for _ in range(nsteps):
+                dycore.time_step(coupler, dt)
+            torch.cuda.synchronize()
+            results[rank] = (coupler.grid.i_beg, coupler.grid.j_beg, gpu_fields(coupler))
+        except Exception as e:                                          # pragma: no cover
+            ex.errors.append("rank %d: %r" % (rank, e))
+            ex.bar.abort()
+
+    ths = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not ex.errors, ex.errors
+    coupler, dycore, _, _ = modules.make_simple_city(nxg, nyg, nz, 1, xlen, ylen, zlen, "city")
+    dt = dycore.compute_time_step(coupler)
+    for _ in range(nsteps):
+        dycore.time_step(coupler, dt)
+    ref = gpu_fields(coupler)
+    assert float(np.abs(ref["uvel"]).max()) > 1.0                      # the flow is there
+    for ib, jb, blk in results:
+        for k, a in blk.items():
+            ny, nx = a.shape[1], a.shape[2]
+            assert np.array_equal(a, ref[k][:, jb:jb + ny, ib:ib + nx]), (k, ib, jb)
+
+
 def test_two_ranks_2d(mw):
     run_ranks(2, 64, 1, 16, 1, 3)           # 2x1: west == east peer
 
