@@ -57,9 +57,11 @@ def parse():
     ap.add_argument("--cpu-sample", type=str, default="200x200x50", help="oracle sample grid nx x ny x nz")
     ap.add_argument("--strict", type=int, default=0)
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl", help="halo-exchange transport for N > 1")
-    ap.add_argument("--workload", choices=["config2", "config4"], default="config2",
+    ap.add_argument("--workload", choices=["config2", "config4", "config5"], default="config2",
                     help="config2 (default): BASELINE.json configs[1], 400x400x100 nens 1 per GPU, dx 500 m.  config4: configs[3]'s per-GPU "
-                         "block 256x512x128 nens 4, dx 800 m (weak-scaling series 256x512 ... 1024x1024 global for 1 ... 8 GPUs)")
+                         "block 256x512x128 nens 4, dx 800 m (weak-scaling series 256x512 ... 1024x1024 global for 1 ... 8 GPUs).  config5: configs[4], "
+                         "simple_city 512x512x256 per GPU (immersed buildings, gravity off, water vapour only: V = 6), dx = dy = dz = 5 m; "
+                         "--full-loop adds Horizontal_Sponge, sponge_layer and Time_Averager (experiments/simple_city/driver.cpp:66-79)")
     ap.add_argument("--ord", type=int, default=5, choices=[3, 5, 7, 9], help="WENO order (the reference's -DMW_ORD; 5 = its default and the headline; "
                     "3 = the order its GPU benchmark environment builds, build/machines/aws/aws_a100_gpu.env:21)")
     ap.add_argument("--storm-steps", type=int, default=2600, help="steps of the complete supercell loop before the 'storm' dycore timing of the "
@@ -68,6 +70,9 @@ def parse():
     a = ap.parse_args()
     if a.workload == "config4":
         a.nx, a.ny, a.nz, a.nens = 256, 512, 128, 4
+    if a.workload == "config5":
+        a.nx, a.ny, a.nz, a.nens = 512, 512, 256, 1
+        a.no_cpu_baseline = True                                 # (the CPU sample is a supercell run)
     return a
 
 
@@ -247,10 +252,15 @@ def main():
     capi.check(L.mw_decompose(world, rank, a.nx * world, a.ny * world if a.ny > 1 else 1, C.byref(g0)))   # only to learn nproc_x/y
     npx, npy = g0.nproc_x, g0.nproc_y
     nx_glob, ny_glob = a.nx * npx, (a.ny * npy if a.ny > 1 else 1)
-    dxy = 800.0 if a.workload == "config4" else 500.0              # input_euler3d_1024x1024x100.yaml: xlen = 819200 / 1024 cells
+    dxy = 800.0 if a.workload == "config4" else 5.0 if a.workload == "config5" else 500.0   # input_euler3d_1024x1024x100.yaml: xlen = 819200 / 1024 cells
     xlen, ylen, zlen = dxy * nx_glob, dxy * max(ny_glob, 1) if ny_glob > 1 else dxy * a.ny, 20000.0
     nudger = None
-    if a.full_loop:
+    city = None
+    if a.workload == "config5":
+        zlen = 5.0 * a.nz
+        coupler, dycore, hs_, ta_ = modules.make_simple_city(nx_glob, ny_glob, a.nz, 1, xlen, ylen, zlen, "city", device, nranks=world, myrank=rank)
+        micro, city = None, (hs_, ta_)
+    elif a.full_loop:
         coupler, dycore, micro, nudger = modules.make_supercell(nx_glob, ny_glob, a.nz, a.nens, xlen, ylen, zlen, "supercell", device,
                                                                 nranks=world, myrank=rank, with_nudger=True, ord=a.ord)
     else:
@@ -271,6 +281,9 @@ def main():
             torch.cuda.synchronize()
 
     def step():
+        if city is not None and a.full_loop:                      # experiments/simple_city/driver.cpp:66-79
+            modules.simple_city_step(coupler, dycore, city[0], city[1])
+            return
         dycore.time_step(coupler, dt)
         if nudger is not None:                                   # experiments/supercell_example/driver.cpp:74-76
             micro.time_step(coupler, dt)
@@ -373,13 +386,16 @@ def main():
             except Exception:
                 traffic = dom_traffic = valu_side = None
         what = "complete supercell_example loop: WENO-FV dycore + Kessler + sponge_layer + ColumnNudger" if a.full_loop else "WENO-FV dycore only"
+        if city is not None:
+            what = "complete simple_city loop: Horizontal_Sponge + WENO-FV dycore + sponge_layer + Time_Averager" if a.full_loop else "WENO-FV dycore only"
         out = {
             "metric": "cell-updates/s" + (" (full supercell_example loop)" if a.full_loop else "") + (" (MW_ORD = %d)" % a.ord if a.ord != 5 else ""), "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "supercell %dx%dx%d nens=%d per GPU (global %dx%dx%d, dx = dy = %g m), %s, 3 tracers, "
-                                   "CFL dt" % (a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz, dxy, what),
-                       "baseline_config": "configs[3] per-GPU block" if a.workload == "config4" else "configs[1]",
+            "config": {"workload": "%s %dx%dx%d nens=%d per GPU (global %dx%dx%d, dx = dy = %g m), %s, %d tracer%s, "
+                                   "CFL dt" % ("simple_city" if city is not None else "supercell", a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz, dxy, what,
+                                               V - 5, "" if V == 6 else "s"),
+                       "baseline_config": "configs[3] per-GPU block" if a.workload == "config4" else "configs[4] per-GPU block" if city is not None else "configs[1]",
                        "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict, "weno_order": a.ord,
                        "schedule": ("two streams (state | tracers, tracer stream at high priority)" if two_streams else
                                     "one compute stream, strip exchange on a side stream beside the inner y chunks / the tracer stage" if pipelined else "one stream"),
@@ -413,7 +429,7 @@ def main():
             "kernel_ms_per_step": {k: v[0] / 3.0 for k, v in prof.items()},
             "kernel_ms_per_step_exclusive": ({k: v[0] / 3.0 for k, v in prof_excl.items()} if prof_excl else None),
         }
-        if world == 1 and not a.no_micro and not a.strict:
+        if world == 1 and not a.no_micro and not a.strict and city is None:
             out.update(micro_section(torch, modules, coupler, dycore, micro, dt, a))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
