@@ -19,6 +19,9 @@
 #include "mw_weno.h"
 #include "mw_glibc_pow.h"
 #include <vector>
+#include <map>
+#include <tuple>
+#include <mutex>
 #include <cmath>
 #include <cstring>
 #include <random>
@@ -941,6 +944,9 @@ struct mw_dycore_s {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[9];       // kernel classes 0..7; 8 = one whole RK stage (all its launches)
   size_t ev_used[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   void (*xchg_free)(void *) = nullptr;       // set when the handle owns xchg_ctx (the built-in RCCL transport, mw_rccl.cpp)
+  // balanced launch lists (pick_sched): per (columns, cells, resident workgroups) the Sched with its device table
+  std::map<std::tuple<long long, int, int>, mw::Sched> sched_cache;
+  std::map<std::tuple<long long, int, int>, int> sched_n2;
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Padding the blocks-per-plane count to a
@@ -1225,6 +1231,83 @@ static int balanced_chunk(int nz, long long base_waves, const char *env, long lo
   return (best < 0.97 * cost_of(old_chunk)) ? best_chunk : old_chunk;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The balanced schedule of the marching kernels (Sched, mw_march.h; round 4, an experiment that is kept behind MW_SCHED): a launch whose
+// workgroups are a longest-first list -- whole columns, then equal slices of the remaining columns sized for P = CUs x resident
+// workgroups per CU.  Against equal chunks this halves the ghost iterations (a whole column has none inside) and removes the partly
+// filled last round of workgroups; measured, it does not pay (see pick_sched).  The residency comes from the runtime's occupancy query
+// for the very kernel instantiation (registers, LDS), cached per kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef MW_SCHED_DEFAULT_MASK
+#define MW_SCHED_DEFAULT_MASK 7
+#endif
+static int device_cus() {
+  static int n = -1;
+  if (n < 0) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; else n = 0; }
+  return n;
+}
+static int resident_blocks(const void *fn, size_t lds) {
+  static std::mutex mu; static std::map<std::pair<const void *, size_t>, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto key = std::make_pair(fn, lds);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+  cache[key] = nb;
+  return nb;
+}
+// -> the schedule of one launch; `grid` becomes the list's length when the balanced form applies.  N columns of `len` cells; classic =
+// chunks of `chunk`.  The list of a (N, len, P) triple -- the order of the straddling slices' second parts -- is built once per handle.
+static Sched classic_sched(int len, int chunk) { Sched sc = {0, 0, 0, len, chunk, 0, nullptr}; return sc; }
+static Sched pick_sched(mw_dycore_s *d, const void *fn, size_t lds_balanced, long long N, int len, int chunk, dim3 &grid, int which) {
+  Sched sc = classic_sched(len, chunk);
+  // MW_SCHED: 0 (default) the chunked grid; 1 the balanced lists where a launch has >= 16 cells per workgroup; 2 forced (tests).
+  // Measured (round 4, 400 x 400 x 100, two boxes, three interleaved repetitions each): k_y_all 1.47 -> 1.83 ms per step with the lists
+  // (its chunks keep x-adjacent workgroups on the same row at the same time -- DRAM pages are read out whole; slices start anywhere),
+  // k_xz_state 1.98-2.03 -> 2.01-2.04, k_tracers_fused 1.70 -> 1.65-1.68: -1 % of the step at best with the mask 6, so the default stays 0.
+  const char *e = getenv("MW_SCHED");
+  const int mode = e ? atoi(e) : 0;
+  const char *m = getenv("MW_SCHED_MASK");                      // bit 0: k_y_all, bit 1: k_xz_state, bit 2: k_tracers_fused
+  const int mask = m ? atoi(m) : MW_SCHED_DEFAULT_MASK;
+  if (mode == 0 || !((mask >> which) & 1) || d->overlap || N < 1 || N > 0x3fffffff || len < 1) return sc;
+  const int cus = device_cus(), occ = cus > 0 ? resident_blocks(fn, lds_balanced) : 0;
+  if (occ < 1) return sc;
+  const long long P = (long long)cus * occ;
+  if (mode != 2 && N * len < P * 16) return sc;                 // small launches: the chunk model of balanced_chunk
+  const auto key = std::make_tuple(N, len, (int)P);
+  auto it = d->sched_cache.find(key);
+  if (it == d->sched_cache.end()) {
+    Sched n = {(int)P, 0, (int)N, len, 0, 0, nullptr};
+    const long long q = N / P, R = N - q * P;
+    n.W = (int)(q * P);
+    if (R) {
+      long long piece = (R * len + P - 1) / P;
+      if (piece < 8) piece = std::min<long long>(len, 8);        // (a segment re-primes its pipeline: none shorter than 8 cells)
+      n.piece = (int)piece;
+      n.nsl = (int)((R * len + piece - 1) / piece);
+      std::vector<std::pair<long long, int>> second;            // (cells behind the column boundary inside the slice, slice)
+      for (int sl = 0; sl < n.nsl; sl++) {
+        const long long g0 = sl * piece, g1 = std::min(g0 + piece, R * len), c = g0 / len, rest = g1 - (c + 1) * len;
+        if (rest > 0) second.push_back({rest, sl});
+      }
+      std::sort(second.begin(), second.end(), [](const std::pair<long long, int> &a, const std::pair<long long, int> &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+      std::vector<int> tab; for (auto &pr : second) tab.push_back(pr.second);
+      if (!tab.empty()) {
+        int *dev = nullptr;
+        if (hipMalloc(&dev, tab.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return sc; }
+        if (hipMemcpy(dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dev); return sc; }
+        n.tab = dev;
+      }
+      d->sched_n2[key] = (int)tab.size();
+    } else d->sched_n2[key] = 0;
+    it = d->sched_cache.emplace(key, n).first;
+  }
+  sc = it->second;
+  grid = dim3((unsigned)(sc.W + sc.nsl + d->sched_n2[key]));
+  return sc;
+}
+
 // Which compile-time configuration of the marching kernels (Cf<K>) fits this view of the handle: 1 / 2 = the shipped supercell /
 // simple_city set-ups with their run-time switches folded, 0 = everything at run time.  MW_NO_SPEC=1 forces 0 (A/B timing, tests).
 static int marching_config(const DyP &p) {
@@ -1305,6 +1388,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
   if (conv && d->member_major) {                                // mm_direct: all members in one launch, the members of the same cells in one workgroup
     const View v = view(d, 0);
     const DyP &p = v.p;
+    if (!d->mm_direct || marching_config(p) == 0) MW_FAIL("internal: the converting k_y_all of a member-major handle exists for 2 or 4 members of a folded configuration only");
     const MemberOff mo = member_off(d);
     const long long mthreads = (long long)p.nz * p.nx;
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (mthreads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
@@ -1314,7 +1398,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
       const int n = (int)grid.y;
       row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk);
     }
-#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end)
+#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, classic_sched(row_end - row0, chunk))
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
     if (marching_config(p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
@@ -1341,8 +1425,11 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
         if (split) { chunk = MW_Y_EDGE; rstride = p.ny - MW_Y_EDGE; grid.y = 2u; }
       }
     }
-#define MW_YA(C_, K_, O_, T_) hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), grid, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
-                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end)
+    // (part 0 / 1 = one contiguous row range [row0, row_end): the balanced schedule applies; the two edge strips of part 2 stay chunks)
+#define MW_YA(C_, K_, O_, T_) do { dim3 g_ = grid; const Sched sc_ = (part == 2) ? classic_sched(row_end - row0, chunk) : \
+                                  pick_sched(d, (const void *)&k_y_all<C_, K_, O_, T_>, 0, (long long)grid.x, row_end - row0, chunk, g_, 0); \
+                                hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), g_, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
+                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_); } while (0)
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
     const int K = marching_config(p);
@@ -1414,7 +1501,7 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
       const size_t lds = (size_t)(chunk + 2) * 64 * 4;
 #define MW_XZ_MT(K_) { if (d->ord == 3) MW_XZ_MTO(K_, 3); else MW_XZ_MTO(K_, 5); }
 #define MW_XZ_MTO(K_, O_) hipLaunchKernelGGL((k_xz_state<3, true, 1, 1, K_, O_, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
-                                        d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo)
+                                        d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo, classic_sched(p.nz, chunk))
       if (marching_config(p) == 1) MW_XZ_MT(1) else MW_XZ_MT(0)
 #undef MW_XZ_MT
 #undef MW_XZ_MTO
@@ -1431,8 +1518,11 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
     unsigned char *UX = d->UP[par][0] + e * v.m[0], *UZ = d->UP[par][2] + e * v.m[2];
     // nens == 1 (also: one member of a member-major handle): the per-level background values come through LDS
     // (k_xz_state<.., HPL = 1>; dynamic LDS = the chunk's rows)
-#define MW_XZ(N1_, HPL_, K_, O_, lds) hipLaunchKernelGGL((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), grid, dim3(256), lds, d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
-                                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, MemberOff())
+    // (balanced schedule: a segment can be a whole column -- the LDS table then holds nz + 2 rows)
+#define MW_XZ(N1_, HPL_, K_, O_, lds) do { dim3 g_ = grid; const size_t lds_bal_ = (lds) ? (size_t)(p.nz + 2) * 64 : 0; \
+                                        const Sched sc_ = pick_sched(d, (const void *)&k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>, lds_bal_, (long long)grid.x, p.nz, chunk, g_, 1); \
+                                        hipLaunchKernelGGL((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), g_, dim3(256), sc_.P ? lds_bal_ : (lds), d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
+                                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, MemberOff(), sc_); } while (0)
 #define MW_XZ_K(K_) { if (d->ord == 3) MW_XZ(true, 1, K_, 3, hpl_bytes); else MW_XZ(true, 1, K_, 5, hpl_bytes); }
     const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
     if (p.nens == 1) {
@@ -1493,9 +1583,10 @@ template <int STAGE, int MODE, int T, bool N1, int K, int ORD = 5>
 static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
   const int e = v.e;
+  const Sched sc = pick_sched(d, (const void *)&k_tracers_fused<STAGE, MODE, T, N1, K, ORD>, 0, (long long)grid.x, v.p.nz, chunk, grid, 2);
   hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1, K, ORD>), grid, dim3(256), 0, st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
                      d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
-                     d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4, MemberOff());
+                     d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4, MemberOff(), sc);
 }
 // x/z tracer fluxes + FCT + update in one kernel, then the (normally empty) y-face correction
 template <int STAGE, int MODE>
@@ -1516,7 +1607,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
 #define MW_FUSED_MT(TT) case TT: MW_FUSED_MTK(TT, 0) break;
 #define MW_FUSED_MTK(TT, K_) { if (d->ord == 3) MW_FUSED_MTO(TT, K_, 3); else MW_FUSED_MTO(TT, K_, 5); }
 #define MW_FUSED_MTO(TT, K_, O_) hipLaunchKernelGGL((k_tracers_fused<3, 1, TT, true, K_, O_, true>), grid, dim3(256), 0, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
-                                 d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo)
+                                 d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo, classic_sched(p.nz, chunk))
       if (marching_config(p) == 1) MW_FUSED_MTK(3, 1)
       else switch (p.nt) { MW_FUSED_MT(1) MW_FUSED_MT(2) MW_FUSED_MT(3) MW_FUSED_MT(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
 #undef MW_FUSED_MT
@@ -1817,6 +1908,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
   for (int w = 0; w < 9; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto &kv : d->sched_cache) if (kv.second.tab) (void)hipFree(const_cast<int *>(kv.second.tab));
   delete d;
 }
 
@@ -2015,6 +2107,10 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   // edge-strip y launch reads are converted up front; the inner rows are converted by the first k_y_all<true> while the strips travel.
   const bool pipe_conv = d->pipe && (!d->member_major || (d->mm_direct && !getenv("MW_NO_MM_CONV") && marching_config(view(d, 0).p) != 0)) && p.nt <= 3 &&
                          !getenv("MW_NO_FUSED_CONVERT") && !getenv("MW_NO_PIPE_CONVERT") && (d->p.wrap_y || p.ny >= 4 * MW_Y_EDGE);
+  // (the pipelined schedule converts inside k_y_all<true> ONLY in the forms pipe_conv names: any other handle -- e.g. three members, or a
+  //  member-major handle whose configuration is not a folded one -- gets the full conversion pass below; without this a 1 x 1
+  //  decomposition with a transport installed (both wraps on) reached the members-in-one-workgroup launch with the wrong kernel)
+  if (d->pipe) d->conv_pending = false;
   if (pipe_conv) {
     ProfScope ps(d, 4);
     const int ylo = d->p.wrap_y ? 0 : MW_Y_EDGE + 3, yhi = d->p.wrap_y ? p.ny : p.ny - MW_Y_EDGE - 3;

@@ -94,6 +94,49 @@ __device__ __forceinline__ BlockXY xcd_block() {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Which (column, [a, b)) SEGMENT of the marching direction a workgroup processes (round 4).
+//   classic  (P == 0): blockIdx.x = column, blockIdx.y = chunk of `piece` cells.  Every chunk pays its ghost iterations (2 / 4 / 2
+//             for k_xz_state / k_tracers_fused / k_y_all) and the launch ends with a partly filled round of workgroups: 4 x 25
+//             levels on 400 x 400 x 100 are 5.47 rounds of the 512 workgroups the chip holds.
+//   balanced (P > 0 = the workgroups the chip holds at once): a one-dimensional launch whose workgroups are a LIST in dispatch order,
+//             longest items first, so that the hardware's in-order dispatch (next workgroup to the first free slot) is a greedy
+//             longest-first list schedule:
+//               W = q P whole columns                   (no ghost iterations inside a column; all in step from cell 0, so x-adjacent
+//                                                        tiles still meet in L2);
+//               the remaining R = N - W columns laid end to end and cut into `nsl` equal slices of `piece` cells (R len / P each):
+//               the part of a slice up to the first column boundary inside it ...
+//               ... and, for the slices that straddle a boundary, the part behind it: `n2` workgroups ordered by decreasing
+//               length (tab[] = their slices).  A straddling slice's first part is short, ends early, and the slot it frees takes the
+//               longest waiting second part -- its own -- so every slot ends after ~len q + piece cells.
+//   (A persistent form -- one workgroup looping over its segments -- keeps every kernel argument alive across the marching loop:
+//    60-160 SGPR spills in kernels that sit at the register limit.  One segment per workgroup costs nothing.)
+// ---------------------------------------------------------------------------------------------------------------
+struct Sched { int P, W, N, len, piece, nsl; const int *__restrict__ tab; };
+struct Segment { unsigned col; int a, b; };
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg) {   // (see xcd_block: blocks b, b + 8, ... share an XCD)
+#if MW_XCD_SWIZZLE
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+#else
+  return b;
+#endif
+}
+__device__ __forceinline__ bool sched_segment(const Sched &sc, Segment &sg) {
+  if (sc.P == 0) { const BlockXY blk = xcd_block(); sg.col = blk.x; sg.a = (int)blk.y * sc.piece; sg.b = min(sg.a + sc.piece, sc.len); return true; }
+  unsigned b = blockIdx.x;
+  if (b < (unsigned)sc.W) { sg.col = xcd_remap(b, (unsigned)sc.W); sg.a = 0; sg.b = sc.len; return true; }
+  b -= (unsigned)sc.W;                                          // (W is a multiple of 8: the XCD of the block is b % 8 still)
+  const bool second = b >= (unsigned)sc.nsl;
+  const long long sl = second ? sc.tab[b - (unsigned)sc.nsl] : xcd_remap(b, (unsigned)sc.nsl);
+  const long long R = sc.N - sc.W;
+  const long long g0 = sl * sc.piece, g1 = min(g0 + sc.piece, R * sc.len);
+  const int c = (int)(g0 / sc.len);
+  if (!second) { sg.col = (unsigned)(sc.W + c); sg.a = (int)(g0 - (long long)c * sc.len); sg.b = (int)min((long long)sc.len, sg.a + (g1 - g0)); return sg.b > sg.a; }
+  sg.col = (unsigned)(sc.W + c + 1); sg.a = 0; sg.b = (int)(g1 - (long long)(c + 1) * sc.len);   // (piece <= len: one boundary at most)
+  return sg.b > 0;
+}
+
 // Periodic direction owned by one rank (DyP::wrap_x / wrap_y): the interior index that a halo index stands for.
 __device__ __forceinline__ int wrap_xq(const DyP &p, int q, int NXI) { return p.wrap_x ? (q < 0 ? q + NXI : (q >= NXI ? q - NXI : q)) : q; }
 __device__ __forceinline__ int wrap_row(const DyP &p, int j) { return p.wrap_y ? (j < 0 ? j + p.ny : (j >= p.ny ? j - p.ny : j)) : j; }
@@ -570,21 +613,26 @@ __device__ __forceinline__ double tracer_slab_value(double rho_t, double inv_den
 // (see MemberOff) -- the converting launch of such a handle.
 template <bool CONV, int K, int ORD, int T, bool MT = false>
 __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk,
-                                               CouplerPtrs c, double *__restrict__ Sw, MemberOff mo, int row0, int rstride, int row_end) {
+                                               CouplerPtrs c, double *__restrict__ Sw, MemberOff mo, int row0, int rstride, int row_end, Sched sc) {
   static_assert(!MT || CONV, "the member-co-located form exists for the converting launch only");
   constexpr int NV = 5 + T;
   const int NXI = p.nx * p.nens;
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;       // flattened (k, ie): no idle tail per row
+  __shared__ double lds_fprev[CONV ? 5 : 1][CONV ? 256 : 1];
+  int mt_sub = 0;
   if (MT) {                                                      // (p = one member's view: nens = 1, cst = the member count)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), em = wv & (mo.n - 1);
-    t = ((long long)blockIdx.x * (4 >> mo.sh) + (wv >> mo.sh)) * 64 + (threadIdx.x & 63);
+    mt_sub = wv >> mo.sh;
     FY += em * mo.fy; tendY += em * mo.tend; Sw += em * mo.slab; S += em * mo.slab; p.hypk += em * mo.per; p.ce = em;
   }
+  // (sc.P > 0: the balanced schedule -- this workgroup's thread column and row segment [ja, jb) come from the launch's list, see Sched)
+  unsigned colx; int ja, jb;
+  if (sc.P) { Segment sg; if (!sched_segment(sc, sg)) return; colx = sg.col; ja = row0 + sg.a; jb = row0 + sg.b; }   // (sc.len = row_end - row0)
+  else { colx = blockIdx.x; ja = row0 + (int)blockIdx.y * rstride; jb = min(ja + chunk, row_end); }   // (a launch covers the rows [row0, row_end) in chunks `rstride` rows apart: all of them, the inner ones, or the two edge strips)
+  long long t = (long long)colx * 256 + threadIdx.x;             // flattened (k, ie): no idle tail per row
+  if (MT) t = ((long long)colx * (4 >> mo.sh) + mt_sub) * 64 + (threadIdx.x & 63);
   if (t >= (long long)p.nz * NXI) return;
   const int k = (int)(t / NXI);
   const int ie = (int)(t - (long long)k * NXI);
-  const int ja = row0 + (int)blockIdx.y * rstride;               // (a launch covers the rows [row0, row_end) in chunks `rstride` rows apart: all of them, the inner ones, or the two edge strips)
-  const int jb = min(ja + chunk, row_end);
   const int e = ie % p.nens;
   const double *hp = p.hypk + (long long)(k * p.nens + e) * 8;
   const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
@@ -593,7 +641,6 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
   constexpr int HS = (ORD - 1) / 2;
   double w[NV][ORD], nxt[NV], cn[NV], fprev_r[CONV ? 1 : 5];
-  __shared__ double lds_fprev[CONV ? 5 : 1][CONV ? 256 : 1];
 #define MW_ROW_CI(r) cpl(p, ((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
 #define MW_ROW_FINISH(raw, r, out)                                                                                    \
   { double inv_den_;                                                                                                  \
@@ -682,10 +729,14 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
       double fp[5];
 #pragma unroll
       for (int l = 0; l < 5; l++) fp[l] = CONV ? lds_fprev[l][threadIdx.x] : fprev_r[l];
+#ifndef MW_EXP_NO_TENDY                                         // (timing experiment, DESIGN.md 0c: what the y-tendency hand-off costs)
       if (j > ja) {
 #pragma unroll
         for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fp[l]) * p.rdy;
       }
+#else
+      if (j > ja && f[0] == 1.2345e300) ty[(long long)(j - 1) * NXI] = -(f[0] - fp[0]) * p.rdy + f[1] + f[2] + f[3] + f[4] + fp[1] + fp[2] + fp[3] + fp[4];
+#endif
 #pragma unroll
       for (int l = 0; l < 5; l++) { if (CONV) lds_fprev[l][threadIdx.x] = f[l]; else fprev_r[l] = f[l]; }
     }
@@ -728,8 +779,9 @@ struct XzGeom {
 // (nens == 1: hs + 1 halo lanes per side -- hs stencil cells and one more so that the west neighbour's east-edge value is rebuilt in
 //  the wave: 58 cells per wave for WENO-5, 60 for WENO-3)
 __host__ __device__ __forceinline__ int xz_cells_per_wave(int nens, int ord = 5) { return nens == 1 ? 64 - 2 * ((ord - 1) / 2 + 1) : 64 - 2 * nens; }
+// (colx = the workgroup's column of wavefronts, [ka, kb) = the levels it marches: from the launch grid or the balanced schedule, see Sched)
 template <bool N1, int ORD = 5>
-__device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, int rows4 = 0, int wslot = -1, int wpb = 4) {
+__device__ __forceinline__ XzGeom xz_geom(const DyP &p, unsigned colx, int ka, int kb, int tiles_x, int rows4 = 0, int wslot = -1, int wpb = 4) {
   static_assert(N1 || ORD == 5, "the neighbour-load form (nens > 1 in the fused layout) exists for WENO-5 only");
   constexpr int HS = (ORD - 1) / 2;
   XzGeom g;
@@ -739,11 +791,10 @@ __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, 
   const int hw = N1 ? HS + 1 : 1;                             // halo cells per side
   const int U = 64 - 2 * hw * g.n;                            // cells (fused) a wave completes
   g.cell_lo = hw * g.n; g.cell_hi = 64 - hw * g.n; g.face_hi = N1 ? 64 - HS * g.n : 64;
-  const BlockXY blk = xcd_block();
   // (wslot / wpb: a block of the member-transposing form holds the nens members of 4 / nens tiles -- MemberOff below)
-  const long long wid = (long long)blk.x * wpb + (wslot < 0 ? (int)(threadIdx.x >> 6) : wslot);   // wave id -> (row j, x tile)
+  const long long wid = (long long)colx * wpb + (wslot < 0 ? (int)(threadIdx.x >> 6) : wslot);   // wave id -> (row j, x tile)
   int tx;
-  if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); g.j = jg * 4 + (threadIdx.x >> 6); }
+  if (rows4) { const int jg = (int)(colx / tiles_x); tx = (int)(colx - (unsigned)jg * tiles_x); g.j = jg * 4 + (threadIdx.x >> 6); }
   else       { g.j = (int)(wid / tiles_x); tx = (int)(wid - (long long)g.j * tiles_x); }
   g.valid = g.j < p.ny;                                       // whole wave
   g.q = tx * U - hw * g.n + g.lane;                           // interior fused-x index of this lane (may be in the halo)
@@ -757,8 +808,8 @@ __device__ __forceinline__ XzGeom xz_geom(const DyP &p, int chunk, int tiles_x, 
   g.qa = wrap_xq(p, g.qq, g.NXI);
   g.om2 = wrap_xq(p, g.qq - 2 * g.n, g.NXI) - g.qa; g.om1 = wrap_xq(p, g.qq - g.n, g.NXI) - g.qa;       // qq in [-n, NXI+n): all four stay
   g.op1 = wrap_xq(p, g.qq + g.n, g.NXI) - g.qa;     g.op2 = wrap_xq(p, g.qq + 2 * g.n, g.NXI) - g.qa;   // inside the 3-cell halo
-  g.ka = blk.y * chunk;
-  g.kb = min(g.ka + chunk, p.nz);
+  g.ka = ka;
+  g.kb = kb;
   g.kstart = (g.ka == 0) ? 0 : g.ka - 1;                      // no ghost cell below the wall
   return g;
 }
@@ -792,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
                                                   unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                   const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
                                                   int tiles_x, double *__restrict__ cu, double *__restrict__ cv, double *__restrict__ cw,
-                                                  MemberOff mo) {
+                                                  MemberOff mo, Sched sc) {
   static_assert(!MT || (N1 && HPL && MODE == 1), "the member-co-located form is the D13 variant of the nens == 1 kernel");
   constexpr int HS = (ORD - 1) / 2;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -802,17 +853,21 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
     S += mt_e * mo.slab; Sn += mt_e * mo.slab; Sout += mt_e * mo.slab; MX += mt_e * mo.mx; UPX += mt_e * mo.mx; MZ += mt_e * mo.mz; UPZ += mt_e * mo.mz;
     tendY += mt_e * mo.tend; p.hypk += mt_e * mo.per; p.ce = mt_e;
   }
-  const XzGeom g = xz_geom<N1, ORD>(p, chunk, tiles_x, 0, MT ? mt_sub : -1, MT ? 4 >> mo.sh : 4);
+  __shared__ double lds_c[8];
+  __shared__ double lds_xpart[5][256], lds_fzprev[5][256];
+  extern __shared__ double lds_hp_all[];
+  Segment sg;                                                   // (from the launch grid or the balanced schedule's list, see Sched)
+  if (!sched_segment(sc, sg)) return;
+  const XzGeom g = xz_geom<N1, ORD>(p, sg.col, sg.a, sg.b, tiles_x, 0, MT ? mt_sub : -1, MT ? 4 >> mo.sh : 4);
+  const int seg_len = sg.b - sg.a;
   // HPL (nens == 1): the eight background values of every level of this chunk (DyP::hypk rows kstart..kb) are copied to LDS once
   // and read from there (a broadcast read, issued with the iteration's other loads).  Read as scalar loads they were placed right
   // in front of their first use -- the kernel has no spare SGPRs to hold them any earlier -- and their latency was exposed three
   // times per level (-1 % kernel time).  All 256 threads copy, also those of waves beyond the last row, which leave right after.
-  extern __shared__ double lds_hp_all[];
-  double *lds_hp = lds_hp_all + (MT ? wv * (chunk + 2) * 8 : 0);     // (MT: one table per wave -- the members' backgrounds differ)
+  double *lds_hp = lds_hp_all + (MT ? wv * (seg_len + 2) * 8 : 0);     // (MT: one table per wave -- the members' backgrounds differ)
   // ... and so do the few uniform doubles of the finalisation (grid spacings, the stage's time-step factors, gravity): as kernel
   // arguments they occupy 12 SGPRs for the whole loop in a kernel that spills SGPRs to VGPR lanes (every spilled one comes back as a
   // v_readlane, a VALU instruction); as broadcast LDS reads they are VGPR operands where they are used.
-  __shared__ double lds_c[8];
   if (HPL) {
     const int nrow = g.kb - g.kstart + 1;
     if (MT) { for (int i = g.lane; i < nrow * 8; i += 64) lds_hp[i] = p.hypk[(long long)g.kstart * 8 + i]; }
@@ -832,7 +887,6 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   // The two per-cell carries that are written once and read once per level (the x+y part of the tendency and the lower z-face
   // flux) live in LDS, one private slot per thread: 20 VGPRs less in a kernel that sits at the 256-register limit (measured:
   // -5 % run time; moving more carries there, or doing the same in k_y_state / k_tracers_fused, was slower).
-  __shared__ double lds_xpart[5][256], lds_fzprev[5][256];
   double w[5][ORD], nxt[5], ct[5];
 #pragma unroll
   for (int v = 0; v < 5; v++) {
@@ -863,10 +917,12 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
 #pragma unroll
       for (int l = 0; l < 5; l++) snv[l] = Sn[(long long)l * p.sV + slab0 + (long long)(kfc + p.HZ) * p.sK];
     }
+#ifndef MW_EXP_NO_TENDY
     if (!Cf<K>::sim2d(p)) {
 #pragma unroll
       for (int l = 0; l < 5; l++) tyv[l] = tendY[(long long)l * p.nC + cell0 + (long long)kxc * planeC];
     }
+#endif
     if (Cf<K>::immersed(p)) immv = p.imm[cpl(p, cell0 + (long long)kfc * planeC)];
     double hpl[8];
     if (HPL) {
@@ -1045,7 +1101,8 @@ __global__ __launch_bounds__(256) void k_xz_tracers(DyP p, const double *__restr
                                                     const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
                                                     const unsigned char *__restrict__ UPZ, double dt, int chunk, int tiles_x, int t0,
                                                     int rows4) {
-  const XzGeom g = xz_geom<N1>(p, chunk, tiles_x, rows4);
+  const BlockXY blk_ = xcd_block();
+  const XzGeom g = xz_geom<N1>(p, blk_.x, (int)blk_.y * chunk, min((int)blk_.y * chunk + chunk, p.nz), tiles_x, rows4);
   if (!g.valid) return;
   const int n = g.n, lane = g.lane, NXI = g.NXI, j = g.j, q = g.q;
   const double *col = S + (long long)(5 + t0) * p.sV + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qa;
@@ -1245,7 +1302,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
                                                        const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
                                                        const unsigned char *__restrict__ UPZ, double *__restrict__ DS,
                                                        double *__restrict__ DN, unsigned char *__restrict__ flags, unsigned int *__restrict__ dirty,
-                                                       double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4, MemberOff mo) {
+                                                       double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4, MemberOff mo, Sched sc) {
   static_assert(N1 || ORD == 5, "the neighbour-load form exists for WENO-5 only");
   static_assert(!MT || (N1 && MODE == 1), "the member-co-located form (see MemberOff) is the D13 variant of the nens == 1 kernel");
   constexpr int HS = (ORD - 1) / 2;
@@ -1268,17 +1325,18 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   // (58 cells per wave: 7 instead of 8 waves per 400-cell row).  nens > 1: neighbour loads, 2 cells per side.
   const int hw = N1 ? HS + 1 : 2;                             // (WENO-3: 2 lanes per side, 60 cells per wave)
   const int U = 64 - 2 * hw * n;
+  constexpr bool LC = true;
+  __shared__ double lds_c[8];
+  Segment sg;                                                   // (from the launch grid or the balanced schedule's list, see Sched)
+  if (!sched_segment(sc, sg)) return;
   int j, tx;
-  const BlockXY blk = xcd_block();
-  if (MT)         { const int rpb = 4 >> mo.sh, jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); j = jg * rpb + mt_sub; }   // rows of one tile
-  else if (rows4) { const int jg = (int)(blk.x / tiles_x); tx = (int)(blk.x - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
-  else            { const long long wid = (long long)blk.x * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
+  if (MT)         { const int rpb = 4 >> mo.sh, jg = (int)(sg.col / tiles_x); tx = (int)(sg.col - (unsigned)jg * tiles_x); j = jg * rpb + mt_sub; }   // rows of one tile
+  else if (rows4) { const int jg = (int)(sg.col / tiles_x); tx = (int)(sg.col - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }
+  else            { const long long wid = (long long)sg.col * 4 + (threadIdx.x >> 6); j = (int)(wid / tiles_x); tx = (int)(wid - (long long)j * tiles_x); }
   // (MODE 1: D13's pressure comes out of the result slab -- k_xz_state<3, ., 1> evaluated the series and left p in the (rho theta)'
   //  slot -- so this kernel needs neither the series nor its three background values per level.)
   // the uniform doubles of the loop (reciprocal grid spacings, time-step factors) as broadcast LDS reads instead of resident SGPRs
   // (as in k_xz_state: the kernel spills SGPRs to VGPR lanes)
-  constexpr bool LC = true;
-  __shared__ double lds_c[8];
   if (LC && threadIdx.x < 8) {
     const double cdt = (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;
     lds_c[threadIdx.x] = threadIdx.x == 0 ? p.rdx : threadIdx.x == 1 ? p.rdy : threadIdx.x == 2 ? p.rdz : threadIdx.x == 3 ? dt : threadIdx.x == 4 ? cdt : 0.0;
@@ -1308,7 +1366,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const long long fzo = (long long)j * p.fzJ + qm;
   const long long fyo = (long long)j * p.fyJ + qm;
   const bool do_y = !Cf<K>::sim2d(p);
-  const int ka = blk.y * chunk, kb = min(ka + chunk, p.nz);
+  const int ka = sg.a, kb = sg.b;
   const int k_lo = max(ka - 1, 0);                            // cells k_lo .. k_hi get all six fluxes (FCT multiplier)
   const int k_hi = min(kb, p.nz - 1);
   const int kstart = max(ka - 2, 0);

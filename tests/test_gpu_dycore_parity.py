@@ -75,6 +75,28 @@ def test_time_steps_match_oracle(mw, oracle, name, mode):
     assert abs(dycore.etime - 10 * dt) < 1e-12
 
 
+@pytest.mark.parametrize("name", sorted(SNAP["cases"]))
+def test_balanced_schedule_bitwise_equal_to_chunked_grid(mw, oracle, name, monkeypatch):
+    """The marching kernels' balanced launch lists (round 4: whole columns first, then equal slices of the remaining columns, the parts
+    of a slice behind a column boundary last; MW_SCHED=2 forces them at any size) only re-partition the marching direction: the
+    production path's results are BITWISE those of the chunked grid (MW_SCHED=0), and match the oracle."""
+    res = {}
+    for sched in ("0", "2"):
+        monkeypatch.setenv("MW_SCHED", sched)
+        coupler, dycore, odyc, of = setup_case(oracle, SNAP["cases"][name])
+        push_fields(coupler, of)
+        dt = dycore.compute_time_step(coupler)
+        for _ in range(3):
+            dycore.time_step(coupler, dt)
+        res[sched] = gpu_fields(coupler)
+    for k in res["0"]:
+        assert np.array_equal(res["0"][k], res["2"][k]), k
+    for _ in range(3):
+        odyc.time_step(of, dt)
+    sens = case_sensitivity(oracle, name, (3,)) if sens_allowed(name) else {3: None}
+    compare_fields(res["2"], of.as_dict(), 1e-10, "%s mode 0 balanced schedule, 3 steps" % name, sens[3])
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_compute_tendencies_and_fluxes(mw, oracle, mode):
     coupler, dycore, odyc, of = setup_case(oracle, SNAP["cases"]["supercell3d_16x16x8"])

@@ -136,6 +136,18 @@ def test_four_ranks_simple_city(mw):
             assert np.array_equal(a, ref[k][:, jb:jb + ny, ib:ib + nx]), (k, ib, jb)
 
 
+def test_one_rank_with_exchange_installed_three_members(mw):
+    """A 1 x 1 decomposition WITH a transport installed (both index wraps on, pipelined schedule selected): three members have no
+    members-in-one-workgroup launch, so the handle must take the full conversion pass instead of the converting k_y_all (round 3's
+    advisor finding: the K = 2 kernel was launched for this K = 0 configuration).  Bitwise against the handle without a transport."""
+    run_ranks(1, 40, 24, 8, 3, 2)
+
+
+def test_one_rank_with_exchange_installed_four_members(mw):
+    """... and four members (members-in-one-workgroup form exists: D1 inside the first k_y_all of the pipelined schedule)."""
+    run_ranks(1, 64, 40, 8, 4, 2)
+
+
 def test_two_ranks_2d(mw):
     run_ranks(2, 64, 1, 16, 1, 3)           # 2x1: west == east peer
 

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Builds gpurun_out-independent VARIANTS of libmw_cdna4.so with extra hipcc flags for A/B timing (MW_LIB_PATH selects one at run time):
-#   bash tools/build_variant.sh <name> <extra flags...>   ->  miniweatherml_amd/variants/libmw_<name>.so
+#   bash tools/build_variant.sh <name> <extra flags...>   ->  miniweatherml_amd/ab/libmw_<name>.so
 set -e
 name=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=${MW_SRC_DIR:-$R/miniweatherml_amd/csrc}     # MW_SRC_DIR: another checkout's csrc (e.g. `git archive <rev>` for a same-box baseline)
-mkdir -p $R/miniweatherml_amd/variants /tmp/mwvar_$name
+mkdir -p $R/miniweatherml_amd/ab /tmp/mwvar_$name
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -Wno-unused-function -Wno-unused-variable -ffp-contract=on -I/opt/rocm/include"
 objs=""
 for s in mw_host.cpp mw_dycore.hip mw_kessler.hip mw_mlp.hip mw_column.hip mw_output.hip mw_netcdf.cpp mw_rccl.cpp mw_h5.cpp; do
@@ -16,5 +16,5 @@ for s in mw_host.cpp mw_dycore.hip mw_kessler.hip mw_mlp.hip mw_column.hip mw_ou
   objs="$objs $o"
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/miniweatherml_amd/variants/libmw_$name.so $objs -ldl
-echo built $R/miniweatherml_amd/variants/libmw_$name.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/miniweatherml_amd/ab/libmw_$name.so $objs -ldl
+echo built $R/miniweatherml_amd/ab/libmw_$name.so
