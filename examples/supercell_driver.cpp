@@ -51,7 +51,10 @@ int main(int argc, char **argv) {
     (void)hipMemcpy(r.data(), dm.get<real>("density_dry").data(), n * 8, hipMemcpyDeviceToHost);
     double maxw = 0, sum = 0;
     for (size_t i = 0; i < n; i++) { maxw = std::max(maxw, std::fabs(w[i])); sum += r[i]; }
-    printf("etime %.17g maxw %.17e sum_density_dry %.17e steps_per_s %.4f\n", etime, maxw, sum, nsteps / el);
+    // the reference's only built-in health check (DataManager::validate_all, DataManager.h:385-387): NaN / inf everywhere, negative
+    // values in the positive-definite entries -- one device pass per entry here
+    const long long bad = dm.validate_all(false);
+    printf("etime %.17g maxw %.17e sum_density_dry %.17e steps_per_s %.4f validate_all %lld\n", etime, maxw, sum, nsteps / el, bad);
   } catch (std::exception &e) { fprintf(stderr, "endrun: %s\n", e.what()); return 1; }
   return 0;
 }

@@ -245,6 +245,16 @@ int  mw_mlp_forward(long long ncells, const double *temp, const double *rho_d, c
  * microphysics_kessler_ponni.h:103-110); 0 (default): the MFMA kernels (the same products summed in the matrix cores' order). */
 int  mw_mlp_set_strict(int strict);
 
+/* ponni's own surface: ponni::Inference<...>::forward_batch_parallel(float2d in(num_in, batch)) -> float2d
+ * (num_out, batch), experiments/supercell_kessler_surrogate/custom_modules/microphysics_kessler_ponni.h:40-45,103-110,189, for a stack
+ * of ponni::Matvec<float> (kind 0: weights (n_in, n_out) in Keras order, y = x W), ponni::Bias<float> (kind 1) and ponni::Relu<float>(n,
+ * negative_slope) (kind 2) layers.  layers / params: HOST memory (params = all weights back to back, `offset` in floats); in / out:
+ * DEVICE fp32, batch fastest.  The surrogate's stack (5 -> 10 -> 4) runs on the MFMA tiles, any other stack of up to 10 layers, widths
+ * <= 32 and 960 parameters on a thread-per-element kernel; a size mismatch between consecutive layers is an error (Inference::validate). */
+typedef struct { int kind, n_in, n_out; float negative_slope; int offset; } mw_ponni_layer_t;
+int  mw_ponni_forward(const mw_ponni_layer_t *layers, int nlayers, const float *params, int nparams, long long batch,
+                      const float *in, float *out, void *stream);
+
 /* ---- file output ------------------------------------------------------------ */
 /* A minimal netCDF *classic* writer (mw_netcdf.cpp): the reference writes through PnetCDF with NC_CLOBBER | NC_64BIT_DATA,
  * i.e. the CDF-5 on-disk format, dims x,y,z (+ unlimited t), double variables, no attributes
@@ -304,6 +314,15 @@ int  mw_micro_sample_mask(const mw_grid_t *g, const double *const *in4, const do
                           double thr_active, double thr_inactive, unsigned char *mask, void *stream);
 int  mw_micro_gather_samples(const mw_grid_t *g, const double *rho_d, const double *const *in4, const double *const *out4,
                              const long long *cells, long long n, float *inputs, float *outputs, void *stream);
+
+/* ---- DataManager validators ---------------------------------------------------------------------------- */
+/* core::DataManager::validate / validate_nan / validate_inf / validate_pos (model/core/DataManager.h:385-483) -- the reference's only
+ * built-in health check: it copies an entry to the host and loops over it.  Here ONE device pass over the entry's `n` elements
+ * (DEVICE pointer): out6[0..2] = number of NaN / inf / negative elements, out6[3..5] = the lowest flat ("global") index of each
+ * kind, i.e. the first one the reference's loop reports, or -1.  The caller decides which of the three apply (negative values only
+ * matter for entries registered `positive`, :469) and whether to die (die_on_failed_check).  Synchronises the stream. */
+int  mw_validate_f64(const double *field, long long n, long long *out6, void *stream);
+int  mw_validate_f32(const float *field, long long n, long long *out6, void *stream);
 
 #ifdef __cplusplus
 }

@@ -50,10 +50,10 @@ def build_examples(verbose=True):
     """The C++ callers of examples/ (mirrors of the reference's drivers) against the C++ facade + C ABI."""
     root = os.path.dirname(HERE)
     exes = []
-    for name in ("supercell_driver", "simple_city_driver"):
+    for name in ("supercell_driver", "simple_city_driver", "inference_ponni_driver"):
         src = os.path.join(root, "examples", name + ".cpp")
         exe = os.path.join(root, "examples", name)
-        deps = [src, os.path.join(HERE, "host", "mw_facade.h"), os.path.join(root, "include", "mw_cdna4.h"), LIB]
+        deps = [src, os.path.join(HERE, "host", "mw_facade.h"), os.path.join(HERE, "host", "mw_ponni.h"), os.path.join(root, "include", "mw_cdna4.h"), LIB]
         if _stale(exe, deps):
             cmd = [HIPCC, "-O2", "-std=c++17", "-x", "c++", src, "-o", exe, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
                    "-L" + HERE, "-lmw_cdna4", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../miniweatherml_amd",

@@ -113,6 +113,9 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p]),
     "mw_micro_gather_samples": (C.c_int, [C.POINTER(Grid), C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_longlong,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mw_ponni_forward": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mw_validate_f64": (C.c_int, [C.c_void_p, C.c_longlong, C.POINTER(C.c_longlong), C.c_void_p]),
+    "mw_validate_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.POINTER(C.c_longlong), C.c_void_p]),
     "mw_mlp_forward": (C.c_int, [C.c_longlong] + [C.c_void_p] * 5 + [C.POINTER(C.c_float)] * 4 +
                        [C.POINTER(C.c_double)] * 2 + [C.c_void_p] * 4 + [C.c_void_p]),
 }

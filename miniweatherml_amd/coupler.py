@@ -52,6 +52,79 @@ class DataManager:
     def entry_exists(self, name):
         return name in self.entries
 
+    def unregister_and_deallocate(self, name):                  # :199-203
+        self._find_entry_or_error(name)
+        del self.entries[name]
+
+    # ---- dirty flags (:206-237): set by every non-const get ----
+    def clean_all_entries(self):
+        for e in self.entries.values():
+            e["dirty"] = False
+
+    def clean_entry(self, name):
+        self._find_entry_or_error(name)["dirty"] = False
+
+    def entry_is_dirty(self, name):
+        return self._find_entry_or_error(name)["dirty"]
+
+    def get_dirty_entries(self):
+        return [k for k, e in self.entries.items() if e["dirty"]]
+
+    def _find_entry_or_error(self, name):                       # :505-511
+        if name not in self.entries:
+            endrun("ERROR: Attempting to retrieve variable name [" + name + "], but it doesn't exist. ")
+        return self.entries[name]
+
+    # ---- validators (:385-483).  The reference copies every array to the host ("This is EXPENSIVE"); here one device pass per entry
+    # (mw_validate_f64 / _f32: counts and the first flat index of NaN / inf / negative elements).  A failed check prints the
+    # reference's warning (first offending index) to stderr and ends the run when die_on_failed_check.  Returns the findings. ----
+    def _scan(self, name):
+        e = self._find_entry_or_error(name)
+        t = e["data"]
+        if t.dtype not in (torch.float64, torch.float32):       # integer / bool entries: no NaN / inf; negatives only for signed ints
+            neg = (t < 0) if t.dtype in (torch.int8, torch.int16, torch.int32, torch.int64) else None
+            n_neg = int(neg.sum()) if neg is not None else 0
+            first = int(neg.view(-1).nonzero()[0]) if n_neg else -1
+            return e, [0, 0, n_neg, -1, -1, first]
+        out = (C.c_longlong * 6)()
+        fn = capi.lib().mw_validate_f64 if t.dtype == torch.float64 else capi.lib().mw_validate_f32
+        capi.check(fn(t.data_ptr(), t.numel(), out, torch.cuda.current_stream(t.device).cuda_stream))
+        return e, list(out)
+
+    def _report(self, what, name, count, first, die):
+        if count:
+            import sys
+            print("WARNING: %s discovered in: %s at global index: %d  (%d element%s)" % (what, name, first, count, "" if count == 1 else "s"),
+                  file=sys.stderr)
+            if die:
+                endrun("")
+        return count
+
+    def validate_nan(self, name, die_on_failed_check=False):    # :402-418
+        _, r = self._scan(name)
+        return self._report("NaN", name, r[0], r[3], die_on_failed_check)
+
+    def validate_inf(self, name, die_on_failed_check=False):    # :421-428
+        _, r = self._scan(name)
+        return self._report("inf", name, r[1], r[4], die_on_failed_check)
+
+    def validate_pos(self, name, die_on_failed_check=False):    # :431-441, :471-483: only entries registered positive
+        e, r = self._scan(name)
+        if not e["positive"]:
+            return 0
+        return self._report("negative value in positive-definite entry", name, r[2], r[5], die_on_failed_check)
+
+    def validate(self, name, die_on_failed_check=False):        # :393-397 (one scan for the three checks)
+        e, r = self._scan(name)
+        bad = self._report("NaN", name, r[0], r[3], die_on_failed_check)
+        bad += self._report("inf", name, r[1], r[4], die_on_failed_check)
+        if e["positive"]:
+            bad += self._report("negative value in positive-definite entry", name, r[2], r[5], die_on_failed_check)
+        return bad
+
+    def validate_all(self, die_on_failed_check=False):          # :385-387
+        return sum(self.validate(n, die_on_failed_check) for n in list(self.entries))
+
     def get(self, name, readonly=False):                        # :246-286
         if name not in self.entries:
             endrun("ERROR: Could not find entry name: " + name)

@@ -1001,6 +1001,25 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       fzs[idV] = fs.m_upw * (up ? be[idV] : ct[idV]);
       upz = up;
     }
+#ifdef MW_EXP_MOCK_Y
+    // Timing experiment, never a product path: the ARITHMETIC a y direction inside this kernel would add at the very
+    // least -- five reconstructions and one Riemann solve per level, on register data (the window's values in another order, so that
+    // nothing is shared with the z reconstruction) -- without the LDS tile, the barriers, the halo rows or the tile-edge faces a
+    // real fused kernel needs on top.  Together with MW_EXP_NO_TENDY (no y-tendency hand-off) it bounds such a kernel from below.
+    {
+      double ys[5], yn[5];
+#pragma unroll
+      for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][1], w[v][0], w[v][HS], w[v][ORD - 1], w[v][ORD - 2], ys[v], yn[v]);
+      const double *hp = p.hypk + (long long)(k * n + e) * 8;
+      const double hyr = HPL ? hpl[0] : hp[0], hyt = HPL ? hpl[1] : hp[1], p0 = HPL ? hpl[2] : hp[2], ihyt = HPL ? hpl[3] : hp[3];
+      double fn, fT;
+      FaceState fs = riemann_primary<K>(p, yn[idR] + hyr, ys[idR] + hyr, yn[idV], ys[idV], yn[idT], ys[idT], hyt, p0, ihyt, false, fn, fT);
+      const double z0 = lds_c[7];                               // (0 at run time, unknown to the compiler: the mock values are computed and do not disturb the run)
+      tyv[idR] += -(fs.m_upw - ct[idR]) * z0; tyv[idV] += -(fn - ct[idV]) * z0; tyv[idT] += -(fT - ct[idT]) * z0;
+      tyv[idU] += -(fs.m_upw * (fs.ind ? ys[idU] : yn[idU]) - ct[idU]) * z0;
+      tyv[idW] += -(fs.m_upw * (fs.ind ? ys[idW] : yn[idW]) - ct[idW]) * z0;
+    }
+#endif
     // ------------------------------------------------ all loads of this iteration have landed (see landed()); its stores follow
     landed(nxt); landed(snv); landed(tyv); landed(immv);
     if (xwork && g.owns_face && (g.owns_cell || q >= NXI)) {

@@ -18,6 +18,8 @@
 #include "mw_common.h"
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <algorithm>
 
 namespace mw {
 
@@ -140,6 +142,74 @@ __global__ __launch_bounds__(256) void k_mlp_x2(MlpP P, long long ncells, const 
   }
 }
 
+
+// ponni::Inference::forward_batch_parallel for the surrogate's stack on fp32 arrays in ponni's own layout -- in (5, batch), out (4, batch),
+// batch fastest (microphysics_kessler_ponni.h:176-189: ponni_in(feature, iglob)) -- with the same MFMA tiles as k_mlp: lane group g
+// reads feature g's row (64 contiguous bytes per group and tile), output n leaves from group n.  The activation slope is an argument
+// (ponni::Relu<float>(n, negative_slope), :105).
+template <int TILES>
+__global__ __launch_bounds__(256) void k_mlp_f32(MlpP P, float slope, long long batch, const float *__restrict__ in, float *__restrict__ out) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, cidx = lane & 15;
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * 256) >> 6;
+  const float *in_g = in + (long long)g * batch, *in_4 = in + 4 * batch;
+  float *out_g = out + (long long)g * batch;
+  const float a10 = P.a1[0][lane], a11 = P.a1[1][lane];
+  const float a20 = P.a2[0][lane], a21 = P.a2[1][lane], a22 = P.a2[2][lane];
+  const f32x4 c1 = {P.c1[g][0], P.c1[g][1], P.c1[g][2], P.c1[g][3]};
+  const f32x4 c2 = {P.c2[g], 0.f, 0.f, 0.f};
+  const long long ntiles = (batch + 15) / 16;
+  for (long long t0 = wave * TILES; t0 < ntiles; t0 += nwaves * TILES) {
+    float x0[TILES], x4[TILES];
+#pragma unroll
+    for (int u = 0; u < TILES; u++) {
+      const long long cell = (t0 + u) * 16 + cidx;
+      const bool ok = cell < batch;
+      x0[u] = ok ? in_g[cell] : 0.f;
+      x4[u] = (ok && g == 0) ? in_4[cell] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < TILES; u++) {
+      const long long cell = (t0 + u) * 16 + cidx;
+      f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a10, x0[u], c1, 0, 0, 0);
+      d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a11, x4[u], d1, 0, 0, 0);
+      const float h0 = d1[0] > 0.f ? d1[0] : slope * d1[0], h1 = d1[1] > 0.f ? d1[1] : slope * d1[1], h2 = d1[2] > 0.f ? d1[2] : slope * d1[2];
+      f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a20, h0, c2, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a21, h1, d2, 0, 0, 0);
+      d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a22, h2, d2, 0, 0, 0);
+      if (cell < batch) out_g[cell] = d2[0];
+    }
+  }
+}
+
+// Any other stack of ponni layers (Matvec / Bias / Relu), and the strict form of the surrogate's: thread = one batch element, every
+// layer a plain fp32 loop in index order (Matvec: acc = 0; acc += x[i] * W[i][o] for i = 0 .. n_in - 1), no contraction.
+#define MW_PONNI_MAX_LAYERS 10                                  // (microphysics_kessler_ponni.h:32)
+#define MW_PONNI_MAX_WIDTH 32
+#define MW_PONNI_MAX_PARAMS 960
+struct PonniStack { int nlayers; int kind[MW_PONNI_MAX_LAYERS], n_in[MW_PONNI_MAX_LAYERS], n_out[MW_PONNI_MAX_LAYERS], off[MW_PONNI_MAX_LAYERS];
+                    float slope[MW_PONNI_MAX_LAYERS]; float params[MW_PONNI_MAX_PARAMS]; };
+__global__ __launch_bounds__(256) void k_ponni_generic(PonniStack P, long long batch, const float *__restrict__ in, float *__restrict__ out) {
+#pragma clang fp contract(off)
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (c >= batch) return;
+  float a[MW_PONNI_MAX_WIDTH], b[MW_PONNI_MAX_WIDTH];
+  int n = P.n_in[0];
+  for (int i = 0; i < n; i++) a[i] = in[(long long)i * batch + c];
+  for (int l = 0; l < P.nlayers; l++) {
+    const float *w = P.params + P.off[l];
+    if (P.kind[l] == 0) {                                        // Matvec: weights (n_in, n_out), y = x W
+      for (int o = 0; o < P.n_out[l]; o++) { float acc = 0.f; for (int i = 0; i < n; i++) acc += a[i] * w[i * P.n_out[l] + o]; b[o] = acc; }
+      n = P.n_out[l];
+      for (int o = 0; o < n; o++) a[o] = b[o];
+    } else if (P.kind[l] == 1) { for (int o = 0; o < n; o++) a[o] = a[o] + w[o]; }
+    else { const float sl = P.slope[l]; for (int o = 0; o < n; o++) a[o] = a[o] > 0.f ? a[o] : sl * a[o]; }
+  }
+  for (int o = 0; o < n; o++) out[(long long)o * batch + c] = a[o];
+}
+
 } // namespace mw
 
 using namespace mw;
@@ -179,6 +249,29 @@ __global__ __launch_bounds__(256) void k_mlp_strict(MlpRef P, long long n, const
   rho_c_out[c] = fmax(0.0, y[2] * P.out_rng[2] + P.out_min[2]);
   rho_r_out[c] = fmax(0.0, y[3] * P.out_rng[3] + P.out_min[3]);
 }
+// The MFMA operand images of the 5 -> 10 -> 4 stack (see the header of this file): A operands per lane, C initialisers = the biases.
+static void build_operand_images(MlpP &P, const float *W1, const float *b1, const float *W2, const float *b2) {
+  memset(&P, 0, sizeof(P));
+  auto rho = [](int u) { return (u / 3) * 4 + (u % 3); };      // hidden unit u -> D1 row with row % 4 < 3
+  for (int lane = 0; lane < 64; lane++) {
+    int o = lane & 15, g = lane >> 4;
+    int u = -1;
+    for (int uu = 0; uu < 10; uu++) if (rho(uu) == o) u = uu;
+    for (int m = 0; m < 2; m++) { int in = 4 * m + g; P.a1[m][lane] = (u >= 0 && in < 5) ? W1[in * 10 + u] : 0.f; }
+    int n = (o % 4 == 0) ? o / 4 : -1;                          // output n lives at row 4n
+    for (int j = 0; j < 3; j++) {
+      int row = 4 * g + j, uk = -1;                             // k-slot g of MFMA j is hidden row 4g + j
+      for (int uu = 0; uu < 10; uu++) if (rho(uu) == row) uk = uu;
+      P.a2[j][lane] = (n >= 0 && uk >= 0) ? W2[uk * 4 + n] : 0.f;
+    }
+  }
+  for (int g = 0; g < 4; g++) {
+    for (int r = 0; r < 4; r++) { int row = 4 * g + r, u = -1; for (int uu = 0; uu < 10; uu++) if (rho(uu) == row) u = uu;
+                                  P.c1[g][r] = (u >= 0) ? b1[u] : 0.f; }
+    P.c2[g] = b2[g];
+  }
+}
+
 static int g_mlp_strict = 0;
 extern "C" int mw_mlp_set_strict(int strict) { g_mlp_strict = strict ? 1 : 0; return 0; }
 
@@ -201,25 +294,7 @@ extern "C" int mw_mlp_forward(long long ncells, const double *temp, const double
     return 0;
   }
   MlpP P;          // operand images built per call (cheap: 104 weights)
-  memset(&P, 0, sizeof(P));
-  auto rho = [](int u) { return (u / 3) * 4 + (u % 3); };      // hidden unit u -> D1 row with row % 4 < 3
-  for (int lane = 0; lane < 64; lane++) {
-    int o = lane & 15, g = lane >> 4;
-    int u = -1;
-    for (int uu = 0; uu < 10; uu++) if (rho(uu) == o) u = uu;
-    for (int m = 0; m < 2; m++) { int in = 4 * m + g; P.a1[m][lane] = (u >= 0 && in < 5) ? W1[in * 10 + u] : 0.f; }
-    int n = (o % 4 == 0) ? o / 4 : -1;                          // output n lives at row 4n
-    for (int j = 0; j < 3; j++) {
-      int row = 4 * g + j, uk = -1;                             // k-slot g of MFMA j is hidden row 4g + j
-      for (int uu = 0; uu < 10; uu++) if (rho(uu) == row) uk = uu;
-      P.a2[j][lane] = (n >= 0 && uk >= 0) ? W2[uk * 4 + n] : 0.f;
-    }
-  }
-  for (int g = 0; g < 4; g++) {
-    for (int r = 0; r < 4; r++) { int row = 4 * g + r, u = -1; for (int uu = 0; uu < 10; uu++) if (rho(uu) == row) u = uu;
-                                  P.c1[g][r] = (u >= 0) ? b1[u] : 0.f; }
-    P.c2[g] = b2[g];
-  }
+  build_operand_images(P, W1, b1, W2, b2);
   for (int i = 0; i < 5; i++) { P.in_min[i] = scl_in[i * 2 + 0]; P.in_rng[i] = scl_in[i * 2 + 1] - scl_in[i * 2 + 0]; }
   for (int i = 0; i < 4; i++) { P.out_min[i] = scl_out[i * 2 + 0]; P.out_rng[i] = scl_out[i * 2 + 1] - scl_out[i * 2 + 0]; }
   constexpr int TILES = 4, PAIRS = 2;
@@ -248,5 +323,52 @@ extern "C" int mw_mlp_forward(long long ncells, const double *temp, const double
                        rho_c + bulk, rho_r + bulk, temp_out + bulk, rho_v_out + bulk, rho_c_out + bulk, rho_r_out + bulk);
     MW_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// ponni::Inference<...>::forward_batch_parallel (microphysics_kessler_ponni.h:189) for a stack of ponni layers on fp32 device arrays in
+// ponni's layout: in (n_in of the first layer, batch), out (n_out of the last, batch), batch fastest.  layers / params: HOST memory
+// (params = the layers' weights back to back: a Matvec's (n_in, n_out) kernel in Keras order, a Bias's vector; offsets in floats).
+// The surrogate's stack Matvec(5,10), Bias(10), Relu(10), Matvec(10,4), Bias(4) runs on the MFMA tiles; any other stack that fits
+// the limits (MW_PONNI_MAX_*), and every stack under mw_mlp_set_strict(1), on the thread-per-element kernel (index order, no contraction).
+extern "C" int mw_ponni_forward(const mw_ponni_layer_t *layers, int nlayers, const float *params, int nparams, long long batch,
+                                const float *in, float *out, void *stream) {
+  if (!layers || nlayers < 1 || !params || nparams < 0 || !in || !out) MW_FAIL("ponni_forward: null argument");
+  if (batch < 1) MW_FAIL("ponni_forward: batch must be >= 1");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  if (nlayers > MW_PONNI_MAX_LAYERS) MW_FAIL("ponni_forward: more than " + std::to_string(MW_PONNI_MAX_LAYERS) + " layers");
+  if (nparams > MW_PONNI_MAX_PARAMS) MW_FAIL("ponni_forward: more than " + std::to_string(MW_PONNI_MAX_PARAMS) + " parameters");
+  // Inference::validate(): every layer's input size is its predecessor's output size, parameters inside the buffer
+  int width = layers[0].n_in;
+  for (int l = 0; l < nlayers; l++) {
+    const mw_ponni_layer_t &L = layers[l];
+    if (L.kind < 0 || L.kind > 2) MW_FAIL("ponni_forward: unknown layer kind");
+    if (L.n_in != width) MW_FAIL("ponni_forward: layer " + std::to_string(l) + " expects " + std::to_string(L.n_in) + " inputs but its predecessor provides " + std::to_string(width));
+    if (L.kind != 0 && L.n_out != L.n_in) MW_FAIL("ponni_forward: Bias / Relu layers keep the size");
+    if (L.n_in < 1 || L.n_out < 1 || L.n_in > MW_PONNI_MAX_WIDTH || L.n_out > MW_PONNI_MAX_WIDTH) MW_FAIL("ponni_forward: layer width outside [1, " + std::to_string(MW_PONNI_MAX_WIDTH) + "]");
+    const long long need = L.kind == 0 ? (long long)L.n_in * L.n_out : L.kind == 1 ? L.n_out : 0;
+    if (need && (L.offset < 0 || L.offset + need > nparams)) MW_FAIL("ponni_forward: layer parameters outside the buffer");
+    width = L.n_out;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const bool surrogate = nlayers == 5 && layers[0].kind == 0 && layers[0].n_in == 5 && layers[0].n_out == 10 && layers[1].kind == 1 &&
+                         layers[2].kind == 2 && layers[3].kind == 0 && layers[3].n_out == 4 && layers[4].kind == 1;
+  if (surrogate && !g_mlp_strict) {
+    MlpP P;
+    build_operand_images(P, params + layers[0].offset, params + layers[1].offset, params + layers[3].offset, params + layers[4].offset);
+    constexpr int TILES = 4;
+    long long blocks = (((batch + 15) / 16 + TILES - 1) / TILES + 3) / 4;
+    blocks = std::max<long long>(1, std::min<long long>(blocks, 256 * 16));
+    hipLaunchKernelGGL(k_mlp_f32<TILES>, dim3((unsigned)blocks), dim3(256), 0, st, P, layers[2].negative_slope, batch, in, out);
+    MW_LAUNCH_CHECK();
+    return 0;
+  }
+  PonniStack S;
+  memset(&S, 0, sizeof(S));
+  S.nlayers = nlayers;
+  for (int l = 0; l < nlayers; l++) { S.kind[l] = layers[l].kind; S.n_in[l] = layers[l].n_in; S.n_out[l] = layers[l].n_out; S.off[l] = layers[l].offset; S.slope[l] = layers[l].negative_slope; }
+  memcpy(S.params, params, sizeof(float) * (size_t)nparams);
+  hipLaunchKernelGGL(k_ponni_generic, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st, S, batch, in, out);
+  MW_LAUNCH_CHECK();
   return 0;
 }

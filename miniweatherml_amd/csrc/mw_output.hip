@@ -166,6 +166,29 @@ static int six_ptrs(double *const *p, Six &s, const char *what) {
 
 namespace mw { int nc_staging(mw_nc_t nc, size_t bytes, double **dev, double **host); }   // mw_netcdf.cpp
 
+// DataManager::validate_single_nan / _inf / _pos (model/core/DataManager.h:446-483) as ONE pass over the device array: the reference
+// copies the array to the host and loops.  out[0..2] = how many NaN / inf / negative elements, out[3..5] = the lowest flat index of
+// each kind (the first one the reference's loop would report; ~0 = none).  grid-stride, wave reduction, one atomic per wave and kind.
+template <class T>
+__global__ __launch_bounds__(256) void k_validate(const T *__restrict__ a, long long n, unsigned long long *__restrict__ out) {
+  unsigned long long cnt[3] = {0, 0, 0}, first[3] = {~0ull, ~0ull, ~0ull};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const T v = a[i];
+    const bool hit[3] = {v != v, (v - v != (T)0) && (v == v), v < (T)0};           // NaN; inf (finite - finite = 0); negative
+#pragma unroll
+    for (int c = 0; c < 3; c++) if (hit[c]) { cnt[c]++; if ((unsigned long long)i < first[c]) first[c] = (unsigned long long)i; }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    for (int off = 32; off > 0; off >>= 1) {
+      cnt[c] += __shfl_down(cnt[c], off, 64);
+      const unsigned long long o = __shfl_down(first[c], off, 64);
+      if (o < first[c]) first[c] = o;
+    }
+    if ((threadIdx.x & 63) == 0 && cnt[c]) { atomicAdd(&out[c], cnt[c]); atomicMin(&out[3 + c], first[c]); }
+  }
+}
+
 extern "C" {
 
 int mw_output_put_field(mw_nc_t nc, int varid, long long record, const mw_grid_t *g, const double *field, void *stream) {
@@ -276,6 +299,29 @@ int mw_mean_diff(long long n, const double *a, const double *b, double *workspac
   *mean_out = sum / (double)n;
   return 0;
 }
+
+static int validate_any(const void *field, long long n, int is_f32, long long *out6, void *stream) {
+  if (!field || n < 1 || !out6) MW_FAIL("mw_validate: bad argument");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long *dev = nullptr, host[6] = {0, 0, 0, ~0ull, ~0ull, ~0ull};
+  MW_HIP(hipMalloc(&dev, sizeof(host)));
+  int rc = 0;
+  if (hipMemcpyAsync(dev, host, sizeof(host), hipMemcpyHostToDevice, st) != hipSuccess) rc = 1;
+  const unsigned nb = (unsigned)std::min<long long>(4096, (n + 255) / 256);
+  if (!rc) {
+    if (is_f32) hipLaunchKernelGGL(k_validate<float>, dim3(nb), dim3(256), 0, st, (const float *)field, n, dev);
+    else        hipLaunchKernelGGL(k_validate<double>, dim3(nb), dim3(256), 0, st, (const double *)field, n, dev);
+    if (hipGetLastError() != hipSuccess) rc = 1;
+  }
+  if (!rc && (hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = 1;
+  (void)hipFree(dev);
+  if (rc) MW_FAIL("mw_validate: device operation failed");
+  for (int c = 0; c < 3; c++) { out6[c] = (long long)host[c]; out6[3 + c] = host[c] ? (long long)host[3 + c] : -1; }
+  return 0;
+}
+int mw_validate_f64(const double *field, long long n, long long *out6, void *stream) { return validate_any(field, n, 0, out6, stream); }
+int mw_validate_f32(const float *field, long long n, long long *out6, void *stream) { return validate_any(field, n, 1, out6, stream); }
 
 int mw_time_average_accumulate(const mw_grid_t *g, const double *const *fields6, double *const *avg6, double etime, double dt, void *stream) {
   if (!g) MW_FAIL("time_average_accumulate: null argument");

@@ -20,6 +20,7 @@
 #include "../../include/mw_cdna4.h"
 #include <hip/hip_runtime_api.h>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -102,6 +103,43 @@ class DataManager {                                                   // model/c
   template <class T> DeviceView<T> get_collapsed(const std::string &name) { auto v = get<T>(name); return DeviceView<T>{v.ptr, {(int)v.size()}}; }   // :333-365
   bool get_dirty(const std::string &n) const { int id = find_entry(n); return id >= 0 && entries[id].dirty; }
   void clean_all() { for (auto &e : entries) e.dirty = false; }
+  // ---- the rest of the reference's public surface -------------------------------------------------------------------------------
+  int find_entry_or_error(const std::string &n) const {                                                         // :505-511
+    int id = find_entry(n); if (id < 0) endrun("ERROR: Attempting to retrieve variable name [" + n + "], but it doesn't exist. "); return id; }
+  void unregister_and_deallocate(const std::string &n) {                                                        // :199-203
+    int id = find_entry_or_error(n); if (entries[id].ptr) (void)hipFree(entries[id].ptr); entries.erase(entries.begin() + id); }
+  void clean_all_entries() { clean_all(); }                                                                     // :208-210
+  void clean_entry(const std::string &n) { entries[find_entry_or_error(n)].dirty = false; }                     // :215-218
+  bool entry_is_dirty(const std::string &n) const { return entries[find_entry_or_error(n)].dirty; }             // :223-226
+  std::vector<std::string> get_dirty_entries() const { std::vector<std::string> r; for (auto &e : entries) if (e.dirty) r.push_back(e.name); return r; }   // :231-237
+  // validators (:385-483).  The reference copies each array to the host ("This is EXPENSIVE"); here one device pass per entry
+  // (mw_validate_f64 / _f32).  Same warnings on std::cerr (the first offending flat index), endrun when die_on_failed_check.
+  // Entries of other types (bool, integers) hold no NaN / inf; their sign check is not needed by any shipped module.
+ private:
+  bool scan(int id, long long *r) const {
+    const Entry &e = entries[id];
+    if (e.type_hash == typeid(double).hash_code()) { mw_check(mw_validate_f64((const double *)e.ptr, (long long)(e.bytes / sizeof(double)), r, nullptr)); return true; }
+    if (e.type_hash == typeid(float).hash_code())  { mw_check(mw_validate_f32((const float *)e.ptr, (long long)(e.bytes / sizeof(float)), r, nullptr)); return true; }
+    return false;
+  }
+  static long long report(const char *what, const std::string &n, long long count, long long first, bool die) {
+    if (count) { fprintf(stderr, "WARNING: %s discovered in: %s at global index: %lld\n", what, n.c_str(), first); if (die) endrun(""); }
+    return count;
+  }
+ public:
+  long long validate_nan(const std::string &n, bool die_on_failed_check = false) const {                       // :402-418
+    long long r[6]; int id = find_entry_or_error(n); return scan(id, r) ? report("NaN", n, r[0], r[3], die_on_failed_check) : 0; }
+  long long validate_inf(const std::string &n, bool die_on_failed_check = false) const {                       // :421-428
+    long long r[6]; int id = find_entry_or_error(n); return scan(id, r) ? report("inf", n, r[1], r[4], die_on_failed_check) : 0; }
+  long long validate_pos(const std::string &n, bool die_on_failed_check = false) const {                       // :431-441, :471-483
+    long long r[6]; int id = find_entry_or_error(n); if (!entries[id].positive || !scan(id, r)) return 0;
+    return report("negative value discovered in positive-definite entry", n, r[2], r[5], die_on_failed_check); }
+  long long validate(const std::string &n, bool die_on_failed_check = false) const {                           // :393-397 (one scan for the three checks)
+    long long r[6]; int id = find_entry_or_error(n); if (!scan(id, r)) return 0;
+    long long bad = report("NaN", n, r[0], r[3], die_on_failed_check) + report("inf", n, r[1], r[4], die_on_failed_check);
+    if (entries[id].positive) bad += report("negative value discovered in positive-definite entry", n, r[2], r[5], die_on_failed_check);
+    return bad; }
+  long long validate_all(bool die_on_failed_check = false) const { long long bad = 0; for (auto &e : entries) bad += validate(e.name, die_on_failed_check); return bad; }   // :385-387
 };
 
 class Coupler {                                                       // model/core/coupler.h:17-493

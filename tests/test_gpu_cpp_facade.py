@@ -18,9 +18,10 @@ def run_driver(*args):
         build.build_examples(verbose=False)
     out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    m = re.search(r"etime (\S+) maxw (\S+) sum_density_dry (\S+) steps_per_s (\S+)", out.stdout)
+    m = re.search(r"etime (\S+) maxw (\S+) sum_density_dry (\S+) steps_per_s (\S+) validate_all (\d+)", out.stdout)
     assert m, out.stdout
-    return [float(v) for v in m.groups()]
+    assert int(m.group(5)) == 0                               # DataManager::validate_all after the run: no NaN / inf / negative tracer
+    return [float(v) for v in m.groups()[:4]]
 
 
 def test_cpp_driver_matches_oracle_known_answers(mw, oracle):
