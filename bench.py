@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--storm-steps", type=int, default=2600, help="steps of the complete supercell loop before the 'storm' dycore timing of the "
                     "micro section (0 = skip)")
     ap.add_argument("--no-micro", action="store_true", help="skip the Kessler / MLP / developed-state section after the timed region")
+    ap.add_argument("--timeout-s", type=float, default=float(os.environ.get("MW_BENCH_TIMEOUT_S", "900")),
+                    help="wall-clock limit of a run: a rank that has not finished by then prints where it is and exits non-zero "
+                         "(a first contact between GPUs over RCCL must fail fast, not hang the caller's lease)")
     a = ap.parse_args()
     if a.workload == "config4":
         a.nx, a.ny, a.nz, a.nens = 256, 512, 128, 4
@@ -219,7 +222,30 @@ def spawn_ranks(a):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL between processes needs it on this pool
-    sys.exit(subprocess.call(cmd, env=env))
+    # the ranks report their progress into one small file each; if the job does not end within the limit this GPU-less parent ends
+    # the child's whole process group, says which rank stopped where, and exits non-zero
+    import signal
+    import tempfile
+    pdir = tempfile.mkdtemp(prefix="mw_bench_progress_")
+    env["MW_BENCH_PROGRESS_DIR"] = pdir
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = child.wait(timeout=a.timeout_s + 60.0)              # (every rank has its own watchdog at timeout_s: this is the backstop)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        child.wait()
+        print("bench.py: the %d-rank job did not finish within %.0f s and was ended; last progress per rank:" % (a.gpus, a.timeout_s + 60.0), file=sys.stderr)
+        for r in range(a.gpus):
+            try:
+                last = open(os.path.join(pdir, "rank%d" % r)).read().strip().splitlines()[-1]
+            except (OSError, IndexError):
+                last = "(nothing reported)"
+            print("  rank %d: %s" % (r, last), file=sys.stderr)
+        rc = 124
+    sys.exit(rc)
 
 
 def main():
@@ -228,11 +254,37 @@ def main():
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a)                                           # does not return
-    import torch
-    import torch.distributed as dist
+    import threading
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    t_start = time.time()
+    where = ["start"]
+
+    def progress(msg):
+        """One line per milestone: to stderr on multi-rank runs, and into the parent's progress file when there is one."""
+        where[0] = msg
+        line = "[bench rank %d/%d +%.1fs] %s" % (rank, world, time.time() - t_start, msg)
+        if world > 1:
+            print(line, file=sys.stderr, flush=True)
+        pdir = os.environ.get("MW_BENCH_PROGRESS_DIR")
+        if pdir:
+            try:
+                with open(os.path.join(pdir, "rank%d" % rank), "a") as f:
+                    f.write(line + "\n")
+            except OSError:
+                pass
+
+    def watchdog():
+        # fires only if the run is still going after --timeout-s: the main thread may be blocked inside RCCL / a HIP call (the GIL is
+        # released there), so this thread reports and ends the process; the launcher then ends the other ranks
+        print("bench.py: rank %d did not finish within %.0f s; last milestone: %s" % (rank, a.timeout_s, where[0]), file=sys.stderr, flush=True)
+        os._exit(3)
+    wd = threading.Timer(a.timeout_s, watchdog)
+    wd.daemon = True
+    wd.start()
+    import torch
+    import torch.distributed as dist
     if world != a.gpus:                                          # a launcher started a different number of ranks than asked for
         sys.exit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d" % (a.gpus, world))
     if torch.cuda.device_count() <= local_rank:
@@ -241,7 +293,10 @@ def main():
     device = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        progress("init_process_group(nccl) on %s ..." % device)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        progress("init_process_group ok")
 
     from miniweatherml_amd import capi, modules
     import ctypes as C
@@ -268,7 +323,17 @@ def main():
                                                         nranks=world, myrank=rank, ord=a.ord)
     assert coupler.get_nx() == a.nx and (coupler.get_ny() == a.ny or ny_glob == 1)
     dycore.set_strict(a.strict)
+    progress("model set up (%d x %d x %d x %d per rank); installing the halo-exchange transport ..." % (a.nx, coupler.get_ny(), a.nz, a.nens))
     transport = modules.install_exchange(dycore, coupler, a.transport) if world > 1 else "none"   # all ranks agree on one
+    rccl = None
+    if transport == "rccl":
+        ver = C.c_int(0)
+        path = (L.mw_rccl_library_path(C.byref(ver)) or b"").decode()
+        n_, r_, lanes_ = dycore.rccl_info()
+        rccl = {"comm_ranks": n_, "comm_rank": r_, "lanes": lanes_, "library": path, "version": ver.value}
+        progress("ncclCommInitRank ok: communicator of %d ranks, this is rank %d, %s (version %d)" % (n_, r_, path, ver.value))
+        if n_ != world:
+            sys.exit("bench.py: the RCCL communicator reports %d ranks, the job has %d" % (n_, world))
 
     dt = dycore.compute_time_step(coupler)
     V = 5 + coupler.get_num_tracers()
@@ -290,15 +355,22 @@ def main():
             modules.sponge_layer(coupler, dt)
             nudger.nudge_to_column(coupler, dt)
 
-    for _ in range(a.warmup):
+    if world > 1:
+        step()
+        sync()
+        progress("first time_step (first halo exchanges between the GPUs) ok")
+    for _ in range(a.warmup - (1 if world > 1 else 0)):
         step()
     sync()
+    progress("warm-up done")
     dycore.profile(2)                                            # hipEvents around the dominant kernel only (on its stream)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     sync()
     el = time.perf_counter() - t0
+    progress("timed region done")
+    sched = dycore.schedule()                                    # what the timed time_steps ran (mw_dycore_schedule), not re-derived here
     KNAMES = ["xz_state", "tracer_patch", "tracer_update_unfused", "halo", "convert", "y_state", "y_tracers", "tracers_fused"]
     prof_dom = dycore.profile_get(0)                             # the dominant kernel: live, over the timed region
     prof_stage = dycore.profile_get(8)                           # every RK stage, first to last launch: live, over the timed region
@@ -327,16 +399,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    # sanity: the run must still be physical (no NaN) -- a blown-up run would be an invalid measurement
-    wmax = float(coupler.get_data_manager_readonly().get("wvel", True).abs().max())
-    assert wmax == wmax and wmax < 100.0, "unphysical state after the timed region (max|w| = %r)" % wmax
-
-    # N > 1: the pipelined one-stream schedule (rk_stage_pipe) unless MW_OVERLAP / MW_NO_PIPE select the two-stream one
-    if "MW_OVERLAP" in os.environ:
-        two_streams = os.environ["MW_OVERLAP"] != "0" and not a.strict
+    # sanity: the run must still be physical -- a blown-up run would be an invalid measurement.  DataManager::validate_all
+    # (DataManager.h:385-387, one device pass per entry here): NaN / inf in any field, negative values in the positive-definite tracers
+    coupler.get_data_manager_readonly().validate_all(die_on_failed_check=True)
+    if world > 1:                                                # every rank's library path / communicator view, gathered for the JSON line
+        infos = [None] * world
+        dist.all_gather_object(infos, rccl)
     else:
-        two_streams = world > 1 and bool(os.environ.get("MW_NO_PIPE")) and not a.strict
-    pipelined = world > 1 and not two_streams and "MW_OVERLAP" not in os.environ and not a.strict
+        infos = [rccl]
+
+    two_streams = (sched["code"] & 3) == 1                       # (decided inside the library per time_step, not re-derived here)
     if rank == 0:
         ncycles = 1
         total_updates = float(ncells_local) * world * ncycles * a.steps
@@ -357,7 +429,7 @@ def main():
             dom_bytes = 32.0 * V * ncells_local
         dom_achieved = dom_bytes / avg_flux_s / 1e9 if flux_n else None
         # ---- counters from the committed rocprofv3 summary: only while the kernel sources are the profiled ones
-        traffic, dom_traffic, valu_busy, valu_instr, prov, valu_side = None, None, None, None, None, None
+        traffic, dom_traffic, valu_busy, valu_instr, prov, valu_side, derived = None, None, None, None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "latest_summary.json")
         if os.path.exists(pmc) and not a.strict:
             try:
@@ -377,6 +449,12 @@ def main():
                     stage_k = [v for k, v in K.items() if k.startswith(("k_xz_state", "k_y_all", "k_y_state", "k_y_tracers", "k_tracers_fused", "k_tracer_patch"))]
                     nstages = sum(k["calls"] for k in ks)      # one k_xz_state launch per RK stage
                     traffic = sum((k["hbm_read_bytes"] + k["hbm_write_bytes"]) * k["calls"] for k in stage_k if "hbm_read_bytes" in k) / nstages
+                    # per-kernel counted bandwidth of the profiled run (bytes / that run's average duration) and VALU-busy range
+                    big = [k for k in stage_k if "hbm_read_bytes" in k and k.get("avg_us", 0) > 50]
+                    kbw = [(k["hbm_read_bytes"] + k["hbm_write_bytes"]) / (k["avg_us"] * 1e-6) / 1e12 for k in big]
+                    kvb = [k["valu_busy_frac"] for k in big if "valu_busy_frac" in k]
+                    derived = {"kernel_TBps_min": min(kbw), "kernel_TBps_max": max(kbw), "valu_busy_min": min(kvb), "valu_busy_max": max(kvb),
+                               "traffic_over_algorithmic": traffic / (32.0 * V * ncells_local)}
                     # fp64-VALU side of the roofline (the binding one): counted VALU instructions of one cell-update against the
                     # chip's issue rate (1024 SIMDs, one wave64 instruction per 4 cycles, 2.4 GHz peak engine clock)
                     instr_cu = sum(k["valu_instr_per_cell"] * k["calls"] for k in stage_k if "valu_instr_per_cell" in k) / nstages * 3.0
@@ -384,7 +462,7 @@ def main():
                                  "peak_wave_instr_per_s": 1024 * 2.4e9 / 4.0, "frac": per_gpu * instr_cu / 64.0 / (1024 * 2.4e9 / 4.0),
                                  "source": "SQ_INSTS_VALU of profiles/latest_summary.json x live cell-updates/s"}
             except Exception:
-                traffic = dom_traffic = valu_side = None
+                traffic = dom_traffic = valu_side = derived = None
         what = "complete supercell_example loop: WENO-FV dycore + Kessler + sponge_layer + ColumnNudger" if a.full_loop else "WENO-FV dycore only"
         if city is not None:
             what = "complete simple_city loop: Horizontal_Sponge + WENO-FV dycore + sponge_layer + Time_Averager" if a.full_loop else "WENO-FV dycore only"
@@ -397,19 +475,28 @@ def main():
                                                V - 5, "" if V == 6 else "s"),
                        "baseline_config": "configs[3] per-GPU block" if a.workload == "config4" else "configs[4] per-GPU block" if city is not None else "configs[1]",
                        "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict, "weno_order": a.ord,
-                       "schedule": ("two streams (state | tracers, tracer stream at high priority)" if two_streams else
-                                    "one compute stream, strip exchange on a side stream beside the inner y chunks / the tracer stage" if pipelined else "one stream"),
+                       "schedule": sched["streams"], "schedule_code": sched["code"], "y_faces_in_one_launch": sched["y_all"],
+                       "rccl_ranks": (infos[0] or {}).get("comm_ranks") if world > 1 else None,
+                       "rccl_per_rank": infos if world > 1 else None,
                        "alg_bytes_per_cell_update": 64 * V,
-                       "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world},
+                       "hbm_frac_cell_update": value * 64 * V / 8.0e12 / world,
+                       # through the Coupler boundary, which is what is timed: + 32 V for D1 and D13, + 24 with immersed boundaries
+                       "alg_bytes_per_cell_update_boundary": 96 * V + (24 if city is not None else 0),
+                       "hbm_frac_cell_update_boundary": value * (96 * V + (24 if city is not None else 0)) / 8.0e12 / world},
             # bound: the resource that binds the stage: its COUNTED HBM traffic -- 2.1 x the algorithmic bytes: y tendencies,
             # face mass fluxes, tracer y fluxes written by one launch and read by the next -- moving at 4.6-5.6 TB/s, with the fp64
             # instruction stream at 0.80-0.87 VALU busy right under it (the WENO-3 build, half the arithmetic, takes 93 % of the time).
             # achieved / peak / frac are SURVEY.md 8(d)'s algorithmic figure (32 V B per cell against 8 TB/s: what the north star's 60 %
             # target is quoted in); traffic / traffic_frac the counted bytes; roofline.fp64_valu the instruction side.
             "roofline": {"bound": "hbm",
-                         "binding_resource": "HBM traffic of the stage's three launches (counted bytes: roofline.traffic, ~2.1 x algorithmic; "
-                                             "4.6-5.6 TB/s per kernel = 85-100 % of what a streaming copy reaches on this part), "
-                                             "fp64 VALU issue co-limiting at 0.80-0.87 busy",
+                         "binding_resource": ("HBM traffic of the stage's three launches (counted bytes: roofline.traffic = %.2f x algorithmic; "
+                                              "%.2f-%.2f TB/s per kernel in the profiled run, a streaming copy reaches 5.0-5.5 on this part) with "
+                                              "fp64 VALU issue co-limiting at %.2f-%.2f busy; numbers from roofline.pmc_provenance.file"
+                                              % (derived["traffic_over_algorithmic"], derived["kernel_TBps_min"], derived["kernel_TBps_max"],
+                                                 derived["valu_busy_min"], derived["valu_busy_max"])) if derived else
+                                             "HBM traffic of the stage's launches with fp64 VALU issue co-limiting (DESIGN.md 0b / 0c); no counter "
+                                             "summary matches the current kernel sources, so no figures are quoted here",
+                         "binding_resource_derived": derived,
                          "kernel": "one RK stage = k_y_all (y faces of all variables) + k_xz_state + k_tracers_fused + k_tracer_patch "
                                    "(SURVEY.md 8(d) flux stencil, 32 V B per cell)" if not a.strict else "one RK stage (general path)",
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
@@ -431,12 +518,16 @@ def main():
         }
         if world == 1 and not a.no_micro and not a.strict and city is None:
             out.update(micro_section(torch, modules, coupler, dycore, micro, dt, a))
+            # the headline state is the benign one (cloud-free initial field): the same step on a developed storm, next to `value`
+            out["config"]["value_storm"] = out.get("value_storm")
+            out["config"]["value_developed"] = out.get("value_developed")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    wd.cancel()
 
 
 if __name__ == "__main__":

@@ -122,6 +122,9 @@ double mw_dycore_get_etime(mw_dycore_t h);   /* member etime, :55 */
  * of the unfused production path), 3 halo, 4 convert, 5 y stencil state, 6 y stencil tracers, 7 x/z tracer stage (fused:
  * fluxes + FCT + update), 8 one whole RK stage of the production path (first to last launch on the handle's stream; also
  * recorded by mw_dycore_profile(h,2)). */
+/* Which schedule the last mw_dycore_time_step chose: 0 one stream, 1 two streams (state | tracer pipelines), 2 pipelined one-stream
+ * schedule of a decomposed block; + 4: y faces of all variables in one launch (k_y_all); + 8: general (flux-materialising) kernels. */
+int  mw_dycore_schedule(mw_dycore_t h);
 int  mw_dycore_profile(mw_dycore_t h, int enable);
 int  mw_dycore_profile_get(mw_dycore_t h, int which, double *total_ms, long long *launches);
 
@@ -172,6 +175,9 @@ int  mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, i
  * torch.distributed's "nccl" backend), else from the loader's search path -- never two RCCLs in one process.  Returns the
  * path it came from ("" when none is available) and, optionally, its version code (ncclGetVersion). */
 const char *mw_rccl_library_path(int *version);
+/* ncclCommCount / ncclCommUserRank of the installed transport's communicator, and its number of lanes (side streams): what a
+ * multi-GPU run reports as evidence that RCCL connected all ranks.  Error if the handle's transport is not the built-in RCCL one. */
+int  mw_dycore_rccl_info(mw_dycore_t h, int *comm_ranks, int *comm_rank, int *lanes);
 /* Diagnostic: one rank sends 4 strips of n doubles to itself through the exchange's own ncclGroup / side stream / event
  * sequence and compares; 0 = RCCL initialises on this box and the ordering against `stream` holds. */
 int  mw_rccl_selftest(long long n, void *stream);

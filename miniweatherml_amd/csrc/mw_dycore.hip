@@ -914,6 +914,7 @@ struct mw_dycore_s {
   hipEvent_t ev_state[8] = {nullptr}, ev_tr[8] = {nullptr}, ev_misc = nullptr;
   long long gstage = 0;                                 // global stage counter (event ring index, buffer parity)
   int overlap = 1;
+  int last_march = 0;                        // the last time_step ran on the marching kernels (mw_dycore_schedule)
   int pipe = 0;                              // blocks of a decomposed domain: pipelined one-stream schedule (rk_stage_pipe)
   bool pipe_ready = false;                   // ... the next stage's input strips are already on their way (event ev_pipe[2])
   hipEvent_t ev_pipe[3] = {nullptr, nullptr, nullptr};
@@ -2071,6 +2072,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   // nens == 1 or the member-major layout.  Orders 7 / 9 run on the general kernels.
   const bool ord3_ok = d->fused && (p.nens == 1 || !getenv("MW_NO_MEMBER_MAJOR"));
   const bool march = (d->strict == 0) && (p.bc_z != MW_BC_PERIODIC) && (d->ord == 5 || (d->ord == 3 && ord3_ok));
+  d->last_march = march ? 1 : 0;
   if (march && !getenv("MW_NO_WRAP")) {                       // index wrap instead of halo cells (see DyP::wrap_x)
     d->p.wrap_x = (p.bc_x == MW_BC_PERIODIC) && !(d->xchg && p.nproc_x > 1) && p.nx >= 3;
     d->p.wrap_y = !p.sim2d && (p.bc_y == MW_BC_PERIODIC) && !(d->xchg && p.nproc_y > 1) && p.ny >= 3;
@@ -2241,7 +2243,18 @@ int dycore_set_exchange_owned(mw_dycore_t d, mw_exchange_fn fn, void *ctx, void 
   d->xchg_free = free_ctx;
   return 0;
 }
+// the installed transport of a handle (mw_rccl.cpp recognises its own by the callback's address)
+void *dycore_exchange_ctx(mw_dycore_t d, mw_exchange_fn *fn) { if (fn) *fn = d ? d->xchg : nullptr; return d ? d->xchg_ctx : nullptr; }
 } // namespace mw
+
+// Which schedule the LAST mw_dycore_time_step of this handle chose (decided per call from the transport, the configuration and the
+// MW_* switches): 0 = one stream, 1 = two streams (state | tracer pipelines, rk_stage_march with overlap), 2 = the pipelined
+// one-stream schedule of a decomposed block (rk_stage_pipe); + 4 when the y faces of all variables go through the one k_y_all launch,
+// + 8 when that time step ran on the general (flux-materialising) kernels instead of the marching ones.  -1: null handle.
+extern "C" int mw_dycore_schedule(mw_dycore_t d) {
+  if (!d) return -1;
+  return (d->pipe ? 2 : d->overlap ? 1 : 0) + (d->last_march && y_all_ok(d) ? 4 : 0) + (d->last_march ? 0 : 8);
+}
 
 // ---- init (:1197-1683): host column profiles + device quadrature --------------------------------------
 namespace {

@@ -19,6 +19,7 @@
 
 namespace mw {   // defined in mw_dycore.hip: installs a transport whose context the handle owns (freed on replace / destroy)
 int dycore_set_exchange_owned(mw_dycore_t h, mw_exchange_fn fn, void *ctx, void (*free_ctx)(void *));
+void *dycore_exchange_ctx(mw_dycore_t h, mw_exchange_fn *fn);
 }
 
 namespace {
@@ -39,6 +40,8 @@ struct RcclApi {
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;
   decltype(&ncclCommSplit) CommSplit = nullptr;           // optional (NCCL >= 2.18): the second lane's communicator
+  decltype(&ncclCommCount) CommCount = nullptr;           // optional: what the communicator itself says (mw_dycore_rccl_info)
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   std::string path;
   bool ok = false;
 };
@@ -62,6 +65,8 @@ RcclApi &rccl_api() {
     MW_SYM(GetErrorString, ncclGetErrorString) MW_SYM(GetVersion, ncclGetVersion)
 #undef MW_SYM
     api.CommSplit = (decltype(api.CommSplit))dlsym(h, "ncclCommSplit");
+    api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
+    api.CommUserRank = (decltype(api.CommUserRank))dlsym(h, "ncclCommUserRank");
     Dl_info di;
     if (dladdr((void *)api.Send, &di) && di.dli_fname) api.path = di.dli_fname;
     api.ok = true;
@@ -114,14 +119,19 @@ void free_ctx(RcclCtx *c) {
 }
 // streams and events of the lanes; lane 1 only when a second communicator can be split off
 int init_lanes(RcclCtx *c, RcclApi &R, int nranks, int myrank) {
-  c->nlanes = 1;
   c->nlanes = getenv("MW_RCCL_ONE_LANE") ? 1 : 2;
   c->lane[1].comm = c->lane[0].comm; c->own_comm1 = false;     // shared communicator (default)
   { const char *tc = getenv("MW_RCCL_TWO_COMMS");
-    if (c->nlanes == 2 && tc && tc[0] == '1' && R.CommSplit) {
+    if (c->nlanes == 2 && tc && tc[0] == '1') {
+      // ncclCommSplit is a COLLECTIVE: a rank that quietly fell back to the shared communicator while its peers split would post its
+      // sends / receives on another communicator than they do and the first exchange would hang.  Asked for explicitly, a second
+      // communicator that cannot be had is therefore an error on this rank (the caller's ranks then fail together or not at all:
+      // every rank resolves the same librccl and calls the same split).
+      if (!R.CommSplit) { mw::set_error("MW_RCCL_TWO_COMMS=1 but this librccl has no ncclCommSplit"); return 1; }
       ncclComm_t split = nullptr;
       ncclResult_t r = R.CommSplit(c->lane[0].comm, 0, myrank, &split, nullptr);
-      if (r == ncclSuccess && split) { c->lane[1].comm = split; c->own_comm1 = true; }
+      if (r != ncclSuccess || !split) { mw::set_error(std::string("MW_RCCL_TWO_COMMS=1: ncclCommSplit failed: ") + R.GetErrorString(r)); return 1; }
+      c->lane[1].comm = split; c->own_comm1 = true;
     } }
   for (int l = 0; l < c->nlanes; l++) {
     RcclLane &L = c->lane[l];
@@ -195,6 +205,23 @@ int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, in
   if (init_lanes(c, R, nranks, myrank)) return fail();
   if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return fail();
   if (mw::dycore_set_exchange_owned(h, rccl_exchange, c, [](void *p) { free_ctx((RcclCtx *)p); })) return fail();   // the handle frees it
+  return 0;
+}
+
+// What the installed RCCL transport's communicator says about itself (ncclCommCount / ncclCommUserRank): the evidence a multi-GPU
+// run prints that RCCL really connected N ranks.  *lanes: side streams in use.  Fails when the handle's transport is not this one.
+int mw_dycore_rccl_info(mw_dycore_t h, int *comm_ranks, int *comm_rank, int *lanes) {
+  if (!h) MW_FAIL("null handle");
+  MW_NEED_RCCL();
+  mw_exchange_fn fn = nullptr;
+  RcclCtx *c = (RcclCtx *)mw::dycore_exchange_ctx(h, &fn);
+  if (fn != rccl_exchange || !c) MW_FAIL("mw_dycore_rccl_info: the handle's halo-exchange transport is not the built-in RCCL one");
+  int n = -1, r = -1;
+  if (R.CommCount) MW_NCCL(R.CommCount(c->lane[0].comm, &n));
+  if (R.CommUserRank) MW_NCCL(R.CommUserRank(c->lane[0].comm, &r));
+  if (comm_ranks) *comm_ranks = n;
+  if (comm_rank) *comm_rank = r;
+  if (lanes) *lanes = c->nlanes;
   return 0;
 }
 

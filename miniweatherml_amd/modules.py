@@ -183,6 +183,19 @@ class Dynamics_Euler_Stratified_WenoFV:
         check(capi.lib().mw_dycore_set_bc(self.h, bc_x, bc_y, bc_z))
         coupler.set_option("bc_x", bc_x); coupler.set_option("bc_y", bc_y); coupler.set_option("bc_z", bc_z)
 
+    def schedule(self):
+        """What the last time_step ran (mw_dycore_schedule): dict(streams = "one" | "two" | "pipelined", y_all, general_kernels)."""
+        v = capi.lib().mw_dycore_schedule(self.h)
+        return dict(code=v, streams=("one stream", "two streams (state | tracers, tracer stream at high priority)",
+                                     "one compute stream, strip exchange on a side stream beside the inner y rows / the tracer stage")[v & 3],
+                    y_all=bool(v & 4), general_kernels=bool(v & 8))
+
+    def rccl_info(self):
+        """(ranks, rank, lanes) as the installed RCCL transport's communicator reports them (ncclCommCount / ncclCommUserRank)."""
+        n, r, l = C.c_int(-1), C.c_int(-1), C.c_int(0)
+        check(capi.lib().mw_dycore_rccl_info(self.h, C.byref(n), C.byref(r), C.byref(l)))
+        return n.value, r.value, l.value
+
     def profile(self, enable):
         check(capi.lib().mw_dycore_profile(self.h, int(enable)))
 

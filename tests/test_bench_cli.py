@@ -27,6 +27,15 @@ def test_launcher_world_size_mismatch_is_refused():
     assert "WORLD_SIZE=2" in r.stderr
 
 
+def test_watchdog_ends_a_run_that_overstays_its_limit():
+    """--timeout-s: a rank still running at the limit reports its last milestone and exits non-zero (a first RCCL contact between GPUs
+    that hangs must not eat the caller's lease).  Here the limit expires while torch is still being imported."""
+    r = run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--timeout-s", "0.05"])
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    assert "did not finish within" in r.stderr and "last milestone" in r.stderr
+    assert "cell-updates" not in r.stdout
+
+
 import pytest
 
 
