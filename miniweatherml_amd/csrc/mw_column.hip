@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_nudge_apply(FieldPtrs fp, int nz, long 
 
 using namespace mw;
 
-static int g_column_strict = 0;
+static thread_local int g_column_strict = 0;        // per calling thread: a rank harness with one host thread per rank may use different modes side by side
 // 1: the horizontal sums of sponge_layer / ColumnNudger in the reference's serial order (bit-identical to the serial backend);
 // 0 (default): fixed-slice tree sums.  Process-wide.
 extern "C" int mw_column_set_strict(int strict) { g_column_strict = strict ? 1 : 0; return 0; }

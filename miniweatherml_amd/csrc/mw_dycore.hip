@@ -914,6 +914,7 @@ struct mw_dycore_s {
   hipEvent_t ev_state[8] = {nullptr}, ev_tr[8] = {nullptr}, ev_misc = nullptr;
   long long gstage = 0;                                 // global stage counter (event ring index, buffer parity)
   int overlap = 1;
+  int pre_lo = 0, pre_hi = 0;                // pipelined schedule: rows outside [pre_lo, pre_hi) (and the W / E strip columns) were converted up front
   int last_march = 0;                        // the last time_step ran on the marching kernels (mw_dycore_schedule)
   int pipe = 0;                              // blocks of a decomposed domain: pipelined one-stream schedule (rk_stage_pipe)
   bool pipe_ready = false;                   // ... the next stage's input strips are already on their way (event ev_pipe[2])
@@ -1386,6 +1387,8 @@ static bool y_all_ok(const mw_dycore_s *d) {
 #define MW_Y_EDGE 4                                            // (>= 4: the converting inner launch requests coupler rows up to row_end + 3 < ny)
 static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv, int part = 0) {
   ProfScope ps(d, 5);
+  // the cells the pipelined schedule converted up front (time_step): the converting launch leaves them alone (see k_y_all)
+  const int pre_lo = (conv && part == 1) ? d->pre_lo : 0, pre_hi = (conv && part == 1) ? d->pre_hi : 0;
   if (conv && d->member_major) {                                // mm_direct: all members in one launch, the members of the same cells in one workgroup
     const View v = view(d, 0);
     const DyP &p = v.p;
@@ -1399,7 +1402,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
       const int n = (int)grid.y;
       row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk);
     }
-#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, classic_sched(row_end - row0, chunk))
+#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, classic_sched(row_end - row0, chunk), pre_lo, pre_hi)
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
     if (marching_config(p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
@@ -1430,7 +1433,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
 #define MW_YA(C_, K_, O_, T_) do { dim3 g_ = grid; const Sched sc_ = (part == 2) ? classic_sched(row_end - row0, chunk) : \
                                   pick_sched(d, (const void *)&k_y_all<C_, K_, O_, T_>, 0, (long long)grid.x, row_end - row0, chunk, g_, 0); \
                                 hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), g_, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
-                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_); } while (0)
+                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_, pre_lo, pre_hi); } while (0)
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
     const int K = marching_config(p);
@@ -1499,6 +1502,10 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
       const MemberOff mo = member_off(d);
       const int wpb = 4 / mo.n;
       grid.x = (unsigned)(((long long)p.ny * tiles_x + wpb - 1) / wpb);
+      // one background table per wave here: (chunk + 2) x 256 B of dynamic LDS on top of the kernel's ~20.5 KB of static LDS must fit
+      // the 64 KB a workgroup may have -- shorter chunks for this launch when nz is large and the chunk rule asks for one long chunk
+      { const int cap = (65536 - 21504) / 256 - 2;               // 170 levels
+        if (chunk > cap) { chunk = cap; grid.y = (unsigned)((p.nz + chunk - 1) / chunk); } }
       const size_t lds = (size_t)(chunk + 2) * 64 * 4;
 #define MW_XZ_MT(K_) { if (d->ord == 3) MW_XZ_MTO(K_, 3); else MW_XZ_MTO(K_, 5); }
 #define MW_XZ_MTO(K_, O_) hipLaunchKernelGGL((k_xz_state<3, true, 1, 1, K_, O_, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
@@ -2113,9 +2120,11 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   //  member-major handle whose configuration is not a folded one -- gets the full conversion pass below; without this a 1 x 1
   //  decomposition with a transport installed (both wraps on) reached the members-in-one-workgroup launch with the wrong kernel)
   if (d->pipe) d->conv_pending = false;
+  d->pre_lo = d->pre_hi = 0;
   if (pipe_conv) {
     ProfScope ps(d, 4);
     const int ylo = d->p.wrap_y ? 0 : MW_Y_EDGE + 3, yhi = d->p.wrap_y ? p.ny : p.ny - MW_Y_EDGE - 3;
+    d->pre_lo = ylo; d->pre_hi = yhi;
     if (d->member_major) {
       const View v = view(d, 0);
       const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};

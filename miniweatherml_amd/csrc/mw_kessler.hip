@@ -456,7 +456,7 @@ int mw_kessler_math_probe(long long n, const double *x, double *y, int fn, void 
   return 0;
 }
 
-static int g_kessler_strict = 0;
+static thread_local int g_kessler_strict = 0;        // per calling thread: a rank harness with one host thread per rank may use different modes side by side
 // 1: the strict path (reference operation order, glibc's pow / exp: bit-identical to the CPU oracle); 0: the production kernels
 int mw_kessler_set_strict(int strict) { g_kessler_strict = strict ? 1 : 0; return 0; }
 

@@ -613,9 +613,14 @@ __device__ __forceinline__ double tracer_slab_value(double rho_t, double inv_den
 // (see MemberOff) -- the converting launch of such a handle.
 template <bool CONV, int K, int ORD, int T, bool MT = false>
 __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk,
-                                               CouplerPtrs c, double *__restrict__ Sw, MemberOff mo, int row0, int rstride, int row_end, Sched sc) {
+                                               CouplerPtrs c, double *__restrict__ Sw, MemberOff mo, int row0, int rstride, int row_end, Sched sc,
+                                               int pre_lo, int pre_hi) {
   static_assert(!MT || CONV, "the member-co-located form exists for the converting launch only");
   constexpr int NV = 5 + T;
+  // (pre_lo < pre_hi: the pipelined multi-rank schedule has converted the strips it packs for the neighbours up front -- the HX cells
+  //  next to the block's west / east edge in every row, and the rows outside [pre_lo, pre_hi) -- with k_coupler_to_state_fast on this
+  //  stream, and the pack kernels read them on the exchange stream WHILE this launch runs: those slab cells are not stored again here.
+  //  Storing the same values twice was only benign as long as two instantiations of the conversion produce the same bits.)
   const int NXI = p.nx * p.nens;
   __shared__ double lds_fprev[CONV ? 5 : 1][CONV ? 256 : 1];
   int mt_sub = 0;
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   { double inv_den_;                                                                                                  \
     convert_cell_fast<K>(p, raw, hyr, hyt, p0, out, inv_den_);                                                        \
     _Pragma("unroll") for (int v_ = 0; v_ < T; v_++) out[5 + v_] = tracer_slab_value(raw.tr[v_], inv_den_);          \
-    if ((r) >= ja && (r) < jb) {                                                                                      \
+    if ((r) >= ja && (r) < jb && !(pre_lo < pre_hi && ((r) < pre_lo || (r) >= pre_hi || ie < p.HX * p.nens || ie >= NXI - p.HX * p.nens))) { \
       double *s_ = Sw + (long long)(k + p.HZ) * p.sK + (long long)((r) + p.HY) * p.sJ + (long long)p.HX * p.nens + ie; \
       _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++) s_[(long long)v_ * p.sV] = out[v_];                           \
     } }

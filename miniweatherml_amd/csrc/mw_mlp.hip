@@ -272,7 +272,7 @@ static void build_operand_images(MlpP &P, const float *W1, const float *b1, cons
   }
 }
 
-static int g_mlp_strict = 0;
+static thread_local int g_mlp_strict = 0;        // per calling thread: a rank harness with one host thread per rank may use different modes side by side
 extern "C" int mw_mlp_set_strict(int strict) { g_mlp_strict = strict ? 1 : 0; return 0; }
 
 extern "C" int mw_mlp_forward(long long ncells, const double *temp, const double *rho_d, const double *rho_v, const double *rho_c,

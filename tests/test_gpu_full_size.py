@@ -299,6 +299,26 @@ def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracl
     compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "members in one workgroup (D1 / D13), nens %d %dx%dx%d WENO-%d, 2 steps" % (nens, nx, ny, nz, order))
 
 
+def test_members_in_one_workgroup_with_a_chunk_longer_than_the_lds_tables_allow(mw, oracle, monkeypatch):
+    """The D13 launch of k_xz_state with the members of a tile in one workgroup keeps one background table per wave in LDS:
+    (chunk + 2) x 256 B on top of ~20.5 KB of static LDS.  A chunk of 200 levels (MW_CHUNK_Z, or the chunk rule on a grid with many
+    wavefronts and a tall column) would exceed the 64 KB a workgroup may have and the launch would fail (round 3's advisor finding):
+    that launch now cuts its own chunks at 170 levels.  nens = 4, nz = 200, against the oracle."""
+    from miniweatherml_amd import modules
+    from util import compare_fields, gpu_fields, push_fields
+    monkeypatch.setenv("MW_CHUNK_Z", "200"); monkeypatch.setenv("MW_CHUNK_F", "200")
+    nx, ny, nz, nens = 24, 8, 200, 4
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
+    odyc, of = oracle.supercell_setup(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
+    of.temp += 0.05 * np.arange(nens)
+    push_fields(coupler, of)
+    dt = dycore.compute_time_step(coupler)
+    for _ in range(2):
+        dycore.time_step(coupler, dt)
+        odyc.time_step(of, dt)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "members in one workgroup, one 200-level chunk, 2 steps")
+
+
 @pytest.mark.parametrize("nx,ny,nz,order", [(61, 23, 17, 5), (130, 9, 26, 5), (64, 37, 12, 3)])
 def test_y_faces_of_all_variables_in_one_launch_equal_the_two_launches(mw, oracle, monkeypatch, nx, ny, nz, order):
     """k_y_all (state variables and tracers in one y march; the converting first stage included) against k_y_state + k_y_tracers
