@@ -178,6 +178,12 @@ const char *mw_rccl_library_path(int *version);
 /* ncclCommCount / ncclCommUserRank of the installed transport's communicator, and its number of lanes (side streams): what a
  * multi-GPU run reports as evidence that RCCL connected all ranks.  Error if the handle's transport is not the built-in RCCL one. */
 int  mw_dycore_rccl_info(mw_dycore_t h, int *comm_ranks, int *comm_rank, int *lanes);
+/* The other two collectives of a decomposed run, on the handle's communicator, for hosts without torch.distributed / MPI:
+ * MPI_Allreduce(SUM) of sponge_layer.h:53-63 / column_nudging.h:89-99 -- pass this function as the mw_allreduce_fn of mw_sponge_layer /
+ * mw_column_average / mw_nudge_to_column with ctx = the dycore handle -- and MPI_Bcast(root) of horizontal_sponge.h:72-77.  DEVICE
+ * buffers, in place, ordered on `stream`. */
+int  mw_dycore_rccl_allreduce_sum(void *dycore_handle, double *buf, long long n, void *stream);
+int  mw_dycore_rccl_bcast(mw_dycore_t h, double *buf, long long n, int root, void *stream);
 /* Diagnostic: one rank sends 4 strips of n doubles to itself through the exchange's own ncclGroup / side stream / event
  * sequence and compares; 0 = RCCL initialises on this box and the ordering against `stream` holds. */
 int  mw_rccl_selftest(long long n, void *stream);

@@ -50,7 +50,7 @@ def build_examples(verbose=True):
     """The C++ callers of examples/ (mirrors of the reference's drivers) against the C++ facade + C ABI."""
     root = os.path.dirname(HERE)
     exes = []
-    for name in ("supercell_driver", "simple_city_driver", "inference_ponni_driver"):
+    for name in ("supercell_driver", "simple_city_driver", "inference_ponni_driver", "supercell_multirank"):
         src = os.path.join(root, "examples", name + ".cpp")
         exe = os.path.join(root, "examples", name)
         deps = [src, os.path.join(HERE, "host", "mw_facade.h"), os.path.join(HERE, "host", "mw_ponni.h"), os.path.join(root, "include", "mw_cdna4.h"), LIB]

@@ -61,6 +61,8 @@ SYMBOLS = {
     "mw_dycore_get_etime": (C.c_double, [C.c_void_p]),
     "mw_dycore_schedule": (C.c_int, [C.c_void_p]),
     "mw_dycore_rccl_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mw_dycore_rccl_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "mw_dycore_rccl_bcast": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
     "mw_dycore_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "mw_dycore_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "mw_calib_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),

@@ -40,6 +40,8 @@ struct RcclApi {
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclGetVersion) GetVersion = nullptr;
   decltype(&ncclCommSplit) CommSplit = nullptr;           // optional (NCCL >= 2.18): the second lane's communicator
+  decltype(&ncclAllReduce) AllReduce = nullptr;           // optional: the column modules' sums / the broadcast of a C++ host (below)
+  decltype(&ncclBroadcast) Broadcast = nullptr;
   decltype(&ncclCommCount) CommCount = nullptr;           // optional: what the communicator itself says (mw_dycore_rccl_info)
   decltype(&ncclCommUserRank) CommUserRank = nullptr;
   std::string path;
@@ -65,6 +67,8 @@ RcclApi &rccl_api() {
     MW_SYM(GetErrorString, ncclGetErrorString) MW_SYM(GetVersion, ncclGetVersion)
 #undef MW_SYM
     api.CommSplit = (decltype(api.CommSplit))dlsym(h, "ncclCommSplit");
+    api.AllReduce = (decltype(api.AllReduce))dlsym(h, "ncclAllReduce");
+    api.Broadcast = (decltype(api.Broadcast))dlsym(h, "ncclBroadcast");
     api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
     api.CommUserRank = (decltype(api.CommUserRank))dlsym(h, "ncclCommUserRank");
     Dl_info di;
@@ -222,6 +226,34 @@ int mw_dycore_rccl_info(mw_dycore_t h, int *comm_ranks, int *comm_rank, int *lan
   if (comm_ranks) *comm_ranks = n;
   if (comm_rank) *comm_rank = r;
   if (lanes) *lanes = c->nlanes;
+  return 0;
+}
+
+// The two collectives a C++ host of a decomposed run needs besides the halo exchange, on the handle's own communicator (a PyTorch host
+// uses torch.distributed for them): MPI_Allreduce(SUM) of sponge_layer / ColumnNudger (sponge_layer.h:53-63, column_nudging.h:89-99) --
+// the signature IS mw_allreduce_fn with ctx = the dycore handle -- and the MPI_Bcast from the main rank of Horizontal_Sponge::init
+// (horizontal_sponge.h:72-77).  Ordered on `stream` like any other work of the caller.
+static RcclCtx *own_ctx(mw_dycore_t h) {
+  mw_exchange_fn fn = nullptr;
+  RcclCtx *c = (RcclCtx *)mw::dycore_exchange_ctx(h, &fn);
+  return (fn == rccl_exchange) ? c : nullptr;
+}
+int mw_dycore_rccl_allreduce_sum(void *handle, double *buf, long long n, void *stream) {
+  if (!handle || !buf || n < 1) MW_FAIL("mw_dycore_rccl_allreduce_sum: bad argument");
+  MW_NEED_RCCL();
+  RcclCtx *c = own_ctx((mw_dycore_t)handle);
+  if (!c) MW_FAIL("mw_dycore_rccl_allreduce_sum: the handle has no built-in RCCL transport (mw_dycore_use_rccl)");
+  if (!R.AllReduce) MW_FAIL("this librccl has no ncclAllReduce");
+  MW_NCCL(R.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, c->lane[0].comm, (hipStream_t)stream));
+  return 0;
+}
+int mw_dycore_rccl_bcast(mw_dycore_t h, double *buf, long long n, int root, void *stream) {
+  if (!h || !buf || n < 1) MW_FAIL("mw_dycore_rccl_bcast: bad argument");
+  MW_NEED_RCCL();
+  RcclCtx *c = own_ctx(h);
+  if (!c) MW_FAIL("mw_dycore_rccl_bcast: the handle has no built-in RCCL transport (mw_dycore_use_rccl)");
+  if (!R.Broadcast) MW_FAIL("this librccl has no ncclBroadcast");
+  MW_NCCL(R.Broadcast(buf, buf, (size_t)n, ncclDouble, root, c->lane[0].comm, (hipStream_t)stream));
   return 0;
 }
 

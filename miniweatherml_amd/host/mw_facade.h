@@ -361,6 +361,11 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
     mw_check(mw_nc_close(nc));
   }
   mw_dycore_t handle() const { return h; }
+  // Decomposed runs (coupler.distribute_mpi_and_allocate_coupled_state(..., nranks, myrank)): the reference exchanges halos with
+  // MPI_Isend / Irecv (:641-723); here every rank joins one RCCL communicator -- id128: the 128 bytes of mw_rccl_unique_id() made by
+  // rank 0 and handed to the other ranks by whatever launched them (a file, a pipe, an environment variable).  Afterwards
+  // mw_dycore_rccl_allreduce_sum (ctx = handle()) is the all-reduce of sponge_layer / ColumnNudger.
+  void use_rccl(core::Coupler const &coupler, const unsigned char *id128) { mw_check(mw_dycore_use_rccl(h, id128, coupler.get_nranks(), coupler.get_myrank())); }
  private:
   void bind(core::Coupler &coupler) {
     auto &dm = coupler.get_data_manager_readwrite();
@@ -424,14 +429,21 @@ inline std::vector<double *> six_fields(core::Coupler &c, const char *prefix = "
   return s;
 }
 
-struct Horizontal_Sponge {                                             // horizontal_sponge.h:7-194 (single rank: no MPI_Bcast)
+struct Horizontal_Sponge {                                             // horizontal_sponge.h:7-194
   double *column = nullptr; int nz = 0, nens = 0; int sponge_cells = 10; real time_scale = 1;
   ~Horizontal_Sponge() { if (column) (void)hipFree(column); }
-  void init(core::Coupler &coupler, int sponge_cells_ = 10, real time_scale_ = 1) {                              // :18-91
+  // rccl_handle: on a decomposed run, the dycore handle whose RCCL transport carries the MPI_Bcast from the main rank (:72-77:
+  // every rank relaxes towards the MAIN rank's column at (j, i) = (0, 0)); nullptr on one rank
+  void init(core::Coupler &coupler, int sponge_cells_ = 10, real time_scale_ = 1, mw_dycore_t rccl_handle = nullptr) {   // :18-91
     nz = coupler.get_nz(); nens = coupler.get_nens();
     if (!column && hipMalloc((void **)&column, sizeof(double) * 6 * (size_t)nz * nens) != hipSuccess) endrun("Horizontal_Sponge: allocation failed");
     auto f = six_fields(coupler);
     mw_check(mw_horizontal_sponge_column(&coupler.grid, f.data(), column, nullptr));
+    if (coupler.get_nranks() > 1) {
+      if (!rccl_handle) endrun("Horizontal_Sponge::init on a decomposed run needs the dycore handle whose transport carries the broadcast");
+      mw_check(mw_dycore_rccl_bcast(rccl_handle, column, 6ll * nz * nens, 0, nullptr));
+      (void)hipStreamSynchronize(nullptr);
+    }
     sponge_cells = sponge_cells_; time_scale = time_scale_;
   }
   void override_field(int l, real val) { std::vector<double> h((size_t)nz * nens, val);

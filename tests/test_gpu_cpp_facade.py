@@ -98,3 +98,57 @@ def test_cpp_simple_city_driver_equals_python_and_writes_the_files(mw, tmp_path)
     assert open(str(tmp_path / "cpp_avg.nc"), "rb").read() == open(str(tmp_path / "py_avg.nc"), "rb").read()
     r = cdf.Reader(str(tmp_path / "cpp.nc"))
     assert r.numrecs == 3 and list(r.get("t")) == [0.0, r.get("t")[1], etime]
+
+
+def _multirank(world, args, tmp_path, extra_env=None):
+    exe = os.path.join(ROOT, "examples", "supercell_multirank")
+    if not os.path.exists(exe):
+        from miniweatherml_amd import build
+        build.build_examples(verbose=False)
+    idf = str(tmp_path / "nccl_id")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MW_RANK=str(r), MW_WORLD=str(world), MW_ID_FILE=idf, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([exe] + [str(a) for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e[-2000:]
+        m = re.search(r"rank (\d+) of (\d+) block (\d+)x(\d+) at \((\d+),(\d+)\) etime (\S+) maxw (\S+) sum_density_dry (\S+) total_density_dry (\S+) validate_all (\d+)", o)
+        assert m, o
+        outs.append((m, e))
+    return outs
+
+
+def test_cpp_multirank_host_one_rank_over_rccl(mw, tmp_path):
+    """examples/supercell_multirank.cpp with MW_FORCE_RCCL=1 on one GPU: the C++ host joins a 1-rank RCCL communicator
+    (mw_dycore_use_rccl through the facade's dycore.use_rccl), and sponge_layer / ColumnNudger sum over it with
+    mw_dycore_rccl_allreduce_sum.  A sum over one rank is the identity: same bits as the plain single-rank driver."""
+    args = (24, 20, 12, 1, 12000., 10000., 20000., 3)
+    (m, err), = _multirank(1, args, tmp_path, {"MW_FORCE_RCCL": "1"})
+    assert "RCCL communicator: 1 ranks, this is rank 0" in err
+    etime, maxw, sumr, _ = run_driver(*args, "supercell", 2)
+    assert float(m.group(7)) == etime and float(m.group(8)) == maxw and float(m.group(9)) == sumr == float(m.group(10))
+    assert int(m.group(11)) == 0
+
+
+def test_cpp_multirank_host_between_gpus(mw, tmp_path):
+    """Two C++ processes, one GPU each (skipped on the one-GPU development box): halo strips, the all-reduce of the column modules and
+    the id hand-over without MPI or torch.  The dycore is decomposition-invariant; the column sums are added in another order
+    (partial sums per rank): 1e-12."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    args = (48, 40, 12, 1, 24000., 20000., 20000., 3)
+    outs = _multirank(2, args, tmp_path)
+    etime, maxw, sumr, _ = run_driver(*args, "supercell", 2)
+    tot = [float(m.group(10)) for m, _ in outs]
+    assert tot[0] == tot[1] and abs(tot[0] - sumr) <= 1e-12 * sumr
+    assert abs(max(float(m.group(8)) for m, _ in outs) - maxw) <= 1e-11 * maxw
+    assert abs(sum(float(m.group(9)) for m, _ in outs) - sumr) <= 1e-12 * sumr
