@@ -934,6 +934,46 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
 #pragma unroll
       for (int f = 0; f < 8; f++) hpl[f] = lds_hp[(k - g.kstart) * 8 + f];
     }
+#ifdef MW_EXP_MOCK_Y
+    // Timing experiment (DESIGN.md 0c), never a product path: the ARITHMETIC a y direction inside this kernel would add at the very
+    // least -- five reconstructions and one Riemann solve per level, on register data (the window's values in another order, so that
+    // nothing is shared with the z reconstruction) -- without the LDS tile, the barriers, the halo rows or the tile-edge faces a
+    // real fused kernel needs on top.  Together with MW_EXP_NO_TENDY (no y-tendency hand-off) it bounds such a kernel from below.
+    {
+      double ys[5], yn[5];
+#ifdef MW_EXP_MOCK_Y_LDS
+      // ... and the DATA MOVEMENT of an LDS-staged row tile (4 rows = the 4 waves of this workgroup, no halo rows, no tile-edge faces):
+      // every wave publishes its level, waits, takes its four "y neighbours" from the other waves' rows, publishes its north edge
+      // values, waits again and takes its southern neighbour's -- two workgroup barriers per level.
+      __shared__ double lds_tile[5][4][64], lds_edge[5][4][64];
+#pragma unroll
+      for (int v = 0; v < 5; v++) lds_tile[v][wv][lane] = w[v][HS];
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < 5; v++) {                             // (one variable at a time: all twenty LDS reads hoisted in front of the arithmetic spill 50-80 VGPRs)
+        MW_SCHED_FENCE();
+        weno5_edges_fast(lds_tile[v][(wv + 2) & 3][lane], lds_tile[v][(wv + 3) & 3][lane], w[v][HS], lds_tile[v][(wv + 1) & 3][lane], lds_tile[v][(wv + 2) & 3][lane ^ 1], ys[v], yn[v]);
+      }
+      MW_SCHED_FENCE();
+#pragma unroll
+      for (int v = 0; v < 5; v++) lds_edge[v][wv][lane] = yn[v];
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < 5; v++) yn[v] = lds_edge[v][(wv + 3) & 3][lane];
+#else
+#pragma unroll
+      for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][1], w[v][0], w[v][HS], w[v][ORD - 1], w[v][ORD - 2], ys[v], yn[v]);
+#endif
+      const double *hp = p.hypk + (long long)(k * n + e) * 8;
+      const double hyr = HPL ? hpl[0] : hp[0], hyt = HPL ? hpl[1] : hp[1], p0 = HPL ? hpl[2] : hp[2], ihyt = HPL ? hpl[3] : hp[3];
+      double fn, fT;
+      FaceState fs = riemann_primary<K>(p, yn[idR] + hyr, ys[idR] + hyr, yn[idV], ys[idV], yn[idT], ys[idT], hyt, p0, ihyt, false, fn, fT);
+      const double z0 = lds_c[7];                               // (0 at run time, unknown to the compiler: the mock values are computed and do not disturb the run)
+      tyv[idR] += -(fs.m_upw - ct[idR]) * z0; tyv[idV] += -(fn - ct[idV]) * z0; tyv[idT] += -(fT - ct[idT]) * z0;
+      tyv[idU] += -(fs.m_upw * (fs.ind ? ys[idU] : yn[idU]) - ct[idU]) * z0;
+      tyv[idW] += -(fs.m_upw * (fs.ind ? ys[idW] : yn[idW]) - ct[idW]) * z0;
+    }
+#endif
     // ------------------------------------------------ X direction (cell k = window centre)
     double fxs[5];
     int upx = 0;
@@ -1006,25 +1046,6 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
       fzs[idV] = fs.m_upw * (up ? be[idV] : ct[idV]);
       upz = up;
     }
-#ifdef MW_EXP_MOCK_Y
-    // Timing experiment (DESIGN.md 0c), never a product path: the ARITHMETIC a y direction inside this kernel would add at the very
-    // least -- five reconstructions and one Riemann solve per level, on register data (the window's values in another order, so that
-    // nothing is shared with the z reconstruction) -- without the LDS tile, the barriers, the halo rows or the tile-edge faces a
-    // real fused kernel needs on top.  Together with MW_EXP_NO_TENDY (no y-tendency hand-off) it bounds such a kernel from below.
-    {
-      double ys[5], yn[5];
-#pragma unroll
-      for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][1], w[v][0], w[v][HS], w[v][ORD - 1], w[v][ORD - 2], ys[v], yn[v]);
-      const double *hp = p.hypk + (long long)(k * n + e) * 8;
-      const double hyr = HPL ? hpl[0] : hp[0], hyt = HPL ? hpl[1] : hp[1], p0 = HPL ? hpl[2] : hp[2], ihyt = HPL ? hpl[3] : hp[3];
-      double fn, fT;
-      FaceState fs = riemann_primary<K>(p, yn[idR] + hyr, ys[idR] + hyr, yn[idV], ys[idV], yn[idT], ys[idT], hyt, p0, ihyt, false, fn, fT);
-      const double z0 = lds_c[7];                               // (0 at run time, unknown to the compiler: the mock values are computed and do not disturb the run)
-      tyv[idR] += -(fs.m_upw - ct[idR]) * z0; tyv[idV] += -(fn - ct[idV]) * z0; tyv[idT] += -(fT - ct[idT]) * z0;
-      tyv[idU] += -(fs.m_upw * (fs.ind ? ys[idU] : yn[idU]) - ct[idU]) * z0;
-      tyv[idW] += -(fs.m_upw * (fs.ind ? ys[idW] : yn[idW]) - ct[idW]) * z0;
-    }
-#endif
     // ------------------------------------------------ all loads of this iteration have landed (see landed()); its stores follow
     landed(nxt); landed(snv); landed(tyv); landed(immv);
     if (xwork && g.owns_face && (g.owns_cell || q >= NXI)) {
