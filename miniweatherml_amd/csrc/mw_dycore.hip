@@ -947,8 +947,8 @@ struct mw_dycore_s {
   size_t ev_used[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   void (*xchg_free)(void *) = nullptr;       // set when the handle owns xchg_ctx (the built-in RCCL transport, mw_rccl.cpp)
   // balanced launch lists (pick_sched): per (columns, cells, resident workgroups) the Sched with its device table
-  std::map<std::tuple<long long, int, int>, mw::Sched> sched_cache;
-  std::map<std::tuple<long long, int, int>, int> sched_n2;
+  struct SchedEntry { const mw::Sched *dev; unsigned wgs; };
+  std::map<std::tuple<long long, int, int>, SchedEntry> sched_cache;
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Padding the blocks-per-plane count to a
@@ -1259,30 +1259,33 @@ static int resident_blocks(const void *fn, size_t lds) {
   cache[key] = nb;
   return nb;
 }
-// -> the schedule of one launch; `grid` becomes the list's length when the balanced form applies.  N columns of `len` cells; classic =
-// chunks of `chunk`.  The list of a (N, len, P) triple -- the order of the straddling slices' second parts -- is built once per handle.
-static Sched classic_sched(int len, int chunk) { Sched sc = {0, 0, 0, len, chunk, 0, nullptr}; return sc; }
-static Sched pick_sched(mw_dycore_s *d, const void *fn, size_t lds_balanced, long long N, int len, int chunk, dim3 &grid, int which) {
-  Sched sc = classic_sched(len, chunk);
+// -> the schedule of one launch: nullptr = the chunked grid; else the DEVICE list (Sched header + the order of the straddling slices'
+// second parts), and `grid` becomes the list's length.  N columns of `len` cells.  Built once per (N, len, P) and handle.
+static const Sched *pick_sched(mw_dycore_s *d, const void *fn, size_t lds_balanced, long long N, int len, dim3 &grid, int which) {
   // MW_SCHED: 0 (default) the chunked grid; 1 the balanced lists where a launch has >= 16 cells per workgroup; 2 forced (tests).
   // Measured (round 4, 400 x 400 x 100, two boxes, three interleaved repetitions each): k_y_all 1.47 -> 1.83 ms per step with the lists
   // (its chunks keep x-adjacent workgroups on the same row at the same time -- DRAM pages are read out whole; slices start anywhere),
   // k_xz_state 1.98-2.03 -> 2.01-2.04, k_tracers_fused 1.70 -> 1.65-1.68: -1 % of the step at best with the mask 6, so the default stays 0.
+#ifndef MW_SCHED_LISTS
+  (void)d; (void)fn; (void)lds_balanced; (void)N; (void)len; (void)grid; (void)which;
+  return nullptr;                                               // (the default build has no list code in its kernels, see Sched in mw_march.h)
+#else
   const char *e = getenv("MW_SCHED");
   const int mode = e ? atoi(e) : 0;
   const char *m = getenv("MW_SCHED_MASK");                      // bit 0: k_y_all, bit 1: k_xz_state, bit 2: k_tracers_fused
   const int mask = m ? atoi(m) : MW_SCHED_DEFAULT_MASK;
-  if (mode == 0 || !((mask >> which) & 1) || d->overlap || N < 1 || N > 0x3fffffff || len < 1) return sc;
+  if (mode == 0 || !((mask >> which) & 1) || d->overlap || N < 1 || N > 0x3fffffff || len < 1) return nullptr;
   const int cus = device_cus(), occ = cus > 0 ? resident_blocks(fn, lds_balanced) : 0;
-  if (occ < 1) return sc;
+  if (occ < 1) return nullptr;
   const long long P = (long long)cus * occ;
-  if (mode != 2 && N * len < P * 16) return sc;                 // small launches: the chunk model of balanced_chunk
+  if (mode != 2 && N * len < P * 16) return nullptr;            // small launches: the chunk model of balanced_chunk
   const auto key = std::make_tuple(N, len, (int)P);
   auto it = d->sched_cache.find(key);
   if (it == d->sched_cache.end()) {
-    Sched n = {(int)P, 0, (int)N, len, 0, 0, nullptr};
+    Sched n = {(int)P, 0, (int)N, len, 0, 0};
     const long long q = N / P, R = N - q * P;
     n.W = (int)(q * P);
+    std::vector<int> tab;
     if (R) {
       long long piece = (R * len + P - 1) / P;
       if (piece < 8) piece = std::min<long long>(len, 8);        // (a segment re-primes its pipeline: none shorter than 8 cells)
@@ -1294,20 +1297,20 @@ static Sched pick_sched(mw_dycore_s *d, const void *fn, size_t lds_balanced, lon
         if (rest > 0) second.push_back({rest, sl});
       }
       std::sort(second.begin(), second.end(), [](const std::pair<long long, int> &a, const std::pair<long long, int> &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
-      std::vector<int> tab; for (auto &pr : second) tab.push_back(pr.second);
-      if (!tab.empty()) {
-        int *dev = nullptr;
-        if (hipMalloc(&dev, tab.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return sc; }
-        if (hipMemcpy(dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dev); return sc; }
-        n.tab = dev;
-      }
-      d->sched_n2[key] = (int)tab.size();
-    } else d->sched_n2[key] = 0;
-    it = d->sched_cache.emplace(key, n).first;
+      for (auto &pr : second) tab.push_back(pr.second);
+    }
+    std::vector<int> img(sizeof(Sched) / sizeof(int) + tab.size());
+    memcpy(img.data(), &n, sizeof(Sched));
+    if (!tab.empty()) memcpy(img.data() + sizeof(Sched) / sizeof(int), tab.data(), tab.size() * sizeof(int));
+    int *dev = nullptr;
+    if (hipMalloc(&dev, img.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemcpy(dev, img.data(), img.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dev); return nullptr; }
+    mw_dycore_s::SchedEntry en; en.dev = (const Sched *)dev; en.wgs = (unsigned)(n.W + n.nsl + (int)tab.size());
+    it = d->sched_cache.emplace(key, en).first;
   }
-  sc = it->second;
-  grid = dim3((unsigned)(sc.W + sc.nsl + d->sched_n2[key]));
-  return sc;
+  grid = dim3(it->second.wgs);
+  return it->second.dev;
+#endif
 }
 
 // Which compile-time configuration of the marching kernels (Cf<K>) fits this view of the handle: 1 / 2 = the shipped supercell /
@@ -1402,7 +1405,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
       const int n = (int)grid.y;
       row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk);
     }
-#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, classic_sched(row_end - row0, chunk), pre_lo, pre_hi)
+#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, nullptr, pre_lo, pre_hi)
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
     if (marching_config(p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
@@ -1430,8 +1433,8 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
       }
     }
     // (part 0 / 1 = one contiguous row range [row0, row_end): the balanced schedule applies; the two edge strips of part 2 stay chunks)
-#define MW_YA(C_, K_, O_, T_) do { dim3 g_ = grid; const Sched sc_ = (part == 2) ? classic_sched(row_end - row0, chunk) : \
-                                  pick_sched(d, (const void *)&k_y_all<C_, K_, O_, T_>, 0, (long long)grid.x, row_end - row0, chunk, g_, 0); \
+#define MW_YA(C_, K_, O_, T_) do { dim3 g_ = grid; const Sched *sc_ = (part == 2) ? nullptr : \
+                                  pick_sched(d, (const void *)&k_y_all<C_, K_, O_, T_>, 0, (long long)grid.x, row_end - row0, g_, 0); \
                                 hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), g_, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
                                                  conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_, pre_lo, pre_hi); } while (0)
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
@@ -1509,7 +1512,7 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
       const size_t lds = (size_t)(chunk + 2) * 64 * 4;
 #define MW_XZ_MT(K_) { if (d->ord == 3) MW_XZ_MTO(K_, 3); else MW_XZ_MTO(K_, 5); }
 #define MW_XZ_MTO(K_, O_) hipLaunchKernelGGL((k_xz_state<3, true, 1, 1, K_, O_, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
-                                        d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo, classic_sched(p.nz, chunk))
+                                        d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo, nullptr)
       if (marching_config(p) == 1) MW_XZ_MT(1) else MW_XZ_MT(0)
 #undef MW_XZ_MT
 #undef MW_XZ_MTO
@@ -1528,8 +1531,8 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
     // (k_xz_state<.., HPL = 1>; dynamic LDS = the chunk's rows)
     // (balanced schedule: a segment can be a whole column -- the LDS table then holds nz + 2 rows)
 #define MW_XZ(N1_, HPL_, K_, O_, lds) do { dim3 g_ = grid; const size_t lds_bal_ = (lds) ? (size_t)(p.nz + 2) * 64 : 0; \
-                                        const Sched sc_ = pick_sched(d, (const void *)&k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>, lds_bal_, (long long)grid.x, p.nz, chunk, g_, 1); \
-                                        hipLaunchKernelGGL((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), g_, dim3(256), sc_.P ? lds_bal_ : (lds), d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
+                                        const Sched *sc_ = pick_sched(d, (const void *)&k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>, lds_bal_, (long long)grid.x, p.nz, g_, 1); \
+                                        hipLaunchKernelGGL((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), g_, dim3(256), sc_ ? lds_bal_ : (lds), d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
                                                         MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, MemberOff(), sc_); } while (0)
 #define MW_XZ_K(K_) { if (d->ord == 3) MW_XZ(true, 1, K_, 3, hpl_bytes); else MW_XZ(true, 1, K_, 5, hpl_bytes); }
     const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
@@ -1591,7 +1594,7 @@ template <int STAGE, int MODE, int T, bool N1, int K, int ORD = 5>
 static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
   const int e = v.e;
-  const Sched sc = pick_sched(d, (const void *)&k_tracers_fused<STAGE, MODE, T, N1, K, ORD>, 0, (long long)grid.x, v.p.nz, chunk, grid, 2);
+  const Sched *sc = pick_sched(d, (const void *)&k_tracers_fused<STAGE, MODE, T, N1, K, ORD>, 0, (long long)grid.x, v.p.nz, grid, 2);
   hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1, K, ORD>), grid, dim3(256), 0, st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
                      d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
                      d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4, MemberOff(), sc);
@@ -1615,7 +1618,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
 #define MW_FUSED_MT(TT) case TT: MW_FUSED_MTK(TT, 0) break;
 #define MW_FUSED_MTK(TT, K_) { if (d->ord == 3) MW_FUSED_MTO(TT, K_, 3); else MW_FUSED_MTO(TT, K_, 5); }
 #define MW_FUSED_MTO(TT, K_, O_) hipLaunchKernelGGL((k_tracers_fused<3, 1, TT, true, K_, O_, true>), grid, dim3(256), 0, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
-                                 d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo, classic_sched(p.nz, chunk))
+                                 d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo, nullptr)
       if (marching_config(p) == 1) MW_FUSED_MTK(3, 1)
       else switch (p.nt) { MW_FUSED_MT(1) MW_FUSED_MT(2) MW_FUSED_MT(3) MW_FUSED_MT(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
 #undef MW_FUSED_MT
@@ -1628,7 +1631,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const DyP &p = v.p;
       const int U = p.nens == 1 ? 64 - 2 * ((d->ord - 1) / 2 + 1) : 64 - 4 * p.nens;   // hs + 1 / 2 halo cells per side (k_tracers_fused)
       const int tiles_x = (p.nx * p.nens + U - 1) / U;
-      const int rows4 = p.ny >= 4 ? 1 : 0;
+      const int rows4 = (p.ny >= 4 && !getenv("MW_TF_NO_ROWS4")) ? 1 : 0;   // (workgroup = 4 rows of one x tile: the rows' shared y faces meet in L1; MW_TF_NO_ROWS4: 4 x tiles of one row, A/B)
       const long long waves = (long long)p.ny * tiles_x;
       const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F", 10000, 2, 4.5, true));
       dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
@@ -1916,7 +1919,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
   for (int w = 0; w < 9; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  for (auto &kv : d->sched_cache) if (kv.second.tab) (void)hipFree(const_cast<int *>(kv.second.tab));
+  for (auto &kv : d->sched_cache) if (kv.second.dev) (void)hipFree(const_cast<mw::Sched *>(kv.second.dev));
   delete d;
 }
 

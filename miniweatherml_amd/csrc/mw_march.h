@@ -110,9 +110,12 @@ __device__ __forceinline__ BlockXY xcd_block() {
 //               length (tab[] = their slices).  A straddling slice's first part is short, ends early, and the slot it frees takes the
 //               longest waiting second part -- its own -- so every slot ends after ~len q + piece cells.
 //   (A persistent form -- one workgroup looping over its segments -- keeps every kernel argument alive across the marching loop:
-//    60-160 SGPR spills in kernels that sit at the register limit.  One segment per workgroup costs nothing.)
+//    60-160 SGPR spills in kernels that sit at the register limit.)
+//   MEASURED (round 4): k_y_all +24 %, k_xz_state +1.5 %, k_tracers_fused -2.5 %: no gain.  The balanced form is therefore
+//   only compiled with -DMW_SCHED_LISTS (tools/build_variant.sh lists -DMW_SCHED_LISTS; MW_SCHED=1|2 at run time; MW_TEST_SCHED_LISTS=1
+//   enables its tests); the default build takes the chunked grid unconditionally.
 // ---------------------------------------------------------------------------------------------------------------
-struct Sched { int P, W, N, len, piece, nsl; const int *__restrict__ tab; };
+struct Sched { int P, W, N, len, piece, nsl; };   // in DEVICE memory, followed by tab[n2] (ints); a launch on the chunked grid passes nullptr
 struct Segment { unsigned col; int a, b; };
 __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg) {   // (see xcd_block: blocks b, b + 8, ... share an XCD)
 #if MW_XCD_SWIZZLE
@@ -122,19 +125,29 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg) {   // (
   return b;
 #endif
 }
-__device__ __forceinline__ bool sched_segment(const Sched &sc, Segment &sg) {
-  if (sc.P == 0) { const BlockXY blk = xcd_block(); sg.col = blk.x; sg.a = (int)blk.y * sc.piece; sg.b = min(sg.a + sc.piece, sc.len); return true; }
+// (the list is one pointer among the kernel arguments: passed by value, its seven words cost the marching kernels 5-13 more SGPR spills
+//  and 16 instructions per level -- they sit at the register limit -- although the default launch never looks at them)
+__device__ __forceinline__ bool sched_segment(const Sched *__restrict__ scp, int chunk, int len, Segment &sg) {
+#ifndef MW_SCHED_LISTS
+  // (the default build: the mere presence of the list branch costs k_xz_state 5 more SGPR spills and 16 instructions per level --
+  //  the segment then arrives as a phi of two paths -- for a schedule that measured no gain; -DMW_SCHED_LISTS builds it in, see Sched)
+  { const BlockXY blk = xcd_block(); sg.col = blk.x; sg.a = (int)blk.y * chunk; sg.b = min(sg.a + chunk, len); return true; }
+#else
+  if (scp == nullptr) { const BlockXY blk = xcd_block(); sg.col = blk.x; sg.a = (int)blk.y * chunk; sg.b = min(sg.a + chunk, len); return true; }
+  const Sched sc = *scp;
+  const int *__restrict__ tab = (const int *)(scp + 1);
   unsigned b = blockIdx.x;
   if (b < (unsigned)sc.W) { sg.col = xcd_remap(b, (unsigned)sc.W); sg.a = 0; sg.b = sc.len; return true; }
   b -= (unsigned)sc.W;                                          // (W is a multiple of 8: the XCD of the block is b % 8 still)
   const bool second = b >= (unsigned)sc.nsl;
-  const long long sl = second ? sc.tab[b - (unsigned)sc.nsl] : xcd_remap(b, (unsigned)sc.nsl);
+  const long long sl = second ? tab[b - (unsigned)sc.nsl] : xcd_remap(b, (unsigned)sc.nsl);
   const long long R = sc.N - sc.W;
   const long long g0 = sl * sc.piece, g1 = min(g0 + sc.piece, R * sc.len);
   const int c = (int)(g0 / sc.len);
   if (!second) { sg.col = (unsigned)(sc.W + c); sg.a = (int)(g0 - (long long)c * sc.len); sg.b = (int)min((long long)sc.len, sg.a + (g1 - g0)); return sg.b > sg.a; }
   sg.col = (unsigned)(sc.W + c + 1); sg.a = 0; sg.b = (int)(g1 - (long long)(c + 1) * sc.len);   // (piece <= len: one boundary at most)
   return sg.b > 0;
+#endif
 }
 
 // Periodic direction owned by one rank (DyP::wrap_x / wrap_y): the interior index that a halo index stands for.
@@ -613,8 +626,8 @@ __device__ __forceinline__ double tracer_slab_value(double rho_t, double inv_den
 // (see MemberOff) -- the converting launch of such a handle.
 template <bool CONV, int K, int ORD, int T, bool MT = false>
 __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk,
-                                               CouplerPtrs c, double *__restrict__ Sw, MemberOff mo, int row0, int rstride, int row_end, Sched sc,
-                                               int pre_lo, int pre_hi) {
+                                               CouplerPtrs c, double *__restrict__ Sw, MemberOff mo, int row0, int rstride, int row_end,
+                                               const Sched *__restrict__ scp, int pre_lo, int pre_hi) {
   static_assert(!MT || CONV, "the member-co-located form exists for the converting launch only");
   constexpr int NV = 5 + T;
   // (pre_lo < pre_hi: the pipelined multi-rank schedule has converted the strips it packs for the neighbours up front -- the HX cells
@@ -629,10 +642,13 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
     mt_sub = wv >> mo.sh;
     FY += em * mo.fy; tendY += em * mo.tend; Sw += em * mo.slab; S += em * mo.slab; p.hypk += em * mo.per; p.ce = em;
   }
-  // (sc.P > 0: the balanced schedule -- this workgroup's thread column and row segment [ja, jb) come from the launch's list, see Sched)
+  // (scp != nullptr: the balanced schedule -- this workgroup's thread column and row segment [ja, jb) come from the launch's list, see Sched)
   unsigned colx; int ja, jb;
-  if (sc.P) { Segment sg; if (!sched_segment(sc, sg)) return; colx = sg.col; ja = row0 + sg.a; jb = row0 + sg.b; }   // (sc.len = row_end - row0)
-  else { colx = blockIdx.x; ja = row0 + (int)blockIdx.y * rstride; jb = min(ja + chunk, row_end); }   // (a launch covers the rows [row0, row_end) in chunks `rstride` rows apart: all of them, the inner ones, or the two edge strips)
+#ifdef MW_SCHED_LISTS
+  if (scp) { Segment sg; if (!sched_segment(scp, 0, 0, sg)) return; colx = sg.col; ja = row0 + sg.a; jb = row0 + sg.b; }   // (the list's len = row_end - row0)
+  else
+#endif
+  { colx = blockIdx.x; ja = row0 + (int)blockIdx.y * rstride; jb = min(ja + chunk, row_end); }   // (a launch covers the rows [row0, row_end) in chunks `rstride` rows apart: all of them, the inner ones, or the two edge strips)
   long long t = (long long)colx * 256 + threadIdx.x;             // flattened (k, ie): no idle tail per row
   if (MT) t = ((long long)colx * (4 >> mo.sh) + mt_sub) * 64 + (threadIdx.x & 63);
   if (t >= (long long)p.nz * NXI) return;
@@ -646,12 +662,17 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
   constexpr int HS = (ORD - 1) / 2;
   double w[NV][ORD], nxt[NV], cn[NV], fprev_r[CONV ? 1 : 5];
+  // (the pre-converted cells, see above: the lane's column inside a west / east strip, rows outside [plo_, phi_))
+  // -> this lane's slab rows are [sja_, sjb_): the chunk's rows minus the pre-converted ones (an empty range for a strip column)
+  const bool pre_on_ = pre_lo < pre_hi;
+  const int sja_ = pre_on_ ? max(ja, pre_lo) : ja;
+  const int sjb_ = (pre_on_ && (ie < p.HX * p.nens || ie >= NXI - p.HX * p.nens)) ? sja_ : (pre_on_ ? min(jb, pre_hi) : jb);
 #define MW_ROW_CI(r) cpl(p, ((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
 #define MW_ROW_FINISH(raw, r, out)                                                                                    \
   { double inv_den_;                                                                                                  \
     convert_cell_fast<K>(p, raw, hyr, hyt, p0, out, inv_den_);                                                        \
     _Pragma("unroll") for (int v_ = 0; v_ < T; v_++) out[5 + v_] = tracer_slab_value(raw.tr[v_], inv_den_);          \
-    if ((r) >= ja && (r) < jb && !(pre_lo < pre_hi && ((r) < pre_lo || (r) >= pre_hi || ie < p.HX * p.nens || ie >= NXI - p.HX * p.nens))) { \
+    if ((r) >= sja_ && (r) < sjb_) {                                                                                  \
       double *s_ = Sw + (long long)(k + p.HZ) * p.sK + (long long)((r) + p.HY) * p.sJ + (long long)p.HX * p.nens + ie; \
       _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++) s_[(long long)v_ * p.sV] = out[v_];                           \
     } }
@@ -848,7 +869,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
                                                   unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                   const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
                                                   int tiles_x, double *__restrict__ cu, double *__restrict__ cv, double *__restrict__ cw,
-                                                  MemberOff mo, Sched sc) {
+                                                  MemberOff mo, const Sched *__restrict__ scp) {
   static_assert(!MT || (N1 && HPL && MODE == 1), "the member-co-located form is the D13 variant of the nens == 1 kernel");
   constexpr int HS = (ORD - 1) / 2;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -862,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   __shared__ double lds_xpart[5][256], lds_fzprev[5][256];
   extern __shared__ double lds_hp_all[];
   Segment sg;                                                   // (from the launch grid or the balanced schedule's list, see Sched)
-  if (!sched_segment(sc, sg)) return;
+  if (!sched_segment(scp, chunk, p.nz, sg)) return;
   const XzGeom g = xz_geom<N1, ORD>(p, sg.col, sg.a, sg.b, tiles_x, 0, MT ? mt_sub : -1, MT ? 4 >> mo.sh : 4);
   const int seg_len = sg.b - sg.a;
   // HPL (nens == 1): the eight background values of every level of this chunk (DyP::hypk rows kstart..kb) are copied to LDS once
@@ -1347,7 +1368,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
                                                        const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
                                                        const unsigned char *__restrict__ UPZ, double *__restrict__ DS,
                                                        double *__restrict__ DN, unsigned char *__restrict__ flags, unsigned int *__restrict__ dirty,
-                                                       double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4, MemberOff mo, Sched sc) {
+                                                       double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4, MemberOff mo,
+                                                       const Sched *__restrict__ scp) {
   static_assert(N1 || ORD == 5, "the neighbour-load form exists for WENO-5 only");
   static_assert(!MT || (N1 && MODE == 1), "the member-co-located form (see MemberOff) is the D13 variant of the nens == 1 kernel");
   constexpr int HS = (ORD - 1) / 2;
@@ -1373,7 +1395,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   constexpr bool LC = true;
   __shared__ double lds_c[8];
   Segment sg;                                                   // (from the launch grid or the balanced schedule's list, see Sched)
-  if (!sched_segment(sc, sg)) return;
+  if (!sched_segment(scp, chunk, p.nz, sg)) return;
   int j, tx;
   if (MT)         { const int rpb = 4 >> mo.sh, jg = (int)(sg.col / tiles_x); tx = (int)(sg.col - (unsigned)jg * tiles_x); j = jg * rpb + mt_sub; }   // rows of one tile
   else if (rows4) { const int jg = (int)(sg.col / tiles_x); tx = (int)(sg.col - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }

@@ -75,6 +75,7 @@ def test_time_steps_match_oracle(mw, oracle, name, mode):
     assert abs(dycore.etime - 10 * dt) < 1e-12
 
 
+@pytest.mark.skipif(not os.environ.get("MW_TEST_SCHED_LISTS"), reason="the balanced launch lists exist in a -DMW_SCHED_LISTS build only (a measured dead end, DESIGN.md 0c)")
 @pytest.mark.parametrize("name", sorted(SNAP["cases"]))
 def test_balanced_schedule_bitwise_equal_to_chunked_grid(mw, oracle, name, monkeypatch):
     """The marching kernels' balanced launch lists (round 4: whole columns first, then equal slices of the remaining columns, the parts

@@ -32,9 +32,9 @@ def test_random_configuration(mw, oracle, seed, monkeypatch):
     c = draw(seed)
     for k, v in c["chunks"].items():
         monkeypatch.setenv(k, v)
-    # every other seed: the balanced launch lists (Sched, mw_march.h) forced at these small sizes -- whole columns, slices, and the second
+    # every other seed: the balanced launch lists (Sched, mw_march.h; only in a -DMW_SCHED_LISTS build, MW_TEST_SCHED_LISTS=1) forced at these small sizes -- whole columns, slices, and the second
     # parts of slices that straddle a column boundary; the others run the chunked grid with the drawn chunk sizes
-    monkeypatch.setenv("MW_SCHED", "2" if seed % 2 else "0")
+    monkeypatch.setenv("MW_SCHED", "2" if (seed % 2 and os.environ.get("MW_TEST_SCHED_LISTS")) else "0")
     nx, ny, nz, nens, nt = c["nx"], c["ny"], c["nz"], c["nens"], c["nt"]
     xlen, ylen = 500.0 * nx, 500.0 * max(ny, 2)
 
