@@ -1,6 +1,8 @@
 #!/bin/bash
 # Builds gpurun_out-independent VARIANTS of libmw_cdna4.so with extra hipcc flags for A/B timing (MW_LIB_PATH selects one at run time):
 #   bash tools/build_variant.sh <name> <extra flags...>   ->  miniweatherml_amd/ab/libmw_<name>.so
+# (miniweatherml_amd/ab/ is listed in .gpurunignore so that stale A/B builds never travel with a round-end push: take the line out for
+#  the gpurun call that times them, and `rm -rf miniweatherml_amd/ab` afterwards)
 set -e
 name=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
