@@ -796,6 +796,7 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
 //   What would close the gap is a member-major layout of the handle's internal arrays (every kernel then runs its nens = 1 path per
 //   member and only the coupler-side accesses are strided) -- not done.)
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool lane_init_xnb(unsigned t) { return (t & 63) < 4; }   // (MW_EXP_LDS_XNB: lanes 0..3 zero the row's four padding cells)
 struct XzGeom {
   int n, lane, NXI, j, q, qq, qa, e, i, qc, ka, kb, kstart;   // qq: index incl. halo (BC logic), qa: the index that is addressed (wrapped)
   int cell_lo, cell_hi, face_hi;                              // lanes [cell_lo, cell_hi) own a cell, [cell_lo, face_hi) a lower x face
@@ -881,6 +882,10 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   }
   __shared__ double lds_c[8];
   __shared__ double lds_xpart[5][256], lds_fzprev[5][256];
+#ifdef MW_EXP_LDS_XNB
+  __shared__ double lds_xnb[5][4][68];
+  if (lane_init_xnb(threadIdx.x)) { for (int v = 0; v < 5; v++) { lds_xnb[v][threadIdx.x >> 6][(threadIdx.x & 63) < 2 ? (threadIdx.x & 63) : (threadIdx.x & 63) + 64] = 0.0; } }
+#endif
   extern __shared__ double lds_hp_all[];
   Segment sg;                                                   // (from the launch grid or the balanced schedule's list, see Sched)
   if (!sched_segment(scp, chunk, p.nz, sg)) return;
@@ -1007,6 +1012,17 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
         double c0 = w[v][HS], m2, m1, p1, p2;
         if (ORD == 3) { m1 = from_west<true>(c0, lane, n); p1 = from_east<true>(c0, lane, n); weno3_edges_fast(m1, c0, p1, we[v], ee[v]); }
         else {
+#ifdef MW_EXP_LDS_XNB
+          // Timing experiment: the four x neighbours through a wave-private LDS row (one write, four reads: LDS
+          // instructions) instead of four DPP wave shifts (eight VALU moves).  The row is padded by two zeros per side.
+          if (N1) {
+            lds_xnb[v][wv][lane + 2] = c0;
+            // (the other lanes' writes must be ordered before this lane's reads: per thread the addresses differ, so the compiler
+            //  would otherwise be free to hoist the reads; the LDS queue itself is in order per wave)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            m2 = lds_xnb[v][wv][lane]; m1 = lds_xnb[v][wv][lane + 1]; p1 = lds_xnb[v][wv][lane + 3]; p2 = lds_xnb[v][wv][lane + 4];
+          } else
+#endif
           x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK, g.om2, g.om1, g.op1, g.op2, lane, n, m2, m1, p1, p2);
           weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
         }
