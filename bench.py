@@ -57,8 +57,10 @@ def parse():
     ap.add_argument("--cpu-sample", type=str, default="200x200x50", help="oracle sample grid nx x ny x nz")
     ap.add_argument("--strict", type=int, default=0)
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl", help="halo-exchange transport for N > 1")
-    ap.add_argument("--workload", choices=["config2", "config4", "config5"], default="config2",
-                    help="config2 (default): BASELINE.json configs[1], 400x400x100 nens 1 per GPU, dx 500 m.  config4: configs[3]'s per-GPU "
+    ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config2",
+                    help="config2 (default): BASELINE.json configs[1], 400x400x100 nens 1 per GPU, dx 500 m.  config3: configs[2], the same grid with the "
+                         "complete surrogate loop of inference_ponni.cpp:69-82 (dycore, ponni MLP inference beside the true Kessler step, sponge_layer, "
+                         "ColumnNudger); not the headline metric.  config4: configs[3]'s per-GPU "
                          "block 256x512x128 nens 4, dx 800 m (weak-scaling series 256x512 ... 1024x1024 global for 1 ... 8 GPUs).  config5: configs[4], "
                          "simple_city 512x512x256 per GPU (immersed buildings, gravity off, water vapour only: V = 6), dx = dy = dz = 5 m; "
                          "--full-loop adds Horizontal_Sponge, sponge_layer and Time_Averager (experiments/simple_city/driver.cpp:66-79)")
@@ -71,6 +73,8 @@ def parse():
                     help="wall-clock limit of a run: a rank that has not finished by then prints where it is and exits non-zero "
                          "(a first contact between GPUs over RCCL must fail fast, not hang the caller's lease)")
     a = ap.parse_args()
+    if a.workload == "config3":
+        a.full_loop = True
     if a.workload == "config4":
         a.nx, a.ny, a.nz, a.nens = 256, 512, 128, 4
     if a.workload == "config5":
@@ -317,7 +321,8 @@ def main():
         micro, city = None, (hs_, ta_)
     elif a.full_loop:
         coupler, dycore, micro, nudger = modules.make_supercell(nx_glob, ny_glob, a.nz, a.nens, xlen, ylen, zlen, "supercell", device,
-                                                                nranks=world, myrank=rank, with_nudger=True, ord=a.ord)
+                                                                nranks=world, myrank=rank, with_nudger=True, ord=a.ord,
+                                                                micro=modules.Microphysics_Kessler_Surrogate() if a.workload == "config3" else None)
     else:
         coupler, dycore, micro = modules.make_supercell(nx_glob, ny_glob, a.nz, a.nens, xlen, ylen, zlen, "supercell", device,
                                                         nranks=world, myrank=rank, ord=a.ord)
@@ -464,16 +469,19 @@ def main():
             except Exception:
                 traffic = dom_traffic = valu_side = derived = None
         what = "complete supercell_example loop: WENO-FV dycore + Kessler + sponge_layer + ColumnNudger" if a.full_loop else "WENO-FV dycore only"
+        if a.workload == "config3":
+            what = "complete supercell_kessler_surrogate loop: WENO-FV dycore + ponni MLP inference (MFMA) beside Kessler + sponge_layer + ColumnNudger"
         if city is not None:
             what = "complete simple_city loop: Horizontal_Sponge + WENO-FV dycore + sponge_layer + Time_Averager" if a.full_loop else "WENO-FV dycore only"
         out = {
-            "metric": "cell-updates/s" + (" (full supercell_example loop)" if a.full_loop else "") + (" (MW_ORD = %d)" % a.ord if a.ord != 5 else ""), "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
+            "metric": "cell-updates/s" + (" (full supercell_kessler_surrogate loop)" if a.workload == "config3" else " (full supercell_example loop)" if a.full_loop else "") + (" (MW_ORD = %d)" % a.ord if a.ord != 5 else ""), "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s %dx%dx%d nens=%d per GPU (global %dx%dx%d, dx = dy = %g m), %s, %d tracer%s, "
                                    "CFL dt" % ("simple_city" if city is not None else "supercell", a.nx, coupler.get_ny(), a.nz, a.nens, nx_glob, ny_glob, a.nz, dxy, what,
                                                V - 5, "" if V == 6 else "s"),
-                       "baseline_config": "configs[3] per-GPU block" if a.workload == "config4" else "configs[4] per-GPU block" if city is not None else "configs[1]",
+                       "baseline_config": "configs[3] per-GPU block" if a.workload == "config4" else "configs[4] per-GPU block" if city is not None else
+                                          "configs[2]" if a.workload == "config3" else "configs[1]",
                        "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict, "weno_order": a.ord,
                        "schedule": sched["streams"], "schedule_code": sched["code"], "y_faces_in_one_launch": sched["y_all"],
                        "rccl_ranks": (infos[0] or {}).get("comm_ranks") if world > 1 else None,
