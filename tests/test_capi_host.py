@@ -187,3 +187,51 @@ def test_h5_weight_reader_survives_malformed_files(mw, tmp_path):
             assert str(e)
             bad += 1
     assert bad >= 6 and ok + bad == len(cases)              # (at least the truncated copies; most random flips miss the structure)
+
+
+def test_ponni_surface_host_side(tmp_path):
+    """miniweatherml_amd/host/mw_ponni.h without a GPU: load_h5_weights<N> through the library's HDF5 reader, the layer classes,
+    Inference::validate / print, a size mismatch between consecutive layers, a rank mismatch of load_h5_weights<N>, and the loud
+    failure of forward_batch_parallel when there is no HIP device (no CPU fallback)."""
+    import subprocess
+    lib = os.path.join(ROOT, "miniweatherml_amd")
+    src = tmp_path / "ponni_host.cpp"
+    src.write_text(r'''
+#include "%s/miniweatherml_amd/host/mw_ponni.h"
+int main(int, char **argv) {
+  try {
+    auto W1 = ponni::load_h5_weights<2>(argv[1], "/dense_6/dense_6", "kernel:0");
+    auto b1 = ponni::load_h5_weights<1>(argv[1], "/dense_6/dense_6", "bias:0");
+    auto W2 = ponni::load_h5_weights<2>(argv[1], "/dense_7/dense_7", "kernel:0");
+    auto b2 = ponni::load_h5_weights<1>(argv[1], "/dense_7/dense_7", "bias:0");
+    printf("shapes %%d %%d %%d %%d %%d %%d w00 %%.9g\n", W1.extent(0), W1.extent(1), b1.extent(0), W2.extent(0), W2.extent(1), b2.extent(0), (double)W1.data[0]);
+    ponni::Matvec<float> m1(W1), m2(W2); ponni::Bias<float> c1(b1), c2(b2); ponni::Relu<float> r1(c1.get_num_outputs(), 0.1);
+    auto model = ponni::create_inference_model(m1, c1, r1, m2, c2);
+    model.validate(); model.print();
+    printf("io %%d %%d layers %%d params %%d\n", model.get_num_inputs(), model.get_num_outputs(), model.num_layers, (int)model.parameters().size());
+    try { auto bad = ponni::create_inference_model(m1, c2); bad.validate(); printf("NOT REACHED\n"); }
+    catch (std::exception &e) { printf("mismatch: %%s\n", e.what()); }
+    try { auto w = ponni::load_h5_weights<1>(argv[1], "/dense_6/dense_6", "kernel:0"); printf("NOT REACHED\n"); }
+    catch (std::exception &e) { printf("rank: %%s\n", e.what()); }
+    if (argc_gpu_less()) {
+      try { DeviceView<float> in{nullptr, {5, 16}}; in.ptr = (float *)0x1000; auto out = model.forward_batch_parallel(in); printf("NOT REACHED\n"); }
+      catch (std::exception &e) { printf("nogpu: %%s\n", e.what()); }
+    }
+  } catch (std::exception &e) { fprintf(stderr, "endrun: %%s\n", e.what()); return 1; }
+  return 0;
+}
+'''.replace("argc_gpu_less()", "mw_device_count() < 1") % ROOT)
+    exe = tmp_path / "ponni_host"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "-x", "c++", str(src), "-o", str(exe), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                           "-L" + lib, "-lmw_cdna4", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe), os.path.join(lib, "data", "supercell_kessler_singlecell_model_weights.h5")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    o = out.stdout
+    assert "shapes 5 10 10 10 4 4" in o and "io 5 4 layers 5 params 104" in o
+    assert "Matvec with 5 inputs and 10 outputs" in o and "Relu with 10 inputs and 10 outputs and negative_slope == 0.1" in o
+    assert "mismatch: ERROR: layer 1 expects 4 inputs, but the layer before it has 10 outputs" in o
+    assert "rank: ERROR: load_h5_weights<1>" in o and "has 2 dimensions" in o
+    assert "NOT REACHED" not in o
+    import torch
+    if not torch.cuda.is_available():
+        assert "nogpu:" in o and ("no HIP device available" in o or "device allocation failed" in o)
