@@ -118,6 +118,18 @@ def test_device_entry_points_fail_loudly_without_gpu(mw):
     assert b"no HIP device" in L.mw_last_error()
     with pytest.raises(capi.MWError):
         capi.check(rc)
+    # round 4's device entry points: the validators and the ponni forward (argument checks first, then "no HIP device")
+    out6 = (C.c_longlong * 6)()
+    assert L.mw_validate_f64(C.c_void_p(0x1000), 10, out6, None) != 0 and b"no HIP device" in L.mw_last_error()
+    assert L.mw_validate_f32(C.c_void_p(0x1000), 10, out6, None) != 0 and b"no HIP device" in L.mw_last_error()
+    assert L.mw_validate_f64(None, 10, out6, None) != 0 and b"bad argument" in L.mw_last_error()
+    from miniweatherml_amd import modules
+    lay = (modules._PonniLayer * 1)(modules._PonniLayer(0, 3, 2, 0.0, 0))
+    w = (C.c_float * 6)(*([0.5] * 6))
+    assert L.mw_ponni_forward(C.cast(lay, C.c_void_p), 1, w, 6, 4, C.c_void_p(0x1000), C.c_void_p(0x2000), None) != 0
+    assert b"no HIP device" in L.mw_last_error()
+    assert L.mw_dycore_schedule(None) == -1
+    assert L.mw_dycore_rccl_info(None, None, None, None) != 0 and b"null handle" in L.mw_last_error()
 
 
 def test_create_rejects_bad_grids(mw):
