@@ -661,6 +661,7 @@ __global__ __launch_bounds__(256) void k_state_to_coupler(DyP p, const double *_
 
 } // namespace mw
 #include "mw_march.h"
+#include "mw_fused.h"
 namespace mw {
 
 // -----------------------------------------------------------------------------------------------------
@@ -1546,6 +1547,29 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
   return 0;
 }
 
+// The state variables' complete stage in one launch (k_state_xyz, mw_fused.h): MW_FUSED_STATE=1, folded configurations with periodic y
+// owned by this rank, nens = 1, WENO-5, ny a multiple of 4.  The stage is then k_state_xyz -> k_y_tracers -> k_tracers_fused.
+static bool fused_state_ok(const mw_dycore_s *d) {
+  const DyP &p = d->p;
+  return getenv("MW_FUSED_STATE") && atoi(getenv("MW_FUSED_STATE")) != 0 && !d->overlap && !d->pipe && d->fused && d->ord == 5 && p.nens == 1 &&
+         !p.sim2d && p.wrap_y && p.ny % 4 == 0 && p.ny >= 8 && marching_config(p) != 0;
+}
+template <int STAGE, int MODE>
+static int launch_state_xyz(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn, int par, const CouplerPtrs &c) {
+  ProfScope ps(d, 0);
+  const DyP &p = d->p;
+  dim3 grid; int chunk, tiles_x;
+  if (xz_grid(d, p, grid, chunk, tiles_x)) return 1;
+  grid.x = (unsigned)((p.ny / 4) * tiles_x);
+  const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
+#define MW_SXYZ(K_) hipLaunchKernelGGL((k_state_xyz<STAGE, MODE, K_>), grid, dim3(256), hpl_bytes, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
+                                       d->UP[par][0], d->UP[par][2], d->M[par][1], d->UP[par][1], dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
+  if (marching_config(p) == 1) MW_SXYZ(1); else MW_SXYZ(2);
+#undef MW_SXYZ
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int T, bool N1>
 static void launch_xz_tracers_t(mw_dycore_s *d, const double *S, dim3 grid, int chunk, int tiles_x, int t0, int par, double dt, int rows4,
                                 hipStream_t st) {
@@ -1692,10 +1716,14 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   d->conv_pending = false;
   // (the converting launch of a member-major handle exists in the members-in-one-workgroup form of the folded configurations only)
   const bool mm_conv_ok = d->mm_direct && !getenv("MW_NO_MM_CONV") && marching_config(view(d, 0).p) != 0;
-  const bool yall = y_all_ok(d) && !(conv && ((d->member_major && !mm_conv_ok) || getenv("MW_NO_Y_ALL_CONV")));   // y faces of state variables and tracers in one launch
+  const bool fxyz = fused_state_ok(d) && !conv;                 // (round 4 experiment: all three directions of the state variables in one launch)
+  const bool yall = !fxyz && y_all_ok(d) && !(conv && ((d->member_major && !mm_conv_ok) || getenv("MW_NO_Y_ALL_CONV")));   // y faces of state variables and tracers in one launch
+  if (fxyz) { if (launch_state_xyz<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1; }
+  else {
   if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin, conv ? &c : nullptr)) return 1; }
   else if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
+  }
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
   // previous stage, which this stream produced itself: it is issued BEFORE the wait for this stage's state kernels and so
   // runs beside them; the state stream's exchange for stage s+1 in turn runs beside this stage's tracer kernels.

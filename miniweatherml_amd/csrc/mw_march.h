@@ -188,7 +188,10 @@ __device__ __forceinline__ FaceState riemann_primary(const DyP &p, double rL, do
   double p_upw = w1 + w2;
   FaceState fs;
   fs.m_upw = (w2 - w1) * (1.0 / 350.0);
-  fs.ind = (mL + mR > 0) ? 0 : 1;
+  // (an explicit, unfused sum: under contract(fast) the compiler may turn mL + mR into fma(uL, rL, mR) or fma(uR, rR, mL), and WHICH one
+  //  depended on the instantiation -- k_state_xyz and k_y_all chose differently -- which flips the selector where the two momenta
+  //  cancel to rounding (v = 0 in a y-symmetric run).  The reference adds the two rounded products, :408.)
+  fs.ind = (__dadd_rn(mL, mR) > 0) ? 0 : 1;
   double r_upw = fs.ind ? rR : rL;
   double u_upw = zero_nrm ? 0.0 : (fs.ind ? uR : uL);
   f_nrm = fs.m_upw * u_upw + p_upw;

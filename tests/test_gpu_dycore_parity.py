@@ -98,6 +98,34 @@ def test_balanced_schedule_bitwise_equal_to_chunked_grid(mw, oracle, name, monke
     compare_fields(res["2"], of.as_dict(), 1e-10, "%s mode 0 balanced schedule, 3 steps" % name, sens[3])
 
 
+@pytest.mark.parametrize("case", ["supercell", "city"])
+def test_fused_state_stage_bitwise_equal_to_production(mw, oracle, case, monkeypatch):
+    """MW_FUSED_STATE=1: the state variables' x, y AND z faces in one z-marching launch (k_state_xyz, mw_fused.h: the y stencil from an
+    LDS tile of the workgroup's four rows, tile-edge faces rebuilt inside the workgroup, three barriers per level) instead of k_y_all's
+    state part + k_xz_state; the tracers' y fluxes then come from k_y_tracers.  Statement by statement the same arithmetic: the
+    coupler's fields after several steps (one of them sub-cycled) are BITWISE those of the production schedule; also against the oracle."""
+    from miniweatherml_amd import modules
+    res = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("MW_FUSED_STATE", fused)
+        monkeypatch.setenv("MW_CHUNK_Z", "7")                  # several z chunks with ghost levels on these small grids
+        if case == "supercell":
+            coupler, dycore, _ = modules.make_supercell(130, 24, 26, 1, 65000., 12000., 20000.)
+            dm = coupler.get_data_manager_readwrite()
+            dm.get("cloud_liquid").fill_(3.0e-4); dm.get("precip_liquid").fill_(1.0e-4)
+        else:
+            coupler, dycore, _, _ = modules.make_simple_city(96, 48, 16, 1, 480., 240., 80., "building")
+        dt = dycore.compute_time_step(coupler)
+        for n in range(3):
+            dycore.time_step(coupler, dt * (2.2 if n == 1 else 1.0))
+        assert dycore.schedule()["code"] & 3 == 0
+        res[fused] = gpu_fields(coupler)
+    for k in res["0"]:
+        assert np.array_equal(res["0"][k], res["1"][k]), k
+    if case == "supercell":
+        assert float(np.abs(res["1"]["vvel"]).max()) > 0.0     # the y direction is alive
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_compute_tendencies_and_fluxes(mw, oracle, mode):
     coupler, dycore, odyc, of = setup_case(oracle, SNAP["cases"]["supercell3d_16x16x8"])
