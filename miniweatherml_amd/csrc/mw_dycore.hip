@@ -1549,22 +1549,29 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
 
 // The state variables' complete stage in one launch (k_state_xyz, mw_fused.h): MW_FUSED_STATE=1, folded configurations with periodic y
 // owned by this rank, nens = 1, WENO-5, ny a multiple of 4.  The stage is then k_state_xyz -> k_y_tracers -> k_tracers_fused.
-static bool fused_state_ok(const mw_dycore_s *d) {
+// (MW_FUSED_STATE=1 | 4: four row-waves per workgroup, two workgroups per CU; 8: eight, one workgroup per CU)
+static int fused_state_rows(const mw_dycore_s *d) {
   const DyP &p = d->p;
-  return getenv("MW_FUSED_STATE") && atoi(getenv("MW_FUSED_STATE")) != 0 && !d->overlap && !d->pipe && d->fused && d->ord == 5 && p.nens == 1 &&
-         !p.sim2d && p.wrap_y && p.ny % 4 == 0 && p.ny >= 8 && marching_config(p) != 0;
+  const char *e = getenv("MW_FUSED_STATE");
+  const int v = e ? atoi(e) : 0, W = v == 8 ? 8 : 4;
+  const bool ok = v != 0 && !d->overlap && !d->pipe && d->fused && d->ord == 5 && p.nens == 1 && !p.sim2d && p.wrap_y && p.ny % W == 0 && p.ny >= 2 * W &&
+                  marching_config(p) != 0;
+  return ok ? W : 0;
 }
+static bool fused_state_ok(const mw_dycore_s *d) { return fused_state_rows(d) != 0; }
 template <int STAGE, int MODE>
 static int launch_state_xyz(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn, int par, const CouplerPtrs &c) {
   ProfScope ps(d, 0);
   const DyP &p = d->p;
   dim3 grid; int chunk, tiles_x;
   if (xz_grid(d, p, grid, chunk, tiles_x)) return 1;
-  grid.x = (unsigned)((p.ny / 4) * tiles_x);
+  const int W = fused_state_rows(d);
+  grid.x = (unsigned)((p.ny / W) * tiles_x);
   const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
-#define MW_SXYZ(K_) hipLaunchKernelGGL((k_state_xyz<STAGE, MODE, K_>), grid, dim3(256), hpl_bytes, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
+#define MW_SXYZ(K_, W_) hipLaunchKernelGGL((k_state_xyz<STAGE, MODE, K_, W_>), grid, dim3(64 * W_), hpl_bytes, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
                                        d->UP[par][0], d->UP[par][2], d->M[par][1], d->UP[par][1], dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
-  if (marching_config(p) == 1) MW_SXYZ(1); else MW_SXYZ(2);
+  if (W == 8) { if (marching_config(p) == 1) MW_SXYZ(1, 8); else MW_SXYZ(2, 8); }
+  else        { if (marching_config(p) == 1) MW_SXYZ(1, 4); else MW_SXYZ(2, 4); }
 #undef MW_SXYZ
   MW_LAUNCH_CHECK();
   return 0;

@@ -18,7 +18,9 @@
 //     (4) y tendency = -(F(j+1) - F(j)) / dy with F(j+1) from the wave above; then x, z, finalise exactly as k_xz_state.
 //   Same arithmetic as k_y_all + k_xz_state statement by statement: results are BITWISE those of the production path.
 // Exists for the folded configurations (Cf<K>, K = 1 / 2: periodic y owned by one rank -> the row index wraps), nens = 1, WENO-5,
-// ny a multiple of 4; selected with MW_FUSED_STATE=1 (the stage is then: k_state_xyz -> k_y_tracers -> k_tracers_fused).
+// ny a multiple of W; selected with MW_FUSED_STATE=4 | 8 = W row-waves per workgroup (the stage is then: k_state_xyz -> k_y_tracers ->
+// k_tracers_fused).  MEASURED: bitwise equal, 1.0-1.35 GB per stage less HBM traffic, and 30 % slower than the two launches it
+// replaces (1.30 + 0.20 ms against 1.14 ms): 1.9-2.1 k instructions per cell at 0.64-0.69 VALU busy.  Not the default.
 // reference: dynamics_euler_stratified_wenofv.h:271-388 (D6), :395-485 (D9), :519-551 (D11), :121-174 (D12) -- all three directions
 // in one lambda there.
 // =====================================================================================================
@@ -26,8 +28,8 @@
 
 namespace mw {
 
-template <int STAGE, int MODE, int K>
-__global__ __launch_bounds__(256, 2) void k_state_xyz(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
+template <int STAGE, int MODE, int K, int W>
+__global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_state_xyz(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
                                                    double *__restrict__ Sout, double *__restrict__ MX, double *__restrict__ MZ,
                                                    unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                    double *__restrict__ MY, unsigned char *__restrict__ UPY, double dt_stage, double dt_dyn,
@@ -37,19 +39,24 @@ __global__ __launch_bounds__(256, 2) void k_state_xyz(DyP p, const double *__res
   constexpr bool N1 = true;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   __shared__ double lds_c[8];
-  __shared__ double lds_xpart[5][256], lds_fzprev[5][256];
-  __shared__ double lds_tile[5][10][64];        // [variable][tile row: 0..2 = rows j0-3..j0-1, 3..6 = the workgroup's rows, 7..9 = j0+4..j0+6][x lane]
-  __shared__ double lds_ne[5][5][64];           // north edge values of rows j0-1 (slot 0) .. j0+3 (slot 4)
-  __shared__ double lds_set[5][64];             // south edge values of row j0+4 (the tile's top face)
-  __shared__ double lds_fy[5][5][64];           // y face fluxes of faces j0 (slot 0) .. j0+4 (slot 4)
+  static_assert(W == 4 || W == 8, "4 row-waves (two workgroups per CU) or 8 (one)");
+  constexpr int NP = (30 + W - 1) / W;           // halo (row, variable) pairs per wave
+  constexpr int NT = (10 + W - 1) / W;           // tile-edge reconstructions per wave
+  __shared__ double lds_xpart[5][64 * W], lds_fzprev[5][64 * W];
+  __shared__ double lds_tile[5][W + 6][64];     // [variable][tile row: 0..2 = rows j0-3..j0-1, 3..W+2 = the workgroup's rows, W+3..W+5 = j0+W..j0+W+2][x lane]
+  __shared__ double lds_ne[5][W + 1][64];       // north edge values of rows j0-1 (slot 0) .. j0+W-1 (slot W)
+  __shared__ double lds_set[5][64];             // south edge values of row j0+W (the tile's top face)
+  __shared__ double lds_fy[5][W + 1][64];       // y face fluxes of faces j0 (slot 0) .. j0+W (slot W)
   extern __shared__ double lds_hp_all[];
   const BlockXY blk = xcd_block();
   const int ka = (int)blk.y * chunk, kb = min(ka + chunk, p.nz);
-  const XzGeom g = xz_geom<true, 5>(p, blk.x, ka, kb, tiles_x, /*rows4*/ 1);
+  XzGeom g = xz_geom<true, 5>(p, blk.x, ka, kb, tiles_x, /*rows4*/ 1);
+  g.j = (int)(blk.x / (unsigned)tiles_x) * W + wv;             // (W rows of one x tile per workgroup)
+  g.valid = g.j < p.ny;
   double *lds_hp = lds_hp_all;
   {
     const int nrow = g.kb - g.kstart + 1;
-    for (int i = threadIdx.x; i < nrow * 8; i += 256) lds_hp[i] = p.hypk[(long long)g.kstart * 8 + i];
+    for (int i = threadIdx.x; i < nrow * 8; i += 64 * W) lds_hp[i] = p.hypk[(long long)g.kstart * 8 + i];
     if (threadIdx.x < 8) {
       const double cdt = (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;
       lds_c[threadIdx.x] = threadIdx.x == 0 ? p.rdx : threadIdx.x == 1 ? p.rdz : threadIdx.x == 2 ? cdt : threadIdx.x == 3 ? -p.grav : 0.0;
@@ -65,17 +72,17 @@ __global__ __launch_bounds__(256, 2) void k_state_xyz(DyP p, const double *__res
   const long long planeC = (long long)p.ny * NXI;
   // the halo rows this wave brings in: pairs (halo row h = 0..5, variable v), pair id = wv + 4 i
   // (wave-uniform row / variable offsets + the lane's x offset: scalar base + one shared VGPR offset per load)
-  long long hoff[8];
-  int hrow[8], hvar[8];
+  long long hoff[NP];
+  int hrow[NP], hvar[NP];
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int id = min(wv + 4 * i, 29);                         // (ids 30, 31 repeat pair 29: harmless duplicates)
+  for (int i = 0; i < NP; i++) {
+    const int id = min(wv + W * i, 29);                         // (ids 30, 31 repeat pair 29: harmless duplicates)
     hrow[i] = id / 5; hvar[i] = id - hrow[i] * 5;
-    const int jr = wrap_row(p, j0 + (hrow[i] < 3 ? hrow[i] - 3 : hrow[i] + 1));
+    const int jr = wrap_row(p, j0 + (hrow[i] < 3 ? hrow[i] - 3 : hrow[i] - 3 + W));
     hoff[i] = (long long)hvar[i] * p.sV + (long long)(jr + p.HY) * p.sJ + (long long)p.HX * n;
   }
 #define MW_HALO_LOAD(i_, kl_) (S + hoff[i_] + (long long)((kl_) + p.HZ) * p.sK)[g.qa]
-  double w[5][ORD], nxt[5], ct[5], hal[8];
+  double w[5][ORD], nxt[5], ct[5], hal[NP];
 #pragma unroll
   for (int v = 0; v < 5; v++) {
     ct[v] = 0; lds_fzprev[v][threadIdx.x] = 0; lds_xpart[v][threadIdx.x] = 0;
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void k_state_xyz(DyP p, const double *__res
     for (int s = 0; s < ORD; s++) w[v][s] = load_zlevel<K>(p, col + (long long)v * p.sV, g.kstart - HS + s, v == idW);
   }
 #pragma unroll
-  for (int i = 0; i < 8; i++) hal[i] = MW_HALO_LOAD(i, min(max(g.kstart, g.ka), g.kb - 1));   // (levels of the chunk: interior, no z rule to apply)
+  for (int i = 0; i < NP; i++) hal[i] = MW_HALO_LOAD(i, min(max(g.kstart, g.ka), g.kb - 1));   // (levels of the chunk: interior, no z rule to apply)
 #pragma unroll
   for (int v = 0; v < 5; v++) landed(w[v]);
   landed(hal);
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void k_state_xyz(DyP p, const double *__res
 #pragma unroll
       for (int v = 0; v < 5; v++) lds_tile[v][3 + wv][lane] = w[v][HS];
 #pragma unroll
-      for (int i = 0; i < 8; i++) lds_tile[hvar[i]][hrow[i] < 3 ? hrow[i] : hrow[i] + 4][lane] = hal[i];
+      for (int i = 0; i < NP; i++) lds_tile[hvar[i]][hrow[i] < 3 ? hrow[i] : hrow[i] + W][lane] = hal[i];
       __syncthreads();
       const double *hq_ = lds_hp + (kl - g.kstart) * 8;
       const double hyr = hq_[0], hyt = hq_[1], p0 = hq_[2], ihyt = hq_[3];
@@ -106,12 +113,12 @@ __global__ __launch_bounds__(256, 2) void k_state_xyz(DyP p, const double *__res
         lds_ne[v][1 + wv][lane] = ne[v];
       }
       MW_SCHED_FENCE();
-      // tile-edge tasks: t < 5: north edge of row j0-1 (variable t); t >= 5: south edge of row j0+4 (variable t-5).  wave w: t = w, w+4, w+8
+      // tile-edge tasks: t < 5: north edge of row j0-1 (variable t); t >= 5: south edge of row j0+W (variable t-5).  wave w: t = w, w+W, ...
 #pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const int t = wv + 4 * i;
+      for (int i = 0; i < NT; i++) {
+        const int t = wv + W * i;
         if (t < 10) {                                          // (wave-uniform)
-          const int v = t < 5 ? t : t - 5, r0 = t < 5 ? 0 : 5; // tile rows r0 .. r0+4: the stencil of tile row 2 / 7
+          const int v = t < 5 ? t : t - 5, r0 = t < 5 ? 0 : W + 1; // tile rows r0 .. r0+4: the stencil of tile row 2 / W+3
           double s_, n_;
           weno5_edges_fast(lds_tile[v][r0][lane], lds_tile[v][r0 + 1][lane], lds_tile[v][r0 + 2][lane], lds_tile[v][r0 + 3][lane], lds_tile[v][r0 + 4][lane], s_, n_);
           if (t < 5) lds_ne[v][0][lane] = n_; else lds_set[v][lane] = s_;
@@ -135,15 +142,15 @@ __global__ __launch_bounds__(256, 2) void k_state_xyz(DyP p, const double *__res
         for (int l = 0; l < 5; l++) lds_fy[l][wv][lane] = fS[l];
         if (g.owns_cell) { const long long fo = (long long)kl * p.fyK + (long long)j * p.fyJ + q; MY[fo] = fs.m_upw; UPY[fo] = (unsigned char)up; }
       }
-      if (wv == 3) {                                           // the tile's top face j0+4: L = own north edge, R = south edge of row j0+4
+      if (wv == W - 1) {                                       // the tile's top face j0+W: L = own north edge, R = south edge of row j0+W
         double fn, fT;
         const double Rr = lds_set[idR][lane], Ru = lds_set[idV][lane], Rt = lds_set[idT][lane], sU = lds_set[idU][lane], sW = lds_set[idW][lane];
         FaceState fs = riemann_primary<K>(p, ne[idR] + hyr, Rr + hyr, ne[idV], Ru, ne[idT], Rt, hyt, p0, ihyt, false, fn, fT);
         const int up = fs.ind;
-        lds_fy[idR][4][lane] = fs.m_upw; lds_fy[idV][4][lane] = fn; lds_fy[idT][4][lane] = fT;
+        lds_fy[idR][W][lane] = fs.m_upw; lds_fy[idV][W][lane] = fn; lds_fy[idT][W][lane] = fT;
         { const double cU = ne[idU], cW = ne[idW];
-          lds_fy[idU][4][lane] = fs.m_upw * (up ? sU : cU);
-          lds_fy[idW][4][lane] = fs.m_upw * (up ? sW : cW); }
+          lds_fy[idU][W][lane] = fs.m_upw * (up ? sU : cU);
+          lds_fy[idW][W][lane] = fs.m_upw * (up ? sW : cW); }
         if (g.owns_cell && j + 1 == p.ny) {                    // face ny has no tile above it to store it
           const long long fo = (long long)kl * p.fyK + (long long)(j + 1) * p.fyJ + q; MY[fo] = fs.m_upw; UPY[fo] = (unsigned char)up; }
       }
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_state_xyz(DyP p, const double *__res
     const int kfc = max(k - 1, g.ka), kxc = min(max(k, g.ka), g.kb - 1);
     const int khn = min(max(k + 1, g.ka), g.kb - 1);           // the level whose y phase runs at the end of this iteration
 #pragma unroll
-    for (int i = 0; i < 8; i++) hal[i] = MW_HALO_LOAD(i, khn);
+    for (int i = 0; i < NP; i++) hal[i] = MW_HALO_LOAD(i, khn);
 #pragma unroll
     for (int l = 0; l < 5; l++) { snv[l] = 0; tyv[l] = tyc[l]; }
     if (STAGE != 1) {

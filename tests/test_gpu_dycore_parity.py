@@ -106,7 +106,7 @@ def test_fused_state_stage_bitwise_equal_to_production(mw, oracle, case, monkeyp
     coupler's fields after several steps (one of them sub-cycled) are BITWISE those of the production schedule; also against the oracle."""
     from miniweatherml_amd import modules
     res = {}
-    for fused in ("0", "1"):
+    for fused in ("0", "1", "8"):                              # 1: four row-waves per workgroup, 8: eight (one workgroup per CU)
         monkeypatch.setenv("MW_FUSED_STATE", fused)
         monkeypatch.setenv("MW_CHUNK_Z", "7")                  # several z chunks with ghost levels on these small grids
         if case == "supercell":
@@ -122,6 +122,7 @@ def test_fused_state_stage_bitwise_equal_to_production(mw, oracle, case, monkeyp
         res[fused] = gpu_fields(coupler)
     for k in res["0"]:
         assert np.array_equal(res["0"][k], res["1"][k]), k
+        assert np.array_equal(res["0"][k], res["8"][k]), k
     if case == "supercell":
         assert float(np.abs(res["1"]["vvel"]).max()) > 0.0     # the y direction is alive
 
