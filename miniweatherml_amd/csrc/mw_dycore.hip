@@ -1554,8 +1554,8 @@ static int fused_state_rows(const mw_dycore_s *d) {
   const DyP &p = d->p;
   const char *e = getenv("MW_FUSED_STATE");
   const int v = e ? atoi(e) : 0, W = v == 8 ? 8 : 4;
-  const bool ok = v != 0 && !d->overlap && !d->pipe && d->fused && d->ord == 5 && p.nens == 1 && !p.sim2d && p.wrap_y && p.ny % W == 0 && p.ny >= 2 * W &&
-                  marching_config(p) != 0;
+  const bool ok = v != 0 && !d->overlap && !d->pipe && d->fused && (d->ord == 5 || d->ord == 3) && p.nens == 1 && !p.sim2d && p.wrap_y && p.ny % W == 0 &&
+                  p.ny >= 2 * W && marching_config(p) != 0;
   return ok ? W : 0;
 }
 static bool fused_state_ok(const mw_dycore_s *d) { return fused_state_rows(d) != 0; }
@@ -1568,11 +1568,13 @@ static int launch_state_xyz(mw_dycore_s *d, const double *S, const double *Sn, d
   const int W = fused_state_rows(d);
   grid.x = (unsigned)((p.ny / W) * tiles_x);
   const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
-#define MW_SXYZ(K_, W_) hipLaunchKernelGGL((k_state_xyz<STAGE, MODE, K_, W_>), grid, dim3(64 * W_), hpl_bytes, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
+#define MW_SXYZO(K_, W_, O_) hipLaunchKernelGGL((k_state_xyz<STAGE, MODE, K_, W_, O_>), grid, dim3(64 * W_), hpl_bytes, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
                                        d->UP[par][0], d->UP[par][2], d->M[par][1], d->UP[par][1], dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
+#define MW_SXYZ(K_, W_) do { if (d->ord == 3) MW_SXYZO(K_, W_, 3); else MW_SXYZO(K_, W_, 5); } while (0)
   if (W == 8) { if (marching_config(p) == 1) MW_SXYZ(1, 8); else MW_SXYZ(2, 8); }
   else        { if (marching_config(p) == 1) MW_SXYZ(1, 4); else MW_SXYZ(2, 4); }
 #undef MW_SXYZ
+#undef MW_SXYZO
   MW_LAUNCH_CHECK();
   return 0;
 }

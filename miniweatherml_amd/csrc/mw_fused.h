@@ -17,10 +17,10 @@
 //         top face j0+4                                                                                                 | barrier
 //     (4) y tendency = -(F(j+1) - F(j)) / dy with F(j+1) from the wave above; then x, z, finalise exactly as k_xz_state.
 //   Same arithmetic as k_y_all + k_xz_state statement by statement: results are BITWISE those of the production path.
-// Exists for the folded configurations (Cf<K>, K = 1 / 2: periodic y owned by one rank -> the row index wraps), nens = 1, WENO-5,
+// Exists for the folded configurations (Cf<K>, K = 1 / 2: periodic y owned by one rank -> the row index wraps), nens = 1, WENO-5 and WENO-3,
 // ny a multiple of W; selected with MW_FUSED_STATE=4 | 8 = W row-waves per workgroup (the stage is then: k_state_xyz -> k_y_tracers ->
 // k_tracers_fused).  MEASURED: bitwise equal, 1.0-1.35 GB per stage less HBM traffic, and 30 % slower than the two launches it
-// replaces (1.30 + 0.20 ms against 1.14 ms): 1.9-2.1 k instructions per cell at 0.64-0.69 VALU busy.  Not the default.
+// replaces (1.30 + 0.20 ms against 1.14 ms): 1.9-2.1 k instructions per cell at 0.64-0.69 VALU busy; a tie at WENO-3.  Not the default.
 // reference: dynamics_euler_stratified_wenofv.h:271-388 (D6), :395-485 (D9), :519-551 (D11), :121-174 (D12) -- all three directions
 // in one lambda there.
 // =====================================================================================================
@@ -28,29 +28,31 @@
 
 namespace mw {
 
-template <int STAGE, int MODE, int K, int W>
+template <int STAGE, int MODE, int K, int W, int ORD>
 __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_state_xyz(DyP p, const double *__restrict__ S, const double *__restrict__ Sn,
                                                    double *__restrict__ Sout, double *__restrict__ MX, double *__restrict__ MZ,
                                                    unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                    double *__restrict__ MY, unsigned char *__restrict__ UPY, double dt_stage, double dt_dyn,
                                                    int chunk, int tiles_x, double *__restrict__ cu, double *__restrict__ cv,
                                                    double *__restrict__ cw) {
-  constexpr int ORD = 5, HS = 2;
+  static_assert(ORD == 5 || ORD == 3, "the marching kernels exist for WENO orders 5 and 3");
+  constexpr int HS = (ORD - 1) / 2, HR = HS + 1;   // stencil half width; halo rows per side (hs + 1: the neighbour's edge value is rebuilt here)
   constexpr bool N1 = true;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   __shared__ double lds_c[8];
   static_assert(W == 4 || W == 8, "4 row-waves (two workgroups per CU) or 8 (one)");
-  constexpr int NP = (30 + W - 1) / W;           // halo (row, variable) pairs per wave
+  constexpr int NPAIR = 2 * HR * 5;              // halo (row, variable) pairs per level: 30 / 20
+  constexpr int NP = (NPAIR + W - 1) / W;        // ... per wave
   constexpr int NT = (10 + W - 1) / W;           // tile-edge reconstructions per wave
   __shared__ double lds_xpart[5][64 * W], lds_fzprev[5][64 * W];
-  __shared__ double lds_tile[5][W + 6][64];     // [variable][tile row: 0..2 = rows j0-3..j0-1, 3..W+2 = the workgroup's rows, W+3..W+5 = j0+W..j0+W+2][x lane]
+  __shared__ double lds_tile[5][W + 2 * HR][64]; // [variable][tile row: 0..HR-1 = rows j0-HR..j0-1, HR..HR+W-1 = the workgroup's rows, then j0+W..j0+W+HR-1][x lane]
   __shared__ double lds_ne[5][W + 1][64];       // north edge values of rows j0-1 (slot 0) .. j0+W-1 (slot W)
   __shared__ double lds_set[5][64];             // south edge values of row j0+W (the tile's top face)
   __shared__ double lds_fy[5][W + 1][64];       // y face fluxes of faces j0 (slot 0) .. j0+W (slot W)
   extern __shared__ double lds_hp_all[];
   const BlockXY blk = xcd_block();
   const int ka = (int)blk.y * chunk, kb = min(ka + chunk, p.nz);
-  XzGeom g = xz_geom<true, 5>(p, blk.x, ka, kb, tiles_x, /*rows4*/ 1);
+  XzGeom g = xz_geom<true, ORD>(p, blk.x, ka, kb, tiles_x, /*rows4*/ 1);
   g.j = (int)(blk.x / (unsigned)tiles_x) * W + wv;             // (W rows of one x tile per workgroup)
   g.valid = g.j < p.ny;
   double *lds_hp = lds_hp_all;
@@ -76,9 +78,9 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_state_xyz(DyP p, con
   int hrow[NP], hvar[NP];
 #pragma unroll
   for (int i = 0; i < NP; i++) {
-    const int id = min(wv + W * i, 29);                         // (ids 30, 31 repeat pair 29: harmless duplicates)
+    const int id = min(wv + W * i, NPAIR - 1);                  // (ids beyond the last pair repeat it: harmless duplicates)
     hrow[i] = id / 5; hvar[i] = id - hrow[i] * 5;
-    const int jr = wrap_row(p, j0 + (hrow[i] < 3 ? hrow[i] - 3 : hrow[i] - 3 + W));
+    const int jr = wrap_row(p, j0 + (hrow[i] < HR ? hrow[i] - HR : hrow[i] - HR + W));
     hoff[i] = (long long)hvar[i] * p.sV + (long long)(jr + p.HY) * p.sJ + (long long)p.HX * n;
   }
 #define MW_HALO_LOAD(i_, kl_) (S + hoff[i_] + (long long)((kl_) + p.HZ) * p.sK)[g.qa]
@@ -99,9 +101,9 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_state_xyz(DyP p, con
   // are dead -- and once in front of the loop when the chunk starts at the wall; placed first in the iteration it spilled 26-50 VGPRs.
   auto y_phase = [&](int kl, double (&tyo)[5]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int v = 0; v < 5; v++) lds_tile[v][3 + wv][lane] = w[v][HS];
+      for (int v = 0; v < 5; v++) lds_tile[v][HR + wv][lane] = w[v][HS];
 #pragma unroll
-      for (int i = 0; i < NP; i++) lds_tile[hvar[i]][hrow[i] < 3 ? hrow[i] : hrow[i] + W][lane] = hal[i];
+      for (int i = 0; i < NP; i++) lds_tile[hvar[i]][hrow[i] < HR ? hrow[i] : hrow[i] + W][lane] = hal[i];
       __syncthreads();
       const double *hq_ = lds_hp + (kl - g.kstart) * 8;
       const double hyr = hq_[0], hyt = hq_[1], p0 = hq_[2], ihyt = hq_[3];
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_state_xyz(DyP p, con
 #pragma unroll
       for (int v = 0; v < 5; v++) {                             // (one variable at a time: all LDS reads hoisted in front of the arithmetic would spill)
         MW_SCHED_FENCE();
-        weno5_edges_fast(lds_tile[v][1 + wv][lane], lds_tile[v][2 + wv][lane], w[v][HS], lds_tile[v][4 + wv][lane], lds_tile[v][5 + wv][lane], se[v], ne[v]);
+        if (ORD == 3) weno3_edges_fast(lds_tile[v][HR - 1 + wv][lane], w[v][HS], lds_tile[v][HR + 1 + wv][lane], se[v], ne[v]);
+        else          weno5_edges_fast(lds_tile[v][1 + wv][lane], lds_tile[v][2 + wv][lane], w[v][HS], lds_tile[v][4 + wv][lane], lds_tile[v][5 + wv][lane], se[v], ne[v]);
         lds_ne[v][1 + wv][lane] = ne[v];
       }
       MW_SCHED_FENCE();
@@ -118,9 +121,10 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_state_xyz(DyP p, con
       for (int i = 0; i < NT; i++) {
         const int t = wv + W * i;
         if (t < 10) {                                          // (wave-uniform)
-          const int v = t < 5 ? t : t - 5, r0 = t < 5 ? 0 : W + 1; // tile rows r0 .. r0+4: the stencil of tile row 2 / W+3
+          const int v = t < 5 ? t : t - 5, r0 = t < 5 ? 0 : W + 1; // tile rows r0 .. r0+ORD-1: the stencil of tile row HR-1 (row j0-1) / HR+W (row j0+W)
           double s_, n_;
-          weno5_edges_fast(lds_tile[v][r0][lane], lds_tile[v][r0 + 1][lane], lds_tile[v][r0 + 2][lane], lds_tile[v][r0 + 3][lane], lds_tile[v][r0 + 4][lane], s_, n_);
+          if (ORD == 3) weno3_edges_fast(lds_tile[v][r0][lane], lds_tile[v][r0 + 1][lane], lds_tile[v][r0 + 2][lane], s_, n_);
+          else          weno5_edges_fast(lds_tile[v][r0][lane], lds_tile[v][r0 + 1][lane], lds_tile[v][r0 + 2][lane], lds_tile[v][r0 + 3][lane], lds_tile[v][r0 + 4][lane], s_, n_);
           if (t < 5) lds_ne[v][0][lane] = n_; else lds_set[v][lane] = s_;
         }
         MW_SCHED_FENCE();
@@ -196,8 +200,11 @@ __global__ __launch_bounds__(64 * W, W == 4 ? 2 : 1) void k_state_xyz(DyP p, con
 #pragma unroll
       for (int v = 0; v < 5; v++) {
         double c0 = w[v][HS], m2, m1, p1, p2;
-        x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK, g.om2, g.om1, g.op1, g.op2, lane, n, m2, m1, p1, p2);
-        weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
+        if (ORD == 3) { m1 = from_west<true>(c0, lane, n); p1 = from_east<true>(c0, lane, n); weno3_edges_fast(m1, c0, p1, we[v], ee[v]); }
+        else {
+          x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK, g.om2, g.om1, g.op1, g.op2, lane, n, m2, m1, p1, p2);
+          weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
+        }
       }
       double Lv[5];
 #pragma unroll

@@ -98,8 +98,9 @@ def test_balanced_schedule_bitwise_equal_to_chunked_grid(mw, oracle, name, monke
     compare_fields(res["2"], of.as_dict(), 1e-10, "%s mode 0 balanced schedule, 3 steps" % name, sens[3])
 
 
+@pytest.mark.parametrize("order", [5, 3])
 @pytest.mark.parametrize("case", ["supercell", "city"])
-def test_fused_state_stage_bitwise_equal_to_production(mw, oracle, case, monkeypatch):
+def test_fused_state_stage_bitwise_equal_to_production(mw, oracle, case, order, monkeypatch):
     """MW_FUSED_STATE=1: the state variables' x, y AND z faces in one z-marching launch (k_state_xyz, mw_fused.h: the y stencil from an
     LDS tile of the workgroup's four rows, tile-edge faces rebuilt inside the workgroup, three barriers per level) instead of k_y_all's
     state part + k_xz_state; the tracers' y fluxes then come from k_y_tracers.  Statement by statement the same arithmetic: the
@@ -110,10 +111,12 @@ def test_fused_state_stage_bitwise_equal_to_production(mw, oracle, case, monkeyp
         monkeypatch.setenv("MW_FUSED_STATE", fused)
         monkeypatch.setenv("MW_CHUNK_Z", "7")                  # several z chunks with ghost levels on these small grids
         if case == "supercell":
-            coupler, dycore, _ = modules.make_supercell(130, 24, 26, 1, 65000., 12000., 20000.)
+            coupler, dycore, _ = modules.make_supercell(130, 24, 26, 1, 65000., 12000., 20000., ord=order)
             dm = coupler.get_data_manager_readwrite()
             dm.get("cloud_liquid").fill_(3.0e-4); dm.get("precip_liquid").fill_(1.0e-4)
         else:
+            if order != 5:
+                pytest.skip("make_simple_city builds the default order")
             coupler, dycore, _, _ = modules.make_simple_city(96, 48, 16, 1, 480., 240., 80., "building")
         dt = dycore.compute_time_step(coupler)
         for n in range(3):
