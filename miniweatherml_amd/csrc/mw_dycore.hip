@@ -919,6 +919,7 @@ struct mw_dycore_s {
   int last_march = 0;                        // the last time_step ran on the marching kernels (mw_dycore_schedule)
   int pipe = 0;                              // blocks of a decomposed domain: pipelined one-stream schedule (rk_stage_pipe)
   bool pipe_ready = false;                   // ... the next stage's input strips are already on their way (event ev_pipe[2])
+  bool pipe_edge_done = false;               // ... and its two edge strips of the y launch were issued behind them on the exchange stream
   hipEvent_t ev_pipe[3] = {nullptr, nullptr, nullptr};
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
@@ -1389,8 +1390,9 @@ static bool y_all_ok(const mw_dycore_s *d) {
 // part: 0 = all rows; 1 = the rows whose chunks read no halo row (all of them with the row wrap), 2 = the two edge strips of
 // MW_Y_EDGE rows (short chunks: their launch runs between the exchange and k_xz_state, with a quarter of the wavefronts)
 #define MW_Y_EDGE 4                                            // (>= 4: the converting inner launch requests coupler rows up to row_end + 3 < ny)
-static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv, int part = 0) {
-  ProfScope ps(d, 5);
+static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv, int part = 0, hipStream_t st = nullptr) {
+  if (!st) st = d->stream;
+  ProfScope ps(d, 5, st);
   // the cells the pipelined schedule converted up front (time_step): the converting launch leaves them alone (see k_y_all)
   const int pre_lo = (conv && part == 1) ? d->pre_lo : 0, pre_hi = (conv && part == 1) ? d->pre_hi : 0;
   if (conv && d->member_major) {                                // mm_direct: all members in one launch, the members of the same cells in one workgroup
@@ -1406,7 +1408,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
       const int n = (int)grid.y;
       row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk);
     }
-#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, d->stream, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, nullptr, pre_lo, pre_hi)
+#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, st, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, nullptr, pre_lo, pre_hi)
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
     if (marching_config(p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
@@ -1436,7 +1438,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     // (part 0 / 1 = one contiguous row range [row0, row_end): the balanced schedule applies; the two edge strips of part 2 stay chunks)
 #define MW_YA(C_, K_, O_, T_) do { dim3 g_ = grid; const Sched *sc_ = (part == 2) ? nullptr : \
                                   pick_sched(d, (const void *)&k_y_all<C_, K_, O_, T_>, 0, (long long)grid.x, row_end - row0, g_, 0); \
-                                hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), g_, dim3(256), 0, d->stream, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
+                                hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), g_, dim3(256), 0, st, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
                                                  conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_, pre_lo, pre_hi); } while (0)
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
@@ -1772,15 +1774,21 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   ProfScope stage_scope(d, 8, ss);
   const bool conv = (STAGE == 1) && d->conv_pending;            // the inner rows come from the coupler's arrays (see time_step)
   d->conv_pending = false;
+  // (round 4: the two edge strips of the y launch run on the EXCHANGE stream right behind the unpack kernels -- beside the inner rows on
+  //  the compute stream -- instead of behind them: a launch of 2 x 157 workgroups no longer sits alone between k_y_all and k_xz_state)
+  const bool edge_side = !getenv("MW_PIPE_EDGE_INLINE");
   if (!d->pipe_ready) {                                       // this stage's input has not been exchanged yet
     MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
     if (halo_fill(d, Sin, 0, -1, xs, 0, true)) return 1;
+    if (edge_side && launch_y_all(d, Sin, nullptr, 2, xs)) return 1;
     MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
+    d->pipe_edge_done = edge_side;
   }
   d->pipe_ready = false;
   if (launch_y_all(d, Sin, conv ? &c : nullptr, 1)) return 1;  // rows whose chunks read no halo row
   MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));
-  if (launch_y_all(d, Sin, nullptr, 2)) return 1;             // first and last chunk
+  if (!d->pipe_edge_done && launch_y_all(d, Sin, nullptr, 2)) return 1;   // first and last chunk
+  d->pipe_edge_done = false;
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;
   const bool early = (STAGE < 3);                             // the next stage of this cycle reads Sout
   if (early) {
@@ -1791,8 +1799,9 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   if (early) {
     MW_HIP(hipEventRecord(d->ev_pipe[1], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[1], 0));
     if (halo_fill(d, Sout, 5, T, xs, 1, true)) return 1;      // tracer strips, beside the next stage's interior y chunks
+    if (edge_side && launch_y_all(d, Sout, nullptr, 2, xs)) return 1;   // ... and the NEXT stage's edge strips right behind them
     MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
-    d->pipe_ready = true;
+    d->pipe_ready = true; d->pipe_edge_done = edge_side;
   }
   return 0;
 }
@@ -1800,7 +1809,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
 static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, const CouplerPtrs &c) {
   const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
   if (d->pipe) {                                              // blocks of a decomposed domain, pipelined schedule
-    d->pipe_ready = false;
+    d->pipe_ready = false; d->pipe_edge_done = false;
     if (rk_stage_pipe<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;
     if (rk_stage_pipe<2, 0>(d, Q[1], Q[0], Q[2], dt2, dt_dyn, c)) return 1;
     const bool pass13p = d->member_major && !d->mm_direct;
