@@ -101,12 +101,16 @@ def cpu_baseline(sample):
                       "(oracle/mw_oracle.cpp, -O2 -ffp-contract=off), %.1f s on 1 of %d host cores" % (nx, ny, nz, el, os.cpu_count())}
 
 
+# what the release build of the dycore kernels is compiled from (mw_fused.h only enters a -DMW_EXPERIMENTS build)
+KERNEL_SOURCES = ("mw_march.h", "mw_weno.h", "mw_weno79.h", "mw_common.h", "mw_calib.h", "mw_dycore.hip")
+
+
 def kernel_source_hash():
     """sha256 (16 hex digits) over the HIP sources of the dycore kernels: ties counter values copied from a committed
     rocprofv3 summary to the code they were measured on (tools/summarize_profiles.py records the same hash)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("mw_march.h", "mw_weno.h", "mw_weno79.h", "mw_common.h", "mw_dycore.hip"):
+    for f in KERNEL_SOURCES:
         h.update(open(os.path.join(ROOT, "miniweatherml_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -386,11 +390,11 @@ def main():
     prof = {n: dycore.profile_get(i) for i, n in enumerate(KNAMES)}
     dycore.profile(0)
     # Outside the timed region: the same kernels with the two pipelines serialised, so that each kernel's duration is
-    # exclusive.  (With N > 1 -- or MW_OVERLAP=1 -- the state and tracer pipelines of the timed region run on two streams and
+    # exclusive.  (With N > 1 -- or option overlap = 1 -- the state and tracer pipelines of the timed region run on two streams and
     # share the chip; on one rank the default schedule is one stream and the two sets of numbers agree.)
     prof_excl = None
     if not a.strict:
-        os.environ["MW_NO_OVERLAP"] = "1"
+        dycore.set_option("overlap", 0)                          # (a handle option: nothing in this process reads the environment per launch)
         dycore.time_step(coupler, dt)
         torch.cuda.synchronize()
         dycore.profile(1)
@@ -398,7 +402,7 @@ def main():
             dycore.time_step(coupler, dt)
         prof_excl = {n: dycore.profile_get(i) for i, n in enumerate(KNAMES)}
         dycore.profile(0)
-        del os.environ["MW_NO_OVERLAP"]
+        dycore.set_option("overlap", -1)
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

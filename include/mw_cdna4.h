@@ -95,6 +95,21 @@ int  mw_dycore_set_bc(mw_dycore_t h, int bc_x, int bc_y, int bc_z);
  * reference's exact operation order with FMA contraction off (diagnostic / parity proof; also env MW_STRICT=1 at
  * create).  2: the general flux-materialising kernels with the fast arithmetic (A/B of the two kernel structures). */
 int  mw_dycore_set_strict(mw_dycore_t h, int strict);
+/* Run-time options of a handle (no reference counterpart: the reference's variants are compile-time).  They replace the MW_* environment
+ * switches of rounds 1-4: typed integers stored in the handle, read when the schedule of a time step is decided; no entry point of this
+ * library reads the environment per call (the two process defaults left: MW_STRICT=1 at mw_dycore_create, MW_RCCL_LANES for the
+ * built-in transport).  Schedule: "overlap" (-1 automatic | 0 | 1: the two-stream schedule), "pipe" (1: the pipelined schedule of a
+ * decomposed block), "pipe_edge_inline", "pipe_convert".  Kernel forms: "spec" (folded configurations), "wrap" (index wrap on one
+ * rank), "y_all", "y_all_conv", "member_major", "mm_direct", "mm_conv", "fused_convert", "fused_convert_mm", "fused_tracers", "tf_rows4".
+ * Launch shapes: "chunk_y", "chunk_yt", "chunk_z", "chunk_f" (cells per chunk, 0 = the chunk model), "chunk_model".  Built-in transport
+ * (read when mw_dycore_use_rccl / _self installs it): "rccl_lanes" (0 = process default | 1 | 2), "rccl_two_comms" (-1 | 0 | 1),
+ * "xchg_fuzz" (seed of random delays around the sends / receives; a test aid).  Experiments that are not part of the release build:
+ * "fused_state", "debug_no_patch" (-DMW_EXPERIMENTS), "sched", "sched_mask" (-DMW_SCHED_LISTS) -- setting them on a build without
+ * them is an error.  Unknown keys and out-of-range values are errors. */
+int  mw_dycore_set_option(mw_dycore_t h, const char *key, long long value);
+int  mw_dycore_get_option(mw_dycore_t h, const char *key, long long *value);
+/* What this build of the library contains: bit 0 = -DMW_EXPERIMENTS, bit 1 = -DMW_SCHED_LISTS (tools/build_variant.sh); 0 = the release build. */
+int  mw_build_flags(void);
 /* WENO order, the reference's compile-time -DMW_ORD (dynamics_euler_stratified_wenofv.h:24-29; 3 in build/machines/aws/aws_a100_gpu.env:21):
  * 5 (default), 3, 7 or 9.  Call before mw_dycore_init (the supercell initial data uses `ord` GLL points, :1725-1886).  Orders 3, 7
  * and 9 run on the general flux-materialising kernels; 7 and 9 (WenoLimiter<7> / <9>, hs = 3 / 4) re-allocate the handle's slabs
@@ -143,6 +158,21 @@ int  mw_strict_pow(long long n, const double *x, const double *y, double *out, u
  * moves exactly 8n bytes each way, which calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE counters (tools/calib_pmc.py). */
 int  mw_calib_copy(const double *in, double *out, long long n, void *stream);
 
+/* Calibration (no reference counterpart; SURVEY.md 8(d) asks for a measured fp64 ceiling).  mw_calib_fma64: independent v_fma_f64
+ * chains, `waves_per_simd` (1..8) wavefronts per SIMD on every CU for about `seconds`; out5 (HOST) = wave-instructions per second,
+ * kernel ms, shader clock GHz during the run (0 if the part's two counters tick alike), wave-instructions issued, CUs.
+ * mw_calib_stage_arith: the arithmetic of one RK stage and nothing else -- per cell 24 WENO-5 reconstructions + 3 Riemann solves + the
+ * passive fluxes (the production arithmetic) on register windows fed from `tab`, DEVICE (nlev >= 6, 8, 64) doubles that stay in L2
+ * (variables rho', u, v, w, (rho theta)', q_v, q_c, q_r of a 64-cell row; smooth or rough data as the caller likes), `levels` cells per
+ * thread, 256-thread workgroups, two per CU (k_xz_state's shape and register budget).  bg4 (HOST): hy_dens, hy_dens_theta, C0
+ * hy_dens_theta^gamma, 1 / hy_dens_theta of the level.  sink: DEVICE, mw_calib_stage_arith_threads(cells, levels) doubles.  out3
+ * (HOST): ms of the timed launch, cells processed, workgroups.  No stage of that many cells can take less on this chip. */
+int  mw_calib_fma64(int waves_per_simd, double seconds, double *out5, void *stream);
+long long mw_calib_stage_arith_threads(long long cells, int levels);
+int  mw_calib_stage_arith(const double *tab, int nlev, long long cells, int levels, const double *bg4, double *sink, double *out3, void *stream);
+/* Test aid: occupies `stream` for about `usec` microseconds (delay fuzz of the exchange tests). */
+int  mw_debug_spin(long long usec, void *stream);
+
 /* modules::perturb_temperature(coupler, thermal=true, random=false), perturb_temperature.h:41-66 */
 int  mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream);
 /* the random = true branch, perturb_temperature.h:25-39 (applied BEFORE the thermal, as there): +-3 K uniform noise on the lowest
@@ -171,6 +201,13 @@ int  mw_dycore_set_exchange(mw_dycore_t h, mw_exchange_fn fn, void *ctx);
  * unique_id: the 128-byte ncclUniqueId created on rank 0 (mw_rccl_unique_id) and broadcast by the host. */
 int  mw_rccl_unique_id(unsigned char *id128);
 int  mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, int myrank);
+/* Test transport (no reference counterpart): ONE rank plays every rank of the handle's nproc_x x nproc_y rank grid -- a 1-rank
+ * communicator, every active direction's peer is this rank itself (sends W,E,S,N matched FIFO by receives E,W,N,S), i.e. the messages a
+ * block exchanges with neighbours that hold the same data.  For a periodic domain tiled from copies of one block the handle's result
+ * equals the one-rank run of that block bit for bit, with the real send / receive groups, side streams and event pairs of
+ * halo_exchange's replacement in flight beside compute on one GPU.  mw_dycore_rccl_allreduce_sum on such a handle multiplies by the
+ * number of blocks (identical contributions; exact), mw_dycore_rccl_bcast is the identity. */
+int  mw_dycore_use_rccl_self(mw_dycore_t h);
 /* RCCL is resolved at run time from the librccl ALREADY mapped in the process (a PyTorch host: torch's own, the one behind
  * torch.distributed's "nccl" backend), else from the loader's search path -- never two RCCLs in one process.  Returns the
  * path it came from ("" when none is available) and, optionally, its version code (ncclGetVersion). */
@@ -189,8 +226,10 @@ int  mw_dycore_rccl_bcast(mw_dycore_t h, double *buf, long long n, int root, voi
 int  mw_rccl_selftest(long long n, void *stream);
 /* What the last mw_rccl_selftest drove: 10 x the number of exchange lanes (side stream + event pair each; one per pipeline of the
  * two-stream schedule) + the number of communicators behind them: 21 = two lanes on one communicator (default), 22 = a communicator
- * per lane (MW_RCCL_TWO_COMMS=1, split with ncclCommSplit). */
+ * per lane (split with ncclCommSplit).  mw_rccl_selftest_config chooses the form of the following self-tests of this process: lanes
+ * 1 | 2 (0 = back to the process default, MW_RCCL_LANES = "1" | "2" | "2x2"), two_comms 0 | 1. */
 int  mw_rccl_selftest_lanes(void);
+int  mw_rccl_selftest_config(int lanes, int two_comms);
 
 /* ---- Kessler microphysics ------------------------------------------------------------------------- */
 /* Microphysics_Kessler::time_step(coupler, dt), microphysics_kessler.h:99-162 + kessler() :234-339.

@@ -54,6 +54,15 @@ SYMBOLS = {
     "mw_dycore_set_bc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mw_dycore_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
     "mw_dycore_set_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "mw_dycore_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong]),
+    "mw_dycore_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_longlong)]),
+    "mw_build_flags": (C.c_int, []),
+    "mw_calib_fma64": (C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_double), C.c_void_p]),
+    "mw_calib_stage_arith_threads": (C.c_longlong, [C.c_longlong, C.c_int]),
+    "mw_calib_stage_arith": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
+    "mw_debug_spin": (C.c_int, [C.c_longlong, C.c_void_p]),
+    "mw_dycore_use_rccl_self": (C.c_int, [C.c_void_p]),
+    "mw_rccl_selftest_config": (C.c_int, [C.c_int, C.c_int]),
     "mw_dycore_time_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_double]),
     "mw_dycore_compute_tendencies": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_double,
                                                                                C.c_void_p, C.c_void_p]),

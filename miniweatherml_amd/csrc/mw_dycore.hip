@@ -73,7 +73,7 @@ struct CouplerPtrs {
 //   K = 1 (supercell_example, supercell_kessler_surrogate, community_benchmark): gravity on, no immersed boundaries, the three
 //         Kessler tracers;
 //   K = 2 (simple_city): immersed boundaries, gravity off, water vapour only.
-// marching_config() in the host part decides; anything else runs K = 0.
+// marching_config(d, ) in the host part decides; anything else runs K = 0.
 template <int K> struct Cf {
   static constexpr bool spec = (K != 0);
   static __device__ __forceinline__ bool x_periodic(const DyP &p) { return spec || p.bc_x == MW_BC_PERIODIC; }
@@ -661,7 +661,10 @@ __global__ __launch_bounds__(256) void k_state_to_coupler(DyP p, const double *_
 
 } // namespace mw
 #include "mw_march.h"
-#include "mw_fused.h"
+#ifdef MW_EXPERIMENTS
+#include "mw_fused.h"      // k_state_xyz: a measured dead end, kept as a tested experiment outside the release build
+#endif
+#include "mw_calib.h"      // calibration kernels: fp64 FMA ceiling, the arithmetic floor of a stage (WENO + Riemann on registers)
 namespace mw {
 
 // -----------------------------------------------------------------------------------------------------
@@ -903,8 +906,31 @@ __global__ __launch_bounds__(256) void k_calib_copy(const double *__restrict__ i
 // =====================================================================================================
 using namespace mw;
 
+// Run-time options of a handle (mw_dycore_set_option / mw_dycore_get_option; rounds 1-4 read MW_* environment variables per launch
+// instead -- process-global, untyped and racy under threads).  Typed integers, read where the schedule of a time step is decided.
+struct DyOpts {
+  int overlap = -1;            // two-stream schedule (state | tracer pipelines): -1 = automatic (with a transport installed), 0 / 1 forced
+  int pipe = 1;                // with a transport: the pipelined one-stream schedule (rk_stage_pipe) where k_y_all applies
+  int pipe_edge_inline = 0;    // ... its two edge strips of the y launch on the compute stream instead of the exchange stream
+  int pipe_convert = 1;        // ... D1 of the inner rows inside the first k_y_all<true>
+  int spec = 1;                // folded configurations of the marching kernels (Cf<1>, Cf<2>)
+  int wrap = 1;                // index wrap instead of halo cells in a periodic direction owned by one rank
+  int y_all = 1, y_all_conv = 1;      // y faces of all variables in one launch; ... also the converting first stage
+  int member_major = 1, mm_direct = 1, mm_conv = 1;   // nens > 1: member-major arrays; D13 / D1 inside the members-in-one-workgroup launches
+  int fused_convert = 1, fused_convert_mm = 1;        // D1 inside the first y launch (one rank, periodic x and y)
+  int chunk_y = 0, chunk_yt = 0, chunk_z = 0, chunk_f = 0;   // cells per chunk of the marching kernels (0 = the chunk model)
+  int chunk_model = 1;
+  int tf_rows4 = 1;            // tracer stage: workgroup = 4 rows of one x tile (0: 4 tiles of one row)
+  int rccl_lanes = 0, rccl_two_comms = -1;            // built-in RCCL transport: side streams (1 | 2), a communicator per lane (0 | 1); 0 / -1 = the
+                                                      // process default (MW_RCCL_LANES); read when mw_dycore_use_rccl* installs the transport
+  int xchg_fuzz = 0;           // test aid: seeded random delays (spin kernels) around the built-in transport's sends / receives
+  int fused_state = 0, debug_no_patch = 0;            // -DMW_EXPERIMENTS builds only (mw_fused.h; the negative control of the FCT patch pass)
+  int sched = 0, sched_mask = 7;                      // -DMW_SCHED_LISTS builds only (balanced launch lists)
+};
+
 struct mw_dycore_s {
   mw_grid_t g;
+  DyOpts o;
   unsigned char pos[MW_MAX_TRACERS], adds[MW_MAX_TRACERS];
   hipStream_t stream;
   DyP p;
@@ -1205,13 +1231,12 @@ static int launch_update(mw_dycore_s *d, const double *Sstar, const double *Sn, 
 // ~1.7 x faster); o = cells of work a chunk adds (ghost levels, pipeline priming); the last factor is what long chunks lose in
 // cache locality.  Fitted to chunk sweeps on 100 x 100 x 50, 200 x 200 x 50, 256 x 256 x 64, 300 x 300 x 80 and 400 x 400 x 100
 // (tools/tail_probe.py); `model` = false keeps the older rule (enough chunks for `target` waves, none under 8 cells).
-static int balanced_chunk(int nz, long long base_waves, const char *env, long long target, int bpc, double o, bool model) {
-  const char *s = getenv(env);
-  if (s && atoi(s) > 0) return std::min(nz, atoi(s));
+static int balanced_chunk(const mw_dycore_s *d, int nz, long long base_waves, int forced, long long target, int bpc, double o, bool model) {
+  if (forced > 0) return std::min(nz, forced);                 // (options chunk_y / chunk_yt / chunk_z / chunk_f)
   long long nch = std::max(1ll, (target + base_waves - 1) / base_waves);
   nch = std::min<long long>(nch, std::max(1, nz / 8));
   const long long cap = 256ll * bpc;
-  if (!model || getenv("MW_NO_CHUNK_MODEL")) return (int)((nz + nch - 1) / nch);
+  if (!model || !d->o.chunk_model) return (int)((nz + nch - 1) / nch);
   auto t_of = [&](long long B) {
     const long long full = B / cap, rem = B - full * cap;
     if (rem == 0) return (double)full;
@@ -1264,7 +1289,7 @@ static int resident_blocks(const void *fn, size_t lds) {
 // -> the schedule of one launch: nullptr = the chunked grid; else the DEVICE list (Sched header + the order of the straddling slices'
 // second parts), and `grid` becomes the list's length.  N columns of `len` cells.  Built once per (N, len, P) and handle.
 static const Sched *pick_sched(mw_dycore_s *d, const void *fn, size_t lds_balanced, long long N, int len, dim3 &grid, int which) {
-  // MW_SCHED: 0 (default) the chunked grid; 1 the balanced lists where a launch has >= 16 cells per workgroup; 2 forced (tests).
+  // option "sched": 0 (default) the chunked grid; 1 the balanced lists where a launch has >= 16 cells per workgroup; 2 forced (tests).
   // Measured (round 4, 400 x 400 x 100, two boxes, three interleaved repetitions each): k_y_all 1.47 -> 1.83 ms per step with the lists
   // (its chunks keep x-adjacent workgroups on the same row at the same time -- DRAM pages are read out whole; slices start anywhere),
   // k_xz_state 1.98-2.03 -> 2.01-2.04, k_tracers_fused 1.70 -> 1.65-1.68: -1 % of the step at best with the mask 6, so the default stays 0.
@@ -1272,10 +1297,8 @@ static const Sched *pick_sched(mw_dycore_s *d, const void *fn, size_t lds_balanc
   (void)d; (void)fn; (void)lds_balanced; (void)N; (void)len; (void)grid; (void)which;
   return nullptr;                                               // (the default build has no list code in its kernels, see Sched in mw_march.h)
 #else
-  const char *e = getenv("MW_SCHED");
-  const int mode = e ? atoi(e) : 0;
-  const char *m = getenv("MW_SCHED_MASK");                      // bit 0: k_y_all, bit 1: k_xz_state, bit 2: k_tracers_fused
-  const int mask = m ? atoi(m) : MW_SCHED_DEFAULT_MASK;
+  const int mode = d->o.sched;
+  const int mask = d->o.sched_mask;                             // bit 0: k_y_all, bit 1: k_xz_state, bit 2: k_tracers_fused
   if (mode == 0 || !((mask >> which) & 1) || d->overlap || N < 1 || N > 0x3fffffff || len < 1) return nullptr;
   const int cus = device_cus(), occ = cus > 0 ? resident_blocks(fn, lds_balanced) : 0;
   if (occ < 1) return nullptr;
@@ -1316,9 +1339,9 @@ static const Sched *pick_sched(mw_dycore_s *d, const void *fn, size_t lds_balanc
 }
 
 // Which compile-time configuration of the marching kernels (Cf<K>) fits this view of the handle: 1 / 2 = the shipped supercell /
-// simple_city set-ups with their run-time switches folded, 0 = everything at run time.  MW_NO_SPEC=1 forces 0 (A/B timing, tests).
-static int marching_config(const DyP &p) {
-  if (getenv("MW_NO_SPEC")) return 0;                          // (read per launch: tests switch it inside one process)
+// simple_city set-ups with their run-time switches folded, 0 = everything at run time.  Option "spec" = 0 forces 0 (A/B timing, tests).
+static int marching_config(const mw_dycore_s *d, const DyP &p) {
+  if (!d->o.spec) return 0;                                    // (option "spec" = 0: A/B timing, tests)
   const unsigned all = (1u << p.nt) - 1u;
   if (p.nens != 1 || p.sim2d || p.bc_x != MW_BC_PERIODIC || p.bc_y != MW_BC_PERIODIC || p.bc_z != MW_BC_WALL || p.fcor != 0.0 ||
       !p.bn_default || !p.an_default || p.pos_mask != all || p.mass_mask != all || p.idWV != 0) return 0;
@@ -1338,13 +1361,13 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     const DyP &p = d->p;
     const long long threads = (long long)p.nz * p.nx * p.nens;
     const long long mthreads = (long long)p.nz * p.nx;                                   // one member's: the chunk rule of the per-member launches
-    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (mthreads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
+    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(d, p.ny, (mthreads + 63) / 64, d->o.chunk_y, 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     const MemberOff mo = member_off(d);
     const YMember mm = {v0.p.sJ, v0.p.sK, v0.p.sV, v0.slab, v0.p.fyJ, v0.p.fyK, v0.m[1], v0.p.nC, v0.tend, p.nx, mo.per, mo.n, mo.sh};
     double *Sw = const_cast<double *>(S);
-    const int K = marching_config(v0.p);
-    if (d->mm_direct && !getenv("MW_NO_MM_CONV")) {      // the members of the same cells in one workgroup (k_y_state<.., MM = 2>)
+    const int K = marching_config(d, v0.p);
+    if (d->mm_direct && d->o.mm_conv) {      // the members of the same cells in one workgroup (k_y_state<.., MM = 2>)
       grid.x = (unsigned)((mthreads + 64 * (4 / mo.n) - 1) / (64 * (4 / mo.n)));
 #define MW_YSM2(K_) { if (d->ord == 3) MW_YSM2O(K_, 3); else MW_YSM2O(K_, 5); }
 #define MW_YSM2O(K_, O_) hipLaunchKernelGGL((k_y_state<true, K_, O_, 2>), grid, dim3(256), 0, d->stream, v0.p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
@@ -1366,14 +1389,14 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     const DyP &p = v.p;
     long long threads = (long long)p.nz * p.nx * p.nens;
     // measured on 400x400x100 (625 wave columns): 8 x 50 rows for k_y_state, 14 x 29 for k_y_tracers (-5 % / -2 % vs. 32-row chunks)
-    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
+    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(d, p.ny, (threads + 63) / 64, d->o.chunk_y, 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     double *MY = d->M[par][1] + e * v.m[1]; unsigned char *UY = d->UP[par][1] + e * v.m[1];
 #define MW_YS(CONV_, K_, O_, cp, sw) hipLaunchKernelGGL((k_y_state<CONV_, K_, O_>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw, YMember())
 #define MW_YS_K(K_) { if (d->ord == 3) { if (conv) MW_YS(true, K_, 3, *conv, Sw); else MW_YS(false, K_, 3, CouplerPtrs(), nullptr); } \
                       else             { if (conv) MW_YS(true, K_, 5, *conv, Sw); else MW_YS(false, K_, 5, CouplerPtrs(), nullptr); } }
     double *Sw = const_cast<double *>(v.S(S));
-    switch (marching_config(p)) { case 1: MW_YS_K(1) break; case 2: MW_YS_K(2) break; default: MW_YS_K(0) break; }
+    switch (marching_config(d, p)) { case 1: MW_YS_K(1) break; case 2: MW_YS_K(2) break; default: MW_YS_K(0) break; }
 #undef MW_YS_K
 #undef MW_YS
     MW_LAUNCH_CHECK();
@@ -1385,7 +1408,7 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
 // the eight register windows do not fit -- 90-96 VGPRs go to scratch -- and the one launch is still 2.5 % of the step faster than
 // k_y_state + k_y_tracers: 5.44-5.49 against 5.57-5.62 ms on the supercell grid with MW_NO_SPEC=1.)
 static bool y_all_ok(const mw_dycore_s *d) {
-  return !d->overlap && d->fused && !d->p.sim2d && d->p.nt <= 3 && !getenv("MW_NO_Y_ALL");
+  return !d->overlap && d->fused && !d->p.sim2d && d->p.nt <= 3 && d->o.y_all;
 }
 // part: 0 = all rows; 1 = the rows whose chunks read no halo row (all of them with the row wrap), 2 = the two edge strips of
 // MW_Y_EDGE rows (short chunks: their launch runs between the exchange and k_xz_state, with a quarter of the wavefronts)
@@ -1398,10 +1421,10 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
   if (conv && d->member_major) {                                // mm_direct: all members in one launch, the members of the same cells in one workgroup
     const View v = view(d, 0);
     const DyP &p = v.p;
-    if (!d->mm_direct || marching_config(p) == 0) MW_FAIL("internal: the converting k_y_all of a member-major handle exists for 2 or 4 members of a folded configuration only");
+    if (!d->mm_direct || marching_config(d, p) == 0) MW_FAIL("internal: the converting k_y_all of a member-major handle exists for 2 or 4 members of a folded configuration only");
     const MemberOff mo = member_off(d);
     const long long mthreads = (long long)p.nz * p.nx;
-    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (mthreads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
+    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(d, p.ny, (mthreads + 63) / 64, d->o.chunk_y, 5000, 2, 5.0, (mthreads + 255) / 256 < 96));
     dim3 grid((unsigned)((mthreads + 64 * (4 / mo.n) - 1) / (64 * (4 / mo.n))), (unsigned)((p.ny + chunk - 1) / chunk));
     int row0 = 0, row_end = p.ny;
     if (part == 1 && !p.wrap_y) {                               // (pipelined schedule: the inner rows; the edge strips come from the slab later)
@@ -1410,7 +1433,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     }
 #define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, st, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, nullptr, pre_lo, pre_hi)
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
-    if (marching_config(p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
+    if (marching_config(d, p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
 #undef MW_YAM
     MW_LAUNCH_CHECK();
@@ -1420,7 +1443,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     const View v = view(d, e);
     const DyP &p = v.p;
     long long threads = (long long)p.nz * p.nx * p.nens;
-    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_Y", 5000, 2, 5.0, (threads + 255) / 256 < 96));
+    int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(d, p.ny, (threads + 63) / 64, d->o.chunk_y, 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     int row0 = 0, rstride = chunk, row_end = p.ny;
     if (part) {
@@ -1442,7 +1465,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
                                                  conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_, pre_lo, pre_hi); } while (0)
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
-    const int K = marching_config(p);
+    const int K = marching_config(d, p);
     if (K == 1) MW_YA_O(1, 3)
     else if (K == 2) MW_YA_O(2, 1)
     else if (p.nt == 1) MW_YA_O(0, 1)
@@ -1462,7 +1485,7 @@ static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_
     const View v = view(d, e);
     const DyP &p = v.p;
     long long threads = (long long)p.nz * p.nx * p.nens;
-    int chunk = d->chunk_yt ? d->chunk_yt : (d->chunk_yt = balanced_chunk(p.ny, (threads + 63) / 64, "MW_CHUNK_YT", 8400, 3, 5.0, (threads + 255) / 256 < 96));
+    int chunk = d->chunk_yt ? d->chunk_yt : (d->chunk_yt = balanced_chunk(d, p.ny, (threads + 63) / 64, d->o.chunk_yt, 8400, 3, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     double *FY = d->FY + e * v.f[1];
     for (int t0 = 0; t0 < p.nt; t0 += 4) {
@@ -1486,7 +1509,7 @@ static int xz_grid(mw_dycore_s *d, const DyP &p, dim3 &grid, int &chunk, int &ti
   if (!d->chunk_z) {
     // k_xz_state: equal chunks, enough of them for ~5 rounds of 2 waves/SIMD over the 1024 SIMDs (measured on 400x400x100:
     // 4 x 25 levels beats 32,32,32,4 by 4 %)
-    d->chunk_z = balanced_chunk(p.nz, waves, "MW_CHUNK_Z", 10000, 2, 2.5, true);
+    d->chunk_z = balanced_chunk(d, p.nz, waves, d->o.chunk_z, 10000, 2, 2.5, true);
     // k_xz_state<.., HPL = 1> keeps (chunk + 2) rows of 64 bytes in dynamic LDS: stay well inside the 64 KB a workgroup may have
     d->chunk_z = std::min(d->chunk_z, 900);
   }
@@ -1516,7 +1539,7 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
 #define MW_XZ_MT(K_) { if (d->ord == 3) MW_XZ_MTO(K_, 3); else MW_XZ_MTO(K_, 5); }
 #define MW_XZ_MTO(K_, O_) hipLaunchKernelGGL((k_xz_state<3, true, 1, 1, K_, O_, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
                                         d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo, nullptr)
-      if (marching_config(p) == 1) MW_XZ_MT(1) else MW_XZ_MT(0)
+      if (marching_config(d, p) == 1) MW_XZ_MT(1) else MW_XZ_MT(0)
 #undef MW_XZ_MT
 #undef MW_XZ_MTO
       MW_LAUNCH_CHECK();
@@ -1540,7 +1563,7 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
 #define MW_XZ_K(K_) { if (d->ord == 3) MW_XZ(true, 1, K_, 3, hpl_bytes); else MW_XZ(true, 1, K_, 5, hpl_bytes); }
     const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
     if (p.nens == 1) {
-      switch (marching_config(p)) { case 1: MW_XZ_K(1) break; case 2: MW_XZ_K(2) break; default: MW_XZ_K(0) break; }
+      switch (marching_config(d, p)) { case 1: MW_XZ_K(1) break; case 2: MW_XZ_K(2) break; default: MW_XZ_K(0) break; }
     } else MW_XZ(false, 0, 0, 5, 0);                          // (the fused-layout form for nens > 1: WENO-5 only, see time_step)
 #undef MW_XZ_K
 #undef MW_XZ
@@ -1549,15 +1572,15 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
   return 0;
 }
 
-// The state variables' complete stage in one launch (k_state_xyz, mw_fused.h): MW_FUSED_STATE=1, folded configurations with periodic y
+#ifdef MW_EXPERIMENTS
+// The state variables' complete stage in one launch (k_state_xyz, mw_fused.h): option "fused_state" (-DMW_EXPERIMENTS builds), folded configurations with periodic y
 // owned by this rank, nens = 1, WENO-5, ny a multiple of 4.  The stage is then k_state_xyz -> k_y_tracers -> k_tracers_fused.
-// (MW_FUSED_STATE=1 | 4: four row-waves per workgroup, two workgroups per CU; 8: eight, one workgroup per CU)
+// (fused_state = 1 | 4: four row-waves per workgroup, two workgroups per CU; 8: eight, one workgroup per CU)
 static int fused_state_rows(const mw_dycore_s *d) {
   const DyP &p = d->p;
-  const char *e = getenv("MW_FUSED_STATE");
-  const int v = e ? atoi(e) : 0, W = v == 8 ? 8 : 4;
+  const int v = d->o.fused_state, W = v == 8 ? 8 : 4;
   const bool ok = v != 0 && !d->overlap && !d->pipe && d->fused && (d->ord == 5 || d->ord == 3) && p.nens == 1 && !p.sim2d && p.wrap_y && p.ny % W == 0 &&
-                  p.ny >= 2 * W && marching_config(p) != 0;
+                  p.ny >= 2 * W && marching_config(d, p) != 0;
   return ok ? W : 0;
 }
 static bool fused_state_ok(const mw_dycore_s *d) { return fused_state_rows(d) != 0; }
@@ -1573,13 +1596,17 @@ static int launch_state_xyz(mw_dycore_s *d, const double *S, const double *Sn, d
 #define MW_SXYZO(K_, W_, O_) hipLaunchKernelGGL((k_state_xyz<STAGE, MODE, K_, W_, O_>), grid, dim3(64 * W_), hpl_bytes, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
                                        d->UP[par][0], d->UP[par][2], d->M[par][1], d->UP[par][1], dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
 #define MW_SXYZ(K_, W_) do { if (d->ord == 3) MW_SXYZO(K_, W_, 3); else MW_SXYZO(K_, W_, 5); } while (0)
-  if (W == 8) { if (marching_config(p) == 1) MW_SXYZ(1, 8); else MW_SXYZ(2, 8); }
-  else        { if (marching_config(p) == 1) MW_SXYZ(1, 4); else MW_SXYZ(2, 4); }
+  if (W == 8) { if (marching_config(d, p) == 1) MW_SXYZ(1, 8); else MW_SXYZ(2, 8); }
+  else        { if (marching_config(d, p) == 1) MW_SXYZ(1, 4); else MW_SXYZ(2, 4); }
 #undef MW_SXYZ
 #undef MW_SXYZO
   MW_LAUNCH_CHECK();
   return 0;
 }
+
+#else
+static bool fused_state_ok(const mw_dycore_s *) { return false; }
+#endif
 
 template <int T, bool N1>
 static void launch_xz_tracers_t(mw_dycore_s *d, const double *S, dim3 grid, int chunk, int tiles_x, int t0, int par, double dt, int rows4,
@@ -1648,13 +1675,13 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const MemberOff mo = member_off(d);
       const int U = 64 - 2 * ((d->ord - 1) / 2 + 1), tiles_x = (p.nx + U - 1) / U, rpb = 4 / mo.n;
       const long long waves = (long long)p.ny * tiles_x;
-      const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F", 10000, 2, 4.5, true));
+      const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(d, p.nz, waves, d->o.chunk_f, 10000, 2, 4.5, true));
       dim3 grid((unsigned)(((p.ny + rpb - 1) / rpb) * tiles_x), (unsigned)((p.nz + chunk - 1) / chunk));
 #define MW_FUSED_MT(TT) case TT: MW_FUSED_MTK(TT, 0) break;
 #define MW_FUSED_MTK(TT, K_) { if (d->ord == 3) MW_FUSED_MTO(TT, K_, 3); else MW_FUSED_MTO(TT, K_, 5); }
 #define MW_FUSED_MTO(TT, K_, O_) hipLaunchKernelGGL((k_tracers_fused<3, 1, TT, true, K_, O_, true>), grid, dim3(256), 0, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
                                  d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo, nullptr)
-      if (marching_config(p) == 1) MW_FUSED_MTK(3, 1)
+      if (marching_config(d, p) == 1) MW_FUSED_MTK(3, 1)
       else switch (p.nt) { MW_FUSED_MT(1) MW_FUSED_MT(2) MW_FUSED_MT(3) MW_FUSED_MT(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
 #undef MW_FUSED_MT
 #undef MW_FUSED_MTK
@@ -1666,16 +1693,16 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const DyP &p = v.p;
       const int U = p.nens == 1 ? 64 - 2 * ((d->ord - 1) / 2 + 1) : 64 - 4 * p.nens;   // hs + 1 / 2 halo cells per side (k_tracers_fused)
       const int tiles_x = (p.nx * p.nens + U - 1) / U;
-      const int rows4 = (p.ny >= 4 && !getenv("MW_TF_NO_ROWS4")) ? 1 : 0;   // (workgroup = 4 rows of one x tile: the rows' shared y faces meet in L1; MW_TF_NO_ROWS4: 4 x tiles of one row, A/B)
+      const int rows4 = (p.ny >= 4 && d->o.tf_rows4) ? 1 : 0;   // (workgroup = 4 rows of one x tile: the rows' shared y faces meet in L1; option tf_rows4 = 0: 4 x tiles of one row, A/B)
       const long long waves = (long long)p.ny * tiles_x;
-      const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(p.nz, waves, "MW_CHUNK_F", 10000, 2, 4.5, true));
+      const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(d, p.nz, waves, d->o.chunk_f, 10000, 2, 4.5, true));
       dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
 #define MW_FUSED_ARGS d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st
 #define MW_FUSED_CASE(TT) \
       case TT: if (p.nens != 1)     launch_tracers_fused_t<STAGE, MODE, TT, false, 0>(MW_FUSED_ARGS); \
                else if (d->ord == 3) launch_tracers_fused_t<STAGE, MODE, TT, true, 0, 3>(MW_FUSED_ARGS); \
                else                  launch_tracers_fused_t<STAGE, MODE, TT, true, 0>(MW_FUSED_ARGS); break;
-      const int K = marching_config(p);
+      const int K = marching_config(d, p);
       if (K == 1)      { if (d->ord == 3) launch_tracers_fused_t<STAGE, MODE, 3, true, 1, 3>(MW_FUSED_ARGS); else launch_tracers_fused_t<STAGE, MODE, 3, true, 1>(MW_FUSED_ARGS); }
       else if (K == 2) { if (d->ord == 3) launch_tracers_fused_t<STAGE, MODE, 1, true, 2, 3>(MW_FUSED_ARGS); else launch_tracers_fused_t<STAGE, MODE, 1, true, 2>(MW_FUSED_ARGS); }
       else switch (p.nt) { MW_FUSED_CASE(1) MW_FUSED_CASE(2) MW_FUSED_CASE(3) MW_FUSED_CASE(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
@@ -1685,7 +1712,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
     }
   }
   const DyP &p = d->p;
-  if (!p.sim2d && p.pos_mask && !getenv("MW_DEBUG_NO_PATCH")) {   // (the switch exists for the negative control in tests/)
+  if (!p.sim2d && p.pos_mask && !d->o.debug_no_patch) {   // (the switch exists for the negative control in tests/, -DMW_EXPERIMENTS builds)
     ProfScope ps(d, 1, st);
     for (int e = 0; e < n_views(d); e++) {
       const View v = view(d, e);
@@ -1726,11 +1753,14 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   const bool conv = (STAGE == 1) && d->conv_pending;            // first stage of the step: D1 + D2 inside k_y_state
   d->conv_pending = false;
   // (the converting launch of a member-major handle exists in the members-in-one-workgroup form of the folded configurations only)
-  const bool mm_conv_ok = d->mm_direct && !getenv("MW_NO_MM_CONV") && marching_config(view(d, 0).p) != 0;
+  const bool mm_conv_ok = d->mm_direct && d->o.mm_conv && marching_config(d, view(d, 0).p) != 0;
   const bool fxyz = fused_state_ok(d) && !conv;                 // (round 4 experiment: all three directions of the state variables in one launch)
-  const bool yall = !fxyz && y_all_ok(d) && !(conv && ((d->member_major && !mm_conv_ok) || getenv("MW_NO_Y_ALL_CONV")));   // y faces of state variables and tracers in one launch
+  const bool yall = !fxyz && y_all_ok(d) && !(conv && ((d->member_major && !mm_conv_ok) || !d->o.y_all_conv));   // y faces of state variables and tracers in one launch
+#ifdef MW_EXPERIMENTS
   if (fxyz) { if (launch_state_xyz<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1; }
-  else {
+  else
+#endif
+  {
   if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin, conv ? &c : nullptr)) return 1; }
   else if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
@@ -1776,7 +1806,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   d->conv_pending = false;
   // (round 4: the two edge strips of the y launch run on the EXCHANGE stream right behind the unpack kernels -- beside the inner rows on
   //  the compute stream -- instead of behind them: a launch of 2 x 157 workgroups no longer sits alone between k_y_all and k_xz_state)
-  const bool edge_side = !getenv("MW_PIPE_EDGE_INLINE");
+  const bool edge_side = !d->o.pipe_edge_inline;
   if (!d->pipe_ready) {                                       // this stage's input has not been exchanged yet
     MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
     if (halo_fill(d, Sin, 0, -1, xs, 0, true)) return 1;
@@ -1915,8 +1945,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
     set_error("hipMalloc(workspace) failed"); return fail(); }
   (void)hipMemsetAsync(d->flags, 0, (size_t)p.nC, d->stream);
   (void)hipMemsetAsync(d->dirty, 0, 4 * sizeof(unsigned int), d->stream);
-  { const char *f = getenv("MW_FUSED_TRACERS");
-    d->fused = (g->num_tracers <= 4 && g->nens <= 12 && !(f && f[0] == '0')) ? 1 : 0; }
+  d->fused = (g->num_tracers <= 4 && g->nens <= 12) ? 1 : 0;       // (option "fused_tracers" = 0: the unfused tracer stage)
   // zero everything once: halo corners are never written and the flux arrays start at 0 (:1677-1682)
   (void)hipMemsetAsync(d->S0, 0, slab, d->stream); (void)hipMemsetAsync(d->S1, 0, slab, d->stream);
   (void)hipMemsetAsync(d->S2, 0, slab, d->stream); (void)hipMemsetAsync(d->S3, 0, slab, d->stream); (void)hipMemsetAsync(d->tendY, 0, (size_t)5 * p.nC * sizeof(double), d->stream);
@@ -1932,11 +1961,9 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
     }
     { // The tracer stream gets the highest stream priority: its kernels are the older work (stage s while the state stream is
       // already in stage s+1), and with both pipelines fp64-VALU bound an even split of the chip only stretches both (measured on
-      // one rank with MW_OVERLAP=1: step time -0.5 % against equal priorities).  MW_TSTREAM_PRIO=0 / 1: default / lowest priority.
+      // one rank with the two-stream schedule forced: step time -0.5 % against equal priorities).
       int least = 0, greatest = 0; (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      const char *pe = getenv("MW_TSTREAM_PRIO"); const int pm = pe ? atoi(pe) : 2;
-      hipError_t er = (pm == 0) ? hipStreamCreateWithFlags(&d->tstream, hipStreamNonBlocking)
-                                : hipStreamCreateWithPriority(&d->tstream, hipStreamNonBlocking, pm == 1 ? least : greatest);
+      hipError_t er = hipStreamCreateWithPriority(&d->tstream, hipStreamNonBlocking, greatest);
       if (er != hipSuccess) { set_error("hipStreamCreate failed"); return fail(); } }
     for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
                                     hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
@@ -1983,6 +2010,57 @@ int mw_dycore_set_bc(mw_dycore_t d, int bc_x, int bc_y, int bc_z) {
   return 0;
 }
 int mw_dycore_set_strict(mw_dycore_t d, int strict) { if (!d) MW_FAIL("null handle"); d->strict = strict; return 0; }
+
+// ---- run-time options (see DyOpts) ------------------------------------------------------------------------------------
+namespace {
+struct OptDesc { const char *key; int DyOpts::*field; long long lo, hi; int build; };   // build: 0 any, 1 -DMW_EXPERIMENTS, 2 -DMW_SCHED_LISTS
+const OptDesc OPTS[] = {
+  {"overlap", &DyOpts::overlap, -1, 1, 0}, {"pipe", &DyOpts::pipe, 0, 1, 0}, {"pipe_edge_inline", &DyOpts::pipe_edge_inline, 0, 1, 0},
+  {"pipe_convert", &DyOpts::pipe_convert, 0, 1, 0}, {"spec", &DyOpts::spec, 0, 1, 0}, {"wrap", &DyOpts::wrap, 0, 1, 0},
+  {"y_all", &DyOpts::y_all, 0, 1, 0}, {"y_all_conv", &DyOpts::y_all_conv, 0, 1, 0}, {"member_major", &DyOpts::member_major, 0, 1, 0},
+  {"mm_direct", &DyOpts::mm_direct, 0, 1, 0}, {"mm_conv", &DyOpts::mm_conv, 0, 1, 0}, {"fused_convert", &DyOpts::fused_convert, 0, 1, 0},
+  {"fused_convert_mm", &DyOpts::fused_convert_mm, 0, 1, 0}, {"chunk_y", &DyOpts::chunk_y, 0, 1 << 20, 0}, {"chunk_yt", &DyOpts::chunk_yt, 0, 1 << 20, 0},
+  {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
+  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
+  {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0},
+  {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
+  {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},
+};
+constexpr int BUILD_FLAGS = 0
+#ifdef MW_EXPERIMENTS
+  | 1
+#endif
+#ifdef MW_SCHED_LISTS
+  | 2
+#endif
+  ;
+}
+int mw_build_flags(void) { return BUILD_FLAGS; }
+int mw_dycore_set_option(mw_dycore_t d, const char *key, long long value) {
+  if (!d || !key) MW_FAIL("mw_dycore_set_option: null argument");
+  if (!strcmp(key, "fused_tracers")) {                          // (0: the unfused tracer stage k_xz_tracers + k_tracer_update)
+    if (value != 0 && value != 1) MW_FAIL("option fused_tracers must be 0 or 1");
+    if (value && !(d->g.num_tracers <= 4 && d->g.nens <= 12)) MW_FAIL("option fused_tracers = 1 needs at most 4 tracers and 12 members");
+    d->fused = (int)value;
+    return 0;
+  }
+  for (const OptDesc &od : OPTS) {
+    if (strcmp(key, od.key)) continue;
+    if (od.build && !(BUILD_FLAGS & od.build) && value != (long long)(DyOpts().*(od.field)))     // (its default value is accepted: a no-op)
+      MW_FAIL(std::string("option ") + key + " exists in a " + (od.build == 1 ? "-DMW_EXPERIMENTS" : "-DMW_SCHED_LISTS") + " build of libmw_cdna4 only (tools/build_variant.sh)");
+    if (value < od.lo || value > od.hi) MW_FAIL(std::string("option ") + key + ": value out of range [" + std::to_string(od.lo) + ", " + std::to_string(od.hi) + "]");
+    d->o.*(od.field) = (int)value;
+    if (!strncmp(key, "chunk_", 6)) d->chunk_y = d->chunk_yt = d->chunk_z = d->chunk_f = 0;      // (cached chunk sizes: decided again at the next launch)
+    return 0;
+  }
+  MW_FAIL(std::string("unknown option: ") + key);
+}
+int mw_dycore_get_option(mw_dycore_t d, const char *key, long long *value) {
+  if (!d || !key || !value) MW_FAIL("mw_dycore_get_option: null argument");
+  if (!strcmp(key, "fused_tracers")) { *value = d->fused; return 0; }
+  for (const OptDesc &od : OPTS) if (!strcmp(key, od.key)) { *value = d->o.*(od.field); return 0; }
+  MW_FAIL(std::string("unknown option: ") + key);
+}
 int mw_dycore_set_order(mw_dycore_t d, int ord) {
   if (!d) MW_FAIL("null handle");
   if (ord != 3 && ord != 5 && ord != 7 && ord != 9) MW_FAIL("WENO order must be 3, 5, 7 or 9");
@@ -2126,24 +2204,23 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   // :1008-1019; no shipped case): the marching kernels apply the wall / open z rule while loading and have no periodic form.
   // WENO-3 (the reference's GPU-benchmark build, -DMW_ORD=3) marches too, in the forms that exist for it: fused tracer stage, and
   // nens == 1 or the member-major layout.  Orders 7 / 9 run on the general kernels.
-  const bool ord3_ok = d->fused && (p.nens == 1 || !getenv("MW_NO_MEMBER_MAJOR"));
+  const bool ord3_ok = d->fused && (p.nens == 1 || d->o.member_major);
   const bool march = (d->strict == 0) && (p.bc_z != MW_BC_PERIODIC) && (d->ord == 5 || (d->ord == 3 && ord3_ok));
   d->last_march = march ? 1 : 0;
-  if (march && !getenv("MW_NO_WRAP")) {                       // index wrap instead of halo cells (see DyP::wrap_x)
+  if (march && d->o.wrap) {                       // index wrap instead of halo cells (see DyP::wrap_x)
     d->p.wrap_x = (p.bc_x == MW_BC_PERIODIC) && !(d->xchg && p.nproc_x > 1) && p.nx >= 3;
     d->p.wrap_y = !p.sim2d && (p.bc_y == MW_BC_PERIODIC) && !(d->xchg && p.nproc_y > 1) && p.ny >= 3;
   }
   // Two-stream schedule (see rk_stage_march): the default when strips are exchanged with neighbour ranks (the exchange of one
   // pipeline then runs beside the kernels of the other).  On one rank both pipelines are fp64-VALU bound, the step takes the
   // same time either way (measured without any timing events: +-0.3 %) and sharing the chip only stretches every kernel, so the
-  // default there is the handle's stream for everything.  MW_OVERLAP=1 / 0 forces either schedule.
-  { const char *ov = getenv("MW_OVERLAP");
-    bool want = ov ? (atoi(ov) != 0) : (d->xchg != nullptr);
-    if (getenv("MW_NO_OVERLAP")) want = false;
+  // default there is the handle's stream for everything.  Option "overlap" = 1 / 0 forces either schedule.
+  { const bool ov = d->o.overlap >= 0;                          // forced either way
+    const bool want = ov ? (d->o.overlap != 0) : (d->xchg != nullptr);
     d->overlap = march && d->tstream && want;
     // ... unless k_y_all applies: then the pipelined one-stream schedule (rk_stage_pipe) is the default with an exchange
     d->pipe = 0;
-    if (d->overlap && d->xchg && !ov && !getenv("MW_NO_PIPE")) {
+    if (d->overlap && d->xchg && !ov && d->o.pipe) {
       d->overlap = 0;
       if (y_all_ok(d) && d->ev_pipe[0]) d->pipe = 1; else d->overlap = 1;
     } }
@@ -2152,19 +2229,19 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   //  last stage -- issued SIDE BY SIDE on one stream per member, hoping that the quarter lines the four members read / write would
   //  meet in L2: they do not.  27.3 ms per step with the two coalesced conversion passes; 33.2 with D13 inside the member launches
   //  (k_tracers_fused 7.6 -> 12.0 ms, k_xz_state 9.4 -> 11.7), 30.3 with D1 inside (k_y_state 3.8 -> 7.7), 34.3 with both.)
-  d->member_major = march && d->fused && p.nens > 1 && !getenv("MW_NO_MEMBER_MAJOR");
+  d->member_major = march && d->fused && p.nens > 1 && d->o.member_major;
   // ... with D13 written by the last stage's kernels themselves and D1 read by the first k_y_state, the members of a tile in one
   // workgroup so that their quarter-sector accesses meet in L1 / L2 (MemberOff, mw_march.h): 2 or 4 members
-  d->mm_direct = d->member_major && (p.nens == 2 || p.nens == 4) && !getenv("MW_NO_MM_DIRECT");
+  d->mm_direct = d->member_major && (p.nens == 2 || p.nens == 4) && d->o.mm_direct;
   // D1 + D2 (:101, :248-255).  Production path with periodic x and y owned by this rank (either schedule: the tracer stream waits
   // for the stage's state kernels anyway): done inside the first k_y_state (no separate pass); otherwise a conversion kernel first
   // (the reference's operation order on the general path).
-  d->conv_pending = march && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && !getenv("MW_NO_FUSED_CONVERT") &&
-                    (!d->member_major || !getenv("MW_NO_FUSED_CONVERT_MM"));
+  d->conv_pending = march && d->p.wrap_x && d->p.wrap_y && p.nt <= 4 && d->o.fused_convert &&
+                    (!d->member_major || d->o.fused_convert_mm);
   // Pipelined schedule of a decomposed block (rk_stage_pipe): only the strips that are packed for the neighbours and the rows the
   // edge-strip y launch reads are converted up front; the inner rows are converted by the first k_y_all<true> while the strips travel.
-  const bool pipe_conv = d->pipe && (!d->member_major || (d->mm_direct && !getenv("MW_NO_MM_CONV") && marching_config(view(d, 0).p) != 0)) && p.nt <= 3 &&
-                         !getenv("MW_NO_FUSED_CONVERT") && !getenv("MW_NO_PIPE_CONVERT") && (d->p.wrap_y || p.ny >= 4 * MW_Y_EDGE);
+  const bool pipe_conv = d->pipe && (!d->member_major || (d->mm_direct && d->o.mm_conv && marching_config(d, view(d, 0).p) != 0)) && p.nt <= 3 &&
+                         d->o.fused_convert && d->o.pipe_convert && (d->p.wrap_y || p.ny >= 4 * MW_Y_EDGE);
   // (the pipelined schedule converts inside k_y_all<true> ONLY in the forms pipe_conv names: any other handle -- e.g. three members, or a
   //  member-major handle whose configuration is not a folded one -- gets the full conversion pass below; without this a 1 x 1
   //  decomposition with a transport installed (both wraps on) reached the members-in-one-workgroup launch with the wrong kernel)
@@ -2271,6 +2348,76 @@ int mw_calib_copy(const double *in, double *out, long long n, void *stream) {
   return 0;
 }
 
+// ---- calibration (mw_calib.h) --------------------------------------------------------------------------------------------
+// Sustained v_fma_f64 issue rate with `waves_per_simd` wavefronts per SIMD on every CU, for about `seconds` (a short run sizes the
+// long one).  out5 (HOST): wave-instructions per second, kernel milliseconds, shader clock in GHz during the run (the kernel's cycle
+// counter over its 100 MHz real-time counter; 0 when the two counters run at the same rate on this part), wave-instructions issued, CUs.
+int mw_calib_fma64(int waves_per_simd, double seconds, double *out5, void *stream) {
+  if (waves_per_simd < 1 || waves_per_simd > 8 || !(seconds > 0) || seconds > 20 || !out5) MW_FAIL("mw_calib_fma64: waves_per_simd in 1..8, seconds in (0, 20]");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipStream_t st = (hipStream_t)stream;
+  const int cus = device_cus();
+  if (cus < 1) MW_FAIL("mw_calib_fma64: cannot read the device's CU count");
+  double *sink = nullptr; long long *clk = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+  MW_HIP(hipMalloc(&sink, 8)); MW_HIP(hipMalloc(&clk, 16));
+  MW_HIP(hipEventCreate(&e0)); MW_HIP(hipEventCreate(&e1));
+  const dim3 grid((unsigned)(cus * waves_per_simd));            // 256 threads = one wave per SIMD; waves_per_simd workgroups per CU
+  auto run = [&](long long trips, float &ms) -> int {
+    MW_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_calib_fma64, grid, dim3(256), 0, st, trips, 1.0, sink, clk);
+    MW_LAUNCH_CHECK();
+    MW_HIP(hipEventRecord(e1, st));
+    MW_HIP(hipEventSynchronize(e1));
+    MW_HIP(hipEventElapsedTime(&ms, e0, e1));
+    return 0;
+  };
+  float ms = 0;
+  long long trips = 20000;
+  int rc = run(trips, ms) || run(trips, ms);                     // (the first launch also loads the code object)
+  if (!rc) { trips = std::max(1000ll, (long long)(trips * (seconds * 1e3 / std::max(1e-3f, ms)))); rc = run(trips, ms); }
+  long long h[2] = {0, 0};
+  if (!rc && hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost) != hipSuccess) { set_error("mw_calib_fma64: download failed"); rc = 1; }
+  (void)hipFree(sink); (void)hipFree(clk); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc) return 1;
+  const double winstr = (double)trips * 64.0 * (double)grid.x * 4.0;
+  out5[0] = winstr / (ms * 1e-3); out5[1] = ms;
+  out5[2] = (h[1] > 0 && h[0] != h[1]) ? (double)h[0] / (double)h[1] * 0.1 : 0.0;
+  out5[3] = winstr; out5[4] = cus;
+  return 0;
+}
+
+// The arithmetic floor of one RK stage: `cells` cell-stages (24 reconstructions + 3 Riemann solves + the passive fluxes each, the
+// production arithmetic of mw_weno.h / mw_march.h) on register windows fed from `tab` -- DEVICE (nlev, 8, 64) doubles, a few KB that
+// stay in L2 -- in workgroups of 256 threads, two per CU, `levels` cells per thread (k_xz_state's shape).  bg4 (HOST): hyr, hyt, p0,
+// 1/hyt of the level.  sink: DEVICE, one double per thread (mw_calib_stage_arith_threads).  out3 (HOST): milliseconds, cells processed,
+// workgroups.  The table decides smooth or rough data; the time is what a stage of that many cells cannot beat on this chip.
+long long mw_calib_stage_arith_threads(long long cells, int levels) {
+  if (cells < 1 || levels < 1) return 0;
+  const long long thr = (cells + levels - 1) / levels;
+  return ((thr + 255) / 256) * 256;
+}
+int mw_calib_stage_arith(const double *tab, int nlev, long long cells, int levels, const double *bg4, double *sink, double *out3, void *stream) {
+  if (!tab || nlev < 6 || cells < 1 || levels < 1 || !bg4 || !sink || !out3) MW_FAIL("mw_calib_stage_arith: bad argument (nlev >= 6)");
+  if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
+  hipStream_t st = (hipStream_t)stream;
+  const long long thr = mw_calib_stage_arith_threads(cells, levels);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  MW_HIP(hipEventCreate(&e0)); MW_HIP(hipEventCreate(&e1));
+  float ms = 0; int rc = 0;
+  for (int rep = 0; rep < 2 && !rc; rep++) {                     // (the second launch is the measurement)
+    if (hipEventRecord(e0, st) != hipSuccess) rc = 1;
+    hipLaunchKernelGGL(k_calib_stage_arith, dim3((unsigned)(thr / 256)), dim3(256), 0, st, tab, nlev, levels, bg4[0], bg4[1], bg4[2], bg4[3], sink);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+        hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = 1;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (rc) MW_FAIL("mw_calib_stage_arith: launch or timing failed");
+  out3[0] = ms; out3[1] = (double)(thr * levels); out3[2] = (double)(thr / 256);
+  return 0;
+}
+// Test aid: occupies `stream` for about `usec` microseconds (one wavefront polling the 100 MHz counter).
+int mw_debug_spin(long long usec, void *stream) { return launch_spin(usec, (hipStream_t)stream); }
+
 int mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream) {
   if (!g || !temp) MW_FAIL("null argument");
   long long n = (long long)g->nz * g->ny * g->nx * g->nens;
@@ -2302,6 +2449,7 @@ int dycore_set_exchange_owned(mw_dycore_t d, mw_exchange_fn fn, void *ctx, void 
   return 0;
 }
 // the installed transport of a handle (mw_rccl.cpp recognises its own by the callback's address)
+int dycore_option(mw_dycore_t d, const char *key) { long long v = 0; return (d && !mw_dycore_get_option(d, key, &v)) ? (int)v : 0; }
 void *dycore_exchange_ctx(mw_dycore_t d, mw_exchange_fn *fn) { if (fn) *fn = d ? d->xchg : nullptr; return d ? d->xchg_ctx : nullptr; }
 } // namespace mw
 
@@ -2311,7 +2459,7 @@ void *dycore_exchange_ctx(mw_dycore_t d, mw_exchange_fn *fn) { if (fn) *fn = d ?
 // + 8 when that time step ran on the general (flux-materialising) kernels instead of the marching ones.  -1: null handle.
 extern "C" int mw_dycore_schedule(mw_dycore_t d) {
   if (!d) return -1;
-  return (d->pipe ? 2 : d->overlap ? 1 : 0) + (d->last_march && y_all_ok(d) ? 4 : 0) + (d->last_march ? 0 : 8);
+  return (d->pipe ? 2 : d->overlap ? 1 : 0) + (d->last_march && y_all_ok(d) && !fused_state_ok(d) ? 4 : 0) + (d->last_march ? 0 : 8);
 }
 
 // ---- init (:1197-1683): host column profiles + device quadrature --------------------------------------

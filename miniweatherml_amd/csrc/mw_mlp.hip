@@ -302,8 +302,7 @@ extern "C" int mw_mlp_forward(long long ncells, const double *temp, const double
   bool aligned = true;
   for (const void *q : {(const void *)temp, (const void *)rho_d, (const void *)rho_v, (const void *)rho_c, (const void *)rho_r, (const void *)temp_out,
                         (const void *)rho_v_out, (const void *)rho_c_out, (const void *)rho_r_out}) aligned = aligned && (((size_t)q & 15) == 0);
-  static const bool x2 = !(getenv("MW_MLP_X2") && getenv("MW_MLP_X2")[0] == '0');
-  const long long bulk = (aligned && x2) ? (ncells / 32) * 32 : 0;
+  const long long bulk = aligned ? (ncells / 32) * 32 : 0;
   if (bulk > 0) {
     long long waves_needed = (bulk / 32 + PAIRS - 1) / PAIRS;
     long long blocks = (waves_needed + 3) / 4;

@@ -20,6 +20,9 @@
 namespace mw {   // defined in mw_dycore.hip: installs a transport whose context the handle owns (freed on replace / destroy)
 int dycore_set_exchange_owned(mw_dycore_t h, mw_exchange_fn fn, void *ctx, void (*free_ctx)(void *));
 void *dycore_exchange_ctx(mw_dycore_t h, mw_exchange_fn *fn);
+int dycore_option(mw_dycore_t h, const char *key);            // a handle's run-time option (mw_dycore_get_option), 0 when unknown
+int launch_spin(long long usec, hipStream_t st);               // mw_calib.h: a kernel that spins for `usec` microseconds (delay fuzz)
+int launch_scale(double *buf, long long n, double f, hipStream_t st);   // buf[i] *= f
 }
 
 namespace {
@@ -86,7 +89,7 @@ RcclApi &rccl_api() {
 // the pack kernels of ITS pipeline and only its pipeline's unpack kernels wait for it.  A lane belongs to the first caller stream
 // that uses it; a third stream shares lane 0.
 // Communicators: by default both lanes use the ONE communicator of the handle -- RCCL then runs the two groups in the order they
-// were issued, which is the same on every rank (the schedule is a function of the stage counter alone).  MW_RCCL_TWO_COMMS=1 gives
+// were issued, which is the same on every rank (the schedule is a function of the stage counter alone).  Option rccl_two_comms = 1 (process default: MW_RCCL_LANES=2x2) gives
 // lane 1 its own communicator (split off lane 0's with ncclCommSplit: no second unique id in the ABI), so that the two transfers
 // can also overlap each other; NCCL's documentation warns that kernels of two communicators may dead-lock each other if the
 // device cannot hold both at once, and this path could not be run between distinct GPUs on the one-GPU development box, so it is
@@ -100,9 +103,25 @@ struct RcclLane {
 struct RcclCtx {
   RcclLane lane[2];
   int nlanes = 1;
-  bool own_comm1 = false;                                       // lane 1 has a communicator of its own (MW_RCCL_TWO_COMMS=1)
+  bool own_comm1 = false;                                       // lane 1 has a communicator of its own (option rccl_two_comms = 1)
   int peers[4], send_order[4], recv_order[4], active[4];        // mw_exchange_plan
+  int self_ranks = 0;                                           // > 0: the self-loop transport (mw_dycore_use_rccl_self): this rank stands for that many identical blocks
+  unsigned long long fuzz = 0;                                  // != 0: state of the delay fuzz (option xchg_fuzz = seed)
 };
+// xorshift64*: the next delay in microseconds, 0 .. 255 (about the duration of the kernels an exchange runs beside)
+long long fuzz_usec(RcclCtx *c) {
+  unsigned long long x = c->fuzz;
+  x ^= x >> 12; x ^= x << 25; x ^= x >> 27; c->fuzz = x;
+  return (long long)(((x * 0x2545F4914F6CDD1DULL) >> 40) & 0xff);
+}
+// Process default of the lanes: MW_RCCL_LANES = "1" (one side stream), "2" (two, one communicator: the default), "2x2" (two, a communicator
+// each).  A handle's options rccl_lanes / rccl_two_comms override it for that handle (mw_dycore_use_rccl reads them).
+void default_lanes(int &lanes, int &two_comms) {
+  static int dl = 0, dt = 0;
+  static std::once_flag once;
+  std::call_once(once, [] { const char *e = getenv("MW_RCCL_LANES"); dl = (e && e[0] == '1') ? 1 : 2; dt = (e && !strcmp(e, "2x2")) ? 1 : 0; });
+  lanes = dl; two_comms = dt;
+}
 
 #define MW_NCCL(call)                                                                                   \
   do { ncclResult_t r__ = (call);                                                                       \
@@ -122,19 +141,18 @@ void free_ctx(RcclCtx *c) {
   delete c;
 }
 // streams and events of the lanes; lane 1 only when a second communicator can be split off
-int init_lanes(RcclCtx *c, RcclApi &R, int nranks, int myrank) {
-  c->nlanes = getenv("MW_RCCL_ONE_LANE") ? 1 : 2;
+int init_lanes(RcclCtx *c, RcclApi &R, int nranks, int myrank, int lanes, int two_comms) {
+  c->nlanes = lanes == 1 ? 1 : 2;
   c->lane[1].comm = c->lane[0].comm; c->own_comm1 = false;     // shared communicator (default)
-  { const char *tc = getenv("MW_RCCL_TWO_COMMS");
-    if (c->nlanes == 2 && tc && tc[0] == '1') {
+  { if (c->nlanes == 2 && two_comms) {
       // ncclCommSplit is a COLLECTIVE: a rank that quietly fell back to the shared communicator while its peers split would post its
       // sends / receives on another communicator than they do and the first exchange would hang.  Asked for explicitly, a second
       // communicator that cannot be had is therefore an error on this rank (the caller's ranks then fail together or not at all:
       // every rank resolves the same librccl and calls the same split).
-      if (!R.CommSplit) { mw::set_error("MW_RCCL_TWO_COMMS=1 but this librccl has no ncclCommSplit"); return 1; }
+      if (!R.CommSplit) { mw::set_error("rccl_two_comms = 1 but this librccl has no ncclCommSplit"); return 1; }
       ncclComm_t split = nullptr;
       ncclResult_t r = R.CommSplit(c->lane[0].comm, 0, myrank, &split, nullptr);
-      if (r != ncclSuccess || !split) { mw::set_error(std::string("MW_RCCL_TWO_COMMS=1: ncclCommSplit failed: ") + R.GetErrorString(r)); return 1; }
+      if (r != ncclSuccess || !split) { mw::set_error(std::string("rccl_two_comms = 1: ncclCommSplit failed: ") + R.GetErrorString(r)); return 1; }
       c->lane[1].comm = split; c->own_comm1 = true;
     } }
   for (int l = 0; l < c->nlanes; l++) {
@@ -160,6 +178,7 @@ int rccl_exchange(void *vctx, const double *sW, const double *sE, const double *
   RcclLane &L = lane_of(c, main_stream);
   MW_HIP(hipEventRecord(L.ev_ready, main_stream));           // pack kernels done
   MW_HIP(hipStreamWaitEvent(L.side, L.ev_ready, 0));
+  if (c->fuzz && mw::launch_spin(fuzz_usec(c), L.side)) return 1;        // (test aid: the strips leave late)
   const double *sbuf[4] = {sW, sE, sS, sN};
   double *rbuf[4] = {rW, rE, rS, rN};
   const long long cnt[4] = {nWE, nWE, nSN, nSN};
@@ -169,6 +188,7 @@ int rccl_exchange(void *vctx, const double *sW, const double *sE, const double *
   for (int o = 0; o < 4; o++) { int dir = c->recv_order[o];
     if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Recv(rbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], L.comm, L.side)); }
   MW_NCCL(R.GroupEnd());
+  if (c->fuzz && mw::launch_spin(fuzz_usec(c), L.side)) return 1;        // (... and are reported complete late)
   MW_HIP(hipEventRecord(L.ev_done, L.side));
   MW_HIP(hipStreamWaitEvent(main_stream, L.ev_done, 0));     // unpack kernels wait for the strips
   return 0;
@@ -194,6 +214,13 @@ const char *mw_rccl_library_path(int *version) {
   return R.ok ? R.path.c_str() : "";
 }
 
+// lanes of a handle's transport: its options, else the process default
+static void handle_lanes(mw_dycore_t h, int &lanes, int &two) {
+  default_lanes(lanes, two);
+  const int ol = mw::dycore_option(h, "rccl_lanes"), ot = mw::dycore_option(h, "rccl_two_comms");
+  if (ol > 0) lanes = ol;
+  if (ot >= 0) two = ot;
+}
 int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, int myrank) {
   if (!h || !id128) MW_FAIL("null argument");
   MW_NEED_RCCL();
@@ -206,9 +233,41 @@ int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, in
   ncclUniqueId id; memcpy(&id, id128, 128);
   { ncclResult_t r = R.CommInitRank(&c->lane[0].comm, nranks, id, myrank);
     if (r != ncclSuccess) { c->lane[0].comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
-  if (init_lanes(c, R, nranks, myrank)) return fail();
+  int lanes, two; handle_lanes(h, lanes, two);
+  if (init_lanes(c, R, nranks, myrank, lanes, two)) return fail();
   if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return fail();
+  if (int seed = mw::dycore_option(h, "xchg_fuzz")) c->fuzz = 0x9E3779B97F4A7C15ULL * (unsigned long long)seed + (unsigned long long)myrank + 1;
   if (mw::dycore_set_exchange_owned(h, rccl_exchange, c, [](void *p) { free_ctx((RcclCtx *)p); })) return fail();   // the handle frees it
+  return 0;
+}
+
+// Test transport (no reference counterpart): ONE rank plays every rank of the handle's rank grid.  The handle's grid says nproc_x x nproc_y
+// (mw_decompose), the communicator has one rank, and every active direction's peer is this rank itself -- sends W,E,S,N matched in FIFO
+// order by receives E,W,N,S, exactly the messages a block exchanges with a neighbour that holds the same data.  That is the situation of
+// a periodic domain tiled from copies of one block: this rank's result must then equal the one-rank run of that block bit for bit, and
+// the whole asynchronous machinery -- pack kernels, ncclGroup of sends and receives on the side stream, event pairs, the pipelined /
+// two-stream schedules with exchanges in flight beside compute -- runs for real on one GPU.  The handle's sums over ranks
+// (mw_dycore_rccl_allreduce_sum) are multiplied by the number of blocks (exact: identical contributions), the broadcast is the identity.
+int mw_dycore_use_rccl_self(mw_dycore_t h) {
+  if (!h) MW_FAIL("null argument");
+  MW_NEED_RCCL();
+  mw_grid_t g;
+  if (mw_dycore_get_grid(h, &g)) return 1;
+  RcclCtx *c = new RcclCtx();
+  auto fail = [&]() { free_ctx(c); return 1; };
+  ncclUniqueId id;
+  { ncclResult_t r = R.GetUniqueId(&id);
+    if (r != ncclSuccess) { mw::set_error(std::string("ncclGetUniqueId failed: ") + R.GetErrorString(r)); return fail(); } }
+  { ncclResult_t r = R.CommInitRank(&c->lane[0].comm, 1, id, 0);
+    if (r != ncclSuccess) { c->lane[0].comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
+  int lanes, two; handle_lanes(h, lanes, two);
+  if (init_lanes(c, R, 1, 0, lanes, two)) return fail();
+  if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return fail();   // (which directions exchange: the grid's)
+  for (int d = 0; d < 4; d++) { c->peers[d] = 0; c->send_order[d] = d; }
+  c->recv_order[0] = 1; c->recv_order[1] = 0; c->recv_order[2] = 3; c->recv_order[3] = 2;
+  c->self_ranks = g.nproc_x * g.nproc_y;
+  if (int seed = mw::dycore_option(h, "xchg_fuzz")) c->fuzz = 0x9E3779B97F4A7C15ULL * (unsigned long long)seed + 1;
+  if (mw::dycore_set_exchange_owned(h, rccl_exchange, c, [](void *p) { free_ctx((RcclCtx *)p); })) return fail();
   return 0;
 }
 
@@ -245,6 +304,7 @@ int mw_dycore_rccl_allreduce_sum(void *handle, double *buf, long long n, void *s
   if (!c) MW_FAIL("mw_dycore_rccl_allreduce_sum: the handle has no built-in RCCL transport (mw_dycore_use_rccl)");
   if (!R.AllReduce) MW_FAIL("this librccl has no ncclAllReduce");
   MW_NCCL(R.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, c->lane[0].comm, (hipStream_t)stream));
+  if (c->self_ranks > 1 && mw::launch_scale(buf, n, (double)c->self_ranks, (hipStream_t)stream)) return 1;   // (self-loop test transport: identical blocks)
   return 0;
 }
 int mw_dycore_rccl_bcast(mw_dycore_t h, double *buf, long long n, int root, void *stream) {
@@ -258,8 +318,15 @@ int mw_dycore_rccl_bcast(mw_dycore_t h, double *buf, long long n, int root, void
 }
 
 static int g_selftest_lanes = 0, g_selftest_comms = 0;
+static int g_selftest_cfg[2] = {0, 0};                         // lanes / communicator per lane of the next self-test (0: the process default)
+// lanes = 1 | 2, two_comms = 0 | 1 for the following mw_rccl_selftest calls of this process; lanes = 0: back to the process default
+int mw_rccl_selftest_config(int lanes, int two_comms) {
+  if (lanes < 0 || lanes > 2 || (two_comms != 0 && two_comms != 1)) MW_FAIL("mw_rccl_selftest_config: lanes must be 0, 1 or 2 and two_comms 0 or 1");
+  g_selftest_cfg[0] = lanes; g_selftest_cfg[1] = two_comms;
+  return 0;
+}
 // How many lanes (side stream + event pair) the last mw_rccl_selftest drove, times 10, plus the number of communicators behind them:
-// 21 = two lanes on the handle's one communicator (default), 22 = two lanes with a communicator each (MW_RCCL_TWO_COMMS=1).
+// 21 = two lanes on the handle's one communicator (default), 22 = two lanes with a communicator each (rccl_two_comms = 1).
 int mw_rccl_selftest_lanes(void) { return g_selftest_lanes * 10 + g_selftest_comms; }
 
 // Diagnostic: a 1-rank communicator that sends n doubles to itself through the same group/stream/event sequence as
@@ -275,7 +342,8 @@ int mw_rccl_selftest(long long n, void *vstream) {
   auto fail = [&]() { free_ctx(c); return 1; };
   { ncclResult_t r = R.CommInitRank(&c->lane[0].comm, 1, id, 0);
     if (r != ncclSuccess) { c->lane[0].comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
-  if (init_lanes(c, R, 1, 0)) return fail();
+  { int lanes, two; default_lanes(lanes, two); if (g_selftest_cfg[0] > 0) { lanes = g_selftest_cfg[0]; two = g_selftest_cfg[1]; }
+    if (init_lanes(c, R, 1, 0, lanes, two)) return fail(); }
   for (int d = 0; d < 4; d++) { c->peers[d] = 0; c->send_order[d] = d; c->active[d] = 1; }
   c->recv_order[0] = 1; c->recv_order[1] = 0; c->recv_order[2] = 3; c->recv_order[3] = 2;      // E,W,N,S like mw_exchange_plan
   std::vector<double> h((size_t)4 * n), back((size_t)4 * n, -1.0);

@@ -366,6 +366,10 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
   // rank 0 and handed to the other ranks by whatever launched them (a file, a pipe, an environment variable).  Afterwards
   // mw_dycore_rccl_allreduce_sum (ctx = handle()) is the all-reduce of sponge_layer / ColumnNudger.
   void use_rccl(core::Coupler const &coupler, const unsigned char *id128) { mw_check(mw_dycore_use_rccl(h, id128, coupler.get_nranks(), coupler.get_myrank())); }
+  // Run-time options of the handle (schedule, kernel forms, chunk sizes, transport lanes: include/mw_cdna4.h) -- the typed replacement of
+  // the MW_* environment switches; call after init().
+  void set_option(const char *key, long long value) { mw_check(mw_dycore_set_option(h, key, value)); }
+  long long get_option(const char *key) const { long long v = 0; mw_check(mw_dycore_get_option(h, key, &v)); return v; }
  private:
   void bind(core::Coupler &coupler) {
     auto &dm = coupler.get_data_manager_readwrite();

@@ -31,6 +31,16 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+# Options every NEW dycore handle of this process gets right after mw_dycore_create (mw_dycore_set_option; keys in include/mw_cdna4.h).
+# Tests and A/B tools fill it (monkeypatch.setitem) where rounds 1-4 set MW_* environment variables; empty = the library's defaults.
+DEFAULT_OPTIONS = {}
+# (convenience of THIS Python host, read once at import -- the library itself never looks at it: MW_OPTIONS="pipe=0,chunk_z=7" pre-fills
+#  the table for command-line A/B runs, e.g. tools/ab_bench.sh)
+for _kv in filter(None, os.environ.get("MW_OPTIONS", "").split(",")):
+    _k, _, _v = _kv.partition("=")
+    DEFAULT_OPTIONS[_k.strip()] = int(_v)
+
+
 class Dynamics_Euler_Stratified_WenoFV:
     ord = 5               # the reference's compile-time MW_ORD (:24-29); Dynamics_Euler_Stratified_WenoFV(ord=3) = its -DMW_ORD=3 build
     hs = 2
@@ -112,6 +122,8 @@ class Dynamics_Euler_Stratified_WenoFV:
         g.bc_x, g.bc_y, g.bc_z, g.use_immersed = capi.BC_PERIODIC, capi.BC_PERIODIC, capi.BC_WALL, 0
         with torch.cuda.device(coupler.device):
             check(L.mw_dycore_create(C.byref(self.h), C.byref(g), pos, adds, _stream_ptr(coupler.device)))
+            for key, val in DEFAULT_OPTIONS.items():
+                self.set_option(key, val)
             if self.ord != 5:
                 check(L.mw_dycore_set_order(self.h, self.ord))              # before init: the supercell data uses `ord` GLL points
             self._bind(coupler)
@@ -178,6 +190,15 @@ class Dynamics_Euler_Stratified_WenoFV:
 
     def set_strict(self, strict):
         check(capi.lib().mw_dycore_set_strict(self.h, int(strict)))
+
+    def set_option(self, key, value):
+        """A run-time option of this handle (mw_dycore_set_option: schedule, kernel forms, chunk sizes, transport; include/mw_cdna4.h)."""
+        check(capi.lib().mw_dycore_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_longlong(0)
+        check(capi.lib().mw_dycore_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def set_bc(self, coupler, bc_x, bc_y, bc_z):
         check(capi.lib().mw_dycore_set_bc(self.h, bc_x, bc_y, bc_z))
@@ -397,8 +418,19 @@ def perturb_temperature(coupler, thermal=True, random=False):                   
             check(capi.lib().mw_perturb_temperature(C.byref(coupler.grid), _ptr(temp), _stream_ptr(coupler.device)))
 
 
+def use_rccl_allreduce(coupler, dycore):
+    """The column modules' sums over ranks (sponge_layer, ColumnNudger) on the dycore handle's own RCCL communicator
+    (mw_dycore_rccl_allreduce_sum, ctx = the handle) instead of torch.distributed -- what a C++ host does (host/mw_facade.h)."""
+    fn = C.cast(capi.lib().mw_dycore_rccl_allreduce_sum, capi.ALLREDUCE_FN)
+    coupler._allreduce = (fn, dycore.h, dycore)
+
+
 def _torch_allreduce(coupler, group=None):
-    """mw_allreduce_fn over torch.distributed (RCCL on GPUs) for the sponge / nudger horizontal means; None on one rank."""
+    """-> (mw_allreduce_fn, ctx) for the sponge / nudger horizontal means: the override installed by use_rccl_allreduce, else
+    torch.distributed (RCCL on GPUs); (NULL, None) on one rank."""
+    ov = getattr(coupler, "_allreduce", None)
+    if ov is not None:
+        return ov[0], ov[1]
     import torch.distributed as dist
     if coupler.get_nranks() <= 1 or not dist.is_initialized():
         return C.cast(None, capi.ALLREDUCE_FN), None
@@ -423,7 +455,8 @@ def _torch_allreduce(coupler, group=None):
             print("allreduce callback failed: %r" % (e,), file=sys.stderr)
             return 1
     fn = capi.ALLREDUCE_FN(cb)
-    return fn, fn
+    coupler._allreduce_keep = fn                                 # (the callback object must outlive the call)
+    return fn, None
 
 
 def _field_ptr_array(tensors):
@@ -453,10 +486,10 @@ def sponge_layer(coupler, dt, time_scale=60.0):
     dm = coupler.get_data_manager_readwrite()
     fields = [dm.get(n) for n in ("density_dry", "uvel", "vvel", "wvel", "temp")] + [dm.get(n) for n in coupler.get_tracer_names()]
     ws = _column_ws(coupler, len(fields), coupler)
-    fn, keep = _torch_allreduce(coupler)
+    fn, ctx = _torch_allreduce(coupler)
     with torch.cuda.device(coupler.device):
         check(capi.lib().mw_sponge_layer(C.byref(coupler.grid), _field_ptr_array(fields), len(fields), float(dt), float(time_scale),
-                                         _ptr(ws), fn, None, _stream_ptr(coupler.device)))
+                                         _ptr(ws), fn, ctx, _stream_ptr(coupler.device)))
 
 
 class ColumnNudger:
@@ -474,19 +507,19 @@ class ColumnNudger:
     def set_column(self, coupler):                                             # :15-36
         self.column = torch.zeros((5, coupler.get_nz(), coupler.get_nens()), dtype=torch.float64, device=coupler.device)
         ws = _column_ws(coupler, 5, self)
-        fn, keep = _torch_allreduce(coupler)
+        fn, ctx = _torch_allreduce(coupler)
         with torch.cuda.device(coupler.device):
             check(capi.lib().mw_column_average(C.byref(coupler.grid), _field_ptr_array(self._state(coupler)), _ptr(self.column), _ptr(ws),
-                                               fn, None, _stream_ptr(coupler.device)))
+                                               fn, ctx, _stream_ptr(coupler.device)))
 
     def nudge_to_column(self, coupler, dt):                                    # :39-66
         if self.column is None:
             endrun("ColumnNudger.nudge_to_column before set_column")
         ws = _column_ws(coupler, 5, self)
-        fn, keep = _torch_allreduce(coupler)
+        fn, ctx = _torch_allreduce(coupler)
         with torch.cuda.device(coupler.device):
             check(capi.lib().mw_nudge_to_column(C.byref(coupler.grid), _field_ptr_array(self._state(coupler)), _ptr(self.column), float(dt),
-                                                _ptr(ws), fn, None, _stream_ptr(coupler.device)))
+                                                _ptr(ws), fn, ctx, _stream_ptr(coupler.device)))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -917,6 +950,15 @@ def use_rccl_exchange(dycore, coupler, group=None):
         raise MWError("rank 0 could not create the ncclUniqueId" + (": " + why if why else ""))
     with torch.cuda.device(coupler.device):
         check(L.mw_dycore_use_rccl(dycore.h, bytes(host[:128]), world, rank))
+
+
+def use_rccl_self_exchange(dycore, coupler):
+    """The self-loop test transport (mw_dycore_use_rccl_self): this one rank plays every rank of the coupler's rank grid over a 1-rank
+    RCCL communicator -- the real send / receive groups on the side stream(s), on one GPU.  The column modules' sums go through the
+    handle's communicator too (times the number of blocks)."""
+    with torch.cuda.device(coupler.device):
+        check(capi.lib().mw_dycore_use_rccl_self(dycore.h))
+    use_rccl_allreduce(coupler, dycore)
 
 
 def use_torch_distributed_exchange(dycore, coupler, group=None, host_staged=False):

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import pytest
 
-from util import compare_fields, gpu_fields, oracle_sensitivity, push_fields, sens_allowed
+from util import build_has, compare_fields, gpu_fields, oracle_sensitivity, push_fields, sens_allowed, set_options
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -75,15 +75,16 @@ def test_time_steps_match_oracle(mw, oracle, name, mode):
     assert abs(dycore.etime - 10 * dt) < 1e-12
 
 
-@pytest.mark.skipif(not os.environ.get("MW_TEST_SCHED_LISTS"), reason="the balanced launch lists exist in a -DMW_SCHED_LISTS build only (a measured dead end, DESIGN.md 0c)")
 @pytest.mark.parametrize("name", sorted(SNAP["cases"]))
 def test_balanced_schedule_bitwise_equal_to_chunked_grid(mw, oracle, name, monkeypatch):
     """The marching kernels' balanced launch lists (round 4: whole columns first, then equal slices of the remaining columns, the parts
-    of a slice behind a column boundary last; MW_SCHED=2 forces them at any size) only re-partition the marching direction: the
-    production path's results are BITWISE those of the chunked grid (MW_SCHED=0), and match the oracle."""
+    of a slice behind a column boundary last; option sched = 2 forces them at any size) only re-partition the marching direction: the
+    production path's results are BITWISE those of the chunked grid (sched = 0), and match the oracle."""
+    if not build_has(2):
+        pytest.skip("the balanced launch lists exist in a -DMW_SCHED_LISTS build only (a measured dead end, DESIGN.md 0c)")
     res = {}
     for sched in ("0", "2"):
-        monkeypatch.setenv("MW_SCHED", sched)
+        set_options(monkeypatch, sched=sched)
         coupler, dycore, odyc, of = setup_case(oracle, SNAP["cases"][name])
         push_fields(coupler, of)
         dt = dycore.compute_time_step(coupler)
@@ -101,15 +102,16 @@ def test_balanced_schedule_bitwise_equal_to_chunked_grid(mw, oracle, name, monke
 @pytest.mark.parametrize("order", [5, 3])
 @pytest.mark.parametrize("case", ["supercell", "city"])
 def test_fused_state_stage_bitwise_equal_to_production(mw, oracle, case, order, monkeypatch):
-    """MW_FUSED_STATE=1: the state variables' x, y AND z faces in one z-marching launch (k_state_xyz, mw_fused.h: the y stencil from an
+    """Option fused_state (-DMW_EXPERIMENTS builds): the state variables' x, y AND z faces in one z-marching launch (k_state_xyz, mw_fused.h: the y stencil from an
     LDS tile of the workgroup's four rows, tile-edge faces rebuilt inside the workgroup, three barriers per level) instead of k_y_all's
     state part + k_xz_state; the tracers' y fluxes then come from k_y_tracers.  Statement by statement the same arithmetic: the
     coupler's fields after several steps (one of them sub-cycled) are BITWISE those of the production schedule; also against the oracle."""
     from miniweatherml_amd import modules
+    if not build_has(1):
+        pytest.skip("k_state_xyz (mw_fused.h) is a measured dead end kept outside the release build: -DMW_EXPERIMENTS (tools/build_variant.sh)")
     res = {}
     for fused in ("0", "1", "8"):                              # 1: four row-waves per workgroup, 8: eight (one workgroup per CU)
-        monkeypatch.setenv("MW_FUSED_STATE", fused)
-        monkeypatch.setenv("MW_CHUNK_Z", "7")                  # several z chunks with ghost levels on these small grids
+        set_options(monkeypatch, fused_state=fused, chunk_z=7)  # several z chunks with ghost levels on these small grids
         if case == "supercell":
             coupler, dycore, _ = modules.make_supercell(130, 24, 26, 1, 65000., 12000., 20000., ord=order)
             dm = coupler.get_data_manager_readwrite()
@@ -333,10 +335,7 @@ def test_fct_limiter_heavy(mw, oracle, fused, shape, monkeypatch, overlap):
     by a donor in another row are corrected afterwards); fused=0: k_xz_tracers + k_tracer_update."""
     from miniweatherml_amd import modules
     nx, ny, nz, nens = shape
-    monkeypatch.setenv("MW_FUSED_TRACERS", fused)
-    monkeypatch.setenv("MW_OVERLAP", overlap)
-    monkeypatch.setenv("MW_CHUNK_F", "4")
-    monkeypatch.setenv("MW_CHUNK_Z", "4")
+    set_options(monkeypatch, fused_tracers=fused, overlap=overlap, chunk_f=4, chunk_z=4)
     xlen, ylen = 500.0 * nx, 500.0 * max(ny, 2)
     coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000.)
 
@@ -371,7 +370,9 @@ def test_fct_limiter_heavy(mw, oracle, fused, shape, monkeypatch, overlap):
 def test_fct_patch_pass_is_exercised(mw, oracle, monkeypatch):
     """Negative control for the test above: with the y-face correction pass switched off the fused path must MISS the
     oracle on the limiter-heavy case (i.e. donors in neighbouring rows really do scale y faces there)."""
-    monkeypatch.setenv("MW_DEBUG_NO_PATCH", "1")
+    if not build_has(1):
+        pytest.skip("the no-patch switch of the negative control exists in a -DMW_EXPERIMENTS build only")
+    set_options(monkeypatch, debug_no_patch=1)
     with pytest.raises(AssertionError):
         test_fct_limiter_heavy(mw, oracle, "1", (70, 9, 12, 1), monkeypatch, "0")
 

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from util import set_options
+
 pytestmark = pytest.mark.gpu
 
 
@@ -90,15 +92,12 @@ def test_production_path_equals_general_path_at_size(mw, order):
 @pytest.mark.parametrize("case", ["supercell", "supercell_ord3", "supercell_nens2", "city"])
 def test_folded_configurations_are_bitwise_the_run_time_switches(mw, monkeypatch, case):
     """Cf<K>: the marching kernels with the shipped configurations' switches folded at compile time (K = 1 supercell, K = 2
-    simple_city) execute the same arithmetic as with every switch at run time (K = 0, MW_NO_SPEC=1) -- the folded terms are exact
+    simple_city) execute the same arithmetic as with every switch at run time (K = 0, option spec = 0) -- the folded terms are exact
     no-ops (fcor = 0, bcmode = 0, mask bits set) -- so the results must be bit-identical, 5 steps, orders 5 and 3, member-major too."""
     from miniweatherml_amd import modules
     out = []
     for nospec in (False, True):
-        if nospec:
-            monkeypatch.setenv("MW_NO_SPEC", "1")
-        else:
-            monkeypatch.delenv("MW_NO_SPEC", raising=False)
+        set_options(monkeypatch, spec=0 if nospec else 1)
         if case == "city":
             coupler, dycore, hs, ta = modules.make_simple_city(96, 80, 24, 1, 480., 400., 120., "city")
         else:
@@ -120,13 +119,13 @@ def test_folded_configurations_are_bitwise_the_run_time_switches(mw, monkeypatch
 
 
 def test_two_stream_schedule_is_bitwise_the_one_stream_schedule(mw, monkeypatch):
-    """MW_OVERLAP=1 runs the state and tracer pipelines on two streams (the default with a neighbour exchange), MW_OVERLAP=0 on
+    """Option overlap = 1 runs the state and tracer pipelines on two streams (the default with a neighbour exchange), overlap = 0 on
     one (the default on one rank): the same kernels on the same data, so any difference would be a missing stream dependency."""
     import torch
     from miniweatherml_amd import modules
     out = []
     for ov in ("0", "1"):
-        monkeypatch.setenv("MW_OVERLAP", ov)
+        set_options(monkeypatch, overlap=ov)
         coupler, dycore, _ = modules.make_supercell(160, 120, 60, 1, 80000., 60000., 20000.)
         modules.perturb_temperature(coupler)
         dt = dycore.compute_time_step(coupler)
@@ -139,15 +138,14 @@ def test_two_stream_schedule_is_bitwise_the_one_stream_schedule(mw, monkeypatch)
 
 
 def test_index_wrap_is_bitwise_the_halo_fill(mw, monkeypatch):
-    """Periodic x/y on one rank: the marching kernels wrap their indices and no halo is filled (default); MW_NO_WRAP=1 fills the
+    """Periodic x/y on one rank: the marching kernels wrap their indices and no halo is filled (default); option wrap = 0 fills the
     x/y halos and reads them.  Same values reach the same arithmetic, so the fields must be identical -- also with 3 members."""
     import torch
     from miniweatherml_amd import modules
     for nens in (1, 3):
         out = []
         for nowrap in (None, "1"):
-            if nowrap: monkeypatch.setenv("MW_NO_WRAP", nowrap)
-            else: monkeypatch.delenv("MW_NO_WRAP", raising=False)
+            set_options(monkeypatch, wrap=0 if nowrap else 1)
             coupler, dycore, _ = modules.make_supercell(100, 61, 24, nens, 50000., 30500., 20000.)
             modules.perturb_temperature(coupler)
             dt = dycore.compute_time_step(coupler)
@@ -163,14 +161,13 @@ def test_index_wrap_is_bitwise_the_halo_fill(mw, monkeypatch):
 
 def test_conversion_inside_y_state_is_bitwise_the_conversion_pass(mw, monkeypatch):
     """One rank, periodic x/y, one stream: the first k_y_state converts the coupler rows it loads and fills the slab (default);
-    MW_NO_FUSED_CONVERT=1 runs k_coupler_to_state_fast first.  Same device function on the same inputs: identical fields, also
+    option fused_convert = 0 runs k_coupler_to_state_fast first.  Same device function on the same inputs: identical fields, also
     with sub-cycling (only the first cycle converts) and with a developed, perturbed state."""
     import torch
     from miniweatherml_amd import modules
     out = []
     for nofuse in (None, "1"):
-        if nofuse: monkeypatch.setenv("MW_NO_FUSED_CONVERT", nofuse)
-        else: monkeypatch.delenv("MW_NO_FUSED_CONVERT", raising=False)
+        set_options(monkeypatch, fused_convert=0 if nofuse else 1)
         coupler, dycore, _ = modules.make_supercell(90, 70, 30, 1, 45000., 35000., 20000.)
         modules.perturb_temperature(coupler)
         dt = dycore.compute_time_step(coupler)
@@ -222,17 +219,16 @@ def test_config5_city_block(mw):
 
 def test_member_major_layout_agrees_with_the_member_fastest_kernels(mw, monkeypatch):
     """nens > 1: the default keeps the handle's arrays member after member and runs the nens = 1 kernels per member (DPP shifts);
-    MW_NO_MEMBER_MAJOR=1 keeps the coupler's member-fastest order inside and fetches the x neighbours by loads.  The stencil
+    Option member_major = 0 keeps the coupler's member-fastest order inside and fetches the x neighbours by loads.  The stencil
     arithmetic is the same; the conversions at the coupler boundary are not (the member-major handle stores q / rho in its slab and
     multiplies back in k_member_to_coupler, the other writes rho q straight from the last stage): agreement to a few ulp, with
     members that differ from each other and chunks that do not divide nz."""
     import torch
     from miniweatherml_amd import modules
-    monkeypatch.setenv("MW_CHUNK_Z", "7"); monkeypatch.setenv("MW_CHUNK_F", "9")
+    set_options(monkeypatch, chunk_z=7, chunk_f=9)
     out = []
     for legacy in (None, "1"):
-        if legacy: monkeypatch.setenv("MW_NO_MEMBER_MAJOR", legacy)
-        else: monkeypatch.delenv("MW_NO_MEMBER_MAJOR", raising=False)
+        set_options(monkeypatch, member_major=0 if legacy else 1)
         coupler, dycore, _ = modules.make_supercell(70, 45, 26, 3, 35000., 22500., 20000.)
         modules.perturb_temperature(coupler)
         dm = coupler.get_data_manager_readwrite()
@@ -257,18 +253,17 @@ def test_member_major_layout_agrees_with_the_member_fastest_kernels(mw, monkeypa
 def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracle(mw, oracle, monkeypatch, nens, nx, ny, nz, order):
     """Member-major handles with 2 or 4 members read D1 in the first k_y_state and write D13 from the last stage's kernels, with the
     members of the same cells in ONE workgroup (MemberOff / k_y_state<.., MM = 2>, mw_march.h) so that their accesses to the coupler's
-    member-fastest arrays meet in L1 / L2.  MW_NO_MM_DIRECT=1 keeps the k_member_to_coupler pass (q / rho in the slab, multiplied
+    member-fastest arrays meet in L1 / L2.  Option mm_direct = 0 keeps the k_member_to_coupler pass (q / rho in the slab, multiplied
     back: a few ulp apart) and the fused-lane D1 launch.  Members that differ, several tiles per row with a ragged last one, an odd row
     count (nens = 2: a workgroup's second row does not exist), chunks that do not divide nz, a sub-cycled step.  Then the same path
     against the CPU oracle (tolerance of BASELINE.md section 4); WENO-5 and WENO-3."""
     import torch
     from miniweatherml_amd import modules
     from util import compare_fields, gpu_fields, push_fields
-    monkeypatch.setenv("MW_CHUNK_Z", "7"); monkeypatch.setenv("MW_CHUNK_F", "9")
+    set_options(monkeypatch, chunk_z=7, chunk_f=9)
     out = []
     for pass13 in (None, "1"):
-        if pass13: monkeypatch.setenv("MW_NO_MM_DIRECT", pass13)
-        else: monkeypatch.delenv("MW_NO_MM_DIRECT", raising=False)
+        set_options(monkeypatch, mm_direct=0 if pass13 else 1)
         coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000., ord=order)
         modules.perturb_temperature(coupler)
         dm = coupler.get_data_manager_readwrite()
@@ -287,7 +282,7 @@ def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracl
     a = out[0]["temp"]
     assert not torch.equal(a[..., 0], a[..., 1])
     # --- against the oracle, production arithmetic
-    monkeypatch.delenv("MW_NO_MM_DIRECT", raising=False)
+    set_options(monkeypatch, mm_direct=1)
     coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000., ord=order)
     odyc, of = (oracle if order == 5 else oracle.with_order(order)).supercell_setup(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
     of.temp += 0.05 * np.arange(nens)
@@ -301,12 +296,12 @@ def test_members_in_one_workgroup_agree_with_the_conversion_passes_and_the_oracl
 
 def test_members_in_one_workgroup_with_a_chunk_longer_than_the_lds_tables_allow(mw, oracle, monkeypatch):
     """The D13 launch of k_xz_state with the members of a tile in one workgroup keeps one background table per wave in LDS:
-    (chunk + 2) x 256 B on top of ~20.5 KB of static LDS.  A chunk of 200 levels (MW_CHUNK_Z, or the chunk rule on a grid with many
+    (chunk + 2) x 256 B on top of ~20.5 KB of static LDS.  A chunk of 200 levels (option chunk_z, or the chunk rule on a grid with many
     wavefronts and a tall column) would exceed the 64 KB a workgroup may have and the launch would fail (round 3's advisor finding):
     that launch now cuts its own chunks at 170 levels.  nens = 4, nz = 200, against the oracle."""
     from miniweatherml_amd import modules
     from util import compare_fields, gpu_fields, push_fields
-    monkeypatch.setenv("MW_CHUNK_Z", "200"); monkeypatch.setenv("MW_CHUNK_F", "200")
+    set_options(monkeypatch, chunk_z=200, chunk_f=200)
     nx, ny, nz, nens = 24, 8, 200, 4
     coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
     odyc, of = oracle.supercell_setup(nx, ny, nz, nens, 500. * nx, 500. * ny, 20000.)
@@ -322,15 +317,14 @@ def test_members_in_one_workgroup_with_a_chunk_longer_than_the_lds_tables_allow(
 @pytest.mark.parametrize("nx,ny,nz,order", [(61, 23, 17, 5), (130, 9, 26, 5), (64, 37, 12, 3)])
 def test_y_faces_of_all_variables_in_one_launch_equal_the_two_launches(mw, oracle, monkeypatch, nx, ny, nz, order):
     """k_y_all (state variables and tracers in one y march; the converting first stage included) against k_y_state + k_y_tracers
-    (MW_NO_Y_ALL=1): the same arithmetic, so the same bits -- odd sizes, y chunks that do not divide ny, a sub-cycled step, cloud
+    (option y_all = 0): the same arithmetic, so the same bits -- odd sizes, y chunks that do not divide ny, a sub-cycled step, cloud
     and rain present.  Then against the CPU oracle (tolerance of BASELINE.md section 4)."""
     from miniweatherml_amd import modules
     from util import compare_fields, gpu_fields, push_fields
-    monkeypatch.setenv("MW_CHUNK_Y", "7")
+    set_options(monkeypatch, chunk_y=7)
     out = []
     for two in (None, "1"):
-        if two: monkeypatch.setenv("MW_NO_Y_ALL", two)
-        else: monkeypatch.delenv("MW_NO_Y_ALL", raising=False)
+        set_options(monkeypatch, y_all=0 if two else 1)
         coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 500. * nx, 500. * ny, 20000., ord=order)
         dm = coupler.get_data_manager_readwrite()
         dm.get("cloud_liquid", True).fill_(3.0e-4); dm.get("precip_liquid", True).fill_(1.0e-4)
@@ -340,7 +334,7 @@ def test_y_faces_of_all_variables_in_one_launch_equal_the_two_launches(mw, oracl
         out.append(gpu_fields(coupler))
     for n in out[0]:
         assert np.array_equal(out[0][n], out[1][n]), n
-    monkeypatch.delenv("MW_NO_Y_ALL", raising=False)
+    set_options(monkeypatch, y_all=1)
     O = oracle if order == 5 else oracle.with_order(order)
     coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 500. * nx, 500. * ny, 20000., ord=order)
     odyc, of = O.supercell_setup(nx, ny, nz, 1, 500. * nx, 500. * ny, 20000.)

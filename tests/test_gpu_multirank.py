@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import Exchanger, OracleExchanger, compare_fields, gpu_fields, push_fields
+from util import Exchanger, OracleExchanger, compare_fields, gpu_fields, push_fields, set_options
 
 pytestmark = pytest.mark.gpu
 
@@ -82,9 +82,9 @@ def test_four_ranks_other_weno_orders(mw, ord):
 
 def test_four_ranks_two_stream_schedule(mw, monkeypatch):
     """The default with an exchange is the pipelined one-stream schedule (rk_stage_pipe: k_y_all on the rows that read no halo row while
-    the strips travel, then the two 4-row edge strips).  MW_NO_PIPE=1 selects the two-stream schedule (state | tracer pipelines,
+    the strips travel, then the two 4-row edge strips).  Option pipe = 0 selects the two-stream schedule (state | tracer pipelines,
     k_y_state + k_y_tracers): same bits."""
-    monkeypatch.setenv("MW_NO_PIPE", "1")
+    set_options(monkeypatch, pipe=0)
     run_ranks(4, 32, 72, 10, 1, 2)
 
 
@@ -165,9 +165,15 @@ def test_rccl_transport_selftest(mw, monkeypatch):
         # on the handle's one communicator (default) ...
         assert capi.lib().mw_rccl_selftest_lanes() == 21
         # ... and with a communicator per lane (opt-in; torch's RCCL 2.26 provides ncclCommSplit)
-        monkeypatch.setenv("MW_RCCL_TWO_COMMS", "1")
-        capi.check(capi.lib().mw_rccl_selftest(4096, C.c_void_p(st)))
-        assert capi.lib().mw_rccl_selftest_lanes() == 22
+        capi.check(capi.lib().mw_rccl_selftest_config(2, 1))
+        try:
+            capi.check(capi.lib().mw_rccl_selftest(4096, C.c_void_p(st)))
+            assert capi.lib().mw_rccl_selftest_lanes() == 22
+            capi.check(capi.lib().mw_rccl_selftest_config(1, 0))      # one lane: a third caller stream shares it
+            capi.check(capi.lib().mw_rccl_selftest(4096, C.c_void_p(st)))
+            assert capi.lib().mw_rccl_selftest_lanes() == 11
+        finally:
+            capi.check(capi.lib().mw_rccl_selftest_config(0, 0))
 
 
 @pytest.mark.parametrize("layout", [(2, 20, 24, 10), (4, 32, 28, 8)])

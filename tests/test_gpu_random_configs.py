@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from util import compare_fields, gpu_fields, push_fields
+from util import compare_fields, gpu_fields, push_fields, set_options
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +22,7 @@ def draw(seed):
     pos = [1] + [int(rng.uniform() < 0.7) for _ in range(nt - 1)]
     adds = [1] + [int(rng.uniform() < 0.5) for _ in range(nt - 1)]
     bc = (int(rng.choice([0, 0, 1, 2])), 0 if two_d else int(rng.choice([0, 0, 1, 2])), int(rng.choice([1, 2, 2])))
-    chunks = {k: str(int(rng.integers(3, 12))) for k in ("MW_CHUNK_Z", "MW_CHUNK_F", "MW_CHUNK_Y")}
+    chunks = {k: int(rng.integers(3, 12)) for k in ("chunk_z", "chunk_f", "chunk_y")}
     return dict(nx=nx, ny=ny, nz=nz, nens=nens, nt=nt, pos=pos, adds=adds, bc=bc, chunks=chunks, rng=rng)
 
 
@@ -30,11 +30,10 @@ def draw(seed):
 def test_random_configuration(mw, oracle, seed, monkeypatch):
     from miniweatherml_amd import modules
     c = draw(seed)
-    for k, v in c["chunks"].items():
-        monkeypatch.setenv(k, v)
+    set_options(monkeypatch, **c["chunks"])
     # every other seed: the balanced launch lists (Sched, mw_march.h; only in a -DMW_SCHED_LISTS build, MW_TEST_SCHED_LISTS=1) forced at these small sizes -- whole columns, slices, and the second
     # parts of slices that straddle a column boundary; the others run the chunked grid with the drawn chunk sizes
-    monkeypatch.setenv("MW_SCHED", "2" if (seed % 2 and os.environ.get("MW_TEST_SCHED_LISTS")) else "0")
+    set_options(monkeypatch, sched=2 if (seed % 2 and os.environ.get("MW_TEST_SCHED_LISTS")) else 0)
     nx, ny, nz, nens, nt = c["nx"], c["ny"], c["nz"], c["nens"], c["nt"]
     xlen, ylen = 500.0 * nx, 500.0 * max(ny, 2)
 

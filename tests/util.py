@@ -21,6 +21,20 @@ def sens_allowed(what):
     return any(what.startswith(a) for a in SENS_ALLOW)
 
 
+def set_options(monkeypatch, **opts):
+    """Run-time options (mw_dycore_set_option) for every dycore handle created from here to the end of the test: the typed replacement
+    of the MW_* environment switches of rounds 1-4 (modules.DEFAULT_OPTIONS is applied right after mw_dycore_create)."""
+    from miniweatherml_amd import modules
+    for k, v in opts.items():
+        monkeypatch.setitem(modules.DEFAULT_OPTIONS, k, int(v))
+
+
+def build_has(bit):
+    """1: a -DMW_EXPERIMENTS build of libmw_cdna4 (mw_fused.h, the no-patch negative control), 2: -DMW_SCHED_LISTS (mw_build_flags)."""
+    from miniweatherml_amd import capi
+    return bool(capi.lib().mw_build_flags() & bit)
+
+
 def rel_err(a, b):
     """max|a-b| / max|b|  (the tolerance definition of BASELINE.md section 4)."""
     a = np.asarray(a, dtype=np.float64)
@@ -225,3 +239,86 @@ class OracleExchanger:
         return cb
 
 
+
+
+class StreamExchanger:
+    """Stream-ordered in-process transport (round 5): like Exchanger, all ranks live in threads of this process and strips are copied
+    device-to-device, but NOTHING waits on the host for the device inside the callback -- the copies run on a per-rank side stream behind
+    the peers' post-pack events, and the caller's stream waits for events, exactly the shape of the built-in RCCL transport
+    (mw_rccl.cpp: ev_ready -> side stream -> ev_done).  The two host barriers only hand event / buffer handles from thread to thread.
+    fuzz_seed != 0: spin kernels of seeded random length (mw_debug_spin) in front of and behind the copies, so that a missing wait in the
+    schedule shows up as a wrong bit instead of hiding behind lucky timing."""
+
+    def __init__(self, nranks, fuzz_seed=0):
+        import torch                                               # noqa: F401  (the HIP runtime torch loaded is the process's one)
+        self.n = nranks
+        self.bar = threading.Barrier(nranks)
+        self.send = [None] * nranks
+        self.errors = []
+        self.fuzz = fuzz_seed
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        hip.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        self.hip = hip
+        self.lanes = {}                                            # (rank, caller stream) -> (side stream, ready event, copied event)
+        self.ready = [None] * nranks
+        self.copied = [None] * nranks
+        self.calls = 0
+
+    def _lane(self, rank, stream):
+        key = (rank, stream or 0)
+        if key not in self.lanes:
+            side, e0, e1 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            assert self.hip.hipStreamCreateWithFlags(C.byref(side), 1) == 0                 # hipStreamNonBlocking
+            assert self.hip.hipEventCreateWithFlags(C.byref(e0), 2) == 0                    # hipEventDisableTiming
+            assert self.hip.hipEventCreateWithFlags(C.byref(e1), 2) == 0
+            self.lanes[key] = (side, e0, e1)
+        return self.lanes[key]
+
+    def make_cb(self, rank, grid):
+        from miniweatherml_amd import capi
+        L = capi.lib()
+        peers, so, ro, act = (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)(), (C.c_int * 4)()
+        capi.check(L.mw_exchange_plan(C.byref(grid), peers, so, ro, act))
+        hip = self.hip
+        rng = np.random.default_rng([self.fuzz, rank]) if self.fuzz else None
+
+        def spin(stream):
+            if rng is not None:
+                us = int(rng.integers(0, 250))
+                if us:
+                    capi.check(L.mw_debug_spin(us, stream))
+
+        def cb(ctx, sW, sE, sS, sN, rW, rE, rS, rN, nWE, nSN, stream):
+            try:
+                side, ready, copied = self._lane(rank, stream)
+                assert hip.hipEventRecord(ready, stream) == 0             # my strips are packed (and my last unpack has read its buffers)
+                self.send[rank] = (sW, sE, sS, sN)
+                self.ready[rank], self.copied[rank] = ready, copied
+                self.bar.wait(timeout=120)                               # (host rendezvous: handles only)
+                cnt = [nWE, nWE, nSN, nSN]
+                recv = [rW, rE, rS, rN]
+                assert hip.hipStreamWaitEvent(side, ready, 0) == 0
+                spin(side)
+                for d in range(4):                                      # my halo d comes from peer[d]'s opposite strip
+                    if recv[d] and cnt[d] and act[d]:
+                        assert hip.hipStreamWaitEvent(side, self.ready[peers[d]], 0) == 0
+                        src = self.send[peers[d]][d ^ 1]
+                        assert hip.hipMemcpyAsync(recv[d], src, cnt[d] * 8, 3, side) == 0      # hipMemcpyDeviceToDevice
+                spin(side)
+                assert hip.hipEventRecord(copied, side) == 0
+                self.bar.wait(timeout=120)                               # every rank's `copied` event has been recorded
+                assert hip.hipStreamWaitEvent(stream, copied, 0) == 0     # my halos have arrived ...
+                for d in range(4):                                      # ... and the peers have read my strips: the buffers may be packed again
+                    if act[d] and cnt[d]:
+                        assert hip.hipStreamWaitEvent(stream, self.copied[peers[d]], 0) == 0
+                self.bar.wait(timeout=120)                               # (nobody re-records an event a peer is still about to wait for)
+                return 0
+            except Exception as e:                                      # pragma: no cover
+                self.errors.append(repr(e))
+                self.bar.abort()
+                return 1
+        return capi.EXCHANGE_FN(cb)

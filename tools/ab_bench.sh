@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B timing of environment-selected kernel variants in ONE gpurun call: bash tools/ab_bench.sh "VAR=a" "VAR=b" ...
+# A/B timing of kernel variants in ONE gpurun call: bash tools/ab_bench.sh "MW_OPTIONS=chunk_z=20" "MW_LIB_PATH=.../libmw_x.so" ...
+# (MW_OPTIONS = handle options for the Python host, modules.DEFAULT_OPTIONS; MW_LIB_PATH = another build of the library)
 # Each variant: bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-micro, three repetitions, interleaved.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

@@ -20,13 +20,13 @@ def report(tag):
 for _ in range(3): modules.supercell_step(coupler, dycore, micro, nudger)
 report("start")
 def classes():
-    os.environ["MW_NO_OVERLAP"] = "1"
+    dycore.set_option("overlap", 0)
     dycore.time_step(coupler, dt); torch.cuda.synchronize()
     dycore.profile(1)
     for _ in range(5): dycore.time_step(coupler, dt)
     names = ["xz_state", "patch", "upd", "halo", "convert", "y_state", "y_tracers", "fused"]
     out = {n: round(dycore.profile_get(i)[0] / 5, 3) for i, n in enumerate(names)}
-    dycore.profile(0); del os.environ["MW_NO_OVERLAP"]
+    dycore.profile(0); dycore.set_option("overlap", -1)
     return out
 print("dycore ms", timed(lambda: dycore.time_step(coupler, dt)), "kessler ms", timed(lambda: micro.time_step(coupler, dt)), classes(), flush=True)
 for s in range(2600):

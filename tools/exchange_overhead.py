@@ -2,7 +2,9 @@
 loop-back transport (every strip this rank sends is copied, device to device and stream-ordered, into its own opposite halo --
 what a periodic neighbour with identical data would send).  Pack, unpack, the copies and the two-stream schedule are all there;
 only the xGMI transfer itself is missing.  Compared with the plain single-rank run of the same block (index wrap, one stream).
-    python tools/exchange_overhead.py [--steps 20]"""
+Round 5: next to the memcpy loop-back the REAL transport -- mw_dycore_use_rccl_self: ncclSend / ncclRecv groups on the side stream of a
+1-rank communicator, every peer this rank itself -- on the block's own state tiled periodically (physically the one-rank run).
+    python tools/exchange_overhead.py [--steps 20] [--pipe 0|1]"""
 import argparse
 import ctypes as C
 import json
@@ -17,7 +19,9 @@ from miniweatherml_amd import capi, modules
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--nx", type=int, default=400); ap.add_argument("--ny", type=int, default=400); ap.add_argument("--nz", type=int, default=100)
+ap.add_argument("--pipe", type=int, default=1, help="0: the two-stream schedule instead of the pipelined one")
 a = ap.parse_args()
+modules.DEFAULT_OPTIONS["pipe"] = a.pipe
 hip = C.CDLL("libamdhip64.so")
 hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
 
@@ -42,9 +46,10 @@ def timed(dycore, coupler, dt, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-res = {}
+res = {"schedule": "pipelined" if a.pipe else "two streams"}
 coupler, dycore, _ = modules.make_supercell(a.nx, a.ny, a.nz, 1, 500.0 * a.nx, 500.0 * a.ny, 20000.)
 dt = dycore.compute_time_step(coupler)
+start = {n: coupler.get_data_manager_readonly().get(n, True).clone() for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid", "precip_liquid")}
 res["single_rank_ms"] = timed(dycore, coupler, dt, a.steps)
 keep = []
 for nranks in (2, 4, 8):
@@ -59,4 +64,15 @@ for nranks in (2, 4, 8):
     ms = timed(dycore, coupler, dt, a.steps)
     res["%d_ranks_%dx%d_ms" % (nranks, npx, npy)] = ms
     res["%d_ranks_overhead" % nranks] = ms / res["single_rank_ms"] - 1.0
+    # the real RCCL transport, every peer = this rank, on the one-rank block's own initial state (a periodic tiling of it)
+    coupler, dycore, _ = modules.make_supercell(a.nx * npx, a.ny * npy, a.nz, 1, 500.0 * a.nx * npx, 500.0 * a.ny * npy, 20000.,
+                                                nranks=nranks, myrank=0)
+    for n, t in start.items():
+        coupler.get_data_manager_readwrite().get(n).copy_(t)
+    modules.use_rccl_self_exchange(dycore, coupler)
+    ms = timed(dycore, coupler, dt, a.steps)
+    res["%d_ranks_%dx%d_rccl_self_ms" % (nranks, npx, npy)] = ms
+    res["%d_ranks_rccl_self_overhead" % nranks] = ms / res["single_rank_ms"] - 1.0
+    del coupler, dycore
+    torch.cuda.empty_cache()
 print(json.dumps(res))

@@ -1,5 +1,5 @@
-"""Field-by-field comparison of the fused state-stage kernel (MW_FUSED_STATE=4, csrc/mw_fused.h) with the production schedule on one GPU:
-    python tools/fused_state_check.py supercell|city <steps> [MW_CHUNK_Z] [rough]
+"""Field-by-field comparison of the fused state-stage kernel (option fused_state = 4, csrc/mw_fused.h; a -DMW_EXPERIMENTS build: MW_LIB_PATH=miniweatherml_amd/ab/libmw_exp.so) with the production schedule on one GPU:
+    python tools/fused_state_check.py supercell|city <steps> [chunk_z] [rough]
 prints max |difference|, where it sits and how many cells differ (0 everywhere = bitwise equal).  `rough` adds a random perturbation of
 every field first (an indexing error then shows as an O(1) difference; a rounding-level one only on smooth states)."""
 import os, sys
@@ -11,8 +11,8 @@ from util import gpu_fields
 case = sys.argv[1]; nsteps = int(sys.argv[2]); chunk = sys.argv[3] if len(sys.argv) > 3 else None
 res = {}
 for fused in ("0", "1"):
-    os.environ["MW_FUSED_STATE"] = "4" if fused == "1" else fused
-    if chunk: os.environ["MW_CHUNK_Z"] = chunk
+    modules.DEFAULT_OPTIONS["fused_state"] = 4 if fused == "1" else 0
+    if chunk: modules.DEFAULT_OPTIONS["chunk_z"] = int(chunk)
     if case == "supercell":
         coupler, dycore, _ = modules.make_supercell(130, 24, 26, 1, 65000., 12000., 20000.)
     else:

@@ -33,7 +33,7 @@ for f in glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv")):
 F, W, SQ = pmc(fdir), pmc(wdir), pmc(sqdir)
 import hashlib
 _h = hashlib.sha256()
-for _f in ("mw_march.h", "mw_weno.h", "mw_weno79.h", "mw_common.h", "mw_dycore.hip"):
+for _f in ("mw_march.h", "mw_weno.h", "mw_weno79.h", "mw_common.h", "mw_calib.h", "mw_dycore.hip"):      # = bench.py KERNEL_SOURCES
     _h.update(open(os.path.join(root, "miniweatherml_amd", "csrc", _f), "rb").read())
 out = {"tag": tag, "cells_per_launch": cells, "kernel_sources_sha16": _h.hexdigest()[:16],
        "note": "FETCH_SIZE x2 (calibrated with mw_calib_copy: 8 B/lane streaming reads report exactly 1/2 on gfx950), WRITE_SIZE x1; KiB -> bytes",
