@@ -18,16 +18,21 @@ roofline: SURVEY.md 8(d)'s flux-stencil figure: 32 V = 256 B per cell and RK sta
           (mw_dycore_profile class 8; N > 1 runs two streams: one third of the step instead).  roofline.dominant_kernel carries
           k_xz_state's own numbers (its algorithmic bytes: read 5 state + 5 y-tendencies (+ 5 q^n in stages 2,3), write 5 state + 2
           face mass fluxes + 2 selector bytes = 138 / 178 B per cell, 164.7 B on average), roofline.pipeline the 512 B per
-          cell-update figure.  peak 8 TB/s HBM3E spec.  traffic / valu_* come from the committed rocprofv3 PMC summary
-          (profiles/latest_summary.json, 2 x FETCH_SIZE + WRITE_SIZE calibrated with mw_calib_copy) and are reported ONLY while
-          the kernel sources still hash to what that profile was taken from (roofline.pmc_provenance); otherwise null.
-          The stage is bound by its COUNTED HBM traffic (the intermediates between its three launches make it ~2.1 x the algorithmic
-          bytes) with the fp64 instruction stream at 0.80-0.87 VALU busy right under it (roofline.binding_resource, roofline.traffic_frac,
-          roofline.fp64_valu; DESIGN.md 0b: the WENO-3 build runs half the arithmetic in 93 % of the time).
+          cell-update figure.  peak 8 TB/s HBM3E spec.  traffic / valu_* are counted LIVE at N = 1: before this process touches the GPU,
+          three child processes `rocprofv3 --pmc <counters> -- python3 bench.py --pmc-worker` run the same workload for three steps
+          (2 x FETCH_SIZE + WRITE_SIZE calibrated with mw_calib_copy; roofline.pmc_provenance.source says "live"); when rocprofv3 is
+          absent or fails the committed summary profiles/latest_summary.json is quoted instead, and only while the kernel sources still
+          hash to what it was taken from; otherwise null.
+          roofline.calibration / roofline.floors / roofline.fp64_valu.peak_measured (round 5): the ceilings MEASURED in this run -- sustained
+          v_fma_f64 issue rate and the clock it held (mw_calib_fma64), the stage's bare arithmetic on registers (mw_calib_stage_arith: the
+          time no schedule of this arithmetic can beat), the streaming copy rate -- and roofline.bound says what they imply: the stage is
+          co-limited by fp64 VALU issue and HBM traffic, and the arithmetic alone caps the algorithmic HBM fraction below the 0.60 target.
 micro   : after the timed region (the headline is untouched): Kessler (two states) and the surrogate MLP on the same grid, 72 B per
           cell each, and the dycore step on a state with cloud and rain (FCT limiter + y-face correction pass active):
           developed_ms_per_step (a seeded stress state: rims everywhere) and storm.ms_per_step / value_storm (the real storm after
-          --storm-steps steps of the complete supercell_example loop).
+          --storm-steps steps of the complete supercell_example loop).  simulation_loop / value_simulation_loop: the wall clock of that whole
+          loop -- the reference's own timed region (community_benchmark/driver.cpp:66-82), the storm developing inside it; value_storm and
+          value_simulation_loop, not the cloud-free `value`, are the regression metrics.
 cpu_baseline: the CPU oracle (a port: the reference itself is unbuildable here) timed on one host core
           on BASELINE.json configs[0] (supercell 200x200x50), rank 0, N = 1 only.
 """
@@ -69,6 +74,10 @@ def parse():
     ap.add_argument("--storm-steps", type=int, default=2600, help="steps of the complete supercell loop before the 'storm' dycore timing of the "
                     "micro section (0 = skip)")
     ap.add_argument("--no-micro", action="store_true", help="skip the Kessler / MLP / developed-state section after the timed region")
+    ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 --pmc child processes that count HBM bytes / VALU "
+                    "instructions of this very run's kernels (roofline.traffic, fp64_valu); the committed summary is quoted instead")
+    ap.add_argument("--no-calib", action="store_true", help="skip the fp64 FMA ceiling / arithmetic floor / streaming-copy calibration after the timed region")
+    ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)      # the child's mode: a few dycore steps, nothing else
     ap.add_argument("--timeout-s", type=float, default=float(os.environ.get("MW_BENCH_TIMEOUT_S", "900")),
                     help="wall-clock limit of a run: a rank that has not finished by then prints where it is and exits non-zero "
                          "(a first contact between GPUs over RCCL must fail fast, not hang the caller's lease)")
@@ -113,6 +122,124 @@ def kernel_source_hash():
     for f in KERNEL_SOURCES:
         h.update(open(os.path.join(ROOT, "miniweatherml_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+PMC_PASSES = (("f", ["FETCH_SIZE"]), ("w", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_WAVES"]))
+
+
+def pmc_worker(a):
+    """The counted child (bench.py --pmc-worker, started under rocprofv3 --pmc by pmc_children): the bench's own handle and state, one
+    warm-up step and two steps of the timed loop's step(), nothing else."""
+    import torch
+    from miniweatherml_amd import modules
+    dxy = 800.0 if a.workload == "config4" else 500.0
+    coupler, dycore, _ = modules.make_supercell(a.nx, a.ny, a.nz, a.nens, dxy * a.nx, dxy * a.ny, 20000.0, "supercell", "cuda:0", ord=a.ord)
+    dt = dycore.compute_time_step(coupler)
+    for _ in range(3):
+        dycore.time_step(coupler, dt)
+    torch.cuda.synchronize()
+
+
+def pmc_children(a):
+    """LIVE hardware counters of this run's kernels: before this process touches the GPU, three fresh child processes -- `rocprofv3 --pmc
+    <counters> -- python3 bench.py --pmc-worker` (the program directly behind `--`, counters in their own passes, no tracing: the pool's
+    rules) -- run the bench workload for three steps each; their CSVs give, per kernel and launch, HBM bytes (2 x FETCH_SIZE + WRITE_SIZE
+    in KiB: the gfx950 correction calibrated with mw_calib_copy, tools/calib_pmc.py) and VALU instructions / busy cycles.
+    -> (summary dict in the layout of profiles/*_summary.json, None) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 is not on PATH"
+    tmp = tempfile.mkdtemp(prefix="mw_bench_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("MW_BENCH_PROGRESS_DIR", None)
+    t0 = time.time()
+    try:
+        for tag, ctrs in PMC_PASSES:
+            cmd = [exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "--", sys.executable, os.path.abspath(__file__),
+                                           "--pmc-worker", "--nx", str(a.nx), "--ny", str(a.ny), "--nz", str(a.nz), "--nens", str(a.nens),
+                                           "--ord", str(a.ord), "--workload", a.workload if a.workload in ("config2", "config4") else "config2"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=max(60.0, a.timeout_s / 4))
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited with %d: %s" % (" ".join(ctrs), r.returncode, r.stderr.decode(errors="replace")[-300:])
+
+        def short(n):
+            return n.replace("void ", "").replace("mw::", "").split("(")[0]
+
+        def load(tag):
+            acc = collections.defaultdict(lambda: collections.defaultdict(list))
+            dur = collections.defaultdict(dict)
+            for f in glob.glob(os.path.join(tmp, tag, "*", "*counter_collection.csv")):
+                for row in csv.DictReader(open(f)):
+                    if "mw::" not in row["Kernel_Name"]:
+                        continue
+                    k = short(row["Kernel_Name"])
+                    acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                    try:
+                        dur[k][row["Dispatch_Id"]] = (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-3
+                    except (KeyError, ValueError):
+                        pass
+            return ({k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()},
+                    {k: len(next(iter(cs.values()))) for k, cs in acc.items()}, {k: (sum(d.values()) / len(d)) for k, d in dur.items() if d})
+        (F, nF, _), (W, _, _), (SQ, _, usSQ) = load("f"), load("w"), load("sq")
+        if not F or not W or not SQ:
+            return None, "the rocprofv3 passes produced no rows for the library's kernels"
+        cells = float(a.nx * a.ny * a.nz * a.nens)
+        kernels = {}
+        for k in F:
+            e = {"calls": nF[k]}
+            if k in W:
+                e["hbm_read_bytes"] = 2.0 * F[k]["FETCH_SIZE"] * 1024
+                e["hbm_write_bytes"] = W[k]["WRITE_SIZE"] * 1024
+            m = SQ.get(k, {})
+            if "SQ_INSTS_VALU" in m:
+                e["valu_instr_per_cell"] = m["SQ_INSTS_VALU"] * 64 / cells
+                if m.get("GRBM_GUI_ACTIVE"):
+                    cyc = m["GRBM_GUI_ACTIVE"] / 8
+                    e["valu_busy_frac"] = m["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc
+                    if k in usSQ and usSQ[k] > 0:
+                        e["avg_us"] = usSQ[k]                   # (duration under the SQ pass: the counters' own run)
+                        e["clock_GHz_under_profile"] = cyc / (usSQ[k] * 1e-6) / 1e9
+            kernels[k] = e
+        return {"tag": "live", "cells_per_launch": cells, "kernel_sources_sha16": kernel_source_hash(), "kernels": kernels,
+                "seconds": time.time() - t0, "note": "FETCH_SIZE x2 (gfx950: 8 B/lane streaming reads report exactly 1/2, calibrated with "
+                "mw_calib_copy), WRITE_SIZE x1; KiB -> bytes; three rocprofv3 --pmc child processes of this bench run"}, None
+    except Exception as e:                                       # a profiler problem must never cost the measurement
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def calibration(torch, device, stage_cells):
+    """The measured ceilings this run's fractions are quoted against (mw_calib_*; SURVEY.md 8(d) "calibrate with an FMA microbenchmark"):
+    sustained v_fma_f64 issue at 2 and 8 wavefronts per SIMD and the clock it held, the stage's bare arithmetic (24 WENO-5 + 3 Riemann
+    per cell on registers) for one stage of this block on smooth and on rough data, and the streaming copy rate (8 B per lane)."""
+    import ctypes as C
+    from miniweatherml_amd import calib, capi
+    out = {"fma64": [calib.fma64(w, 0.4, device) for w in (2, 8)],
+           "stage_arith": {k: calib.stage_arith(k, stage_cells, 25, device) for k in ("smooth", "rough")}}
+    n = 1 << 27                                                  # 1 GiB each way
+    src = torch.ones(n, dtype=torch.float64, device=device)
+    dst = torch.empty_like(src)
+    L = capi.lib()
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    for _ in range(2):
+        capi.check(L.mw_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n, st))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        capi.check(L.mw_calib_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), n, st))
+    e1.record()
+    torch.cuda.synchronize()
+    out["stream_copy_TBps"] = 5 * 16.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    del src, dst
+    torch.cuda.empty_cache()
+    return out
 
 
 def micro_section(torch, modules, coupler, dycore, micro, dt, a):
@@ -162,7 +289,7 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
         ms = timed(kessler_once) - timed(restore)
         res["kessler"]["states"][name] = {"state": desc, "ms_per_call": ms, "cells_per_s": ncell / ms * 1e3,
                                           "achieved_GBps": ncell * 72 / ms / 1e6, "frac": ncell * 72 / ms / 1e6 / 8000.0}
-    res["kessler"]["kernels"] = "k_kessler_prep + k_kessler_chunks (+ k_kessler_column when rainsplit > 1)"
+    res["kessler"]["kernels"] = "k_kessler_prep + k_kessler_sweep (z chunks when rainsplit == 1, whole columns otherwise): two launches per call"
     restore()
     W1, b1, W2, b2, si, so = modules.load_surrogate_weights()
     ins = [dm.get(n) for n in ("temp", "density_dry", "water_vapor", "cloud_liquid", "precip_liquid")]
@@ -201,8 +328,23 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
         xlen, ylen = float(coupler.get_xlen()), float(coupler.get_ylen())
         c2, d2, m2, n2 = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000.0, "supercell", rho_d.device, with_nudger=True, ord=a.ord)
         dt2 = d2.compute_time_step(c2)
-        for _ in range(a.storm_steps):
+        # the REFERENCE'S OWN timed region (experiments/community_benchmark/driver.cpp:66-82: the whole `while (etime < sim_time)` loop,
+        # init excluded, out_freq = -1, CFL dt): wall clock around all a.storm_steps iterations of dycore + Kessler + sponge + nudger,
+        # the storm developing inside it
+        for _ in range(3):
             modules.supercell_step(c2, d2, m2, n2, dt2)
+        torch.cuda.synchronize()
+        t_loop = time.perf_counter()
+        for _ in range(a.storm_steps - 3):
+            modules.supercell_step(c2, d2, m2, n2, dt2)
+        torch.cuda.synchronize()
+        loop_s = time.perf_counter() - t_loop
+        res["simulation_loop"] = {"what": "wall clock of the whole simulation loop the reference's benchmark driver times (community_benchmark/"
+                                          "driver.cpp:66-82): %d iterations of dycore.time_step + micro.time_step + sponge_layer + "
+                                          "nudge_to_column from the initial state, the storm developing inside it" % (a.storm_steps - 3),
+                                  "steps": a.storm_steps - 3, "seconds": loop_s, "ms_per_step": loop_s / (a.storm_steps - 3) * 1e3,
+                                  "simulated_seconds": dt2 * (a.storm_steps - 3), "cell_updates_per_s": ncell * (a.storm_steps - 3) / loop_s}
+        res["value_simulation_loop"] = ncell * (a.storm_steps - 3) / loop_s
         storm_ms = timed(lambda: d2.time_step(c2, dt2), 10)
         f2 = c2.get_data_manager_readonly()
         res["storm"] = {"state": "after %d steps of the complete supercell_example loop from the initial state" % a.storm_steps,
@@ -260,6 +402,9 @@ def main():
     a = parse()
     if a.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
+    if a.pmc_worker:
+        pmc_worker(a)
+        return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a)                                           # does not return
     import threading
@@ -291,6 +436,12 @@ def main():
     wd = threading.Timer(a.timeout_s, watchdog)
     wd.daemon = True
     wd.start()
+    # live counters first: fresh child processes under rocprofv3 --pmc, BEFORE this process imports torch or touches the GPU
+    live_pmc, live_pmc_why = None, "not attempted"
+    if a.gpus == 1 and "WORLD_SIZE" not in os.environ and not a.no_pmc and not a.strict and not a.full_loop and a.workload in ("config2", "config4"):
+        progress("rocprofv3 --pmc child processes (live counters of this run's kernels) ...")
+        live_pmc, live_pmc_why = pmc_children(a)
+        progress("live counters: %s" % ("ok" if live_pmc else live_pmc_why))
     import torch
     import torch.distributed as dist
     if world != a.gpus:                                          # a launcher started a different number of ranks than asked for
@@ -411,6 +562,24 @@ def main():
     # sanity: the run must still be physical -- a blown-up run would be an invalid measurement.  DataManager::validate_all
     # (DataManager.h:385-387, one device pass per entry here): NaN / inf in any field, negative values in the positive-definite tracers
     coupler.get_data_manager_readonly().validate_all(die_on_failed_check=True)
+    # ... and bounded: a run that blew up but stayed finite is not a measurement either (the supercell's updraft reaches 20-50 m/s, the
+    # city's flow 20 m/s; the reference has no such check -- its validators only look for NaN / inf / negative values)
+    w_max = float(coupler.get_data_manager_readonly().get("wvel", True).abs().max())
+    assert w_max < 100.0, "max|w| = %g m/s after the timed region: the run is not physical, the measurement is invalid" % w_max
+    # the timed region is over: from here on a slow host section (micro, CPU baseline) must not cost the finished measurement -- the
+    # watchdog is re-armed and, should it fire, prints the headline line that is complete by then and exits 0
+    wd.cancel()
+    pending = [None]
+
+    def watchdog_late():
+        if pending[0] is not None:
+            pending[0]["note"] = "the optional sections after the timed region did not finish within %.0f s (last: %s); headline complete" % (a.timeout_s, where[0])
+            print(json.dumps(pending[0]), flush=True)
+            os._exit(0)
+        watchdog()
+    wd = threading.Timer(a.timeout_s, watchdog_late)
+    wd.daemon = True
+    wd.start()
     if world > 1:                                                # every rank's library path / communicator view, gathered for the JSON line
         infos = [None] * world
         dist.all_gather_object(infos, rccl)
@@ -440,15 +609,21 @@ def main():
         # ---- counters from the committed rocprofv3 summary: only while the kernel sources are the profiled ones
         traffic, dom_traffic, valu_busy, valu_instr, prov, valu_side, derived = None, None, None, None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "latest_summary.json")
-        if os.path.exists(pmc) and not a.strict:
+        if (live_pmc is not None or os.path.exists(pmc)) and not a.strict:
             try:
-                pj = json.load(open(pmc))
                 now = kernel_source_hash()
-                prov = {"file": "profiles/latest_summary.json", "tag": pj.get("tag"), "profiled_sources_sha16": pj.get("kernel_sources_sha16"),
-                        "current_sources_sha16": now, "valid": bool(pj.get("kernel_sources_sha16") == now and
-                                                                    int(pj.get("cells_per_launch", 0)) == ncells_local)}
-                if a.ord != 5:
-                    prov["valid"] = False                      # the committed counters are the WENO-5 kernels'
+                if live_pmc is not None:                       # counted on THIS box by this run's own child processes
+                    pj = live_pmc
+                    prov = {"file": None, "source": "live: rocprofv3 --pmc child processes of this bench run (%.0f s)" % pj["seconds"], "tag": "live",
+                            "profiled_sources_sha16": now, "current_sources_sha16": now, "valid": int(pj["cells_per_launch"]) == ncells_local}
+                else:
+                    pj = json.load(open(pmc))
+                    prov = {"file": "profiles/latest_summary.json", "source": "replayed from the committed summary (live counters: %s)" % live_pmc_why,
+                            "tag": pj.get("tag"), "profiled_sources_sha16": pj.get("kernel_sources_sha16"),
+                            "current_sources_sha16": now, "valid": bool(pj.get("kernel_sources_sha16") == now and
+                                                                        int(pj.get("cells_per_launch", 0)) == ncells_local)}
+                    if a.ord != 5:
+                        prov["valid"] = False                  # the committed counters are the WENO-5 kernels'
                 if prov["valid"]:
                     K = pj["kernels"]
                     ks = [v for k, v in K.items() if k.startswith("k_xz_state")]
@@ -469,9 +644,37 @@ def main():
                     instr_cu = sum(k["valu_instr_per_cell"] * k["calls"] for k in stage_k if "valu_instr_per_cell" in k) / nstages * 3.0
                     valu_side = {"instr_per_cell_update": instr_cu, "achieved_wave_instr_per_s": per_gpu * instr_cu / 64.0,
                                  "peak_wave_instr_per_s": 1024 * 2.4e9 / 4.0, "frac": per_gpu * instr_cu / 64.0 / (1024 * 2.4e9 / 4.0),
-                                 "source": "SQ_INSTS_VALU of profiles/latest_summary.json x live cell-updates/s"}
+                                 "source": "SQ_INSTS_VALU of %s x live cell-updates/s" % (prov["file"] or "this run's rocprofv3 --pmc children")}
             except Exception:
                 traffic = dom_traffic = valu_side = derived = None
+        # ---- measured ceilings (mw_calib_*): the fp64 issue rate this chip sustains, the stage's bare arithmetic, the streaming copy rate
+        cal, floors, bound = None, None, "hbm"
+        if world == 1 and not a.no_calib and not a.strict:
+            try:
+                cal = calibration(torch, device, ncells_local)
+                peak_meas = max(c["wave_instr_per_s"] for c in cal["fma64"])
+                fl_s, fl_r = cal["stage_arith"]["smooth"]["ms_per_stage_of_requested_cells"], cal["stage_arith"]["rough"]["ms_per_stage_of_requested_cells"]
+                hbm_floor = (traffic / (cal["stream_copy_TBps"] * 1e12) * 1e3) if traffic else None
+                alg_floor = stage_bytes / (cal["stream_copy_TBps"] * 1e12) * 1e3
+                top = max(fl_s, hbm_floor or 0.0)
+                floors = {"arith_floor_ms_per_stage": fl_s, "arith_floor_ms_per_stage_rough_data": fl_r,
+                          "hbm_floor_ms_per_stage_counted_traffic": hbm_floor, "hbm_floor_ms_per_stage_algorithmic_bytes": alg_floor,
+                          "stream_copy_TBps": cal["stream_copy_TBps"], "stage_ms": stage_ms, "stage_over_arith_floor": stage_ms / fl_s,
+                          "stage_over_max_floor": stage_ms / top,
+                          "frac_ceiling_if_arith_bound": stage_bytes / (fl_s * 1e-3) / 8.0e12,
+                          "what": "arith floor = mw_calib_stage_arith: 24 WENO-5 + 3 Riemann solves + passive fluxes per cell on registers, no HBM "
+                                  "traffic, k_xz_state's workgroup shape; hbm floor = bytes / the measured streaming copy rate"}
+                if valu_side:
+                    valu_side["peak_measured"] = peak_meas
+                    valu_side["frac_of_measured"] = valu_side["achieved_wave_instr_per_s"] / peak_meas
+                    valu_side["clock_GHz_under_fma_load"] = [c["clock_GHz_in_kernel"] for c in cal["fma64"]]
+                # what the numbers say: the stage cannot beat its bare arithmetic, which alone caps the algorithmic HBM fraction
+                cap = floors["frac_ceiling_if_arith_bound"]
+                bound = ("fp64-valu + hbm co-limited: the stage's bare arithmetic alone takes %.2f ms (frac <= %.2f at any schedule), its counted "
+                         "traffic at streaming speed %s; 0.60 of 8 TB/s is out of reach in fp64 with the reference's limiter"
+                         % (fl_s, cap, ("%.2f ms" % hbm_floor) if hbm_floor else "n/a"))
+            except Exception as e:                               # calibration is evidence, not the measurement
+                cal = {"error": "%s: %s" % (type(e).__name__, e)}
         what = "complete supercell_example loop: WENO-FV dycore + Kessler + sponge_layer + ColumnNudger" if a.full_loop else "WENO-FV dycore only"
         if a.workload == "config3":
             what = "complete supercell_kessler_surrogate loop: WENO-FV dycore + ponni MLP inference (MFMA) beside Kessler + sponge_layer + ColumnNudger"
@@ -500,7 +703,8 @@ def main():
             # instruction stream at 0.80-0.87 VALU busy right under it (the WENO-3 build, half the arithmetic, takes 93 % of the time).
             # achieved / peak / frac are SURVEY.md 8(d)'s algorithmic figure (32 V B per cell against 8 TB/s: what the north star's 60 %
             # target is quoted in); traffic / traffic_frac the counted bytes; roofline.fp64_valu the instruction side.
-            "roofline": {"bound": "hbm",
+            "roofline": {"bound": bound,
+                         "floors": floors,
                          "binding_resource": ("HBM traffic of the stage's three launches (counted bytes: roofline.traffic = %.2f x algorithmic; "
                                               "%.2f-%.2f TB/s per kernel in the profiled run, a streaming copy reaches 5.0-5.5 on this part) with "
                                               "fp64 VALU issue co-limiting at %.2f-%.2f busy; numbers from roofline.pmc_provenance.file"
@@ -524,18 +728,24 @@ def main():
                                              "avg_launch_ms_exclusive": (prof_excl["xz_state"][0] / max(1, prof_excl["xz_state"][1])) if prof_excl else None,
                                              "valu_busy_frac": valu_busy, "valu_instr_per_cell": valu_instr},
                          "fp64_valu": valu_side,
+                         "calibration": cal,
                          "pipeline": {"alg_bytes_per_cell_update": 64 * V, "achieved": per_gpu * 64 * V / 1e9, "frac": per_gpu * 64 * V / 8.0e12}},
             "kernel_ms_per_step": {k: v[0] / 3.0 for k, v in prof.items()},
             "kernel_ms_per_step_exclusive": ({k: v[0] / 3.0 for k, v in prof_excl.items()} if prof_excl else None),
         }
+        pending[0] = out
         if world == 1 and not a.no_micro and not a.strict and city is None:
+            progress("micro section (Kessler, MLP, developed state, the whole simulation loop) ...")
             out.update(micro_section(torch, modules, coupler, dycore, micro, dt, a))
+            out["config"]["value_simulation_loop"] = out.get("value_simulation_loop")
             # the headline state is the benign one (cloud-free initial field): the same step on a developed storm, next to `value`
             out["config"]["value_storm"] = out.get("value_storm")
             out["config"]["value_developed"] = out.get("value_developed")
         if world == 1 and not a.no_cpu_baseline:
+            progress("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
-        print(json.dumps(out))
+        pending[0] = None
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

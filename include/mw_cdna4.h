@@ -102,7 +102,7 @@ int  mw_dycore_set_strict(mw_dycore_t h, int strict);
  * decomposed block), "pipe_edge_inline", "pipe_convert".  Kernel forms: "spec" (folded configurations), "wrap" (index wrap on one
  * rank), "y_all", "y_all_conv", "member_major", "mm_direct", "mm_conv", "fused_convert", "fused_convert_mm", "fused_tracers", "tf_rows4".
  * Launch shapes: "chunk_y", "chunk_yt", "chunk_z", "chunk_f" (cells per chunk, 0 = the chunk model), "chunk_model".  Built-in transport
- * (read when mw_dycore_use_rccl / _self installs it): "rccl_lanes" (0 = process default | 1 | 2), "rccl_two_comms" (-1 | 0 | 1),
+ * (read when mw_dycore_use_rccl / _self installs it): "rccl_lanes" (0 = process default | 1 | 2), "rccl_two_comms" (-1 | 0 | 1), "rccl_prio" (1: side streams at the highest priority),
  * "xchg_fuzz" (seed of random delays around the sends / receives; a test aid).  Experiments that are not part of the release build:
  * "fused_state", "debug_no_patch" (-DMW_EXPERIMENTS), "sched", "sched_mask" (-DMW_SCHED_LISTS) -- setting them on a build without
  * them is an error.  Unknown keys and out-of-range values are errors. */
@@ -140,6 +140,12 @@ double mw_dycore_get_etime(mw_dycore_t h);   /* member etime, :55 */
 /* Which schedule the last mw_dycore_time_step chose: 0 one stream, 1 two streams (state | tracer pipelines), 2 pipelined one-stream
  * schedule of a decomposed block; + 4: y faces of all variables in one launch (k_y_all); + 8: general (flux-materialising) kernels. */
 int  mw_dycore_schedule(mw_dycore_t h);
+/* The same decision spelled out (valid until the handle's next call): "march | general-strict | general-fast", the WENO order, and on the
+ * marching kernels the folded configuration (K0 | K1 | K2), the internal layout (nens1 | fused_members | member_major | mm_direct), the
+ * schedule (one_stream | two_stream | pipe), y_all | y_split, where D1 happened (conv_in_y | conv_pipe | conv_pass), tracers_fused |
+ * tracers_unfused, 2d | 3d, "transport" with a halo exchange installed.  The tests log it with every parity comparison and assert at
+ * session end that every combination the dispatcher can produce was compared (tests/conftest.py). */
+const char *mw_dycore_path(mw_dycore_t h);
 int  mw_dycore_profile(mw_dycore_t h, int enable);
 int  mw_dycore_profile_get(mw_dycore_t h, int which, double *total_ms, long long *launches);
 
@@ -172,6 +178,10 @@ long long mw_calib_stage_arith_threads(long long cells, int levels);
 int  mw_calib_stage_arith(const double *tab, int nlev, long long cells, int levels, const double *bg4, double *sink, double *out3, void *stream);
 /* Test aid: occupies `stream` for about `usec` microseconds (delay fuzz of the exchange tests). */
 int  mw_debug_spin(long long usec, void *stream);
+/* Test aid: the names (as the code object spells them -- mangled; newline-separated) of the dycore kernels this PROCESS has launched since
+ * the last reset; every instantiation of the dispatcher's kernel templates has its own.  Returns the bytes needed (terminator included)
+ * and writes at most `cap`; reset != 0 clears the registry.  (tests/conftest.py: instantiation coverage of the parity comparisons.) */
+long long mw_debug_launched_kernels(char *buf, long long cap, int reset);
 
 /* modules::perturb_temperature(coupler, thermal=true, random=false), perturb_temperature.h:41-66 */
 int  mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream);

@@ -20,12 +20,24 @@
 #include "mw_glibc_pow.h"
 #include <vector>
 #include <map>
+#include <set>
 #include <tuple>
 #include <mutex>
 #include <cmath>
 #include <cstring>
 #include <random>
 #include <algorithm>
+
+// Every kernel launch of this file goes through MW_KLAUNCH: besides launching it notes the kernel's host function in a process-wide
+// registry, so that a test session can ask which INSTANTIATIONS of the dispatcher's kernels its oracle comparisons really exercised
+// (mw_debug_launched_kernels; tests/conftest.py checks them against the list of everything compiled into this object).  Host-side only:
+// one uncontended mutex and a set insert per launch, nothing in the kernels.
+namespace mw {
+static std::mutex g_launch_mu;
+static std::set<const void *> g_launched;
+static inline void note_launch(const void *fn) { std::lock_guard<std::mutex> lk(g_launch_mu); g_launched.insert(fn); }
+}
+#define MW_KLAUNCH(kern, ...) do { mw::note_launch((const void *)&kern); hipLaunchKernelGGL(kern, __VA_ARGS__); } while (0)
 
 namespace mw {
 
@@ -289,9 +301,6 @@ __device__ __forceinline__ void halo_z_body(const DyP &p, double *__restrict__ S
   col[(long long)kh * p.sK] = val;
 }
 
-__global__ __launch_bounds__(256) void k_halo_x(DyP p, double *__restrict__ S) { halo_x_body(p, S, (long long)blockIdx.x * 256 + threadIdx.x); }
-__global__ __launch_bounds__(256) void k_halo_y(DyP p, double *__restrict__ S) { halo_y_body(p, S, (long long)blockIdx.x * 256 + threadIdx.x); }
-__global__ __launch_bounds__(256) void k_halo_z(DyP p, double *__restrict__ S) { halo_z_body(p, S, (long long)blockIdx.x * 256 + threadIdx.x); }
 // All three regions in one launch (they are independent: each writes its own halo cells from interior cells, and the corners
 // are never read): blocks [0, nbx) do x, [nbx, nbx+nby) do y, the rest z.  Used when no direction needs a neighbour exchange.
 __global__ __launch_bounds__(256) void k_halo_xyz(DyP p, double *__restrict__ S, unsigned nbx, unsigned nby) {
@@ -632,33 +641,6 @@ __global__ __launch_bounds__(256) void k_update(DyP p, const double *Sstar, cons
   }
 }
 
-// stored slab -> coupler fields (used when ncycles == 0 cannot happen; used by init + tests): D13 on a slab
-__global__ __launch_bounds__(256) void k_state_to_coupler(DyP p, const double *__restrict__ S, CouplerPtrs c) {
-#pragma clang fp contract(off)
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  int k = blockIdx.y;
-  int NXI = p.nx * p.nens;
-  if (t >= (long long)p.ny * NXI) return;
-  int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
-  int e = ie % p.nens;
-  long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
-  long long ci = ((long long)k * p.ny + j) * NXI + ie;
-  double hyc = p.hyc[k * p.nens + e], hytc = p.hytc[k * p.nens + e];
-  double rho = S[so + idR * p.sV] + hyc;
-  double u = (S[so + idU * p.sV] * rho) / rho, v = (S[so + idV * p.sV] * rho) / rho, w = (S[so + idW * p.sV] * rho) / rho;
-  double theta = (S[so + idT * p.sV] + hytc) / rho;
-  double press = p.C0 * pow_ref(rho * theta, p.gamma);
-  double rho_d = rho, rho_v = 0;
-  for (int tr = 0; tr < p.nt; tr++) {
-    double q = S[so + (5 + tr) * p.sV] * rho;
-    c.tr[tr][ci] = q;
-    if (tr == p.idWV) rho_v = q;
-    if ((p.mass_mask >> tr) & 1u) rho_d -= q;
-  }
-  c.rho_d[ci] = rho_d; c.u[ci] = u; c.v[ci] = v; c.w[ci] = w;
-  c.temp[ci] = press / (rho_d * p.R_d + rho_v * p.R_v);
-}
-
 } // namespace mw
 #include "mw_march.h"
 #ifdef MW_EXPERIMENTS
@@ -923,6 +905,7 @@ struct DyOpts {
   int tf_rows4 = 1;            // tracer stage: workgroup = 4 rows of one x tile (0: 4 tiles of one row)
   int rccl_lanes = 0, rccl_two_comms = -1;            // built-in RCCL transport: side streams (1 | 2), a communicator per lane (0 | 1); 0 / -1 = the
                                                       // process default (MW_RCCL_LANES); read when mw_dycore_use_rccl* installs the transport
+  int rccl_prio = 1;           // ... its side streams at the highest stream priority (0: default priority; A/B)
   int xchg_fuzz = 0;           // test aid: seeded random delays (spin kernels) around the built-in transport's sends / receives
   int fused_state = 0, debug_no_patch = 0;            // -DMW_EXPERIMENTS builds only (mw_fused.h; the negative control of the FCT patch pass)
   int sched = 0, sched_mask = 7;                      // -DMW_SCHED_LISTS builds only (balanced launch lists)
@@ -943,6 +926,7 @@ struct mw_dycore_s {
   int overlap = 1;
   int pre_lo = 0, pre_hi = 0;                // pipelined schedule: rows outside [pre_lo, pre_hi) (and the W / E strip columns) were converted up front
   int last_march = 0;                        // the last time_step ran on the marching kernels (mw_dycore_schedule)
+  std::string path;                          // what the dispatcher chose for the last time_step, spelled out (mw_dycore_path)
   int pipe = 0;                              // blocks of a decomposed domain: pipelined one-stream schedule (rk_stage_pipe)
   bool pipe_ready = false;                   // ... the next stage's input strips are already on their way (event ev_pipe[2])
   bool pipe_edge_done = false;               // ... and its two edge strips of the y launch were issued behind them on the exchange stream
@@ -1143,8 +1127,8 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
     // Directions with a single rank still wrap locally below.
     for (int e = 0; e < nv_views; e++) {
       DyP q; double *S; member(e, q, S);
-      if (ex_x) { hipLaunchKernelGGL(k_pack_x, dim3((unsigned)((mWE + 255) / 256)), dim3(256), 0, st, q, S, bf[0] + e * mWE, bf[1] + e * mWE); MW_LAUNCH_CHECK(); }
-      if (ex_y) { hipLaunchKernelGGL(k_pack_y, dim3((unsigned)((mSN + 255) / 256)), dim3(256), 0, st, q, S, bf[2] + e * mSN, bf[3] + e * mSN); MW_LAUNCH_CHECK(); }
+      if (ex_x) { MW_KLAUNCH(k_pack_x, dim3((unsigned)((mWE + 255) / 256)), dim3(256), 0, st, q, S, bf[0] + e * mWE, bf[1] + e * mWE); MW_LAUNCH_CHECK(); }
+      if (ex_y) { MW_KLAUNCH(k_pack_y, dim3((unsigned)((mSN + 255) / 256)), dim3(256), 0, st, q, S, bf[2] + e * mSN, bf[3] + e * mSN); MW_LAUNCH_CHECK(); }
     }
     int rc = d->xchg(d->xchg_ctx, ex_x ? bf[0] : nullptr, ex_x ? bf[1] : nullptr, ex_y ? bf[2] : nullptr, ex_y ? bf[3] : nullptr,
                      ex_x ? bf[4] : nullptr, ex_x ? bf[5] : nullptr, ex_y ? bf[6] : nullptr, ex_y ? bf[7] : nullptr, ex_x ? nWE : 0,
@@ -1152,8 +1136,8 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
     if (rc) MW_FAIL("halo exchange callback failed");
     for (int e = 0; e < nv_views; e++) {
       DyP q; double *S; member(e, q, S);
-      if (ex_x) { hipLaunchKernelGGL(k_unpack_x, dim3((unsigned)((mWE + 255) / 256)), dim3(256), 0, st, q, S, bf[4] + e * mWE, bf[5] + e * mWE); MW_LAUNCH_CHECK(); }
-      if (ex_y) { hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((mSN + 255) / 256)), dim3(256), 0, st, q, S, bf[6] + e * mSN, bf[7] + e * mSN); MW_LAUNCH_CHECK(); }
+      if (ex_x) { MW_KLAUNCH(k_unpack_x, dim3((unsigned)((mWE + 255) / 256)), dim3(256), 0, st, q, S, bf[4] + e * mWE, bf[5] + e * mWE); MW_LAUNCH_CHECK(); }
+      if (ex_y) { MW_KLAUNCH(k_unpack_y, dim3((unsigned)((mSN + 255) / 256)), dim3(256), 0, st, q, S, bf[6] + e * mSN, bf[7] + e * mSN); MW_LAUNCH_CHECK(); }
     }
   }
   // local wrap / BC:  x when this direction has one rank (periodic self-wrap), or a wall / open boundary on a domain-edge rank.
@@ -1171,7 +1155,7 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
     const unsigned nbx = ((ex_x && !bcx_after) || (skip_z && p.wrap_x)) ? 0u : (unsigned)((nx_ + 255) / 256);      // skip_z = production path
     const unsigned nby = ((ex_y && !bcy_after) || p.sim2d || (skip_z && p.wrap_y)) ? 0u : (unsigned)((ny_ + 255) / 256);
     const unsigned nbz = skip_z ? 0u : (unsigned)((nz_ + 255) / 256);      // (the marching kernels apply the z rule while loading)
-    if (nbx + nby + nbz) { hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + nbz), dim3(256), 0, st, p, S, nbx, nby); MW_LAUNCH_CHECK(); }
+    if (nbx + nby + nbz) { MW_KLAUNCH(k_halo_xyz, dim3(nbx + nby + nbz), dim3(256), 0, st, p, S, nbx, nby); MW_LAUNCH_CHECK(); }
   }
   return 0;
 }
@@ -1182,17 +1166,17 @@ static int launch_flux(mw_dycore_s *d, const double *S) {
   long long per_plane = (long long)(p.sim2d ? p.ny : p.ny + 1) * (p.nx + 1) * p.nens;
   dim3 grid = plane_grid(per_plane, p.nz + 1);
   if (d->ord == 3) {
-    if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 3>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
-    else                hipLaunchKernelGGL((k_flux<false, 3>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    if (d->strict == 1) MW_KLAUNCH((k_flux<true, 3>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    else                MW_KLAUNCH((k_flux<false, 3>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
   } else if (d->ord == 7) {
-    if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 7>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
-    else                hipLaunchKernelGGL((k_flux<false, 7>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    if (d->strict == 1) MW_KLAUNCH((k_flux<true, 7>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    else                MW_KLAUNCH((k_flux<false, 7>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
   } else if (d->ord == 9) {
-    if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 9>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
-    else                hipLaunchKernelGGL((k_flux<false, 9>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    if (d->strict == 1) MW_KLAUNCH((k_flux<true, 9>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    else                MW_KLAUNCH((k_flux<false, 9>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
   } else {
-    if (d->strict == 1) hipLaunchKernelGGL((k_flux<true, 5>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
-    else                hipLaunchKernelGGL((k_flux<false, 5>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    if (d->strict == 1) MW_KLAUNCH((k_flux<true, 5>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
+    else                MW_KLAUNCH((k_flux<false, 5>), grid, dim3(256), 0, d->stream, p, S, d->FX, d->FY, d->FZ);
   }
   MW_LAUNCH_CHECK();
   return 0;
@@ -1204,8 +1188,8 @@ static int launch_fct(mw_dycore_s *d, const double *S, double dt, hipStream_t st
   if (p.nt == 0 || p.pos_mask == 0) return 0;
   ProfScope ps(d, 1, st);
   dim3 grid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz, p.nt);
-  if (d->strict == 1) hipLaunchKernelGGL(k_fct<false>, grid, dim3(256), 0, st, p, S, d->FX, d->FY, d->FZ, dt);
-  else                hipLaunchKernelGGL(k_fct<true>, grid, dim3(256), 0, st, p, S, d->FX, d->FY, d->FZ, dt);
+  if (d->strict == 1) MW_KLAUNCH(k_fct<false>, grid, dim3(256), 0, st, p, S, d->FX, d->FY, d->FZ, dt);
+  else                MW_KLAUNCH(k_fct<true>, grid, dim3(256), 0, st, p, S, d->FX, d->FY, d->FZ, dt);
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -1216,7 +1200,7 @@ static int launch_update(mw_dycore_s *d, const double *Sstar, const double *Sn, 
   ProfScope ps(d, 2);
   const DyP &p = d->p;
   dim3 grid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
-  hipLaunchKernelGGL((k_update<STAGE, MODE>), grid, dim3(256), 0, d->stream, p, Sstar, Sn, Sout, d->FX, d->FY, d->FZ, dt_stage,
+  MW_KLAUNCH((k_update<STAGE, MODE>), grid, dim3(256), 0, d->stream, p, Sstar, Sn, Sout, d->FX, d->FY, d->FZ, dt_stage,
                      dt_dyn, c, st, tt);
   MW_LAUNCH_CHECK();
   return 0;
@@ -1370,14 +1354,14 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     if (d->mm_direct && d->o.mm_conv) {      // the members of the same cells in one workgroup (k_y_state<.., MM = 2>)
       grid.x = (unsigned)((mthreads + 64 * (4 / mo.n) - 1) / (64 * (4 / mo.n)));
 #define MW_YSM2(K_) { if (d->ord == 3) MW_YSM2O(K_, 3); else MW_YSM2O(K_, 5); }
-#define MW_YSM2O(K_, O_) hipLaunchKernelGGL((k_y_state<true, K_, O_, 2>), grid, dim3(256), 0, d->stream, v0.p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
+#define MW_YSM2O(K_, O_) MW_KLAUNCH((k_y_state<true, K_, O_, 2>), grid, dim3(256), 0, d->stream, v0.p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
       if (K == 1) MW_YSM2(1) else if (K == 2) MW_YSM2(2) else MW_YSM2(0)
 #undef MW_YSM2
 #undef MW_YSM2O
       MW_LAUNCH_CHECK();
       return 0;
     }
-#define MW_YSM(K_, O_) hipLaunchKernelGGL((k_y_state<true, K_, O_, 1>), grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
+#define MW_YSM(K_, O_) MW_KLAUNCH((k_y_state<true, K_, O_, 1>), grid, dim3(256), 0, d->stream, p, S, d->M[par][1], d->UP[par][1], d->tendY, chunk, *conv, Sw, mm)
     if (d->ord == 3) { if (K == 1) MW_YSM(1, 3); else if (K == 2) MW_YSM(2, 3); else MW_YSM(0, 3); }
     else             { if (K == 1) MW_YSM(1, 5); else if (K == 2) MW_YSM(2, 5); else MW_YSM(0, 5); }
 #undef MW_YSM
@@ -1392,7 +1376,7 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(d, p.ny, (threads + 63) / 64, d->o.chunk_y, 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     double *MY = d->M[par][1] + e * v.m[1]; unsigned char *UY = d->UP[par][1] + e * v.m[1];
-#define MW_YS(CONV_, K_, O_, cp, sw) hipLaunchKernelGGL((k_y_state<CONV_, K_, O_>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw, YMember())
+#define MW_YS(CONV_, K_, O_, cp, sw) MW_KLAUNCH((k_y_state<CONV_, K_, O_>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw, YMember())
 #define MW_YS_K(K_) { if (d->ord == 3) { if (conv) MW_YS(true, K_, 3, *conv, Sw); else MW_YS(false, K_, 3, CouplerPtrs(), nullptr); } \
                       else             { if (conv) MW_YS(true, K_, 5, *conv, Sw); else MW_YS(false, K_, 5, CouplerPtrs(), nullptr); } }
     double *Sw = const_cast<double *>(v.S(S));
@@ -1431,7 +1415,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
       const int n = (int)grid.y;
       row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk);
     }
-#define MW_YAM(K_, O_, T_) hipLaunchKernelGGL((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, st, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, nullptr, pre_lo, pre_hi)
+#define MW_YAM(K_, O_, T_) MW_KLAUNCH((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, st, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, nullptr, pre_lo, pre_hi)
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
     if (marching_config(d, p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
@@ -1461,7 +1445,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     // (part 0 / 1 = one contiguous row range [row0, row_end): the balanced schedule applies; the two edge strips of part 2 stay chunks)
 #define MW_YA(C_, K_, O_, T_) do { dim3 g_ = grid; const Sched *sc_ = (part == 2) ? nullptr : \
                                   pick_sched(d, (const void *)&k_y_all<C_, K_, O_, T_>, 0, (long long)grid.x, row_end - row0, g_, 0); \
-                                hipLaunchKernelGGL((k_y_all<C_, K_, O_, T_>), g_, dim3(256), 0, st, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
+                                MW_KLAUNCH((k_y_all<C_, K_, O_, T_>), g_, dim3(256), 0, st, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
                                                  conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_, pre_lo, pre_hi); } while (0)
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
@@ -1491,8 +1475,8 @@ static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_
     for (int t0 = 0; t0 < p.nt; t0 += 4) {
       int cnt = std::min(4, p.nt - t0);
       const double *M = d->M[par][1] + e * v.m[1]; const unsigned char *U = d->UP[par][1] + e * v.m[1];
-#define MW_YT(T_) { if (d->ord == 3) hipLaunchKernelGGL((k_y_tracers<T_, 3>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); \
-                    else             hipLaunchKernelGGL((k_y_tracers<T_, 5>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); }
+#define MW_YT(T_) { if (d->ord == 3) MW_KLAUNCH((k_y_tracers<T_, 3>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); \
+                    else             MW_KLAUNCH((k_y_tracers<T_, 5>), grid, dim3(256), 0, st, p, v.S(S), FY, M, U, chunk, t0); }
       switch (cnt) { case 1: MW_YT(1) break; case 2: MW_YT(2) break; case 3: MW_YT(3) break; default: MW_YT(4) break; }
 #undef MW_YT
       MW_LAUNCH_CHECK();
@@ -1537,7 +1521,7 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
         if (chunk > cap) { chunk = cap; grid.y = (unsigned)((p.nz + chunk - 1) / chunk); } }
       const size_t lds = (size_t)(chunk + 2) * 64 * 4;
 #define MW_XZ_MT(K_) { if (d->ord == 3) MW_XZ_MTO(K_, 3); else MW_XZ_MTO(K_, 5); }
-#define MW_XZ_MTO(K_, O_) hipLaunchKernelGGL((k_xz_state<3, true, 1, 1, K_, O_, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
+#define MW_XZ_MTO(K_, O_) MW_KLAUNCH((k_xz_state<3, true, 1, 1, K_, O_, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
                                         d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo, nullptr)
       if (marching_config(d, p) == 1) MW_XZ_MT(1) else MW_XZ_MT(0)
 #undef MW_XZ_MT
@@ -1558,7 +1542,7 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
     // (balanced schedule: a segment can be a whole column -- the LDS table then holds nz + 2 rows)
 #define MW_XZ(N1_, HPL_, K_, O_, lds) do { dim3 g_ = grid; const size_t lds_bal_ = (lds) ? (size_t)(p.nz + 2) * 64 : 0; \
                                         const Sched *sc_ = pick_sched(d, (const void *)&k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>, lds_bal_, (long long)grid.x, p.nz, g_, 1); \
-                                        hipLaunchKernelGGL((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), g_, dim3(256), sc_ ? lds_bal_ : (lds), d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
+                                        MW_KLAUNCH((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), g_, dim3(256), sc_ ? lds_bal_ : (lds), d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
                                                         MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, MemberOff(), sc_); } while (0)
 #define MW_XZ_K(K_) { if (d->ord == 3) MW_XZ(true, 1, K_, 3, hpl_bytes); else MW_XZ(true, 1, K_, 5, hpl_bytes); }
     const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
@@ -1593,7 +1577,7 @@ static int launch_state_xyz(mw_dycore_s *d, const double *S, const double *Sn, d
   const int W = fused_state_rows(d);
   grid.x = (unsigned)((p.ny / W) * tiles_x);
   const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
-#define MW_SXYZO(K_, W_, O_) hipLaunchKernelGGL((k_state_xyz<STAGE, MODE, K_, W_, O_>), grid, dim3(64 * W_), hpl_bytes, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
+#define MW_SXYZO(K_, W_, O_) MW_KLAUNCH((k_state_xyz<STAGE, MODE, K_, W_, O_>), grid, dim3(64 * W_), hpl_bytes, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
                                        d->UP[par][0], d->UP[par][2], d->M[par][1], d->UP[par][1], dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
 #define MW_SXYZ(K_, W_) do { if (d->ord == 3) MW_SXYZO(K_, W_, 3); else MW_SXYZO(K_, W_, 5); } while (0)
   if (W == 8) { if (marching_config(d, p) == 1) MW_SXYZ(1, 8); else MW_SXYZ(2, 8); }
@@ -1611,7 +1595,7 @@ static bool fused_state_ok(const mw_dycore_s *) { return false; }
 template <int T, bool N1>
 static void launch_xz_tracers_t(mw_dycore_s *d, const double *S, dim3 grid, int chunk, int tiles_x, int t0, int par, double dt, int rows4,
                                 hipStream_t st) {
-  hipLaunchKernelGGL((k_xz_tracers<T, N1>), grid, dim3(256), 0, st, d->p, S, d->FX, d->FY, d->FZ, d->M[par][0], d->M[par][2], d->UP[par][0],
+  MW_KLAUNCH((k_xz_tracers<T, N1>), grid, dim3(256), 0, st, d->p, S, d->FX, d->FY, d->FZ, d->M[par][0], d->M[par][2], d->UP[par][0],
                      d->UP[par][2], dt, chunk, tiles_x, t0, rows4);
 }
 
@@ -1647,7 +1631,7 @@ static int launch_tracer_update(mw_dycore_s *d, const double *Sstar, const doubl
   ProfScope ps(d, 2, st);
   const DyP &p = d->p;
   dim3 grid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
-  hipLaunchKernelGGL((k_tracer_update<STAGE, MODE>), grid, dim3(256), 0, st, p, Sstar, Sn, Sout, d->FX, d->FY, d->FZ, dt_dyn, c);
+  MW_KLAUNCH((k_tracer_update<STAGE, MODE>), grid, dim3(256), 0, st, p, Sstar, Sn, Sout, d->FX, d->FY, d->FZ, dt_dyn, c);
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -1657,7 +1641,7 @@ static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
   const int e = v.e;
   const Sched *sc = pick_sched(d, (const void *)&k_tracers_fused<STAGE, MODE, T, N1, K, ORD>, 0, (long long)grid.x, v.p.nz, grid, 2);
-  hipLaunchKernelGGL((k_tracers_fused<STAGE, MODE, T, N1, K, ORD>), grid, dim3(256), 0, st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
+  MW_KLAUNCH((k_tracers_fused<STAGE, MODE, T, N1, K, ORD>), grid, dim3(256), 0, st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
                      d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
                      d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4, MemberOff(), sc);
 }
@@ -1679,7 +1663,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       dim3 grid((unsigned)(((p.ny + rpb - 1) / rpb) * tiles_x), (unsigned)((p.nz + chunk - 1) / chunk));
 #define MW_FUSED_MT(TT) case TT: MW_FUSED_MTK(TT, 0) break;
 #define MW_FUSED_MTK(TT, K_) { if (d->ord == 3) MW_FUSED_MTO(TT, K_, 3); else MW_FUSED_MTO(TT, K_, 5); }
-#define MW_FUSED_MTO(TT, K_, O_) hipLaunchKernelGGL((k_tracers_fused<3, 1, TT, true, K_, O_, true>), grid, dim3(256), 0, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
+#define MW_FUSED_MTO(TT, K_, O_) MW_KLAUNCH((k_tracers_fused<3, 1, TT, true, K_, O_, true>), grid, dim3(256), 0, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
                                  d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo, nullptr)
       if (marching_config(d, p) == 1) MW_FUSED_MTK(3, 1)
       else switch (p.nt) { MW_FUSED_MT(1) MW_FUSED_MT(2) MW_FUSED_MT(3) MW_FUSED_MT(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
@@ -1719,7 +1703,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const DyP &q = v.p;
       // (member-major: every member's launch reads the same `dirty` word; only the last one may clear the next stage's word)
       unsigned int *next = (e == n_views(d) - 1) ? d->dirty + ((d->fused_launches + 1) & 1) : d->dirty + 2;
-      hipLaunchKernelGGL((k_tracer_patch<STAGE, MODE>), plane_grid((long long)q.ny * q.nx * q.nens, (q.nz + MW_PATCH_LEVELS - 1) / MW_PATCH_LEVELS), dim3(256), 0, st, q,
+      MW_KLAUNCH((k_tracer_patch<STAGE, MODE>), plane_grid((long long)q.ny * q.nx * q.nens, (q.nz + MW_PATCH_LEVELS - 1) / MW_PATCH_LEVELS), dim3(256), 0, st, q,
                          v.S(Sout), d->flags + e * v.cells, d->FX + e * v.f[0], d->FZ + e * v.f[2], dt_dyn, c, d->dirty + (d->fused_launches & 1), next);
       MW_LAUNCH_CHECK();
     }
@@ -1849,7 +1833,7 @@ static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, 
       ProfScope ps(d, 4, d->stream);
       const View v = view(d, 0);
       const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
-      hipLaunchKernelGGL(k_member_to_coupler, plane_grid((long long)d->p.ny * d->p.nx * d->p.nens, d->p.nz), dim3(256), 0, d->stream, d->p, Q[3], c, ms);
+      MW_KLAUNCH(k_member_to_coupler, plane_grid((long long)d->p.ny * d->p.nx * d->p.nens, d->p.nz), dim3(256), 0, d->stream, d->p, Q[3], c, ms);
       MW_LAUNCH_CHECK();
     }
     d->flux_src = Q[2]; d->flux_dt = dt3;
@@ -1865,7 +1849,7 @@ static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, 
     ProfScope ps(d, 4, ts);
     const View v = view(d, 0);
     const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
-    hipLaunchKernelGGL(k_member_to_coupler, plane_grid((long long)d->p.ny * d->p.nx * d->p.nens, d->p.nz), dim3(256), 0, ts, d->p, Q[3], c, ms);
+    MW_KLAUNCH(k_member_to_coupler, plane_grid((long long)d->p.ny * d->p.nx * d->p.nens, d->p.nz), dim3(256), 0, ts, d->p, Q[3], c, ms);
     MW_LAUNCH_CHECK();
     if (d->overlap) MW_HIP(hipEventRecord(d->ev_tr[(d->gstage - 1) & 7], ts));     // the step's join waits for this event
   }
@@ -2022,7 +2006,7 @@ const OptDesc OPTS[] = {
   {"fused_convert_mm", &DyOpts::fused_convert_mm, 0, 1, 0}, {"chunk_y", &DyOpts::chunk_y, 0, 1 << 20, 0}, {"chunk_yt", &DyOpts::chunk_yt, 0, 1 << 20, 0},
   {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
   {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
-  {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0},
+  {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0},
   {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
   {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},
 };
@@ -2130,7 +2114,7 @@ int mw_dycore_get_fluxes(mw_dycore_t d, double **out6) {
   if (d->flux_src) {     // production path: the state-variable fluxes of the last stage were never written; rebuild all six
     if (d->member_major) {   // the retained stage input is member-major: bring it into the fused layout the general kernels read (S1 is free)
       const long long n = (long long)d->p.V * d->p.sV;
-      hipLaunchKernelGGL(k_member_to_fused, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, d->p, d->flux_src, d->S1);
+      MW_KLAUNCH(k_member_to_fused, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, d->p, d->flux_src, d->S1);
       MW_LAUNCH_CHECK();
       d->flux_src = d->S1;
     }
@@ -2141,7 +2125,7 @@ int mw_dycore_get_fluxes(mw_dycore_t d, double **out6) {
       const long long nx_ = (long long)p.V * p.nz * p.ny * 2 * p.HX * p.nens, ny_ = (long long)p.V * p.nz * 2 * p.HY * p.nx * p.nens;
       const long long nz_ = (long long)p.V * 2 * p.HZ * p.ny * p.nx * p.nens;
       const unsigned nbx = p.wrap_x ? (unsigned)((nx_ + 255) / 256) : 0u, nby = p.wrap_y ? (unsigned)((ny_ + 255) / 256) : 0u;
-      hipLaunchKernelGGL(k_halo_xyz, dim3(nbx + nby + (unsigned)((nz_ + 255) / 256)), dim3(256), 0, d->stream, p, S, nbx, nby);
+      MW_KLAUNCH(k_halo_xyz, dim3(nbx + nby + (unsigned)((nz_ + 255) / 256)), dim3(256), 0, d->stream, p, S, nbx, nby);
       MW_LAUNCH_CHECK(); }
     if (launch_flux(d, d->flux_src)) return 1;              // arrays from the retained stage input exactly as D9+D10 leave them
     if (launch_fct(d, d->flux_src, d->flux_dt)) return 1;
@@ -2246,6 +2230,20 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   //  member-major handle whose configuration is not a folded one -- gets the full conversion pass below; without this a 1 x 1
   //  decomposition with a transport installed (both wraps on) reached the members-in-one-workgroup launch with the wrong kernel)
   if (d->pipe) d->conv_pending = false;
+  { // the dispatcher's decisions of this time step, for the tests' path-coverage matrix (mw_dycore_path)
+    const int K = march ? marching_config(d, view(d, 0).p) : 0;
+    d->path = std::string(march ? "march" : (d->strict == 1 ? "general-strict" : "general-fast")) + " ord" + std::to_string(d->ord);
+    if (march) {
+      d->path += " K" + std::to_string(K);
+      d->path += p.nens == 1 ? " nens1" : d->mm_direct ? " mm_direct" : d->member_major ? " member_major" : " fused_members";
+      d->path += d->pipe ? " pipe" : d->overlap ? " two_stream" : " one_stream";
+      d->path += (y_all_ok(d) && !fused_state_ok(d)) ? " y_all" : " y_split";
+      d->path += pipe_conv ? " conv_pipe" : d->conv_pending ? " conv_in_y" : " conv_pass";
+      d->path += d->fused ? " tracers_fused" : " tracers_unfused";
+      d->path += p.sim2d ? " 2d" : " 3d";
+      if (fused_state_ok(d)) d->path += " fused_state";
+    } else d->path += p.nens == 1 ? " nens1" : " fused_members";
+    if (d->xchg) d->path += " transport"; }
   d->pre_lo = d->pre_hi = 0;
   if (pipe_conv) {
     ProfScope ps(d, 4);
@@ -2254,9 +2252,9 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     if (d->member_major) {
       const View v = view(d, 0);
       const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
-      hipLaunchKernelGGL(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms, ylo, yhi);
+      MW_KLAUNCH(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms, ylo, yhi);
     } else
-    hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ylo, yhi);
+    MW_KLAUNCH(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ylo, yhi);
     MW_LAUNCH_CHECK();
     d->conv_pending = true;
   }
@@ -2265,9 +2263,9 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     if (d->member_major) {      // one coalesced pass in the coupler's order (see k_coupler_to_member)
       const View v = view(d, 0);
       const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
-      hipLaunchKernelGGL(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms, p.ny, p.ny);
-    } else if (march && p.nt <= 4) hipLaunchKernelGGL(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, p.ny, p.ny);
-    else       hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
+      MW_KLAUNCH(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms, p.ny, p.ny);
+    } else if (march && p.nt <= 4) MW_KLAUNCH(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, p.ny, p.ny);
+    else       MW_KLAUNCH(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
     MW_LAUNCH_CHECK();
   }
   if (d->overlap) { MW_HIP(hipEventRecord(d->ev_misc, d->stream)); MW_HIP(hipStreamWaitEvent(d->tstream, d->ev_misc, 0)); d->gstage = 0; }
@@ -2316,7 +2314,7 @@ int mw_dycore_compute_tendencies(mw_dycore_t d, const double *rho_d, const doubl
   const DyP &p = d->p;
   if (need_exchange(d) || check_halo_fit(d)) return 1;
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
-  hipLaunchKernelGGL(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK();
+  MW_KLAUNCH(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK();
   if (halo_fill(d, d->S0)) return 1;
   if (launch_flux(d, d->S0)) return 1;
   if (launch_fct(d, d->S0, dt)) return 1;
@@ -2328,7 +2326,7 @@ int mw_dycore_compute_tendencies(mw_dycore_t d, const double *rho_d, const doubl
 int mw_weno5_edges(long long n, const double *stencils, double *edges, int strict, void *stream) {
   if (n < 1 || !stencils || !edges) MW_FAIL("weno5_edges: bad argument");
   if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
-  hipLaunchKernelGGL(k_weno5_edges, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stencils, edges, n, strict);
+  MW_KLAUNCH(k_weno5_edges, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stencils, edges, n, strict);
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -2336,14 +2334,14 @@ int mw_weno5_edges(long long n, const double *stencils, double *edges, int stric
 int mw_strict_pow(long long n, const double *x, const double *y, double *out, unsigned char *main_path, void *stream) {
   if (n < 1 || !x || !y || !out) MW_FAIL("strict_pow: bad argument");
   if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
-  hipLaunchKernelGGL(k_strict_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, out, main_path, n);
+  MW_KLAUNCH(k_strict_pow, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, out, main_path, n);
   MW_LAUNCH_CHECK();
   return 0;
 }
 
 int mw_calib_copy(const double *in, double *out, long long n, void *stream) {
   if (!in || !out || n < 1) MW_FAIL("mw_calib_copy: bad arguments");
-  hipLaunchKernelGGL(k_calib_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+  MW_KLAUNCH(k_calib_copy, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n);
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -2364,7 +2362,7 @@ int mw_calib_fma64(int waves_per_simd, double seconds, double *out5, void *strea
   const dim3 grid((unsigned)(cus * waves_per_simd));            // 256 threads = one wave per SIMD; waves_per_simd workgroups per CU
   auto run = [&](long long trips, float &ms) -> int {
     MW_HIP(hipEventRecord(e0, st));
-    hipLaunchKernelGGL(k_calib_fma64, grid, dim3(256), 0, st, trips, 1.0, sink, clk);
+    MW_KLAUNCH(k_calib_fma64, grid, dim3(256), 0, st, trips, 1.0, sink, clk);
     MW_LAUNCH_CHECK();
     MW_HIP(hipEventRecord(e1, st));
     MW_HIP(hipEventSynchronize(e1));
@@ -2406,7 +2404,7 @@ int mw_calib_stage_arith(const double *tab, int nlev, long long cells, int level
   float ms = 0; int rc = 0;
   for (int rep = 0; rep < 2 && !rc; rep++) {                     // (the second launch is the measurement)
     if (hipEventRecord(e0, st) != hipSuccess) rc = 1;
-    hipLaunchKernelGGL(k_calib_stage_arith, dim3((unsigned)(thr / 256)), dim3(256), 0, st, tab, nlev, levels, bg4[0], bg4[1], bg4[2], bg4[3], sink);
+    MW_KLAUNCH(k_calib_stage_arith, dim3((unsigned)(thr / 256)), dim3(256), 0, st, tab, nlev, levels, bg4[0], bg4[1], bg4[2], bg4[3], sink);
     if (hipGetLastError() != hipSuccess || hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
         hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = 1;
   }
@@ -2415,13 +2413,30 @@ int mw_calib_stage_arith(const double *tab, int nlev, long long cells, int level
   out3[0] = ms; out3[1] = (double)(thr * levels); out3[2] = (double)(thr / 256);
   return 0;
 }
+// Test aid: the names (as the code object spells them, i.e. mangled; newline-separated) of the dycore kernels this PROCESS has launched
+// since the last reset -- every instantiation of the dispatcher's templates has its own.  Returns the bytes needed (terminator included);
+// writes at most `cap` of them.  reset != 0 clears the registry afterwards.
+long long mw_debug_launched_kernels(char *buf, long long cap, int reset) {
+  std::string all;
+  {
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    for (const void *fn : g_launched) {
+      const char *n = hipKernelNameRefByPtr(fn, nullptr);
+      if (!n) { (void)hipGetLastError(); continue; }
+      all += n; all += "\n";
+    }
+    if (reset) g_launched.clear();
+  }
+  if (buf && cap > 0) { const size_t m = std::min<size_t>((size_t)cap - 1, all.size()); memcpy(buf, all.data(), m); buf[m] = 0; }
+  return (long long)all.size() + 1;
+}
 // Test aid: occupies `stream` for about `usec` microseconds (one wavefront polling the 100 MHz counter).
 int mw_debug_spin(long long usec, void *stream) { return launch_spin(usec, (hipStream_t)stream); }
 
 int mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream) {
   if (!g || !temp) MW_FAIL("null argument");
   long long n = (long long)g->nz * g->ny * g->nx * g->nens;
-  hipLaunchKernelGGL(k_perturb_temperature, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g->nz, g->ny, g->nx,
+  MW_KLAUNCH(k_perturb_temperature, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g->nz, g->ny, g->nx,
                      g->nens, g->i_beg, g->j_beg, g->xlen / g->nx_glob, g->ylen / g->ny_glob, g->zlen / g->nz, g->xlen, g->ylen, temp);
   MW_LAUNCH_CHECK();
   return 0;
@@ -2435,7 +2450,7 @@ int mw_perturb_temperature_random(const mw_grid_t *g, double *temp, void *stream
   const unsigned long long myrank = (unsigned long long)g->py * g->nproc_x + g->px;
   const unsigned long long seed = myrank * (unsigned long long)g->nz * g->nx * g->ny * g->nens;
   const long long n = (long long)num_levels * ncol;
-  hipLaunchKernelGGL(k_perturb_temperature_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, num_levels, ncol, seed, temp);
+  MW_KLAUNCH(k_perturb_temperature_random, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, num_levels, ncol, seed, temp);
   MW_LAUNCH_CHECK();
   return 0;
 }
@@ -2457,6 +2472,7 @@ void *dycore_exchange_ctx(mw_dycore_t d, mw_exchange_fn *fn) { if (fn) *fn = d ?
 // MW_* switches): 0 = one stream, 1 = two streams (state | tracer pipelines, rk_stage_march with overlap), 2 = the pipelined
 // one-stream schedule of a decomposed block (rk_stage_pipe); + 4 when the y faces of all variables go through the one k_y_all launch,
 // + 8 when that time step ran on the general (flux-materialising) kernels instead of the marching ones.  -1: null handle.
+extern "C" const char *mw_dycore_path(mw_dycore_t d) { return d ? d->path.c_str() : ""; }
 extern "C" int mw_dycore_schedule(mw_dycore_t d) {
   if (!d) return -1;
   return (d->pipe ? 2 : d->overlap ? 1 : 0) + (d->last_march && y_all_ok(d) && !fused_state_ok(d) ? 4 : 0) + (d->last_march ? 0 : 8);
@@ -2652,7 +2668,7 @@ extern "C" int mw_dycore_init(mw_dycore_t d, int init_data, double *rho_d, doubl
   }
   MW_HIP(hipMemsetAsync(d->imm, 0, (size_t)d->p.nC * 8, d->stream));                    // :1315
   const DyP &p = d->p;
-  hipLaunchKernelGGL(k_init_cells, plane_grid((long long)p.ny * p.nx * p.nens, p.nz), dim3(256), 0, d->stream, p, q, c, d->imm);
+  MW_KLAUNCH(k_init_cells, plane_grid((long long)p.ny * p.nx * p.nens, p.nz), dim3(256), 0, d->stream, p, q, c, d->imm);
   MW_LAUNCH_CHECK();
   MW_HIP(hipStreamSynchronize(d->stream));
   if (dev_cols) (void)hipFree(dev_cols);

@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace mw {
 
@@ -113,10 +115,12 @@ struct KesP {
   double R_d, cp_d, R_v, p0;       // module constants, microphysics_kessler.h:29-41
 };
 
-// workspace layout (doubles): [0] dt_max bits (as unsigned long long) | velqr(nz,ncol) | theta | qv | qc | qr
-__global__ __launch_bounds__(256) void k_kessler_init_min(unsigned long long *dtmax_bits) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *dtmax_bits = 0x7FF0000000000000ull;   // +inf
-}
+// workspace layout (doubles): [0..15] unused | velqr(nz,ncol) | theta | qv | qc | qr
+// The minimum of dt2d over the rank (:276) is one 64-bit word that every block of the CFL pass atomicMin's into.  It lives in a
+// library-owned pair of words per (device, stream) -- kessler_min_words below -- used alternately: call n accumulates into word n & 1
+// while block (0, 0) of its CFL pass resets word (n + 1) & 1 to +inf for call n + 1 (whose readers finished with it one call ago,
+// in stream order).  No separate initialisation launch (round 5; rounds 1-4 spent a 5 us launch per call on it).
+#define MW_KES_INF 0x7FF0000000000000ull
 
 // Terminal velocity of rain, :256-260, from the density fields (one definition for the CFL pass, the chunk sweep and the
 // column sweep: the 16 bytes per cell of a stored copy cost more than recomputing it, and a rain-free wavefront skips it).
@@ -138,8 +142,9 @@ __device__ __forceinline__ double kessler_velqr(double rho_r, double rd, double 
 // chunk-boundary level, whose flux the sweep needs -- evaluate the fall speed (:260).  The pass is then a stream over two fields.
 __global__ __launch_bounds__(256) void k_kessler_prep(KesP p, const double *__restrict__ rho_r, const double *__restrict__ rho_d,
                                                       double *__restrict__ flux_top, int chunk, int klevels,
-                                                      unsigned long long *dtmax_bits) {
+                                                      unsigned long long *dtmax_bits, unsigned long long *next_bits) {
 #pragma clang fp contract(off)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *next_bits = MW_KES_INF;      // the NEXT call's word (see MW_KES_INF)
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int k0 = blockIdx.y * klevels, k1 = min(k0 + klevels, p.nz);
   double dtc = p.dt;                                          // every cell's contribution is capped at dt (see above)
@@ -243,14 +248,11 @@ __device__ __forceinline__ double kessler_cell(const KesP &p, int k, double rd, 
 }
 
 // rainsplit == 1: thread = (column i, z chunk c), top-down over the chunk's levels.
-__global__ __launch_bounds__(256) void k_kessler_chunks(KesP p, double *__restrict__ rho_v, double *__restrict__ rho_c,
-                                                        double *__restrict__ rho_r, const double *__restrict__ rho_d,
-                                                        double *__restrict__ temp, double *__restrict__ precl,
-                                                        const unsigned long long *dtmax_bits, const double *__restrict__ velqr_in,
-                                                        const double *__restrict__ flux_top, int chunk) {
+__device__ __forceinline__ void kessler_chunks_body(const KesP &p, double *__restrict__ rho_v, double *__restrict__ rho_c,
+                                                    double *__restrict__ rho_r, const double *__restrict__ rho_d,
+                                                    double *__restrict__ temp, double *__restrict__ precl,
+                                                    const double *__restrict__ flux_top, int chunk) {
 #pragma clang fp contract(off)
-  const double dt_max = __longlong_as_double((long long)*dtmax_bits);
-  if ((int)ceil(p.dt / dt_max) != 1) return;                  // k_kessler_column handles rainsplit > 1
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.ncol) return;
   const int c = blockIdx.y;
@@ -280,14 +282,11 @@ __global__ __launch_bounds__(256) void k_kessler_chunks(KesP p, double *__restri
   if (c == 0) precl[i] = precl_acc / 1.0;                                // :332-334
 }
 
-__global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restrict__ rho_v, double *__restrict__ rho_c,
-                                                        double *__restrict__ rho_r, const double *__restrict__ rho_d,
-                                                        double *__restrict__ temp, double *__restrict__ precl,
-                                                        const unsigned long long *dtmax_bits, double *__restrict__ ws) {
+// rainsplit > 1: thread = column, all sub-cycles, top-down.
+__device__ __forceinline__ void kessler_column_body(const KesP &p, int rainsplit, double *__restrict__ rho_v, double *__restrict__ rho_c,
+                                                    double *__restrict__ rho_r, const double *__restrict__ rho_d,
+                                                    double *__restrict__ temp, double *__restrict__ precl, double *__restrict__ ws) {
 #pragma clang fp contract(off)
-  const double dt_max = __longlong_as_double((long long)*dtmax_bits);
-  const int rainsplit = (int)ceil(p.dt / dt_max);             // :279
-  if (rainsplit == 1) return;                                 // done by k_kessler_chunks
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= p.ncol) return;
   const long long n = (long long)p.nz * p.ncol;
@@ -322,6 +321,44 @@ __global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restri
   precl[i] = precl_acc / (double)rainsplit;                               // :332-334
 }
 
+// K4 + K5 in ONE launch (round 5; two launches before, one of them a no-op): the grid of the z-chunk sweep; with rainsplit == 1 every
+// workgroup sweeps its chunk, with rainsplit > 1 (wave-uniform: one word) the workgroups of chunk 0 run whole columns and the others leave.
+#ifndef MW_KES_SWEEP
+#define MW_KES_SWEEP 0          // 0: k_kessler_chunks + k_kessler_column (one of them returns at once); 1 / 2: one merged launch, capped at 128 VGPRs / uncapped (A/B)
+#endif
+#if MW_KES_SWEEP == 1
+__global__ __launch_bounds__(256, 4)
+#else
+__global__ __launch_bounds__(256)
+#endif
+void k_kessler_sweep(KesP p, double *__restrict__ rho_v, double *__restrict__ rho_c,
+                                                       double *__restrict__ rho_r, const double *__restrict__ rho_d,
+                                                       double *__restrict__ temp, double *__restrict__ precl,
+                                                       const unsigned long long *dtmax_bits, double *__restrict__ ws,
+                                                       const double *__restrict__ flux_top, int chunk) {
+#pragma clang fp contract(off)
+  const double dt_max = __longlong_as_double((long long)*dtmax_bits);
+  const int rainsplit = (int)ceil(p.dt / dt_max);             // :279
+  if (rainsplit == 1) kessler_chunks_body(p, rho_v, rho_c, rho_r, rho_d, temp, precl, flux_top, chunk);
+  else if (blockIdx.y == 0) kessler_column_body(p, rainsplit, rho_v, rho_c, rho_r, rho_d, temp, precl, ws);
+}
+
+__global__ __launch_bounds__(256) void k_kessler_chunks(KesP p, double *__restrict__ rho_v, double *__restrict__ rho_c, double *__restrict__ rho_r,
+                                                        const double *__restrict__ rho_d, double *__restrict__ temp, double *__restrict__ precl,
+                                                        const unsigned long long *dtmax_bits, const double *__restrict__ flux_top, int chunk) {
+  const double dt_max = __longlong_as_double((long long)*dtmax_bits);
+  if ((int)ceil(p.dt / dt_max) != 1) return;                  // k_kessler_column handles rainsplit > 1
+  kessler_chunks_body(p, rho_v, rho_c, rho_r, rho_d, temp, precl, flux_top, chunk);
+}
+__global__ __launch_bounds__(256) void k_kessler_column(KesP p, double *__restrict__ rho_v, double *__restrict__ rho_c, double *__restrict__ rho_r,
+                                                        const double *__restrict__ rho_d, double *__restrict__ temp, double *__restrict__ precl,
+                                                        const unsigned long long *dtmax_bits, double *__restrict__ ws) {
+  const double dt_max = __longlong_as_double((long long)*dtmax_bits);
+  const int rainsplit = (int)ceil(p.dt / dt_max);             // :279
+  if (rainsplit == 1) return;                                 // done by k_kessler_chunks
+  kessler_column_body(p, rainsplit, rho_v, rho_c, rho_r, rho_d, temp, precl, ws);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // STRICT path (mw_kessler_set_strict(1)): the reference's formulas in the reference's operation order -- theta form, IEEE divisions,
 // no contraction -- with glibc's pow and exp (mw_glibc_pow.h): BIT-identical to the CPU oracle (and, with it, to the reference on a
@@ -335,8 +372,9 @@ __device__ __forceinline__ double kes_exp_ref(double x) { double r; if (glibc_ex
 __global__ __launch_bounds__(256) void k_kessler_strict_prep(KesP p, const double *__restrict__ rho_v, const double *__restrict__ rho_c,
                                                              const double *__restrict__ rho_r, const double *__restrict__ rho_d,
                                                              const double *__restrict__ temp, double *__restrict__ ws,
-                                                             unsigned long long *dtmax_bits) {
+                                                             unsigned long long *dtmax_bits, unsigned long long *next_bits) {
 #pragma clang fp contract(off)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *next_bits = MW_KES_INF;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n = (long long)p.nz * p.ncol;
   double dtc = __builtin_huge_val();
@@ -458,6 +496,26 @@ int mw_kessler_math_probe(long long n, const double *x, double *y, int fn, void 
 
 static thread_local int g_kessler_strict = 0;        // per calling thread: a rank harness with one host thread per rank may use different modes side by side
 // 1: the strict path (reference operation order, glibc's pow / exp: bit-identical to the CPU oracle); 0: the production kernels
+// The pair of min words of a (device, stream): allocated and set to +inf once, then kept consistent by the kernels themselves (see
+// MW_KES_INF).  -> this call's word and the one its CFL pass resets for the next call.
+static int kessler_min_words(hipStream_t st, unsigned long long **cur, unsigned long long **next) {
+  struct Entry { unsigned long long *w = nullptr; unsigned long long calls = 0; };
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Entry> tab;
+  int dev = 0;
+  MW_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  Entry &e = tab[{dev, st}];
+  if (!e.w) {
+    const unsigned long long init[2] = {MW_KES_INF, MW_KES_INF};
+    MW_HIP(hipMalloc(&e.w, 16));
+    if (hipMemcpy(e.w, init, 16, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(e.w); e.w = nullptr; MW_FAIL("kessler: initialising the min words failed"); }
+  }
+  *cur = e.w + (e.calls & 1); *next = e.w + ((e.calls + 1) & 1);
+  e.calls++;
+  return 0;
+}
+
 int mw_kessler_set_strict(int strict) { g_kessler_strict = strict ? 1 : 0; return 0; }
 
 int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *rho_v, double *rho_c, double *rho_r,
@@ -468,12 +526,12 @@ int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *r
   if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
   hipStream_t st = (hipStream_t)stream;
   KesP p; p.nz = nz; p.ncol = ncol; p.dz = dz; p.dt = dt; p.R_d = 287.; p.cp_d = 1003.; p.R_v = 461.; p.p0 = 1.e5;
-  unsigned long long *bits = (unsigned long long *)workspace;
+  unsigned long long *bits = nullptr, *next_bits = nullptr;
+  if (kessler_min_words(st, &bits, &next_bits)) return 1;
   double *ws = (double *)workspace + 16;
-  hipLaunchKernelGGL(k_kessler_init_min, dim3(1), dim3(64), 0, st, bits); MW_LAUNCH_CHECK();
   if (g_kessler_strict) {
     const long long n = (long long)nz * ncol;
-    hipLaunchKernelGGL(k_kessler_strict_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp, ws, bits); MW_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_kessler_strict_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp, ws, bits, next_bits); MW_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_kessler_strict_column, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp,
                        precl, bits, ws); MW_LAUNCH_CHECK();
     if (rainsplit_out) {
@@ -492,11 +550,16 @@ int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *r
   double *flux_top = ws + 5ll * nz * ncol;                    // (nchunks-1, ncol)
   const int klevels = 5;                                        // levels per thread of the CFL pass (k_kessler_prep: KL)
   hipLaunchKernelGGL(k_kessler_prep, dim3((unsigned)((ncol + 255) / 256), (unsigned)((nz + klevels - 1) / klevels)), dim3(256), 0, st, p,
-                     rho_r, rho_d, flux_top, chunk, klevels, bits); MW_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_kessler_chunks, dim3((unsigned)((ncol + 255) / 256), (unsigned)nchunks), dim3(256), 0, st, p, rho_v, rho_c, rho_r,
+                     rho_r, rho_d, flux_top, chunk, klevels, bits, next_bits); MW_LAUNCH_CHECK();
+#if MW_KES_SWEEP
+  hipLaunchKernelGGL(k_kessler_sweep, dim3((unsigned)((ncol + 255) / 256), (unsigned)nchunks), dim3(256), 0, st, p, rho_v, rho_c, rho_r,
                      rho_d, temp, precl, bits, ws, flux_top, chunk); MW_LAUNCH_CHECK();
+#else
+  hipLaunchKernelGGL(k_kessler_chunks, dim3((unsigned)((ncol + 255) / 256), (unsigned)nchunks), dim3(256), 0, st, p, rho_v, rho_c, rho_r,
+                     rho_d, temp, precl, bits, flux_top, chunk); MW_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_kessler_column, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp,
                      precl, bits, ws); MW_LAUNCH_CHECK();
+#endif
   if (rainsplit_out) {
     unsigned long long hb = 0;
     MW_HIP(hipMemcpyAsync(&hb, bits, 8, hipMemcpyDeviceToHost, st));

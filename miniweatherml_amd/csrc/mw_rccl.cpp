@@ -141,7 +141,7 @@ void free_ctx(RcclCtx *c) {
   delete c;
 }
 // streams and events of the lanes; lane 1 only when a second communicator can be split off
-int init_lanes(RcclCtx *c, RcclApi &R, int nranks, int myrank, int lanes, int two_comms) {
+int init_lanes(RcclCtx *c, RcclApi &R, int nranks, int myrank, int lanes, int two_comms, int high_prio = 1) {
   c->nlanes = lanes == 1 ? 1 : 2;
   c->lane[1].comm = c->lane[0].comm; c->own_comm1 = false;     // shared communicator (default)
   { if (c->nlanes == 2 && two_comms) {
@@ -157,7 +157,13 @@ int init_lanes(RcclCtx *c, RcclApi &R, int nranks, int myrank, int lanes, int tw
     } }
   for (int l = 0; l < c->nlanes; l++) {
     RcclLane &L = c->lane[l];
-    if (hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess ||
+    // The side stream gets the HIGHEST stream priority (round 5): the send / receive kernels of a group are a handful of workgroups that
+    // poll each other's flags, launched beside compute kernels that fill every CU with two 250-VGPR workgroups -- a transfer workgroup only
+    // becomes resident when a compute workgroup retires, and at equal priority the next compute workgroup competes for that slot while
+    // the transfer's resident half spins (measured with the self-loop transport, tools/exchange_overhead.py).
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if ((high_prio ? hipStreamCreateWithPriority(&L.side, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking)) != hipSuccess ||
         hipEventCreateWithFlags(&L.ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming) != hipSuccess) { mw::set_error("mw_rccl: stream/event creation failed"); return 1; }
   }
@@ -234,7 +240,7 @@ int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, in
   { ncclResult_t r = R.CommInitRank(&c->lane[0].comm, nranks, id, myrank);
     if (r != ncclSuccess) { c->lane[0].comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
   int lanes, two; handle_lanes(h, lanes, two);
-  if (init_lanes(c, R, nranks, myrank, lanes, two)) return fail();
+  if (init_lanes(c, R, nranks, myrank, lanes, two, mw::dycore_option(h, "rccl_prio"))) return fail();
   if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return fail();
   if (int seed = mw::dycore_option(h, "xchg_fuzz")) c->fuzz = 0x9E3779B97F4A7C15ULL * (unsigned long long)seed + (unsigned long long)myrank + 1;
   if (mw::dycore_set_exchange_owned(h, rccl_exchange, c, [](void *p) { free_ctx((RcclCtx *)p); })) return fail();   // the handle frees it
@@ -261,7 +267,7 @@ int mw_dycore_use_rccl_self(mw_dycore_t h) {
   { ncclResult_t r = R.CommInitRank(&c->lane[0].comm, 1, id, 0);
     if (r != ncclSuccess) { c->lane[0].comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
   int lanes, two; handle_lanes(h, lanes, two);
-  if (init_lanes(c, R, 1, 0, lanes, two)) return fail();
+  if (init_lanes(c, R, 1, 0, lanes, two, mw::dycore_option(h, "rccl_prio"))) return fail();
   if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return fail();   // (which directions exchange: the grid's)
   for (int d = 0; d < 4; d++) { c->peers[d] = 0; c->send_order[d] = d; }
   c->recv_order[0] = 1; c->recv_order[1] = 0; c->recv_order[2] = 3; c->recv_order[3] = 2;

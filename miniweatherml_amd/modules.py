@@ -41,6 +41,11 @@ for _kv in filter(None, os.environ.get("MW_OPTIONS", "").split(",")):
     DEFAULT_OPTIONS[_k.strip()] = int(_v)
 
 
+# What the dispatcher chose in every time_step of this process since the list was last cleared (mw_dycore_path): the tests' comparisons
+# drain it, so that each oracle comparison is logged with the kernel paths that produced the compared fields (tests/util.py).
+PATH_LOG = []
+
+
 class Dynamics_Euler_Stratified_WenoFV:
     ord = 5               # the reference's compile-time MW_ORD (:24-29); Dynamics_Euler_Stratified_WenoFV(ord=3) = its -DMW_ORD=3 build
     hs = 2
@@ -173,6 +178,9 @@ class Dynamics_Euler_Stratified_WenoFV:
         with torch.cuda.device(coupler.device):
             check(capi.lib().mw_dycore_time_step(self.h, *[_ptr(t) for t in self._fields], self._tracer_ptrs, float(dt_phys)))
         self.etime += dt_phys
+        PATH_LOG.append(self.path())
+        if len(PATH_LOG) > 4096:                                # (a long run that nobody drains: keep the distinct entries)
+            PATH_LOG[:] = sorted(set(PATH_LOG))
         # :183-186.  out_freq == 0: the reference's etime/0. is +inf >= num_out+1, i.e. a record after every step
         if self.out_freq >= 0.0 and (self.out_freq == 0.0 or self.etime / self.out_freq >= self.num_out + 1):
             self.output(coupler, self.etime)
@@ -210,6 +218,10 @@ class Dynamics_Euler_Stratified_WenoFV:
         return dict(code=v, streams=("one stream", "two streams (state | tracers, tracer stream at high priority)",
                                      "one compute stream, strip exchange on a side stream beside the inner y rows / the tracer stage")[v & 3],
                     y_all=bool(v & 4), general_kernels=bool(v & 8))
+
+    def path(self):
+        """The dispatcher's decisions of the last time_step, spelled out (mw_dycore_path)."""
+        return (capi.lib().mw_dycore_path(self.h) or b"").decode()
 
     def rccl_info(self):
         """(ranks, rank, lanes) as the installed RCCL transport's communicator reports them (ncclCommCount / ncclCommUserRank)."""
@@ -1042,7 +1054,7 @@ def make_supercell(nx_glob, ny_glob, nz, nens=1, xlen=1.0e5, ylen=1.0e5, zlen=2.
 
 
 def make_simple_city(nx_glob, ny_glob, nz, nens=1, xlen=2400.0, ylen=2400.0, zlen=120.0, init_data="city", device="cuda:0",
-                     nranks=1, myrank=0, out_prefix="test"):
+                     nranks=1, myrank=0, out_prefix="test", ord=5):
     """The set-up sequence of experiments/simple_city/driver.cpp:32-62: only water_vapor is registered (zero), gravity off,
     dycore.init -> horiz_sponge.init(coupler, 10, 1.) -> time_averager.init."""
     coupler = Coupler(device)
@@ -1054,7 +1066,7 @@ def make_simple_city(nx_glob, ny_glob, nz, nens=1, xlen=2400.0, ylen=2400.0, zle
     coupler.set_grid(xlen, ylen, zlen)
     coupler.add_tracer("water_vapor", "water_vapor", True, True)               # driver.cpp:55-56
     coupler.get_data_manager_readwrite().get("water_vapor").zero_()
-    dycore, horiz_sponge, time_averager = Dynamics_Euler_Stratified_WenoFV(), Horizontal_Sponge(), Time_Averager()
+    dycore, horiz_sponge, time_averager = Dynamics_Euler_Stratified_WenoFV(ord), Horizontal_Sponge(), Time_Averager()
     dycore.init(coupler)
     horiz_sponge.init(coupler, 10, 1.0)
     time_averager.init(coupler)

@@ -28,6 +28,18 @@ def mw():
     return miniweatherml_amd
 
 
+@pytest.fixture(autouse=True)
+def _fresh_path_log():
+    """Every test starts with an empty dispatcher-path log and launch registry, so that a comparison is only credited with the time steps
+    of its own test (tests/util.py: compare_fields drains both)."""
+    capi = sys.modules.get("miniweatherml_amd.capi")
+    if capi is not None and getattr(capi, "_lib", None) is not None:
+        from util import drain_paths, launched_kernels
+        drain_paths()
+        launched_kernels(reset=True)
+    yield
+
+
 def pytest_sessionstart(session):
     from util import PARITY_LOG
     try:
@@ -45,7 +57,8 @@ def pytest_sessionfinish(session, exitstatus):
         return
     rows = [json.loads(ln) for ln in open(PARITY_LOG)]
     failed = [r for r in rows if not r["passed"]]          # comparisons that raised (negative controls expect to)
-    rows = [r for r in rows if r["passed"]]
+    all_passed = [r for r in rows if r["passed"]]
+    rows = [r for r in all_passed if r["fields"]]          # (record_comparison rows carry no per-field numbers: coverage only)
     out = {"comparisons": len(rows), "failed_comparisons (negative controls included)": sorted({r["what"] for r in failed}),
            "needed_fallback": sorted({r["what"] for r in rows if any(f["needed_fallback"] for f in r["fields"].values())}),
            "worst_rel_by_tolerance": {}, "cases": []}
@@ -71,4 +84,71 @@ def pytest_sessionfinish(session, exitstatus):
                              "fallback_allowed": r["fallback_allowed"],
                              "needed_fallback": sorted(k for k, f in r["fields"].items() if f["needed_fallback"]),
                              "rel": {k: f["rel"] for k, f in r["fields"].items()}})
+    cov = _coverage(session, all_passed)
+    if cov is not None:
+        out["coverage"] = cov
     json.dump(out, open(os.path.join(os.path.dirname(PARITY_LOG), "parity_summary.json"), "w"), indent=1)
+    if cov is not None and cov["enforced"] and (cov["missing_paths"] or cov["unknown_paths"] or cov["kernels_never_compared"]):
+        print("\nCOVERAGE FAILURE (tests/conftest.py): dispatcher paths without a passed oracle comparison: %r; paths the library reported that "
+              "tests/util.py:reachable_paths does not know: %r; compiled kernel instantiations no oracle comparison exercised: %r"
+              % (cov["missing_paths"], cov["unknown_paths"], cov["kernels_never_compared"]))
+        session.exitstatus = 1
+
+
+# kernel families of the dispatcher: everything mw_dycore_init / time_step / compute_tendencies / get_fluxes / perturb_temperature can
+# launch (the calibration kernels and test aids of mw_calib.h, and the other modules' kernels, are not part of this path)
+_DISPATCHED = {"k_y_all", "k_y_state", "k_y_tracers", "k_xz_state", "k_tracers_fused", "k_tracer_patch", "k_xz_tracers", "k_tracer_update",
+               "k_flux", "k_fct", "k_update", "k_coupler_to_state", "k_coupler_to_state_fast", "k_coupler_to_member", "k_member_to_coupler",
+               "k_member_to_fused", "k_halo_xyz", "k_pack_x", "k_pack_y", "k_unpack_x", "k_unpack_y", "k_init_cells", "k_perturb_temperature",
+               "k_perturb_temperature_random", "k_state_xyz"}
+
+
+def _compiled_dycore_kernels(lib_path):
+    """Mangled names of every dispatcher kernel compiled into the library: the `.kd` kernel descriptors of its embedded gfx950 code
+    object whose function name (the length-prefixed identifier behind _ZN2mw) is one of the dispatcher's families."""
+    import re
+    out = set()
+    for m in re.finditer(rb"(_ZN2mw(\d+)([0-9A-Za-z_]+))\.kd\x00", open(lib_path, "rb").read()):
+        n = int(m.group(2))
+        if m.group(3)[:n].decode() in _DISPATCHED:
+            out.add(m.group(1).decode())
+    return sorted(out)
+
+
+def _demangle(names):
+    import shutil
+    import subprocess
+    if not names or not shutil.which("c++filt"):
+        return list(names)
+    r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
+    return [ln.replace("void ", "").split("(")[0] for ln in r.stdout.split("\n") if ln] if r.returncode == 0 else list(names)
+
+
+def _coverage(session, rows):
+    """Path-coverage matrix of this session (round 5): which dispatcher paths (mw_dycore_path) and which compiled kernel instantiations
+    (mw_debug_launched_kernels against the kernel descriptors found in the loaded library itself) produced fields that a PASSED oracle
+    comparison checked.
+    Enforced -- the session fails -- when the whole path matrix ran (tests/test_gpu_path_matrix.py, i.e. a full `-m gpu` run)."""
+    import collections
+    from util import path_string, reachable_paths
+    rows = [r for r in rows if r.get("paths") or r.get("kernels")]
+    if not rows:
+        return None
+    seen = collections.Counter(p for r in rows for p in r.get("paths", []))
+    want = [path_string(c) for c in reachable_paths()]
+    ran = sum(1 for it in getattr(session, "items", []) if "test_gpu_path_matrix.py::test_path[" in it.nodeid)
+    enforced = ran == len(want) and session.exitstatus == 0
+    base = lambda p: p.replace(" fused_state", "")                # noqa: E731  (the -DMW_EXPERIMENTS kernel rides on a production path)
+    cov = {"enforced": enforced, "paths_compared": dict(sorted(seen.items())), "reachable_paths": len(want),
+           "missing_paths": sorted(set(want) - set(seen)), "unknown_paths": sorted(p for p in seen if base(p) not in set(want)),
+           "kernels_never_compared": [], "kernels_compiled": None}
+    try:
+        from miniweatherml_amd import capi
+        compiled = _compiled_dycore_kernels(capi.LIB_PATH)
+        hit = set(k for r in rows for k in r.get("kernels", []))
+        cov["kernels_compiled"] = len(compiled)
+        cov["kernels_compared"] = len([n for n in compiled if n in hit])
+        cov["kernels_never_compared"] = sorted(_demangle([n for n in compiled if n not in hit]))
+    except Exception as e:                                        # pragma: no cover
+        cov["kernel_list_error"] = repr(e)
+    return cov

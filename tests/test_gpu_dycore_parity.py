@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import pytest
 
-from util import build_has, compare_fields, gpu_fields, oracle_sensitivity, push_fields, sens_allowed, set_options
+from util import build_has, compare_fields, record_comparison, gpu_fields, oracle_sensitivity, push_fields, sens_allowed, set_options
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -159,6 +159,7 @@ def check_fluxes(dycore, coupler, odyc, tol):
                 assert gfl[grp + d].shape == ofl[grp + d].shape
                 err = np.max(np.abs(gfl[grp + d][v] - ofl[grp + d][v]))
                 assert err <= tol * scale + 1e-300, (grp + d, v, err, scale)
+    record_comparison("six public flux arrays against the oracle's, tol %g of each variable's largest flux" % tol)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
@@ -510,6 +511,7 @@ def test_random_temperature_perturbation_is_bitwise_the_oracles(mw, oracle, nran
     oracle.perturb_temperature(odyc.p, of.temp, thermal=False, random=True, myrank=rank)
     got = coupler.get_data_manager_readonly().get("temp", True).cpu().numpy()
     assert np.array_equal(got, of.temp)                           # the noise: bit for bit
+    record_comparison("perturb_temperature(random = true): bit for bit the oracle's")
     push_fields(coupler, of)
     of.temp[...] = t0
     coupler.get_data_manager_readwrite().get("temp", True).copy_(torch.as_tensor(t0, device="cuda"))

@@ -35,6 +35,24 @@ def build_has(bit):
     return bool(capi.lib().mw_build_flags() & bit)
 
 
+def launched_kernels(reset=True):
+    """Mangled names of the dycore kernels this process has launched since the last reset (mw_debug_launched_kernels)."""
+    from miniweatherml_amd import capi
+    L = capi.lib()
+    n = L.mw_debug_launched_kernels(None, 0, 0)
+    buf = C.create_string_buffer(int(n) + 16)
+    L.mw_debug_launched_kernels(buf, len(buf), 1 if reset else 0)
+    return sorted(set(buf.value.decode().split()))
+
+
+def drain_paths():
+    """The dispatcher paths (mw_dycore_path) of every time_step since the last drain."""
+    from miniweatherml_amd import modules
+    p = sorted(set(modules.PATH_LOG))
+    modules.PATH_LOG.clear()
+    return p
+
+
 def rel_err(a, b):
     """max|a-b| / max|b|  (the tolerance definition of BASELINE.md section 4)."""
     a = np.asarray(a, dtype=np.float64)
@@ -131,10 +149,14 @@ def compare_fields(got, ref, tol, what="", sens=None):
         if fail is None and not d <= lim:
             fail = "%s: field %s max|diff| %.3e > %.3e (scale %.3e)" % (what, k, d, lim, scale)
     try:
+        paths, kernels = drain_paths(), launched_kernels(reset=True)       # what produced the compared fields (GPU side)
+    except Exception:                                              # (CPU-only sessions: oracle against golden vectors, no library call)
+        paths, kernels = [], []
+    try:
         os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
         with open(PARITY_LOG, "a") as fh:
             fh.write(json.dumps({"what": what, "tol": 0.0 if bitwise else tol, "bitwise": bitwise, "fallback_allowed": sens is not None, "passed": fail is None,
-                                 "test": os.environ.get("PYTEST_CURRENT_TEST", ""), "fields": rec}) + "\n")
+                                 "test": os.environ.get("PYTEST_CURRENT_TEST", ""), "paths": paths, "kernels": kernels, "fields": rec}) + "\n")
     except OSError:
         pass
     assert fail is None, fail
@@ -322,3 +344,75 @@ class StreamExchanger:
                 self.bar.abort()
                 return 1
         return capi.EXCHANGE_FN(cb)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The dispatcher's path space (round 5): every combination of kernel family x folded configuration x WENO order x internal layout x
+# schedule x y launch form x where D1 happens x tracer stage x 2-D / 3-D x transport that mw_dycore_time_step can choose -- a Python
+# statement of its rules (mw_dycore.hip: march / y_all_ok / marching_config / member_major / pipe_conv / conv_pending), spelled like
+# mw_dycore_path spells them.  tests/test_gpu_path_matrix.py realises each one against the oracle; tests/conftest.py asserts at session
+# end that every one was hit by a passed oracle comparison and that the library never reported a path outside this set.
+# ------------------------------------------------------------------------------------------------------------------
+def path_string(c):
+    if c["family"] != "march":
+        return "%s ord%d %s%s" % (c["family"], c["ord"], c["layout"], " transport" if c["transport"] else "")
+    return "march ord%d K%d %s %s %s %s %s %s%s" % (c["ord"], c["K"], c["layout"], c["sched"], c["y"], c["conv"], c["tracers"], c["dim"],
+                                                    " transport" if c["transport"] else "")
+
+
+def path_valid(c):
+    """The dispatcher's rules (see above).  fused_members = nens > 1 in the coupler's member-fastest layout (option member_major = 0)."""
+    o, K, lay, sch, y, cv, tr, dim, tp = c["ord"], c["K"], c["layout"], c["sched"], c["y"], c["conv"], c["tracers"], c["dim"], c["transport"]
+    if lay == "fused_members" and (o != 5 or K != 0):
+        return False                                              # WENO-3 marches member-major only; a folded configuration needs a one-member view
+    if lay in ("member_major", "mm_direct") and tr != "tracers_fused":
+        return False                                              # member-major exists for the fused tracer stage
+    if o == 3 and tr != "tracers_fused":
+        return False
+    if dim == "2d" and (K != 0 or y != "y_split" or cv != "conv_pass" or sch == "pipe"):
+        return False                                              # 2-D: no y launch, no row wrap, never a folded configuration
+    if y == "y_all" and (tr != "tracers_fused" or sch == "two_stream"):
+        return False
+    if sch == "pipe" and (y != "y_all" or not tp):
+        return False
+    if cv == "conv_pipe" and not (sch == "pipe" and (lay in ("nens1", "fused_members") or (lay == "mm_direct" and K != 0))):
+        return False
+    if cv == "conv_in_y" and (sch == "pipe" or tp):
+        return False                                              # needs both index wraps: a block of a decomposed domain has neither
+    return True
+
+
+def reachable_paths():
+    out = []
+    for fam in ("general-strict", "general-fast"):
+        for o in (3, 5, 7, 9):
+            for lay in ("nens1", "fused_members"):
+                for tp in (False, True):
+                    out.append(dict(family=fam, ord=o, layout=lay, transport=tp))
+    for o in (3, 5):
+        for K in (0, 1, 2):
+            for lay in ("nens1", "fused_members", "member_major", "mm_direct"):
+                for sch in ("one_stream", "two_stream", "pipe"):
+                    for y in ("y_all", "y_split"):
+                        for cv in ("conv_in_y", "conv_pipe", "conv_pass"):
+                            for tr in ("tracers_fused", "tracers_unfused"):
+                                for dim in ("3d", "2d"):
+                                    for tp in (False, True):
+                                        c = dict(family="march", ord=o, K=K, layout=lay, sched=sch, y=y, conv=cv, tracers=tr, dim=dim, transport=tp)
+                                        if path_valid(c):
+                                            out.append(c)
+    return out
+
+
+def record_comparison(what, passed=True):
+    """For checks that do not go through compare_fields (flux arrays judged per variable over the three directions, bitwise array
+    comparisons): logs the comparison with the dispatcher paths and kernel instantiations that produced the compared data, so that the
+    session's coverage matrix (tests/conftest.py) credits them."""
+    try:
+        paths, kernels = drain_paths(), launched_kernels(reset=True)
+        os.makedirs(os.path.dirname(PARITY_LOG), exist_ok=True)
+        with open(PARITY_LOG, "a") as fh:
+            fh.write(json.dumps({"what": what, "tol": None, "bitwise": False, "fallback_allowed": False, "passed": bool(passed),
+                                 "test": os.environ.get("PYTEST_CURRENT_TEST", ""), "paths": paths, "kernels": kernels, "fields": {}}) + "\n")
+    except Exception:
+        pass

@@ -20,8 +20,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--nx", type=int, default=400); ap.add_argument("--ny", type=int, default=400); ap.add_argument("--nz", type=int, default=100)
 ap.add_argument("--pipe", type=int, default=1, help="0: the two-stream schedule instead of the pipelined one")
+ap.add_argument("--opt", action="append", default=[], help="key=value handle option (repeatable), e.g. --opt rccl_prio=0")
 a = ap.parse_args()
 modules.DEFAULT_OPTIONS["pipe"] = a.pipe
+for kv in a.opt:
+    modules.DEFAULT_OPTIONS[kv.split("=")[0]] = int(kv.split("=")[1])
 hip = C.CDLL("libamdhip64.so")
 hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
 
@@ -46,7 +49,7 @@ def timed(dycore, coupler, dt, steps):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-res = {"schedule": "pipelined" if a.pipe else "two streams"}
+res = {"schedule": "pipelined" if a.pipe else "two streams", "options": dict(modules.DEFAULT_OPTIONS)}
 coupler, dycore, _ = modules.make_supercell(a.nx, a.ny, a.nz, 1, 500.0 * a.nx, 500.0 * a.ny, 20000.)
 dt = dycore.compute_time_step(coupler)
 start = {n: coupler.get_data_manager_readonly().get(n, True).clone() for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid", "precip_liquid")}
