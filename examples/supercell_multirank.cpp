@@ -3,11 +3,17 @@
 // (mw_dycore_rccl_allreduce_sum).  The loop is experiments/supercell_example/driver.cpp:66-79.
 //     MW_RANK=r MW_WORLD=n MW_ID_FILE=/tmp/id supercell_multirank nx_glob ny_glob nz nens xlen ylen zlen nsteps
 // Rank 0 writes the ncclUniqueId to MW_ID_FILE, the others wait for it (no MPI, no torch).  Rank r uses GPU r % (visible devices).
+// The file is tied to the launch: it starts with a 32-byte token -- MW_RUN_ID, which the launcher sets to something unique per job (its
+// PID, a time stamp) -- and a reader only accepts a file whose token is its own, so a file left behind by an earlier run is ignored
+// instead of handing the ranks a dead id.  Joining the communicator has a wall-clock limit (MW_RCCL_TIMEOUT_S, default 120): a rank whose
+// peers never arrive exits non-zero instead of hanging.
 // Every rank prints max|w| of its block and the sum of its density_dry; rank 0 also the all-reduced total mass.
 #include "../miniweatherml_amd/host/mw_facade.h"
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <cstring>
 #include <fstream>
 #include <thread>
 
@@ -37,20 +43,42 @@ int main(int argc, char **argv) {
     if (world > 1 || getenv("MW_FORCE_RCCL")) {
       if (!id_file) endrun("MW_ID_FILE is needed to hand the ncclUniqueId to the other ranks");
       unsigned char id[128];
+      char token[32]; memset(token, 0, sizeof(token));
+      if (const char *run = getenv("MW_RUN_ID")) strncpy(token, run, sizeof(token) - 1);
+      else if (world > 1) fprintf(stderr, "[rank %d] warning: MW_RUN_ID is not set -- a stale %s of an earlier run cannot be told from this run's\n", rank, id_file);
       if (rank == 0) {
+        (void)remove(id_file);                                  // (best effort; the token is what protects the readers)
         mw_check(mw_rccl_unique_id(id));
         std::string tmp = std::string(id_file) + ".tmp";
-        { std::ofstream f(tmp, std::ios::binary); f.write((const char *)id, 128); }
+        { std::ofstream f(tmp, std::ios::binary); f.write(token, sizeof(token)); f.write((const char *)id, 128); }
         if (rename(tmp.c_str(), id_file) != 0) endrun("cannot publish the ncclUniqueId");
       } else {
         bool ok = false;
         for (int t = 0; t < 600 && !ok; t++) {                   // up to 60 s
           std::ifstream f(id_file, std::ios::binary);
-          if (f && f.read((char *)id, 128) && f.gcount() == 128) ok = true; else std::this_thread::sleep_for(std::chrono::milliseconds(100));
+          char got[32];
+          if (f && f.read(got, sizeof(got)) && f.gcount() == (std::streamsize)sizeof(got) && !memcmp(got, token, sizeof(token)) &&
+              f.read((char *)id, 128) && f.gcount() == 128) ok = true;
+          else std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
-        if (!ok) endrun("rank 0 never published the ncclUniqueId");
+        if (!ok) endrun("rank 0 never published an ncclUniqueId for this run (MW_RUN_ID token mismatch or no file)");
       }
-      dycore.use_rccl(coupler, id);
+      { // ncclCommInitRank blocks until every rank has joined: a limit, so that a missing peer ends the job instead of hanging it
+        std::atomic<bool> joined{false};
+        const double limit = getenv("MW_RCCL_TIMEOUT_S") ? atof(getenv("MW_RCCL_TIMEOUT_S")) : 120.0;
+        std::thread watchdog([&joined, limit, rank]() {
+          const auto t0 = std::chrono::steady_clock::now();
+          while (!joined.load()) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+              fprintf(stderr, "[rank %d] the RCCL communicator was not formed within %.0f s: giving up\n", rank, limit);
+              _Exit(3);
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+          }
+        });
+        try { dycore.use_rccl(coupler, id); } catch (...) { joined = true; watchdog.join(); throw; }
+        joined = true; watchdog.join();
+      }
       int n = 0, r = 0, lanes = 0;
       mw_check(mw_dycore_rccl_info(dycore.handle(), &n, &r, &lanes));
       fprintf(stderr, "[rank %d] RCCL communicator: %d ranks, this is rank %d, %d lanes\n", rank, n, r, lanes);

@@ -88,7 +88,9 @@ class DataManager:
             return e, [0, 0, n_neg, -1, -1, first]
         out = (C.c_longlong * 6)()
         fn = capi.lib().mw_validate_f64 if t.dtype == torch.float64 else capi.lib().mw_validate_f32
-        capi.check(fn(t.data_ptr(), t.numel(), out, torch.cuda.current_stream(t.device).cuda_stream))
+        t = t.contiguous()                                      # (the scan walks numel() elements from data_ptr(): flat index = the reference's global index)
+        with torch.cuda.device(t.device):                       # the scan allocates and launches on the CURRENT device: make it the entry's
+            capi.check(fn(t.data_ptr(), t.numel(), out, torch.cuda.current_stream(t.device).cuda_stream))
         return e, list(out)
 
     def _report(self, what, name, count, first, die):

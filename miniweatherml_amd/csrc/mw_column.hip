@@ -89,18 +89,30 @@ __global__ __launch_bounds__(256) void k_div_scalar(double *__restrict__ a, long
   if (t < n) a[t] = a[t] / d;
 }
 
-// column_nudging.h:62-65
+// column_nudging.h:62-65.  The increment dt (column - avg) / time_scale is one number per (field, level, member): a thread computes it
+// once (the reference's expression, IEEE division) and adds it to NPT cells `nens * 256` apart -- rounds 1-4 ran one thread, and one
+// division, per cell (0.45 ms per call on config 2, twice the time its 1.9 GB take).  Fields and levels are walked in REVERSE order:
+// the sums in front of this pass read the arrays field 0 .. 4, level 0 .. nz - 1, so the last 256 MB they touched -- what the
+// Infinity Cache still holds -- are the first this pass asks for.
+static constexpr int NUDGE_NPT = 8;
 __global__ __launch_bounds__(256) void k_nudge_apply(FieldPtrs fp, int nz, long long ncell_lev, int nens, double dt,
                                                      const double *__restrict__ column, const double *__restrict__ avg) {
 #pragma clang fp contract(off)
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int k = blockIdx.y, l = blockIdx.z;
-  if (t >= ncell_lev * nens) return;
-  const int e = (int)(t % nens);
+  const int k = nz - 1 - (int)blockIdx.y, l = 4 - (int)blockIdx.z;
+  const long long n = ncell_lev * nens;
+  const long long stride = 256ll * nens;                       // (a multiple of nens: every cell of a thread belongs to one member)
+  const long long t0 = (long long)blockIdx.x * (stride * NUDGE_NPT) + (long long)threadIdx.x * nens;
   const double time_scale = 900;
-  const long long m = ((long long)l * nz + k) * nens + e;
-  double *q = fp.f[l] + (long long)k * ncell_lev * nens + t;
-  *q = *q + dt * (column[m] - avg[m]) / time_scale;
+  double *q = fp.f[l] + (long long)k * n;
+  for (int e = 0; e < nens; e++) {
+    const long long m = ((long long)l * nz + k) * nens + e;
+    const double inc = dt * (column[m] - avg[m]) / time_scale;
+    double v[NUDGE_NPT];
+#pragma unroll
+    for (int c = 0; c < NUDGE_NPT; c++) { const long long t = t0 + c * stride + e; v[c] = (t < n) ? q[t] : 0.0; }
+#pragma unroll
+    for (int c = 0; c < NUDGE_NPT; c++) { const long long t = t0 + c * stride + e; if (t < n) q[t] = v[c] + inc; }
+  }
 }
 
 } // namespace mw
@@ -190,7 +202,7 @@ int mw_nudge_to_column(const mw_grid_t *g, double *const *state5, const double *
   FieldPtrs fp;
   for (int f = 0; f < 5; f++) fp.f[f] = state5[f];
   const long long ncell_lev = (long long)g->ny * g->nx;
-  dim3 grid((unsigned)((ncell_lev * g->nens + 255) / 256), (unsigned)g->nz, 5u);
+  dim3 grid((unsigned)((ncell_lev + 256ll * NUDGE_NPT - 1) / (256ll * NUDGE_NPT)), (unsigned)g->nz, 5u);
   hipLaunchKernelGGL(k_nudge_apply, grid, dim3(256), 0, st, fp, g->nz, ncell_lev, g->nens, dt, column, avg);
   MW_LAUNCH_CHECK();
   return 0;

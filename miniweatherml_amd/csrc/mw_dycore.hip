@@ -312,8 +312,7 @@ __global__ __launch_bounds__(256) void k_halo_xyz(DyP p, double *__restrict__ S,
 
 // Pack / unpack for a neighbour exchange (3-cell halos of all V variables; interior rows only, like :606-631,:725-747)
 // W/E buffers (V,nz,ny,HX,nens), S/N buffers (V,nz,HY,nx,nens).
-__global__ __launch_bounds__(256) void k_pack_x(DyP p, const double *__restrict__ S, double *__restrict__ bW, double *__restrict__ bE) {
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_x_body(const DyP &p, const double *__restrict__ S, double *__restrict__ bW, double *__restrict__ bE, long long t) {
   long long n = (long long)p.V * p.nz * p.ny * p.HX * p.nens;
   if (t >= n) return;
   long long r = t;
@@ -325,8 +324,7 @@ __global__ __launch_bounds__(256) void k_pack_x(DyP p, const double *__restrict_
   bW[t] = row[(long long)(p.HX + h) * p.nens];              // my first HX interior cells -> west neighbour's east halo
   bE[t] = row[(long long)(p.nx + h) * p.nens];              // my last  HX interior cells -> east neighbour's west halo
 }
-__global__ __launch_bounds__(256) void k_unpack_x(DyP p, double *__restrict__ S, const double *__restrict__ bW, const double *__restrict__ bE) {
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void unpack_x_body(const DyP &p, double *__restrict__ S, const double *__restrict__ bW, const double *__restrict__ bE, long long t) {
   long long n = (long long)p.V * p.nz * p.ny * p.HX * p.nens;
   if (t >= n) return;
   long long r = t;
@@ -338,8 +336,7 @@ __global__ __launch_bounds__(256) void k_unpack_x(DyP p, double *__restrict__ S,
   row[(long long)h * p.nens]                 = bW[t];       // received from west
   row[(long long)(p.nx + p.HX + h) * p.nens] = bE[t];       // received from east
 }
-__global__ __launch_bounds__(256) void k_pack_y(DyP p, const double *__restrict__ S, double *__restrict__ bS, double *__restrict__ bN) {
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_y_body(const DyP &p, const double *__restrict__ S, double *__restrict__ bS, double *__restrict__ bN, long long t) {
   int NXI = p.nx * p.nens;
   long long n = (long long)p.V * p.nz * p.HY * NXI;
   if (t >= n) return;
@@ -351,8 +348,7 @@ __global__ __launch_bounds__(256) void k_pack_y(DyP p, const double *__restrict_
   bS[t] = col[(long long)(p.HY + h) * p.sJ];
   bN[t] = col[(long long)(p.ny + h) * p.sJ];
 }
-__global__ __launch_bounds__(256) void k_unpack_y(DyP p, double *__restrict__ S, const double *__restrict__ bS, const double *__restrict__ bN) {
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void unpack_y_body(const DyP &p, double *__restrict__ S, const double *__restrict__ bS, const double *__restrict__ bN, long long t) {
   int NXI = p.nx * p.nens;
   long long n = (long long)p.V * p.nz * p.HY * NXI;
   if (t >= n) return;
@@ -363,6 +359,20 @@ __global__ __launch_bounds__(256) void k_unpack_y(DyP p, double *__restrict__ S,
   double *col = S + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;
   col[(long long)h * p.sJ]                 = bS[t];
   col[(long long)(p.ny + p.HY + h) * p.sJ] = bN[t];
+}
+
+// Both directions in ONE launch (round 5; blocks [0, nbx) pack / unpack the W / E strips, the rest the S / N strips -- nbx or the rest
+// may be 0): an exchange is a chain pack -> transfer -> unpack on a stream that shares the chip with the big stencil kernels, where every
+// launch waits for a workgroup slot; two launches per exchange instead of four shorten the chain (tools/exchange_serial_probe.py).
+__global__ __launch_bounds__(256) void k_pack_xy(DyP p, const double *__restrict__ S, double *__restrict__ bW, double *__restrict__ bE,
+                                                 double *__restrict__ bS, double *__restrict__ bN, unsigned nbx) {
+  if (blockIdx.x < nbx) pack_x_body(p, S, bW, bE, (long long)blockIdx.x * 256 + threadIdx.x);
+  else pack_y_body(p, S, bS, bN, (long long)(blockIdx.x - nbx) * 256 + threadIdx.x);
+}
+__global__ __launch_bounds__(256) void k_unpack_xy(DyP p, double *__restrict__ S, const double *__restrict__ bW, const double *__restrict__ bE,
+                                                   const double *__restrict__ bS, const double *__restrict__ bN, unsigned nbx) {
+  if (blockIdx.x < nbx) unpack_x_body(p, S, bW, bE, (long long)blockIdx.x * 256 + threadIdx.x);
+  else unpack_y_body(p, S, bS, bN, (long long)(blockIdx.x - nbx) * 256 + threadIdx.x);
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -1127,8 +1137,8 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
     // Directions with a single rank still wrap locally below.
     for (int e = 0; e < nv_views; e++) {
       DyP q; double *S; member(e, q, S);
-      if (ex_x) { MW_KLAUNCH(k_pack_x, dim3((unsigned)((mWE + 255) / 256)), dim3(256), 0, st, q, S, bf[0] + e * mWE, bf[1] + e * mWE); MW_LAUNCH_CHECK(); }
-      if (ex_y) { MW_KLAUNCH(k_pack_y, dim3((unsigned)((mSN + 255) / 256)), dim3(256), 0, st, q, S, bf[2] + e * mSN, bf[3] + e * mSN); MW_LAUNCH_CHECK(); }
+      const unsigned nbx = ex_x ? (unsigned)((mWE + 255) / 256) : 0u, nby = ex_y ? (unsigned)((mSN + 255) / 256) : 0u;
+      MW_KLAUNCH(k_pack_xy, dim3(nbx + nby), dim3(256), 0, st, q, S, bf[0] + e * mWE, bf[1] + e * mWE, bf[2] + e * mSN, bf[3] + e * mSN, nbx); MW_LAUNCH_CHECK();
     }
     int rc = d->xchg(d->xchg_ctx, ex_x ? bf[0] : nullptr, ex_x ? bf[1] : nullptr, ex_y ? bf[2] : nullptr, ex_y ? bf[3] : nullptr,
                      ex_x ? bf[4] : nullptr, ex_x ? bf[5] : nullptr, ex_y ? bf[6] : nullptr, ex_y ? bf[7] : nullptr, ex_x ? nWE : 0,
@@ -1136,8 +1146,8 @@ static int halo_fill(mw_dycore_s *d, double *Sbase, int v0 = 0, int nv = -1, hip
     if (rc) MW_FAIL("halo exchange callback failed");
     for (int e = 0; e < nv_views; e++) {
       DyP q; double *S; member(e, q, S);
-      if (ex_x) { MW_KLAUNCH(k_unpack_x, dim3((unsigned)((mWE + 255) / 256)), dim3(256), 0, st, q, S, bf[4] + e * mWE, bf[5] + e * mWE); MW_LAUNCH_CHECK(); }
-      if (ex_y) { MW_KLAUNCH(k_unpack_y, dim3((unsigned)((mSN + 255) / 256)), dim3(256), 0, st, q, S, bf[6] + e * mSN, bf[7] + e * mSN); MW_LAUNCH_CHECK(); }
+      const unsigned nbx = ex_x ? (unsigned)((mWE + 255) / 256) : 0u, nby = ex_y ? (unsigned)((mSN + 255) / 256) : 0u;
+      MW_KLAUNCH(k_unpack_xy, dim3(nbx + nby), dim3(256), 0, st, q, S, bf[4] + e * mWE, bf[5] + e * mWE, bf[6] + e * mSN, bf[7] + e * mSN, nbx); MW_LAUNCH_CHECK();
     }
   }
   // local wrap / BC:  x when this direction has one rank (periodic self-wrap), or a wall / open boundary on a domain-edge rank.
@@ -1402,6 +1412,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
   ProfScope ps(d, 5, st);
   // the cells the pipelined schedule converted up front (time_step): the converting launch leaves them alone (see k_y_all)
   const int pre_lo = (conv && part == 1) ? d->pre_lo : 0, pre_hi = (conv && part == 1) ? d->pre_hi : 0;
+  int fy_skip = 0;                                              // (set below where the inner launch shares its first / last face with the edge strips' launch)
   if (conv && d->member_major) {                                // mm_direct: all members in one launch, the members of the same cells in one workgroup
     const View v = view(d, 0);
     const DyP &p = v.p;
@@ -1414,8 +1425,9 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     if (part == 1 && !p.wrap_y) {                               // (pipelined schedule: the inner rows; the edge strips come from the slab later)
       const int n = (int)grid.y;
       row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk);
+      fy_skip = 3;
     }
-#define MW_YAM(K_, O_, T_) MW_KLAUNCH((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, st, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, nullptr, pre_lo, pre_hi)
+#define MW_YAM(K_, O_, T_) MW_KLAUNCH((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, st, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, nullptr, pre_lo, pre_hi, fy_skip)
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
     if (marching_config(d, p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
@@ -1436,7 +1448,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
       const bool split = p.ny >= 4 * MW_Y_EDGE;                 // (an inner chunk reads up to 3 rows beyond its own: MW_Y_EDGE >= 3)
       if (part == 1) {
         if (edges) { if (!split) continue; row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; rstride = chunk;
-                     grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk); }
+                     grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk); fy_skip = 3; }
       } else {
         if (!edges) continue;
         if (split) { chunk = MW_Y_EDGE; rstride = p.ny - MW_Y_EDGE; grid.y = 2u; }
@@ -1446,7 +1458,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
 #define MW_YA(C_, K_, O_, T_) do { dim3 g_ = grid; const Sched *sc_ = (part == 2) ? nullptr : \
                                   pick_sched(d, (const void *)&k_y_all<C_, K_, O_, T_>, 0, (long long)grid.x, row_end - row0, g_, 0); \
                                 MW_KLAUNCH((k_y_all<C_, K_, O_, T_>), g_, dim3(256), 0, st, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
-                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_, pre_lo, pre_hi); } while (0)
+                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_, pre_lo, pre_hi, fy_skip); } while (0)
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
     const int K = marching_config(d, p);

@@ -630,8 +630,11 @@ __device__ __forceinline__ double tracer_slab_value(double rho_t, double inv_den
 template <bool CONV, int K, int ORD, int T, bool MT = false>
 __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk,
                                                CouplerPtrs c, double *__restrict__ Sw, MemberOff mo, int row0, int rstride, int row_end,
-                                               const Sched *__restrict__ scp, int pre_lo, int pre_hi) {
+                                               const Sched *__restrict__ scp, int pre_lo, int pre_hi, int fy_skip) {
   static_assert(!MT || CONV, "the member-co-located form exists for the converting launch only");
+  // (fy_skip: the pipelined multi-rank schedule runs the inner rows and the two edge strips as TWO launches, possibly of two different
+  //  instantiations, side by side on two streams; both compute the faces row0 and row_end they share.  The edge launch owns their tracer
+  //  fluxes: bit 0 / bit 1 = this launch does not store face row0 / row_end -- one writer per face, whatever the compiler contracted where.)
   constexpr int NV = 5 + T;
   // (pre_lo < pre_hi: the pipelined multi-rank schedule has converted the strips it packs for the neighbours up front -- the HX cells
   //  next to the block's west / east edge in every row, and the rows outside [pre_lo, pre_hi) -- with k_coupler_to_state_fast on this
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
         for (int tr = 0; tr < T; tr++) landed(raw.tr[tr]);
       }
       else landed(nxt);                                        // the iteration's loads, in front of its stores (see landed())
-      if (face) {
+      if (face && !((fy_skip & 1) && j == row0) && !((fy_skip & 2) && j == row_end)) {
 #pragma unroll
         for (int v = 0; v < T; v++) {                          // scalar copies first (a select between two arrays' elements would go through scratch)
           const double sv = se[5 + v], cv = cn[5 + v];

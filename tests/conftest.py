@@ -99,7 +99,7 @@ def pytest_sessionfinish(session, exitstatus):
 # launch (the calibration kernels and test aids of mw_calib.h, and the other modules' kernels, are not part of this path)
 _DISPATCHED = {"k_y_all", "k_y_state", "k_y_tracers", "k_xz_state", "k_tracers_fused", "k_tracer_patch", "k_xz_tracers", "k_tracer_update",
                "k_flux", "k_fct", "k_update", "k_coupler_to_state", "k_coupler_to_state_fast", "k_coupler_to_member", "k_member_to_coupler",
-               "k_member_to_fused", "k_halo_xyz", "k_pack_x", "k_pack_y", "k_unpack_x", "k_unpack_y", "k_init_cells", "k_perturb_temperature",
+               "k_member_to_fused", "k_halo_xyz", "k_pack_xy", "k_unpack_xy", "k_init_cells", "k_perturb_temperature",
                "k_perturb_temperature_random", "k_state_xyz"}
 
 

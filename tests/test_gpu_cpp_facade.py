@@ -108,7 +108,7 @@ def _multirank(world, args, tmp_path, extra_env=None):
     idf = str(tmp_path / "nccl_id")
     procs = []
     for r in range(world):
-        env = dict(os.environ, MW_RANK=str(r), MW_WORLD=str(world), MW_ID_FILE=idf, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, MW_RANK=str(r), MW_WORLD=str(world), MW_ID_FILE=idf, MW_RUN_ID="pytest-%d" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.update(extra_env or {})
         procs.append(subprocess.Popen([exe] + [str(a) for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
