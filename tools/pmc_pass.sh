@@ -5,7 +5,7 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${tag} -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-micro > /dev/null 2> $R/gpurun_out/pmc_${tag}.err
+rocprofv3 --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${tag} -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-micro --no-pmc --no-calib > /dev/null 2> $R/gpurun_out/pmc_${tag}.err
 cd $R
 python3 - "$tag" <<'PY'
 import csv, glob, sys, collections

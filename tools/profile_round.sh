@@ -6,9 +6,9 @@ tag=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-micro $*"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-micro --no-pmc --no-calib $*"      # (no nested rocprofv3 children under the profiler)
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_stats -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${tag}_bench.json 2> $R/gpurun_out/prof_${tag}_stats.err
-PARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-micro $*"
+PARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-micro --no-pmc --no-calib $*"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${tag}_f -- python3 $R/bench.py $PARGS > /dev/null 2> $R/gpurun_out/prof_${tag}_f.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${tag}_w -- python3 $R/bench.py $PARGS > /dev/null 2> $R/gpurun_out/prof_${tag}_w.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $R/gpurun_out/prof_${tag}_sq -- python3 $R/bench.py $PARGS > /dev/null 2> $R/gpurun_out/prof_${tag}_sq.err
