@@ -32,7 +32,9 @@ micro   : after the timed region (the headline is untouched): Kessler (two state
           developed_ms_per_step (a seeded stress state: rims everywhere) and storm.ms_per_step / value_storm (the real storm after
           --storm-steps steps of the complete supercell_example loop).  simulation_loop / value_simulation_loop: the wall clock of that whole
           loop -- the reference's own timed region (community_benchmark/driver.cpp:66-82), the storm developing inside it; value_storm and
-          value_simulation_loop, not the cloud-free `value`, are the regression metrics.
+          value_simulation_loop, not the cloud-free `value`, are the regression metrics.  transport_self_loop: rank 0's block of the
+          1 x 2 / 2 x 2 / 4 x 2 decompositions with the built-in RCCL transport in its self-loop form (every peer is this rank on a 1-rank
+          communicator) -- what the exchange costs beside the stencils with the real send / receive groups, on one GPU; not a multi-GPU number.
 cpu_baseline: the CPU oracle (a port: the reference itself is unbuildable here) timed on one host core
           on BASELINE.json configs[0] (supercell 200x200x50), rank 0, N = 1 only.
 """
@@ -76,6 +78,7 @@ def parse():
     ap.add_argument("--no-micro", action="store_true", help="skip the Kessler / MLP / developed-state section after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 --pmc child processes that count HBM bytes / VALU "
                     "instructions of this very run's kernels (roofline.traffic, fp64_valu); the committed summary is quoted instead")
+    ap.add_argument("--no-selfloop", action="store_true", help="skip the micro section's run of the RCCL self-loop transport (rank 0's block of 2 / 4 / 8 ranks)")
     ap.add_argument("--no-calib", action="store_true", help="skip the fp64 FMA ceiling / arithmetic floor / streaming-copy calibration after the timed region")
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)      # the child's mode: a few dycore steps, nothing else
     ap.add_argument("--timeout-s", type=float, default=float(os.environ.get("MW_BENCH_TIMEOUT_S", "900")),
@@ -352,6 +355,35 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
                         "max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()),
                         "rain_max": float(f2.get("precip_liquid").max())}
         res["value_storm"] = ncell / storm_ms * 1e3
+    # ---- what the strip exchange costs beside the stencils, with the REAL transport, on this one GPU: rank 0's block of the 1 x 2, 2 x 2
+    # and 4 x 2 decompositions the driver's N = 2, 4, 8 runs use, the built-in RCCL transport in its self-loop form (every peer is this rank
+    # on a 1-rank communicator: mw_dycore_use_rccl_self; the block's own state tiled periodically, so the run is physical and -- tests --
+    # bitwise the one-rank run).  The strips move through local HBM instead of xGMI; pack / group / unpack, the side streams, the pipelined
+    # schedule and the contention with the compute kernels are the real ones.  NOT a multi-GPU measurement.
+    if nens == 1 and not getattr(a, "no_selfloop", False):
+        try:
+            import ctypes as C
+            from miniweatherml_amd import capi
+            base_ms = timed(lambda: dycore.time_step(coupler, dt), 10)
+            emu = {"what": "rank 0's block of an N-rank decomposition with the built-in RCCL transport in self-loop form on ONE GPU (mw_dycore_use_rccl_self); "
+                           "ratio = one-rank ms / N-rank-block ms: what the weak-scaling efficiency of the dycore step would be if xGMI behaved like the "
+                           "self-loop.  Not a multi-GPU measurement.", "one_rank_ms": base_ms, "ranks": {}}
+            for nr in (2, 4, 8):
+                g = capi.Grid()
+                capi.check(capi.lib().mw_decompose(nr, 0, nx * nr, ny * nr, C.byref(g)))
+                npx, npy = g.nproc_x, g.nproc_y
+                xl, yl = float(coupler.get_xlen()), float(coupler.get_ylen())
+                c3, d3, _ = modules.make_supercell(nx * npx, ny * npy, nz, 1, xl * npx, yl * npy, 20000.0, "supercell", rho_d.device, nranks=nr, myrank=0, ord=a.ord)
+                for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid", "precip_liquid"):
+                    c3.get_data_manager_readwrite().get(n).copy_(dm.get(n))
+                modules.use_rccl_self_exchange(d3, c3)
+                ms = timed(lambda: d3.time_step(c3, dt), 10)
+                emu["ranks"][str(nr)] = {"rank_grid": "%dx%d" % (npx, npy), "ms_per_step": ms, "ratio": base_ms / ms, "path": d3.path()}
+                del c3, d3
+                torch.cuda.empty_cache()
+            res["transport_self_loop"] = emu
+        except Exception as e:                                   # evidence, not the measurement
+            res["transport_self_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
 
 

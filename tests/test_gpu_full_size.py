@@ -345,3 +345,58 @@ def test_y_faces_of_all_variables_in_one_launch_equal_the_two_launches(mw, oracl
         dycore.time_step(coupler, dt)
         odyc.time_step(of, dt)
     compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "k_y_all %dx%dx%d WENO-%d, 2 steps" % (nx, ny, nz, order))
+
+
+@pytest.mark.parametrize("schedule", ["pipelined", "two_stream"])
+def test_config4_8_rank_block_over_the_rccl_self_loop(mw, monkeypatch, schedule):
+    """BASELINE.json configs[3] in the form the 8-GPU job runs it, at FULL size on one GPU: rank 0's 256 x 512 x 128 x 4 block of the
+    4 x 2 decomposition with the built-in RCCL transport (33.6 / 16.8 MB strips per direction and stage through ncclSend / ncclRecv groups
+    on the side stream, mw_dycore_use_rccl_self: every peer is this rank, i.e. the 1024 x 1024 domain is the periodic tiling of the block)
+    against the one-rank run of the block: bit for bit, members differing, after two steps."""
+    from miniweatherml_amd import modules
+    if schedule == "two_stream":
+        set_options(monkeypatch, pipe=0)
+    nx, ny, nz, nens = 256, 512, 128, 4
+    ref = modules.make_supercell(nx, ny, nz, nens, 800.0 * nx, 800.0 * ny, 20000.)
+    til = modules.make_supercell(4 * nx, 2 * ny, nz, nens, 3200.0 * nx, 1600.0 * ny, 20000., nranks=8, myrank=0)
+    (rc, rd, _), (tc, td, _) = ref, til
+    assert (tc.grid.nproc_x, tc.grid.nproc_y, tc.get_nx(), tc.get_ny()) == (4, 2, nx, ny)
+    rc.get_data_manager_readwrite().get("temp").add_(0.05 * torch.arange(nens, device=rc.device, dtype=torch.float64))
+    for n in ("density_dry", "uvel", "vvel", "wvel", "temp") + tuple(rc.get_tracer_names()):
+        tc.get_data_manager_readwrite().get(n).copy_(rc.get_data_manager_readonly().get(n, True))
+    modules.use_rccl_self_exchange(td, tc)
+    dt = rd.compute_time_step(rc)
+    for _ in range(2):
+        rd.time_step(rc, dt)
+        td.time_step(tc, dt)
+    assert "mm_direct" in td.path() and ("pipe" if schedule == "pipelined" else "two_stream") in td.path() and "transport" in td.path(), td.path()
+    for n in ("density_dry", "uvel", "vvel", "wvel", "temp") + tuple(rc.get_tracer_names()):
+        assert torch.equal(tc.get_data_manager_readonly().get(n, True), rc.get_data_manager_readonly().get(n, True)), n
+    t = rc.get_data_manager_readonly().get("temp", True)
+    assert not torch.equal(t[..., 0], t[..., 1])
+    del ref, til, rc, rd, tc, td
+    torch.cuda.empty_cache()
+
+
+def test_config5_8_rank_block_over_the_rccl_self_loop(mw):
+    """BASELINE.json configs[4]'s weak-scaling block (128 x 256 x 256 of the 4 x 2 decomposition, simple_city: immersed buildings, V = 6) with
+    the built-in RCCL transport in self-loop form against the one-rank run of the block: bit for bit after two steps."""
+    from miniweatherml_amd import modules
+    nx, ny, nz = 128, 256, 256
+    rc, rd, _, _ = modules.make_simple_city(nx, ny, nz, 1, 5.0 * nx, 5.0 * ny, 5.0 * nz, "building")
+    tc, td, _, _ = modules.make_simple_city(4 * nx, 2 * ny, nz, 1, 20.0 * nx, 10.0 * ny, 5.0 * nz, "building", nranks=8, myrank=0)
+    for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor"):
+        tc.get_data_manager_readwrite().get(n).copy_(rc.get_data_manager_readonly().get(n, True))
+    imm = rd.immersed_proportion(rc)
+    assert float(imm.max()) == 1.0
+    td.immersed_proportion(tc).copy_(imm)
+    modules.use_rccl_self_exchange(td, tc)
+    dt = rd.compute_time_step(rc)
+    for _ in range(2):
+        rd.time_step(rc, dt)
+        td.time_step(tc, dt)
+    assert "K2" in td.path() and "pipe" in td.path(), td.path()
+    for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor"):
+        assert torch.equal(tc.get_data_manager_readonly().get(n, True), rc.get_data_manager_readonly().get(n, True)), n
+    del rc, rd, tc, td
+    torch.cuda.empty_cache()
