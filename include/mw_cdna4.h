@@ -99,10 +99,10 @@ int  mw_dycore_set_strict(mw_dycore_t h, int strict);
  * switches of rounds 1-4: typed integers stored in the handle, read when the schedule of a time step is decided; no entry point of this
  * library reads the environment per call (the two process defaults left: MW_STRICT=1 at mw_dycore_create, MW_RCCL_LANES for the
  * built-in transport).  Schedule: "overlap" (-1 automatic | 0 | 1: the two-stream schedule), "pipe" (1: the pipelined schedule of a
- * decomposed block), "pipe_edge_inline", "pipe_convert".  Kernel forms: "spec" (folded configurations), "wrap" (index wrap on one
+ * decomposed block), "pipe_edge_inline", "pipe_convert", "pipe_split_edges".  Kernel forms: "spec" (folded configurations), "wrap" (index wrap on one
  * rank), "y_all", "y_all_conv", "member_major", "mm_direct", "mm_conv", "fused_convert", "fused_convert_mm", "fused_tracers", "tf_rows4".
  * Launch shapes: "chunk_y", "chunk_yt", "chunk_z", "chunk_f" (cells per chunk, 0 = the chunk model), "chunk_model".  Built-in transport
- * (read when mw_dycore_use_rccl / _self installs it): "rccl_lanes" (0 = process default | 1 | 2), "rccl_two_comms" (-1 | 0 | 1), "rccl_prio" (1: side streams at the highest priority),
+ * (read when mw_dycore_use_rccl / _self installs it): "rccl_lanes" (0 = process default | 1 | 2), "rccl_two_comms" (-1 | 0 | 1), "rccl_prio" (1: side streams at the highest priority), "rccl_inline" (1: the group runs on the caller's stream, no side stream),
  * "xchg_fuzz" (seed of random delays around the sends / receives; a test aid).  Experiments that are not part of the release build:
  * "fused_state", "debug_no_patch" (-DMW_EXPERIMENTS), "sched", "sched_mask" (-DMW_SCHED_LISTS) -- setting them on a build without
  * them is an error.  Unknown keys and out-of-range values are errors. */

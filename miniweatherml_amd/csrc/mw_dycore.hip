@@ -905,6 +905,7 @@ struct DyOpts {
   int pipe = 1;                // with a transport: the pipelined one-stream schedule (rk_stage_pipe) where k_y_all applies
   int pipe_edge_inline = 0;    // ... its two edge strips of the y launch on the compute stream instead of the exchange stream
   int pipe_convert = 1;        // ... D1 of the inner rows inside the first k_y_all<true>
+  int pipe_split_edges = 1;    // ... the next stage's edge strips split into a state part (behind the state strips) and a tracer part
   int spec = 1;                // folded configurations of the marching kernels (Cf<1>, Cf<2>)
   int wrap = 1;                // index wrap instead of halo cells in a periodic direction owned by one rank
   int y_all = 1, y_all_conv = 1;      // y faces of all variables in one launch; ... also the converting first stage
@@ -916,6 +917,7 @@ struct DyOpts {
   int rccl_lanes = 0, rccl_two_comms = -1;            // built-in RCCL transport: side streams (1 | 2), a communicator per lane (0 | 1); 0 / -1 = the
                                                       // process default (MW_RCCL_LANES); read when mw_dycore_use_rccl* installs the transport
   int rccl_prio = 1;           // ... its side streams at the highest stream priority (0: default priority; A/B)
+  int rccl_inline = 1;         // ... the send / receive group on the caller's stream instead of a side stream of the transport's own
   int xchg_fuzz = 0;           // test aid: seeded random delays (spin kernels) around the built-in transport's sends / receives
   int fused_state = 0, debug_no_patch = 0;            // -DMW_EXPERIMENTS builds only (mw_fused.h; the negative control of the FCT patch pass)
   int sched = 0, sched_mask = 7;                      // -DMW_SCHED_LISTS builds only (balanced launch lists)
@@ -940,7 +942,7 @@ struct mw_dycore_s {
   int pipe = 0;                              // blocks of a decomposed domain: pipelined one-stream schedule (rk_stage_pipe)
   bool pipe_ready = false;                   // ... the next stage's input strips are already on their way (event ev_pipe[2])
   bool pipe_edge_done = false;               // ... and its two edge strips of the y launch were issued behind them on the exchange stream
-  hipEvent_t ev_pipe[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_pipe[4] = {nullptr, nullptr, nullptr, nullptr};   // [0], [1]: compute -> exchange stream; [2]: state strips + state edge rows ready; [3]: tracer strips + tracer edge faces ready
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
@@ -1344,10 +1346,14 @@ static int marching_config(const mw_dycore_s *d, const DyP &p) {
   return 0;
 }
 
+#define MW_Y_EDGE 4                                            // rows of an edge strip of the pipelined schedule (>= 4: the converting inner launch requests coupler rows up to row_end + 3 < ny)
 // conv != nullptr: the slab S is still empty -- the kernel converts the coupler's fields on the way and fills it (k_y_state<true>)
-static int launch_y_state(mw_dycore_s *d, const double *S, int par, const CouplerPtrs *conv = nullptr) {
+// edges: only the two MW_Y_EDGE-row strips at the block's south / north end (pipelined multi-rank schedule, on stream st); a block too
+// short to split (see launch_y_all) takes all its rows here
+static int launch_y_state(mw_dycore_s *d, const double *S, int par, const CouplerPtrs *conv = nullptr, bool edges = false, hipStream_t st = nullptr) {
   if (d->p.sim2d) return 0;
-  ProfScope ps(d, 5);
+  if (!st) st = d->stream;
+  ProfScope ps(d, 5, st);
   if (conv && d->member_major) {
     // D1 inside the launch, member-major handle: ONE launch over the fused lanes (k_y_state<.., MM>): unit-stride reads of the
     // coupler's arrays, outputs into the members' arrays.  The folded configuration is decided on a member's view (nens = 1 there).
@@ -1385,8 +1391,9 @@ static int launch_y_state(mw_dycore_s *d, const double *S, int par, const Couple
     // measured on 400x400x100 (625 wave columns): 8 x 50 rows for k_y_state, 14 x 29 for k_y_tracers (-5 % / -2 % vs. 32-row chunks)
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(d, p.ny, (threads + 63) / 64, d->o.chunk_y, 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
+    if (edges && p.ny >= 4 * MW_Y_EDGE) { chunk = -MW_Y_EDGE; grid.y = 2u; }      // (k_y_state: chunk < 0 = the two edge strips)
     double *MY = d->M[par][1] + e * v.m[1]; unsigned char *UY = d->UP[par][1] + e * v.m[1];
-#define MW_YS(CONV_, K_, O_, cp, sw) MW_KLAUNCH((k_y_state<CONV_, K_, O_>), grid, dim3(256), 0, d->stream, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw, YMember())
+#define MW_YS(CONV_, K_, O_, cp, sw) MW_KLAUNCH((k_y_state<CONV_, K_, O_>), grid, dim3(256), 0, st, p, v.S(S), MY, UY, d->tendY + e * v.tend, chunk, cp, sw, YMember())
 #define MW_YS_K(K_) { if (d->ord == 3) { if (conv) MW_YS(true, K_, 3, *conv, Sw); else MW_YS(false, K_, 3, CouplerPtrs(), nullptr); } \
                       else             { if (conv) MW_YS(true, K_, 5, *conv, Sw); else MW_YS(false, K_, 5, CouplerPtrs(), nullptr); } }
     double *Sw = const_cast<double *>(v.S(S));
@@ -1406,7 +1413,6 @@ static bool y_all_ok(const mw_dycore_s *d) {
 }
 // part: 0 = all rows; 1 = the rows whose chunks read no halo row (all of them with the row wrap), 2 = the two edge strips of
 // MW_Y_EDGE rows (short chunks: their launch runs between the exchange and k_xz_state, with a quarter of the wavefronts)
-#define MW_Y_EDGE 4                                            // (>= 4: the converting inner launch requests coupler rows up to row_end + 3 < ny)
 static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv, int part = 0, hipStream_t st = nullptr) {
   if (!st) st = d->stream;
   ProfScope ps(d, 5, st);
@@ -1474,7 +1480,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
   return 0;
 }
 
-static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_t st) {
+static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_t st, bool edges = false) {
   if (d->p.sim2d) return 0;
   ProfScope ps(d, 6, st);
   for (int e = 0; e < n_views(d); e++) {
@@ -1483,6 +1489,7 @@ static int launch_y_tracers(mw_dycore_s *d, const double *S, int par, hipStream_
     long long threads = (long long)p.nz * p.nx * p.nens;
     int chunk = d->chunk_yt ? d->chunk_yt : (d->chunk_yt = balanced_chunk(d, p.ny, (threads + 63) / 64, d->o.chunk_yt, 8400, 3, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
+    if (edges && p.ny >= 4 * MW_Y_EDGE) { chunk = -MW_Y_EDGE; grid.y = 2u; }      // (k_y_tracers: chunk < 0 = the two edge strips)
     double *FY = d->FY + e * v.f[1];
     for (int t0 = 0; t0 < p.nt; t0 += 4) {
       int cnt = std::min(4, p.nt - t0);
@@ -1803,16 +1810,26 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   // (round 4: the two edge strips of the y launch run on the EXCHANGE stream right behind the unpack kernels -- beside the inner rows on
   //  the compute stream -- instead of behind them: a launch of 2 x 157 workgroups no longer sits alone between k_y_all and k_xz_state)
   const bool edge_side = !d->o.pipe_edge_inline;
+  // (round 5: the edge strips of the NEXT stage's y launch are SPLIT by what they wait for.  Their state part -- y tendencies of the edge
+  //  rows, k_y_state -- only needs the state strips, which travel beside this stage's tracer kernel: it runs right behind them, and
+  //  k_xz_state of the next stage waits for nothing else.  Their tracer part -- the tracer y fluxes of the edge faces, k_y_tracers, which
+  //  only the next stage's TRACER kernel reads -- runs behind the tracer strips and has the next stage's inner y rows AND its k_xz_state
+  //  to hide behind.  Before, k_xz_state waited for the whole tracer chain (pack, group, unpack, edge launch: 0.3-0.4 ms of idle compute
+  //  stream per stage in the rocprofv3 timeline of the self-loop transport).  pipe_split_edges = 0: one k_y_all edge launch
+  //  behind the tracer strips, as in rounds 3-4.)
+  const bool split_edges = edge_side && d->o.pipe_split_edges;
+  const int par_next = (int)((gs + 1) & 1);
   if (!d->pipe_ready) {                                       // this stage's input has not been exchanged yet
     MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
     if (halo_fill(d, Sin, 0, -1, xs, 0, true)) return 1;
     if (edge_side && launch_y_all(d, Sin, nullptr, 2, xs)) return 1;
     MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
+    MW_HIP(hipEventRecord(d->ev_pipe[3], xs));
     d->pipe_edge_done = edge_side;
   }
   d->pipe_ready = false;
   if (launch_y_all(d, Sin, conv ? &c : nullptr, 1)) return 1;  // rows whose chunks read no halo row
-  MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));
+  MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));           // state strips (+ the edge rows' y tendencies) of this stage's input
   if (!d->pipe_edge_done && launch_y_all(d, Sin, nullptr, 2)) return 1;   // first and last chunk
   d->pipe_edge_done = false;
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;
@@ -1820,13 +1837,20 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   if (early) {
     MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
     if (halo_fill(d, Sout, 0, 5, xs, 0, true)) return 1;      // state strips, beside the tracer stage
+    if (split_edges) {
+      if (launch_y_state(d, Sout, par_next, nullptr, true, xs)) return 1;   // ... and the state part of the NEXT stage's edge strips right behind them
+      MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
+    }
   }
+  MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[3], 0));           // tracer strips + the edge faces' tracer fluxes of this stage's input
   if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ss)) return 1;
   if (early) {
     MW_HIP(hipEventRecord(d->ev_pipe[1], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[1], 0));
-    if (halo_fill(d, Sout, 5, T, xs, 1, true)) return 1;      // tracer strips, beside the next stage's interior y chunks
-    if (edge_side && launch_y_all(d, Sout, nullptr, 2, xs)) return 1;   // ... and the NEXT stage's edge strips right behind them
-    MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
+    if (halo_fill(d, Sout, 5, T, xs, 1, true)) return 1;      // tracer strips, beside the next stage's interior y chunks (and, split, its k_xz_state)
+    if (split_edges) { if (launch_y_tracers(d, Sout, par_next, xs, true)) return 1; }                    // the tracer part of the next stage's edge strips
+    else if (edge_side && launch_y_all(d, Sout, nullptr, 2, xs)) return 1;                               // ... or both parts in one launch
+    if (!split_edges) MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
+    MW_HIP(hipEventRecord(d->ev_pipe[3], xs));
     d->pipe_ready = true; d->pipe_edge_done = edge_side;
   }
   return 0;
@@ -1964,7 +1988,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
     for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
                                     hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
     if (hipEventCreateWithFlags(&d->ev_misc, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 4; i++)
       if (hipEventCreateWithFlags(&d->ev_pipe[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
   }
   fill_params(d);
@@ -1983,7 +2007,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
-  for (int i = 0; i < 3; i++) if (d->ev_pipe[i]) (void)hipEventDestroy(d->ev_pipe[i]);
+  for (int i = 0; i < 4; i++) if (d->ev_pipe[i]) (void)hipEventDestroy(d->ev_pipe[i]);
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
@@ -2012,13 +2036,13 @@ namespace {
 struct OptDesc { const char *key; int DyOpts::*field; long long lo, hi; int build; };   // build: 0 any, 1 -DMW_EXPERIMENTS, 2 -DMW_SCHED_LISTS
 const OptDesc OPTS[] = {
   {"overlap", &DyOpts::overlap, -1, 1, 0}, {"pipe", &DyOpts::pipe, 0, 1, 0}, {"pipe_edge_inline", &DyOpts::pipe_edge_inline, 0, 1, 0},
-  {"pipe_convert", &DyOpts::pipe_convert, 0, 1, 0}, {"spec", &DyOpts::spec, 0, 1, 0}, {"wrap", &DyOpts::wrap, 0, 1, 0},
+  {"pipe_convert", &DyOpts::pipe_convert, 0, 1, 0}, {"pipe_split_edges", &DyOpts::pipe_split_edges, 0, 1, 0}, {"spec", &DyOpts::spec, 0, 1, 0}, {"wrap", &DyOpts::wrap, 0, 1, 0},
   {"y_all", &DyOpts::y_all, 0, 1, 0}, {"y_all_conv", &DyOpts::y_all_conv, 0, 1, 0}, {"member_major", &DyOpts::member_major, 0, 1, 0},
   {"mm_direct", &DyOpts::mm_direct, 0, 1, 0}, {"mm_conv", &DyOpts::mm_conv, 0, 1, 0}, {"fused_convert", &DyOpts::fused_convert, 0, 1, 0},
   {"fused_convert_mm", &DyOpts::fused_convert_mm, 0, 1, 0}, {"chunk_y", &DyOpts::chunk_y, 0, 1 << 20, 0}, {"chunk_yt", &DyOpts::chunk_yt, 0, 1 << 20, 0},
   {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
   {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
-  {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0},
+  {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0}, {"rccl_inline", &DyOpts::rccl_inline, 0, 1, 0},
   {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
   {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},
 };

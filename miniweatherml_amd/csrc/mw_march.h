@@ -416,8 +416,10 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   if (t >= (long long)p.nz * NXI) return;
   const int k = (int)(t / NXI);
   const int ie = (int)(t - (long long)k * NXI);
-  const int ja = blockIdx.y * chunk;
-  const int jb = min(ja + chunk, p.ny);
+  // (chunk < 0: the two EDGE strips of -chunk rows at the block's south and north end -- grid.y = 2 -- for the pipelined multi-rank
+  //  schedule, which runs them on the exchange stream as soon as the state strips have arrived; see rk_stage_pipe)
+  const int ja = chunk < 0 ? (blockIdx.y ? p.ny + chunk : 0) : (int)blockIdx.y * chunk;
+  const int jb = chunk < 0 ? ja - chunk : min(ja + chunk, p.ny);
   const int e = ie % p.nens;
   const double *hp = p.hypk + (long long)(k * p.nens + e) * 8;
   const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
@@ -553,8 +555,8 @@ __global__ __launch_bounds__(256) void k_y_tracers(DyP p, const double *__restri
   if (t >= (long long)p.nz * NXI) return;
   const int k = (int)(t / NXI);
   const int ie = (int)(t - (long long)k * NXI);
-  const int ja = blockIdx.y * chunk;
-  const int jb = min(ja + chunk, p.ny);
+  const int ja = chunk < 0 ? (blockIdx.y ? p.ny + chunk : 0) : (int)blockIdx.y * chunk;      // (chunk < 0: the two edge strips, see k_y_state)
+  const int jb = chunk < 0 ? ja - chunk : min(ja + chunk, p.ny);
   const double *col = S + (long long)(5 + t0) * p.sV + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;
   double *fy = FY + (long long)k * p.fyK + ie;
   const unsigned char *upy = UPY + (long long)k * p.fyK + ie;

@@ -105,6 +105,7 @@ struct RcclCtx {
   int nlanes = 1;
   bool own_comm1 = false;                                       // lane 1 has a communicator of its own (option rccl_two_comms = 1)
   int peers[4], send_order[4], recv_order[4], active[4];        // mw_exchange_plan
+  int inline_group = 1;                                         // 1: the group runs on the CALLER's stream (option rccl_inline; see rccl_exchange)
   int self_ranks = 0;                                           // > 0: the self-loop transport (mw_dycore_use_rccl_self): this rank stands for that many identical blocks
   unsigned long long fuzz = 0;                                  // != 0: state of the delay fuzz (option xchg_fuzz = seed)
 };
@@ -182,21 +183,31 @@ int rccl_exchange(void *vctx, const double *sW, const double *sE, const double *
   MW_NEED_RCCL();
   hipStream_t main_stream = (hipStream_t)vstream;
   RcclLane &L = lane_of(c, main_stream);
-  MW_HIP(hipEventRecord(L.ev_ready, main_stream));           // pack kernels done
-  MW_HIP(hipStreamWaitEvent(L.side, L.ev_ready, 0));
-  if (c->fuzz && mw::launch_spin(fuzz_usec(c), L.side)) return 1;        // (test aid: the strips leave late)
+  // Round 5: the group runs IN LINE on the caller's stream by default.  The caller's stream is never free to do anything else between
+  // its pack and its unpack kernels -- in the pipelined schedule it is the handle's exchange stream, in the two-stream schedule a
+  // pipeline that needs the strips next -- so a side stream of the transport's own bought no overlap, and each of its two event
+  // hand-overs between hardware queues cost 50-90 us on a chip that is full of stencil workgroups (rocprofv3 timeline of the self-loop
+  // transport, DESIGN.md 0d: 2 x 3 hops per RK stage on the critical chain).  rccl_inline = 0 keeps the side stream (A/B).
+  hipStream_t gs = c->inline_group ? main_stream : L.side;
+  if (!c->inline_group) {
+    MW_HIP(hipEventRecord(L.ev_ready, main_stream));         // pack kernels done
+    MW_HIP(hipStreamWaitEvent(L.side, L.ev_ready, 0));
+  }
+  if (c->fuzz && mw::launch_spin(fuzz_usec(c), gs)) return 1;            // (test aid: the strips leave late)
   const double *sbuf[4] = {sW, sE, sS, sN};
   double *rbuf[4] = {rW, rE, rS, rN};
   const long long cnt[4] = {nWE, nWE, nSN, nSN};
   MW_NCCL(R.GroupStart());
   for (int o = 0; o < 4; o++) { int dir = c->send_order[o];
-    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Send(sbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], L.comm, L.side)); }
+    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Send(sbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], L.comm, gs)); }
   for (int o = 0; o < 4; o++) { int dir = c->recv_order[o];
-    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Recv(rbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], L.comm, L.side)); }
+    if (c->active[dir] && cnt[dir] > 0) MW_NCCL(R.Recv(rbuf[dir], (size_t)cnt[dir], ncclDouble, c->peers[dir], L.comm, gs)); }
   MW_NCCL(R.GroupEnd());
-  if (c->fuzz && mw::launch_spin(fuzz_usec(c), L.side)) return 1;        // (... and are reported complete late)
-  MW_HIP(hipEventRecord(L.ev_done, L.side));
-  MW_HIP(hipStreamWaitEvent(main_stream, L.ev_done, 0));     // unpack kernels wait for the strips
+  if (c->fuzz && mw::launch_spin(fuzz_usec(c), gs)) return 1;            // (... and are reported complete late)
+  if (!c->inline_group) {
+    MW_HIP(hipEventRecord(L.ev_done, L.side));
+    MW_HIP(hipStreamWaitEvent(main_stream, L.ev_done, 0));   // unpack kernels wait for the strips
+  }
   return 0;
 }
 } // namespace
@@ -243,6 +254,7 @@ int mw_dycore_use_rccl(mw_dycore_t h, const unsigned char *id128, int nranks, in
   if (init_lanes(c, R, nranks, myrank, lanes, two, mw::dycore_option(h, "rccl_prio"))) return fail();
   if (mw_exchange_plan(&g, c->peers, c->send_order, c->recv_order, c->active)) return fail();
   if (int seed = mw::dycore_option(h, "xchg_fuzz")) c->fuzz = 0x9E3779B97F4A7C15ULL * (unsigned long long)seed + (unsigned long long)myrank + 1;
+  c->inline_group = mw::dycore_option(h, "rccl_inline");
   if (mw::dycore_set_exchange_owned(h, rccl_exchange, c, [](void *p) { free_ctx((RcclCtx *)p); })) return fail();   // the handle frees it
   return 0;
 }
@@ -273,6 +285,7 @@ int mw_dycore_use_rccl_self(mw_dycore_t h) {
   c->recv_order[0] = 1; c->recv_order[1] = 0; c->recv_order[2] = 3; c->recv_order[3] = 2;
   c->self_ranks = g.nproc_x * g.nproc_y;
   if (int seed = mw::dycore_option(h, "xchg_fuzz")) c->fuzz = 0x9E3779B97F4A7C15ULL * (unsigned long long)seed + 1;
+  c->inline_group = mw::dycore_option(h, "rccl_inline");
   if (mw::dycore_set_exchange_owned(h, rccl_exchange, c, [](void *p) { free_ctx((RcclCtx *)p); })) return fail();
   return 0;
 }
@@ -350,6 +363,8 @@ int mw_rccl_selftest(long long n, void *vstream) {
     if (r != ncclSuccess) { c->lane[0].comm = nullptr; mw::set_error(std::string("ncclCommInitRank failed: ") + R.GetErrorString(r)); return fail(); } }
   { int lanes, two; default_lanes(lanes, two); if (g_selftest_cfg[0] > 0) { lanes = g_selftest_cfg[0]; two = g_selftest_cfg[1]; }
     if (init_lanes(c, R, 1, 0, lanes, two)) return fail(); }
+  c->inline_group = 0;                                           // (this diagnostic drives the side-stream form: lanes, event pairs; the in-line
+                                                                 //  form runs in every self-loop time-step test)
   for (int d = 0; d < 4; d++) { c->peers[d] = 0; c->send_order[d] = d; c->active[d] = 1; }
   c->recv_order[0] = 1; c->recv_order[1] = 0; c->recv_order[2] = 3; c->recv_order[3] = 2;      // E,W,N,S like mw_exchange_plan
   std::vector<double> h((size_t)4 * n), back((size_t)4 * n, -1.0);

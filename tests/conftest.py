@@ -136,8 +136,14 @@ def _coverage(session, rows):
         return None
     seen = collections.Counter(p for r in rows for p in r.get("paths", []))
     want = [path_string(c) for c in reachable_paths()]
-    ran = sum(1 for it in getattr(session, "items", []) if "test_gpu_path_matrix.py::test_path[" in it.nodeid)
-    enforced = ran == len(want) and session.exitstatus == 0
+    items = getattr(session, "items", [])
+    ran = sum(1 for it in items if "test_gpu_path_matrix.py::test_path[" in it.nodeid)
+    # enforced on a FULL `-m gpu` session only: the whole matrix ran and every tests/test_gpu_*.py file contributed items (a run of
+    # selected files still reports its coverage, without failing on what the files left out cover)
+    import glob
+    all_files = {os.path.basename(f) for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_*.py"))}
+    ran_files = {os.path.basename(it.nodeid.split("::")[0]) for it in items}
+    enforced = ran == len(want) and all_files <= ran_files and session.exitstatus == 0
     base = lambda p: p.replace(" fused_state", "")                # noqa: E731  (the -DMW_EXPERIMENTS kernel rides on a production path)
     cov = {"enforced": enforced, "paths_compared": dict(sorted(seen.items())), "reachable_paths": len(want),
            "missing_paths": sorted(set(want) - set(seen)), "unknown_paths": sorted(p for p in seen if base(p) not in set(want)),

@@ -131,7 +131,8 @@ def test_rccl_self_loop_with_delay_fuzz(mw, monkeypatch, seed):
     without waiting for its exchange, or a pack that overwrote a strip still in flight, changes bits."""
     from miniweatherml_amd import modules
     tiles = 4 if seed % 2 else 8
-    set_options(monkeypatch, xchg_fuzz=seed, pipe=0 if seed % 3 == 0 else 1, rccl_lanes=1 if seed % 4 == 0 else 0)
+    set_options(monkeypatch, xchg_fuzz=seed, pipe=0 if seed % 3 == 0 else 1, rccl_lanes=1 if seed % 4 == 0 else 0,
+                rccl_inline=seed % 2)                          # even seeds: the group on the transport's side stream (event hand-overs both ways)
     (tc, td, _), (rc, rd, _) = _tiled_supercell(tiles, 70, 36, 10, 1)
     rc.get_data_manager_readwrite().get("cloud_liquid").fill_(2.0e-4)
     _copy_state(rc, tc)
