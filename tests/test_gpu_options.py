@@ -1,0 +1,89 @@
+"""mw_dycore_set_option / mw_dycore_get_option (include/mw_cdna4.h): the typed run-time options that replaced the MW_* environment switches of
+rounds 1-4 -- defaults, round trips, error behaviour, and that the library really stopped reading the environment per call."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from util import build_has, gpu_fields
+
+pytestmark = pytest.mark.gpu
+
+DEFAULTS = {"overlap": -1, "pipe": 1, "pipe_edge_inline": 0, "pipe_convert": 1, "pipe_split_edges": 1, "spec": 1, "wrap": 1, "y_all": 1, "y_all_conv": 1,
+            "member_major": 1, "mm_direct": 1, "mm_conv": 1, "fused_convert": 1, "fused_convert_mm": 1, "fused_tracers": 1, "chunk_y": 0, "chunk_yt": 0,
+            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
+
+
+def test_defaults_round_trips_and_errors(mw):
+    from miniweatherml_amd import capi, modules
+    from miniweatherml_amd.capi import MWError
+    coupler, dycore, _ = modules.make_supercell(24, 20, 10, 1, 12000., 10000., 20000.)
+    for k, v in DEFAULTS.items():
+        assert dycore.get_option(k) == v, k
+    dycore.set_option("chunk_z", 7)
+    assert dycore.get_option("chunk_z") == 7
+    dycore.set_option("overlap", 1)
+    assert dycore.get_option("overlap") == 1
+    for bad in (("no_such_option", 1), ("overlap", 2), ("pipe", -1), ("chunk_z", -5), ("rccl_lanes", 3)):
+        with pytest.raises(MWError):
+            dycore.set_option(*bad)
+    with pytest.raises(MWError):
+        dycore.get_option("no_such_option")
+    flags = capi.lib().mw_build_flags()
+    for key, bit in (("fused_state", 1), ("debug_no_patch", 1), ("sched", 2)):
+        if flags & bit:
+            dycore.set_option(key, 1 if key != "fused_state" else 4)
+            dycore.set_option(key, 0)
+        else:
+            dycore.set_option(key, 0)                          # the default value is accepted on any build
+            with pytest.raises(MWError, match="build of libmw_cdna4 only"):
+                dycore.set_option(key, 1)
+
+
+def test_the_environment_no_longer_steers_a_handle(mw, monkeypatch):
+    """Rounds 1-4 read ~30 MW_* variables per time step / per launch.  Setting them now changes nothing: same path, same bits."""
+    from miniweatherml_amd import modules
+    res, paths = [], []
+    for env in ({}, {"MW_NO_SPEC": "1", "MW_NO_Y_ALL": "1", "MW_OVERLAP": "1", "MW_NO_WRAP": "1", "MW_CHUNK_Z": "3", "MW_FUSED_TRACERS": "0",
+                     "MW_NO_FUSED_CONVERT": "1", "MW_DEBUG_NO_PATCH": "1", "MW_FUSED_STATE": "4", "MW_SCHED": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        coupler, dycore, _ = modules.make_supercell(70, 24, 12, 1, 35000., 12000., 20000.)
+        dt = dycore.compute_time_step(coupler)
+        for _ in range(2):
+            dycore.time_step(coupler, dt)
+        res.append(gpu_fields(coupler))
+        paths.append(dycore.path())
+    assert paths[0] == paths[1] == "march ord5 K1 nens1 one_stream y_all conv_in_y tracers_fused 3d"
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
+def test_options_select_what_they_say(mw, monkeypatch):
+    from miniweatherml_amd import modules
+    want = {(): "march ord5 K1 nens1 one_stream y_all conv_in_y tracers_fused 3d",
+            (("spec", 0),): "march ord5 K0 nens1 one_stream y_all conv_in_y tracers_fused 3d",
+            (("y_all", 0),): "march ord5 K1 nens1 one_stream y_split conv_in_y tracers_fused 3d",
+            (("overlap", 1),): "march ord5 K1 nens1 two_stream y_split conv_in_y tracers_fused 3d",
+            (("fused_convert", 0),): "march ord5 K1 nens1 one_stream y_all conv_pass tracers_fused 3d",
+            (("fused_tracers", 0),): "march ord5 K1 nens1 one_stream y_split conv_in_y tracers_unfused 3d",
+            (("wrap", 0),): "march ord5 K1 nens1 one_stream y_all conv_pass tracers_fused 3d"}
+    ref = None
+    for opts, path in want.items():
+        coupler, dycore, _ = modules.make_supercell(70, 24, 12, 1, 35000., 12000., 20000.)
+        for k, v in opts:
+            dycore.set_option(k, v)
+        dt = dycore.compute_time_step(coupler)
+        for _ in range(2):
+            dycore.time_step(coupler, dt)
+        assert dycore.path() == path, (opts, dycore.path())
+        f = gpu_fields(coupler)
+        if ref is None:
+            ref = f
+        elif opts[0][0] in ("y_all", "overlap", "fused_convert", "wrap"):      # these forms are the same arithmetic on the same data: bitwise
+            for k in ref:
+                assert np.array_equal(f[k], ref[k]), (opts, k)
+        else:                                                  # (K = 0 and the unfused tracer stage: rounding-level differences at most)
+            for k in ref:
+                assert np.max(np.abs(f[k] - ref[k])) <= 1e-11 * max(np.max(np.abs(ref[k])), 1e-3), (opts, k)
