@@ -85,7 +85,7 @@ struct CouplerPtrs {
 //   K = 1 (supercell_example, supercell_kessler_surrogate, community_benchmark): gravity on, no immersed boundaries, the three
 //         Kessler tracers;
 //   K = 2 (simple_city): immersed boundaries, gravity off, water vapour only.
-// marching_config(d, ) in the host part decides; anything else runs K = 0.
+// marching_config() in the host part decides; anything else runs K = 0.
 template <int K> struct Cf {
   static constexpr bool spec = (K != 0);
   static __device__ __forceinline__ bool x_periodic(const DyP &p) { return spec || p.bc_x == MW_BC_PERIODIC; }

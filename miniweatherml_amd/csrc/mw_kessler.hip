@@ -498,7 +498,9 @@ static thread_local int g_kessler_strict = 0;        // per calling thread: a ra
 // 1: the strict path (reference operation order, glibc's pow / exp: bit-identical to the CPU oracle); 0: the production kernels
 // The pair of min words of a (device, stream): allocated and set to +inf once, then kept consistent by the kernels themselves (see
 // MW_KES_INF).  -> this call's word and the one its CFL pass resets for the next call.
-static int kessler_min_words(hipStream_t st, unsigned long long **cur, unsigned long long **next) {
+// (commit = true, after the CFL pass was launched: the call counts -- a call that failed before its CFL pass must not flip the parity,
+//  its word for the next call would never have been reset)
+static int kessler_min_words(hipStream_t st, unsigned long long **cur, unsigned long long **next, bool commit = false) {
   struct Entry { unsigned long long *w = nullptr; unsigned long long calls = 0; };
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, Entry> tab;
@@ -506,13 +508,13 @@ static int kessler_min_words(hipStream_t st, unsigned long long **cur, unsigned 
   MW_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(mu);
   Entry &e = tab[{dev, st}];
+  if (commit) { e.calls++; return 0; }
   if (!e.w) {
     const unsigned long long init[2] = {MW_KES_INF, MW_KES_INF};
     MW_HIP(hipMalloc(&e.w, 16));
     if (hipMemcpy(e.w, init, 16, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(e.w); e.w = nullptr; MW_FAIL("kessler: initialising the min words failed"); }
   }
   *cur = e.w + (e.calls & 1); *next = e.w + ((e.calls + 1) & 1);
-  e.calls++;
   return 0;
 }
 
@@ -532,6 +534,7 @@ int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *r
   if (g_kessler_strict) {
     const long long n = (long long)nz * ncol;
     hipLaunchKernelGGL(k_kessler_strict_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp, ws, bits, next_bits); MW_LAUNCH_CHECK();
+    if (kessler_min_words(st, nullptr, nullptr, true)) return 1;
     hipLaunchKernelGGL(k_kessler_strict_column, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp,
                        precl, bits, ws); MW_LAUNCH_CHECK();
     if (rainsplit_out) {
@@ -551,6 +554,7 @@ int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *r
   const int klevels = 5;                                        // levels per thread of the CFL pass (k_kessler_prep: KL)
   hipLaunchKernelGGL(k_kessler_prep, dim3((unsigned)((ncol + 255) / 256), (unsigned)((nz + klevels - 1) / klevels)), dim3(256), 0, st, p,
                      rho_r, rho_d, flux_top, chunk, klevels, bits, next_bits); MW_LAUNCH_CHECK();
+  if (kessler_min_words(st, nullptr, nullptr, true)) return 1;
 #if MW_KES_SWEEP
   hipLaunchKernelGGL(k_kessler_sweep, dim3((unsigned)((ncol + 255) / 256), (unsigned)nchunks), dim3(256), 0, st, p, rho_v, rho_c, rho_r,
                      rho_d, temp, precl, bits, ws, flux_top, chunk); MW_LAUNCH_CHECK();

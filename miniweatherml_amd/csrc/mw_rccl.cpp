@@ -3,8 +3,9 @@
 // Replaces the MPI_Isend/Irecv/Waitall pattern of halo_exchange
 // (reference: model/modules/dynamics_euler_stratified_wenofv.h:641-723; neighbour matrix coupler.h:169-179).
 //
-// One ncclGroup per exchange on a dedicated side stream: up to four sends + four receives, each peer reached
-// over its own xGMI link.  Message matching between one pair of ranks is FIFO, so when the west and east
+// One ncclGroup per exchange: up to four sends + four receives, each peer reached over its own xGMI link.  Since round 5 the group
+// runs in line on the stream the dycore hands over (the handle's exchange stream in the pipelined schedule, a pipeline's own stream
+// in the two-stream schedule); option rccl_inline = 0 keeps the transport's own side stream per lane (see rccl_exchange).  Message matching between one pair of ranks is FIFO, so when the west and east
 // (or south and north) neighbour are the same rank (2 ranks in that direction) sends are posted W,E,S,N and
 // receives E,W,N,S: the peer's first send (its W strip) is my E halo.
 // =====================================================================================================
