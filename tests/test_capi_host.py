@@ -3,6 +3,7 @@ host-only entry points agree with the oracle, and the device entry points fail L
 import ctypes as C
 import os
 import re
+import sys
 
 import pytest
 
@@ -247,3 +248,41 @@ int main(int, char **argv) {
     import torch
     if not torch.cuda.is_available():
         assert "nogpu:" in o and ("no HIP device available" in o or "device allocation failed" in o)
+
+
+def test_round5_entry_points_host_side(mw):
+    """The options / calibration / coverage entry points of round 5 as far as they go without a GPU: argument errors, the release build's
+    flags, the thread count of the arithmetic-floor launch, an empty launch registry."""
+    import torch
+    from miniweatherml_amd import capi
+    L = capi.lib()
+    v = C.c_longlong(0)
+    assert L.mw_dycore_set_option(None, b"pipe", 0) != 0 and b"null argument" in L.mw_last_error()
+    assert L.mw_dycore_get_option(None, b"pipe", C.byref(v)) != 0
+    assert L.mw_dycore_path(None) == b""
+    assert L.mw_dycore_use_rccl_self(None) != 0
+    if "MW_LIB_PATH" not in os.environ:
+        assert L.mw_build_flags() == 0                           # the shipped library contains no experiment
+    assert L.mw_calib_stage_arith_threads(16000000, 25) == 640000 and L.mw_calib_stage_arith_threads(1, 25) == 256
+    assert L.mw_calib_stage_arith_threads(0, 25) == 0
+    out5 = (C.c_double * 5)()
+    assert L.mw_calib_fma64(0, 1.0, out5, None) != 0 and L.mw_calib_fma64(2, -1.0, out5, None) != 0
+    assert L.mw_rccl_selftest_config(3, 0) != 0 and L.mw_rccl_selftest_config(0, 0) == 0
+    if not torch.cuda.is_available():
+        assert L.mw_calib_fma64(2, 0.1, out5, None) != 0 and b"no HIP device" in L.mw_last_error()
+        assert L.mw_debug_launched_kernels(None, 0, 0) == 1      # nothing launched: an empty, terminated string
+
+
+def test_dispatcher_path_space_is_well_formed():
+    """tests/util.py: reachable_paths -- the Python statement of the dispatcher's rules that the GPU path matrix realises: every path
+    spelled uniquely, the shipped configurations' paths among them."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import path_string, reachable_paths
+    paths = [path_string(c) for c in reachable_paths()]
+    assert len(paths) == len(set(paths)) == 293
+    for must in ("march ord5 K1 nens1 one_stream y_all conv_in_y tracers_fused 3d",             # configs[1], [2]: one GPU
+                 "march ord5 K1 mm_direct pipe y_all conv_pipe tracers_fused 3d transport",      # configs[3]: 8 GPUs, 4 members
+                 "march ord5 K2 nens1 pipe y_all conv_pipe tracers_fused 3d transport",          # configs[4]: simple_city, 8 GPUs
+                 "march ord3 K1 nens1 one_stream y_all conv_in_y tracers_fused 3d",              # the reference's GPU-benchmark order
+                 "general-strict ord5 nens1", "general-fast ord9 fused_members transport"):
+        assert must in paths, must

@@ -216,6 +216,8 @@ def test_stream_ordered_exchange_with_delay_fuzz(mw, monkeypatch, layout, seed):
     for t in ths:
         t.join(300)
     assert not ex.errors, ex.errors
+    torch.cuda.synchronize()
+    ex.close()
     ref = _one_rank_reference(nxg, nyg, nz, nsteps, pipe)
     for ib, jb, blk, code in results:
         assert (code & 3) == (2 if pipe else 1)

@@ -284,11 +284,23 @@ class StreamExchanger:
         hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
         hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
         hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        hip.hipStreamDestroy.argtypes = [C.c_void_p]
+        hip.hipEventDestroy.argtypes = [C.c_void_p]
         self.hip = hip
         self.lanes = {}                                            # (rank, caller stream) -> (side stream, ready event, copied event)
         self.ready = [None] * nranks
         self.copied = [None] * nranks
         self.calls = 0
+
+    def close(self):
+        """Side streams and events of this transport (call when every rank has finished and synchronised)."""
+        for side, e0, e1 in self.lanes.values():
+            self.hip.hipStreamSynchronize(side)
+            self.hip.hipEventDestroy(e0)
+            self.hip.hipEventDestroy(e1)
+            self.hip.hipStreamDestroy(side)
+        self.lanes = {}
 
     def _lane(self, rank, stream):
         key = (rank, stream or 0)
