@@ -58,6 +58,7 @@ struct DyP {                      // kernel parameter block (by value)
   int wrap_x, wrap_y;             // production path, periodic direction owned by one rank: the marching kernels wrap their x / row index
                                   // instead of reading halo cells, and that halo is not filled
   int enable_gravity, use_immersed, idWV;
+  int zero_skip;                  // marching kernels: skip the reconstructions of a tracer that is exactly zero over a wavefront's stencil (mw_march.h)
   unsigned pos_mask, mass_mask;
   double dx, dy, dz, rdx, rdy, rdz, C0, gamma, grav, fcor, R_d, R_v;
   const double *hyc, *hytc, *hye, *hyte;       // device (nz,nens) / (nz+1,nens)
@@ -914,6 +915,7 @@ struct DyOpts {
   int chunk_y = 0, chunk_yt = 0, chunk_z = 0, chunk_f = 0;   // cells per chunk of the marching kernels (0 = the chunk model)
   int chunk_model = 1;
   int tf_rows4 = 1;            // tracer stage: workgroup = 4 rows of one x tile (0: 4 tiles of one row)
+  int zero_skip = 1;           // wave-uniform short-cut for tracers that are exactly zero over a wavefront's stencil (bit-neutral; 0: A/B)
   int rccl_lanes = 0, rccl_two_comms = -1;            // built-in RCCL transport: side streams (1 | 2), a communicator per lane (0 | 1); 0 / -1 = the
                                                       // process default (MW_RCCL_LANES); read when mw_dycore_use_rccl* installs the transport
   int rccl_prio = 1;           // ... its side streams at the highest stream priority (0: default priority; A/B)
@@ -998,6 +1000,7 @@ static void fill_params(mw_dycore_s *d) {
   p.v0 = 0; p.wrap_x = 0; p.wrap_y = 0; p.cst = 1; p.ce = 0;
   p.bc_x = g.bc_x; p.bc_y = g.bc_y; p.bc_z = g.bc_z; p.px = g.px; p.py = g.py; p.nproc_x = g.nproc_x; p.nproc_y = g.nproc_y;
   p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
+  p.zero_skip = d->o.zero_skip;
   p.pos_mask = 0; p.mass_mask = 0;
   for (int t = 0; t < g.num_tracers; t++) { if (d->pos[t]) p.pos_mask |= 1u << t; if (d->adds[t]) p.mass_mask |= 1u << t; }
   p.dx = g.xlen / g.nx_glob; p.dy = g.ylen / g.ny_glob; p.dz = g.zlen / g.nz;        // coupler.h:262-268
@@ -2041,7 +2044,7 @@ const OptDesc OPTS[] = {
   {"mm_direct", &DyOpts::mm_direct, 0, 1, 0}, {"mm_conv", &DyOpts::mm_conv, 0, 1, 0}, {"fused_convert", &DyOpts::fused_convert, 0, 1, 0},
   {"fused_convert_mm", &DyOpts::fused_convert_mm, 0, 1, 0}, {"chunk_y", &DyOpts::chunk_y, 0, 1 << 20, 0}, {"chunk_yt", &DyOpts::chunk_yt, 0, 1 << 20, 0},
   {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
-  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
+  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
   {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0}, {"rccl_inline", &DyOpts::rccl_inline, 0, 1, 0},
   {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
   {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},

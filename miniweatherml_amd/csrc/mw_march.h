@@ -165,6 +165,14 @@ __device__ __forceinline__ double load_zlevel(const DyP &p, const double *__rest
   return val;
 }
 
+#ifndef MW_ZERO_SKIP
+#define MW_ZERO_SKIP 1
+#endif
+// Tracers that can be identically zero over large parts of a domain (see the zero short-cut of k_tracers_fused): everything but the
+// water vapour of the supercell set-ups; simple_city's vapour IS zero (its only tracer); with the switches at run time: all of them.
+// (DyP::zero_skip = the handle's option zero_skip: 0 switches the short-cut off at run time -- the bitwise A/B of tests/ and tools/)
+template <int K> __device__ __forceinline__ bool tracer_may_vanish(const DyP &p, int v) { return p.zero_skip && (K == 1 ? v != 0 : true); }
+
 struct FaceState {   // what the passive variables need from the Riemann solve of one face
   double m_upw;      // upwind mass flux (= flux of idR)
   int ind;           // 0: upwind is the low ("L") side, 1: the high ("R") side
@@ -708,6 +716,16 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   }
 #pragma unroll
   for (int v = 0; v < NV; v++) landed(w[v]);
+#if MW_ZERO_SKIP
+  unsigned zm[T];                                                // (the zero short-cut of k_tracers_fused, for the tracers' y windows)
+#pragma unroll
+  for (int v = 0; v < T; v++) {
+    zm[v] = 0;
+#pragma unroll
+    for (int s = 0; s < ORD; s++) zm[v] |= (__any(w[5 + v][s] != 0.0) ? 1u : 0u) << s;
+    if (!tracer_may_vanish<K>(p, v)) zm[v] = ~0u;
+  }
+#endif
   for (int j = ja - 1; j <= jb; j++) {
     const int jn = min(j + HS + 1, p.ny + p.HY - 1);            // clamp: the last prefetch is never used
     CouplerCell raw;
@@ -718,7 +736,12 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
     }
     double se[NV], ne[NV];
 #pragma unroll
-    for (int v = 0; v < NV; v++) weno_window_edges<ORD>(w[v], se[v], ne[v]);
+    for (int v = 0; v < NV; v++) {
+#if MW_ZERO_SKIP
+      if (v >= 5 && zm[v >= 5 ? v - 5 : 0] == 0u) { se[v] = 0.0; ne[v] = 0.0; continue; }
+#endif
+      weno_window_edges<ORD>(w[v], se[v], ne[v]);
+    }
     {
       const bool face = (j >= ja);
       const int jc = max(j, 0);
@@ -775,6 +798,10 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
       for (int l = 0; l < 5; l++) { if (CONV) lds_fprev[l][threadIdx.x] = f[l]; else fprev_r[l] = f[l]; }
     }
     if (CONV) MW_ROW_FINISH(raw, jn, nxt)
+#if MW_ZERO_SKIP
+#pragma unroll
+    for (int v = 0; v < T; v++) if (tracer_may_vanish<K>(p, v)) zm[v] = (zm[v] >> 1) | ((__any(nxt[5 + v] != 0.0) ? 1u : 0u) << (ORD - 1));
+#endif
 #pragma unroll
     for (int v = 0; v < NV; v++) {
       cn[v] = ne[v];
@@ -1480,6 +1507,21 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #pragma unroll
   for (int v = 0; v < T; v++) landed(w[v]);
   landed(xpn);
+#if MW_ZERO_SKIP
+  // Round 5: a tracer that is exactly ZERO over a wavefront's whole stencil (cloud and rain outside the storm; simple_city's vapour) has
+  // edge values exactly 0 -- weno5_edges_fast of five zeros is +0 -- so the reconstruction is skipped, wave-uniformly and bit-neutrally.
+  // zm[v]: bit s = "window slot s of tracer v is non-zero in some lane", kept in a scalar register and shifted with the window: one
+  // v_cmp per tracer and level when the new level has landed (and one for the patch cell of the x stencil), no test on the way in.
+  unsigned zm[T]; bool xzc[T], xzn[T];
+#pragma unroll
+  for (int v = 0; v < T; v++) {
+    zm[v] = 0; xzc[v] = false;
+#pragma unroll
+    for (int s = 0; s < ORD; s++) zm[v] |= (__any(w[v][s] != 0.0) ? 1u : 0u) << s;
+    xzn[v] = __any(xpn[v] != 0.0);
+    if (!tracer_may_vanish<K>(p, v)) { zm[v] = ~0u; xzn[v] = true; }
+  }
+#endif
   // The loop body is branch-free apart from predicated stores and the rare limiter paths: every load uses a clamped
   // (always valid) address and is issued at the top, the z reconstruction (registers only) runs while they are in flight.
   // Iterations outside a quantity's range compute values that are never stored or carried into a used result.
@@ -1498,6 +1540,10 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     double xpatch[T];                                            // level k, the cell beyond lane 0 / lane 63
 #pragma unroll
     for (int v = 0; v < T; v++) xpatch[v] = xpn[v];
+#if MW_ZERO_SKIP
+#pragma unroll
+    for (int v = 0; v < T; v++) xzc[v] = xzn[v];
+#endif
 #pragma unroll
     for (int v = 0; v < T; v++) xpn[v] = N1 ? col[(long long)v * p.sV + (long long)(min(k + 1, p.nz - 1) + p.HZ) * p.sK + opatch] : 0.0;
 #pragma unroll
@@ -1540,6 +1586,10 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     double te[T], fxn[T], fzn[T], be_[T], xe_[T];
 #pragma unroll
     for (int v = 0; v < T; v++) {                                // all reconstructions first: they need no loaded operand
+#if MW_ZERO_SKIP
+      if (zm[v] == 0u) { be_[v] = 0.0; te[v] = 0.0; }
+      else
+#endif
       weno_window_edges<ORD>(w[v], be_[v], te[v]);
       if (!cell) be_[v] = 0;
       if (MW_FENCED) MW_SCHED_FENCE();
@@ -1548,6 +1598,14 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       const bool quirk = bc_mode_x<K>(p, i) == 3;
 #pragma unroll
       for (int v = 0; v < T; v++) {
+#if MW_ZERO_SKIP
+        if (N1 && !quirk && !((zm[v] >> HS) & 1u) && !xzc[v]) {   // the wave's whole x stencil of this level is zero
+          be_[v] = upz ? be_[v] : ct[v];
+          xe_[v] = 0.0;
+          if (MW_FENCED) MW_SCHED_FENCE();
+          continue;
+        }
+#endif
         double c0 = w[v][HS], m2 = nbw2[v], m1 = nbw1[v], p1 = nbe1[v], p2 = nbe2[v];
         if (N1) {                                              // whole-wave DPP shifts
           m1 = dpp_mov_old<0x138>(xpatch[v], c0); p1 = dpp_mov_old<0x130>(xpatch[v], c0);   // lanes 0 / 63 keep the loaded cell
@@ -1646,6 +1704,15 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     }
     // ------------------------------------------------ carries
     rhos2 = rhop;
+#if MW_ZERO_SKIP
+#pragma unroll
+    for (int v = 0; v < T; v++) {
+      if (tracer_may_vanish<K>(p, v)) {
+        zm[v] = (zm[v] >> 1) | ((__any(nxt[v] != 0.0) ? 1u : 0u) << (ORD - 1));
+        xzn[v] = __any(xpn[v] != 0.0);
+      }
+    }
+#endif
 #pragma unroll
     for (int v = 0; v < T; v++) {
       fxp[v] = fxn[v]; fzp[v] = fzn[v]; szf[v] = szn[v]; P[v] = Pn[v];

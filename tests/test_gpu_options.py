@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"overlap": -1, "pipe": 1, "pipe_edge_inline": 0, "pipe_convert": 1, "pipe_split_edges": 1, "spec": 1, "wrap": 1, "y_all": 1, "y_all_conv": 1,
             "member_major": 1, "mm_direct": 1, "mm_conv": 1, "fused_convert": 1, "fused_convert_mm": 1, "fused_tracers": 1, "chunk_y": 0, "chunk_yt": 0,
-            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
+            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
 
 
 def test_defaults_round_trips_and_errors(mw):
@@ -87,3 +87,36 @@ def test_options_select_what_they_say(mw, monkeypatch):
         else:                                                  # (K = 0 and the unfused tracer stage: rounding-level differences at most)
             for k in ref:
                 assert np.max(np.abs(f[k] - ref[k])) <= 1e-11 * max(np.max(np.abs(ref[k])), 1e-3), (opts, k)
+
+
+@pytest.mark.parametrize("case", ["cloud_free", "one_storm", "city", "nens4", "ord3"])
+def test_zero_tracer_shortcut_is_bit_neutral(mw, case):
+    """Option zero_skip (default 1): the marching kernels skip the reconstructions of a tracer that is exactly zero over a wavefront's whole
+    stencil (cloud and rain outside a storm, simple_city's vapour) -- the skipped reconstruction would have returned +0.  Same bits with the
+    short-cut switched off, on a cloud-free state, on a state whose cloud / rain fill one box (wavefronts of all three kinds: empty, full,
+    cut by the box's faces in x, y and z), on the city, with four members and at WENO-3; one step sub-cycled."""
+    import torch
+    from miniweatherml_amd import modules
+    res = []
+    for skip in (1, 0):
+        if case == "city":
+            coupler, dycore, _, _ = modules.make_simple_city(96, 48, 16, 1, 480., 240., 80., "building")
+        else:
+            nens, order = (4 if case == "nens4" else 1), (3 if case == "ord3" else 5)
+            coupler, dycore, _ = modules.make_supercell(130, 44, 26, nens, 65000., 22000., 20000., ord=order)
+            dm = coupler.get_data_manager_readwrite()
+            if case != "cloud_free":
+                box = torch.zeros_like(dm.get("density_dry"))
+                box[3:15, 9:31, 37:101] = 1.0
+                dm.get("cloud_liquid").copy_(3.0e-4 * box * dm.get("density_dry"))
+                dm.get("precip_liquid").copy_(1.0e-4 * box * dm.get("density_dry") * (1.0 + 0.1 * torch.arange(nens, device=box.device)))
+        dycore.set_option("zero_skip", skip)
+        dycore.set_option("chunk_z", 7); dycore.set_option("chunk_f", 7); dycore.set_option("chunk_y", 9)
+        dt = dycore.compute_time_step(coupler)
+        for n in range(3):
+            dycore.time_step(coupler, dt * (2.2 if n == 1 else 1.0))
+        res.append(gpu_fields(coupler))
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+    if case == "one_storm":
+        assert float(res[0]["tracer1"].max()) > 0.0 and float((res[0]["tracer1"] == 0).mean()) > 0.5
