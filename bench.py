@@ -723,6 +723,8 @@ def main():
                                           "configs[2]" if a.workload == "config3" else "configs[1]",
                        "parallelism": "%dx%d slab" % (npx, npy), "halo_transport": transport, "V": V, "strict": a.strict, "weno_order": a.ord,
                        "schedule": sched["streams"], "schedule_code": sched["code"], "y_faces_in_one_launch": sched["y_all"],
+                       "dispatcher_path": dycore.path(),
+                       "zero_tracer_shortcut": bool(dycore.get_option("zero_skip")),   # (bit-neutral: tracers that are exactly 0 over a wavefront's stencil are not reconstructed)
                        "rccl_ranks": (infos[0] or {}).get("comm_ranks") if world > 1 else None,
                        "rccl_per_rank": infos if world > 1 else None,
                        "alg_bytes_per_cell_update": 64 * V,
