@@ -171,12 +171,13 @@ int  mw_calib_copy(const double *in, double *out, long long n, void *stream);
  * mw_calib_stage_arith: the arithmetic of one RK stage and nothing else -- per cell 24 WENO-5 reconstructions + 3 Riemann solves + the
  * passive fluxes (the production arithmetic) on register windows fed from `tab`, DEVICE (nlev >= 6, 8, 64) doubles that stay in L2
  * (variables rho', u, v, w, (rho theta)', q_v, q_c, q_r of a 64-cell row; smooth or rough data as the caller likes), `levels` cells per
- * thread, 256-thread workgroups, two per CU (k_xz_state's shape and register budget).  bg4 (HOST): hy_dens, hy_dens_theta, C0
+ * thread, 256-thread workgroups, two per CU (k_xz_state's shape and register budget).  active_tracers = 3: all 24 reconstructions; 1: cloud and rain
+ * exactly zero, which the production kernels do not reconstruct (option zero_skip): 18 per cell, the floor of a stage on a cloud-free state.  bg4 (HOST): hy_dens, hy_dens_theta, C0
  * hy_dens_theta^gamma, 1 / hy_dens_theta of the level.  sink: DEVICE, mw_calib_stage_arith_threads(cells, levels) doubles.  out3
  * (HOST): ms of the timed launch, cells processed, workgroups.  No stage of that many cells can take less on this chip. */
 int  mw_calib_fma64(int waves_per_simd, double seconds, double *out5, void *stream);
 long long mw_calib_stage_arith_threads(long long cells, int levels);
-int  mw_calib_stage_arith(const double *tab, int nlev, long long cells, int levels, const double *bg4, double *sink, double *out3, void *stream);
+int  mw_calib_stage_arith(const double *tab, int nlev, long long cells, int levels, int active_tracers, const double *bg4, double *sink, double *out3, void *stream);
 /* Test aid: occupies `stream` for about `usec` microseconds (delay fuzz of the exchange tests). */
 int  mw_debug_spin(long long usec, void *stream);
 /* Test aid: the names (as the code object spells them -- mangled; newline-separated) of the dycore kernels this PROCESS has launched since

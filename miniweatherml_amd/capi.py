@@ -59,7 +59,7 @@ SYMBOLS = {
     "mw_build_flags": (C.c_int, []),
     "mw_calib_fma64": (C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_double), C.c_void_p]),
     "mw_calib_stage_arith_threads": (C.c_longlong, [C.c_longlong, C.c_int]),
-    "mw_calib_stage_arith": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
+    "mw_calib_stage_arith": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "mw_debug_spin": (C.c_int, [C.c_longlong, C.c_void_p]),
     "mw_debug_launched_kernels": (C.c_longlong, [C.c_char_p, C.c_longlong, C.c_int]),
     "mw_dycore_path": (C.c_char_p, [C.c_void_p]),

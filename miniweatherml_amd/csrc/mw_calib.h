@@ -60,14 +60,17 @@ __device__ __forceinline__ FaceState riemann_floor(double rL, double rR, double 
 
 // One stage's arithmetic per cell.  tab: (nlev, 8, 64) doubles -- level k of a 64-lane row of the eight reconstruction variables
 // (rho', u, v, w, (rho theta)', three tracers); every wave reads the same rows (L2 hits).  bg: hyr, hyt, p0, 1/hyt of the level.
+// NV = 8: all three tracers are reconstructed (24 reconstructions per cell); NV = 6: cloud and rain are exactly zero and take the production
+// kernels' zero short-cut (mw_march.h, MW_ZERO_SKIP) -- 18 reconstructions per cell: the floor of a stage on a cloud-free state.
+template <int NV>
 __global__ __launch_bounds__(256, 2) void k_calib_stage_arith(const double *__restrict__ tab, int nlev, int levels, double hyr, double hyt,
                                                               double p0, double ihyt, double *__restrict__ sink) {
   const int lane = threadIdx.x & 63;
   const double *col = tab + lane;
-  double w[8][5], nxt[8], ct[8];
+  double w[NV][5], nxt[NV], ct[NV];
   int kt = (int)((blockIdx.x * 7u + (threadIdx.x >> 6)) % (unsigned)nlev);     // (every wave starts somewhere else in the table)
 #pragma unroll
-  for (int v = 0; v < 8; v++) {
+  for (int v = 0; v < NV; v++) {
     ct[v] = 0;
 #pragma unroll
     for (int s = 0; s < 5; s++) w[v][s] = col[((long long)((kt + s) % nlev) * 8 + v) * 64];
@@ -75,56 +78,56 @@ __global__ __launch_bounds__(256, 2) void k_calib_stage_arith(const double *__re
   kt = (kt + 5) % nlev;
   double acc = 0;
 #pragma unroll
-  for (int v = 0; v < 8; v++) landed(w[v]);
+  for (int v = 0; v < NV; v++) landed(w[v]);
   for (int k = 0; k < levels; k++) {
 #pragma unroll
-    for (int v = 0; v < 8; v++) nxt[v] = col[((long long)kt * 8 + v) * 64];
+    for (int v = 0; v < NV; v++) nxt[v] = col[((long long)kt * 8 + v) * 64];
     kt = (kt + 1 == nlev) ? 0 : kt + 1;
     // z direction: the window as it is;  "x" and "y": the same five values in two other orders (nothing is shared between the three
     // reconstructions of a variable: their first differences all differ).  One direction at a time, its Riemann solve right behind it
     // (the production kernels' order; all 48 edge values at once would not fit the register file).
     double f = 0;
     {   // z face: lower cell's top edge (carried) against this cell's bottom edge
-      double be[8], te[8];
+      double be[NV], te[NV];
 #pragma unroll
-      for (int v = 0; v < 8; v++) { weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be[v], te[v]); if (v & 1) MW_SCHED_FENCE(); }
+      for (int v = 0; v < NV; v++) { weno5_edges_fast(w[v][0], w[v][1], w[v][2], w[v][3], w[v][4], be[v], te[v]); if (v & 1) MW_SCHED_FENCE(); }
       double fn, fT;
       const FaceState fs = riemann_floor(ct[idR] + hyr, be[idR] + hyr, ct[idW], be[idW], ct[idT], be[idT], hyt, p0, ihyt, fn, fT);
       f += fs.m_upw + fn + fT;
       f += fs.m_upw * (fs.ind ? be[idU] : ct[idU]) + fs.m_upw * (fs.ind ? be[idV] : ct[idV]);
 #pragma unroll
-      for (int t = 5; t < 8; t++) f += fs.m_upw * (fs.ind ? be[t] : ct[t]);
+      for (int t = 5; t < NV; t++) f += fs.m_upw * (fs.ind ? be[t] : ct[t]);
 #pragma unroll
-      for (int v = 0; v < 8; v++) ct[v] = te[v];
+      for (int v = 0; v < NV; v++) ct[v] = te[v];
     }
     MW_SCHED_FENCE();
     {   // "x" face
-      double we[8], ee[8];
+      double we[NV], ee[NV];
 #pragma unroll
-      for (int v = 0; v < 8; v++) { weno5_edges_fast(w[v][1], w[v][0], w[v][2], w[v][4], w[v][3], we[v], ee[v]); if (v & 1) MW_SCHED_FENCE(); }
+      for (int v = 0; v < NV; v++) { weno5_edges_fast(w[v][1], w[v][0], w[v][2], w[v][4], w[v][3], we[v], ee[v]); if (v & 1) MW_SCHED_FENCE(); }
       double fn, fT;
       const FaceState fs = riemann_floor(ee[idR] + hyr, we[idR] + hyr, ee[idU], we[idU], ee[idT], we[idT], hyt, p0, ihyt, fn, fT);
       f += fs.m_upw + fn + fT;
       f += fs.m_upw * (fs.ind ? we[idV] : ee[idV]) + fs.m_upw * (fs.ind ? we[idW] : ee[idW]);
 #pragma unroll
-      for (int t = 5; t < 8; t++) f += fs.m_upw * (fs.ind ? we[t] : ee[t]);
+      for (int t = 5; t < NV; t++) f += fs.m_upw * (fs.ind ? we[t] : ee[t]);
     }
     MW_SCHED_FENCE();
     {   // "y" face
-      double se[8], ne[8];
+      double se[NV], ne[NV];
 #pragma unroll
-      for (int v = 0; v < 8; v++) { weno5_edges_fast(w[v][3], w[v][1], w[v][2], w[v][0], w[v][4], se[v], ne[v]); if (v & 1) MW_SCHED_FENCE(); }
+      for (int v = 0; v < NV; v++) { weno5_edges_fast(w[v][3], w[v][1], w[v][2], w[v][0], w[v][4], se[v], ne[v]); if (v & 1) MW_SCHED_FENCE(); }
       double fn, fT;
       const FaceState fs = riemann_floor(ne[idR] + hyr, se[idR] + hyr, ne[idV], se[idV], ne[idT], se[idT], hyt, p0, ihyt, fn, fT);
       f += fs.m_upw + fn + fT;
       f += fs.m_upw * (fs.ind ? se[idU] : ne[idU]) + fs.m_upw * (fs.ind ? se[idW] : ne[idW]);
 #pragma unroll
-      for (int t = 5; t < 8; t++) f += fs.m_upw * (fs.ind ? se[t] : ne[t]);
+      for (int t = 5; t < NV; t++) f += fs.m_upw * (fs.ind ? se[t] : ne[t]);
     }
     acc += f;
     landed(nxt);
 #pragma unroll
-    for (int v = 0; v < 8; v++) {
+    for (int v = 0; v < NV; v++) {
 #pragma unroll
       for (int s = 0; s < 4; s++) w[v][s] = w[v][s + 1];
       w[v][4] = nxt[v];

@@ -2433,8 +2433,9 @@ long long mw_calib_stage_arith_threads(long long cells, int levels) {
   const long long thr = (cells + levels - 1) / levels;
   return ((thr + 255) / 256) * 256;
 }
-int mw_calib_stage_arith(const double *tab, int nlev, long long cells, int levels, const double *bg4, double *sink, double *out3, void *stream) {
+int mw_calib_stage_arith(const double *tab, int nlev, long long cells, int levels, int active_tracers, const double *bg4, double *sink, double *out3, void *stream) {
   if (!tab || nlev < 6 || cells < 1 || levels < 1 || !bg4 || !sink || !out3) MW_FAIL("mw_calib_stage_arith: bad argument (nlev >= 6)");
+  if (active_tracers != 1 && active_tracers != 3) MW_FAIL("mw_calib_stage_arith: active_tracers must be 3 (24 reconstructions per cell) or 1 (cloud and rain zero: 18)");
   if (mw_device_count() < 1) MW_FAIL("no HIP device available: libmw_cdna4 has no CPU fallback");
   hipStream_t st = (hipStream_t)stream;
   const long long thr = mw_calib_stage_arith_threads(cells, levels);
@@ -2443,7 +2444,8 @@ int mw_calib_stage_arith(const double *tab, int nlev, long long cells, int level
   float ms = 0; int rc = 0;
   for (int rep = 0; rep < 2 && !rc; rep++) {                     // (the second launch is the measurement)
     if (hipEventRecord(e0, st) != hipSuccess) rc = 1;
-    MW_KLAUNCH(k_calib_stage_arith, dim3((unsigned)(thr / 256)), dim3(256), 0, st, tab, nlev, levels, bg4[0], bg4[1], bg4[2], bg4[3], sink);
+    if (active_tracers == 3) MW_KLAUNCH((k_calib_stage_arith<8>), dim3((unsigned)(thr / 256)), dim3(256), 0, st, tab, nlev, levels, bg4[0], bg4[1], bg4[2], bg4[3], sink);
+    else                     MW_KLAUNCH((k_calib_stage_arith<6>), dim3((unsigned)(thr / 256)), dim3(256), 0, st, tab, nlev, levels, bg4[0], bg4[1], bg4[2], bg4[3], sink);
     if (hipGetLastError() != hipSuccess || hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
         hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = 1;
   }

@@ -11,5 +11,5 @@ from miniweatherml_amd import calib
 
 sec = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 out = {"fma64": [calib.fma64(w, sec) for w in (1, 2, 4, 8)],
-       "stage_arith": [calib.stage_arith(kind, levels=lv) for kind in ("smooth", "rough") for lv in (25, 100)]}
+       "stage_arith": [calib.stage_arith(kind, levels=lv) for kind in ("smooth", "cloud_free", "rough") for lv in (25, 100)]}
 print(json.dumps(out))
