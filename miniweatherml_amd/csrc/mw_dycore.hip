@@ -59,6 +59,10 @@ struct DyP {                      // kernel parameter block (by value)
                                   // instead of reading halo cells, and that halo is not filled
   int enable_gravity, use_immersed, idWV;
   int zero_skip;                  // marching kernels: skip the reconstructions of a tracer that is exactly zero over a wavefront's stencil (mw_march.h)
+  // zero-row map of the current RK stage (mw_march.h: k_zero_rows), nullptr = none: one word per (level, row), bit v = "tracer v may be
+  // non-zero in what iterations k-3 .. k of the row's marching wave touch"; word of (k, j) at [k * zq_ld + j + HY]
+  const unsigned *zq;
+  int zq_ld;
   unsigned pos_mask, mass_mask;
   double dx, dy, dz, rdx, rdy, rdz, C0, gamma, grav, fcor, R_d, R_v;
   const double *hyc, *hytc, *hye, *hyte;       // device (nz,nens) / (nz+1,nens)
@@ -916,6 +920,7 @@ struct DyOpts {
   int chunk_model = 1;
   int tf_rows4 = 1;            // tracer stage: workgroup = 4 rows of one x tile (0: 4 tiles of one row)
   int zero_skip = 1;           // wave-uniform short-cut for tracers that are exactly zero over a wavefront's stencil (bit-neutral; 0: A/B)
+  int zero_rows = 1;           // ... and the zero-row maps on top of it: rows of a tracer that are known to be zero are not loaded (mw_march.h: k_zero_rows)
   int rccl_lanes = 0, rccl_two_comms = -1;            // built-in RCCL transport: side streams (1 | 2), a communicator per lane (0 | 1); 0 / -1 = the
                                                       // process default (MW_RCCL_LANES); read when mw_dycore_use_rccl* installs the transport
   int rccl_prio = 1;           // ... its side streams at the highest stream priority (0: default priority; A/B)
@@ -944,7 +949,7 @@ struct mw_dycore_s {
   int pipe = 0;                              // blocks of a decomposed domain: pipelined one-stream schedule (rk_stage_pipe)
   bool pipe_ready = false;                   // ... the next stage's input strips are already on their way (event ev_pipe[2])
   bool pipe_edge_done = false;               // ... and its two edge strips of the y launch were issued behind them on the exchange stream
-  hipEvent_t ev_pipe[4] = {nullptr, nullptr, nullptr, nullptr};   // [0], [1]: compute -> exchange stream; [2]: state strips + state edge rows ready; [3]: tracer strips + tracer edge faces ready
+  hipEvent_t ev_pipe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [0], [1]: compute -> exchange stream; [2]: state strips + state edge rows ready; [3]: tracer strips + tracer edge faces ready; [4]: zero-row maps ready
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
@@ -953,6 +958,8 @@ struct mw_dycore_s {
   unsigned int *dirty = nullptr;           // two words: "a y face was scaled in this / the next fused tracer launch"
   unsigned long long fused_launches = 0;
   unsigned char *flags = nullptr;          // fused tracer stage: per-cell "a y face of this cell was FCT-scaled" bits
+  double *zrx = nullptr;                   // ... and the message buffers of a decomposed block's map exchange (own | rW | rE | sS | sN | rS | rN)
+  unsigned *zr = nullptr; long long zr_msz = 0; bool zr_on = false;   // zero-row maps M0, Q1..Q3 of the running sub-cycle (mw_march.h: k_zero_rows), zr_msz words each
   int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows (see DyP::hypk)
   double *imm = nullptr;
@@ -1001,6 +1008,7 @@ static void fill_params(mw_dycore_s *d) {
   p.bc_x = g.bc_x; p.bc_y = g.bc_y; p.bc_z = g.bc_z; p.px = g.px; p.py = g.py; p.nproc_x = g.nproc_x; p.nproc_y = g.nproc_y;
   p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
   p.zero_skip = d->o.zero_skip;
+  p.zq = nullptr; p.zq_ld = 0;                                  // (set per RK stage by zero_rows_stage)
   p.pos_mask = 0; p.mass_mask = 0;
   for (int t = 0; t < g.num_tracers; t++) { if (d->pos[t]) p.pos_mask |= 1u << t; if (d->adds[t]) p.mass_mask |= 1u << t; }
   p.dx = g.xlen / g.nx_glob; p.dy = g.ylen / g.ny_glob; p.dz = g.zlen / g.nz;        // coupler.h:262-268
@@ -1745,6 +1753,8 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
 // mass fluxes / selectors / new density of their stage (event ev_state); the state pipeline may not run more than
 // one stage ahead because the M/UP buffers are double-buffered and the four slabs rotate (event ev_tr of stage s-2).
 // ---------------------------------------------------------------------------------------------------------------------
+static void zero_rows_stage(mw_dycore_s *d, int stage);
+static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st);
 template <int STAGE, int MODE>
 static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double *Sout, double dt_stage, double dt_dyn,
                           const CouplerPtrs &c) {
@@ -1752,6 +1762,7 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   const int par = (int)(gs & 1), slot = (int)(gs & 7);
   hipStream_t ss = d->stream, ts = d->overlap ? d->tstream : d->stream;
   const int T = d->p.nt;
+  zero_rows_stage(d, STAGE);
   ProfScope stage_scope(d, 8, ss);                            // one-stream schedule: first launch to last launch of the stage
   if (d->overlap && gs >= 2) MW_HIP(hipStreamWaitEvent(ss, d->ev_tr[(gs - 2) & 7], 0));
   // ---- state pipeline
@@ -1829,7 +1840,12 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
     MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
     MW_HIP(hipEventRecord(d->ev_pipe[3], xs));
     d->pipe_edge_done = edge_side;
+    if (STAGE == 1) {                                           // the sub-cycle's zero-row maps, behind the strips: needed by the tracer kernel only
+      if (zero_rows_build(d, Sin, c, conv, xs)) return 1;
+      if (d->zr_on) MW_HIP(hipEventRecord(d->ev_pipe[4], xs));
+    }
   }
+  zero_rows_stage(d, STAGE);
   d->pipe_ready = false;
   if (launch_y_all(d, Sin, conv ? &c : nullptr, 1)) return 1;  // rows whose chunks read no halo row
   MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));           // state strips (+ the edge rows' y tendencies) of this stage's input
@@ -1846,6 +1862,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
     }
   }
   MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[3], 0));           // tracer strips + the edge faces' tracer fluxes of this stage's input
+  if (STAGE == 1 && d->zr_on) MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[4], 0));
   if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ss)) return 1;
   if (early) {
     MW_HIP(hipEventRecord(d->ev_pipe[1], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[1], 0));
@@ -1858,9 +1875,78 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   }
   return 0;
 }
+// Zero-row maps (mw_march.h: k_zero_rows).  Which handles: nens == 1, fused tracer stage, x and y periodic; one rank on the one-stream
+// schedule, or the blocks of a decomposed domain on the pipelined schedule.  The ranks of a decomposed domain exchange maps, so all of
+// them must decide alike: the size test looks at the smallest block of the decomposition, not at this rank's.
+static bool zero_rows_ok(const mw_dycore_s *d) {
+  const DyP &p = d->p;
+  if (!(d->o.zero_skip && d->o.zero_rows && d->fused && p.nens == 1 && p.nt >= 1 && p.nt <= 4 && !p.sim2d && !d->member_major &&
+        !fused_state_ok(d) && p.nz >= 2 && p.bc_x == MW_BC_PERIODIC && p.bc_y == MW_BC_PERIODIC)) return false;
+  const long long nx_min = d->g.nx_glob / std::max(1, p.nproc_x), ny_min = d->g.ny_glob / std::max(1, p.nproc_y);
+  if (ny_min < MW_ZR_HALO || nx_min < 2 * MW_ZR_HALO) return false;   // (a tracer must not cross a whole block in one sub-cycle)
+  if (!d->xchg) return !d->overlap && !d->pipe;
+  return d->pipe != 0;
+}
+// ... built at the start of a sub-cycle from its input on stream `st`: the coupler's arrays while the conversion is still pending (it
+// happens inside the first y launch), slab S0 otherwise.  Blocks of a decomposed domain: + the neighbours' maps (see k_zero_merge).
+static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st) {
+  d->zr_on = zero_rows_ok(d);
+  if (!d->zr_on) return 0;
+  DyP &p = d->p;
+  const int ld = p.ny + 2 * MW_ZR_HALO;
+  const long long msz = (long long)p.nz * ld;
+  const bool ex_x = d->xchg && p.nproc_x > 1, ex_y = d->xchg && p.nproc_y > 1;
+  const long long nrow = (long long)p.nz * p.ny, nedge = (long long)p.nz * MW_ZR_HALO;
+  const long long dWE = (nrow + 1) / 2, dSN = (nedge + 1) / 2;   // message lengths in doubles (the transport's unit)
+  if (!d->zr || d->zr_msz != msz) {
+    if (d->zr) { MW_HIP(hipDeviceSynchronize()); (void)hipFree(d->zr); d->zr = nullptr; }
+    if (d->zrx) { (void)hipFree(d->zrx); d->zrx = nullptr; }
+    if (hipMalloc(&d->zr, 4 * (size_t)msz * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }
+    d->zr_msz = msz;
+  }
+  if ((ex_x || ex_y) && !d->zrx) {
+    if (hipMalloc(&d->zrx, (size_t)(3 * dWE + 4 * dSN) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); MW_FAIL("zero-row maps: out of device memory"); }
+    // (a failure here is an error, not a fall-back: the other ranks are about to exchange maps)
+  }
+  p.zq_ld = ld;
+  const int K = marching_config(d, p);
+  const unsigned vmask = (K == 1) ? 0x6u : 0xFu;                // = tracer_may_vanish<K>
+  ProfScope ps(d, 4, st);
+  const dim3 g((unsigned)((nrow + 3) / 4));
+  const bool local = !ex_x && !ex_y;
+  unsigned *own = local ? d->zr : (unsigned *)d->zrx;
+  const int ldo = local ? ld : p.ny, offo = local ? MW_ZR_HALO : 0;
+  if (from_coupler) MW_KLAUNCH(k_zero_rows<false>, g, dim3(256), 0, st, p, c, S0, own, vmask, ldo, offo, local ? 1 : 0);
+  else              MW_KLAUNCH(k_zero_rows<true>, g, dim3(256), 0, st, p, c, S0, own, vmask, ldo, offo, local ? 1 : 0);
+  MW_LAUNCH_CHECK();
+  if (!local) {
+    double *rW = d->zrx + dWE, *rE = d->zrx + 2 * dWE, *sS = d->zrx + 3 * dWE, *sN = sS + dSN, *rS = sN + dSN, *rN = rS + dSN;
+    if (ex_x && d->xchg(d->xchg_ctx, d->zrx, d->zrx, nullptr, nullptr, rW, rE, nullptr, nullptr, dWE, 0, st)) MW_FAIL("zero-row maps: exchange callback failed");
+    MW_KLAUNCH(k_zero_merge, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, p, own, ex_x ? (const unsigned *)rW : nullptr, (const unsigned *)rE, d->zr,
+               ex_y ? (unsigned *)sS : nullptr, (unsigned *)sN);
+    MW_LAUNCH_CHECK();
+    if (ex_y) {
+      if (d->xchg(d->xchg_ctx, nullptr, nullptr, sS, sN, nullptr, nullptr, rS, rN, 0, dSN, st)) MW_FAIL("zero-row maps: exchange callback failed");
+      MW_KLAUNCH(k_zero_halo, dim3((unsigned)((nedge + 255) / 256)), dim3(256), 0, st, p, d->zr, (const unsigned *)rS, (const unsigned *)rN);
+      MW_LAUNCH_CHECK();
+    }
+  }
+  MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, p, d->zr, msz);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+// ... and handed to the kernels of RK stage `stage` (1..3) through the parameter block
+static void zero_rows_stage(mw_dycore_s *d, int stage) {
+  DyP &p = d->p;
+  if (!d->zr_on) { p.zq = nullptr; p.zq_ld = 0; return; }
+  p.zq = d->zr + (long long)stage * d->zr_msz;
+  p.zq_ld = p.ny + 2 * MW_ZR_HALO;
+}
 // One SSPRK3 sub-cycle.  Slabs: Q[0] = q^n, Q[1..3] scratch; on return the new q^n is in Q[3] (caller rotates).
 static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, const CouplerPtrs &c) {
   const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
+  d->zr_on = false;
+  if (!d->pipe && zero_rows_build(d, Q[0], c, d->conv_pending, d->stream)) return 1;     // (pipelined schedule: inside its first stage, on the exchange stream)
   if (d->pipe) {                                              // blocks of a decomposed domain, pipelined schedule
     d->pipe_ready = false; d->pipe_edge_done = false;
     if (rk_stage_pipe<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;
@@ -1876,6 +1962,7 @@ static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, 
       MW_LAUNCH_CHECK();
     }
     d->flux_src = Q[2]; d->flux_dt = dt3;
+    d->zr_on = false; zero_rows_stage(d, 0);
     return 0;
   }
   if (rk_stage_march<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;                        // stage 1 (:119-132)
@@ -1893,6 +1980,7 @@ static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, 
     if (d->overlap) MW_HIP(hipEventRecord(d->ev_tr[(d->gstage - 1) & 7], ts));     // the step's join waits for this event
   }
   d->flux_src = Q[2]; d->flux_dt = dt3;
+  d->zr_on = false; zero_rows_stage(d, 0);
   return 0;
 }
 
@@ -1991,7 +2079,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
     for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
                                     hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
     if (hipEventCreateWithFlags(&d->ev_misc, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 5; i++)
       if (hipEventCreateWithFlags(&d->ev_pipe[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
   }
   fill_params(d);
@@ -2007,10 +2095,12 @@ void mw_dycore_destroy(mw_dycore_t d) {
   for (double *ptr : {d->S0, d->S1, d->S2, d->S3, d->tendY, d->FX, d->FY, d->FZ, d->hy_dev, d->imm}) if (ptr) (void)hipFree(ptr);
   if (d->flags) (void)hipFree(d->flags);
   if (d->dirty) (void)hipFree(d->dirty);
+  if (d->zr) (void)hipFree(d->zr);
+  if (d->zrx) (void)hipFree(d->zrx);
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
-  for (int i = 0; i < 4; i++) if (d->ev_pipe[i]) (void)hipEventDestroy(d->ev_pipe[i]);
+  for (int i = 0; i < 5; i++) if (d->ev_pipe[i]) (void)hipEventDestroy(d->ev_pipe[i]);
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
@@ -2044,7 +2134,7 @@ const OptDesc OPTS[] = {
   {"mm_direct", &DyOpts::mm_direct, 0, 1, 0}, {"mm_conv", &DyOpts::mm_conv, 0, 1, 0}, {"fused_convert", &DyOpts::fused_convert, 0, 1, 0},
   {"fused_convert_mm", &DyOpts::fused_convert_mm, 0, 1, 0}, {"chunk_y", &DyOpts::chunk_y, 0, 1 << 20, 0}, {"chunk_yt", &DyOpts::chunk_yt, 0, 1 << 20, 0},
   {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
-  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
+  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
   {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0}, {"rccl_inline", &DyOpts::rccl_inline, 0, 1, 0},
   {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
   {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},

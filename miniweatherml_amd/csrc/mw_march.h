@@ -329,6 +329,131 @@ __global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtr
   convert_cell_tracers(p, r, inv_den, s, p.sV);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Zero-row maps (round 5).  Cloud water and rain are exactly zero over most of a supercell domain (all of it at the start), and after
+// the zero short-cut (MW_ZERO_SKIP) the fused tracer kernel is bound by the HBM traffic of values that are all zero.  The maps let it
+// not issue those loads at all:
+//   M0[k][j], bit v : tracer v is non-zero somewhere in the x row (k, j) of the sub-cycle's input q^n   (k_zero_rows: one pass over the
+//                     tracers that can vanish, 16 bytes per cell of the ~500 a stage moves)
+//   Qs[k][j], bit v : (s = 1, 2, 3) tracer v may be non-zero in something that iterations k-3 .. k of row j's marching wave touch in RK
+//                     stage s: the OR of M0 over rows j-3s .. j+3s (periodic) and levels k-3s-5 .. k+3s+1 (clamped)  (k_zero_dilate)
+// One RK stage moves a tracer by at most 3 cells per direction (cell (k, j) is updated from the faces j, j+1 / k, k+1, whose upwind
+// WENO-5 stencils reach rows j-3 .. j+3 / levels k-3 .. k+3; an FCT multiplier only scales a flux, the y-face correction of
+// k_tracer_patch is a difference of scaled and unscaled flux, and every stage adds q^n's own row), and a flux of zeros is zero: a row
+// that is non-zero in the input of stage s (its output, its y fluxes) lies within 3(s-1) (3s) rows and levels of a non-zero row of q^n.
+// Iteration k of k_tracers_fused reads input levels k-2 .. k+3, y fluxes of levels k-1 .. k+1 and q^n of levels k-2 .. k+2, and its
+// carries come from the three iterations before (input levels from k-5, y fluxes from k-5): with Qs[k][j]'s bit clear all of that is
+// exactly zero, and so is the tracer's new value.  The maps are a SUPERSET of the non-zero rows -- a set bit costs the loads, nothing
+// else -- and results equal the run without them (tests/: bitwise up to the sign of a zero; a skipped value enters as +0.0).
+// Handles: nens == 1, x and y periodic, the fused tracer stage; one rank, or the blocks of a decomposed domain on the pipelined
+// schedule (host side: zero_rows_ok / zero_rows_build in mw_dycore.hip).
+// ---------------------------------------------------------------------------------------------------------------
+#define MW_ZR_REACH 3
+#define MW_ZR_HALO (3 * MW_ZR_REACH)                              // rows a tracer can travel in one sub-cycle = halo rows of the maps
+// Map layout: word of (k, j) at [k * zq_ld + j + MW_ZR_HALO], zq_ld = ny + 2 MW_ZR_HALO (j = -9 .. ny+8: the rows beyond the block's
+// south / north edge -- its own rows again when it owns the periodic y direction, the neighbours' rows otherwise).
+// Blocks of a decomposed domain (pipelined schedule): a row's x halo holds the west / east neighbour's cells and its tracer can come
+// from there, so M0 is OR-ed with the neighbours' M0 of the same row (k_zero_merge; whole rows: coarse, but a superset), and the rows
+// beyond the y edges come from the south / north neighbours' merged maps -- two small messages per sub-cycle through the handle's
+// halo transport, on the exchange stream beside the stage's y and x/z kernels.
+// k_zero_rows: wave = one x row (k, j).  SLAB: the tracers of slab S (later sub-cycles of a step, or after a conversion pass); else the
+// coupler's arrays.  vmask: the tracers that can vanish -- the others are flagged non-zero without being read.  ldo / offo: layout of
+// `out` (compact [k][ny] for k_zero_merge, or the map's own); wrap: also write the row's periodic images into the map's halo rows.
+template <bool SLAB>
+__global__ __launch_bounds__(256) void k_zero_rows(DyP p, CouplerPtrs c, const double *__restrict__ S, unsigned *__restrict__ out, unsigned vmask,
+                                                   int ldo, int offo, int wrap) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)p.nz * p.ny) return;
+  const int k = (int)(row / p.ny), j = (int)(row - (long long)k * p.ny), lane = threadIdx.x & 63;
+  const int NXI = p.nx * p.nens;
+  unsigned word = 0;
+  for (int v = 0; v < p.nt && v < 4; v++) {
+    if (!((vmask >> v) & 1u)) { word |= 1u << v; continue; }
+    const double *src = SLAB ? S + (long long)(5 + v) * p.sV + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens
+                             : c.tr[v] + ((long long)k * p.ny + j) * NXI;
+    bool nz = false;
+    int ie = lane;
+    for (; ie + 192 < NXI; ie += 256) {                          // four requests in flight per lane
+      const double a0 = src[ie], a1 = src[ie + 64], a2 = src[ie + 128], a3 = src[ie + 192];
+      nz |= (a0 != 0.0) | (a1 != 0.0) | (a2 != 0.0) | (a3 != 0.0);
+    }
+    for (; ie < NXI; ie += 64) nz |= (src[ie] != 0.0);
+    if (__any(nz)) word |= 1u << v;
+  }
+  if (lane == 0) {
+    unsigned *o = out + (long long)k * ldo + offo;
+    o[j] = word;
+    if (wrap && j < MW_ZR_HALO) o[p.ny + j] = word;
+    if (wrap && j >= p.ny - MW_ZR_HALO) o[j - p.ny] = word;
+  }
+}
+// Decomposed block: M = own rows (compact) OR the west / east neighbours' (rW / rE, nullptr: x is not decomposed); the merged rows next
+// to the south / north edge are packed for those neighbours (sS / sN, nullptr: y is not decomposed -- the halo rows are then the block's
+// own periodic images).
+__global__ __launch_bounds__(256) void k_zero_merge(DyP p, const unsigned *__restrict__ own, const unsigned *__restrict__ rW, const unsigned *__restrict__ rE,
+                                                    unsigned *__restrict__ M, unsigned *__restrict__ sS, unsigned *__restrict__ sN) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)p.nz * p.ny) return;
+  const int k = (int)(t / p.ny), j = (int)(t - (long long)k * p.ny);
+  unsigned wd = own[t];
+  if (rW) wd |= rW[t] | rE[t];
+  unsigned *o = M + (long long)k * p.zq_ld + MW_ZR_HALO;
+  o[j] = wd;
+  if (sS) {
+    if (j < MW_ZR_HALO) sS[k * MW_ZR_HALO + j] = wd;
+    if (j >= p.ny - MW_ZR_HALO) sN[k * MW_ZR_HALO + j - (p.ny - MW_ZR_HALO)] = wd;
+  } else {
+    if (j < MW_ZR_HALO) o[p.ny + j] = wd;
+    if (j >= p.ny - MW_ZR_HALO) o[j - p.ny] = wd;
+  }
+}
+// ... and the rows beyond the y edges from what the south / north neighbours packed (their northernmost / southernmost rows)
+__global__ __launch_bounds__(256) void k_zero_halo(DyP p, unsigned *__restrict__ M, const unsigned *__restrict__ rS, const unsigned *__restrict__ rN) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= p.nz * MW_ZR_HALO) return;
+  const int k = t / MW_ZR_HALO, h = t - k * MW_ZR_HALO;
+  unsigned *o = M + (long long)k * p.zq_ld + MW_ZR_HALO;
+  o[h - MW_ZR_HALO] = rS[t];
+  o[p.ny + h] = rN[t];
+}
+// M0 -> Q1, Q2, Q3 (Q_s at M + s * msz), separably through LDS: rows first (three radii), then levels.
+#define MW_ZR_BEFORE 5                                            // levels below: the three iterations whose carries an iteration inherits
+#define MW_ZR_AFTER 1                                             // levels above: the y fluxes of level k+1 (chunk ends clamp k-1 upwards)
+__global__ __launch_bounds__(256) void k_zero_dilate(DyP p, unsigned *__restrict__ M, long long msz) {
+  constexpr int TK = 16, TJ = 64, R = MW_ZR_HALO, LO = R + MW_ZR_BEFORE, HI = R + MW_ZR_AFTER, EK = TK + LO + HI, EJ = TJ + 2 * R;
+  __shared__ unsigned a[EK][EJ];
+  __shared__ unsigned b[3][EK][TJ];
+  const int k0 = blockIdx.y * TK, j0 = blockIdx.x * TJ, tid = threadIdx.x;
+  for (int t = tid; t < EK * EJ; t += 256) {
+    const int kk = t / EJ, jj = t - kk * EJ;
+    const int k = min(max(k0 + kk - LO, 0), p.nz - 1);
+    const int j = j0 + jj - R;                                   // -9 .. ny+8 are rows of the map; beyond (the last tile's overhang): nobody's
+    a[kk][jj] = (j < p.ny + R) ? M[(long long)k * p.zq_ld + j + MW_ZR_HALO] : 0u;
+  }
+  __syncthreads();
+  for (int t = tid; t < EK * TJ; t += 256) {
+    const int kk = t / TJ, jj = t - kk * TJ, cc = jj + R;
+    unsigned o = a[kk][cc];
+#pragma unroll
+    for (int r = 1; r <= R; r++) {
+      o |= a[kk][cc - r] | a[kk][cc + r];
+      if (r % MW_ZR_REACH == 0) b[r / MW_ZR_REACH - 1][kk][jj] = o;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < TK * TJ; t += 256) {
+    const int kk = t / TJ, jj = t - kk * TJ, k = k0 + kk, j = j0 + jj;
+    if (k >= p.nz || j >= p.ny) continue;
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      const int r = MW_ZR_REACH * (m + 1);
+      unsigned o = 0;
+      for (int dd = -r - MW_ZR_BEFORE; dd <= r + MW_ZR_AFTER; dd++) o |= b[m][kk + LO + dd][jj];
+      M[(long long)(m + 1) * msz + (long long)k * p.zq_ld + j + MW_ZR_HALO] = o;
+    }
+  }
+}
+
 // Member-major handles (nens > 1, see View in mw_dycore.hip): the two conversions between the coupler's member-fastest arrays and
 // the member-after-member slabs, as coalesced passes.  thread = one cell in the COUPLER's order (fused x, member fastest): the
 // coupler side is a unit-stride stream, the slab side 16-lane segments of nens different members.  (Done from inside the
@@ -1521,11 +1646,27 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     xzn[v] = __any(xpn[v] != 0.0);
     if (!tracer_may_vanish<K>(p, v)) { zm[v] = ~0u; xzn[v] = true; }
   }
+  // zero-row map of this stage (see k_zero_rows): bit i of zq_mask = "iteration kstart + i of this wave's row may touch something
+  // non-zero of a tracer that can vanish" -- one word per iteration, fetched by the lanes here and kept as a scalar mask
+  // (iterations beyond the 64th: bit set)
+  unsigned long long zq_mask = ~0ull;
+  if (!MT && p.zq != nullptr) {
+    const int kq = kstart + lane;
+    const unsigned wq = p.zq[(long long)min(kq, p.nz - 1) * p.zq_ld + j + MW_ZR_HALO];
+    zq_mask = __ballot((wq & ((K == 1) ? ~1u : ~0u)) != 0u || !p.zero_skip);
+  }
 #endif
   // The loop body is branch-free apart from predicated stores and the rare limiter paths: every load uses a clamped
   // (always valid) address and is issued at the top, the z reconstruction (registers only) runs while they are in flight.
   // Iterations outside a quantity's range compute values that are never stored or carried into a used result.
-  for (int k = kstart; k <= kb + 1; k++) {
+  // Two forms of the loop body (round 5, see k_zero_rows): FULL, and LEAN for an iteration in which every tracer that can vanish IS zero
+  // in everything the iteration touches -- window, entering level, patch cell, y fluxes, q^n -- and in everything the three iterations
+  // before touched (their carries are zero then): those tracers issue no load and no arithmetic, their new value is 0.  The stage's
+  // row map says so (zq_mask).  ACT = the tracers the form works on; one wave-uniform branch per iteration picks the form.
+  constexpr unsigned FULLM = (1u << T) - 1u, VANM = (K == 1) ? (FULLM & ~1u) : FULLM;     // (VANM = tracer_may_vanish<K>)
+  auto body = [&](auto act_c, const int k) __attribute__((always_inline)) {
+    constexpr unsigned ACT = decltype(act_c)::value;
+#define MW_ACT(v_) ((ACT >> (v_)) & 1u)
     const bool cell = (k < p.nz);
     const int kp = k - 1, ku = k - 2;
     const bool s2cell = (kp >= k_lo) && (kp <= k_hi);          // cell kp has all six fluxes (kp == nz: only the top face is scaled)
@@ -1539,15 +1680,15 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     const int kn = min(k + HS + 1, p.nz + p.HZ - 1);
     double xpatch[T];                                            // level k, the cell beyond lane 0 / lane 63
 #pragma unroll
-    for (int v = 0; v < T; v++) xpatch[v] = xpn[v];
+    for (int v = 0; v < T; v++) xpatch[v] = MW_ACT(v) ? xpn[v] : 0.0;
 #if MW_ZERO_SKIP
 #pragma unroll
     for (int v = 0; v < T; v++) xzc[v] = xzn[v];
 #endif
 #pragma unroll
-    for (int v = 0; v < T; v++) xpn[v] = N1 ? col[(long long)v * p.sV + (long long)(min(k + 1, p.nz - 1) + p.HZ) * p.sK + opatch] : 0.0;
+    for (int v = 0; v < T; v++) if (MW_ACT(v)) xpn[v] = N1 ? col[(long long)v * p.sV + (long long)(min(k + 1, p.nz - 1) + p.HZ) * p.sK + opatch] : 0.0;
 #pragma unroll
-    for (int v = 0; v < T; v++) nxt[v] = load_zlevel(p, col + (long long)v * p.sV, kn, false);
+    for (int v = 0; v < T; v++) if (MW_ACT(v)) nxt[v] = load_zlevel(p, col + (long long)v * p.sV, kn, false);
     const double mx = MX[(long long)kx * p.fxK + fxo];
     const int upx = UPX[(long long)kx * p.fxK + fxo];
     const double mz = MZ[(long long)kz * p.fzK + fzo];
@@ -1559,7 +1700,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #pragma unroll
     for (int v = 0; v < T; v++) {
       const double *fy = FY + (long long)(5 + t0 + v) * p.fyV + (long long)kpc * p.fyK + fyo;
-      fys[v] = do_y ? fy[0] : 0.0; fyn[v] = do_y ? fy[p.fyJ] : 0.0;
+      fys[v] = 0.0; fyn[v] = 0.0;
+      if (MW_ACT(v)) { fys[v] = do_y ? fy[0] : 0.0; fyn[v] = do_y ? fy[p.fyJ] : 0.0; }
     }
     const long long so = (long long)(kuc + p.HZ) * p.sK + so_row;
     const double hyc_u = p.hyc[kuc * p.nens + e];
@@ -1570,7 +1712,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     if (STAGE != 1) {
       rho_n_raw = Sn[so + idR * p.sV];
 #pragma unroll
-      for (int v = 0; v < T; v++) qn_[v] = Sn[so + (5 + t0 + v) * p.sV];
+      for (int v = 0; v < T; v++) if (MW_ACT(v)) qn_[v] = Sn[so + (5 + t0 + v) * p.sV];
     }
     if (MODE == 1) st_T = Sout[so + idT * p.sV];              // (u, v, w were written to the coupler by k_xz_state<3, ., 1>)
     // nens > 1: the x-stencil neighbours of level k come from memory (issued here, with the iteration's other loads)
@@ -1579,13 +1721,14 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     for (int v = 0; v < T; v++) {
       const double *lvl = col + (long long)v * p.sV + (long long)(kx + p.HZ) * p.sK;
       nbw2[v] = nbw1[v] = nbe1[v] = nbe2[v] = 0;
-      if (!N1) { nbw2[v] = lvl[om2]; nbw1[v] = lvl[om1]; nbe1[v] = lvl[op1]; nbe2[v] = lvl[op2]; }
+      if (!N1 && MW_ACT(v)) { nbw2[v] = lvl[om2]; nbw1[v] = lvl[om1]; nbe1[v] = lvl[op1]; nbe2[v] = lvl[op2]; }
     }
     // ------------------------------------------------ S1: z reconstruction (registers only), then the fluxes of level k
     if (MW_FENCED) MW_SCHED_FENCE();
     double te[T], fxn[T], fzn[T], be_[T], xe_[T];
 #pragma unroll
     for (int v = 0; v < T; v++) {                                // all reconstructions first: they need no loaded operand
+      if (!MW_ACT(v)) { be_[v] = 0.0; te[v] = 0.0; continue; }
 #if MW_ZERO_SKIP
       if (zm[v] == 0u) { be_[v] = 0.0; te[v] = 0.0; }
       else
@@ -1598,6 +1741,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       const bool quirk = bc_mode_x<K>(p, i) == 3;
 #pragma unroll
       for (int v = 0; v < T; v++) {
+        if (!MW_ACT(v)) { xe_[v] = 0.0; continue; }
 #if MW_ZERO_SKIP
         if (N1 && !quirk && !((zm[v] >> HS) & 1u) && !xzc[v]) {   // the wave's whole x stencil of this level is zero
           be_[v] = upz ? be_[v] : ct[v];
@@ -1627,7 +1771,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       }
     }
 #pragma unroll
-    for (int v = 0; v < T; v++) { fzn[v] = mz * be_[v]; fxn[v] = mx * xe_[v]; }
+    for (int v = 0; v < T; v++) { fzn[v] = 0.0; fxn[v] = 0.0; if (MW_ACT(v)) { fzn[v] = mz * be_[v]; fxn[v] = mx * xe_[v]; } }
     // ------------------------------------------------ S2: cell k-1 -> multiplier, scaled faces, partial tendency
     const double rhop = rhop_raw + hyc_p;
     double rho_new = rho_new_raw + hyc_u, rho_n = (STAGE != 1) ? rho_n_raw + hyc_u : 0.0;
@@ -1638,6 +1782,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #pragma unroll
       for (int v = 0; v < T; v++) {
 #pragma clang fp contract(off)
+        szn[v] = 0.0; Pn[v] = 0.0;
+        if (!MW_ACT(v)) continue;
         const double fe = from_east<N1>(fxp[v], lane, n);
         double mult = 1.0;
         {
@@ -1665,7 +1811,9 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
         }
         multp[v] = mult;
       }
-      landed(nxt); landed(xpn); landed(qn_); landed(rho_new); landed(rho_n); landed(st_T);  // in front of the iteration's stores (see landed())
+#pragma unroll
+      for (int v = 0; v < T; v++) if (MW_ACT(v)) { landed(nxt[v]); landed(xpn[v]); landed(qn_[v]); }   // in front of the iteration's stores (see landed())
+      landed(rho_new); landed(rho_n); landed(st_T);
       if (rec && do_y) flags[((long long)kp * p.ny + j) * NXI + q] = (unsigned char)fl;     // 2 bits per tracer: (south, north) face scaled
       if (__builtin_expect(fl != 0u, 0)) *dirty = 1u;           // (only set inside `rec`) lets k_tracer_patch return at once when nothing was scaled
     }
@@ -1678,6 +1826,11 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       double rho_dry = rho_new, rho_v = 0;
 #pragma unroll
       for (int v = 0; v < T; v++) {
+        if (!MW_ACT(v)) {                                        // LEAN form: the tracer is zero and stays zero
+          if (MODE == 0) { if (st) Sout[so + (5 + t0 + v) * p.sV] = 0.0; }
+          else           { if (st) c.tr[v][cpl(p, ci)] = 0.0; }
+          continue;
+        }
         const double q_s = (ORD == 3 ? wkm2[v] : w[v][0]) * rhos2;           // level k-2
         const double q_n = (STAGE == 1) ? q_s : qn_[v] * rho_n;
         const double tend = P[v] - (szn[v] - szf[v]) * (LC ? lds_c[2] : p.rdz);
@@ -1707,7 +1860,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #if MW_ZERO_SKIP
 #pragma unroll
     for (int v = 0; v < T; v++) {
-      if (tracer_may_vanish<K>(p, v)) {
+      if (MW_ACT(v) && tracer_may_vanish<K>(p, v)) {
         zm[v] = (zm[v] >> 1) | ((__any(nxt[v] != 0.0) ? 1u : 0u) << (ORD - 1));
         xzn[v] = __any(xpn[v] != 0.0);
       }
@@ -1715,6 +1868,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #endif
 #pragma unroll
     for (int v = 0; v < T; v++) {
+      if (!MW_ACT(v)) continue;                                  // (LEAN form: window and carries are zero and stay zero)
       fxp[v] = fxn[v]; fzp[v] = fzn[v]; szf[v] = szn[v]; P[v] = Pn[v];
       ct[v] = te[v];
       if (ORD == 3) wkm2[v] = w[v][0];                         // level k-1 is level (k+1)-2 of the next iteration
@@ -1722,6 +1876,15 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
       for (int s = 0; s + 1 < ORD; s++) w[v][s] = w[v][s + 1];
       w[v][ORD - 1] = nxt[v];
     }
+#undef MW_ACT
+  };
+  for (int k = kstart; k <= kb + 1; k++) {
+    bool lean = false;
+#if MW_ZERO_SKIP
+    { const int it = k - kstart; lean = (it < 64) && !((zq_mask >> it) & 1ull); }
+#endif
+    if (lean) body(std::integral_constant<unsigned, (FULLM & ~VANM)>{}, k);
+    else      body(std::integral_constant<unsigned, FULLM>{}, k);
   }
 }
 

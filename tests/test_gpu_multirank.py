@@ -327,3 +327,82 @@ def test_boundaries_on_several_ranks_supercell(mw, oracle, layout):
     got, want = _run_decomposed_gpu_and_oracle(oracle, nranks, nxg, nyg, nz, "supercell", bc, 0, 2, xlen, ylen, 20000.)
     for r in range(nranks):
         compare_fields(got[r], want[r], 1e-10, "supercell bc %s, rank %d of %d" % (bc, r, nranks))
+
+
+def _specks(coupler, nxg, nyg, nz):
+    """Single non-zero cells of cloud water / rain at GLOBAL positions: in the domain's corners, and one or two cells either side of the
+    seams of a 2 x 2 / 4 x 2 / 1 x 2 decomposition -- what a block's tracer kernel sees of them arrives through its halos."""
+    dm = coupler.get_data_manager_readwrite()
+    rho = dm.get("density_dry")
+    ib, jb = coupler.grid.i_beg, coupler.grid.j_beg
+    ny, nx = rho.shape[1], rho.shape[2]
+    cl, pr = torch.zeros_like(rho), torch.zeros_like(rho)
+    cloud = [(0, 0, 0), (nz - 1, nyg - 1, nxg - 1), (3, nyg // 2 - 1, nxg // 2 - 1), (4, nyg // 2, nxg // 2 + 1), (2, nyg // 2 + 2, 5),
+             (nz - 2, 7, nxg // 2), (nz // 2, nyg - 1, nxg // 4), (1, nyg // 2 - 2, nxg - 1)]
+    rain = [(nz // 2, nyg // 2, nxg // 4 - 1), (0, nyg - 2, nxg // 2 - 2), (nz - 1, 1, 3 * nxg // 4)]
+    for lst, fld, val in ((cloud, cl, 2.0e-4), (rain, pr, 1.0e-4)):
+        for (k, j, i) in lst:
+            if jb <= j < jb + ny and ib <= i < ib + nx:
+                fld[k, j - jb, i - ib] = val
+    dm.get("cloud_liquid").copy_(cl * rho)
+    dm.get("precip_liquid").copy_(pr * rho)
+
+
+def _specks_blocks(layout, zero_rows, fuzz):
+    from miniweatherml_amd import capi, modules
+    from util import StreamExchanger
+    nranks, nxg, nyg = layout
+    nz, nsteps = 12, 3
+    ex = StreamExchanger(nranks, fuzz_seed=fuzz)
+    results, keep = [None] * nranks, []
+
+    def worker(rank):
+        try:
+            coupler, dycore, _ = modules.make_supercell(nxg, nyg, nz, 1, 500.0 * nxg, 500.0 * nyg, 20000., nranks=nranks, myrank=rank)
+            _specks(coupler, nxg, nyg, nz)
+            dycore.set_option("zero_rows", zero_rows)
+            cb = ex.make_cb(rank, coupler.grid)
+            keep.append(cb)
+            capi.check(capi.lib().mw_dycore_set_exchange(dycore.h, cb, None))
+            dt = dycore.compute_time_step(coupler)
+            for n in range(nsteps):
+                dycore.time_step(coupler, dt * (2.3 if n == 1 else 1.0))
+            torch.cuda.synchronize()
+            results[rank] = (coupler.grid.i_beg, coupler.grid.j_beg, gpu_fields(coupler), dycore.path())
+        except Exception as e:                                          # pragma: no cover
+            ex.errors.append("rank %d: %r" % (rank, e))
+            ex.bar.abort()
+
+    ths = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not ex.errors, ex.errors
+    torch.cuda.synchronize()
+    ex.close()
+    return results
+
+
+@pytest.mark.parametrize("layout", [(4, 96, 64), (8, 160, 40), (2, 40, 72)])
+def test_zero_row_maps_on_decomposed_blocks(mw, layout):
+    """The zero-row maps (mw_march.h: k_zero_rows) of a decomposed domain: every block ORs its neighbours' maps into its own (k_zero_merge:
+    west / east, whole rows; k_zero_halo: the south / north neighbours' edge rows, two small messages per sub-cycle through the halo
+    transport).  Cloud and rain are single cells next to the seams and in the corners, so whether a block's wave may skip a row is decided
+    by what the NEIGHBOUR holds; the transport delays its copies at random.  Same bits as the same decomposition WITHOUT the maps; three
+    steps, one of them sub-cycled.  (Not compared with the one-rank run: single cells keep the positivity limiter busy, and a flux that
+    enters a block from its halo is never scaled -- the reference's FCT loops over a rank's own cells, dynamics_euler_stratified_wenofv.h
+    :496-514 -- so with an active limiter the result depends on where the seams are, there as here.)"""
+    from util import launched_kernels
+    launched_kernels(reset=True)
+    on = _specks_blocks(layout, 1, 7)
+    assert any("k_zero_merge" in k for k in launched_kernels(reset=True))
+    off = _specks_blocks(layout, 0, 0)
+    assert not any("k_zero_rows" in k for k in launched_kernels(reset=False))
+    nonzero = cells = 0
+    for (ib, jb, blk, path), (ib0, jb0, ref, _) in zip(on, off):
+        assert " pipe " in path and (ib, jb) == (ib0, jb0)
+        for k, a in blk.items():
+            assert np.array_equal(a, ref[k]), (k, ib, jb)
+        nonzero += int((ref["tracer1"] != 0).sum()); cells += ref["tracer1"].size
+    assert 0 < nonzero < 0.5 * cells

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"overlap": -1, "pipe": 1, "pipe_edge_inline": 0, "pipe_convert": 1, "pipe_split_edges": 1, "spec": 1, "wrap": 1, "y_all": 1, "y_all_conv": 1,
             "member_major": 1, "mm_direct": 1, "mm_conv": 1, "fused_convert": 1, "fused_convert_mm": 1, "fused_tracers": 1, "chunk_y": 0, "chunk_yt": 0,
-            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
+            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "zero_rows": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
 
 
 def test_defaults_round_trips_and_errors(mw):
@@ -119,4 +119,51 @@ def test_zero_tracer_shortcut_is_bit_neutral(mw, case):
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), k
     if case == "one_storm":
+        assert float(res[0]["tracer1"].max()) > 0.0 and float((res[0]["tracer1"] == 0).mean()) > 0.5
+
+
+@pytest.mark.parametrize("case", ["cloud_free", "one_storm", "specks", "city", "ord3"])
+def test_zero_row_maps_are_bit_neutral(mw, case):
+    """Option zero_rows (default 1, round 5): per (level, row) and tracer a bit "may be non-zero", scanned from the sub-cycle's input and
+    dilated by 3 rows / levels per RK stage (mw_march.h: k_zero_rows, k_zero_dilate); k_y_all and k_tracers_fused do not load rows whose bit
+    is clear, k_y_all does not store y fluxes nobody loads.  The maps must be a superset of the non-zero rows: the same bits as with the
+    maps switched off, and as with the whole zero short-cut switched off -- on a cloud-free state, on one box of cloud and rain, on single
+    non-zero cells in the corners, on the faces and next to the periodic seams (a too small dilation shows here), on the city, at WENO-3;
+    three steps, one of them sub-cycled (a sub-cycle rebuilds the maps from the slab instead of the coupler's arrays)."""
+    import torch
+    from miniweatherml_amd import modules
+    from util import launched_kernels
+    res, used = [], []
+    for rows, skip in ((1, 1), (0, 1), (0, 0)):
+        if case == "city":
+            coupler, dycore, _, _ = modules.make_simple_city(96, 48, 16, 1, 480., 240., 80., "building")
+        else:
+            coupler, dycore, _ = modules.make_supercell(130, 44, 26, 1, 65000., 22000., 20000., ord=(3 if case == "ord3" else 5))
+            dm = coupler.get_data_manager_readwrite()
+            rho = dm.get("density_dry")
+            if case in ("one_storm", "ord3"):
+                box = torch.zeros_like(rho)
+                box[3:15, 9:31, 37:101] = 1.0
+                dm.get("cloud_liquid").copy_(3.0e-4 * box * rho)
+                dm.get("precip_liquid").copy_(1.0e-4 * box * rho)
+            if case == "specks":
+                cl, pr = torch.zeros_like(rho), torch.zeros_like(rho)
+                for (k, j, i) in ((0, 0, 0), (25, 43, 129), (0, 43, 64), (25, 0, 5), (12, 21, 0), (12, 0, 70), (13, 43, 129), (7, 30, 100)):
+                    cl[k, j, i] = 2.0e-4
+                for (k, j, i) in ((25, 20, 64), (0, 22, 3), (9, 1, 127), (18, 42, 60)):
+                    pr[k, j, i] = 1.0e-4
+                dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(pr * rho)
+        dycore.set_option("zero_skip", skip); dycore.set_option("zero_rows", rows)
+        dycore.set_option("chunk_z", 7); dycore.set_option("chunk_f", 7); dycore.set_option("chunk_y", 9)
+        dt = dycore.compute_time_step(coupler)
+        launched_kernels(reset=True)
+        for n in range(3):
+            dycore.time_step(coupler, dt * (2.2 if n == 1 else 1.0))
+        used.append(any("k_zero_rows" in k for k in launched_kernels()))
+        res.append(gpu_fields(coupler))
+    assert used == [True, False, False]
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+        assert np.array_equal(res[0][k], res[2][k]), k
+    if case == "specks":
         assert float(res[0]["tracer1"].max()) > 0.0 and float((res[0]["tracer1"] == 0).mean()) > 0.5
