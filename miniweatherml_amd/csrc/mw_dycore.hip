@@ -959,7 +959,7 @@ struct mw_dycore_s {
   unsigned long long fused_launches = 0;
   unsigned char *flags = nullptr;          // fused tracer stage: per-cell "a y face of this cell was FCT-scaled" bits
   double *zrx = nullptr;                   // ... and the message buffers of a decomposed block's map exchange (own | rW | rE | sS | sN | rS | rN)
-  unsigned *zr = nullptr; long long zr_msz = 0; bool zr_on = false;   // zero-row maps M0, Q1..Q3 of the running sub-cycle (mw_march.h: k_zero_rows), zr_msz words each
+  unsigned *zr = nullptr; long long zr_msz = 0; bool zr_on = false;   // zero-row maps (M0 and the six of k_zero_dilate) of the running sub-cycle (mw_march.h: k_zero_rows), zr_msz words each
   int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows (see DyP::hypk)
   double *imm = nullptr;
@@ -1845,7 +1845,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
       if (d->zr_on) MW_HIP(hipEventRecord(d->ev_pipe[4], xs));
     }
   }
-  zero_rows_stage(d, STAGE);
+  if (STAGE != 1) zero_rows_stage(d, STAGE);                    // (stage 1: its y launches run BESIDE the map build -- the maps are handed over in front of the tracer kernel)
   d->pipe_ready = false;
   if (launch_y_all(d, Sin, conv ? &c : nullptr, 1)) return 1;  // rows whose chunks read no halo row
   MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));           // state strips (+ the edge rows' y tendencies) of this stage's input
@@ -1862,13 +1862,13 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
     }
   }
   MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[3], 0));           // tracer strips + the edge faces' tracer fluxes of this stage's input
-  if (STAGE == 1 && d->zr_on) MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[4], 0));
+  if (STAGE == 1 && d->zr_on) { MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[4], 0)); zero_rows_stage(d, 1); }
   if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ss)) return 1;
   if (early) {
     MW_HIP(hipEventRecord(d->ev_pipe[1], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[1], 0));
     if (halo_fill(d, Sout, 5, T, xs, 1, true)) return 1;      // tracer strips, beside the next stage's interior y chunks (and, split, its k_xz_state)
     if (split_edges) { if (launch_y_tracers(d, Sout, par_next, xs, true)) return 1; }                    // the tracer part of the next stage's edge strips
-    else if (edge_side && launch_y_all(d, Sout, nullptr, 2, xs)) return 1;                               // ... or both parts in one launch
+    else if (edge_side) { zero_rows_stage(d, STAGE + 1); if (launch_y_all(d, Sout, nullptr, 2, xs)) return 1; }   // ... or both parts in one launch (the NEXT stage's maps)
     if (!split_edges) MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
     MW_HIP(hipEventRecord(d->ev_pipe[3], xs));
     d->pipe_ready = true; d->pipe_edge_done = edge_side;
@@ -1901,7 +1901,7 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   if (!d->zr || d->zr_msz != msz) {
     if (d->zr) { MW_HIP(hipDeviceSynchronize()); (void)hipFree(d->zr); d->zr = nullptr; }
     if (d->zrx) { (void)hipFree(d->zrx); d->zrx = nullptr; }
-    if (hipMalloc(&d->zr, 4 * (size_t)msz * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }
+    if (hipMalloc(&d->zr, MW_ZR_MAPS * (size_t)msz * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }
     d->zr_msz = msz;
   }
   if ((ex_x || ex_y) && !d->zrx) {

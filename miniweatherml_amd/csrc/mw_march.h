@@ -263,12 +263,20 @@ __device__ __forceinline__ long long cpl(const DyP &p, long long ci) { return ci
 
 // One cell of the coupler, as loaded (the marching kernel requests row j+3 at the top of iteration j and converts it at the end).
 struct CouplerCell { double rho_d, u, v, w, temp, tr[4]; };
+// (ldmask: wave-uniform; bit tr clear = tracer tr is known to be zero in this row -- the zero-row maps -- and is not loaded)
 template <int K = 0>
-__device__ __forceinline__ CouplerCell load_coupler_cell(const DyP &p, const CouplerPtrs &c, long long ci) {
+__device__ __forceinline__ CouplerCell load_coupler_cell(const DyP &p, const CouplerPtrs &c, long long ci, unsigned ldmask = ~0u) {
   CouplerCell r;
   r.rho_d = c.rho_d[ci]; r.u = c.u[ci]; r.v = c.v[ci]; r.w = c.w[ci]; r.temp = c.temp[ci];
 #pragma unroll
-  for (int tr = 0; tr < 4; tr++) r.tr[tr] = (tr < Cf<K>::ntr(p)) ? c.tr[tr][ci] : 0.0;
+  for (int tr = 0; tr < 4; tr++) r.tr[tr] = 0.0;
+  if (ldmask == ~0u) {
+#pragma unroll
+    for (int tr = 0; tr < 4; tr++) if (tr < Cf<K>::ntr(p)) r.tr[tr] = c.tr[tr][ci];
+  } else {
+#pragma unroll
+    for (int tr = 0; tr < 4; tr++) if (tr < Cf<K>::ntr(p) && ((ldmask >> tr) & 1u)) r.tr[tr] = c.tr[tr][ci];
+  }
   return r;
 }
 // -> the five state variables of the slab (rho', u, v, w, (rho theta)') and 1/rho for the tracers.  hi = k*nens + e.  The last
@@ -366,20 +374,34 @@ __global__ __launch_bounds__(256) void k_zero_rows(DyP p, CouplerPtrs c, const d
   if (row >= (long long)p.nz * p.ny) return;
   const int k = (int)(row / p.ny), j = (int)(row - (long long)k * p.ny), lane = threadIdx.x & 63;
   const int NXI = p.nx * p.nens;
-  unsigned word = 0;
-  for (int v = 0; v < p.nt && v < 4; v++) {
-    if (!((vmask >> v) & 1u)) { word |= 1u << v; continue; }
-    const double *src = SLAB ? S + (long long)(5 + v) * p.sV + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens
-                             : c.tr[v] + ((long long)k * p.ny + j) * NXI;
-    bool nz = false;
-    int ie = lane;
-    for (; ie + 192 < NXI; ie += 256) {                          // four requests in flight per lane
-      const double a0 = src[ie], a1 = src[ie + 64], a2 = src[ie + 128], a3 = src[ie + 192];
-      nz |= (a0 != 0.0) | (a1 != 0.0) | (a2 != 0.0) | (a3 != 0.0);
-    }
-    for (; ie < NXI; ie += 64) nz |= (src[ie] != 0.0);
-    if (__any(nz)) word |= 1u << v;
+  // (all tracers' values of eight 64-cell pieces are requested before the first one is tested: the kernel is a latency-bound stream otherwise)
+  const double *src[4];
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const int vv = min(v, p.nt - 1);
+    src[v] = SLAB ? S + (long long)(5 + vv) * p.sV + (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens
+                  : c.tr[vv] + ((long long)k * p.ny + j) * NXI;
   }
+  const unsigned scan = vmask & ((1u << min(p.nt, 4)) - 1u);
+  bool nz[4] = {false, false, false, false};
+  for (int base = 0; base < NXI; base += 512) {
+    double a[4][8];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      if (!((scan >> v) & 1u)) continue;                        // (wave-uniform)
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int ie = base + u * 64 + lane; a[v][u] = src[v][min(ie, NXI - 1)]; }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      if (!((scan >> v) & 1u)) continue;
+#pragma unroll
+      for (int u = 0; u < 8; u++) nz[v] = nz[v] || (a[v][u] != 0.0);
+    }
+  }
+  unsigned word = ((1u << min(p.nt, 4)) - 1u) & ~vmask;           // the tracers that cannot vanish
+#pragma unroll
+  for (int v = 0; v < 4; v++) if (((scan >> v) & 1u) && __any(nz[v])) word |= 1u << v;
   if (lane == 0) {
     unsigned *o = out + (long long)k * ldo + offo;
     o[j] = word;
@@ -416,11 +438,16 @@ __global__ __launch_bounds__(256) void k_zero_halo(DyP p, unsigned *__restrict__
   o[h - MW_ZR_HALO] = rS[t];
   o[p.ny + h] = rN[t];
 }
-// M0 -> Q1, Q2, Q3 (Q_s at M + s * msz), separably through LDS: rows first (three radii), then levels.
+// M0 -> Q1, Q2, Q3 (Q_s at M + s * msz), separably through LDS: rows first (three radii), then levels; and
+//   FNs[k][j] at M + (3 + s) * msz = the OR of Qs[k-1 .. k+1][j]: "row j's tracer kernel may load its y fluxes of level k" (its iteration k'
+//   reads level k'-1, clamped into the chunk: k' = k-1, k or k+1) -- k_y_all does not store the fluxes of a face whose two rows are clear.
 #define MW_ZR_BEFORE 5                                            // levels below: the three iterations whose carries an iteration inherits
 #define MW_ZR_AFTER 1                                             // levels above: the y fluxes of level k+1 (chunk ends clamp k-1 upwards)
+//   QYs[k][j] at M + (6 + s) * msz = M0 dilated by 3s rows and 3(s-1) levels = the input of stage s, three more rows either way: what
+//   iteration j of k_y_all's wave at level k touches (the window of face j, the row that enters it, the edge value carried from j-1).
+#define MW_ZR_MAPS 10
 __global__ __launch_bounds__(256) void k_zero_dilate(DyP p, unsigned *__restrict__ M, long long msz) {
-  constexpr int TK = 16, TJ = 64, R = MW_ZR_HALO, LO = R + MW_ZR_BEFORE, HI = R + MW_ZR_AFTER, EK = TK + LO + HI, EJ = TJ + 2 * R;
+  constexpr int TK = 16, TJ = 64, R = MW_ZR_HALO, LO = R + MW_ZR_BEFORE + 1, HI = R + MW_ZR_AFTER + 1, EK = TK + LO + HI, EJ = TJ + 2 * R;
   __shared__ unsigned a[EK][EJ];
   __shared__ unsigned b[3][EK][TJ];
   const int k0 = blockIdx.y * TK, j0 = blockIdx.x * TJ, tid = threadIdx.x;
@@ -447,9 +474,17 @@ __global__ __launch_bounds__(256) void k_zero_dilate(DyP p, unsigned *__restrict
 #pragma unroll
     for (int m = 0; m < 3; m++) {
       const int r = MW_ZR_REACH * (m + 1);
-      unsigned o = 0;
-      for (int dd = -r - MW_ZR_BEFORE; dd <= r + MW_ZR_AFTER; dd++) o |= b[m][kk + LO + dd][jj];
+      const int ry = MW_ZR_REACH * m;
+      unsigned o = 0, fn = 0, qy = 0;
+      for (int dd = -r - MW_ZR_BEFORE - 1; dd <= r + MW_ZR_AFTER + 1; dd++) {
+        const unsigned v = b[m][kk + LO + dd][jj];
+        fn |= v;
+        if (dd >= -r - MW_ZR_BEFORE && dd <= r + MW_ZR_AFTER) o |= v;
+        if (dd >= -ry && dd <= ry) qy |= v;
+      }
       M[(long long)(m + 1) * msz + (long long)k * p.zq_ld + j + MW_ZR_HALO] = o;
+      M[(long long)(m + 4) * msz + (long long)k * p.zq_ld + j + MW_ZR_HALO] = fn;
+      M[(long long)(m + 7) * msz + (long long)k * p.zq_ld + j + MW_ZR_HALO] = qy;
     }
   }
 }
@@ -850,14 +885,49 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
     for (int s = 0; s < ORD; s++) zm[v] |= (__any(w[5 + v][s] != 0.0) ? 1u : 0u) << s;
     if (!tracer_may_vanish<K>(p, v)) zm[v] = ~0u;
   }
+  // zero-row maps (see k_zero_rows / k_zero_dilate), as scalar masks over the chunk's iterations (bit i: j = ja-1+i):
+  //   ym_st: a tracer kernel's row beside face j may load the face's fluxes of the tracers that can vanish -- else they are not stored;
+  //   ym_ld: those tracers may be non-zero in what the iteration touches -- else the entering row is not loaded (it is zero).
+  // A wave's lanes belong to one level, or to two when it straddles a row end: both levels' words then.  (Iterations beyond the 64th,
+  // waves over more than two levels: all bits set.)
+  constexpr unsigned VANM = (K == 1) ? (((1u << T) - 1u) & ~1u) : ((1u << T) - 1u);        // (= tracer_may_vanish<K>)
+  unsigned long long ym_st = ~0ull, ym_ld = ~0ull;
+  if (!MT && p.zq != nullptr && p.zero_skip) {
+    const int kA = __builtin_amdgcn_readfirstlane(k), ieA = __builtin_amdgcn_readfirstlane(ie);
+    if (ieA + 63 < 2 * NXI) {
+      const unsigned *fnA = p.zq + 3 * (long long)p.nz * p.zq_ld + (long long)kA * p.zq_ld + MW_ZR_HALO;
+      const long long nextk = (ieA + 63 >= NXI && kA + 1 < p.nz) ? p.zq_ld : 0;     // the wave's last lanes lie in the next level
+      const int ji = ja - 1 + (int)(threadIdx.x & 63);
+      bool st = (ji > jb);
+      if (ji >= 1 && ji - 1 < p.ny) st = st || (((fnA[ji - 1] | fnA[ji - 1 + nextk]) & VANM) != 0u);
+      if (ji >= 0 && ji < p.ny)     st = st || (((fnA[ji] | fnA[ji + nextk]) & VANM) != 0u);
+      ym_st = __ballot(st);
+      const unsigned *qyA = fnA + 3 * (long long)p.nz * p.zq_ld;
+      const int jw = wrap_row(p, ji);
+      bool ld = true;
+      if (ji <= jb && jw >= 0 && jw < p.ny) ld = ((qyA[jw] | qyA[jw + nextk]) & VANM) != 0u;
+      ym_ld = __ballot(ld);
+    }
+  }
 #endif
   for (int j = ja - 1; j <= jb; j++) {
     const int jn = min(j + HS + 1, p.ny + p.HY - 1);            // clamp: the last prefetch is never used
     CouplerCell raw;
-    if (CONV) raw = load_coupler_cell<K>(p, c, MW_ROW_CI(jn));
+#if MW_ZERO_SKIP
+    const bool lean = (j - (ja - 1)) < 64 && !((ym_ld >> (j - (ja - 1))) & 1ull);
+#else
+    constexpr bool lean = false;
+#endif
+    if (CONV) raw = load_coupler_cell<K>(p, c, MW_ROW_CI(jn), lean ? ~VANM : ~0u);
     else {
 #pragma unroll
-      for (int v = 0; v < NV; v++) nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
+      for (int v = 0; v < NV; v++) nxt[v] = 0.0;
+#pragma unroll
+      for (int v = 0; v < NV; v++) if (v < 5 || !((VANM >> (v >= 5 ? v - 5 : 0)) & 1u)) nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
+      if (!lean) {
+#pragma unroll
+        for (int v = 5; v < NV; v++) if ((VANM >> (v - 5)) & 1u) nxt[v] = col[(long long)v * p.sV + (long long)(wrap_row(p, jn) + p.HY) * p.sJ];
+      }
     }
     double se[NV], ne[NV];
 #pragma unroll
@@ -905,6 +975,9 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
 #pragma unroll
         for (int v = 0; v < T; v++) {                          // scalar copies first (a select between two arrays' elements would go through scratch)
           const double sv = se[5 + v], cv = cn[5 + v];
+#if MW_ZERO_SKIP
+          if (((VANM >> v) & 1u) && (j - (ja - 1)) < 64 && !((ym_st >> (j - (ja - 1))) & 1ull)) continue;   // nobody will load it
+#endif
           fy[(long long)(5 + v) * p.fyV + (long long)j * p.fyJ] = fs.m_upw * (up ? sv : cv);
         }
       }
@@ -1649,12 +1722,15 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   // zero-row map of this stage (see k_zero_rows): bit i of zq_mask = "iteration kstart + i of this wave's row may touch something
   // non-zero of a tracer that can vanish" -- one word per iteration, fetched by the lanes here and kept as a scalar mask
   // (iterations beyond the 64th: bit set)
+  // (the form an iteration takes follows from the map alone, for any chunk length: k_y_all relies on it -- it does not store the y fluxes
+  //  that only LEAN iterations would read)
   unsigned long long zq_mask = ~0ull;
-  if (!MT && p.zq != nullptr) {
-    const int kq = kstart + lane;
-    const unsigned wq = p.zq[(long long)min(kq, p.nz - 1) * p.zq_ld + j + MW_ZR_HALO];
-    zq_mask = __ballot((wq & ((K == 1) ? ~1u : ~0u)) != 0u || !p.zero_skip);
-  }
+  const bool zq_on = !MT && (p.zq != nullptr) && p.zero_skip;
+  auto zq_fetch = [&](int k_first) __attribute__((always_inline)) {
+    const unsigned wq = p.zq[(long long)min(k_first + lane, p.nz - 1) * p.zq_ld + j + MW_ZR_HALO];
+    zq_mask = __ballot((wq & ((K == 1) ? ~1u : ~0u)) != 0u);
+  };
+  if (zq_on) zq_fetch(kstart);
 #endif
   // The loop body is branch-free apart from predicated stores and the rare limiter paths: every load uses a clamped
   // (always valid) address and is issued at the top, the z reconstruction (registers only) runs while they are in flight.
@@ -1881,7 +1957,9 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   for (int k = kstart; k <= kb + 1; k++) {
     bool lean = false;
 #if MW_ZERO_SKIP
-    { const int it = k - kstart; lean = (it < 64) && !((zq_mask >> it) & 1ull); }
+    { const int it = k - kstart;
+      if (zq_on && it > 0 && (it & 63) == 0) zq_fetch(k);       // (chunks of more than 64 levels)
+      lean = !((zq_mask >> (it & 63)) & 1ull); }
 #endif
     if (lean) body(std::integral_constant<unsigned, (FULLM & ~VANM)>{}, k);
     else      body(std::integral_constant<unsigned, FULLM>{}, k);

@@ -100,7 +100,7 @@ def pytest_sessionfinish(session, exitstatus):
 _DISPATCHED = {"k_y_all", "k_y_state", "k_y_tracers", "k_xz_state", "k_tracers_fused", "k_tracer_patch", "k_xz_tracers", "k_tracer_update",
                "k_flux", "k_fct", "k_update", "k_coupler_to_state", "k_coupler_to_state_fast", "k_coupler_to_member", "k_member_to_coupler",
                "k_member_to_fused", "k_halo_xyz", "k_pack_xy", "k_unpack_xy", "k_init_cells", "k_perturb_temperature",
-               "k_perturb_temperature_random", "k_state_xyz"}
+               "k_perturb_temperature_random", "k_state_xyz", "k_zero_rows", "k_zero_merge", "k_zero_halo", "k_zero_dilate"}
 
 
 def _compiled_dycore_kernels(lib_path):
