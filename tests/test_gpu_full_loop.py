@@ -131,3 +131,36 @@ def test_default_2d_run_reaches_the_recorded_state_at_step_800(mw):
     assert 0.9 * R["rho_c_max"] < f["tracer1"].max() < 1.1 * R["rho_c_max"]
     assert 0.6 * R["rho_r_max"] < f["tracer2"].max() < 1.4 * R["rho_r_max"]
     assert f["tracer1"].min() >= 0 and f["tracer2"].min() >= 0
+
+
+def test_zero_row_maps_through_a_developing_storm(mw):
+    """The zero-row maps (option zero_rows, mw_march.h: k_zero_rows) under the real thing: the complete supercell loop in 3-D -- dycore,
+    Kessler, sponge, nudger -- from the cloud-free initial state through the first condensation to a storm with cloud and rain, two handles in
+    lockstep, one with the maps and one without.  Every field equal at every 25th step and at the end (the maps are a superset of where
+    cloud and rain are, whatever Kessler creates between two dycore steps); on the way the map-driven lean form must have been in use
+    (cloud-free rows exist throughout) and the storm must have arrived (cloud and rain non-zero in part of the domain)."""
+    from miniweatherml_amd import modules
+    from util import launched_kernels
+    names = ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid", "precip_liquid")
+    runs = []
+    for rows in (1, 0):
+        coupler, dycore, micro, nudger = modules.make_supercell(100, 40, 40, 1, 1.0e5, 4.0e4, 2.0e4, with_nudger=True)
+        dycore.set_option("zero_rows", rows)
+        runs.append((coupler, dycore, micro, nudger))
+    launched_kernels(reset=True)
+    first_cloud = None
+    for n in range(1, 801):
+        for coupler, dycore, micro, nudger in runs:
+            modules.supercell_step(coupler, dycore, micro, nudger)
+        if n % 25 == 0 or n == 800:
+            a, b = (r[0].get_data_manager_readonly() for r in runs)
+            for name in names:
+                assert torch.equal(a.get(name, True), b.get(name, True)), (name, n)
+            if first_cloud is None and float(a.get("cloud_liquid", True).max()) > 0.0:
+                first_cloud = n
+    assert any("k_zero_rows" in k for k in launched_kernels())
+    dm = runs[0][0].get_data_manager_readonly()
+    cl, pr = dm.get("cloud_liquid", True), dm.get("precip_liquid", True)
+    assert first_cloud is not None and first_cloud < 800
+    assert 0.0 < float((cl != 0).double().mean()) < 0.5 and 0.0 < float((pr != 0).double().mean()) < 0.5
+    assert float(cl.max()) > 1.0e-4 and float(pr.max()) > 1.0e-5
