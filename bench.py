@@ -728,6 +728,7 @@ def main():
                        "schedule": sched["streams"], "schedule_code": sched["code"], "y_faces_in_one_launch": sched["y_all"],
                        "dispatcher_path": dycore.path(),
                        "zero_tracer_shortcut": bool(dycore.get_option("zero_skip")),   # (bit-neutral: tracers that are exactly 0 over a wavefront's stencil are not reconstructed)
+                       "zero_stores_skipped": bool(dycore.get_option("zero_skip") and dycore.get_option("zero_rows") and dycore.get_option("zero_stores")),   # (... nor are zeros stored over rows that hold zeros already)
                        "zero_row_maps": bool(dycore.get_option("zero_skip") and dycore.get_option("zero_rows")),   # (... and x rows of a tracer that are known to be 0 are neither loaded nor computed by the fused tracer kernel)
                        "rccl_ranks": (infos[0] or {}).get("comm_ranks") if world > 1 else None,
                        "rccl_per_rank": infos if world > 1 else None,

@@ -104,7 +104,8 @@ int  mw_dycore_set_strict(mw_dycore_t h, int strict);
  * marching kernels skip the reconstructions of a tracer that is exactly zero over a wavefront's whole stencil: bit-neutral, 1 by default),
  * "zero_rows" (on top of it: per sub-cycle a map of the x rows in which a tracer can be non-zero -- scanned from the input, grown by the three
  * cells per direction an RK stage can move it, OR-ed with the neighbour blocks' maps on a decomposed domain -- lets the fused tracer
- * kernel neither load nor compute rows of cloud / rain that are zero; same results, 1 by default).
+ * kernel neither load nor compute rows of cloud / rain that are zero; same results, 1 by default), "zero_stores" (... nor store zeros over
+ * rows that hold zeros already: the coupler's own arrays, the stage slabs; 1 by default).
  * Launch shapes: "chunk_y", "chunk_yt", "chunk_z", "chunk_f" (cells per chunk, 0 = the chunk model), "chunk_model".  Built-in transport
  * (read when mw_dycore_use_rccl / _self installs it): "rccl_lanes" (0 = process default | 1 | 2), "rccl_two_comms" (-1 | 0 | 1), "rccl_prio" (1: side streams at the highest priority), "rccl_inline" (1: the group runs on the caller's stream, no side stream),
  * "xchg_fuzz" (seed of random delays around the sends / receives; a test aid).  Experiments that are not part of the release build:

@@ -62,6 +62,7 @@ struct DyP {                      // kernel parameter block (by value)
   // zero-row map of the current RK stage (mw_march.h: k_zero_rows), nullptr = none: one word per (level, row), bit v = "tracer v may be
   // non-zero in what iterations k-3 .. k of the row's marching wave touch"; word of (k, j) at [k * zq_ld + j + HY]
   const unsigned *zq;
+  const unsigned *zqp, *zqc;      // ... "the row an iteration stores to holds zeros already": the previous sub-cycle's map of this stage / the coupler's rows (mw_march.h)
   int zq_ld;
   unsigned pos_mask, mass_mask;
   double dx, dy, dz, rdx, rdy, rdz, C0, gamma, grav, fcor, R_d, R_v;
@@ -921,6 +922,7 @@ struct DyOpts {
   int tf_rows4 = 1;            // tracer stage: workgroup = 4 rows of one x tile (0: 4 tiles of one row)
   int zero_skip = 1;           // wave-uniform short-cut for tracers that are exactly zero over a wavefront's stencil (bit-neutral; 0: A/B)
   int zero_rows = 1;           // ... and the zero-row maps on top of it: rows of a tracer that are known to be zero are not loaded (mw_march.h: k_zero_rows)
+  int zero_stores = 1;         // ... and zeros are not stored over rows that hold zeros already (the coupler's arrays, slabs S1 / S2; 0: A/B)
   int rccl_lanes = 0, rccl_two_comms = -1;            // built-in RCCL transport: side streams (1 | 2), a communicator per lane (0 | 1); 0 / -1 = the
                                                       // process default (MW_RCCL_LANES); read when mw_dycore_use_rccl* installs the transport
   int rccl_prio = 1;           // ... its side streams at the highest stream priority (0: default priority; A/B)
@@ -954,11 +956,14 @@ struct mw_dycore_s {
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
   int chunk_y = 0, chunk_yt = 0, chunk_z = 0, chunk_f = 0;
+  bool first_cycle = false;                // the running sub-cycle is the time step's first (zero_rows_build)
   bool conv_pending = false;               // time_step: the coupler -> slab conversion is still to be done by stage 1's k_y_state
   unsigned int *dirty = nullptr;           // two words: "a y face was scaled in this / the next fused tracer launch"
   unsigned long long fused_launches = 0;
   unsigned char *flags = nullptr;          // fused tracer stage: per-cell "a y face of this cell was FCT-scaled" bits
   double *zrx = nullptr;                   // ... and the message buffers of a decomposed block's map exchange (own | rW | rE | sS | sN | rS | rN)
+  int zr_cur = 0;                          // ... double-buffered: set zr_cur belongs to the running sub-cycle, the other one to the one before
+  bool zr_prev_ok = false, zr_prev_use = false;   // the other set describes what slabs S1 / S2 hold now (the sub-cycle before ran with maps, nothing else wrote the slabs since) / ... and is handed to this sub-cycle's kernels
   unsigned *zr = nullptr; long long zr_msz = 0; bool zr_on = false;   // zero-row maps (M0 and the six of k_zero_dilate) of the running sub-cycle (mw_march.h: k_zero_rows), zr_msz words each
   int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows (see DyP::hypk)
@@ -1008,7 +1013,7 @@ static void fill_params(mw_dycore_s *d) {
   p.bc_x = g.bc_x; p.bc_y = g.bc_y; p.bc_z = g.bc_z; p.px = g.px; p.py = g.py; p.nproc_x = g.nproc_x; p.nproc_y = g.nproc_y;
   p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
   p.zero_skip = d->o.zero_skip;
-  p.zq = nullptr; p.zq_ld = 0;                                  // (set per RK stage by zero_rows_stage)
+  p.zq = p.zqp = p.zqc = nullptr; p.zq_ld = 0;                  // (set per RK stage by zero_rows_stage)
   p.pos_mask = 0; p.mass_mask = 0;
   for (int t = 0; t < g.num_tracers; t++) { if (d->pos[t]) p.pos_mask |= 1u << t; if (d->adds[t]) p.mass_mask |= 1u << t; }
   p.dx = g.xlen / g.nx_glob; p.dy = g.ylen / g.ny_glob; p.dz = g.zlen / g.nz;        // coupler.h:262-268
@@ -1754,7 +1759,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
 // one stage ahead because the M/UP buffers are double-buffered and the four slabs rotate (event ev_tr of stage s-2).
 // ---------------------------------------------------------------------------------------------------------------------
 static void zero_rows_stage(mw_dycore_s *d, int stage);
-static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st);
+static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st, bool first_cycle);
 template <int STAGE, int MODE>
 static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double *Sout, double dt_stage, double dt_dyn,
                           const CouplerPtrs &c) {
@@ -1841,7 +1846,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
     MW_HIP(hipEventRecord(d->ev_pipe[3], xs));
     d->pipe_edge_done = edge_side;
     if (STAGE == 1) {                                           // the sub-cycle's zero-row maps, behind the strips: needed by the tracer kernel only
-      if (zero_rows_build(d, Sin, c, conv, xs)) return 1;
+      if (zero_rows_build(d, Sin, c, conv, xs, d->first_cycle)) return 1;
       if (d->zr_on) MW_HIP(hipEventRecord(d->ev_pipe[4], xs));
     }
   }
@@ -1889,7 +1894,7 @@ static bool zero_rows_ok(const mw_dycore_s *d) {
 }
 // ... built at the start of a sub-cycle from its input on stream `st`: the coupler's arrays while the conversion is still pending (it
 // happens inside the first y launch), slab S0 otherwise.  Blocks of a decomposed domain: + the neighbours' maps (see k_zero_merge).
-static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st) {
+static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st, bool first_cycle) {
   d->zr_on = zero_rows_ok(d);
   if (!d->zr_on) return 0;
   DyP &p = d->p;
@@ -1901,9 +1906,12 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   if (!d->zr || d->zr_msz != msz) {
     if (d->zr) { MW_HIP(hipDeviceSynchronize()); (void)hipFree(d->zr); d->zr = nullptr; }
     if (d->zrx) { (void)hipFree(d->zrx); d->zrx = nullptr; }
-    if (hipMalloc(&d->zr, MW_ZR_MAPS * (size_t)msz * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }
-    d->zr_msz = msz;
+    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 1) * (size_t)msz * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }   // two sets + MC
+    d->zr_msz = msz; d->zr_prev_ok = false;
   }
+  d->zr_cur ^= 1;                                               // build into the other set; the one of the sub-cycle before stays readable
+  d->zr_prev_use = d->zr_prev_ok && d->o.zero_stores;
+  unsigned *const zr = d->zr + (long long)d->zr_cur * MW_ZR_MAPS * msz;
   if ((ex_x || ex_y) && !d->zrx) {
     if (hipMalloc(&d->zrx, (size_t)(3 * dWE + 4 * dSN) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); MW_FAIL("zero-row maps: out of device memory"); }
     // (a failure here is an error, not a fall-back: the other ranks are about to exchange maps)
@@ -1914,7 +1922,7 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   ProfScope ps(d, 4, st);
   const dim3 g((unsigned)((nrow + 3) / 4));
   const bool local = !ex_x && !ex_y;
-  unsigned *own = local ? d->zr : (unsigned *)d->zrx;
+  unsigned *own = local ? zr : (unsigned *)d->zrx;
   const int ldo = local ? ld : p.ny, offo = local ? MW_ZR_HALO : 0;
   if (from_coupler) MW_KLAUNCH(k_zero_rows<false>, g, dim3(256), 0, st, p, c, S0, own, vmask, ldo, offo, local ? 1 : 0);
   else              MW_KLAUNCH(k_zero_rows<true>, g, dim3(256), 0, st, p, c, S0, own, vmask, ldo, offo, local ? 1 : 0);
@@ -1922,31 +1930,36 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   if (!local) {
     double *rW = d->zrx + dWE, *rE = d->zrx + 2 * dWE, *sS = d->zrx + 3 * dWE, *sN = sS + dSN, *rS = sN + dSN, *rN = rS + dSN;
     if (ex_x && d->xchg(d->xchg_ctx, d->zrx, d->zrx, nullptr, nullptr, rW, rE, nullptr, nullptr, dWE, 0, st)) MW_FAIL("zero-row maps: exchange callback failed");
-    MW_KLAUNCH(k_zero_merge, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, p, own, ex_x ? (const unsigned *)rW : nullptr, (const unsigned *)rE, d->zr,
+    MW_KLAUNCH(k_zero_merge, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, p, own, ex_x ? (const unsigned *)rW : nullptr, (const unsigned *)rE, zr,
                ex_y ? (unsigned *)sS : nullptr, (unsigned *)sN);
     MW_LAUNCH_CHECK();
     if (ex_y) {
       if (d->xchg(d->xchg_ctx, nullptr, nullptr, sS, sN, nullptr, nullptr, rS, rN, 0, dSN, st)) MW_FAIL("zero-row maps: exchange callback failed");
-      MW_KLAUNCH(k_zero_halo, dim3((unsigned)((nedge + 255) / 256)), dim3(256), 0, st, p, d->zr, (const unsigned *)rS, (const unsigned *)rN);
+      MW_KLAUNCH(k_zero_halo, dim3((unsigned)((nedge + 255) / 256)), dim3(256), 0, st, p, zr, (const unsigned *)rS, (const unsigned *)rN);
       MW_LAUNCH_CHECK();
     }
   }
-  MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, p, d->zr, msz);
+  // the first sub-cycle's M0 doubles as "which rows of the coupler's tracer arrays are zero" until the last sub-cycle's D13 (map MC)
+  if (first_cycle) MW_HIP(hipMemcpyAsync(d->zr + 2 * MW_ZR_MAPS * msz, zr, (size_t)msz * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+  MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, p, zr, msz);
   MW_LAUNCH_CHECK();
   return 0;
 }
 // ... and handed to the kernels of RK stage `stage` (1..3) through the parameter block
 static void zero_rows_stage(mw_dycore_s *d, int stage) {
   DyP &p = d->p;
-  if (!d->zr_on) { p.zq = nullptr; p.zq_ld = 0; return; }
-  p.zq = d->zr + (long long)stage * d->zr_msz;
+  if (!d->zr_on || stage < 1) { p.zq = p.zqp = p.zqc = nullptr; p.zq_ld = 0; return; }
+  const long long set = (long long)MW_ZR_MAPS * d->zr_msz;
+  p.zq = d->zr + d->zr_cur * set + (long long)stage * d->zr_msz;
+  p.zqp = (d->zr_prev_use && stage <= 2) ? d->zr + (d->zr_cur ^ 1) * set + (long long)stage * d->zr_msz : nullptr;   // (S1, S2: the slab of stage s is always the same one)
+  p.zqc = d->o.zero_stores ? d->zr + 2 * set : nullptr;
   p.zq_ld = p.ny + 2 * MW_ZR_HALO;
 }
 // One SSPRK3 sub-cycle.  Slabs: Q[0] = q^n, Q[1..3] scratch; on return the new q^n is in Q[3] (caller rotates).
 static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, const CouplerPtrs &c) {
   const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
   d->zr_on = false;
-  if (!d->pipe && zero_rows_build(d, Q[0], c, d->conv_pending, d->stream)) return 1;     // (pipelined schedule: inside its first stage, on the exchange stream)
+  if (!d->pipe && zero_rows_build(d, Q[0], c, d->conv_pending, d->stream, d->first_cycle)) return 1;     // (pipelined schedule: inside its first stage, on the exchange stream)
   if (d->pipe) {                                              // blocks of a decomposed domain, pipelined schedule
     d->pipe_ready = false; d->pipe_edge_done = false;
     if (rk_stage_pipe<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;
@@ -1962,7 +1975,7 @@ static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, 
       MW_LAUNCH_CHECK();
     }
     d->flux_src = Q[2]; d->flux_dt = dt3;
-    d->zr_on = false; zero_rows_stage(d, 0);
+    d->zr_prev_ok = d->zr_on; d->zr_on = false; zero_rows_stage(d, 0);
     return 0;
   }
   if (rk_stage_march<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;                        // stage 1 (:119-132)
@@ -1980,7 +1993,7 @@ static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, 
     if (d->overlap) MW_HIP(hipEventRecord(d->ev_tr[(d->gstage - 1) & 7], ts));     // the step's join waits for this event
   }
   d->flux_src = Q[2]; d->flux_dt = dt3;
-  d->zr_on = false; zero_rows_stage(d, 0);
+  d->zr_prev_ok = d->zr_on; d->zr_on = false; zero_rows_stage(d, 0);
   return 0;
 }
 
@@ -2134,7 +2147,7 @@ const OptDesc OPTS[] = {
   {"mm_direct", &DyOpts::mm_direct, 0, 1, 0}, {"mm_conv", &DyOpts::mm_conv, 0, 1, 0}, {"fused_convert", &DyOpts::fused_convert, 0, 1, 0},
   {"fused_convert_mm", &DyOpts::fused_convert_mm, 0, 1, 0}, {"chunk_y", &DyOpts::chunk_y, 0, 1 << 20, 0}, {"chunk_yt", &DyOpts::chunk_yt, 0, 1 << 20, 0},
   {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
-  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
+  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"zero_stores", &DyOpts::zero_stores, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
   {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0}, {"rccl_inline", &DyOpts::rccl_inline, 0, 1, 0},
   {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
   {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},
@@ -2197,6 +2210,7 @@ int mw_dycore_set_order(mw_dycore_t d, int ord) {
         return rollback();
       }
     }
+    d->zr_prev_ok = false;
     double **S[4] = {&d->S0, &d->S1, &d->S2, &d->S3};
     for (int i = 0; i < 4; i++) { if (*S[i]) (void)hipFree(*S[i]); *S[i] = fresh[i]; }
     d->flux_src = nullptr;                                      // pointed into a slab that no longer exists
@@ -2243,6 +2257,7 @@ int mw_dycore_get_fluxes(mw_dycore_t d, double **out6) {
   if (d->flux_src) {     // production path: the state-variable fluxes of the last stage were never written; rebuild all six
     if (d->member_major) {   // the retained stage input is member-major: bring it into the fused layout the general kernels read (S1 is free)
       const long long n = (long long)d->p.V * d->p.sV;
+      d->zr_prev_ok = false;
       MW_KLAUNCH(k_member_to_fused, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, d->p, d->flux_src, d->S1);
       MW_LAUNCH_CHECK();
       d->flux_src = d->S1;
@@ -2403,6 +2418,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   dt_dyn = dt_phys / ncycles;                                             // :108
   for (int icycle = 0; icycle < ncycles; icycle++) {
     bool last = (icycle == ncycles - 1);
+    d->first_cycle = (icycle == 0);
     if (march) {
       double *Q[4] = {d->S0, d->S1, d->S2, d->S3};
       if (rk_cycle_march(d, Q, dt_dyn, last, c)) return 1;
@@ -2410,6 +2426,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
       continue;
     }
     // stage 1 (:119-132)
+    d->zr_prev_ok = false;                                      // (the general path writes the slabs without maps)
     if (halo_fill(d, d->S0)) return 1;
     if (launch_flux(d, d->S0)) return 1;
     if (launch_fct(d, d->S0, dt_dyn)) return 1;

@@ -445,6 +445,13 @@ __global__ __launch_bounds__(256) void k_zero_halo(DyP p, unsigned *__restrict__
 #define MW_ZR_AFTER 1                                             // levels above: the y fluxes of level k+1 (chunk ends clamp k-1 upwards)
 //   QYs[k][j] at M + (6 + s) * msz = M0 dilated by 3s rows and 3(s-1) levels = the input of stage s, three more rows either way: what
 //   iteration j of k_y_all's wave at level k touches (the window of face j, the row that enters it, the edge value carried from j-1).
+// Zeros are not stored over zeros either (DyP::zqc / zqp, host side: zero_rows_build):
+//   MC (zqc) = M0 of the time step's FIRST sub-cycle = which rows of the coupler's own tracer arrays are zero (nothing writes them before the
+//   last sub-cycle's D13): a lean iteration of the last stage does not store there;
+//   the PREVIOUS sub-cycle's Qs (zqp; s = 1, 2 -- slabs S1 and S2 always take the output of stages 1 and 2): level k of a row is stored by
+//   iteration k+2, in the lean form (zeros) exactly when Qs[k+2][j] was clear -- for every x tile of the row alike, the form follows from the
+//   row's word alone -- so where the previous Qs is clear the slab row holds zeros already and a lean iteration leaves it alone.  The host
+//   hands the previous maps over only when the previous sub-cycle ran with maps and nothing else has written the slabs since.
 #define MW_ZR_MAPS 10
 __global__ __launch_bounds__(256) void k_zero_dilate(DyP p, unsigned *__restrict__ M, long long msz) {
   constexpr int TK = 16, TJ = 64, R = MW_ZR_HALO, LO = R + MW_ZR_BEFORE + 1, HI = R + MW_ZR_AFTER + 1, EK = TK + LO + HI, EJ = TJ + 2 * R;
@@ -1731,6 +1738,18 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     zq_mask = __ballot((wq & ((K == 1) ? ~1u : ~0u)) != 0u);
   };
   if (zq_on) zq_fetch(kstart);
+  // (bit i of zc_mask = "the row that iteration kstart + i stores to may hold something non-zero": the coupler's arrays in MODE 1 -- map MC,
+  //  the level that is stored -- the result slab otherwise -- the previous sub-cycle's map of this stage, the iteration that stored it)
+  unsigned long long zc_mask = ~0ull;
+  const unsigned *zc_map = (MODE == 1) ? p.zqc : p.zqp;
+  const bool zc_on = zq_on && (zc_map != nullptr);
+  auto zc_fetch = [&](int k_first) __attribute__((always_inline)) {
+    const int kq_ = (MODE == 1) ? min(max(k_first + lane - 2, ka), kb - 1) : min(k_first + lane, p.nz - 1);
+    const unsigned wc = zc_map[(long long)kq_ * p.zq_ld + j + MW_ZR_HALO];
+    zc_mask = __ballot((wc & ((K == 1) ? ~1u : ~0u)) != 0u);
+  };
+  if (zc_on) zc_fetch(kstart);
+  bool zc_store = true;
 #endif
   // The loop body is branch-free apart from predicated stores and the rare limiter paths: every load uses a clamped
   // (always valid) address and is issued at the top, the z reconstruction (registers only) runs while they are in flight.
@@ -1903,8 +1922,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #pragma unroll
       for (int v = 0; v < T; v++) {
         if (!MW_ACT(v)) {                                        // LEAN form: the tracer is zero and stays zero
-          if (MODE == 0) { if (st) Sout[so + (5 + t0 + v) * p.sV] = 0.0; }
-          else           { if (st) c.tr[v][cpl(p, ci)] = 0.0; }
+          if (MODE == 0) { if (st && zc_store) Sout[so + (5 + t0 + v) * p.sV] = 0.0; }     // (not over a row that is zero already: see zc_mask)
+          else           { if (st && zc_store) c.tr[v][cpl(p, ci)] = 0.0; }
           continue;
         }
         const double q_s = (ORD == 3 ? wkm2[v] : w[v][0]) * rhos2;           // level k-2
@@ -1958,8 +1977,9 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     bool lean = false;
 #if MW_ZERO_SKIP
     { const int it = k - kstart;
-      if (zq_on && it > 0 && (it & 63) == 0) zq_fetch(k);       // (chunks of more than 64 levels)
-      lean = !((zq_mask >> (it & 63)) & 1ull); }
+      if (zq_on && it > 0 && (it & 63) == 0) { zq_fetch(k); if (zc_on) zc_fetch(k); }         // (chunks of more than 64 levels)
+      lean = !((zq_mask >> (it & 63)) & 1ull);
+      zc_store = (zc_mask >> (it & 63)) & 1ull; }
 #endif
     if (lean) body(std::integral_constant<unsigned, (FULLM & ~VANM)>{}, k);
     else      body(std::integral_constant<unsigned, FULLM>{}, k);

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"overlap": -1, "pipe": 1, "pipe_edge_inline": 0, "pipe_convert": 1, "pipe_split_edges": 1, "spec": 1, "wrap": 1, "y_all": 1, "y_all_conv": 1,
             "member_major": 1, "mm_direct": 1, "mm_conv": 1, "fused_convert": 1, "fused_convert_mm": 1, "fused_tracers": 1, "chunk_y": 0, "chunk_yt": 0,
-            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "zero_rows": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
+            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "zero_rows": 1, "zero_stores": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
 
 
 def test_defaults_round_trips_and_errors(mw):
@@ -167,3 +167,41 @@ def test_zero_row_maps_are_bit_neutral(mw, case):
         assert np.array_equal(res[0][k], res[2][k]), k
     if case == "specks":
         assert float(res[0]["tracer1"].max()) > 0.0 and float((res[0]["tracer1"] == 0).mean()) > 0.5
+
+
+def test_zero_stores_survive_a_change_of_path(mw):
+    """Option zero_stores (default 1): a lean iteration of the fused tracer kernel does not store zeros over a row that holds zeros already --
+    the coupler's own arrays (known from the step's first scan), the stage slabs S1 / S2 (known from the PREVIOUS sub-cycle's maps).  The
+    second only holds while nothing else writes the slabs: a step on the general kernels in between (set_strict(2): they use S1 as their
+    stage slab, without maps) must invalidate it.  Sequence on one handle -- marching steps, one of them sub-cycled, a general step, marching
+    steps again, the fluxes of the last stage read back (mw_dycore_get_fluxes reads slab S2 whole) -- against the same sequence with
+    zero_stores = 0 and with the maps off: same bits, fluxes included."""
+    import torch
+    from miniweatherml_amd import modules
+    res = []
+    for opts in ({}, {"zero_stores": 0}, {"zero_rows": 0}):
+        coupler, dycore, _ = modules.make_supercell(130, 44, 26, 1, 65000., 22000., 20000.)
+        dm = coupler.get_data_manager_readwrite()
+        rho = dm.get("density_dry")
+        box = torch.zeros_like(rho)
+        box[5:12, 15:27, 50:90] = 1.0
+        dm.get("cloud_liquid").copy_(3.0e-4 * box * rho)
+        dm.get("precip_liquid").copy_(1.0e-4 * box * rho)
+        for k, v in opts.items():
+            dycore.set_option(k, v)
+        dt = dycore.compute_time_step(coupler)
+        for n in range(3):
+            dycore.time_step(coupler, dt * (2.2 if n == 1 else 1.0))
+        dycore.set_strict(2)
+        dycore.time_step(coupler, dt)
+        dycore.set_strict(0)
+        for n in range(3):
+            dycore.time_step(coupler, dt)
+        f = gpu_fields(coupler)
+        for name, a in dycore.fluxes(coupler).items():
+            f[name] = a.cpu().numpy().copy()
+        res.append(f)
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+        assert np.array_equal(res[0][k], res[2][k]), k
+    assert float((res[0]["tracer1"] == 0).mean()) > 0.3
