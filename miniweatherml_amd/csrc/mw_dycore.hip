@@ -62,6 +62,7 @@ struct DyP {                      // kernel parameter block (by value)
   // zero-row map of the current RK stage (mw_march.h: k_zero_rows), nullptr = none: one word per (level, row), bit v = "tracer v may be
   // non-zero in what iterations k-3 .. k of the row's marching wave touch"; word of (k, j) at [k * zq_ld + j + HY]
   const unsigned *zq;
+  const unsigned *zqk;            // ... the converting y launch: the rows of the slab it writes that hold zeros already
   const unsigned *zqp, *zqc;      // ... "the row an iteration stores to holds zeros already": the previous sub-cycle's map of this stage / the coupler's rows (mw_march.h)
   int zq_ld;
   unsigned pos_mask, mass_mask;
@@ -962,6 +963,7 @@ struct mw_dycore_s {
   unsigned long long fused_launches = 0;
   unsigned char *flags = nullptr;          // fused tracer stage: per-cell "a y face of this cell was FCT-scaled" bits
   double *zrx = nullptr;                   // ... and the message buffers of a decomposed block's map exchange (own | rW | rE | sS | sN | rS | rN)
+  const double *kz_buf[2] = {nullptr, nullptr};   // ... and, for the two slabs that take turns as q^n, "the rows the last conversion into it left zero" (maps behind MC; nullptr: unknown)
   int zr_cur = 0;                          // ... double-buffered: set zr_cur belongs to the running sub-cycle, the other one to the one before
   bool zr_prev_ok = false, zr_prev_use = false;   // the other set describes what slabs S1 / S2 hold now (the sub-cycle before ran with maps, nothing else wrote the slabs since) / ... and is handed to this sub-cycle's kernels
   unsigned *zr = nullptr; long long zr_msz = 0; bool zr_on = false;   // zero-row maps (M0 and the six of k_zero_dilate) of the running sub-cycle (mw_march.h: k_zero_rows), zr_msz words each
@@ -1013,7 +1015,7 @@ static void fill_params(mw_dycore_s *d) {
   p.bc_x = g.bc_x; p.bc_y = g.bc_y; p.bc_z = g.bc_z; p.px = g.px; p.py = g.py; p.nproc_x = g.nproc_x; p.nproc_y = g.nproc_y;
   p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
   p.zero_skip = d->o.zero_skip;
-  p.zq = p.zqp = p.zqc = nullptr; p.zq_ld = 0;                  // (set per RK stage by zero_rows_stage)
+  p.zq = p.zqp = p.zqc = p.zqk = nullptr; p.zq_ld = 0;          // (set per RK stage by zero_rows_stage / zero_rows_conv)
   p.pos_mask = 0; p.mass_mask = 0;
   for (int t = 0; t < g.num_tracers; t++) { if (d->pos[t]) p.pos_mask |= 1u << t; if (d->adds[t]) p.mass_mask |= 1u << t; }
   p.dx = g.xlen / g.nx_glob; p.dy = g.ylen / g.ny_glob; p.dz = g.zlen / g.nz;        // coupler.h:262-268
@@ -1759,6 +1761,8 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
 // one stage ahead because the M/UP buffers are double-buffered and the four slabs rotate (event ev_tr of stage s-2).
 // ---------------------------------------------------------------------------------------------------------------------
 static void zero_rows_stage(mw_dycore_s *d, int stage);
+static void zero_rows_conv(mw_dycore_s *d, const double *S, bool done, hipStream_t st);
+static void zero_rows_forget(mw_dycore_s *d, const double *S);
 static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st, bool first_cycle);
 template <int STAGE, int MODE>
 static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double *Sout, double dt_stage, double dt_dyn,
@@ -1778,6 +1782,8 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   const bool mm_conv_ok = d->mm_direct && d->o.mm_conv && marching_config(d, view(d, 0).p) != 0;
   const bool fxyz = fused_state_ok(d) && !conv;                 // (round 4 experiment: all three directions of the state variables in one launch)
   const bool yall = !fxyz && y_all_ok(d) && !(conv && ((d->member_major && !mm_conv_ok) || !d->o.y_all_conv));   // y faces of state variables and tracers in one launch
+  if (STAGE == 1) { if (conv) zero_rows_conv(d, Sin, false, ss); else zero_rows_forget(d, Sin); }   // (what is known about the rows of the slab that is about to be written)
+  if (STAGE == 3 && MODE == 0) zero_rows_forget(d, Sout);
 #ifdef MW_EXPERIMENTS
   if (fxyz) { if (launch_state_xyz<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1; }
   else
@@ -1785,6 +1791,7 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   {
   if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin, conv ? &c : nullptr)) return 1; }
   else if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
+  if (STAGE == 1 && conv) zero_rows_conv(d, Sin, true, ss);
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
   }
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
@@ -1847,10 +1854,12 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
     d->pipe_edge_done = edge_side;
     if (STAGE == 1) {                                           // the sub-cycle's zero-row maps, behind the strips: needed by the tracer kernel only
       if (zero_rows_build(d, Sin, c, conv, xs, d->first_cycle)) return 1;
+      if (conv) zero_rows_conv(d, Sin, true, xs); else zero_rows_forget(d, Sin);
       if (d->zr_on) MW_HIP(hipEventRecord(d->ev_pipe[4], xs));
     }
   }
   if (STAGE != 1) zero_rows_stage(d, STAGE);                    // (stage 1: its y launches run BESIDE the map build -- the maps are handed over in front of the tracer kernel)
+  if (STAGE == 3 && MODE == 0) zero_rows_forget(d, Sout);
   d->pipe_ready = false;
   if (launch_y_all(d, Sin, conv ? &c : nullptr, 1)) return 1;  // rows whose chunks read no halo row
   MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));           // state strips (+ the edge rows' y tendencies) of this stage's input
@@ -1906,8 +1915,8 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   if (!d->zr || d->zr_msz != msz) {
     if (d->zr) { MW_HIP(hipDeviceSynchronize()); (void)hipFree(d->zr); d->zr = nullptr; }
     if (d->zrx) { (void)hipFree(d->zrx); d->zrx = nullptr; }
-    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 1) * (size_t)msz * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }   // two sets + MC
-    d->zr_msz = msz; d->zr_prev_ok = false;
+    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 3) * (size_t)msz * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }   // two sets + MC + the two q^n slabs' maps
+    d->zr_msz = msz; d->zr_prev_ok = false; d->kz_buf[0] = d->kz_buf[1] = nullptr;
   }
   d->zr_cur ^= 1;                                               // build into the other set; the one of the sub-cycle before stays readable
   d->zr_prev_use = d->zr_prev_ok && d->o.zero_stores;
@@ -1948,12 +1957,31 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
 // ... and handed to the kernels of RK stage `stage` (1..3) through the parameter block
 static void zero_rows_stage(mw_dycore_s *d, int stage) {
   DyP &p = d->p;
+  p.zqk = nullptr;
   if (!d->zr_on || stage < 1) { p.zq = p.zqp = p.zqc = nullptr; p.zq_ld = 0; return; }
   const long long set = (long long)MW_ZR_MAPS * d->zr_msz;
   p.zq = d->zr + d->zr_cur * set + (long long)stage * d->zr_msz;
   p.zqp = (d->zr_prev_use && stage <= 2) ? d->zr + (d->zr_cur ^ 1) * set + (long long)stage * d->zr_msz : nullptr;   // (S1, S2: the slab of stage s is always the same one)
   p.zqc = d->o.zero_stores ? d->zr + 2 * set : nullptr;
   p.zq_ld = p.ny + 2 * MW_ZR_HALO;
+}
+// The converting y launch (first stage of a time step, conversion inside k_y_all) writes slab S: before it, hand over what is known about S's
+// rows (written by the last conversion into S, untouched since); after it (`done`), S's rows are zero exactly where the coupler's are: map MC.
+static void zero_rows_conv(mw_dycore_s *d, const double *S, bool done, hipStream_t st) {
+  const long long msz = d->zr_msz;
+  int sl = (d->kz_buf[0] == S) ? 0 : (d->kz_buf[1] == S) ? 1 : -1;
+  if (!done) { d->p.zqk = (sl >= 0 && d->zr_on && d->o.zero_stores) ? d->zr + (2 * MW_ZR_MAPS + 1 + sl) * msz : nullptr; return; }
+  d->p.zqk = nullptr;
+  if (!d->zr_on) { if (sl >= 0) d->kz_buf[sl] = nullptr; return; }
+  if (sl < 0) {                                                 // a free slot, else the one of a slab that is not one of the two q^n slabs any more
+    const double *other = (S == d->S0) ? d->S3 : d->S0;
+    sl = (d->kz_buf[0] == nullptr) ? 0 : (d->kz_buf[1] == nullptr) ? 1 : (d->kz_buf[0] != other) ? 0 : 1;
+  }
+  (void)hipMemcpyAsync(d->zr + (2 * MW_ZR_MAPS + 1 + sl) * msz, d->zr + 2 * MW_ZR_MAPS * msz, (size_t)msz * sizeof(unsigned), hipMemcpyDeviceToDevice, st);
+  d->kz_buf[sl] = S;
+}
+static void zero_rows_forget(mw_dycore_s *d, const double *S) {   // slab S is about to be written by something that keeps no map
+  for (int i = 0; i < 2; i++) if (!S || d->kz_buf[i] == S) d->kz_buf[i] = nullptr;
 }
 // One SSPRK3 sub-cycle.  Slabs: Q[0] = q^n, Q[1..3] scratch; on return the new q^n is in Q[3] (caller rotates).
 static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, const CouplerPtrs &c) {
@@ -2210,7 +2238,7 @@ int mw_dycore_set_order(mw_dycore_t d, int ord) {
         return rollback();
       }
     }
-    d->zr_prev_ok = false;
+    d->zr_prev_ok = false; d->kz_buf[0] = d->kz_buf[1] = nullptr;
     double **S[4] = {&d->S0, &d->S1, &d->S2, &d->S3};
     for (int i = 0; i < 4; i++) { if (*S[i]) (void)hipFree(*S[i]); *S[i] = fresh[i]; }
     d->flux_src = nullptr;                                      // pointed into a slab that no longer exists
@@ -2426,7 +2454,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
       continue;
     }
     // stage 1 (:119-132)
-    d->zr_prev_ok = false;                                      // (the general path writes the slabs without maps)
+    d->zr_prev_ok = false; zero_rows_forget(d, nullptr);        // (the general path writes the slabs without maps)
     if (halo_fill(d, d->S0)) return 1;
     if (launch_flux(d, d->S0)) return 1;
     if (launch_fct(d, d->S0, dt_dyn)) return 1;

@@ -851,13 +851,17 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   const int sja_ = pre_on_ ? max(ja, pre_lo) : ja;
   const int sjb_ = (pre_on_ && (ie < p.HX * p.nens || ie >= NXI - p.HX * p.nens)) ? sja_ : (pre_on_ ? min(jb, pre_hi) : jb);
 #define MW_ROW_CI(r) cpl(p, ((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
-#define MW_ROW_FINISH(raw, r, out)                                                                                    \
+  constexpr unsigned VANM = (K == 1) ? (((1u << T) - 1u) & ~1u) : ((1u << T) - 1u);        // (= tracer_may_vanish<K>)
+  /* (skipv: wave-uniform -- the tracers that can vanish are zero in this row AND the slab row holds zeros already, see ym_ss) */
+#define MW_ROW_FINISH(raw, r, out, skipv)                                                                             \
   { double inv_den_;                                                                                                  \
     convert_cell_fast<K>(p, raw, hyr, hyt, p0, out, inv_den_);                                                        \
     _Pragma("unroll") for (int v_ = 0; v_ < T; v_++) out[5 + v_] = tracer_slab_value(raw.tr[v_], inv_den_);          \
     if ((r) >= sja_ && (r) < sjb_) {                                                                                  \
       double *s_ = Sw + (long long)(k + p.HZ) * p.sK + (long long)((r) + p.HY) * p.sJ + (long long)p.HX * p.nens + ie; \
-      _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++) s_[(long long)v_ * p.sV] = out[v_];                           \
+      _Pragma("unroll") for (int v_ = 0; v_ < 5; v_++) s_[(long long)v_ * p.sV] = out[v_];                            \
+      _Pragma("unroll") for (int v_ = 5; v_ < NV; v_++) if (!((VANM >> (v_ - 5)) & 1u)) s_[(long long)v_ * p.sV] = out[v_]; \
+      if (!(skipv)) { _Pragma("unroll") for (int v_ = 5; v_ < NV; v_++) if ((VANM >> (v_ - 5)) & 1u) s_[(long long)v_ * p.sV] = out[v_]; } \
     } }
 #pragma unroll
   for (int v = 0; v < NV; v++) cn[v] = 0;
@@ -868,7 +872,7 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
     for (int s = 0; s < ORD; s++) {
       const CouplerCell raw = load_coupler_cell<K>(p, c, MW_ROW_CI(ja - 1 - HS + s));
       double r8[NV];
-      MW_ROW_FINISH(raw, ja - 1 - HS + s, r8)
+      MW_ROW_FINISH(raw, ja - 1 - HS + s, r8, false)
 #pragma unroll
       for (int v = 0; v < NV; v++) w[v][s] = r8[v];
     }
@@ -897,8 +901,9 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   //   ym_ld: those tracers may be non-zero in what the iteration touches -- else the entering row is not loaded (it is zero).
   // A wave's lanes belong to one level, or to two when it straddles a row end: both levels' words then.  (Iterations beyond the 64th,
   // waves over more than two levels: all bits set.)
-  constexpr unsigned VANM = (K == 1) ? (((1u << T) - 1u) & ~1u) : ((1u << T) - 1u);        // (= tracer_may_vanish<K>)
-  unsigned long long ym_st = ~0ull, ym_ld = ~0ull;
+  //   ym_ss (converting launch): the slab row that the iteration writes may hold something non-zero (DyP::zqk = the map of the rows the LAST
+  //   conversion into this slab left zero; nullptr: unknown) -- else the zeros of a lean iteration are not stored over zeros.
+  unsigned long long ym_st = ~0ull, ym_ld = ~0ull, ym_ss = ~0ull;
   if (!MT && p.zq != nullptr && p.zero_skip) {
     const int kA = __builtin_amdgcn_readfirstlane(k), ieA = __builtin_amdgcn_readfirstlane(ie);
     if (ieA + 63 < 2 * NXI) {
@@ -914,6 +919,13 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
       bool ld = true;
       if (ji <= jb && jw >= 0 && jw < p.ny) ld = ((qyA[jw] | qyA[jw + nextk]) & VANM) != 0u;
       ym_ld = __ballot(ld);
+      if (CONV && p.zqk != nullptr) {
+        const unsigned *kzA = p.zqk + (long long)kA * p.zq_ld + MW_ZR_HALO;
+        const int jr = wrap_row(p, min(ji + HS + 1, p.ny + p.HY - 1));       // the row iteration ji converts and stores
+        bool ss = true;
+        if (ji <= jb && jr >= 0 && jr < p.ny) ss = ((kzA[jr] | kzA[jr + nextk]) & VANM) != 0u;
+        ym_ss = __ballot(ss);
+      }
     }
   }
 #endif
@@ -1002,7 +1014,12 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
 #pragma unroll
       for (int l = 0; l < 5; l++) { if (CONV) lds_fprev[l][threadIdx.x] = f[l]; else fprev_r[l] = f[l]; }
     }
-    if (CONV) MW_ROW_FINISH(raw, jn, nxt)
+#if MW_ZERO_SKIP
+    const bool ss_skip = CONV && lean && (j - (ja - 1)) < 64 && !((ym_ss >> (j - (ja - 1))) & 1ull);
+#else
+    constexpr bool ss_skip = false;
+#endif
+    if (CONV) MW_ROW_FINISH(raw, jn, nxt, ss_skip)
 #if MW_ZERO_SKIP
 #pragma unroll
     for (int v = 0; v < T; v++) if (tracer_may_vanish<K>(p, v)) zm[v] = (zm[v] >> 1) | ((__any(nxt[5 + v] != 0.0) ? 1u : 0u) << (ORD - 1));
