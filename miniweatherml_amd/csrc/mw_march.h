@@ -913,18 +913,19 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
       bool st = (ji > jb);
       if (ji >= 1 && ji - 1 < p.ny) st = st || (((fnA[ji - 1] | fnA[ji - 1 + nextk]) & VANM) != 0u);
       if (ji >= 0 && ji < p.ny)     st = st || (((fnA[ji] | fnA[ji + nextk]) & VANM) != 0u);
-      ym_st = __ballot(st);
+      const unsigned long long idle = ~__ballot(true);           // (the grid's last wave may be partial: iterations whose lane is not there keep their bit)
+      ym_st = __ballot(st) | idle;
       const unsigned *qyA = fnA + 3 * (long long)p.nz * p.zq_ld;
       const int jw = wrap_row(p, ji);
       bool ld = true;
       if (ji <= jb && jw >= 0 && jw < p.ny) ld = ((qyA[jw] | qyA[jw + nextk]) & VANM) != 0u;
-      ym_ld = __ballot(ld);
+      ym_ld = __ballot(ld) | idle;
       if (CONV && p.zqk != nullptr) {
         const unsigned *kzA = p.zqk + (long long)kA * p.zq_ld + MW_ZR_HALO;
         const int jr = wrap_row(p, min(ji + HS + 1, p.ny + p.HY - 1));       // the row iteration ji converts and stores
         bool ss = true;
         if (ji <= jb && jr >= 0 && jr < p.ny) ss = ((kzA[jr] | kzA[jr + nextk]) & VANM) != 0u;
-        ym_ss = __ballot(ss);
+        ym_ss = __ballot(ss) | idle;
       }
     }
   }
@@ -1752,7 +1753,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const bool zq_on = !MT && (p.zq != nullptr) && p.zero_skip;
   auto zq_fetch = [&](int k_first) __attribute__((always_inline)) {
     const unsigned wq = p.zq[(long long)min(k_first + lane, p.nz - 1) * p.zq_ld + j + MW_ZR_HALO];
-    zq_mask = __ballot((wq & ((K == 1) ? ~1u : ~0u)) != 0u);
+    zq_mask = __ballot((wq & ((K == 1) ? ~1u : ~0u)) != 0u) | ~__ballot(true);     // (all 64 lanes are here; a missing one would keep its bit)
   };
   if (zq_on) zq_fetch(kstart);
   // (bit i of zc_mask = "the row that iteration kstart + i stores to may hold something non-zero": the coupler's arrays in MODE 1 -- map MC,
@@ -1763,7 +1764,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   auto zc_fetch = [&](int k_first) __attribute__((always_inline)) {
     const int kq_ = (MODE == 1) ? min(max(k_first + lane - 2, ka), kb - 1) : min(k_first + lane, p.nz - 1);
     const unsigned wc = zc_map[(long long)kq_ * p.zq_ld + j + MW_ZR_HALO];
-    zc_mask = __ballot((wc & ((K == 1) ? ~1u : ~0u)) != 0u);
+    zc_mask = __ballot((wc & ((K == 1) ? ~1u : ~0u)) != 0u) | ~__ballot(true);
   };
   if (zc_on) zc_fetch(kstart);
   bool zc_store = true;

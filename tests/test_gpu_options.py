@@ -122,14 +122,16 @@ def test_zero_tracer_shortcut_is_bit_neutral(mw, case):
         assert float(res[0]["tracer1"].max()) > 0.0 and float((res[0]["tracer1"] == 0).mean()) > 0.5
 
 
-@pytest.mark.parametrize("case", ["cloud_free", "one_storm", "specks", "city", "ord3"])
+@pytest.mark.parametrize("case", ["cloud_free", "one_storm", "specks", "city", "ord3", "ragged"])
 def test_zero_row_maps_are_bit_neutral(mw, case):
     """Option zero_rows (default 1, round 5): per (level, row) and tracer a bit "may be non-zero", scanned from the sub-cycle's input and
     dilated by 3 rows / levels per RK stage (mw_march.h: k_zero_rows, k_zero_dilate); k_y_all and k_tracers_fused do not load rows whose bit
     is clear, k_y_all does not store y fluxes nobody loads.  The maps must be a superset of the non-zero rows: the same bits as with the
     maps switched off, and as with the whole zero short-cut switched off -- on a cloud-free state, on one box of cloud and rain, on single
     non-zero cells in the corners, on the faces and next to the periodic seams (a too small dilation shows here), on the city, at WENO-3;
-    three steps, one of them sub-cycled (a sub-cycle rebuilds the maps from the slab instead of the coupler's arrays)."""
+    three steps, one of them sub-cycled (a sub-cycle rebuilds the maps from the slab instead of the coupler's arrays).  "ragged": 129 x 44 x 12
+    cells -- the y kernel's last wavefront has 12 lanes (its iteration masks come from a ballot: the missing lanes' iterations must not read
+    as "nothing to load / store"), cloud in exactly those cells, one chunk of 44 rows."""
     import torch
     from miniweatherml_amd import modules
     from util import launched_kernels
@@ -137,6 +139,13 @@ def test_zero_row_maps_are_bit_neutral(mw, case):
     for rows, skip in ((1, 1), (0, 1), (0, 0)):
         if case == "city":
             coupler, dycore, _, _ = modules.make_simple_city(96, 48, 16, 1, 480., 240., 80., "building")
+        elif case == "ragged":
+            coupler, dycore, _ = modules.make_supercell(129, 44, 12, 1, 64500., 22000., 20000.)
+            dm = coupler.get_data_manager_readwrite()
+            rho = dm.get("density_dry")
+            cl = torch.zeros_like(rho)
+            cl[11, 20:24, 119:129] = 2.0e-4; cl[11, 40, 128] = 1.0e-4; cl[0, 3, 0] = 1.0e-4
+            dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(0.5 * cl * rho)
         else:
             coupler, dycore, _ = modules.make_supercell(130, 44, 26, 1, 65000., 22000., 20000., ord=(3 if case == "ord3" else 5))
             dm = coupler.get_data_manager_readwrite()
@@ -154,7 +163,7 @@ def test_zero_row_maps_are_bit_neutral(mw, case):
                     pr[k, j, i] = 1.0e-4
                 dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(pr * rho)
         dycore.set_option("zero_skip", skip); dycore.set_option("zero_rows", rows)
-        dycore.set_option("chunk_z", 7); dycore.set_option("chunk_f", 7); dycore.set_option("chunk_y", 9)
+        dycore.set_option("chunk_z", 7); dycore.set_option("chunk_f", 7); dycore.set_option("chunk_y", 44 if case == "ragged" else 9)
         dt = dycore.compute_time_step(coupler)
         launched_kernels(reset=True)
         for n in range(3):
