@@ -329,7 +329,7 @@ def test_boundaries_on_several_ranks_supercell(mw, oracle, layout):
         compare_fields(got[r], want[r], 1e-10, "supercell bc %s, rank %d of %d" % (bc, r, nranks))
 
 
-def _specks(coupler, nxg, nyg, nz):
+def _specks(coupler, nxg, nyg, nz, extra=()):
     """Single non-zero cells of cloud water / rain at GLOBAL positions: in the domain's corners, and one or two cells either side of the
     seams of a 2 x 2 / 4 x 2 / 1 x 2 decomposition -- what a block's tracer kernel sees of them arrives through its halos."""
     dm = coupler.get_data_manager_readwrite()
@@ -340,6 +340,8 @@ def _specks(coupler, nxg, nyg, nz):
     cloud = [(0, 0, 0), (nz - 1, nyg - 1, nxg - 1), (3, nyg // 2 - 1, nxg // 2 - 1), (4, nyg // 2, nxg // 2 + 1), (2, nyg // 2 + 2, 5),
              (nz - 2, 7, nxg // 2), (nz // 2, nyg - 1, nxg // 4), (1, nyg // 2 - 2, nxg - 1)]
     rain = [(nz // 2, nyg // 2, nxg // 4 - 1), (0, nyg - 2, nxg // 2 - 2), (nz - 1, 1, 3 * nxg // 4)]
+    cloud += [e[:3] for e in extra if e[3] == 0]
+    rain += [e[:3] for e in extra if e[3] == 1]
     for lst, fld, val in ((cloud, cl, 2.0e-4), (rain, pr, 1.0e-4)):
         for (k, j, i) in lst:
             if jb <= j < jb + ny and ib <= i < ib + nx:
@@ -348,25 +350,25 @@ def _specks(coupler, nxg, nyg, nz):
     dm.get("precip_liquid").copy_(pr * rho)
 
 
-def _specks_blocks(layout, zero_rows, fuzz):
+def _specks_blocks(layout, zero_rows, fuzz, nz=12, extra=(), factors=(1.0, 2.3, 1.0)):
     from miniweatherml_amd import capi, modules
     from util import StreamExchanger
     nranks, nxg, nyg = layout
-    nz, nsteps = 12, 3
+    nsteps = len(factors)
     ex = StreamExchanger(nranks, fuzz_seed=fuzz)
     results, keep = [None] * nranks, []
 
     def worker(rank):
         try:
             coupler, dycore, _ = modules.make_supercell(nxg, nyg, nz, 1, 500.0 * nxg, 500.0 * nyg, 20000., nranks=nranks, myrank=rank)
-            _specks(coupler, nxg, nyg, nz)
+            _specks(coupler, nxg, nyg, nz, extra)
             dycore.set_option("zero_rows", zero_rows)
             cb = ex.make_cb(rank, coupler.grid)
             keep.append(cb)
             capi.check(capi.lib().mw_dycore_set_exchange(dycore.h, cb, None))
             dt = dycore.compute_time_step(coupler)
             for n in range(nsteps):
-                dycore.time_step(coupler, dt * (2.3 if n == 1 else 1.0))
+                dycore.time_step(coupler, dt * factors[n])
             torch.cuda.synchronize()
             results[rank] = (coupler.grid.i_beg, coupler.grid.j_beg, gpu_fields(coupler), dycore.path())
         except Exception as e:                                          # pragma: no cover
@@ -382,6 +384,23 @@ def _specks_blocks(layout, zero_rows, fuzz):
     torch.cuda.synchronize()
     ex.close()
     return results
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_zero_row_maps_on_random_decompositions(mw, seed):
+    """Seeded sweep: 2, 4 or 8 blocks of random (uneven) extents, random levels, cloud / rain cells at random global positions on top of the
+    seam cells, random sub-cycling, random transport delays -- the maps on against the maps off on the same decomposition: same bits."""
+    rng = np.random.default_rng(500 + seed)
+    nranks = int(rng.choice([2, 4, 8]))
+    nxg, nyg, nz = int(rng.integers(76, 170)), int(rng.integers(40, 100)), int(rng.integers(6, 20))
+    extra = [(int(rng.integers(0, nz)), int(rng.integers(0, nyg)), int(rng.integers(0, nxg)), int(rng.integers(0, 2))) for _ in range(int(rng.integers(0, 12)))]
+    factors = (1.0, float(rng.choice([1.0, 2.3])), 1.0)
+    on = _specks_blocks((nranks, nxg, nyg), 1, 11 + seed, nz=nz, extra=extra, factors=factors)
+    off = _specks_blocks((nranks, nxg, nyg), 0, 0, nz=nz, extra=extra, factors=factors)
+    for (ib, jb, blk, path), (ib0, jb0, ref, _) in zip(on, off):
+        assert (ib, jb) == (ib0, jb0)
+        for k, a in blk.items():
+            assert np.array_equal(a, ref[k]), (k, ib, jb, seed, nranks, nxg, nyg, nz)
 
 
 @pytest.mark.parametrize("layout", [(4, 96, 64), (8, 160, 40), (2, 40, 72)])

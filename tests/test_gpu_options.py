@@ -214,3 +214,48 @@ def test_zero_stores_survive_a_change_of_path(mw):
         assert np.array_equal(res[0][k], res[1][k]), k
         assert np.array_equal(res[0][k], res[2][k]), k
     assert float((res[0]["tracer1"] == 0).mean()) > 0.3
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_zero_row_maps_on_random_configurations(mw, seed):
+    """Seeded sweep over what the zero-row maps depend on: grid extents (odd sizes, last wavefronts of any width, rows shorter than a wave,
+    fewer levels than a chunk), chunk lengths of all three marching kernels, WENO order, the folded and the run-time configuration (with the
+    switches at run time ALL tracers can vanish: water vapour is zeroed outside a box there), cloud / rain as boxes and single cells anywhere,
+    sub-cycled steps.  Maps on (with zero_stores) against maps off on the same handle settings: same bits."""
+    import torch
+    from miniweatherml_amd import modules
+    rng = np.random.default_rng(1000 + seed)
+    nx, ny, nz = int(rng.integers(18, 150)), int(rng.integers(9, 60)), int(rng.integers(3, 40))
+    order = 3 if seed % 5 == 4 else 5
+    spec = 0 if seed % 3 == 2 else 1
+    chunks = {k: int(rng.integers(3, 40)) for k in ("chunk_y", "chunk_f", "chunk_z") if rng.random() < 0.6}
+    nbox, nspeck = int(rng.integers(0, 3)), int(rng.integers(0, 6))
+    boxes = [(rng.integers(0, nz), rng.integers(0, ny), rng.integers(0, nx), rng.integers(1, 8), rng.integers(1, 12), rng.integers(1, 30)) for _ in range(nbox)]
+    specks = [(int(rng.integers(0, nz)), int(rng.integers(0, ny)), int(rng.integers(0, nx)), int(rng.integers(0, 2))) for _ in range(nspeck)]
+    vbox = (int(rng.integers(0, max(1, nz - 2))), int(rng.integers(0, ny)), int(rng.integers(0, nx)))
+    factors = [1.0, float(rng.choice([1.0, 2.2, 3.1])), 1.0]
+    res = []
+    for rows in (1, 0):
+        coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 500.0 * nx, 500.0 * ny, 20000., ord=order)
+        dm = coupler.get_data_manager_readwrite()
+        rho = dm.get("density_dry")
+        cl, pr = torch.zeros_like(rho), torch.zeros_like(rho)
+        for (k, j, i, dk, dj, di) in boxes:
+            cl[k:k + dk, j:j + dj, i:i + di] = 3.0e-4
+            pr[k:k + dk, j:j + max(1, dj // 2), i:i + di] = 1.0e-4
+        for (k, j, i, which) in specks:
+            (pr if which else cl)[k, j, i] = 2.0e-4
+        dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(pr * rho)
+        if spec == 0:
+            keep = torch.zeros_like(rho)
+            keep[vbox[0]:vbox[0] + 6, vbox[1]:vbox[1] + 12, vbox[2]:vbox[2] + 40] = 1.0
+            dm.get("water_vapor").mul_(keep)
+        dycore.set_option("spec", spec); dycore.set_option("zero_rows", rows)
+        for k, v in chunks.items():
+            dycore.set_option(k, v)
+        dt = dycore.compute_time_step(coupler)
+        for f in factors:
+            dycore.time_step(coupler, dt * f)
+        res.append(gpu_fields(coupler))
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), (k, seed, nx, ny, nz, order, spec, chunks)
