@@ -275,7 +275,12 @@ __device__ __forceinline__ void kessler_chunks_body(const KesP &p, double *__res
     double T = T_in;                                                     // (temperature form: see kessler_cell)
     double velqr = kessler_velqr(rr_in, rd, ird, rho0);                  // :260 (as k_kessler_prep saw it)
     flux_above = kessler_cell(p, k, rd, rho0, pp0, dt0, flux_above, T, qv, qc, qr, velqr, precl_acc);
-    rho_v[idx] = qv * rd; rho_c[idx] = qc * rd; rho_r[idx] = qr * rd;    // :154-161 [K5]
+    // :154-161 [K5].  (Round 5: cloud / rain that came in as zero and go out as zero over a whole wavefront -- most of the domain -- are not
+    //  stored again: 16 of the 72 bytes a cell costs.  Wave-uniform, so that no cache line is written in part.)
+    const double rc_out = qc * rd, rr_out = qr * rd;
+    rho_v[idx] = qv * rd;
+    if (__any(rc_in != 0.0 || rc_out != 0.0)) rho_c[idx] = rc_out;
+    if (__any(rr_in != 0.0 || rr_out != 0.0)) rho_r[idx] = rr_out;
     temp[idx] = T;
     rd = rd_n; T_in = T_n; rv_in = rv_n; rc_in = rc_n; rr_in = rr_n;
   }
