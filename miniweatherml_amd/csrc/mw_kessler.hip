@@ -297,7 +297,7 @@ __device__ __forceinline__ void kessler_chunks_body(const KesP &p, double *__res
     rho_v[idx] = qv * rd;
     if (__any(rc_in != 0.0 || rc_out != 0.0)) rho_c[idx] = rc_out;
     if (__any(rr_in != 0.0 || rr_out != 0.0)) rho_r[idx] = rr_out;
-    temp[idx] = T;
+    if (__any(T != T_in)) temp[idx] = T;                                 // (no phase change anywhere in the wavefront: the temperature comes back bit for bit)
     rd = rd_n; T_in = T_n; rv_in = rv_n; rc_in = rc_n; rr_in = rr_n;
   }
   if (c == 0) precl[i] = precl_acc / 1.0;                                // :332-334
