@@ -1116,6 +1116,11 @@ static View view(const mw_dycore_s *d, int e) {
   const double *m = d->hy_dev + 4 * nzc + 4 * nze + 8 * nze + (size_t)e * per;
   q.hyc = m; q.hytc = m + q.nz; q.p0c = m + 2 * q.nz; q.ihytc = m + 3 * q.nz; q.hypk = m + 4 * q.nz;
   q.hye = q.hyte = q.p0e = q.ihyte = nullptr;              // (edge tables: only through hypk on this path)
+  if (q.zq) {                                                  // the member's own zero-row maps (zero_rows_build)
+    const long long mstride = (2 * MW_ZR_MAPS + 3) * d->zr_msz;
+    q.zq += e * mstride; if (q.zqp) q.zqp += e * mstride;
+    q.zqc = q.zqk = nullptr;
+  }
   v.slab = (long long)q.V * q.sV; v.tend = 5 * q.nC; v.cells = q.nC;
   v.m[0] = q.fxV; v.m[1] = q.fyV; v.m[2] = q.fzV;
   v.f[0] = (long long)q.V * q.fxV; v.f[1] = (long long)q.V * q.fyV; v.f[2] = (long long)q.V * q.fzV;
@@ -1129,6 +1134,7 @@ static MemberOff member_off(const mw_dycore_s *d) {
   mo.slab = v.slab; mo.tend = v.tend; mo.mx = v.m[0]; mo.my = v.m[1]; mo.mz = v.m[2]; mo.fx = v.f[0]; mo.fy = v.f[1]; mo.fz = v.f[2];
   mo.cells = v.cells; mo.per = 4 * (long long)v.p.nz + 8 * (long long)(v.p.nz + 1);
   mo.n = d->p.nens; mo.sh = d->p.nens == 4 ? 2 : 1;
+  mo.zq = (2 * MW_ZR_MAPS + 3) * d->zr_msz;
   return mo;
 }
 
@@ -1794,6 +1800,10 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   if (STAGE == 1 && conv) zero_rows_conv(d, Sin, true, ss);
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;   // x,z faces + finished state variables
   }
+  if (STAGE == 1 && d->member_major && !d->overlap) {           // the members' maps, from the slab the y launch has just completed
+    if (zero_rows_build(d, Sin, c, false, ss, d->first_cycle)) return 1;
+    zero_rows_stage(d, 1);
+  }
   // ---- tracer pipeline.  Its halo fill (and, on several ranks, its strip exchange over RCCL) only needs the tracer values of the
   // previous stage, which this stream produced itself: it is issued BEFORE the wait for this stage's state kernels and so
   // runs beside them; the state stream's exchange for stage s+1 in turn runs beside this stage's tracer kernels.
@@ -1894,7 +1904,9 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
 // them must decide alike: the size test looks at the smallest block of the decomposition, not at this rank's.
 static bool zero_rows_ok(const mw_dycore_s *d) {
   const DyP &p = d->p;
-  if (!(d->o.zero_skip && d->o.zero_rows && d->fused && p.nens == 1 && p.nt >= 1 && p.nt <= 4 && !p.sim2d && !d->member_major &&
+  // (nens > 1: the member-major layout on one rank -- every member has its own maps and the per-member launches read them; the launches
+  //  that hold all members of a tile in one workgroup run without)
+  if (!(d->o.zero_skip && d->o.zero_rows && d->fused && (p.nens == 1 || (d->member_major && !d->xchg)) && p.nt >= 1 && p.nt <= 4 && !p.sim2d &&
         !fused_state_ok(d) && p.nz >= 2 && p.bc_x == MW_BC_PERIODIC && p.bc_y == MW_BC_PERIODIC)) return false;
   const long long nx_min = d->g.nx_glob / std::max(1, p.nproc_x), ny_min = d->g.ny_glob / std::max(1, p.nproc_y);
   if (ny_min < MW_ZR_HALO || nx_min < 2 * MW_ZR_HALO) return false;   // (a tracer must not cross a whole block in one sub-cycle)
@@ -1915,8 +1927,25 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   if (!d->zr || d->zr_msz != msz) {
     if (d->zr) { MW_HIP(hipDeviceSynchronize()); (void)hipFree(d->zr); d->zr = nullptr; }
     if (d->zrx) { (void)hipFree(d->zrx); d->zrx = nullptr; }
-    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 3) * (size_t)msz * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }   // two sets + MC + the two q^n slabs' maps
+    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 3) * (size_t)msz * sizeof(unsigned) * (size_t)p.nens) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }   // per member: two sets + MC + the two q^n slabs' maps
     d->zr_msz = msz; d->zr_prev_ok = false; d->kz_buf[0] = d->kz_buf[1] = nullptr;
+  }
+  if (d->member_major) {                                        // one map set per member, from the member's slab (the caller runs this behind the first y launch)
+    d->zr_cur ^= 1;
+    d->zr_prev_use = d->zr_prev_ok && d->o.zero_stores;
+    const long long mstride = (2 * MW_ZR_MAPS + 3) * msz;
+    const int K = marching_config(d, view(d, 0).p);
+    const unsigned vmask = (K == 1) ? 0x6u : 0xFu;
+    ProfScope ps(d, 4, st);
+    for (int e = 0; e < n_views(d); e++) {
+      const View v = view(d, e);
+      DyP q = v.p; q.zq_ld = ld;
+      unsigned *zr = d->zr + e * mstride + (long long)d->zr_cur * MW_ZR_MAPS * msz;
+      MW_KLAUNCH(k_zero_rows<true>, dim3((unsigned)((nrow + 3) / 4)), dim3(256), 0, st, q, c, v.S(S0), zr, vmask, ld, MW_ZR_HALO, 1);
+      MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, q, zr, msz);
+    }
+    MW_LAUNCH_CHECK();
+    return 0;
   }
   d->zr_cur ^= 1;                                               // build into the other set; the one of the sub-cycle before stays readable
   d->zr_prev_use = d->zr_prev_ok && d->o.zero_stores;
@@ -1962,7 +1991,8 @@ static void zero_rows_stage(mw_dycore_s *d, int stage) {
   const long long set = (long long)MW_ZR_MAPS * d->zr_msz;
   p.zq = d->zr + d->zr_cur * set + (long long)stage * d->zr_msz;
   p.zqp = (d->zr_prev_use && stage <= 2) ? d->zr + (d->zr_cur ^ 1) * set + (long long)stage * d->zr_msz : nullptr;   // (S1, S2: the slab of stage s is always the same one)
-  p.zqc = d->o.zero_stores ? d->zr + 2 * set : nullptr;
+  p.zqc = (d->o.zero_stores && !d->member_major) ? d->zr + 2 * set : nullptr;      // (member-major: the coupler's arrays are written by launches that read no maps)
+  // (member-major: these are member 0's; view() moves them on to its member)
   p.zq_ld = p.ny + 2 * MW_ZR_HALO;
 }
 // The converting y launch (first stage of a time step, conversion inside k_y_all) writes slab S: before it, hand over what is known about S's
@@ -1987,7 +2017,7 @@ static void zero_rows_forget(mw_dycore_s *d, const double *S) {   // slab S is a
 static int rk_cycle_march(mw_dycore_s *d, double **Q, double dt_dyn, bool last, const CouplerPtrs &c) {
   const double dt2 = (1.0 / 4.0) * dt_dyn, dt3 = (2.0 / 3.0) * dt_dyn;
   d->zr_on = false;
-  if (!d->pipe && zero_rows_build(d, Q[0], c, d->conv_pending, d->stream, d->first_cycle)) return 1;     // (pipelined schedule: inside its first stage, on the exchange stream)
+  if (!d->pipe && !d->member_major && zero_rows_build(d, Q[0], c, d->conv_pending, d->stream, d->first_cycle)) return 1;   // (pipelined schedule: inside its first stage, on the exchange stream; member-major: behind the first y launch, from the slab)
   if (d->pipe) {                                              // blocks of a decomposed domain, pipelined schedule
     d->pipe_ready = false; d->pipe_edge_done = false;
     if (rk_stage_pipe<1, 0>(d, Q[0], Q[0], Q[1], dt_dyn, dt_dyn, c)) return 1;

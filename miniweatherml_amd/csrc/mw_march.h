@@ -353,8 +353,8 @@ __global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtr
 // carries come from the three iterations before (input levels from k-5, y fluxes from k-5): with Qs[k][j]'s bit clear all of that is
 // exactly zero, and so is the tracer's new value.  The maps are a SUPERSET of the non-zero rows -- a set bit costs the loads, nothing
 // else -- and results equal the run without them (tests/: bitwise up to the sign of a zero; a skipped value enters as +0.0).
-// Handles: nens == 1, x and y periodic, the fused tracer stage; one rank, or the blocks of a decomposed domain on the pipelined
-// schedule (host side: zero_rows_ok / zero_rows_build in mw_dycore.hip).
+// Handles: x and y periodic, the fused tracer stage; nens == 1 on one rank or as the blocks of a decomposed domain on the pipelined schedule,
+// member-major handles (nens > 1) on one rank with one map set per member (host side: zero_rows_ok / zero_rows_build in mw_dycore.hip).
 // ---------------------------------------------------------------------------------------------------------------
 #define MW_ZR_REACH 3
 #define MW_ZR_HALO (3 * MW_ZR_REACH)                              // rows a tracer can travel in one sub-cycle = halo rows of the maps
@@ -573,6 +573,7 @@ __global__ __launch_bounds__(256) void k_member_to_coupler(DyP p, const double *
 // doubles apart, then meet in the CU's L1 / the XCD's L2 (the same idea as MemberOff below for the way out).
 struct MemberOff {
   long long slab, tend, mx, my, mz, fx, fy, fz, cells, per;    // doubles (selectors / flags: bytes) from member e to member e + 1
+  long long zq;                                                // ... and words, for the members' zero-row maps
   int n, sh;                                                   // members per workgroup (2 or 4) and log2 of it
 };
 struct YMember { long long sJ, sK, sV, slab, fyJ, fyK, mfy, nC, tend; int nx; long long per; int n, sh; };
@@ -1750,16 +1751,17 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   // (the form an iteration takes follows from the map alone, for any chunk length: k_y_all relies on it -- it does not store the y fluxes
   //  that only LEAN iterations would read)
   unsigned long long zq_mask = ~0ull;
-  const bool zq_on = !MT && (p.zq != nullptr) && p.zero_skip;
+  const bool zq_on = (p.zq != nullptr) && p.zero_skip;
+  const unsigned *zq_own = p.zq + (MT ? mt_e * mo.zq : 0);       // (members in one workgroup: this wave's member)
   auto zq_fetch = [&](int k_first) __attribute__((always_inline)) {
-    const unsigned wq = p.zq[(long long)min(k_first + lane, p.nz - 1) * p.zq_ld + j + MW_ZR_HALO];
+    const unsigned wq = zq_own[(long long)min(k_first + lane, p.nz - 1) * p.zq_ld + j + MW_ZR_HALO];
     zq_mask = __ballot((wq & ((K == 1) ? ~1u : ~0u)) != 0u) | ~__ballot(true);     // (all 64 lanes are here; a missing one would keep its bit)
   };
   if (zq_on) zq_fetch(kstart);
   // (bit i of zc_mask = "the row that iteration kstart + i stores to may hold something non-zero": the coupler's arrays in MODE 1 -- map MC,
   //  the level that is stored -- the result slab otherwise -- the previous sub-cycle's map of this stage, the iteration that stored it)
   unsigned long long zc_mask = ~0ull;
-  const unsigned *zc_map = (MODE == 1) ? p.zqc : p.zqp;
+  const unsigned *zc_map = MT ? nullptr : (MODE == 1) ? p.zqc : p.zqp;
   const bool zc_on = zq_on && (zc_map != nullptr);
   auto zc_fetch = [&](int k_first) __attribute__((always_inline)) {
     const int kq_ = (MODE == 1) ? min(max(k_first + lane - 2, ka), kb - 1) : min(k_first + lane, p.nz - 1);

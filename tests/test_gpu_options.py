@@ -122,7 +122,7 @@ def test_zero_tracer_shortcut_is_bit_neutral(mw, case):
         assert float(res[0]["tracer1"].max()) > 0.0 and float((res[0]["tracer1"] == 0).mean()) > 0.5
 
 
-@pytest.mark.parametrize("case", ["cloud_free", "one_storm", "specks", "city", "ord3", "ragged"])
+@pytest.mark.parametrize("case", ["cloud_free", "one_storm", "specks", "city", "ord3", "ragged", "nens4", "nens3", "nens2_specks"])
 def test_zero_row_maps_are_bit_neutral(mw, case):
     """Option zero_rows (default 1, round 5): per (level, row) and tracer a bit "may be non-zero", scanned from the sub-cycle's input and
     dilated by 3 rows / levels per RK stage (mw_march.h: k_zero_rows, k_zero_dilate); k_y_all and k_tracers_fused do not load rows whose bit
@@ -131,7 +131,9 @@ def test_zero_row_maps_are_bit_neutral(mw, case):
     non-zero cells in the corners, on the faces and next to the periodic seams (a too small dilation shows here), on the city, at WENO-3;
     three steps, one of them sub-cycled (a sub-cycle rebuilds the maps from the slab instead of the coupler's arrays).  "ragged": 129 x 44 x 12
     cells -- the y kernel's last wavefront has 12 lanes (its iteration masks come from a ballot: the missing lanes' iterations must not read
-    as "nothing to load / store"), cloud in exactly those cells, one chunk of 44 rows."""
+    as "nothing to load / store"), cloud in exactly those cells, one chunk of 44 rows.  "nens4" / "nens3" / "nens2_specks": member-major handles
+    (members in one workgroup for 2 and 4, the member-by-member pass for 3) -- one map set per member, cloud and rain differ from member to
+    member (member 0 has none)."""
     import torch
     from miniweatherml_amd import modules
     from util import launched_kernels
@@ -146,6 +148,19 @@ def test_zero_row_maps_are_bit_neutral(mw, case):
             cl = torch.zeros_like(rho)
             cl[11, 20:24, 119:129] = 2.0e-4; cl[11, 40, 128] = 1.0e-4; cl[0, 3, 0] = 1.0e-4
             dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(0.5 * cl * rho)
+        elif case.startswith("nens"):
+            nens = int(case[4])
+            coupler, dycore, _ = modules.make_supercell(130, 44, 26, nens, 65000., 22000., 20000.)
+            dm = coupler.get_data_manager_readwrite()
+            rho = dm.get("density_dry")
+            cl, pr = torch.zeros_like(rho), torch.zeros_like(rho)
+            for e in range(1, nens):
+                if case.endswith("specks"):
+                    cl[0, 0, 0, e] = 2.0e-4; cl[25, 43, 129, e] = 2.0e-4; cl[12, 21, 64, e] = 1.0e-4; pr[9, 1, 127, e] = 1.0e-4
+                else:
+                    cl[3 + e:15, 9:31 - 3 * e, 37 + 5 * e:101, e] = 3.0e-4
+                    pr[3 + e:12, 12:25, 40:90 - 7 * e, e] = 1.0e-4
+            dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(pr * rho)
         else:
             coupler, dycore, _ = modules.make_supercell(130, 44, 26, 1, 65000., 22000., 20000., ord=(3 if case == "ord3" else 5))
             dm = coupler.get_data_manager_readwrite()
@@ -220,14 +235,15 @@ def test_zero_stores_survive_a_change_of_path(mw):
 def test_zero_row_maps_on_random_configurations(mw, seed):
     """Seeded sweep over what the zero-row maps depend on: grid extents (odd sizes, last wavefronts of any width, rows shorter than a wave,
     fewer levels than a chunk), chunk lengths of all three marching kernels, WENO order, the folded and the run-time configuration (with the
-    switches at run time ALL tracers can vanish: water vapour is zeroed outside a box there), cloud / rain as boxes and single cells anywhere,
-    sub-cycled steps.  Maps on (with zero_stores) against maps off on the same handle settings: same bits."""
+    switches at run time ALL tracers can vanish: water vapour is zeroed outside a box there), one to four members (member-major handles keep
+    one map set per member), cloud / rain as boxes and single cells anywhere, sub-cycled steps.  Maps on (with zero_stores) against maps off on the same handle settings: same bits."""
     import torch
     from miniweatherml_amd import modules
     rng = np.random.default_rng(1000 + seed)
     nx, ny, nz = int(rng.integers(18, 150)), int(rng.integers(9, 60)), int(rng.integers(3, 40))
     order = 3 if seed % 5 == 4 else 5
     spec = 0 if seed % 3 == 2 else 1
+    nens = (1, 1, 2, 1, 4, 3)[seed % 6]                          # (member-major handles: one map set per member; every other member cloud-free)
     chunks = {k: int(rng.integers(3, 40)) for k in ("chunk_y", "chunk_f", "chunk_z") if rng.random() < 0.6}
     nbox, nspeck = int(rng.integers(0, 3)), int(rng.integers(0, 6))
     boxes = [(rng.integers(0, nz), rng.integers(0, ny), rng.integers(0, nx), rng.integers(1, 8), rng.integers(1, 12), rng.integers(1, 30)) for _ in range(nbox)]
@@ -236,16 +252,17 @@ def test_zero_row_maps_on_random_configurations(mw, seed):
     factors = [1.0, float(rng.choice([1.0, 2.2, 3.1])), 1.0]
     res = []
     for rows in (1, 0):
-        coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 500.0 * nx, 500.0 * ny, 20000., ord=order)
+        coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, 500.0 * nx, 500.0 * ny, 20000., ord=order)
         dm = coupler.get_data_manager_readwrite()
         rho = dm.get("density_dry")
         cl, pr = torch.zeros_like(rho), torch.zeros_like(rho)
+        member = torch.tensor([1.0 if (e + seed) % 2 == 0 or nens == 1 else 0.0 for e in range(nens)], device=rho.device, dtype=rho.dtype)
         for (k, j, i, dk, dj, di) in boxes:
             cl[k:k + dk, j:j + dj, i:i + di] = 3.0e-4
             pr[k:k + dk, j:j + max(1, dj // 2), i:i + di] = 1.0e-4
         for (k, j, i, which) in specks:
             (pr if which else cl)[k, j, i] = 2.0e-4
-        dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(pr * rho)
+        dm.get("cloud_liquid").copy_(cl * rho * member); dm.get("precip_liquid").copy_(pr * rho * member)
         if spec == 0:
             keep = torch.zeros_like(rho)
             keep[vbox[0]:vbox[0] + 6, vbox[1]:vbox[1] + 12, vbox[2]:vbox[2] + 40] = 1.0
@@ -258,4 +275,4 @@ def test_zero_row_maps_on_random_configurations(mw, seed):
             dycore.time_step(coupler, dt * f)
         res.append(gpu_fields(coupler))
     for k in res[0]:
-        assert np.array_equal(res[0][k], res[1][k]), (k, seed, nx, ny, nz, order, spec, chunks)
+        assert np.array_equal(res[0][k], res[1][k]), (k, seed, nx, ny, nz, nens, order, spec, chunks)
