@@ -99,7 +99,7 @@ int  mw_dycore_set_strict(mw_dycore_t h, int strict);
  * switches of rounds 1-4: typed integers stored in the handle, read when the schedule of a time step is decided; no entry point of this
  * library reads the environment per call (the two process defaults left: MW_STRICT=1 at mw_dycore_create, MW_RCCL_LANES for the
  * built-in transport).  Schedule: "overlap" (-1 automatic | 0 | 1: the two-stream schedule), "pipe" (1: the pipelined schedule of a
- * decomposed block), "pipe_edge_inline", "pipe_convert", "pipe_split_edges".  Kernel forms: "spec" (folded configurations), "wrap" (index wrap on one
+ * decomposed block), "pipe_edge_inline", "pipe_convert", "pipe_split_edges", "pipe_maps_early".  Kernel forms: "spec" (folded configurations), "wrap" (index wrap on one
  * rank), "y_all", "y_all_conv", "member_major", "mm_direct", "mm_conv", "fused_convert", "fused_convert_mm", "fused_tracers", "tf_rows4", "zero_skip" (the
  * marching kernels skip the reconstructions of a tracer that is exactly zero over a wavefront's whole stencil: bit-neutral, 1 by default),
  * "zero_rows" (on top of it: per sub-cycle a map of the x rows in which a tracer can be non-zero -- scanned from the input, grown by the three

@@ -923,6 +923,7 @@ struct DyOpts {
   int tf_rows4 = 1;            // tracer stage: workgroup = 4 rows of one x tile (0: 4 tiles of one row)
   int zero_skip = 1;           // wave-uniform short-cut for tracers that are exactly zero over a wavefront's stencil (bit-neutral; 0: A/B)
   int zero_rows = 1;           // ... and the zero-row maps on top of it: rows of a tracer that are known to be zero are not loaded (mw_march.h: k_zero_rows)
+  int pipe_maps_early = 1;     // pipelined schedule, first stage: local zero-row maps in front of its y launches, two strip exchanges (0: one exchange, maps beside the y launch; A/B)
   int zero_stores = 1;         // ... and zeros are not stored over rows that hold zeros already (the coupler's arrays, slabs S1 / S2; 0: A/B)
   int rccl_lanes = 0, rccl_two_comms = -1;            // built-in RCCL transport: side streams (1 | 2), a communicator per lane (0 | 1); 0 / -1 = the
                                                       // process default (MW_RCCL_LANES); read when mw_dycore_use_rccl* installs the transport
@@ -952,7 +953,7 @@ struct mw_dycore_s {
   int pipe = 0;                              // blocks of a decomposed domain: pipelined one-stream schedule (rk_stage_pipe)
   bool pipe_ready = false;                   // ... the next stage's input strips are already on their way (event ev_pipe[2])
   bool pipe_edge_done = false;               // ... and its two edge strips of the y launch were issued behind them on the exchange stream
-  hipEvent_t ev_pipe[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // [0], [1]: compute -> exchange stream; [2]: state strips + state edge rows ready; [3]: tracer strips + tracer edge faces ready; [4]: zero-row maps ready
+  hipEvent_t ev_pipe[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0], [1]: compute -> exchange stream; [2]: state strips + state edge rows ready; [3]: tracer strips + tracer edge faces ready; [4]: zero-row maps ready; [5]: the block's own row map scanned (compute -> exchange stream)
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
@@ -1770,6 +1771,9 @@ static void zero_rows_stage(mw_dycore_s *d, int stage);
 static void zero_rows_conv(mw_dycore_s *d, const double *S, bool done, hipStream_t st);
 static void zero_rows_forget(mw_dycore_s *d, const double *S);
 static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st, bool first_cycle);
+static bool zero_rows_ok(const mw_dycore_s *d);
+static int zero_rows_local(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st);
+static int zero_rows_merge(mw_dycore_s *d, hipStream_t st, bool first_cycle);
 template <int STAGE, int MODE>
 static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double *Sout, double dt_stage, double dt_dyn,
                           const CouplerPtrs &c) {
@@ -1855,6 +1859,28 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   //  behind the tracer strips, as in rounds 3-4.)
   const bool split_edges = edge_side && d->o.pipe_split_edges;
   const int par_next = (int)((gs + 1) & 1);
+  // (round 5, first stage with the split edge strips: LOCAL zero-row maps on the compute stream in front of the y launches, the state strips
+  //  and the tracer strips as two exchanges -- k_xz_state waits for the first only -- and the neighbours' maps merged in behind them; before,
+  //  this stage's y launch ran without maps, 664 against 476 us, in front of one 609 us exchange chain for all eight variables)
+  bool maps_early = false;
+  if (!d->pipe_ready && STAGE == 1 && split_edges && d->o.pipe_maps_early && !d->p.wrap_y && d->p.ny >= 4 * MW_Y_EDGE && zero_rows_ok(d)) {   // (a y-decomposed block with real edge strips)
+    maps_early = true;
+    MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
+    if (zero_rows_local(d, Sin, c, conv, ss)) return 1;
+    MW_HIP(hipEventRecord(d->ev_pipe[5], ss));
+    if (halo_fill(d, Sin, 0, 5, xs, 0, true)) return 1;
+    if (launch_y_state(d, Sin, par, nullptr, true, xs)) return 1;
+    MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
+    if (halo_fill(d, Sin, 5, T, xs, 1, true)) return 1;
+    if (launch_y_tracers(d, Sin, par, xs, true)) return 1;
+    MW_HIP(hipEventRecord(d->ev_pipe[3], xs));
+    d->pipe_edge_done = true;
+    MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[5], 0));
+    if (zero_rows_merge(d, xs, d->first_cycle)) return 1;
+    if (d->zr_on) MW_HIP(hipEventRecord(d->ev_pipe[4], xs));
+    zero_rows_stage(d, 1);                                      // the local maps, for this stage's inner y rows
+    if (conv) zero_rows_conv(d, Sin, false, ss); else zero_rows_forget(d, Sin);
+  } else
   if (!d->pipe_ready) {                                       // this stage's input has not been exchanged yet
     MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
     if (halo_fill(d, Sin, 0, -1, xs, 0, true)) return 1;
@@ -1868,7 +1894,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
       if (d->zr_on) MW_HIP(hipEventRecord(d->ev_pipe[4], xs));
     }
   }
-  if (STAGE != 1) zero_rows_stage(d, STAGE);                    // (stage 1: its y launches run BESIDE the map build -- the maps are handed over in front of the tracer kernel)
+  if (STAGE != 1) zero_rows_stage(d, STAGE);                    // (stage 1 without the early maps: its y launches run BESIDE the map build -- the maps are handed over in front of the tracer kernel)
   if (STAGE == 3 && MODE == 0) zero_rows_forget(d, Sout);
   d->pipe_ready = false;
   if (launch_y_all(d, Sin, conv ? &c : nullptr, 1)) return 1;  // rows whose chunks read no halo row
@@ -1886,7 +1912,10 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
     }
   }
   MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[3], 0));           // tracer strips + the edge faces' tracer fluxes of this stage's input
-  if (STAGE == 1 && d->zr_on) { MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[4], 0)); zero_rows_stage(d, 1); }
+  if (STAGE == 1 && d->zr_on) {
+    MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[4], 0)); zero_rows_stage(d, 1);
+    if (maps_early && conv) zero_rows_conv(d, Sin, true, ss);     // (the slab's row map changes BEHIND the converting launch that reads it)
+  }
   if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ss)) return 1;
   if (early) {
     MW_HIP(hipEventRecord(d->ev_pipe[1], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[1], 0));
@@ -1941,8 +1970,8 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
       const View v = view(d, e);
       DyP q = v.p; q.zq_ld = ld;
       unsigned *zr = d->zr + e * mstride + (long long)d->zr_cur * MW_ZR_MAPS * msz;
-      MW_KLAUNCH(k_zero_rows<true>, dim3((unsigned)((nrow + 3) / 4)), dim3(256), 0, st, q, c, v.S(S0), zr, vmask, ld, MW_ZR_HALO, 1);
-      MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, q, zr, msz);
+      MW_KLAUNCH(k_zero_rows<true>, dim3((unsigned)((nrow + 3) / 4)), dim3(256), 0, st, q, c, v.S(S0), zr, vmask, ld, MW_ZR_HALO, 1, nullptr);
+      MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, q, zr, msz, 0);
     }
     MW_LAUNCH_CHECK();
     return 0;
@@ -1962,8 +1991,8 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   const bool local = !ex_x && !ex_y;
   unsigned *own = local ? zr : (unsigned *)d->zrx;
   const int ldo = local ? ld : p.ny, offo = local ? MW_ZR_HALO : 0;
-  if (from_coupler) MW_KLAUNCH(k_zero_rows<false>, g, dim3(256), 0, st, p, c, S0, own, vmask, ldo, offo, local ? 1 : 0);
-  else              MW_KLAUNCH(k_zero_rows<true>, g, dim3(256), 0, st, p, c, S0, own, vmask, ldo, offo, local ? 1 : 0);
+  if (from_coupler) MW_KLAUNCH(k_zero_rows<false>, g, dim3(256), 0, st, p, c, S0, own, vmask, ldo, offo, local ? 1 : 0, nullptr);
+  else              MW_KLAUNCH(k_zero_rows<true>, g, dim3(256), 0, st, p, c, S0, own, vmask, ldo, offo, local ? 1 : 0, nullptr);
   MW_LAUNCH_CHECK();
   if (!local) {
     double *rW = d->zrx + dWE, *rE = d->zrx + 2 * dWE, *sS = d->zrx + 3 * dWE, *sN = sS + dSN, *rS = sN + dSN, *rN = rS + dSN;
@@ -1979,8 +2008,68 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   }
   // the first sub-cycle's M0 doubles as "which rows of the coupler's tracer arrays are zero" until the last sub-cycle's D13 (map MC)
   if (first_cycle) MW_HIP(hipMemcpyAsync(d->zr + 2 * MW_ZR_MAPS * msz, zr, (size_t)msz * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
-  MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, p, zr, msz);
+  MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, p, zr, msz, 0);
   MW_LAUNCH_CHECK();
+  return 0;
+}
+// The same in two halves for the first stage of the pipelined schedule (round 5, profiles/r05_selfloop_timeline_maps.txt): LOCAL maps on the
+// compute stream in front of the stage's y launches -- the y kernel reads no x halo, its inner rows only the block's own rows; the rows
+// beyond a decomposed y edge count as "may be non-zero", and FNs as "store" -- ...
+static int zero_rows_local(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st) {
+  d->zr_on = zero_rows_ok(d);
+  if (!d->zr_on) return 0;
+  DyP &p = d->p;
+  const int ld = p.ny + 2 * MW_ZR_HALO;
+  const long long msz = (long long)p.nz * ld;
+  const bool ex_x = d->xchg && p.nproc_x > 1, ex_y = d->xchg && p.nproc_y > 1;
+  const long long nrow = (long long)p.nz * p.ny, nedge = (long long)p.nz * MW_ZR_HALO;
+  const long long dWE = (nrow + 1) / 2, dSN = (nedge + 1) / 2;
+  if (!d->zr || d->zr_msz != msz) {
+    if (d->zr) { MW_HIP(hipDeviceSynchronize()); (void)hipFree(d->zr); d->zr = nullptr; }
+    if (d->zrx) { (void)hipFree(d->zrx); d->zrx = nullptr; }
+    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 3) * (size_t)msz * sizeof(unsigned) * (size_t)p.nens) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }
+    d->zr_msz = msz; d->zr_prev_ok = false; d->kz_buf[0] = d->kz_buf[1] = nullptr;
+  }
+  if (!d->zrx && hipMalloc(&d->zrx, (size_t)(3 * dWE + 4 * dSN) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); MW_FAIL("zero-row maps: out of device memory"); }
+  d->zr_cur ^= 1;
+  d->zr_prev_use = d->zr_prev_ok && d->o.zero_stores;
+  unsigned *const zr = d->zr + (long long)d->zr_cur * MW_ZR_MAPS * msz;
+  p.zq_ld = ld;
+  const unsigned vmask = (marching_config(d, p) == 1) ? 0x6u : 0xFu;
+  ProfScope ps(d, 4, st);
+  const dim3 g((unsigned)((nrow + 3) / 4));
+  const int wrap = ex_y ? 2 : 1;
+  if (from_coupler) MW_KLAUNCH(k_zero_rows<false>, g, dim3(256), 0, st, p, c, S0, zr, vmask, ld, MW_ZR_HALO, wrap, (unsigned *)d->zrx);
+  else              MW_KLAUNCH(k_zero_rows<true>, g, dim3(256), 0, st, p, c, S0, zr, vmask, ld, MW_ZR_HALO, wrap, (unsigned *)d->zrx);
+  MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, p, zr, msz, (ex_x || ex_y) ? 1 : 0);
+  MW_LAUNCH_CHECK();
+  return 0;
+}
+// ... and the neighbours' maps merged in on the exchange stream, for the tracer kernel and everything after it.  (The y launches of the first
+// stage may read either version of a word while this runs: both describe their rows correctly, the merged one only knows more.)
+static int zero_rows_merge(mw_dycore_s *d, hipStream_t st, bool first_cycle) {
+  if (!d->zr_on) return 0;
+  DyP &p = d->p;
+  const long long msz = d->zr_msz;
+  const bool ex_x = d->xchg && p.nproc_x > 1, ex_y = d->xchg && p.nproc_y > 1;
+  const long long nrow = (long long)p.nz * p.ny, nedge = (long long)p.nz * MW_ZR_HALO;
+  const long long dWE = (nrow + 1) / 2, dSN = (nedge + 1) / 2;
+  unsigned *const zr = d->zr + (long long)d->zr_cur * MW_ZR_MAPS * msz;
+  ProfScope ps(d, 4, st);
+  if (ex_x || ex_y) {
+    double *rW = d->zrx + dWE, *rE = d->zrx + 2 * dWE, *sS = d->zrx + 3 * dWE, *sN = sS + dSN, *rS = sN + dSN, *rN = rS + dSN;
+    if (ex_x && d->xchg(d->xchg_ctx, d->zrx, d->zrx, nullptr, nullptr, rW, rE, nullptr, nullptr, dWE, 0, st)) MW_FAIL("zero-row maps: exchange callback failed");
+    MW_KLAUNCH(k_zero_merge, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, p, (const unsigned *)d->zrx, ex_x ? (const unsigned *)rW : nullptr, (const unsigned *)rE, zr,
+               ex_y ? (unsigned *)sS : nullptr, (unsigned *)sN);
+    MW_LAUNCH_CHECK();
+    if (ex_y) {
+      if (d->xchg(d->xchg_ctx, nullptr, nullptr, sS, sN, nullptr, nullptr, rS, rN, 0, dSN, st)) MW_FAIL("zero-row maps: exchange callback failed");
+      MW_KLAUNCH(k_zero_halo, dim3((unsigned)((nedge + 255) / 256)), dim3(256), 0, st, p, zr, (const unsigned *)rS, (const unsigned *)rN);
+      MW_LAUNCH_CHECK();
+    }
+  }
+  if (first_cycle) MW_HIP(hipMemcpyAsync(d->zr + 2 * MW_ZR_MAPS * msz, zr, (size_t)msz * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+  if (ex_x || ex_y) { MW_KLAUNCH(k_zero_dilate, dim3((unsigned)((p.ny + 63) / 64), (unsigned)((p.nz + 15) / 16)), dim3(256), 0, st, p, zr, msz, 0); MW_LAUNCH_CHECK(); }
   return 0;
 }
 // ... and handed to the kernels of RK stage `stage` (1..3) through the parameter block
@@ -2150,7 +2239,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
     for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
                                     hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
     if (hipEventCreateWithFlags(&d->ev_misc, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
-    for (int i = 0; i < 5; i++)
+    for (int i = 0; i < 6; i++)
       if (hipEventCreateWithFlags(&d->ev_pipe[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
   }
   fill_params(d);
@@ -2171,7 +2260,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
-  for (int i = 0; i < 5; i++) if (d->ev_pipe[i]) (void)hipEventDestroy(d->ev_pipe[i]);
+  for (int i = 0; i < 6; i++) if (d->ev_pipe[i]) (void)hipEventDestroy(d->ev_pipe[i]);
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
@@ -2205,7 +2294,7 @@ const OptDesc OPTS[] = {
   {"mm_direct", &DyOpts::mm_direct, 0, 1, 0}, {"mm_conv", &DyOpts::mm_conv, 0, 1, 0}, {"fused_convert", &DyOpts::fused_convert, 0, 1, 0},
   {"fused_convert_mm", &DyOpts::fused_convert_mm, 0, 1, 0}, {"chunk_y", &DyOpts::chunk_y, 0, 1 << 20, 0}, {"chunk_yt", &DyOpts::chunk_yt, 0, 1 << 20, 0},
   {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
-  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"zero_stores", &DyOpts::zero_stores, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
+  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"zero_stores", &DyOpts::zero_stores, 0, 1, 0}, {"pipe_maps_early", &DyOpts::pipe_maps_early, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
   {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0}, {"rccl_inline", &DyOpts::rccl_inline, 0, 1, 0},
   {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
   {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},
@@ -2456,7 +2545,10 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
       const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
       MW_KLAUNCH(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms, ylo, yhi);
     } else
-    MW_KLAUNCH(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ylo, yhi);
+    { // the strip cells only (see the kernel)
+      const long long nstrip = (long long)(ylo + p.ny - yhi) * p.nx * p.nens + (long long)(yhi - ylo) * 2 * p.HX * p.nens;
+      const bool strips = p.nx > 2 * p.HX && nstrip > 0;
+      MW_KLAUNCH(k_coupler_to_state_fast, strips ? plane_grid(nstrip, p.nz) : cgrid, dim3(256), 0, d->stream, p, c, d->S0, ylo, yhi, strips ? 1 : 0); }
     MW_LAUNCH_CHECK();
     d->conv_pending = true;
   }
@@ -2466,7 +2558,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
       const View v = view(d, 0);
       const MemberStrides ms = {v.p.sJ, v.p.sK, v.p.sV, v.slab};
       MW_KLAUNCH(k_coupler_to_member, cgrid, dim3(256), 0, d->stream, p, c, d->S0, ms, p.ny, p.ny);
-    } else if (march && p.nt <= 4) MW_KLAUNCH(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, p.ny, p.ny);
+    } else if (march && p.nt <= 4) MW_KLAUNCH(k_coupler_to_state_fast, cgrid, dim3(256), 0, d->stream, p, c, d->S0, p.ny, p.ny, 0);
     else       MW_KLAUNCH(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0);
     MW_LAUNCH_CHECK();
   }

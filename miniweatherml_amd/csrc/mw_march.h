@@ -320,12 +320,23 @@ __device__ __forceinline__ void convert_cell_tracers(const DyP &p, const Coupler
 // stand-alone form (2-D runs, walls / open boundaries or a neighbour exchange in y, two-stream schedule)
 // (ylo, yhi: only the cells with j < ylo, j >= yhi or within HX cells of the block's west / east edge -- the strips that the pipelined
 //  multi-rank schedule packs and the rows its edge-strip y launch reads; the rest is converted inside k_y_all<true>.  ylo >= ny: all.)
-__global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtrs c, double *__restrict__ S, int ylo, int yhi) {
+// (strips != 0: the launch covers the strip cells only -- whole rows j < ylo and j >= yhi first, then the 2 HX west / east columns of the rows
+//  between -- instead of all cells with most threads leaving at once: 50 -> a few us on the compute stream of a 400 x 400 x 100 block)
+__global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtrs c, double *__restrict__ S, int ylo, int yhi, int strips) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int k = blockIdx.y;
   const int NXI = p.nx * p.nens;
-  if (t >= (long long)p.ny * NXI) return;
-  const int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
+  int j, ie;
+  if (strips) {
+    const int hxn = p.HX * p.nens;
+    const long long nA = (long long)(ylo + p.ny - yhi) * NXI, nB = (long long)(yhi - ylo) * 2 * hxn;
+    if (t >= nA + nB) return;
+    if (t < nA) { const int jj = (int)(t / NXI); ie = (int)(t - (long long)jj * NXI); j = jj < ylo ? jj : yhi + (jj - ylo); }
+    else { const long long u = t - nA; const int r = (int)(u % (2 * hxn)); j = ylo + (int)(u / (2 * hxn)); ie = r < hxn ? r : NXI - 2 * hxn + r; }
+  } else {
+    if (t >= (long long)p.ny * NXI) return;
+    j = (int)(t / NXI); ie = (int)(t - (long long)j * NXI);
+  }
   if (j >= ylo && j < yhi && ie >= p.HX * p.nens && ie < NXI - p.HX * p.nens) return;
   const long long ci = ((long long)k * p.ny + j) * NXI + ie;
   const CouplerCell r = load_coupler_cell(p, c, cpl(p, ci));
@@ -368,8 +379,10 @@ __global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtr
 // coupler's arrays.  vmask: the tracers that can vanish -- the others are flagged non-zero without being read.  ldo / offo: layout of
 // `out` (compact [k][ny] for k_zero_merge, or the map's own); wrap: also write the row's periodic images into the map's halo rows.
 template <bool SLAB>
+// (wrap == 2: the halo rows are marked "may be non-zero" instead -- the LOCAL maps of a decomposed block, used by the first stage's y launches
+//  before the neighbours' maps have arrived; out2: a second, compact [k][ny] copy for k_zero_merge)
 __global__ __launch_bounds__(256) void k_zero_rows(DyP p, CouplerPtrs c, const double *__restrict__ S, unsigned *__restrict__ out, unsigned vmask,
-                                                   int ldo, int offo, int wrap) {
+                                                   int ldo, int offo, int wrap, unsigned *__restrict__ out2) {
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long long)p.nz * p.ny) return;
   const int k = (int)(row / p.ny), j = (int)(row - (long long)k * p.ny), lane = threadIdx.x & 63;
@@ -405,8 +418,9 @@ __global__ __launch_bounds__(256) void k_zero_rows(DyP p, CouplerPtrs c, const d
   if (lane == 0) {
     unsigned *o = out + (long long)k * ldo + offo;
     o[j] = word;
-    if (wrap && j < MW_ZR_HALO) o[p.ny + j] = word;
-    if (wrap && j >= p.ny - MW_ZR_HALO) o[j - p.ny] = word;
+    if (wrap && j < MW_ZR_HALO) o[p.ny + j] = (wrap == 2) ? ~0u : word;
+    if (wrap && j >= p.ny - MW_ZR_HALO) o[j - p.ny] = (wrap == 2) ? ~0u : word;
+    if (out2) out2[(long long)k * p.ny + j] = word;
   }
 }
 // Decomposed block: M = own rows (compact) OR the west / east neighbours' (rW / rE, nullptr: x is not decomposed); the merged rows next
@@ -453,7 +467,8 @@ __global__ __launch_bounds__(256) void k_zero_halo(DyP p, unsigned *__restrict__
 //   row's word alone -- so where the previous Qs is clear the slab row holds zeros already and a lean iteration leaves it alone.  The host
 //   hands the previous maps over only when the previous sub-cycle ran with maps and nothing else has written the slabs since.
 #define MW_ZR_MAPS 10
-__global__ __launch_bounds__(256) void k_zero_dilate(DyP p, unsigned *__restrict__ M, long long msz) {
+// (fn_ones: FNs = "store" everywhere -- the local maps of a decomposed block cannot know what the neighbours make the tracer kernel read)
+__global__ __launch_bounds__(256) void k_zero_dilate(DyP p, unsigned *__restrict__ M, long long msz, int fn_ones) {
   constexpr int TK = 16, TJ = 64, R = MW_ZR_HALO, LO = R + MW_ZR_BEFORE + 1, HI = R + MW_ZR_AFTER + 1, EK = TK + LO + HI, EJ = TJ + 2 * R;
   __shared__ unsigned a[EK][EJ];
   __shared__ unsigned b[3][EK][TJ];
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(256) void k_zero_dilate(DyP p, unsigned *__restrict
         if (dd >= -ry && dd <= ry) qy |= v;
       }
       M[(long long)(m + 1) * msz + (long long)k * p.zq_ld + j + MW_ZR_HALO] = o;
-      M[(long long)(m + 4) * msz + (long long)k * p.zq_ld + j + MW_ZR_HALO] = fn;
+      M[(long long)(m + 4) * msz + (long long)k * p.zq_ld + j + MW_ZR_HALO] = fn_ones ? ~0u : fn;
       M[(long long)(m + 7) * msz + (long long)k * p.zq_ld + j + MW_ZR_HALO] = qy;
     }
   }

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"overlap": -1, "pipe": 1, "pipe_edge_inline": 0, "pipe_convert": 1, "pipe_split_edges": 1, "spec": 1, "wrap": 1, "y_all": 1, "y_all_conv": 1,
             "member_major": 1, "mm_direct": 1, "mm_conv": 1, "fused_convert": 1, "fused_convert_mm": 1, "fused_tracers": 1, "chunk_y": 0, "chunk_yt": 0,
-            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "zero_rows": 1, "zero_stores": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
+            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "zero_rows": 1, "zero_stores": 1, "pipe_maps_early": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
 
 
 def test_defaults_round_trips_and_errors(mw):
