@@ -953,7 +953,8 @@ struct mw_dycore_s {
   int pipe = 0;                              // blocks of a decomposed domain: pipelined one-stream schedule (rk_stage_pipe)
   bool pipe_ready = false;                   // ... the next stage's input strips are already on their way (event ev_pipe[2])
   bool pipe_edge_done = false;               // ... and its two edge strips of the y launch were issued behind them on the exchange stream
-  hipEvent_t ev_pipe[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [0], [1]: compute -> exchange stream; [2]: state strips + state edge rows ready; [3]: tracer strips + tracer edge faces ready; [4]: zero-row maps ready; [5]: the block's own row map scanned (compute -> exchange stream)
+  hipEvent_t ev_pipe[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool entry_marked = false;                 // ev_pipe[6] was recorded at this time step's entry   // [0], [1]: compute -> exchange stream; [2]: state strips + state edge rows ready; [3]: tracer strips + tracer edge faces ready; [4]: zero-row maps ready; [5]: the block's local zero-row maps ready (exchange -> compute stream); [6]: time_step entered (the coupler's arrays are ready)
   double *tendY = nullptr;                              // (5,nz,ny,nx,nens) y part of the state tendencies
   double *FX = nullptr, *FY = nullptr, *FZ = nullptr;
   const double *flux_src = nullptr; double flux_dt = 0; // stage input + dt of the last stage (state fluxes on demand)
@@ -1865,9 +1866,15 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   bool maps_early = false;
   if (!d->pipe_ready && STAGE == 1 && split_edges && d->o.pipe_maps_early && !d->p.wrap_y && d->p.ny >= 4 * MW_Y_EDGE && zero_rows_ok(d)) {   // (a y-decomposed block with real edge strips)
     maps_early = true;
-    MW_HIP(hipEventRecord(d->ev_pipe[0], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
-    if (zero_rows_local(d, Sin, c, conv, ss)) return 1;
-    MW_HIP(hipEventRecord(d->ev_pipe[5], ss));
+    // the local maps on the exchange stream: from the coupler's arrays they only need the step's inputs and run BESIDE the strip conversion
+    // on the compute stream (first sub-cycle); from the slab they wait for it like everything else
+    const bool beside = conv && d->first_cycle && d->entry_marked;
+    MW_HIP(hipEventRecord(d->ev_pipe[0], ss));
+    MW_HIP(hipStreamWaitEvent(xs, beside ? d->ev_pipe[6] : d->ev_pipe[0], 0));
+    if (zero_rows_local(d, Sin, c, conv, xs)) return 1;
+    MW_HIP(hipEventRecord(d->ev_pipe[5], xs));
+    MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[5], 0));         // the stage's inner y rows read them
+    if (beside) MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[0], 0));
     if (halo_fill(d, Sin, 0, 5, xs, 0, true)) return 1;
     if (launch_y_state(d, Sin, par, nullptr, true, xs)) return 1;
     MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
@@ -1875,7 +1882,6 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
     if (launch_y_tracers(d, Sin, par, xs, true)) return 1;
     MW_HIP(hipEventRecord(d->ev_pipe[3], xs));
     d->pipe_edge_done = true;
-    MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[5], 0));
     if (zero_rows_merge(d, xs, d->first_cycle)) return 1;
     if (d->zr_on) MW_HIP(hipEventRecord(d->ev_pipe[4], xs));
     zero_rows_stage(d, 1);                                      // the local maps, for this stage's inner y rows
@@ -2239,7 +2245,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
     for (int i = 0; i < 8; i++) if (hipEventCreateWithFlags(&d->ev_state[i], hipEventDisableTiming) != hipSuccess ||
                                     hipEventCreateWithFlags(&d->ev_tr[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
     if (hipEventCreateWithFlags(&d->ev_misc, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < 7; i++)
       if (hipEventCreateWithFlags(&d->ev_pipe[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return fail(); }
   }
   fill_params(d);
@@ -2260,7 +2266,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
-  for (int i = 0; i < 6; i++) if (d->ev_pipe[i]) (void)hipEventDestroy(d->ev_pipe[i]);
+  for (int i = 0; i < 7; i++) if (d->ev_pipe[i]) (void)hipEventDestroy(d->ev_pipe[i]);
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
@@ -2536,6 +2542,8 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     } else d->path += p.nens == 1 ? " nens1" : " fused_members";
     if (d->xchg) d->path += " transport"; }
   d->pre_lo = d->pre_hi = 0;
+  d->entry_marked = false;
+  if (pipe_conv && d->ev_pipe[6]) { MW_HIP(hipEventRecord(d->ev_pipe[6], d->stream)); d->entry_marked = true; }   // the coupler's arrays are ready here (see rk_stage_pipe: the row scan runs beside the strip conversion)
   if (pipe_conv) {
     ProfScope ps(d, 4);
     const int ylo = d->p.wrap_y ? 0 : MW_Y_EDGE + 3, yhi = d->p.wrap_y ? p.ny : p.ny - MW_Y_EDGE - 3;
