@@ -555,7 +555,7 @@ def main():
         step()
     sync()
     progress("warm-up done")
-    dycore.profile(2)                                            # hipEvents around the dominant kernel only (on its stream)
+    dycore.profile(3)                                            # ONE hipEvent pair per time_step on the handle's stream (pairs around every stage and the dominant kernel cost 1.5 % of the step: tools/event_overhead.py)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -564,13 +564,14 @@ def main():
     progress("timed region done")
     sched = dycore.schedule()                                    # what the timed time_steps ran (mw_dycore_schedule), not re-derived here
     KNAMES = ["xz_state", "tracer_patch", "tracer_update_unfused", "halo", "convert", "y_state", "y_tracers", "tracers_fused"]
-    prof_dom = dycore.profile_get(0)                             # the dominant kernel: live, over the timed region
-    prof_stage = dycore.profile_get(8)                           # every RK stage, first to last launch: live, over the timed region
+    prof_step = dycore.profile_get(9)                            # every time_step, first launch to the join: live, over the timed region
+    prof_stage = (prof_step[0], 3 * prof_step[1])                # = its three RK stages (the bench's dt is one sub-cycle)
     # Outside the timed region: every kernel class bracketed by events (their markers cost ~2 % of the step), same schedule
     dycore.profile(1)
     for _ in range(3):
         step()
     prof = {n: dycore.profile_get(i) for i, n in enumerate(KNAMES)}
+    prof_dom = prof["xz_state"]                                  # the dominant kernel on its own: live, the three steps behind the timed region
     dycore.profile(0)
     # Outside the timed region: the same kernels with the two pipelines serialised, so that each kernel's duration is
     # exclusive.  (With N > 1 -- or option overlap = 1 -- the state and tracer pipelines of the timed region run on two streams and
@@ -757,13 +758,14 @@ def main():
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_frac": (traffic / (stage_ms * 1e-3) / 8.0e12) if traffic else None,
                          "alg_bytes_per_launch": stage_bytes, "avg_launch_ms": stage_ms,
-                         "avg_launch_ms_source": "hipEvents around every RK stage on the handle's stream, timed region" if stage_ms_live
+                         "avg_launch_ms_source": "hipEvents around every time_step on the handle's stream over the timed region, / 3 RK stages (a pair per stage costs 1.5 % of what it times)" if stage_ms_live
                                                  else "ms_per_step / 3 (two-stream schedule: a stage's launches overlap the next stage's)",
                          "launches": prof_stage[1] if stage_ms_live else 3 * a.steps,
                          "pmc_provenance": prov,
                          "dominant_kernel": {"kernel": "k_flux" if a.strict else "k_xz_state", "achieved": dom_achieved,
                                              "frac": (dom_achieved / 8000.0) if dom_achieved else None, "traffic": dom_traffic,
                                              "avg_launch_ms": avg_flux_s * 1e3, "launches": flux_n, "alg_bytes_per_launch": dom_bytes,
+                                             "avg_launch_ms_source": "hipEvents around every launch on its stream, the three steps behind the timed region",
                                              "avg_launch_ms_exclusive": (prof_excl["xz_state"][0] / max(1, prof_excl["xz_state"][1])) if prof_excl else None,
                                              "valu_busy_frac": valu_busy, "valu_instr_per_cell": valu_instr},
                          "fp64_valu": valu_side,

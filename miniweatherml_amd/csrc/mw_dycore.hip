@@ -985,8 +985,8 @@ struct mw_dycore_s {
   long long nWE1 = 0, nSN1 = 0;                  // per variable
   // profiling
   int prof = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[9];       // kernel classes 0..7; 8 = one whole RK stage (all its launches)
-  size_t ev_used[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[10];      // kernel classes 0..7; 8 = one whole RK stage (all its launches); 9 = one whole time_step
+  size_t ev_used[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   void (*xchg_free)(void *) = nullptr;       // set when the handle owns xchg_ctx (the built-in RCCL transport, mw_rccl.cpp)
   // balanced launch lists (pick_sched): per (columns, cells, resident workgroups) the Sched with its device table
   struct SchedEntry { const mw::Sched *dev; unsigned wgs; };
@@ -1074,7 +1074,7 @@ static int upload_background(mw_dycore_s *d) {
 
 struct ProfScope {
   mw_dycore_s *d; int which; size_t idx; bool on; hipStream_t st;
-  ProfScope(mw_dycore_s *d_, int w, hipStream_t st_ = nullptr) : d(d_), which(w), idx(0), on(d_->prof == 1 || (d_->prof == 2 && (w == 0 || w == 8))), st(st_ ? st_ : d_->stream) {
+  ProfScope(mw_dycore_s *d_, int w, hipStream_t st_ = nullptr) : d(d_), which(w), idx(0), on((d_->prof == 1 && w != 9) || (d_->prof == 2 && (w == 0 || w == 8)) || (d_->prof == 3 && w == 9)), st(st_ ? st_ : d_->stream) {
     if (!on) return;
     if (d->ev_used[which] == d->ev[which].size()) {
       hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); d->ev[which].push_back({a, b});
@@ -2270,7 +2270,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
-  for (int w = 0; w < 9; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (int w = 0; w < 10; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto &kv : d->sched_cache) if (kv.second.dev) (void)hipFree(const_cast<mw::Sched *>(kv.second.dev));
   delete d;
 }
@@ -2457,11 +2457,11 @@ int mw_dycore_profile(mw_dycore_t d, int enable) {
   if (!d) MW_FAIL("null handle");
   MW_HIP(hipStreamSynchronize(d->stream));
   d->prof = enable;
-  for (int w = 0; w < 9; w++) d->ev_used[w] = 0;
+  for (int w = 0; w < 10; w++) d->ev_used[w] = 0;
   return 0;
 }
 int mw_dycore_profile_get(mw_dycore_t d, int which, double *total_ms, long long *launches) {
-  if (!d || which < 0 || which > 8) MW_FAIL("bad argument");
+  if (!d || which < 0 || which > 9) MW_FAIL("bad argument");
   MW_HIP(hipStreamSynchronize(d->stream));
   double tot = 0;
   for (size_t i = 0; i < d->ev_used[which]; i++) { float ms = 0; MW_HIP(hipEventElapsedTime(&ms, d->ev[which][i].first, d->ev[which][i].second)); tot += ms; }
@@ -2480,6 +2480,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
   fill_params(d);
   const DyP &p = d->p;
   if (need_exchange(d) || check_halo_fit(d)) return 1;
+  ProfScope step_scope(d, 9);                                   // (mw_dycore_profile(h, 3): the whole time step, first launch to the join on the handle's stream)
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
   // production path; strict = 1/2 use the general flux-materialising kernels below.  So does a z-PERIODIC domain (:752-763,
   // :1008-1019; no shipped case): the marching kernels apply the wall / open z rule while loading and have no periodic form.
