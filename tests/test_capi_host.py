@@ -286,3 +286,22 @@ def test_dispatcher_path_space_is_well_formed():
                  "march ord3 K1 nens1 one_stream y_all conv_in_y tracers_fused 3d",              # the reference's GPU-benchmark order
                  "general-strict ord5 nens1", "general-fast ord9 fused_members transport"):
         assert must in paths, must
+
+
+def test_every_option_is_documented_and_has_a_default_under_test():
+    """The handle's option table (OPTS in csrc/mw_dycore.hip) against the header's list and the GPU test of the defaults: an option added to the
+    library without its line in include/mw_cdna4.h or its entry in tests/test_gpu_options.py::DEFAULTS fails here, on the CPU."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "miniweatherml_amd", "csrc", "mw_dycore.hip")).read()
+    keys = re.findall(r'\{"([a-z_0-9]+)", &DyOpts::[a-z_0-9]+, (-?\d+|0x[0-9a-f]+), [^,]+, (\d)\}', src)
+    assert len(keys) >= 30
+    header = open(os.path.join(root, "include", "mw_cdna4.h")).read()
+    defaults = open(os.path.join(root, "tests", "test_gpu_options.py")).read()
+    defaults = defaults[defaults.index("DEFAULTS = {"):defaults.index("}", defaults.index("DEFAULTS = {"))]
+    for key, _, build in keys:
+        assert '"%s"' % key in header, "option %s is not in the header's list" % key
+        if build == "0":                                           # (experiment options have no default test on the release build)
+            assert '"%s"' % key in defaults, "option %s has no entry in tests/test_gpu_options.py::DEFAULTS" % key
+    assert '"fused_tracers"' in header and '"fused_tracers"' in defaults      # (the one key that is not a plain field)
