@@ -189,6 +189,10 @@ int  mw_debug_spin(long long usec, void *stream);
  * the last reset; every instantiation of the dispatcher's kernel templates has its own.  Returns the bytes needed (terminator included)
  * and writes at most `cap`; reset != 0 clears the registry.  (tests/conftest.py: instantiation coverage of the parity comparisons.) */
 long long mw_debug_launched_kernels(char *buf, long long cap, int reset);
+/* Test aid: the zero-row maps of the handle's LAST sub-cycle, copied to HOST memory after a stream synchronise: ten maps of
+ * nz * (ny + 18) 32-bit words each -- M0, Q1..Q3, FN1..FN3, QY1..QY3; word of (level k, row j) at [k * (ny + 18) + j + 9], bit v = tracer v.
+ * Returns the number of words (0: the last time step ran without maps), writes at most cap_words; dims2 = {nz, ny + 18}. */
+long long mw_debug_zero_maps(mw_dycore_t h, unsigned int *out_host, long long cap_words, int *dims2);
 
 /* modules::perturb_temperature(coupler, thermal=true, random=false), perturb_temperature.h:41-66 */
 int  mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream);

@@ -2720,6 +2720,18 @@ int mw_calib_stage_arith(const double *tab, int nlev, long long cells, int level
   out3[0] = ms; out3[1] = (double)(thr * levels); out3[2] = (double)(thr / 256);
   return 0;
 }
+// Test aid: the zero-row maps of the last sub-cycle, on the host (include/mw_cdna4.h).
+long long mw_debug_zero_maps(mw_dycore_t d, unsigned int *out_host, long long cap_words, int *dims2) {
+  if (!d) return 0;
+  if (!d->zr || !d->zr_prev_ok || d->member_major) return 0;    // (zr_prev_ok: the last sub-cycle ran with maps; member-major handles keep one set per member)
+  (void)hipStreamSynchronize(d->stream);
+  if (d->tstream) (void)hipStreamSynchronize(d->tstream);
+  const long long n = (long long)MW_ZR_MAPS * d->zr_msz;
+  if (dims2) { dims2[0] = d->p.nz; dims2[1] = d->p.ny + 2 * MW_ZR_HALO; }
+  if (out_host && cap_words > 0)
+    (void)hipMemcpy(out_host, d->zr + (long long)d->zr_cur * n, (size_t)std::min(n, cap_words) * sizeof(unsigned), hipMemcpyDeviceToHost);
+  return n;
+}
 // Test aid: the names (as the code object spells them, i.e. mangled; newline-separated) of the dycore kernels this PROCESS has launched
 // since the last reset -- every instantiation of the dispatcher's templates has its own.  Returns the bytes needed (terminator included);
 // writes at most `cap` of them.  reset != 0 clears the registry afterwards.

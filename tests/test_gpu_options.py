@@ -276,3 +276,50 @@ def test_zero_row_maps_on_random_configurations(mw, seed):
         res.append(gpu_fields(coupler))
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), (k, seed, nx, ny, nz, nens, order, spec, chunks)
+
+
+def test_zero_row_maps_are_exactly_what_the_design_says(mw):
+    """The ten maps of a sub-cycle (mw_debug_zero_maps) against a numpy restatement of their definition (mw_march.h): M0 = the rows
+    in which a tracer that can vanish is non-zero (water vapour of the folded supercell configuration: always set), and per RK stage s the OR of
+    M0 over 3s rows (periodic) and, for Qs / FNs / QYs, over levels k-3s-5 .. k+3s+1 / k-3s-6 .. k+3s+2 / k-3(s-1) .. k+3(s-1) (clamped).
+    Equality both ways: a map that misses a row would be a wrong result (the bit-neutrality tests), a map that marks too much only a slower one
+    -- nothing else would notice."""
+    import torch
+    from miniweatherml_amd import capi, modules
+    nx, ny, nz = 130, 44, 26
+    coupler, dycore, _ = modules.make_supercell(nx, ny, nz, 1, 65000., 22000., 20000.)
+    dm = coupler.get_data_manager_readwrite()
+    rho = dm.get("density_dry")
+    cl, pr = torch.zeros_like(rho), torch.zeros_like(rho)
+    cl[3:9, 9:15, 37:60] = 3.0e-4; cl[25, 43, 129] = 2.0e-4; cl[0, 0, 5] = 2.0e-4
+    pr[12:14, 30:33, 100:120] = 1.0e-4; pr[20, 2, 64] = 1.0e-4
+    dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(pr * rho)
+    rows = [torch.ones(nz, ny, dtype=torch.bool), (cl[..., 0] != 0).any(dim=2).cpu(), (pr[..., 0] != 0).any(dim=2).cpu()]
+    m0 = sum((r.numpy().astype(np.uint32) << v) for v, r in enumerate(rows))
+    dycore.time_step(coupler, dycore.compute_time_step(coupler))
+    L = capi.lib()
+    dims = (C.c_int * 2)()
+    n = L.mw_debug_zero_maps(dycore.h, None, 0, dims)
+    assert n == 10 * nz * (ny + 18) and tuple(dims) == (nz, ny + 18)
+    buf = np.zeros(n, dtype=np.uint32)
+    assert L.mw_debug_zero_maps(dycore.h, buf.ctypes.data_as(C.c_void_p), n, dims) == n
+    maps = buf.reshape(10, nz, ny + 18)[:, :, 9:9 + ny]
+
+    def rows_or(a, r):
+        out = a.copy()
+        for d in range(1, r + 1):
+            out |= np.roll(a, d, axis=1) | np.roll(a, -d, axis=1)
+        return out
+
+    def levels_or(a, lo, hi):
+        out = np.zeros_like(a)
+        for d in range(lo, hi + 1):
+            out |= a[np.clip(np.arange(nz) + d, 0, nz - 1)]
+        return out
+    assert np.array_equal(maps[0], m0)
+    for s in (1, 2, 3):
+        b = rows_or(m0, 3 * s)
+        assert np.array_equal(maps[s], levels_or(b, -3 * s - 5, 3 * s + 1)), ("Q", s)
+        assert np.array_equal(maps[3 + s], levels_or(b, -3 * s - 6, 3 * s + 2)), ("FN", s)
+        assert np.array_equal(maps[6 + s], levels_or(b, -3 * (s - 1), 3 * (s - 1))), ("QY", s)
+    assert 0.02 < float((maps[7] & 6 != 0).mean()) < 0.6 and float((maps[1] & 6 != 0).mean()) < 1.0     # (the case has both kinds of row)
