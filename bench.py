@@ -377,8 +377,12 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
                 for n in ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid", "precip_liquid"):
                     c3.get_data_manager_readwrite().get(n).copy_(dm.get(n))
                 modules.use_rccl_self_exchange(d3, c3)
+                # (the part slows down by several per cent over a bench run: the one-rank step is timed again right before and right after
+                #  every block, and the ratio uses their mean -- a single one-rank figure in front of all blocks biased the ratios low)
+                b0 = timed(lambda: dycore.time_step(coupler, dt), 6)
                 ms = timed(lambda: d3.time_step(c3, dt), 10)
-                emu["ranks"][str(nr)] = {"rank_grid": "%dx%d" % (npx, npy), "ms_per_step": ms, "ratio": base_ms / ms, "path": d3.path()}
+                b1 = timed(lambda: dycore.time_step(coupler, dt), 6)
+                emu["ranks"][str(nr)] = {"rank_grid": "%dx%d" % (npx, npy), "ms_per_step": ms, "one_rank_ms_around": [b0, b1], "ratio": 0.5 * (b0 + b1) / ms, "path": d3.path()}
                 del c3, d3
                 torch.cuda.empty_cache()
             res["transport_self_loop"] = emu
