@@ -153,6 +153,7 @@ def pmc_children(a):
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
     exe = shutil.which("rocprofv3")
@@ -167,9 +168,20 @@ def pmc_children(a):
             cmd = [exe, "--pmc"] + ctrs + ["--output-format", "csv", "-d", os.path.join(tmp, tag), "--", sys.executable, os.path.abspath(__file__),
                                            "--pmc-worker", "--nx", str(a.nx), "--ny", str(a.ny), "--nz", str(a.nz), "--nens", str(a.nens),
                                            "--ord", str(a.ord), "--workload", a.workload if a.workload in ("config2", "config4") else "config2"]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=max(60.0, a.timeout_s / 4))
-            if r.returncode != 0:
-                return None, "rocprofv3 --pmc %s exited with %d: %s" % (" ".join(ctrs), r.returncode, r.stderr.decode(errors="replace")[-300:])
+            # (its own process group: on a timeout the whole group goes -- rocprofv3 AND the `python --pmc-worker` grandchild, which would
+            #  otherwise keep running on the GPU during the timed region; three passes may take a quarter of the run's budget together)
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                _, err = child.communicate(timeout=max(40.0, a.timeout_s / 12))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(child.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                child.communicate()
+                return None, "rocprofv3 --pmc %s did not finish within %.0f s (its process group was ended)" % (" ".join(ctrs), max(40.0, a.timeout_s / 12))
+            if child.returncode != 0:
+                return None, "rocprofv3 --pmc %s exited with %d: %s" % (" ".join(ctrs), child.returncode, (err or b"").decode(errors="replace")[-300:])
 
         def short(n):
             return n.replace("void ", "").replace("mw::", "").split("(")[0]
@@ -469,15 +481,16 @@ def main():
         # released there), so this thread reports and ends the process; the launcher then ends the other ranks
         print("bench.py: rank %d did not finish within %.0f s; last milestone: %s" % (rank, a.timeout_s, where[0]), file=sys.stderr, flush=True)
         os._exit(3)
-    wd = threading.Timer(a.timeout_s, watchdog)
-    wd.daemon = True
-    wd.start()
-    # live counters first: fresh child processes under rocprofv3 --pmc, BEFORE this process imports torch or touches the GPU
+    # live counters first: fresh child processes under rocprofv3 --pmc, BEFORE this process imports torch or touches the GPU.  (They carry
+    # their own time limits and are ended as a process group; the run's watchdog is armed behind them, with the whole budget.)
     live_pmc, live_pmc_why = None, "not attempted"
     if a.gpus == 1 and "WORLD_SIZE" not in os.environ and not a.no_pmc and not a.strict and not a.full_loop and a.workload in ("config2", "config4"):
         progress("rocprofv3 --pmc child processes (live counters of this run's kernels) ...")
         live_pmc, live_pmc_why = pmc_children(a)
         progress("live counters: %s" % ("ok" if live_pmc else live_pmc_why))
+    wd = threading.Timer(a.timeout_s, watchdog)
+    wd.daemon = True
+    wd.start()
     import torch
     import torch.distributed as dist
     if world != a.gpus:                                          # a launcher started a different number of ranks than asked for

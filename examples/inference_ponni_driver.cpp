@@ -1,7 +1,8 @@
 // The reference's surrogate driver, experiments/supercell_kessler_surrogate/inference_ponni.cpp:9-86, against the MI355X-native
 // modules: the ponni-shaped surface of miniweatherml_amd/host/mw_ponni.h (load_h5_weights, Matvec / Bias / Relu,
 // create_inference_model, forward_batch_parallel) and custom_modules::Microphysics_Kessler (NN inference beside the true Kessler).
-//     inference_ponni_driver input.yaml [max_steps]
+//     inference_ponni_driver input.yaml [max_steps [online]]
+// online = 1: the four deep_copy_to lines of microphysics_kessler_ponni.h:273-276 un-commented -- the NN result replaces Kessler's.
 // input.yaml: the reference's keys (inputs/input_euler3d.yaml), flat `key: value` lines.  Prints the state checksums, the four mean
 // NN - Kessler differences of the last step, and a checksum of model.forward_batch_parallel on the final state's scaled inputs;
 // used by tests/test_gpu_cpp_facade.py.
@@ -53,6 +54,7 @@ int main(int argc, char **argv) {
     custom_modules::Microphysics_Kessler micro;                                              // :56
     modules::Dynamics_Euler_Stratified_WenoFV dycore;                                        // :58
     micro.verbose = false;
+    micro.online = argc > 3 && atoi(argv[3]) != 0;                                           // (microphysics_kessler_ponni.h:273-276)
     micro.init(coupler);                                                                     // :61
     micro.model.print();
     dycore.init(coupler);                                                                    // :62

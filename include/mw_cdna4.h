@@ -105,7 +105,8 @@ int  mw_dycore_set_strict(mw_dycore_t h, int strict);
  * "zero_rows" (on top of it: per sub-cycle a map of the x rows in which a tracer can be non-zero -- scanned from the input, grown by the three
  * cells per direction an RK stage can move it, OR-ed with the neighbour blocks' maps on a decomposed domain -- lets the fused tracer
  * kernel neither load nor compute rows of cloud / rain that are zero; same results, 1 by default), "zero_stores" (... nor store zeros over
- * rows that hold zeros already: the coupler's own arrays, the stage slabs; 1 by default).
+ * rows that hold zeros already: the coupler's own arrays, the stage slabs; 1 by default), "zero_verify" (a test aid, 0 by default: every
+ * claim of the maps is checked against the data in front of the launch that relies on it -- mw_debug_zero_violations).
  * Launch shapes: "chunk_y", "chunk_yt", "chunk_z", "chunk_f" (cells per chunk, 0 = the chunk model), "chunk_model".  Built-in transport
  * (read when mw_dycore_use_rccl / _self installs it): "rccl_lanes" (0 = process default | 1 | 2), "rccl_two_comms" (-1 | 0 | 1), "rccl_prio" (1: side streams at the highest priority), "rccl_inline" (1: the group runs on the caller's stream, no side stream),
  * "xchg_fuzz" (seed of random delays around the sends / receives; a test aid).  Experiments that are not part of the release build:
@@ -193,6 +194,12 @@ long long mw_debug_launched_kernels(char *buf, long long cap, int reset);
  * nz * (ny + 18) 32-bit words each -- M0, Q1..Q3, FN1..FN3, QY1..QY3; word of (level k, row j) at [k * (ny + 18) + j + 9], bit v = tracer v.
  * Returns the number of words (0: the last time step ran without maps), writes at most cap_words; dims2 = {nz, ny + 18}. */
 long long mw_debug_zero_maps(mw_dycore_t h, unsigned int *out_host, long long cap_words, int *dims2);
+/* Test aid: option "zero_verify" = 1 makes every time step check the zero-row maps' claims against the data, right in front of the launches
+ * that rely on them (k_zero_verify): [0] / [1] a tracer that can vanish is non-zero in a row of a stage's input although the map of the fused
+ * tracer kernel / of the y kernel says it cannot be; [2] / [3] a destination row whose store of zeros is about to be skipped (slab S1 / S2,
+ * the coupler's arrays / the slab the converting y launch fills) is not all zero.  Returns the sum of the four counters since the handle was
+ * created (out4, may be NULL: the four), -1 when the option never ran.  No reference counterpart. */
+long long mw_debug_zero_violations(mw_dycore_t h, unsigned long long *out4);
 
 /* modules::perturb_temperature(coupler, thermal=true, random=false), perturb_temperature.h:41-66 */
 int  mw_perturb_temperature(const mw_grid_t *g, double *temp, void *stream);

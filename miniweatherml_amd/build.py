@@ -62,6 +62,16 @@ def build_examples(verbose=True):
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         exes.append(exe)
+    # a module with its own HIP kernels over core::MultiField (MultipleFields.h:10-96): compiled as HIP for gfx950
+    src = os.path.join(root, "examples", "multifield_module.cpp")
+    exe = os.path.join(root, "examples", "multifield_module")
+    if _stale(exe, [src, os.path.join(HERE, "host", "mw_facade.h"), os.path.join(root, "include", "mw_cdna4.h"), LIB]):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", src, "-o", exe, "-I/opt/rocm/include", "-L" + HERE, "-lmw_cdna4",
+               "-Wl,-rpath,$ORIGIN/../miniweatherml_amd", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    exes.append(exe)
     return exes[0]
 
 

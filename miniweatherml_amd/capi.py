@@ -63,6 +63,7 @@ SYMBOLS = {
     "mw_debug_spin": (C.c_int, [C.c_longlong, C.c_void_p]),
     "mw_debug_launched_kernels": (C.c_longlong, [C.c_char_p, C.c_longlong, C.c_int]),
     "mw_debug_zero_maps": (C.c_longlong, [C.c_void_p, C.c_void_p, C.c_longlong, C.POINTER(C.c_int)]),
+    "mw_debug_zero_violations": (C.c_longlong, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "mw_dycore_path": (C.c_char_p, [C.c_void_p]),
     "mw_dycore_use_rccl_self": (C.c_int, [C.c_void_p]),
     "mw_rccl_selftest_config": (C.c_int, [C.c_int, C.c_int]),

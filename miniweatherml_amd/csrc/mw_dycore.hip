@@ -925,6 +925,7 @@ struct DyOpts {
   int zero_rows = 1;           // ... and the zero-row maps on top of it: rows of a tracer that are known to be zero are not loaded (mw_march.h: k_zero_rows)
   int pipe_maps_early = 1;     // pipelined schedule, first stage: local zero-row maps in front of its y launches, two strip exchanges (0: one exchange, maps beside the y launch; A/B)
   int zero_stores = 1;         // ... and zeros are not stored over rows that hold zeros already (the coupler's arrays, slabs S1 / S2; 0: A/B)
+  int zero_verify = 0;         // test aid: check the maps' claims against the data in front of every launch that relies on them (k_zero_verify; mw_debug_zero_violations)
   int rccl_lanes = 0, rccl_two_comms = -1;            // built-in RCCL transport: side streams (1 | 2), a communicator per lane (0 | 1); 0 / -1 = the
                                                       // process default (MW_RCCL_LANES); read when mw_dycore_use_rccl* installs the transport
   int rccl_prio = 1;           // ... its side streams at the highest stream priority (0: default priority; A/B)
@@ -968,6 +969,7 @@ struct mw_dycore_s {
   const double *kz_buf[2] = {nullptr, nullptr};   // ... and, for the two slabs that take turns as q^n, "the rows the last conversion into it left zero" (maps behind MC; nullptr: unknown)
   int zr_cur = 0;                          // ... double-buffered: set zr_cur belongs to the running sub-cycle, the other one to the one before
   bool zr_prev_ok = false, zr_prev_use = false;   // the other set describes what slabs S1 / S2 hold now (the sub-cycle before ran with maps, nothing else wrote the slabs since) / ... and is handed to this sub-cycle's kernels
+  unsigned long long *zviol = nullptr;     // option zero_verify: four violation counters (k_zero_verify)
   unsigned *zr = nullptr; long long zr_msz = 0; bool zr_on = false;   // zero-row maps (M0 and the six of k_zero_dilate) of the running sub-cycle (mw_march.h: k_zero_rows), zr_msz words each
   int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows (see DyP::hypk)
@@ -1775,6 +1777,29 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
 static bool zero_rows_ok(const mw_dycore_s *d);
 static int zero_rows_local(mw_dycore_s *d, const double *S0, const CouplerPtrs &c, bool from_coupler, hipStream_t st);
 static int zero_rows_merge(mw_dycore_s *d, hipStream_t st, bool first_cycle);
+// Option zero_verify (test aid): the maps' claims against the data, on stream `st`, in front of the launches that rely on them.
+//   what = 0: in front of the stage's tracer kernel -- the stage's input slab against Qs / QYs, the destination (slab Sout, or the coupler's
+//             arrays in the last stage of a time step) against the "holds zeros already" map the kernel was handed;
+//   what = 1: in front of the converting y launch -- the slab it fills against zqk.
+// Uses the parameter block as the next launch will see it (zero_rows_stage / zero_rows_conv have run).  Counters: mw_debug_zero_violations.
+static int zero_rows_verify(mw_dycore_s *d, int what, const double *Sin, const double *Sout, bool dst_coupler, const CouplerPtrs &c, hipStream_t st) {
+  if (!d->o.zero_verify || !d->zr_on) return 0;
+  if (!d->zviol) { MW_HIP(hipMalloc(&d->zviol, 4 * sizeof(unsigned long long))); MW_HIP(hipMemsetAsync(d->zviol, 0, 4 * sizeof(unsigned long long), st)); }
+  for (int e = 0; e < n_views(d); e++) {
+    const View v = view(d, e);
+    const DyP &p = v.p;
+    if (what == 0 && !p.zq) continue;
+    if (what == 1 && !p.zqk) continue;
+    const unsigned vmask = (marching_config(d, p) == 1) ? 0x6u : 0xFu;
+    const long long nrow = (long long)p.nz * p.ny;
+    const bool dstc = what == 0 && dst_coupler && p.zqc != nullptr;
+    const double *dst = (what == 0 && !dst_coupler && p.zqp) ? v.S(Sout) : nullptr;
+    MW_KLAUNCH(k_zero_verify, dim3((unsigned)((nrow + 3) / 4)), dim3(256), 0, st, p, c, what == 0 ? v.S(Sin) : nullptr, dst, dstc ? 1 : 0,
+               what == 1 ? v.S(Sin) : nullptr, d->zr_msz, vmask, d->zviol);
+    MW_LAUNCH_CHECK();
+  }
+  return 0;
+}
 template <int STAGE, int MODE>
 static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double *Sout, double dt_stage, double dt_dyn,
                           const CouplerPtrs &c) {
@@ -1800,6 +1825,7 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   else
 #endif
   {
+  if (conv && zero_rows_verify(d, 1, Sin, nullptr, false, c, ss)) return 1;
   if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin, conv ? &c : nullptr)) return 1; }
   else if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
   if (STAGE == 1 && conv) zero_rows_conv(d, Sin, true, ss);
@@ -1819,6 +1845,7 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   if (d->overlap) { MW_HIP(hipEventRecord(d->ev_state[slot], ss)); MW_HIP(hipStreamWaitEvent(ts, d->ev_state[slot], 0)); }
   if (!yall && launch_y_tracers(d, Sin, par, ts)) return 1;                   // tracer fluxes (public arrays)
   if (d->fused) {
+    if (zero_rows_verify(d, 0, Sin, Sout, MODE == 1, c, ts)) return 1;
     if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ts)) return 1;   // x/z fluxes + D10 + D11/D12 (+ D13)
   } else {
     if (launch_xz_tracers(d, Sin, par, dt_stage, ts)) return 1;               // x/z fluxes + D10 (FCT)
@@ -1864,7 +1891,11 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   //  and the tracer strips as two exchanges -- k_xz_state waits for the first only -- and the neighbours' maps merged in behind them; before,
   //  this stage's y launch ran without maps, 664 against 476 us, in front of one 609 us exchange chain for all eight variables)
   bool maps_early = false;
-  if (!d->pipe_ready && STAGE == 1 && split_edges && d->o.pipe_maps_early && !d->p.wrap_y && d->p.ny >= 4 * MW_Y_EDGE && zero_rows_ok(d)) {   // (a y-decomposed block with real edge strips)
+  // (every rank must take the same branch here -- it posts a different number and size of exchanges -- so the size test looks at the
+  //  SMALLEST block of the decomposition, as zero_rows_ok does: blocks of 15 and 16 rows (ny_glob = 31 on two y ranks) would otherwise
+  //  straddle the threshold and post mismatched send / receive groups)
+  const long long ny_min_blk = d->g.ny_glob / std::max(1, d->p.nproc_y);
+  if (!d->pipe_ready && STAGE == 1 && split_edges && d->o.pipe_maps_early && !d->p.wrap_y && ny_min_blk >= 4 * MW_Y_EDGE && zero_rows_ok(d)) {   // (a y-decomposed block with real edge strips)
     maps_early = true;
     // the local maps on the exchange stream: from the coupler's arrays they only need the step's inputs and run BESIDE the strip conversion
     // on the compute stream (first sub-cycle); from the slab they wait for it like everything else
@@ -1903,6 +1934,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   if (STAGE != 1) zero_rows_stage(d, STAGE);                    // (stage 1 without the early maps: its y launches run BESIDE the map build -- the maps are handed over in front of the tracer kernel)
   if (STAGE == 3 && MODE == 0) zero_rows_forget(d, Sout);
   d->pipe_ready = false;
+  if (conv && zero_rows_verify(d, 1, Sin, nullptr, false, c, ss)) return 1;
   if (launch_y_all(d, Sin, conv ? &c : nullptr, 1)) return 1;  // rows whose chunks read no halo row
   MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));           // state strips (+ the edge rows' y tendencies) of this stage's input
   if (!d->pipe_edge_done && launch_y_all(d, Sin, nullptr, 2)) return 1;   // first and last chunk
@@ -1922,6 +1954,7 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
     MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[4], 0)); zero_rows_stage(d, 1);
     if (maps_early && conv) zero_rows_conv(d, Sin, true, ss);     // (the slab's row map changes BEHIND the converting launch that reads it)
   }
+  if (zero_rows_verify(d, 0, Sin, Sout, MODE == 1, c, ss)) return 1;
   if (launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ss)) return 1;
   if (early) {
     MW_HIP(hipEventRecord(d->ev_pipe[1], ss)); MW_HIP(hipStreamWaitEvent(xs, d->ev_pipe[1], 0));
@@ -1962,7 +1995,10 @@ static int zero_rows_build(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   if (!d->zr || d->zr_msz != msz) {
     if (d->zr) { MW_HIP(hipDeviceSynchronize()); (void)hipFree(d->zr); d->zr = nullptr; }
     if (d->zrx) { (void)hipFree(d->zrx); d->zrx = nullptr; }
-    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 3) * (size_t)msz * sizeof(unsigned) * (size_t)p.nens) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }   // per member: two sets + MC + the two q^n slabs' maps
+    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 3) * (size_t)msz * sizeof(unsigned) * (size_t)p.nens) != hipSuccess) {   // per member: two sets + MC + the two q^n slabs' maps
+      (void)hipGetLastError(); d->zr = nullptr; d->zr_on = false;
+      if (d->xchg) MW_FAIL("zero-row maps: out of device memory");   // (a decomposed block: the other ranks are about to exchange maps -- an error, not a fall-back)
+      return 0; }
     d->zr_msz = msz; d->zr_prev_ok = false; d->kz_buf[0] = d->kz_buf[1] = nullptr;
   }
   if (d->member_major) {                                        // one map set per member, from the member's slab (the caller runs this behind the first y launch)
@@ -2033,7 +2069,10 @@ static int zero_rows_local(mw_dycore_s *d, const double *S0, const CouplerPtrs &
   if (!d->zr || d->zr_msz != msz) {
     if (d->zr) { MW_HIP(hipDeviceSynchronize()); (void)hipFree(d->zr); d->zr = nullptr; }
     if (d->zrx) { (void)hipFree(d->zrx); d->zrx = nullptr; }
-    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 3) * (size_t)msz * sizeof(unsigned) * (size_t)p.nens) != hipSuccess) { (void)hipGetLastError(); d->zr_on = false; return 0; }
+    if (hipMalloc(&d->zr, (2 * MW_ZR_MAPS + 3) * (size_t)msz * sizeof(unsigned) * (size_t)p.nens) != hipSuccess) {
+      (void)hipGetLastError(); d->zr = nullptr; d->zr_on = false;
+      if (d->xchg) MW_FAIL("zero-row maps: out of device memory");   // (as in zero_rows_build: the neighbours still post their map exchanges)
+      return 0; }
     d->zr_msz = msz; d->zr_prev_ok = false; d->kz_buf[0] = d->kz_buf[1] = nullptr;
   }
   if (!d->zrx && hipMalloc(&d->zrx, (size_t)(3 * dWE + 4 * dSN) * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); MW_FAIL("zero-row maps: out of device memory"); }
@@ -2263,6 +2302,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->dirty) (void)hipFree(d->dirty);
   if (d->zr) (void)hipFree(d->zr);
   if (d->zrx) (void)hipFree(d->zrx);
+  if (d->zviol) (void)hipFree(d->zviol);
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
@@ -2300,7 +2340,7 @@ const OptDesc OPTS[] = {
   {"mm_direct", &DyOpts::mm_direct, 0, 1, 0}, {"mm_conv", &DyOpts::mm_conv, 0, 1, 0}, {"fused_convert", &DyOpts::fused_convert, 0, 1, 0},
   {"fused_convert_mm", &DyOpts::fused_convert_mm, 0, 1, 0}, {"chunk_y", &DyOpts::chunk_y, 0, 1 << 20, 0}, {"chunk_yt", &DyOpts::chunk_yt, 0, 1 << 20, 0},
   {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
-  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"zero_stores", &DyOpts::zero_stores, 0, 1, 0}, {"pipe_maps_early", &DyOpts::pipe_maps_early, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
+  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"zero_stores", &DyOpts::zero_stores, 0, 1, 0}, {"zero_verify", &DyOpts::zero_verify, 0, 1, 0}, {"pipe_maps_early", &DyOpts::pipe_maps_early, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
   {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0}, {"rccl_inline", &DyOpts::rccl_inline, 0, 1, 0},
   {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
   {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},
@@ -2731,6 +2771,18 @@ long long mw_debug_zero_maps(mw_dycore_t d, unsigned int *out_host, long long ca
   if (out_host && cap_words > 0)
     (void)hipMemcpy(out_host, d->zr + (long long)d->zr_cur * n, (size_t)std::min(n, cap_words) * sizeof(unsigned), hipMemcpyDeviceToHost);
   return n;
+}
+// Test aid: the four violation counters of option zero_verify (k_zero_verify, mw_march.h) since the handle was created; -1: the option
+// never ran.  out4: [0] input row non-zero under a clear Qs word, [1] ... under a clear QYs word, [2] a destination row the tracer kernel
+// was told holds zeros does not, [3] likewise a row of the slab the converting y launch fills.
+long long mw_debug_zero_violations(mw_dycore_t d, unsigned long long *out4) {
+  if (!d || !d->zviol) return -1;
+  (void)hipStreamSynchronize(d->stream);
+  if (d->tstream) (void)hipStreamSynchronize(d->tstream);
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (hipMemcpy(h, d->zviol, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (out4) for (int i = 0; i < 4; i++) out4[i] = h[i];
+  return (long long)(h[0] + h[1] + h[2] + h[3]);
 }
 // Test aid: the names (as the code object spells them, i.e. mangled; newline-separated) of the dycore kernels this PROCESS has launched
 // since the last reset -- every instantiation of the dispatcher's templates has its own.  Returns the bytes needed (terminator included);

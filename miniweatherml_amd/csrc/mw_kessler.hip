@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <mutex>
 
 namespace mw {
@@ -517,18 +518,24 @@ int mw_kessler_math_probe(long long n, const double *x, double *y, int fn, void 
 
 static thread_local int g_kessler_strict = 0;        // per calling thread: a rank harness with one host thread per rank may use different modes side by side
 // 1: the strict path (reference operation order, glibc's pow / exp: bit-identical to the CPU oracle); 0: the production kernels
-// The pair of min words of a (device, stream): allocated and set to +inf once, then kept consistent by the kernels themselves (see
-// MW_KES_INF).  -> this call's word and the one its CFL pass resets for the next call.
+// The pair of min words of a caller: library-owned device memory, allocated and set to +inf once, then kept consistent by the kernels
+// themselves (see MW_KES_INF).  -> this call's word and the one its CFL pass resets for the next call.
+// Keyed by (device, stream, WORKSPACE): a workspace is one caller's scratch -- two host threads that run Kessler on the same device and
+// stream (the thread-per-rank harness on the null stream) bring their own workspaces and so get their own pairs and their own call
+// parity; round 5 keyed the pair by (device, stream) alone, and two such threads could interleave get / prep / commit on ONE word
+// (a reset between the other thread's CFL pass and its sweep: rainsplit = ceil(dt / inf) = 0).  The words are not IN the workspace:
+// the caller may free it and an allocator may hand the same address out again with other contents -- the pair of that key is still
+// consistent then (one word holds the last call's minimum, the other +inf).
 // (commit = true, after the CFL pass was launched: the call counts -- a call that failed before its CFL pass must not flip the parity,
 //  its word for the next call would never have been reset)
-static int kessler_min_words(hipStream_t st, unsigned long long **cur, unsigned long long **next, bool commit = false) {
+static int kessler_min_words(hipStream_t st, const void *workspace, unsigned long long **cur, unsigned long long **next, bool commit = false) {
   struct Entry { unsigned long long *w = nullptr; unsigned long long calls = 0; };
   static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Entry> tab;
+  static std::map<std::tuple<int, hipStream_t, const void *>, Entry> tab;
   int dev = 0;
   MW_HIP(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(mu);
-  Entry &e = tab[{dev, st}];
+  Entry &e = tab[std::make_tuple(dev, st, workspace)];
   if (commit) { e.calls++; return 0; }
   if (!e.w) {
     const unsigned long long init[2] = {MW_KES_INF, MW_KES_INF};
@@ -550,12 +557,12 @@ int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *r
   hipStream_t st = (hipStream_t)stream;
   KesP p; p.nz = nz; p.ncol = ncol; p.dz = dz; p.dt = dt; p.R_d = 287.; p.cp_d = 1003.; p.R_v = 461.; p.p0 = 1.e5;
   unsigned long long *bits = nullptr, *next_bits = nullptr;
-  if (kessler_min_words(st, &bits, &next_bits)) return 1;
+  if (kessler_min_words(st, workspace, &bits, &next_bits)) return 1;
   double *ws = (double *)workspace + 16;
   if (g_kessler_strict) {
     const long long n = (long long)nz * ncol;
     hipLaunchKernelGGL(k_kessler_strict_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp, ws, bits, next_bits); MW_LAUNCH_CHECK();
-    if (kessler_min_words(st, nullptr, nullptr, true)) return 1;
+    if (kessler_min_words(st, workspace, nullptr, nullptr, true)) return 1;
     hipLaunchKernelGGL(k_kessler_strict_column, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, st, p, rho_v, rho_c, rho_r, rho_d, temp,
                        precl, bits, ws); MW_LAUNCH_CHECK();
     if (rainsplit_out) {
@@ -575,7 +582,7 @@ int mw_kessler_time_step(int nz, long long ncol, double dz, double dt, double *r
   const int klevels = 5;                                        // levels per thread of the CFL pass (k_kessler_prep: KL)
   hipLaunchKernelGGL(k_kessler_prep, dim3((unsigned)((ncol + 255) / 256), (unsigned)((nz + klevels - 1) / klevels)), dim3(256), 0, st, p,
                      rho_r, rho_d, flux_top, chunk, klevels, bits, next_bits); MW_LAUNCH_CHECK();
-  if (kessler_min_words(st, nullptr, nullptr, true)) return 1;
+  if (kessler_min_words(st, workspace, nullptr, nullptr, true)) return 1;
 #if MW_KES_SWEEP
   hipLaunchKernelGGL(k_kessler_sweep, dim3((unsigned)((ncol + 255) / 256), (unsigned)nchunks), dim3(256), 0, st, p, rho_v, rho_c, rho_r,
                      rho_d, temp, precl, bits, ws, flux_top, chunk); MW_LAUNCH_CHECK();

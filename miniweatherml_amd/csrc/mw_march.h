@@ -511,6 +511,62 @@ __global__ __launch_bounds__(256) void k_zero_dilate(DyP p, unsigned *__restrict
   }
 }
 
+// Test aid (option zero_verify, any build): the CLAIMS the maps make, checked against the data right in front of the launches that rely on
+// them.  wave = one x row (k, j) of the block; viol[] counts rows:
+//   [0] a tracer that can vanish is non-zero in row (k, j) of the stage's INPUT slab although Qs[k'][j] is clear for one of the iterations
+//       k' = k-3 .. k+2 (clamped) of the row's tracer wave that touch level k  (k_tracers_fused would not have loaded it);
+//   [1] ... although QYs[k][j'] is clear for one of the rows j' = j-3 .. j+3 whose y-marching iteration touches row j  (k_y_all);
+//   [2] a destination row whose store of zeros the tracer kernel is about to SKIP (its storing iteration is lean and the map handed over as
+//       "the destination holds zeros already" is clear -- zqp: slab S1 / S2; zqc: the coupler's arrays) is NOT all zero: a non-zero value
+//       would be left standing;
+//   [3] likewise a row of the slab that the converting y launch is about to skip (zqk).
+// dst == nullptr / the map pointers == nullptr: that claim is not made in this launch and not checked.
+__global__ __launch_bounds__(256) void k_zero_verify(DyP p, CouplerPtrs c, const double *__restrict__ Sin, const double *__restrict__ Sdst, int dst_coupler,
+                                                     const double *__restrict__ Skz, long long msz, unsigned vmask, unsigned long long *__restrict__ viol) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)p.nz * p.ny) return;
+  const int k = (int)(row / p.ny), j = (int)(row - (long long)k * p.ny), lane = threadIdx.x & 63;
+  const int NXI = p.nx * p.nens;
+  const unsigned scan = vmask & ((1u << min(p.nt, 4)) - 1u);
+  unsigned in_nz = 0, dst_nz = 0, kz_nz = 0;
+  const long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens;
+  const long long ci = ((long long)k * p.ny + j) * NXI;
+  for (int v = 0; v < 4; v++) {
+    if (!((scan >> v) & 1u)) continue;
+    bool a = false, b = false, e = false;
+    for (int ie = lane; ie < NXI; ie += 64) {
+      if (Sin) a = a || (Sin[(long long)(5 + v) * p.sV + so + ie] != 0.0);
+      if (Sdst && !dst_coupler) b = b || (Sdst[(long long)(5 + v) * p.sV + so + ie] != 0.0);
+      if (dst_coupler) b = b || (c.tr[v][cpl(p, ci + ie)] != 0.0);
+      if (Skz) e = e || (Skz[(long long)(5 + v) * p.sV + so + ie] != 0.0);
+    }
+    if (__any(a)) in_nz |= 1u << v;
+    if (__any(b)) dst_nz |= 1u << v;
+    if (__any(e)) kz_nz |= 1u << v;
+  }
+  if (lane != 0) return;
+  const long long ld = p.zq_ld;
+  if (p.zq && in_nz) {
+    bool bad0 = false, bad1 = false;
+    for (int kk = max(k - 3, 0); kk <= min(k + 2, p.nz - 1); kk++) bad0 = bad0 || ((in_nz & ~p.zq[(long long)kk * ld + j + MW_ZR_HALO]) != 0u);
+    const unsigned *qy = p.zq + 6 * msz;
+    for (int dj = -MW_ZR_REACH; dj <= MW_ZR_REACH; dj++) bad1 = bad1 || ((in_nz & ~qy[(long long)k * ld + j + dj + MW_ZR_HALO]) != 0u);
+    if (bad0) atomicAdd(&viol[0], 1ull);
+    if (bad1) atomicAdd(&viol[1], 1ull);
+  }
+  // (the store of level k is skipped by the iteration k + 2 of the row's wave -- word min(k + 2, nz - 1) -- when that iteration is LEAN and
+  //  the destination's map is clear; the converting y launch skips row j when the iteration that converts it, j - 3, is lean and zqk is clear)
+  if (dst_nz && p.zq) {
+    const unsigned *m = dst_coupler ? p.zqc : p.zqp;
+    const int kq = min(k + 2, p.nz - 1);
+    if (m && (dst_nz & ~p.zq[(long long)kq * ld + j + MW_ZR_HALO] & ~m[(long long)(dst_coupler ? k : kq) * ld + j + MW_ZR_HALO])) atomicAdd(&viol[2], 1ull);
+  }
+  if (kz_nz && p.zqk && p.zq) {
+    const unsigned *qy = p.zq + 6 * msz;
+    if (kz_nz & ~qy[(long long)k * ld + j - MW_ZR_REACH + MW_ZR_HALO] & ~p.zqk[(long long)k * ld + j + MW_ZR_HALO]) atomicAdd(&viol[3], 1ull);
+  }
+}
+
 // Member-major handles (nens > 1, see View in mw_dycore.hip): the two conversions between the coupler's member-fastest arrays and
 // the member-after-member slabs, as coalesced passes.  thread = one cell in the COUPLER's order (fused x, member fastest): the
 // coupler side is a unit-stride stream, the slab side 16-lane segments of nens different members.  (Done from inside the

@@ -34,15 +34,70 @@ typedef double real;                                                  // main_he
 inline void endrun(const std::string &msg) { throw std::runtime_error(msg); }
 inline void mw_check(int rc) { if (rc) endrun(mw_last_error()); }
 
+int constexpr max_fields = 50;                                        // main_header.h:57
+
+#if defined(__HIPCC__)
+#define MW_HD __host__ __device__
+#else
+#define MW_HD
+#endif
+
+// A rank-N view that a HIP kernel can take BY VALUE (plain pointer + extents, row-major, last index fastest) -- what the reference's
+// non-owning yakl::Array<T,N,memDevice,styleC> is to its YAKL_LAMBDAs.  Indexable on the device (and on the host for host memory).
+template <class T, int N> struct FieldView {
+  T *ptr = nullptr;
+  int dim[N] = {};
+  MW_HD T *data() const { return ptr; }
+  MW_HD int extent(int i) const { return dim[i]; }
+  MW_HD size_t size() const { size_t n = 1; for (int i = 0; i < N; i++) n *= (size_t)dim[i]; return n; }
+  template <class... I> MW_HD T &operator()(I... idx) const {
+    static_assert(sizeof...(I) == N, "FieldView: the number of indices must equal the rank");
+    const long long ix[N] = {(long long)idx...};
+    long long off = 0;
+    for (int i = 0; i < N; i++) off = off * dim[i] + ix[i];
+    return ptr[off];
+  }
+  operator FieldView<const T, N>() const { FieldView<const T, N> v; v.ptr = ptr; for (int i = 0; i < N; i++) v.dim[i] = dim[i]; return v; }
+};
+
 template <class T> struct DeviceView {                                // non-owning view
   T *ptr = nullptr;
   std::vector<int> dimension;
   T *data() const { return ptr; }
   size_t size() const { size_t n = 1; for (int d : dimension) n *= (size_t)d; return n; }
   int extent(int i) const { return dimension[i]; }
+  template <int N> FieldView<T, N> as() const {                       // the same allocation with its rank in the type (DataManager::get<T,N>)
+    if ((int)dimension.size() != N) throw std::runtime_error("ERROR: Requested dimensions is different from the entry dimensions");   // DataManager.h:263-268
+    FieldView<T, N> v; v.ptr = ptr; for (int i = 0; i < N; i++) v.dim[i] = dimension[i]; return v;
+  }
+  template <int N> operator FieldView<T, N>() const { return as<N>(); }
 };
 
 namespace core {
+
+// core::MultipleFields / core::MultiField (model/core/MultipleFields.h:10-96): several fields of one rank aggregated so that ONE kernel
+// can loop over them ("used mostly for tracers"; sponge_layer.h:32-41, column_nudging.h:28-33, :50-55 build them from DataManager::get).
+// Trivially copyable -- a HIP kernel takes it by value like the reference's YAKL_LAMBDAs capture it -- with the reference's members:
+// add_field, get_field, get_num_fields, operator()(field, indices...).
+template <int MAX_FIELDS, class T>
+class MultipleFields {
+ public:
+  mutable T fields[MAX_FIELDS];                                       // (SArray<T,1,MAX_FIELDS>; get_field is const and returns T&, :53-55)
+  int num_fields;
+  MW_HD MultipleFields() : num_fields(0) {}
+  MW_HD MultipleFields(MultipleFields const &rhs) : num_fields(rhs.num_fields) { for (int i = 0; i < num_fields; i++) fields[i] = rhs.fields[i]; }   // :17-22
+  MW_HD MultipleFields &operator=(MultipleFields const &rhs) { num_fields = rhs.num_fields; for (int i = 0; i < num_fields; i++) fields[i] = rhs.fields[i]; return *this; }
+  MW_HD void add_field(T field) {                                     // :48-51 (the reference writes past the end silently; here that is an error on the host)
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (num_fields >= MAX_FIELDS) throw std::runtime_error("ERROR: MultipleFields: more than MAX_FIELDS fields");
+#endif
+    fields[num_fields] = field; num_fields++;
+  }
+  MW_HD T &get_field(int tr) const { return fields[tr]; }             // :53-55
+  MW_HD int get_num_fields() const { return num_fields; }             // :57
+  template <class... I> MW_HD auto operator()(int tr, I... idx) const -> decltype(fields[tr](idx...)) { return fields[tr](idx...); }   // :59-90
+};
+template <class T, int N> using MultiField = MultipleFields<max_fields, FieldView<T, N>>;                          // :95-96
 
 class Options {                                                       // model/core/Options.h:11-167
   std::map<std::string, std::variant<int, real, bool, std::string, long long>> opts;
@@ -95,6 +150,18 @@ class DataManager {                                                   // model/c
     if (entries[id].type_hash != typeid(TNC).hash_code()) endrun("ERROR: Requested Array type does not match entry type");   // :256-261
     if (!std::is_const<T>::value) entries[id].dirty = true;                                                     // :275
     return DeviceView<T>{(T *)entries[id].ptr, entries[id].dims};
+  }
+  template <class T, int N> FieldView<T, N> get(const std::string &name) { return get<T>(name).template as<N>(); }   // the reference's spelling get<T,N>(name): rank checked (:263-268)
+  // :79-103: an independent copy of every entry (own allocation, device-to-device copy), dimensions included
+  void clone_into(DataManager &dm) const {
+    dm.dimensions = dimensions;
+    for (auto &e : entries) {
+      Entry loc = e;
+      loc.ptr = nullptr;
+      if (hipMalloc(&loc.ptr, e.bytes) != hipSuccess) endrun("ERROR: device allocation failed for " + e.name);
+      if (hipMemcpy(loc.ptr, e.ptr, e.bytes, hipMemcpyDeviceToDevice) != hipSuccess) endrun("ERROR: device copy failed for " + e.name);
+      dm.entries.push_back(loc);
+    }
   }
   template <class T> DeviceView<T> get_lev_col(const std::string &name) {                                      // :289-330
     auto v = get<T>(name); int nlev = v.dimension[0]; int ncol = (int)(v.size() / (size_t)nlev);
@@ -159,6 +226,15 @@ class Coupler {                                                       // model/c
     mw_check(mw_decompose(nranks, myrank, (long long)nx_glob, (long long)ny_glob, &grid));
     grid.nz = nz; grid.nens = nens;
     dm.add_dimension("nens", nens); dm.add_dimension("x", grid.nx); dm.add_dimension("y", grid.ny); dm.add_dimension("z", nz);
+  }
+  // :85-106: grid, decomposition, tracer registry and an independent copy of every DataManager entry go to `coupler`; the OPTIONS do
+  // not (the reference's clone_into leaves coupler.options alone)
+  void clone_into(Coupler &coupler) const {
+    coupler.xlen = xlen; coupler.ylen = ylen; coupler.zlen = zlen; coupler.dt_gcm = dt_gcm;
+    coupler.tracers = tracers;
+    coupler.nranks = nranks; coupler.myrank = myrank;
+    coupler.grid = grid;                                              // nens, nx_glob, ny_glob, nproc_x/y, px, py, i_beg, j_beg, neigh (:94-105)
+    dm.clone_into(coupler.dm);
   }
   void set_grid(real xl, real yl, real zl) { xlen = xl; ylen = yl; zlen = zl; grid.xlen = xl; grid.ylen = yl; grid.zlen = zl; }
   real get_xlen() const { return xlen; }  real get_ylen() const { return ylen; }  real get_zlen() const { return zlen; }

@@ -208,6 +208,13 @@ class Dynamics_Euler_Stratified_WenoFV:
         check(capi.lib().mw_dycore_get_option(self.h, key.encode(), C.byref(v)))
         return v.value
 
+    def zero_violations(self):
+        """(total, [4]) of option zero_verify's counters (mw_debug_zero_violations; a test aid): claims of the zero-row maps that the data
+        contradicted; total = -1 when the option never ran on this handle."""
+        out = (C.c_ulonglong * 4)()
+        n = capi.lib().mw_debug_zero_violations(self.h, out)
+        return n, [int(v) for v in out]
+
     def set_bc(self, coupler, bc_x, bc_y, bc_z):
         check(capi.lib().mw_dycore_set_bc(self.h, bc_x, bc_y, bc_z))
         coupler.set_option("bc_x", bc_x); coupler.set_option("bc_y", bc_y); coupler.set_option("bc_z", bc_z)
@@ -385,6 +392,7 @@ class Microphysics_Kessler_Surrogate(Microphysics_Kessler):
     exactly like the reference with lines :273-276 commented out."""
 
     online = False        # True = the four deep_copy_to lines :273-276 un-commented: the NN result replaces Kessler's
+    mlp_strict = 0        # 1: the thread-per-cell MLP that accumulates in index order (bit-identical to the CPU restatement; tests)
 
     def init(self, coupler, weights_txt=None, in_scaling_txt=None, out_scaling_txt=None, weights_h5=None):
         super().init(coupler)
@@ -397,7 +405,7 @@ class Microphysics_Kessler_Surrogate(Microphysics_Kessler):
         temp, rho_d = dm.get("temp"), dm.get("density_dry", readonly=True)
         rho_v, rho_c, rho_r = dm.get("water_vapor"), dm.get("cloud_liquid"), dm.get("precip_liquid")
         self._nn_out = mlp_forward(temp, rho_d, rho_v, rho_c, rho_r, self.W1, self.b1, self.W2, self.b2, self.scl_in, self.scl_out,
-                                   self._nn_out)
+                                   self._nn_out, strict=self.mlp_strict)
         super().time_step(coupler, dt)
         if self.online:                                                        # :273-276
             self._diffs = self.mean_diffs(coupler)                             # (the prints of :266-269 come first)

@@ -152,3 +152,20 @@ def test_cpp_multirank_host_between_gpus(mw, tmp_path):
     assert tot[0] == tot[1] and abs(tot[0] - sumr) <= 1e-12 * sumr
     assert abs(max(float(m.group(8)) for m, _ in outs) - maxw) <= 1e-11 * maxw
     assert abs(sum(float(m.group(9)) for m, _ in outs) - sumr) <= 1e-12 * sumr
+
+
+@pytest.mark.parametrize("shape", [(16, 12, 10, 2), (20, 1, 12, 1)])
+def test_cpp_multifield_and_clone_into(mw, shape):
+    """core::MultiField (model/core/MultipleFields.h:10-96) and core::Coupler::clone_into (coupler.h:85-106; DataManager.h:79-103) of the
+    C++ facade, from a module with its OWN HIP kernels (examples/multifield_module.cpp): the aggregates are built the way
+    column_nudging.h:28-33, :50-55 build them (`state.add_field(dm.get<real,4>(name))`), taken by value by a kernel that loops
+    `state(l,k,j,i,iens)` over Bounds<5>(num_fields,nz,ny,nx,nens), and every cell of every field is checked on the host; a rank
+    mismatch and more than max_fields fields end the run; the clone is an independent deep copy (grid, tracers, every entry; no options)
+    on which a module runs while the original steps on."""
+    from miniweatherml_amd import build
+    exe = os.path.join(ROOT, "examples", "multifield_module")
+    if not os.path.exists(exe):
+        build.build_examples(verbose=False)
+    out = subprocess.run([exe] + [str(v) for v in shape], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert re.search(r"multifield ok fields 5 cells %d clone_entries_checked 11" % (shape[0] * shape[1] * shape[2] * shape[3]), out.stdout), out.stdout

@@ -146,6 +146,7 @@ def test_zero_row_maps_through_a_developing_storm(mw):
     for rows in (1, 0):
         coupler, dycore, micro, nudger = modules.make_supercell(100, 40, 40, 1, 1.0e5, 4.0e4, 2.0e4, with_nudger=True)
         dycore.set_option("zero_rows", rows)
+        dycore.set_option("zero_verify", rows)                       # (the maps' claims against the data, all 800 steps)
         runs.append((coupler, dycore, micro, nudger))
     launched_kernels(reset=True)
     first_cloud = None
@@ -159,6 +160,7 @@ def test_zero_row_maps_through_a_developing_storm(mw):
             if first_cloud is None and float(a.get("cloud_liquid", True).max()) > 0.0:
                 first_cloud = n
     assert any("k_zero_rows" in k for k in launched_kernels())
+    assert runs[0][1].zero_violations() == (0, [0, 0, 0, 0])         # every claim held (and the check did run: not -1)
     dm = runs[0][0].get_data_manager_readonly()
     cl, pr = dm.get("cloud_liquid", True), dm.get("precip_liquid", True)
     assert first_cloud is not None and first_cloud < 800

@@ -182,6 +182,89 @@ def test_surrogate_module_runs_beside_kessler(mw, oracle):
     assert len(nn) == 4
 
 
+def _oracle_online_step(oracle, dyc, f, nud, dt, precl, W):
+    """One iteration of inference_ponni.cpp:69-82 with microphysics_kessler_ponni.h:273-276 un-commented, on the CPU oracle: dycore, the
+    network on the state IN FRONT of the Kessler step (:176-202), the true Kessler step (:204-262; its result only feeds the printed
+    differences), the four deep_copy_to lines -- the network's (temp, rho_v, rho_c, rho_r) overwrite Kessler's -- sponge layer, nudger."""
+    dyc.time_step(f, dt)
+    nn = oracle.mlp_forward(f.temp, f.rho_d, f.tracers[0], f.tracers[1], f.tracers[2], *W)
+    oracle.kessler_time_step(dyc.p.zlen / dyc.p.nz, dt, f.tracers[0], f.tracers[1], f.tracers[2], f.rho_d, f.temp, precl)
+    diffs = [(float(np.mean(nn[k] - a)), float(np.mean(np.abs(nn[k] - a)))) for k, a in ((1, f.tracers[0]), (2, f.tracers[1]), (3, f.tracers[2]), (0, f.temp))]
+    f.temp[...] = nn[0]
+    for t in range(3):
+        f.tracers[t][...] = nn[1 + t]
+    oracle.sponge_layer(dyc.p, f, dt)
+    nud.nudge_to_column(dyc.p, f, dt)
+    return nn, diffs
+
+
+@pytest.mark.parametrize("shape", [(20, 16, 12, 1), (48, 1, 20, 1)])
+def test_online_surrogate_step_equals_the_oracles_mlp_then_overwrite(mw, oracle, shape):
+    """`online = True` (modules.Microphysics_Kessler_Surrogate; C++ twin: host/mw_ponni.h `online`): the reference's four commented-out
+    deep_copy_to lines, microphysics_kessler_ponni.h:273-276, switched on -- the network's output replaces Kessler's in the coupler and the
+    run is steered by the network from then on.  The complete surrogate loop, three steps, in the strict forms (dycore, Kessler, the
+    horizontal sums, the thread-per-cell MLP in index order): every coupler field BIT-identical to the oracle's MLP-then-overwrite loop
+    after every step, the returned network output equal to the oracle's, the four printed mean differences computed BEFORE the overwrite."""
+    from test_gpu_full_loop import oracle_loop_setup
+    from miniweatherml_amd import capi, modules
+    nx, ny, nz, nens = shape
+    xlen, ylen = 500.0 * nx, (500.0 * ny if ny > 1 else 1.0e5)
+    modules.set_column_strict(1)
+    try:
+        micro = modules.Microphysics_Kessler_Surrogate()
+        micro.online, micro.mlp_strict = True, 1
+        coupler, dycore, micro, nudger = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000., micro=micro, with_nudger=True)
+        dyc, f, nud = oracle_loop_setup(oracle, nx, ny, nz, nens, xlen, ylen, 20000.)
+        push_fields(coupler, f)
+        nudger.column.copy_(torch.from_numpy(np.ascontiguousarray(nud.column)).reshape(nudger.column.shape))
+        dycore.set_strict(1)
+        micro.set_strict(1)
+        W = (micro.W1, micro.b1, micro.W2, micro.b2, micro.scl_in, micro.scl_out)
+        dt = dycore.compute_time_step(coupler)
+        precl = np.zeros((ny, nx, nens))
+        for step in range(1, 4):
+            dycore.time_step(coupler, dt)
+            nn_gpu = micro.time_step(coupler, dt)
+            after_micro = gpu_fields(coupler)
+            modules.sponge_layer(coupler, dt)
+            nudger.nudge_to_column(coupler, dt)
+            nn, diffs = _oracle_online_step(oracle, dyc, f, nud, dt, precl, W)
+            for k in range(4):
+                assert np.array_equal(nn_gpu[k].cpu().numpy(), nn[k]), (step, k)
+            # right behind micro.time_step the coupler holds the NETWORK's values, not Kessler's
+            for k, name in enumerate(("temp", "tracer0", "tracer1", "tracer2")):
+                assert np.array_equal(after_micro[name], nn[k]), (step, name)
+            d = micro._diffs                                      # (:266-269) mean(NN - Kessler), taken before the overwrite
+            for key, (ref, scale) in zip(("rho_v", "rho_c", "rho_r", "temp"), diffs):      # (another summation order: relative to the mean |difference|)
+                assert abs(d[key] - ref) <= 1e-12 * scale + 1e-300, (step, key, d[key], ref)
+            compare_fields(gpu_fields(coupler), f.as_dict(), 0.0, "online surrogate loop %s, %d steps (strict forms)" % (shape, step))
+        assert float(np.max(np.abs(f.tracers[1]))) > 0.0          # the network does produce cloud: the overwrite is not a no-op
+    finally:
+        modules.set_column_strict(0)
+        capi.check(capi.lib().mw_kessler_set_strict(0))
+        capi.check(capi.lib().mw_mlp_set_strict(0))
+
+
+def test_online_surrogate_step_production_kernels(mw, oracle):
+    """The same switch on the production kernels (MFMA MLP, fast Kessler): one micro step from identical inputs -- the coupler holds the
+    network's output, within 1e-5 of the output scaling's range of the oracle's (the MLP tolerance of this suite)."""
+    from miniweatherml_amd import modules
+    micro = modules.Microphysics_Kessler_Surrogate()
+    micro.online = True
+    coupler, dycore, micro = modules.make_supercell(16, 16, 12, 1, 8000., 8000., 20000., micro=micro)
+    dyc, f = oracle.supercell_setup(16, 16, 12, 1, 8000., 8000., 20000.)
+    push_fields(coupler, f)
+    dt = dycore.compute_time_step(coupler)
+    nn_gpu = micro.time_step(coupler, dt)
+    nn = oracle.mlp_forward(f.temp, f.rho_d, f.tracers[0], f.tracers[1], f.tracers[2], micro.W1, micro.b1, micro.W2, micro.b2, micro.scl_in, micro.scl_out)
+    g = gpu_fields(coupler)
+    for k, name in enumerate(("temp", "tracer0", "tracer1", "tracer2")):
+        tol = 1e-5 * (micro.scl_out[k, 1] - micro.scl_out[k, 0])
+        assert np.max(np.abs(g[name] - nn[k])) <= tol, name
+        assert np.array_equal(g[name], nn_gpu[k].cpu().numpy()), name          # the coupler holds exactly what the module returned
+    assert np.array_equal(g["density_dry"], f.rho_d)
+
+
 def test_kessler_math_against_host_libm(mw):
     """The module's own log / exp / sqrt / reciprocal (mw_kessler.hip: short forms for positive finite arguments) against
     numpy's: <= 4 ulp-ish (4.5e-16 relative), log(0) = -inf, exp(-inf) = 0, tiny and huge arguments included."""

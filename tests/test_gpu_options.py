@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"overlap": -1, "pipe": 1, "pipe_edge_inline": 0, "pipe_convert": 1, "pipe_split_edges": 1, "spec": 1, "wrap": 1, "y_all": 1, "y_all_conv": 1,
             "member_major": 1, "mm_direct": 1, "mm_conv": 1, "fused_convert": 1, "fused_convert_mm": 1, "fused_tracers": 1, "chunk_y": 0, "chunk_yt": 0,
-            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "zero_rows": 1, "zero_stores": 1, "pipe_maps_early": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
+            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "zero_rows": 1, "zero_stores": 1, "zero_verify": 0, "pipe_maps_early": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
 
 
 def test_defaults_round_trips_and_errors(mw):
@@ -268,12 +268,16 @@ def test_zero_row_maps_on_random_configurations(mw, seed):
             keep[vbox[0]:vbox[0] + 6, vbox[1]:vbox[1] + 12, vbox[2]:vbox[2] + 40] = 1.0
             dm.get("water_vapor").mul_(keep)
         dycore.set_option("spec", spec); dycore.set_option("zero_rows", rows)
+        dycore.set_option("zero_verify", rows)                       # (the maps' claims against the data in front of every launch that relies on them)
         for k, v in chunks.items():
             dycore.set_option(k, v)
         dt = dycore.compute_time_step(coupler)
         for f in factors:
             dycore.time_step(coupler, dt * f)
         res.append(gpu_fields(coupler))
+        if rows:
+            nviol, kinds = dycore.zero_violations()
+            assert nviol == 0, ("zero_verify", kinds, seed, nx, ny, nz, nens, order, spec, chunks)   # (ran: >= 0; no claim contradicted)
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), (k, seed, nx, ny, nz, nens, order, spec, chunks)
 

@@ -124,10 +124,13 @@ def test_validators_report_counts_and_first_index(mw, capsys):
     assert not dm.entry_is_dirty("temp")
 
 
-def test_cpp_inference_ponni_driver_equals_python_mirror(mw, tmp_path):
+@pytest.mark.parametrize("online", [0, 1])
+def test_cpp_inference_ponni_driver_equals_python_mirror(mw, tmp_path, online):
     """examples/inference_ponni_driver.cpp = experiments/supercell_kessler_surrogate/inference_ponni.cpp:9-86 over the C++ mirrors
     (mw_ponni.h: load_h5_weights<N>, Matvec / Bias / Relu, create_inference_model, forward_batch_parallel; custom_modules::
-    Microphysics_Kessler): every printed number equals the Python mirror's, bit for bit (same library underneath)."""
+    Microphysics_Kessler): every printed number equals the Python mirror's, bit for bit (same library underneath).
+    online = 1: the NN result overwrites Kessler's (microphysics_kessler_ponni.h:273-276 un-commented; mw_ponni.h `online`) -- the run
+    is then steered by the network, and the two mirrors must still agree in every bit."""
     from miniweatherml_amd import build, modules
     exe = os.path.join(ROOT, "examples", "inference_ponni_driver")
     if not os.path.exists(exe):
@@ -139,7 +142,7 @@ def test_cpp_inference_ponni_driver_equals_python_mirror(mw, tmp_path):
                    "xlen: 100000\nylen: 100000\nzlen: 20000\ninit_data: supercell\nout_prefix: test\ndt_gcm: 900\ndt_phys: 0.\nout_freq: -1.\n"
                    "keras_weights_h5: \"%s/supercell_kessler_singlecell_model_weights.h5\"\nnn_input_scaling: \"%s/kessler_surrogate_input_scaling.txt\"\n"
                    "nn_output_scaling: \"%s/kessler_surrogate_output_scaling.txt\"\n" % (nx, ny, nz, data, data, data))
-    out = subprocess.run([exe, str(yml), str(steps)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, str(yml), str(steps), str(online)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Matvec with 5 inputs and 10 outputs" in out.stdout and "negative_slope == 0.1" in out.stdout      # model.print()
     m = re.search(r"steps (\d+) etime (\S+) maxw (\S+) sum_temp (\S+) sum_nn_temp (\S+) diffs (\S+) (\S+) (\S+) (\S+) ponni_out (\S+) (\S+) (\S+) (\S+) validate_all (\d+)", out.stdout)
@@ -147,13 +150,14 @@ def test_cpp_inference_ponni_driver_equals_python_mirror(mw, tmp_path):
     v = [float(g) for g in m.groups()]
     assert int(v[0]) == steps and int(v[-1]) == 0
     surrogate = modules.Microphysics_Kessler_Surrogate()
+    surrogate.online = bool(online)
     coupler, dycore, micro, nudger = modules.make_supercell(nx, ny, nz, 1, 1.0e5, 1.0e5, 2.0e4, micro=surrogate, with_nudger=True)
     etime = 0.0
     for _ in range(steps):                                                      # inference_ponni.cpp:69-82
         dt = dycore.compute_time_step(coupler)
         dycore.time_step(coupler, dt)
         micro.time_step(coupler, dt)
-        d = micro.mean_diffs(coupler)                                           # (:266-269: inside the module's time_step in the reference)
+        d = micro._diffs if online else micro.mean_diffs(coupler)               # (:266-269: inside the module's time_step, BEFORE the overwrite)
         modules.sponge_layer(coupler, dt)
         nudger.nudge_to_column(coupler, dt)
         etime += dt
