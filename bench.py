@@ -75,6 +75,8 @@ def parse():
                     "3 = the order its GPU benchmark environment builds, build/machines/aws/aws_a100_gpu.env:21)")
     ap.add_argument("--storm-steps", type=int, default=2600, help="steps of the complete supercell loop before the 'storm' dycore timing of the "
                     "micro section (0 = skip)")
+    ap.add_argument("--mature-steps", type=int, default=12900, help="total steps of the same loop before the 'mature' dycore timing (12900 CFL steps = 3600 s "
+                    "simulated on the 400 x 400 x 100 grid; the reference's supercell_example runs 7200 s, input_euler3d.yaml:3); 0 or <= --storm-steps = skip")
     ap.add_argument("--no-micro", action="store_true", help="skip the Kessler / MLP / developed-state section after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 --pmc child processes that count HBM bytes / VALU "
                     "instructions of this very run's kernels (roofline.traffic, fp64_valu); the committed summary is quoted instead")
@@ -257,6 +259,42 @@ def calibration(torch, device, stage_cells):
     return out
 
 
+def rows_full_form(dycore):
+    """Fraction of (level, row) words of the last sub-cycle's stage maps Q1..Q3 (mw_debug_zero_maps) in which cloud or rain may be non-zero: the
+    rows whose iterations of the fused tracer kernel take the FULL form (the others neither load nor compute those two tracers).  None: no maps."""
+    import ctypes as C
+    import numpy as np
+    from miniweatherml_amd import capi
+    L = capi.lib()
+    dims = (C.c_int * 2)()
+    n = L.mw_debug_zero_maps(dycore.h, None, 0, dims)
+    if n <= 0:
+        return None
+    buf = np.empty(n, np.uint32)
+    if L.mw_debug_zero_maps(dycore.h, buf.ctypes.data_as(C.c_void_p), n, dims) != n:
+        return None
+    maps = buf.reshape(10, dims[0], dims[1])[:, :, 9:-9]
+    return float(((maps[1:4] & 0x6) != 0).mean())
+
+
+def cloud_extent(torch, dm, tile=58):
+    """Diagnostics of where cloud / rain are (what a finer map granularity could skip): the share of cells that hold any, and -- after growing that
+    set by the 9 cells per direction a sub-cycle can move a tracer -- the share of x rows and of 58-cell x tiles (one wavefront of the marching
+    kernels) that it touches."""
+    m = ((dm.get("cloud_liquid", True) != 0) | (dm.get("precip_liquid", True) != 0))[..., 0].to(torch.float32)
+    cells = float(m.mean())
+    g = m[None, None]
+    for ax, k in ((2, (19, 1, 1)), (3, (1, 19, 1)), (4, (1, 1, 19))):
+        g = torch.nn.functional.max_pool3d(g, kernel_size=k, stride=1, padding=tuple(9 if kk == 19 else 0 for kk in k))
+    g = g[0, 0]
+    nz, ny, nx = g.shape
+    rows = float((g.amax(dim=2) > 0).to(torch.float32).mean())
+    pad = (-nx) % tile
+    gt = torch.nn.functional.pad(g, (0, pad)).reshape(nz, ny, -1, tile)
+    tiles = float((gt.amax(dim=3) > 0).to(torch.float32).mean())
+    return {"cells_with_cloud_or_rain": cells, "rows_touched_grown_by_9": rows, "tiles58_touched_grown_by_9": tiles}
+
+
 def micro_section(torch, modules, coupler, dycore, micro, dt, a):
     """After the timed region: Kessler and the surrogate MLP on the bench grid (72 algorithmic bytes per cell each: 5 fields read, 4
     written) and the dycore on a state that HAS cloud and rain (the headline state has none, so its FCT limiter and y-face
@@ -331,6 +369,7 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
     patch_ms, patch_n = dycore.profile_get(1)
     dycore.profile(0)
     res["developed_ms_per_step"] = dev_ms
+    res["developed_rows_full_form"] = rows_full_form(dycore)
     res["value_developed"] = ncell / dev_ms * 1e3                # cell-updates/s on the developed state: read it next to "value"
     res["developed_state"] = {"state": "the bench state after the timed region + seeded cloud (2e-3) and rain (4e-4) blobs with sharp rims: "
                                        "FCT multipliers < 1 and a busy y-face correction pass", "cell_updates_per_s": ncell / dev_ms * 1e3,
@@ -367,6 +406,28 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
                         "max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()),
                         "rain_max": float(f2.get("precip_liquid").max())}
         res["value_storm"] = ncell / storm_ms * 1e3
+        res["storm"]["rows_full_form"] = rows_full_form(d2)
+        res["storm"]["extent"] = cloud_extent(torch, f2)
+        # ---- ... and on the MATURE storm: the same loop continued to a.mature_steps steps (3600 s simulated by default; the reference's
+        # supercell_example runs 7200 s): cloud and anvil cover a large share of the rows, where the data-dependent short-cuts stop helping
+        if a.mature_steps > a.storm_steps:
+            more = a.mature_steps - a.storm_steps
+            torch.cuda.synchronize()
+            t_loop = time.perf_counter()
+            for _ in range(more):
+                modules.supercell_step(c2, d2, m2, n2, dt2)
+            torch.cuda.synchronize()
+            loop2_s = time.perf_counter() - t_loop
+            mature_ms = timed(lambda: d2.time_step(c2, dt2), 10)
+            res["mature"] = {"state": "after %d steps (%.0f s simulated) of the complete supercell_example loop from the initial state" % (a.mature_steps, a.mature_steps * dt2),
+                             "ms_per_step": mature_ms, "cell_updates_per_s": ncell / mature_ms * 1e3,
+                             "max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()),
+                             "rain_max": float(f2.get("precip_liquid").max()), "rows_full_form": rows_full_form(d2), "extent": cloud_extent(torch, f2),
+                             "loop_ms_per_step_storm_to_mature": loop2_s / more * 1e3, "loop_cell_updates_per_s_storm_to_mature": ncell * more / loop2_s}
+            res["value_mature"] = ncell / mature_ms * 1e3
+            res["simulation_loop"]["to_mature"] = {"steps": a.mature_steps - 3, "seconds": loop_s + loop2_s,
+                                                   "ms_per_step": (loop_s + loop2_s) / (a.mature_steps - 3) * 1e3,
+                                                   "cell_updates_per_s": ncell * (a.mature_steps - 3) / (loop_s + loop2_s)}
     # ---- what the strip exchange costs beside the stencils, with the REAL transport, on this one GPU: rank 0's block of the 1 x 2, 2 x 2
     # and 4 x 2 decompositions the driver's N = 2, 4, 8 runs use, the built-in RCCL transport in its self-loop form (every peer is this rank
     # on a 1-rank communicator: mw_dycore_use_rccl_self; the block's own state tiled periodically, so the run is physical and -- tests --
@@ -588,6 +649,7 @@ def main():
     for _ in range(3):
         step()
     prof = {n: dycore.profile_get(i) for i, n in enumerate(KNAMES)}
+    prof_waits = (dycore.profile_get(10), dycore.profile_get(11))  # pipelined schedule of a decomposed block: the compute stream's waits for the state / tracer strips
     prof_dom = prof["xz_state"]                                  # the dominant kernel on its own: live, the three steps behind the timed region
     dycore.profile(0)
     # Outside the timed region: the same kernels with the two pipelines serialised, so that each kernel's duration is
@@ -604,6 +666,7 @@ def main():
         prof_excl = {n: dycore.profile_get(i) for i, n in enumerate(KNAMES)}
         dycore.profile(0)
         dycore.set_option("overlap", -1)
+    el_local = el
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -635,6 +698,54 @@ def main():
         dist.all_gather_object(infos, rccl)
     else:
         infos = [rccl]
+
+    # ---- self-diagnosis of a launched (torchrun) job, so that ONE run on an 8-GPU node says what the scaling is made of: every rank's
+    # own time per step, what the exchange costs on the critical path (the compute stream's waits for the strips, per RK stage), and the
+    # SAME block as a one-rank periodic domain timed on the same GPUs right behind the run -- efficiency computed inside the run
+    multi = None
+    if "WORLD_SIZE" in os.environ:
+        progress("multi-GPU diagnostics (per-rank times, strip waits, the one-rank block) ...")
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(local_rank), "ms_per_step": el_local / a.steps * 1e3,
+                "wait_state_strips_ms_per_stage": (prof_waits[0][0] / prof_waits[0][1]) if prof_waits[0][1] else 0.0,
+                "wait_tracer_strips_ms_per_stage": (prof_waits[1][0] / prof_waits[1][1]) if prof_waits[1][1] else 0.0,
+                "waits_recorded": int(prof_waits[0][1] + prof_waits[1][1]), "one_rank_block_ms_per_step": None}
+        if city is None and not a.full_loop and not a.strict:
+            try:
+                ny_l = coupler.get_ny()
+                c1, d1, _ = modules.make_supercell(a.nx, ny_l, a.nz, a.nens, dxy * a.nx, dxy * ny_l if ny_l > 1 else ylen, zlen, "supercell", device, ord=a.ord)
+                dt1 = d1.compute_time_step(c1)
+                for _ in range(max(1, a.warmup)):
+                    d1.time_step(c1, dt1)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.steps):
+                    d1.time_step(c1, dt1)
+                e1.record()
+                torch.cuda.synchronize()
+                mine["one_rank_block_ms_per_step"] = e0.elapsed_time(e1) / a.steps
+                mine["one_rank_block_path"] = d1.path()
+                del c1, d1
+                torch.cuda.empty_cache()
+            except Exception as e:                               # evidence, not the measurement
+                mine["one_rank_block_error"] = "%s: %s" % (type(e).__name__, e)
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        else:
+            per_rank = [mine]
+        blocks = [r["one_rank_block_ms_per_step"] for r in per_rank if r.get("one_rank_block_ms_per_step")]
+        multi = {"world": world, "rank_grid": "%dx%d" % (npx, npy), "halo_transport": transport,
+                 "rccl_ranks_seen": (infos[0] or {}).get("comm_ranks") if infos and infos[0] else None,
+                 "per_rank": per_rank,
+                 "ms_per_step_max_over_ranks": el / a.steps * 1e3,
+                 "one_rank_block_ms_per_step_mean": (sum(blocks) / len(blocks)) if blocks else None,
+                 "efficiency_in_run": ((sum(blocks) / len(blocks)) / (el / a.steps * 1e3)) if blocks else None,
+                 "what": "per_rank: every rank's own wall time per step over the timed region, the time its compute stream sat waiting for the state / "
+                         "tracer strips per RK stage (profile classes 10 / 11 of the three profiled steps behind the timed region; 0 without an exchange), "
+                         "and the same local block as a ONE-RANK periodic domain timed on that rank's GPU right after the run; efficiency_in_run = "
+                         "mean one-rank block time / the job's max-over-ranks time per step"}
+        progress("multi-GPU diagnostics done")
 
     two_streams = (sched["code"] & 3) == 1                       # (decided inside the library per time_step, not re-derived here)
     if rank == 0:
@@ -788,6 +899,7 @@ def main():
                          "fp64_valu": valu_side,
                          "calibration": cal,
                          "pipeline": {"alg_bytes_per_cell_update": 64 * V, "achieved": per_gpu * 64 * V / 1e9, "frac": per_gpu * 64 * V / 8.0e12}},
+            "multi_gpu": multi,
             "kernel_ms_per_step": {k: v[0] / 3.0 for k, v in prof.items()},
             "kernel_ms_per_step_exclusive": ({k: v[0] / 3.0 for k, v in prof_excl.items()} if prof_excl else None),
         }
@@ -799,6 +911,29 @@ def main():
             # the headline state is the benign one (cloud-free initial field): the same step on a developed storm, next to `value`
             out["config"]["value_storm"] = out.get("value_storm")
             out["config"]["value_developed"] = out.get("value_developed")
+            out["config"]["value_mature"] = out.get("value_mature")
+            # ---- the roofline figure, state by state (the headline state is the best case: cloud and rain identically zero).  frac = SURVEY.md
+            # 8(d)'s 32 V B per cell and stage with V = 8; frac_moved = the same with the variables that actually move: the six that are
+            # never skipped plus cloud and rain in the share of rows whose tracer iterations take the full form (the zero-row maps)
+            def _state(ms, rows):
+                if not ms:
+                    return None
+                st_s = ms / 3.0 * 1e-3
+                e = {"ms_per_step": ms, "cell_updates_per_s": ncells_local / ms * 1e3, "frac": 32.0 * V * ncells_local / st_s / 8.0e12, "rows_full_form": rows}
+                if rows is not None and V == 8:
+                    e["V_moved"] = 6.0 + 2.0 * rows
+                    e["frac_moved"] = 32.0 * (6.0 + 2.0 * rows) * ncells_local / st_s / 8.0e12
+                return e
+            out["roofline"]["frac_by_state"] = {
+                "cloud_free": _state(stage_ms * 3.0, 0.0 if out["config"]["zero_row_maps"] else 1.0),
+                "storm": _state((out.get("storm") or {}).get("ms_per_step"), (out.get("storm") or {}).get("rows_full_form")),
+                "developed": _state(out.get("developed_ms_per_step"), out.get("developed_rows_full_form")),
+                "mature": _state((out.get("mature") or {}).get("ms_per_step"), (out.get("mature") or {}).get("rows_full_form")),
+                "what": "frac = 32 V B (V = 8) x cells / (ms_per_step / 3) / 8 TB/s per state; rows_full_form = share of (level, row) words of the stage maps in "
+                        "which cloud or rain may be non-zero (the fused tracer kernel's FULL iterations); frac_moved prices only the variables that move: "
+                        "6 + 2 x rows_full_form.  cloud_free = the headline state (this line's roofline.frac); storm = 725 s into the run; developed = a seeded stress "
+                        "state with cloud / rain rims everywhere; mature = 3600 s into the run"}
+            out["roofline"]["state"] = "cloud_free (headline; see frac_by_state for the storm / developed / mature states)"
         if world == 1 and not a.no_cpu_baseline:
             progress("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)

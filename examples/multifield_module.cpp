@@ -126,8 +126,9 @@ int main(int argc, char **argv) {
     CHECK(hipDeviceSynchronize() == hipSuccess);
     CHECK(host(cdm.get<real const>("temp").data(), n) == clone_T);
     CHECK(host(dm.get<real const>("temp").data(), n) != clone_T);
-    // ... and a module can run on the clone: the sponge layer reads the clone's own fields through the clone's DataManager
+    // ... and modules can run on the clone: they reach the clone's own fields through the clone's DataManager and grid
     modules::sponge_layer(clone, dt);
+    modules::perturb_temperature(clone);                                                       // (adds the bubble once more: the clone's temp changes)
     CHECK(hipDeviceSynchronize() == hipSuccess);
     CHECK(host(cdm.get<real const>("temp").data(), n) != clone_T);
     CHECK(clone.get_data_manager_readonly().validate_all(false) == 0);

@@ -143,7 +143,8 @@ double mw_dycore_get_etime(mw_dycore_t h);   /* member etime, :55 */
  * of the unfused production path), 3 halo, 4 convert, 5 y stencil state, 6 y stencil tracers, 7 x/z tracer stage (fused:
  * fluxes + FCT + update), 8 one whole RK stage of the production path (first to last launch on the handle's stream; also
  * recorded by mw_dycore_profile(h,2)), 9 one whole mw_dycore_time_step (the only class of mw_dycore_profile(h,3): two events per time step
- * instead of twelve -- the per-stage pairs of mode 2 cost 1.5 % of the step they time). */
+ * instead of twelve -- the per-stage pairs of mode 2 cost 1.5 % of the step they time), 10 / 11 (mode 1, pipelined schedule of a decomposed
+ * block): the time the compute stream sits waiting for the stage's state strips / tracer strips -- what the exchange costs on the critical path. */
 /* Which schedule the last mw_dycore_time_step chose: 0 one stream, 1 two streams (state | tracer pipelines), 2 pipelined one-stream
  * schedule of a decomposed block; + 4: y faces of all variables in one launch (k_y_all); + 8: general (flux-materialising) kernels. */
 int  mw_dycore_schedule(mw_dycore_t h);

@@ -987,8 +987,8 @@ struct mw_dycore_s {
   long long nWE1 = 0, nSN1 = 0;                  // per variable
   // profiling
   int prof = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[10];      // kernel classes 0..7; 8 = one whole RK stage (all its launches); 9 = one whole time_step
-  size_t ev_used[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[12];      // kernel classes 0..7; 8 = one whole RK stage (all its launches); 9 = one whole time_step; 10 / 11 = the compute stream's waits for the state / tracer strips (pipelined schedule)
+  size_t ev_used[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   void (*xchg_free)(void *) = nullptr;       // set when the handle owns xchg_ctx (the built-in RCCL transport, mw_rccl.cpp)
   // balanced launch lists (pick_sched): per (columns, cells, resident workgroups) the Sched with its device table
   struct SchedEntry { const mw::Sched *dev; unsigned wgs; };
@@ -1936,7 +1936,8 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
   d->pipe_ready = false;
   if (conv && zero_rows_verify(d, 1, Sin, nullptr, false, c, ss)) return 1;
   if (launch_y_all(d, Sin, conv ? &c : nullptr, 1)) return 1;  // rows whose chunks read no halo row
-  MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0));           // state strips (+ the edge rows' y tendencies) of this stage's input
+  { ProfScope wait_scope(d, 10, ss);                           // (profile class 10: how long the compute stream sits in this wait)
+    MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[2], 0)); }        // state strips (+ the edge rows' y tendencies) of this stage's input
   if (!d->pipe_edge_done && launch_y_all(d, Sin, nullptr, 2)) return 1;   // first and last chunk
   d->pipe_edge_done = false;
   if (launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1;
@@ -1949,7 +1950,8 @@ static int rk_stage_pipe(mw_dycore_s *d, double *Sin, const double *Sn, double *
       MW_HIP(hipEventRecord(d->ev_pipe[2], xs));
     }
   }
-  MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[3], 0));           // tracer strips + the edge faces' tracer fluxes of this stage's input
+  { ProfScope wait_scope(d, 11, ss);                           // (profile class 11)
+    MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[3], 0)); }        // tracer strips + the edge faces' tracer fluxes of this stage's input
   if (STAGE == 1 && d->zr_on) {
     MW_HIP(hipStreamWaitEvent(ss, d->ev_pipe[4], 0)); zero_rows_stage(d, 1);
     if (maps_early && conv) zero_rows_conv(d, Sin, true, ss);     // (the slab's row map changes BEHIND the converting launch that reads it)
@@ -2310,7 +2312,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->tstream) (void)hipStreamDestroy(d->tstream);
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
-  for (int w = 0; w < 10; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (int w = 0; w < 12; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (auto &kv : d->sched_cache) if (kv.second.dev) (void)hipFree(const_cast<mw::Sched *>(kv.second.dev));
   delete d;
 }
@@ -2497,11 +2499,11 @@ int mw_dycore_profile(mw_dycore_t d, int enable) {
   if (!d) MW_FAIL("null handle");
   MW_HIP(hipStreamSynchronize(d->stream));
   d->prof = enable;
-  for (int w = 0; w < 10; w++) d->ev_used[w] = 0;
+  for (int w = 0; w < 12; w++) d->ev_used[w] = 0;
   return 0;
 }
 int mw_dycore_profile_get(mw_dycore_t d, int which, double *total_ms, long long *launches) {
-  if (!d || which < 0 || which > 9) MW_FAIL("bad argument");
+  if (!d || which < 0 || which > 11) MW_FAIL("bad argument");
   MW_HIP(hipStreamSynchronize(d->stream));
   double tot = 0;
   for (size_t i = 0; i < d->ev_used[which]; i++) { float ms = 0; MW_HIP(hipEventElapsedTime(&ms, d->ev[which][i].first, d->ev[which][i].second)); tot += ms; }

@@ -550,7 +550,12 @@ __global__ __launch_bounds__(256) void k_zero_verify(DyP p, CouplerPtrs c, const
     bool bad0 = false, bad1 = false;
     for (int kk = max(k - 3, 0); kk <= min(k + 2, p.nz - 1); kk++) bad0 = bad0 || ((in_nz & ~p.zq[(long long)kk * ld + j + MW_ZR_HALO]) != 0u);
     const unsigned *qy = p.zq + 6 * msz;
-    for (int dj = -MW_ZR_REACH; dj <= MW_ZR_REACH; dj++) bad1 = bad1 || ((in_nz & ~qy[(long long)k * ld + j + dj + MW_ZR_HALO]) != 0u);
+    // (the derived maps hold the block's own rows only -- the kernels index them behind wrap_row: rows beyond a decomposed y edge belong to
+    //  the neighbour's maps and are not checked here)
+    for (int dj = -MW_ZR_REACH; dj <= MW_ZR_REACH; dj++) {
+      const int jj = wrap_row(p, j + dj);
+      if (jj >= 0 && jj < p.ny) bad1 = bad1 || ((in_nz & ~qy[(long long)k * ld + jj + MW_ZR_HALO]) != 0u);
+    }
     if (bad0) atomicAdd(&viol[0], 1ull);
     if (bad1) atomicAdd(&viol[1], 1ull);
   }
@@ -563,7 +568,8 @@ __global__ __launch_bounds__(256) void k_zero_verify(DyP p, CouplerPtrs c, const
   }
   if (kz_nz && p.zqk && p.zq) {
     const unsigned *qy = p.zq + 6 * msz;
-    if (kz_nz & ~qy[(long long)k * ld + j - MW_ZR_REACH + MW_ZR_HALO] & ~p.zqk[(long long)k * ld + j + MW_ZR_HALO]) atomicAdd(&viol[3], 1ull);
+    const int jl = wrap_row(p, j - MW_ZR_REACH);                 // the iteration that converts row j; beyond a decomposed edge: never lean
+    if (jl >= 0 && jl < p.ny && (kz_nz & ~qy[(long long)k * ld + jl + MW_ZR_HALO] & ~p.zqk[(long long)k * ld + j + MW_ZR_HALO])) atomicAdd(&viol[3], 1ull);
   }
 }
 

@@ -66,3 +66,12 @@ def test_bench_config4_block_under_the_torchrun_launcher():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["dtype"] == "f64"
     assert "256x512x128 nens=4" in d["config"]["workload"] and d["config"]["baseline_config"] == "configs[3] per-GPU block"
     assert d["value"] > 1e8                                     # a real run (the block takes ~28 ms per step)
+    # the self-diagnosis of a launched job (round 6): what a first run on an 8-GPU node must say about itself
+    m = d["multi_gpu"]
+    assert m["world"] == 1 and m["rank_grid"] == "1x1" and len(m["per_rank"]) == 1
+    r0 = m["per_rank"][0]
+    for k in ("rank", "device", "ms_per_step", "wait_state_strips_ms_per_stage", "wait_tracer_strips_ms_per_stage", "one_rank_block_ms_per_step"):
+        assert k in r0, k
+    assert r0["ms_per_step"] > 1.0 and r0["one_rank_block_ms_per_step"] > 1.0
+    assert 0.5 < m["efficiency_in_run"] < 1.5                   # one rank: the block IS the job
+    assert "rccl_ranks_seen" in m and "ms_per_step_max_over_ranks" in m
