@@ -17,7 +17,7 @@ int main(int argc, char **argv) {
   int nsteps = atoi(argv[8]);
   std::string init_data = argc > 9 ? argv[9] : "supercell";
   int mode = argc > 10 ? atoi(argv[10]) : 0;
-  bool run_micro = mode != 0, full_loop = mode == 2;
+  bool run_micro = mode != 0, full_loop = mode >= 2, defer = mode == 3;       // (3: the nudger's increments ride on the next dycore step's conversion)
   try {
     core::Coupler coupler;
     coupler.set_option<std::string>("out_prefix", "test");
@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
       real dtphys = dycore.compute_time_step(coupler);
       dycore.time_step(coupler, dtphys);
       if (run_micro) micro.time_step(coupler, dtphys);                                    // :74
-      if (full_loop) { modules::sponge_layer(coupler, dtphys); column_nudger.nudge_to_column(coupler, dtphys); }   // :75-76
+      if (full_loop) { modules::sponge_layer(coupler, dtphys); column_nudger.nudge_to_column(coupler, dtphys, nullptr, nullptr, defer ? &dycore : nullptr); }   // :75-76
       etime += dtphys;
     }
     (void)hipDeviceSynchronize();

@@ -310,6 +310,20 @@ int  mw_column_average(const mw_grid_t *g, const double *const *state5, double *
 /* ColumnNudger::nudge_to_column(coupler, dt), :39-66: state += dt (column - column_average(state)) / 900. */
 int  mw_nudge_to_column(const mw_grid_t *g, double *const *state5, const double *column, double dt, void *workspace,
                         mw_allreduce_fn allreduce, void *ctx, void *stream);
+/* The same, DEFERRED (round 6; no reference counterpart -- the reference's nudge_to_column is two passes): the horizontal sums are taken and the
+ * increments dt (column - average) / 900 are PARKED in the dycore handle instead of being added by a second pass over the five fields.  The
+ * handle's next mw_dycore_time_step adds them while its conversion loads the coupler's arrays (the same rounded addition: results are bit for
+ * bit those of mw_nudge_to_column), on the one-rank production path of the supercell configuration; any other path, and
+ * mw_dycore_compute_tendencies, applies them with a pass first.  Between this call and that time step the five arrays do NOT hold the nudged
+ * values: whoever reads them must call mw_dycore_flush_pending first (the Coupler mirrors do so inside DataManager::get).  The grid is the
+ * handle's; sums and increments are ordered on the handle's stream.  state5: density_dry, uvel, vvel, temp, water_vapor -- the arrays later
+ * handed to mw_dycore_time_step. */
+int  mw_nudge_to_column_deferred(mw_dycore_t h, double *const *state5, const double *column, double dt, void *workspace,
+                                 mw_allreduce_fn allreduce, void *ctx);
+/* Applies parked increments now (a no-op when there are none). */
+int  mw_dycore_flush_pending(mw_dycore_t h);
+/* 1 while increments are parked; out2 (may be NULL): how often parked increments rode on a conversion / were applied by a pass, since create. */
+int  mw_dycore_pending(mw_dycore_t h, unsigned long long *out2);
 
 /* ---- ponni surrogate MLP -------------------------------------------------------------------------- */
 /* NN block of custom_modules::Microphysics_Kessler::time_step,

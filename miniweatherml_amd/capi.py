@@ -106,6 +106,9 @@ SYMBOLS = {
     "mw_column_average": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_void_p]),
     "mw_nudge_to_column": (C.c_int, [C.POINTER(Grid), C.POINTER(C.c_void_p), C.c_void_p, C.c_double, C.c_void_p, ALLREDUCE_FN,
                                      C.c_void_p, C.c_void_p]),
+    "mw_nudge_to_column_deferred": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_double, C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "mw_dycore_flush_pending": (C.c_int, [C.c_void_p]),
+    "mw_dycore_pending": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "mw_nc_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_char_p, C.c_int, C.c_longlong, C.c_longlong]),
     "mw_nc_def_dim": (C.c_int, [C.c_void_p, C.c_char_p, C.c_longlong, C.POINTER(C.c_int)]),
     "mw_nc_def_var": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -26,6 +26,13 @@ class DataManager:
         self.device = device
         self.entries = {}
         self.dimensions = {}
+        # callables run in front of every access to an entry (get, the validators, clone_into): a module that keeps part of a field's value parked
+        # elsewhere -- ColumnNudger's deferred increments, modules.py -- registers its flush here, so that whoever LOOKS at a field sees all of it
+        self.before_access = []
+
+    def _sync_entries(self):
+        for fn in self.before_access:
+            fn()
 
     def add_dimension(self, name, length):                      # DataManager.h:106-120
         if name in self.dimensions and self.dimensions[name] != length:
@@ -79,6 +86,7 @@ class DataManager:
     # (mw_validate_f64 / _f32: counts and the first flat index of NaN / inf / negative elements).  A failed check prints the
     # reference's warning (first offending index) to stderr and ends the run when die_on_failed_check.  Returns the findings. ----
     def _scan(self, name):
+        self._sync_entries()
         e = self._find_entry_or_error(name)
         t = e["data"]
         if t.dtype not in (torch.float64, torch.float32):       # integer / bool entries: no NaN / inf; negatives only for signed ints
@@ -130,6 +138,7 @@ class DataManager:
     def get(self, name, readonly=False):                        # :246-286
         if name not in self.entries:
             endrun("ERROR: Could not find entry name: " + name)
+        self._sync_entries()
         if not readonly:
             self.entries[name]["dirty"] = True
         return self.entries[name]["data"]
@@ -142,6 +151,7 @@ class DataManager:
         return self.get(name, readonly).view(-1)
 
     def clone_into(self, other):                                # :79-103
+        self._sync_entries()
         other.dimensions = dict(self.dimensions)
         other.entries = {k: dict(v, data=v["data"].clone()) for k, v in self.entries.items()}
 

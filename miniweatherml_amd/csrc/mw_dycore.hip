@@ -65,6 +65,9 @@ struct DyP {                      // kernel parameter block (by value)
   const unsigned *zqk;            // ... the converting y launch: the rows of the slab it writes that hold zeros already
   const unsigned *zqp, *zqc;      // ... "the row an iteration stores to holds zeros already": the previous sub-cycle's map of this stage / the coupler's rows (mw_march.h)
   int zq_ld;
+  // parked column increments (mw_nudge_to_column_deferred): inc[(l * nz + k) * nens + e] for l = density_dry, uvel, vvel, temp, water_vapor, added to
+  // the coupler's values while the converting y launch loads them; nullptr = none
+  const double *pinc;
   unsigned pos_mask, mass_mask;
   double dx, dy, dz, rdx, rdy, rdz, C0, gamma, grav, fcor, R_d, R_v;
   const double *hyc, *hytc, *hye, *hyte;       // device (nz,nens) / (nz+1,nens)
@@ -893,6 +896,28 @@ __global__ __launch_bounds__(256) void k_member_to_fused(DyP p, const double *__
   dst[t] = src[(long long)e * (n / p.nens) + r];
 }
 
+// ColumnNudger's increment (column_nudging.h:62-65): dt (column - average) / time_scale, one number per (field, level, member) -- the
+// reference's expression, IEEE division, no contraction (= k_nudge_apply in mw_column.hip).
+__global__ __launch_bounds__(256) void k_nudge_increments(const double *__restrict__ column, const double *__restrict__ avg, double dt, long long n, double *__restrict__ inc) {
+#pragma clang fp contract(off)
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const double time_scale = 900;
+  if (t < n) inc[t] = dt * (column[t] - avg[t]) / time_scale;
+}
+// ... and parked increments applied by a pass after all (mw_dycore_flush_pending: somebody wants to see the fields before the next time step,
+// or the next time step runs a path whose conversion does not take them along): state(l,k,j,i,e) += inc(l,k,e), the same rounded addition.
+struct Ptr5 { double *f[5]; };
+__global__ __launch_bounds__(256) void k_apply_pending(Ptr5 fp, int nz, long long ncell_lev, int nens, const double *__restrict__ inc) {
+#pragma clang fp contract(off)
+  const int k = blockIdx.y, l = blockIdx.z;
+  const long long n = ncell_lev * nens;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    const int e = (int)(t % nens);
+    double *q = fp.f[l] + (long long)k * n;
+    q[t] = q[t] + inc[((long long)l * nz + k) * nens + e];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_calib_copy(const double *__restrict__ in, double *__restrict__ out, long long n) {
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = in[i];
@@ -970,6 +995,8 @@ struct mw_dycore_s {
   int zr_cur = 0;                          // ... double-buffered: set zr_cur belongs to the running sub-cycle, the other one to the one before
   bool zr_prev_ok = false, zr_prev_use = false;   // the other set describes what slabs S1 / S2 hold now (the sub-cycle before ran with maps, nothing else wrote the slabs since) / ... and is handed to this sub-cycle's kernels
   unsigned long long *zviol = nullptr;     // option zero_verify: four violation counters (k_zero_verify)
+  double *pinc = nullptr; bool pinc_on = false; double *pinc_fields[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // parked column increments (mw_nudge_to_column_deferred) and the five arrays they belong to
+  unsigned long long pinc_lazy = 0, pinc_eager = 0;             // how often parked increments rode on the conversion / were applied by a pass
   unsigned *zr = nullptr; long long zr_msz = 0; bool zr_on = false;   // zero-row maps (M0 and the six of k_zero_dilate) of the running sub-cycle (mw_march.h: k_zero_rows), zr_msz words each
   int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows (see DyP::hypk)
@@ -1020,6 +1047,7 @@ static void fill_params(mw_dycore_s *d) {
   p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
   p.zero_skip = d->o.zero_skip;
   p.zq = p.zqp = p.zqc = p.zqk = nullptr; p.zq_ld = 0;          // (set per RK stage by zero_rows_stage / zero_rows_conv)
+  p.pinc = nullptr;                                             // (set by mw_dycore_time_step when parked increments ride on the conversion)
   p.pos_mask = 0; p.mass_mask = 0;
   for (int t = 0; t < g.num_tracers; t++) { if (d->pos[t]) p.pos_mask |= 1u << t; if (d->adds[t]) p.mass_mask |= 1u << t; }
   p.dx = g.xlen / g.nx_glob; p.dy = g.ylen / g.ny_glob; p.dz = g.zlen / g.nz;        // coupler.h:262-268
@@ -2305,6 +2333,7 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->zr) (void)hipFree(d->zr);
   if (d->zrx) (void)hipFree(d->zrx);
   if (d->zviol) (void)hipFree(d->zviol);
+  if (d->pinc) (void)hipFree(d->pinc);
   for (int b = 0; b < 2; b++) for (int a = 0; a < 3; a++) { if (d->M[b][a]) (void)hipFree(d->M[b][a]); if (d->UP[b][a]) (void)hipFree(d->UP[b][a]); }
   for (int i = 0; i < 8; i++) { if (d->ev_state[i]) (void)hipEventDestroy(d->ev_state[i]); if (d->ev_tr[i]) (void)hipEventDestroy(d->ev_tr[i]); }
   if (d->ev_misc) (void)hipEventDestroy(d->ev_misc);
@@ -2512,6 +2541,50 @@ int mw_dycore_profile_get(mw_dycore_t d, int which, double *total_ms, long long 
   return 0;
 }
 
+// ---- parked column increments (round 6) ---------------------------------------------------------------------------------------------
+// ColumnNudger::nudge_to_column is two passes over five fields: the horizontal sums, and `state += dt (column - avg) / 900` (1.3 GB read and
+// written again on config 2, 0.25 ms of a 5.4 ms loop iteration).  The second pass adds ONE number per (field, level) -- and the next thing the
+// reference's loop does with those five arrays is dycore.time_step, whose conversion D1 reads them once and whose D13 overwrites them.  The
+// deferred form parks the increments in the dycore handle instead; the next mw_dycore_time_step adds them while its converting y launch
+// loads the coupler's values (the same rounded addition, so the result is bit for bit the eager one's) and the pass disappears.  Anybody who
+// wants to SEE the fields in between calls mw_dycore_flush_pending first (the Coupler mirrors do that inside DataManager::get); a time step
+// on a path whose conversion does not take increments along (strict / general kernels, decomposed blocks, members, 2-D) flushes by itself.
+static int flush_pending(mw_dycore_s *d) {
+  if (!d->pinc_on) return 0;
+  const DyP &p = d->p;
+  Ptr5 fp; for (int l = 0; l < 5; l++) fp.f[l] = d->pinc_fields[l];
+  const long long ncell_lev = (long long)p.ny * p.nx;
+  const unsigned nb = (unsigned)std::min<long long>((ncell_lev * p.nens + 256ll * 8 - 1) / (256ll * 8), 65535);
+  MW_KLAUNCH(k_apply_pending, dim3(nb, (unsigned)p.nz, 5u), dim3(256), 0, d->stream, fp, p.nz, ncell_lev, p.nens, d->pinc);
+  MW_LAUNCH_CHECK();
+  d->pinc_on = false; d->pinc_eager++;
+  return 0;
+}
+int mw_dycore_flush_pending(mw_dycore_t d) { if (!d) MW_FAIL("null handle"); fill_params(d); return flush_pending(d); }
+/* 1: increments are parked; out2 (may be NULL): how often parked increments rode on a conversion / were applied by a pass, since create */
+int mw_dycore_pending(mw_dycore_t d, unsigned long long *out2) {
+  if (!d) return 0;
+  if (out2) { out2[0] = d->pinc_lazy; out2[1] = d->pinc_eager; }
+  return d->pinc_on ? 1 : 0;
+}
+int mw_nudge_to_column_deferred(mw_dycore_t d, double *const *state5, const double *column, double dt, void *workspace, mw_allreduce_fn allreduce,
+                                void *ctx) {
+  if (!d || !state5 || !column || !workspace) MW_FAIL("nudge_to_column_deferred: null argument");
+  for (int l = 0; l < 5; l++) if (!state5[l]) MW_FAIL("nudge_to_column_deferred: null field");
+  fill_params(d);
+  if (flush_pending(d)) return 1;                              // (increments of an earlier call that no time step has consumed: they count in the averages)
+  const DyP &p = d->p;
+  const long long n = 5ll * p.nz * p.nens;
+  if (!d->pinc) MW_HIP(hipMalloc(&d->pinc, (size_t)n * sizeof(double)));
+  double *avg = (double *)workspace, *rest = avg + n;
+  if (mw_column_average(&d->g, state5, avg, rest, allreduce, ctx, d->stream)) return 1;      // (ordered on the handle's stream, like the time step that will use them)
+  MW_KLAUNCH(k_nudge_increments, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, column, avg, dt, n, d->pinc);
+  MW_LAUNCH_CHECK();
+  for (int l = 0; l < 5; l++) d->pinc_fields[l] = state5[l];
+  d->pinc_on = true;
+  return 0;
+}
+
 // ---- time_step (:81-198) -------------------------------------------------------------------------------
 int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, double *w, double *temp, double *const *tracers,
                         double dt_phys) {
@@ -2584,6 +2657,16 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
       if (fused_state_ok(d)) d->path += " fused_state";
     } else d->path += p.nens == 1 ? " nens1" : " fused_members";
     if (d->xchg) d->path += " transport"; }
+  if (d->pinc_on) {
+    // parked column increments: they ride on the conversion where it happens inside k_y_all<true, K = 1> of a one-rank handle, and belong to
+    // exactly the arrays this call was handed; anything else applies them with a pass first
+    const bool same = c.rho_d == d->pinc_fields[0] && c.u == d->pinc_fields[1] && c.v == d->pinc_fields[2] && c.temp == d->pinc_fields[3] &&
+                      p.idWV >= 0 && p.idWV < p.nt && c.tr[p.idWV] == d->pinc_fields[4];
+    const bool lazy = same && march && d->conv_pending && !d->pipe && !d->overlap && !d->member_major && p.nens == 1 && marching_config(d, d->p) == 1 &&
+                      y_all_ok(d) && d->o.y_all_conv && !fused_state_ok(d);
+    if (lazy) { d->p.pinc = d->pinc; d->pinc_on = false; d->pinc_lazy++; }
+    else if (flush_pending(d)) return 1;
+  }
   d->pre_lo = d->pre_hi = 0;
   d->entry_marked = false;
   if (pipe_conv && d->ev_pipe[6]) { MW_HIP(hipEventRecord(d->ev_pipe[6], d->stream)); d->entry_marked = true; }   // the coupler's arrays are ready here (see rk_stage_pipe: the row scan runs beside the strip conversion)
@@ -2660,6 +2743,7 @@ int mw_dycore_compute_tendencies(mw_dycore_t d, const double *rho_d, const doubl
   fill_params(d);
   const DyP &p = d->p;
   if (need_exchange(d) || check_halo_fit(d)) return 1;
+  if (flush_pending(d)) return 1;
   dim3 cgrid = plane_grid((long long)p.ny * p.nx * p.nens, p.nz);
   MW_KLAUNCH(k_coupler_to_state, cgrid, dim3(256), 0, d->stream, p, c, d->S0); MW_LAUNCH_CHECK();
   if (halo_fill(d, d->S0)) return 1;

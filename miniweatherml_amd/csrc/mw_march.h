@@ -897,6 +897,10 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   //  Storing the same values twice was only benign as long as two instantiations of the conversion produce the same bits.)
   const int NXI = p.nx * p.nens;
   __shared__ double lds_fprev[CONV ? 5 : 1][CONV ? 256 : 1];
+  // parked column increments (DyP::pinc, mw_nudge_to_column_deferred): the thread's five numbers -- its level's increments of density_dry, uvel,
+  // vvel, temp and water vapour -- in a private LDS slot, read back where a row is converted (no registers to spare for them across the loop)
+  __shared__ double lds_inc[(CONV && !MT) ? 5 : 1][(CONV && !MT) ? 256 : 1];
+  const bool pinc_on = CONV && !MT && p.pinc != nullptr;          // (wave-uniform)
   int mt_sub = 0;
   if (MT) {                                                      // (p = one member's view: nens = 1, cst = the member count)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), em = wv & (mo.n - 1);
@@ -918,6 +922,10 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   const int e = ie % p.nens;
   const double *hp = p.hypk + (long long)(k * p.nens + e) * 8;
   const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
+  if (pinc_on) {
+#pragma unroll
+    for (int l = 0; l < 5; l++) lds_inc[l][threadIdx.x] = p.pinc[((long long)l * p.nz + k) * p.nens + e];
+  }
   const double *col = S + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;      // row j at col + (j+HY)*sJ
   double *fy = FY + (long long)k * p.fyK + ie;                                                // tracer v, face j at fy + (5+v)*fyV + j*fyJ
   double *ty = tendY + ((long long)k * p.ny) * NXI + ie;                                      // row j at ty + j*NXI (+ l*nC)
@@ -930,6 +938,13 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   const int sjb_ = (pre_on_ && (ie < p.HX * p.nens || ie >= NXI - p.HX * p.nens)) ? sja_ : (pre_on_ ? min(jb, pre_hi) : jb);
 #define MW_ROW_CI(r) cpl(p, ((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
   constexpr unsigned VANM = (K == 1) ? (((1u << T) - 1u) & ~1u) : ((1u << T) - 1u);        // (= tracer_may_vanish<K>)
+  /* the coupler's value + its parked column increment: the addition ColumnNudger's second pass would have stored (rounded once, no contraction) */
+#define MW_ROW_NUDGE(raw)                                                                                             \
+  if (pinc_on) {                                                                                                      \
+    raw.rho_d = __dadd_rn(raw.rho_d, lds_inc[0][threadIdx.x]); raw.u = __dadd_rn(raw.u, lds_inc[1][threadIdx.x]);      \
+    raw.v = __dadd_rn(raw.v, lds_inc[2][threadIdx.x]); raw.temp = __dadd_rn(raw.temp, lds_inc[3][threadIdx.x]);        \
+    _Pragma("unroll") for (int tr_ = 0; tr_ < T; tr_++) if (Cf<K>::is_wv(p, tr_)) raw.tr[tr_] = __dadd_rn(raw.tr[tr_], lds_inc[4][threadIdx.x]); \
+  }
   /* (skipv: wave-uniform -- the tracers that can vanish are zero in this row AND the slab row holds zeros already, see ym_ss) */
 #define MW_ROW_FINISH(raw, r, out, skipv)                                                                             \
   { double inv_den_;                                                                                                  \
@@ -948,8 +963,9 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
     for (int l = 0; l < 5; l++) lds_fprev[l][threadIdx.x] = 0;
 #pragma unroll
     for (int s = 0; s < ORD; s++) {
-      const CouplerCell raw = load_coupler_cell<K>(p, c, MW_ROW_CI(ja - 1 - HS + s));
+      CouplerCell raw = load_coupler_cell<K>(p, c, MW_ROW_CI(ja - 1 - HS + s));
       double r8[NV];
+      MW_ROW_NUDGE(raw)
       MW_ROW_FINISH(raw, ja - 1 - HS + s, r8, false)
 #pragma unroll
       for (int v = 0; v < NV; v++) w[v][s] = r8[v];
@@ -1098,7 +1114,7 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
 #else
     constexpr bool ss_skip = false;
 #endif
-    if (CONV) MW_ROW_FINISH(raw, jn, nxt, ss_skip)
+    if (CONV) { MW_ROW_NUDGE(raw) MW_ROW_FINISH(raw, jn, nxt, ss_skip) }
 #if MW_ZERO_SKIP
 #pragma unroll
     for (int v = 0; v < T; v++) if (tracer_may_vanish<K>(p, v)) zm[v] = (zm[v] >> 1) | ((__any(nxt[5 + v] != 0.0) ? 1u : 0u) << (ORD - 1));
@@ -1113,6 +1129,7 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   }
 #undef MW_ROW_CI
 #undef MW_ROW_FINISH
+#undef MW_ROW_NUDGE
 }
 
 // ---------------------------------------------------------------------------------------------------------------

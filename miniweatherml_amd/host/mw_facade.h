@@ -22,7 +22,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <typeinfo>
@@ -119,12 +121,17 @@ class DataManager {                                                   // model/c
                  std::vector<std::string> dim_names; bool positive, dirty; };
   std::vector<Entry> entries;
   std::map<std::string, int> dimensions;
+  // run in front of every access to an entry's data (get, the validators, clone_into): a module that keeps part of a field's value parked
+  // elsewhere -- ColumnNudger's deferred increments -- registers its flush here, so that whoever LOOKS at a field sees all of it
+  std::vector<std::function<void()>> before_access;
+  void sync_entries() const { for (auto &fn : before_access) fn(); }
   int find_entry(const std::string &n) const { for (size_t i = 0; i < entries.size(); i++) if (entries[i].name == n) return (int)i; return -1; }
  public:
   DataManager() = default;
   DataManager(const DataManager &) = delete;
   ~DataManager() { finalize(); }
   void finalize() { for (auto &e : entries) if (e.ptr) (void)hipFree(e.ptr); entries.clear(); dimensions.clear(); }   // :571-578
+  void add_access_hook(std::function<void()> fn) { before_access.push_back(std::move(fn)); }
   void add_dimension(const std::string &name, int len) {                                                       // :106-120
     auto it = dimensions.find(name);
     if (it != dimensions.end() && it->second != len) endrun("ERROR: Attempting to add a dimension of the same name as an existing dimension but not the same size");
@@ -146,6 +153,7 @@ class DataManager {                                                   // model/c
   template <class T> DeviceView<T> get(const std::string &name) {                                              // :246-286
     int id = find_entry(name);
     if (id == -1) endrun("ERROR: Could not find entry name: " + name);
+    sync_entries();
     typedef typename std::remove_cv<T>::type TNC;
     if (entries[id].type_hash != typeid(TNC).hash_code()) endrun("ERROR: Requested Array type does not match entry type");   // :256-261
     if (!std::is_const<T>::value) entries[id].dirty = true;                                                     // :275
@@ -154,6 +162,7 @@ class DataManager {                                                   // model/c
   template <class T, int N> FieldView<T, N> get(const std::string &name) { return get<T>(name).template as<N>(); }   // the reference's spelling get<T,N>(name): rank checked (:263-268)
   // :79-103: an independent copy of every entry (own allocation, device-to-device copy), dimensions included
   void clone_into(DataManager &dm) const {
+    sync_entries();
     dm.dimensions = dimensions;
     for (auto &e : entries) {
       Entry loc = e;
@@ -184,6 +193,7 @@ class DataManager {                                                   // model/c
   // Entries of other types (bool, integers) hold no NaN / inf; their sign check is not needed by any shipped module.
  private:
   bool scan(int id, long long *r) const {
+    sync_entries();
     const Entry &e = entries[id];
     if (e.type_hash == typeid(double).hash_code()) { mw_check(mw_validate_f64((const double *)e.ptr, (long long)(e.bytes / sizeof(double)), r, nullptr)); return true; }
     if (e.type_hash == typeid(float).hash_code())  { mw_check(mw_validate_f32((const float *)e.ptr, (long long)(e.bytes / sizeof(float)), r, nullptr)); return true; }
@@ -327,7 +337,9 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
   int static constexpr idR = 0, idU = 1, idV = 2, idW = 3, idT = 4;
   real etime = 0, out_freq = -1;  int num_out = 0, idWV = 0;
   std::vector<real> hy_dens_cells, hy_dens_theta_cells, hy_dens_edges, hy_dens_theta_edges;     // (nz[,+1],nens), host copies
-  ~Dynamics_Euler_Stratified_WenoFV() { if (h) mw_dycore_destroy(h); }
+  ~Dynamics_Euler_Stratified_WenoFV() { *self_token = nullptr; if (h) mw_dycore_destroy(h); }
+  Dynamics_Euler_Stratified_WenoFV() = default;
+  Dynamics_Euler_Stratified_WenoFV(const Dynamics_Euler_Stratified_WenoFV &) = delete;       // (owns the handle)
   real compute_time_step(core::Coupler const &coupler) const { return mw_dycore_compute_time_step(&coupler.grid); }     // :70-77
   void init(core::Coupler &coupler) {                                 // :1197-1683
     mw_grid_t &g = coupler.grid;
@@ -437,6 +449,10 @@ class Dynamics_Euler_Stratified_WenoFV {                              // model/m
     mw_check(mw_nc_close(nc));
   }
   mw_dycore_t handle() const { return h; }
+  // column increments that ColumnNudger::nudge_to_column(..., &dycore) parked in the handle: applied now (a no-op when there are none)
+  void flush_pending() { if (h) mw_check(mw_dycore_flush_pending(h)); }
+  bool flush_hook_installed = false;
+  std::shared_ptr<Dynamics_Euler_Stratified_WenoFV *> self_token = std::make_shared<Dynamics_Euler_Stratified_WenoFV *>(this);   // (cleared by the destructor: a hook that outlives the module does nothing)
   // Decomposed runs (coupler.distribute_mpi_and_allocate_coupled_state(..., nranks, myrank)): the reference exchanges halos with
   // MPI_Isend / Irecv (:641-723); here every rank joins one RCCL communicator -- id128: the 128 bytes of mw_rccl_unique_id() made by
   // rank 0 and handed to the other ranks by whatever launched them (a file, a pipe, an environment variable).  Afterwards
@@ -487,10 +503,21 @@ class ColumnNudger {                                                  // model/m
     ensure(coupler); auto s = state(coupler);
     mw_check(mw_column_average(&coupler.grid, s.data(), column, ws, ar, ctx, nullptr));
   }
-  void nudge_to_column(core::Coupler &coupler, real dt, mw_allreduce_fn ar = nullptr, void *ctx = nullptr) {   // :39-66
+  // defer_to = the dycore module (round 6, no reference counterpart): the second pass -- state += dt (column - average) / 900 -- is not run; the
+  // increments are parked in the dycore handle and its next time_step adds them while it converts the coupler's fields (bit for bit the same
+  // result).  Whoever reads a field through the DataManager in between triggers the pass after all (DataManager::add_access_hook).
+  void nudge_to_column(core::Coupler &coupler, real dt, mw_allreduce_fn ar = nullptr, void *ctx = nullptr,
+                       Dynamics_Euler_Stratified_WenoFV *defer_to = nullptr) {                                 // :39-66
     if (!column) endrun("ColumnNudger::nudge_to_column before set_column");
     auto s = state(coupler);
-    mw_check(mw_nudge_to_column(&coupler.grid, s.data(), column, dt, ws, ar, ctx, nullptr));
+    if (defer_to) {
+      if (!defer_to->flush_hook_installed) {
+        auto tok = defer_to->self_token;
+        coupler.get_data_manager_readwrite().add_access_hook([tok]() { if (*tok) (*tok)->flush_pending(); });
+        defer_to->flush_hook_installed = true;
+      }
+      mw_check(mw_nudge_to_column_deferred(defer_to->handle(), s.data(), column, dt, ws, ar, ctx));
+    } else mw_check(mw_nudge_to_column(&coupler.grid, s.data(), column, dt, ws, ar, ctx, nullptr));
   }
 };
 

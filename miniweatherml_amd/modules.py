@@ -208,6 +208,16 @@ class Dynamics_Euler_Stratified_WenoFV:
         check(capi.lib().mw_dycore_get_option(self.h, key.encode(), C.byref(v)))
         return v.value
 
+    def flush_pending(self):
+        """Applies column increments that ColumnNudger.nudge_to_column(..., defer_to=self) parked in this handle (mw_dycore_flush_pending); a
+        no-op when there are none.  The coupler's DataManager calls it in front of every field access."""
+        check(capi.lib().mw_dycore_flush_pending(self.h))
+
+    def pending(self):
+        """(parked now, [rode on a conversion, applied by a pass]) -- mw_dycore_pending."""
+        out = (C.c_ulonglong * 2)()
+        return bool(capi.lib().mw_dycore_pending(self.h, out)), [int(out[0]), int(out[1])]
+
     def zero_violations(self):
         """(total, [4]) of option zero_verify's counters (mw_debug_zero_violations; a test aid): claims of the zero-row maps that the data
         contradicted; total = -1 when the option never ran on this handle."""
@@ -532,14 +542,28 @@ class ColumnNudger:
             check(capi.lib().mw_column_average(C.byref(coupler.grid), _field_ptr_array(self._state(coupler)), _ptr(self.column), _ptr(ws),
                                                fn, ctx, _stream_ptr(coupler.device)))
 
-    def nudge_to_column(self, coupler, dt):                                    # :39-66
+    def nudge_to_column(self, coupler, dt, defer_to=None):                     # :39-66
+        """defer_to = the dycore module (round 6, no reference counterpart): the second pass -- state += dt (column - average) / 900 -- is not
+        run; the increments are parked in the dycore handle and its next time_step adds them while it converts the coupler's fields (bit for
+        bit the same result, one pass over five fields less per loop iteration).  Whoever reads a field through the DataManager in between
+        triggers the pass after all (DataManager.before_access), so nobody ever SEES un-nudged values."""
         if self.column is None:
             endrun("ColumnNudger.nudge_to_column before set_column")
         ws = _column_ws(coupler, 5, self)
         fn, ctx = _torch_allreduce(coupler)
+        state = self._state(coupler)
         with torch.cuda.device(coupler.device):
-            check(capi.lib().mw_nudge_to_column(C.byref(coupler.grid), _field_ptr_array(self._state(coupler)), _ptr(self.column), float(dt),
-                                                _ptr(ws), fn, ctx, _stream_ptr(coupler.device)))
+            if defer_to is not None:
+                dm = coupler.get_data_manager_readwrite()
+                if getattr(defer_to, "_flush_hook_dm", None) is not dm:
+                    import weakref
+                    ref = weakref.ref(defer_to)
+                    dm.before_access.append(lambda: ref() is not None and ref().h and ref().flush_pending())
+                    defer_to._flush_hook_dm = dm
+                check(capi.lib().mw_nudge_to_column_deferred(defer_to.h, _field_ptr_array(state), _ptr(self.column), float(dt), _ptr(ws), fn, ctx))
+            else:
+                check(capi.lib().mw_nudge_to_column(C.byref(coupler.grid), _field_ptr_array(state), _ptr(self.column), float(dt),
+                                                    _ptr(ws), fn, ctx, _stream_ptr(coupler.device)))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1092,12 +1116,13 @@ def simple_city_step(coupler, dycore, horiz_sponge, time_averager, dtphys=None):
     return dtphys
 
 
-def supercell_step(coupler, dycore, micro, nudger, dtphys=None):
-    """One iteration of the reference's time loop, experiments/supercell_example/driver.cpp:66-79."""
+def supercell_step(coupler, dycore, micro, nudger, dtphys=None, defer_nudge=False):
+    """One iteration of the reference's time loop, experiments/supercell_example/driver.cpp:66-79.  defer_nudge: the nudger's increments ride
+    on the next dycore step's conversion instead of a pass of their own (ColumnNudger.nudge_to_column(defer_to=...)): same bits."""
     if dtphys is None:
         dtphys = dycore.compute_time_step(coupler)
     dycore.time_step(coupler, dtphys)
     micro.time_step(coupler, dtphys)
     sponge_layer(coupler, dtphys)
-    nudger.nudge_to_column(coupler, dtphys)
+    nudger.nudge_to_column(coupler, dtphys, defer_to=dycore if defer_nudge else None)
     return dtphys

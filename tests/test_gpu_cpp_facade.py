@@ -169,3 +169,12 @@ def test_cpp_multifield_and_clone_into(mw, shape):
     out = subprocess.run([exe] + [str(v) for v in shape], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr + out.stdout
     assert re.search(r"multifield ok fields 5 cells %d clone_entries_checked 11" % (shape[0] * shape[1] * shape[2] * shape[3]), out.stdout), out.stdout
+
+
+def test_cpp_driver_deferred_nudge_equals_the_eager_loop(mw):
+    """examples/supercell_driver.cpp mode 3: ColumnNudger::nudge_to_column(coupler, dt, nullptr, nullptr, &dycore) -- the increments ride on the
+    next dycore step's conversion (mw_nudge_to_column_deferred); the final fields are read through DataManager::get, whose access hook applies
+    what is still parked.  Same numbers as mode 2 (the eager loop), bit for bit."""
+    a = run_driver(40, 36, 16, 1, 20000., 18000., 20000., 6, "supercell", 2)
+    b = run_driver(40, 36, 16, 1, 20000., 18000., 20000., 6, "supercell", 3)
+    assert a[:3] == b[:3], (a, b)

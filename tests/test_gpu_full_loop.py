@@ -166,3 +166,92 @@ def test_zero_row_maps_through_a_developing_storm(mw):
     assert first_cloud is not None and first_cloud < 800
     assert 0.0 < float((cl != 0).double().mean()) < 0.5 and 0.0 < float((pr != 0).double().mean()) < 0.5
     assert float(cl.max()) > 1.0e-4 and float(pr.max()) > 1.0e-5
+
+
+def _loop(modules, shape, steps, defer, strict=0, peek_every=0, nranks_note=None):
+    nx, ny, nz, nens = shape
+    xlen, ylen = 500.0 * nx, (500.0 * ny if ny > 1 else 1.0e5)
+    coupler, dycore, micro, nudger = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000., with_nudger=True)
+    dycore.set_strict(strict)
+    dt = dycore.compute_time_step(coupler)
+    peeks = []
+    for n in range(1, steps + 1):
+        modules.supercell_step(coupler, dycore, micro, nudger, dt * (2.3 if n == 3 else 1.0), defer_nudge=defer)
+        if peek_every and n % peek_every == 0:
+            peeks.append(gpu_fields(coupler))                       # (through DataManager.get: parked increments are applied first)
+    return coupler, dycore, gpu_fields(coupler), peeks
+
+
+@pytest.mark.parametrize("shape", [(40, 36, 24, 1), (130, 44, 12, 1)])
+def test_deferred_nudge_rides_on_the_next_conversion_bit_for_bit(mw, shape):
+    """ColumnNudger.nudge_to_column(defer_to=dycore) (mw_nudge_to_column_deferred, round 6): the increments are parked in the dycore handle and the
+    next time_step adds them while its converting y launch loads the coupler's fields -- no second pass over five fields.  Ten iterations of the
+    complete supercell loop (one of them sub-cycled), deferred against eager: every field bit for bit equal at the end AND whenever somebody looks
+    in between (the DataManager applies parked increments in front of every access).  The lazy form really ran (the handle counts it)."""
+    from miniweatherml_amd import modules
+    _, _, eager, peeks_e = _loop(modules, shape, 10, False, peek_every=4)
+    coupler, dycore, lazy, peeks_l = _loop(modules, shape, 10, True, peek_every=4)
+    for k in eager:
+        assert np.array_equal(eager[k], lazy[k]), k
+    for a, b in zip(peeks_e, peeks_l):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), ("peek", k)
+    parked, (rode, passes) = dycore.pending()
+    assert not parked                                               # gpu_fields looked at the fields: nothing is parked any more
+    assert rode >= 6 and passes >= 2, (rode, passes)                # 9 consumed by conversions minus the peeks; each peek + the final look: a pass
+    assert " conv_in_y " in (dycore.path() + " ")
+
+
+def test_deferred_nudge_and_the_raw_arrays(mw):
+    """What the contract says about the raw arrays: between the deferred call and the next time step they do NOT hold the nudged values (that is
+    the saving); mw_dycore_flush_pending -- what DataManager.get calls -- makes them whole; a second deferred call with increments still parked
+    applies the old ones first (they count in the new averages)."""
+    from miniweatherml_amd import modules
+    coupler, dycore, micro, nudger = modules.make_supercell(40, 36, 16, 1, 20000., 18000., 20000., with_nudger=True)
+    c2, d2, m2, n2 = modules.make_supercell(40, 36, 16, 1, 20000., 18000., 20000., with_nudger=True)
+    dt = dycore.compute_time_step(coupler)
+    for _ in range(2):
+        modules.supercell_step(coupler, dycore, micro, nudger, dt)
+        modules.supercell_step(c2, d2, m2, n2, dt)
+    T = coupler.dm.entries["temp"]["data"]                          # the raw tensor, NOT through get()
+    before = T.clone()
+    nudger.nudge_to_column(coupler, 7.0, defer_to=dycore)
+    n2.nudge_to_column(c2, 7.0)
+    assert torch.equal(T, before) and dycore.pending()[0]           # parked, not applied
+    assert not torch.equal(T, c2.dm.entries["temp"]["data"])
+    nudger.nudge_to_column(coupler, 3.0, defer_to=dycore)           # old increments applied first, new ones parked
+    n2.nudge_to_column(c2, 3.0)
+    assert dycore.pending()[0]
+    dycore.flush_pending()
+    assert not dycore.pending()[0]
+    for n in ("density_dry", "uvel", "vvel", "temp", "water_vapor"):
+        assert torch.equal(coupler.dm.entries[n]["data"], c2.dm.entries[n]["data"]), n
+
+
+@pytest.mark.parametrize("case", ["strict", "2d", "members", "weno3", "run_time_switches"])
+def test_deferred_nudge_on_paths_that_apply_it_with_a_pass(mw, case):
+    """Paths whose conversion does not take increments along -- the strict / general kernels, 2-D, ensemble members, the run-time configuration
+    (K = 0: water vapour counts as a tracer that can vanish, its rows are scanned from the coupler's arrays) -- apply parked increments with a
+    pass at the start of the time step; WENO-3 on the folded configuration takes them along.  Same bits as the eager loop either way."""
+    from miniweatherml_amd import modules
+    shape = {"2d": (64, 1, 24, 1), "members": (24, 20, 12, 2)}.get(case, (40, 36, 16, 1))
+    res = []
+    for defer in (False, True):
+        nx, ny, nz, nens = shape
+        xlen, ylen = 500.0 * nx, (500.0 * ny if ny > 1 else 1.0e5)
+        coupler, dycore, micro, nudger = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000., with_nudger=True, ord=3 if case == "weno3" else 5)
+        if case == "strict":
+            dycore.set_strict(1)
+        if case == "run_time_switches":
+            dycore.set_option("spec", 0)
+        dt = dycore.compute_time_step(coupler)
+        for _ in range(5):
+            modules.supercell_step(coupler, dycore, micro, nudger, dt, defer_nudge=defer)
+        res.append((gpu_fields(coupler), dycore.pending()[1]))
+    for k in res[0][0]:
+        assert np.array_equal(res[0][0][k], res[1][0][k]), (case, k)
+    rode, passes = res[1][1]
+    if case == "weno3":
+        assert rode == 4 and passes == 1, (rode, passes)
+    else:
+        assert rode == 0 and passes == 5, (case, rode, passes)
