@@ -105,8 +105,7 @@ int  mw_dycore_set_strict(mw_dycore_t h, int strict);
  * "zero_rows" (on top of it: per sub-cycle a map of the x rows in which a tracer can be non-zero -- scanned from the input, grown by the three
  * cells per direction an RK stage can move it, OR-ed with the neighbour blocks' maps on a decomposed domain -- lets the fused tracer
  * kernel neither load nor compute rows of cloud / rain that are zero; same results, 1 by default), "zero_stores" (... nor store zeros over
- * rows that hold zeros already: the coupler's own arrays, the stage slabs; 1 by default), "slab_rows" (an experiment, 0 = off: the stage's three launches run y slab by y slab of that many
- * rows so that their hand-off arrays could stay in the Infinity Cache; same bits, measured slower -- DESIGN.md), "zero_verify" (a test aid, 0 by default: every
+ * rows that hold zeros already: the coupler's own arrays, the stage slabs; 1 by default), "zero_verify" (a test aid, 0 by default: every
  * claim of the maps is checked against the data in front of the launch that relies on it -- mw_debug_zero_violations).
  * Launch shapes: "chunk_y", "chunk_yt", "chunk_z", "chunk_f" (cells per chunk, 0 = the chunk model), "chunk_model".  Built-in transport
  * (read when mw_dycore_use_rccl / _self installs it): "rccl_lanes" (0 = process default | 1 | 2), "rccl_two_comms" (-1 | 0 | 1), "rccl_prio" (1: side streams at the highest priority), "rccl_inline" (1: the group runs on the caller's stream, no side stream),

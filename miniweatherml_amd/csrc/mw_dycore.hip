@@ -68,7 +68,6 @@ struct DyP {                      // kernel parameter block (by value)
   // parked column increments (mw_nudge_to_column_deferred): inc[(l * nz + k) * nens + e] for l = density_dry, uvel, vvel, temp, water_vapor, added to
   // the coupler's values while the converting y launch loads them; nullptr = none
   const double *pinc;
-  int j0, j1;                     // the rows [j0, j1) a launch of k_xz_state / k_tracers_fused covers (0, ny; the slab-stepped stage: one y slab)
   unsigned pos_mask, mass_mask;
   double dx, dy, dz, rdx, rdy, rdz, C0, gamma, grav, fcor, R_d, R_v;
   const double *hyc, *hytc, *hye, *hyte;       // device (nz,nens) / (nz+1,nens)
@@ -951,8 +950,6 @@ struct DyOpts {
   int zero_rows = 1;           // ... and the zero-row maps on top of it: rows of a tracer that are known to be zero are not loaded (mw_march.h: k_zero_rows)
   int pipe_maps_early = 1;     // pipelined schedule, first stage: local zero-row maps in front of its y launches, two strip exchanges (0: one exchange, maps beside the y launch; A/B)
   int zero_stores = 1;         // ... and zeros are not stored over rows that hold zeros already (the coupler's arrays, slabs S1 / S2; 0: A/B)
-  int slab_rows = 0;           // experiment (round 6): > 0 = the stage's three launches run y slab by y slab of this many rows (a multiple of 4), so that their hand-off arrays
-                               // could stay in the 256 MB Infinity Cache; one rank, one stream, nens = 1.  Measured: slower at every slab size -- kept as an option for the A/B
   int zero_verify = 0;         // test aid: check the maps' claims against the data in front of every launch that relies on them (k_zero_verify; mw_debug_zero_violations)
   int rccl_lanes = 0, rccl_two_comms = -1;            // built-in RCCL transport: side streams (1 | 2), a communicator per lane (0 | 1); 0 / -1 = the
                                                       // process default (MW_RCCL_LANES); read when mw_dycore_use_rccl* installs the transport
@@ -1051,7 +1048,6 @@ static void fill_params(mw_dycore_s *d) {
   p.zero_skip = d->o.zero_skip;
   p.zq = p.zqp = p.zqc = p.zqk = nullptr; p.zq_ld = 0;          // (set per RK stage by zero_rows_stage / zero_rows_conv)
   p.pinc = nullptr;                                             // (set by mw_dycore_time_step when parked increments ride on the conversion)
-  p.j0 = 0; p.j1 = g.ny;
   p.pos_mask = 0; p.mass_mask = 0;
   for (int t = 0; t < g.num_tracers; t++) { if (d->pos[t]) p.pos_mask |= 1u << t; if (d->adds[t]) p.mass_mask |= 1u << t; }
   p.dx = g.xlen / g.nx_glob; p.dy = g.ylen / g.ny_glob; p.dz = g.zlen / g.nz;        // coupler.h:262-268
@@ -1473,8 +1469,7 @@ static bool y_all_ok(const mw_dycore_s *d) {
 }
 // part: 0 = all rows; 1 = the rows whose chunks read no halo row (all of them with the row wrap), 2 = the two edge strips of
 // MW_Y_EDGE rows (short chunks: their launch runs between the exchange and k_xz_state, with a quarter of the wavefronts)
-// (rows_lo < rows_hi: only the rows [rows_lo, rows_hi) -- one y slab of the slab-stepped stage, option slab_rows; part must be 0 then)
-static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv, int part = 0, hipStream_t st = nullptr, int rows_lo = 0, int rows_hi = 0) {
+static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv, int part = 0, hipStream_t st = nullptr) {
   if (!st) st = d->stream;
   ProfScope ps(d, 5, st);
   // the cells the pipelined schedule converted up front (time_step): the converting launch leaves them alone (see k_y_all)
@@ -1509,7 +1504,6 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
     int chunk = d->chunk_y ? d->chunk_y : (d->chunk_y = balanced_chunk(d, p.ny, (threads + 63) / 64, d->o.chunk_y, 5000, 2, 5.0, (threads + 255) / 256 < 96));
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)((p.ny + chunk - 1) / chunk));
     int row0 = 0, rstride = chunk, row_end = p.ny;
-    if (rows_lo < rows_hi) { row0 = rows_lo; row_end = rows_hi; chunk = std::min(chunk, row_end - row0); rstride = chunk; grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk); }
     if (part) {
       const int n = (int)grid.y;
       const bool edges = !p.wrap_y;                             // the first / last rows read halo rows of the slab
@@ -1570,8 +1564,7 @@ static int xz_grid(mw_dycore_s *d, const DyP &p, dim3 &grid, int &chunk, int &ti
   int U = xz_cells_per_wave(p.nens, d->ord);
   if (U < 4) MW_FAIL("nens too large for the 64-lane x tiling (need nens <= 30)");
   tiles_x = (p.nx * p.nens + U - 1) / U;
-  long long waves = (long long)p.ny * tiles_x;                  // (the chunk length is decided for the whole block ...)
-  const long long waves_launch = (long long)(p.j1 - p.j0) * tiles_x;   // (... the launch covers the rows [j0, j1))
+  long long waves = (long long)p.ny * tiles_x;
   if (!d->chunk_z) {
     // k_xz_state: equal chunks, enough of them for ~5 rounds of 2 waves/SIMD over the 1024 SIMDs (measured on 400x400x100:
     // 4 x 25 levels beats 32,32,32,4 by 4 %)
@@ -1580,7 +1573,7 @@ static int xz_grid(mw_dycore_s *d, const DyP &p, dim3 &grid, int &chunk, int &ti
     d->chunk_z = std::min(d->chunk_z, 900);
   }
   chunk = d->chunk_z;
-  grid = dim3((unsigned)((waves_launch + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
+  grid = dim3((unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
   return 0;
 }
 
@@ -1728,12 +1721,10 @@ static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *
                      d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4, MemberOff(), sc);
 }
 // x/z tracer fluxes + FCT + update in one kernel, then the (normally empty) y-face correction
-// (what: 0 = the fused kernel and the patch pass; 1 = the fused kernel only, 2 = the patch pass only -- the slab-stepped stage runs the kernel
-//  slab by slab and the receiver-centred patch pass once, behind the last slab)
 template <int STAGE, int MODE>
 static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, int par, double dt, double dt_dyn,
-                                const CouplerPtrs &c, hipStream_t st, int what = 0) {
-  if (what != 2) {
+                                const CouplerPtrs &c, hipStream_t st) {
+  {
     ProfScope ps(d, 7, st);
     bool direct = false;
     if constexpr (STAGE == 3 && MODE == 1) direct = d->mm_direct;
@@ -1764,8 +1755,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const int rows4 = (p.ny >= 4 && d->o.tf_rows4) ? 1 : 0;   // (workgroup = 4 rows of one x tile: the rows' shared y faces meet in L1; option tf_rows4 = 0: 4 x tiles of one row, A/B)
       const long long waves = (long long)p.ny * tiles_x;
       const int chunk = d->chunk_f ? d->chunk_f : (d->chunk_f = balanced_chunk(d, p.nz, waves, d->o.chunk_f, 10000, 2, 4.5, true));
-      const int nrows = p.j1 - p.j0;                            // (the rows this launch covers: all, or one y slab)
-      dim3 grid(rows4 ? (unsigned)(((nrows + 3) / 4) * tiles_x) : (unsigned)(((long long)nrows * tiles_x + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
+      dim3 grid(rows4 ? (unsigned)(((p.ny + 3) / 4) * tiles_x) : (unsigned)((waves + 3) / 4), (unsigned)((p.nz + chunk - 1) / chunk));
 #define MW_FUSED_ARGS d, v, S, Sn, Sout, grid, chunk, tiles_x, par, dt, dt_dyn, c, rows4, st
 #define MW_FUSED_CASE(TT) \
       case TT: if (p.nens != 1)     launch_tracers_fused_t<STAGE, MODE, TT, false, 0>(MW_FUSED_ARGS); \
@@ -1780,7 +1770,6 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       MW_LAUNCH_CHECK();
     }
   }
-  if (what == 1) return 0;
   const DyP &p = d->p;
   if (!p.sim2d && p.pos_mask && !d->o.debug_no_patch) {   // (the switch exists for the negative control in tests/, -DMW_EXPERIMENTS builds)
     ProfScope ps(d, 1, st);
@@ -1865,25 +1854,6 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
 #endif
   {
   if (conv && zero_rows_verify(d, 1, Sin, nullptr, false, c, ss)) return 1;
-  // Experiment (round 6, option slab_rows): the stage's three launches y slab by y slab, so that what one launch hands to the next -- y tendencies,
-  // face mass fluxes, tracer y fluxes: ~100 B per cell -- is still in the Infinity Cache when it is read.  One rank with both index wraps (no halo
-  // fill at all), one stream, nens = 1, the fused tracer stage.  Every slab's k_y_all computes both of its end faces, k_xz_state / k_tracers_fused
-  // take the slab's rows through DyP::j0 / j1, the patch pass runs once behind the last slab.  Same bits as the whole-block launches.
-  const int slab = (yall && !d->overlap && !d->member_major && d->fused && d->p.nens == 1 && d->p.wrap_x && d->p.wrap_y && !d->xchg) ? (d->o.slab_rows / 4) * 4 : 0;
-  if (slab > 0 && slab < d->p.ny) {
-    if (zero_rows_verify(d, 0, Sin, Sout, MODE == 1, c, ss)) return 1;
-    for (int r0 = 0; r0 < d->p.ny; r0 += slab) {
-      const int r1 = std::min(r0 + slab, d->p.ny);
-      if (launch_y_all(d, Sin, conv ? &c : nullptr, 0, ss, r0, r1)) return 1;
-      d->p.j0 = r0; d->p.j1 = r1;
-      int rc = launch_xz_state<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c);
-      if (!rc) rc = launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ss, 1);
-      d->p.j0 = 0; d->p.j1 = d->p.ny;
-      if (rc) return 1;
-    }
-    if (STAGE == 1 && conv) zero_rows_conv(d, Sin, true, ss);
-    return launch_tracers_fused<STAGE, MODE>(d, Sin, Sn, Sout, par, dt_stage, dt_dyn, c, ss, 2);
-  }
   if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin, conv ? &c : nullptr)) return 1; }
   else if (launch_y_state(d, Sin, par, conv ? &c : nullptr)) return 1;             // y faces: m_upw, selector, y tendencies
   if (STAGE == 1 && conv) zero_rows_conv(d, Sin, true, ss);
@@ -2401,7 +2371,7 @@ const OptDesc OPTS[] = {
   {"mm_direct", &DyOpts::mm_direct, 0, 1, 0}, {"mm_conv", &DyOpts::mm_conv, 0, 1, 0}, {"fused_convert", &DyOpts::fused_convert, 0, 1, 0},
   {"fused_convert_mm", &DyOpts::fused_convert_mm, 0, 1, 0}, {"chunk_y", &DyOpts::chunk_y, 0, 1 << 20, 0}, {"chunk_yt", &DyOpts::chunk_yt, 0, 1 << 20, 0},
   {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
-  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"zero_stores", &DyOpts::zero_stores, 0, 1, 0}, {"zero_verify", &DyOpts::zero_verify, 0, 1, 0}, {"slab_rows", &DyOpts::slab_rows, 0, 1 << 20, 0}, {"pipe_maps_early", &DyOpts::pipe_maps_early, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
+  {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"zero_stores", &DyOpts::zero_stores, 0, 1, 0}, {"zero_verify", &DyOpts::zero_verify, 0, 1, 0}, {"pipe_maps_early", &DyOpts::pipe_maps_early, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
   {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0}, {"rccl_inline", &DyOpts::rccl_inline, 0, 1, 0},
   {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
   {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},

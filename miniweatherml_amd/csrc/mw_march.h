@@ -1176,8 +1176,7 @@ __device__ __forceinline__ XzGeom xz_geom(const DyP &p, unsigned colx, int ka, i
   int tx;
   if (rows4) { const int jg = (int)(colx / tiles_x); tx = (int)(colx - (unsigned)jg * tiles_x); g.j = jg * 4 + (threadIdx.x >> 6); }
   else       { g.j = (int)(wid / tiles_x); tx = (int)(wid - (long long)g.j * tiles_x); }
-  g.j += p.j0;                                                // (the launch covers the rows [j0, j1): all of them, or one y slab)
-  g.valid = g.j < p.j1;                                       // whole wave
+  g.valid = g.j < p.ny;                                       // whole wave
   g.q = tx * U - hw * g.n + g.lane;                           // interior fused-x index of this lane (may be in the halo)
   const int q_hi = g.NXI + (N1 ? 3 : 1) * g.n - 1;            // last index a lane may address (nens > 1: +2n must stay in the halo)
   g.owns_face = (g.lane >= g.cell_lo) && (g.lane < g.face_hi) && (g.q < g.NXI + g.n);
@@ -1779,8 +1778,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
     lds_c[threadIdx.x] = threadIdx.x == 0 ? p.rdx : threadIdx.x == 1 ? p.rdy : threadIdx.x == 2 ? p.rdz : threadIdx.x == 3 ? dt : threadIdx.x == 4 ? cdt : 0.0;
   }
   if (LC) __syncthreads();
-  j += p.j0;                                                  // (the launch covers the rows [j0, j1): all of them, or one y slab)
-  if (j >= p.j1) return;
+  if (j >= p.ny) return;
   const int q = tx * U - hw * n + lane;                       // fused-x index of this lane's cell (halo lanes included)
   const int qq = min(max(q, -3 * n), NXI + 3 * n - 1);        // clamped into the 3-cell halo for addressing
   const int e = N1 ? 0 : ((qq % n) + n) % n;

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULTS = {"overlap": -1, "pipe": 1, "pipe_edge_inline": 0, "pipe_convert": 1, "pipe_split_edges": 1, "spec": 1, "wrap": 1, "y_all": 1, "y_all_conv": 1,
             "member_major": 1, "mm_direct": 1, "mm_conv": 1, "fused_convert": 1, "fused_convert_mm": 1, "fused_tracers": 1, "chunk_y": 0, "chunk_yt": 0,
-            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "zero_rows": 1, "zero_stores": 1, "zero_verify": 0, "slab_rows": 0, "pipe_maps_early": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
+            "chunk_z": 0, "chunk_f": 0, "chunk_model": 1, "tf_rows4": 1, "zero_skip": 1, "zero_rows": 1, "zero_stores": 1, "zero_verify": 0, "pipe_maps_early": 1, "rccl_lanes": 0, "rccl_two_comms": -1, "rccl_prio": 1, "rccl_inline": 1, "xchg_fuzz": 0}
 
 
 def test_defaults_round_trips_and_errors(mw):
@@ -327,33 +327,3 @@ def test_zero_row_maps_are_exactly_what_the_design_says(mw):
         assert np.array_equal(maps[3 + s], levels_or(b, -3 * s - 6, 3 * s + 2)), ("FN", s)
         assert np.array_equal(maps[6 + s], levels_or(b, -3 * (s - 1), 3 * (s - 1))), ("QY", s)
     assert 0.02 < float((maps[7] & 6 != 0).mean()) < 0.6 and float((maps[1] & 6 != 0).mean()) < 1.0     # (the case has both kinds of row)
-
-
-@pytest.mark.parametrize("slab", [8, 20, 64])
-def test_slab_stepped_stage_is_bit_neutral(mw, slab):
-    """Option slab_rows (round 6 experiment): k_y_all, k_xz_state and k_tracers_fused of every RK stage run y slab by y slab (DyP::j0 / j1; the
-    patch pass once behind the last slab) instead of over the whole block.  Same bits as the whole-block launches -- cloud and rain boxes across
-    slab boundaries (busy limiter + patch pass), zero-row maps on, one sub-cycled step, a row count that is not a multiple of the slab."""
-    import torch
-    from miniweatherml_amd import modules
-    res = []
-    for rows in (0, slab):
-        coupler, dycore, _ = modules.make_supercell(130, 44, 14, 1, 65000., 22000., 20000.)
-        dm = coupler.get_data_manager_readwrite()
-        rho = dm.get("density_dry")
-        cl, pr = torch.zeros_like(rho), torch.zeros_like(rho)
-        cl[3:9, 5:27, 37:90] = 3.0e-4; cl[12, 43, 129] = 2.0e-4; cl[0, 0, 5] = 2.0e-4
-        pr[2:6, 14:33, 60:120] = 1.0e-4; pr[10, 7, 64] = 1.0e-4
-        dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(pr * rho)
-        dycore.set_option("slab_rows", rows)
-        dycore.set_option("zero_verify", 1)
-        dt = dycore.compute_time_step(coupler)
-        for f in (1.0, 2.4, 1.0):
-            dycore.time_step(coupler, dt * f)
-        f = gpu_fields(coupler)
-        for name, a in dycore.fluxes(coupler).items():
-            f[name] = a.cpu().numpy().copy()
-        res.append(f)
-        assert dycore.zero_violations()[0] == 0
-    for k in res[0]:
-        assert np.array_equal(res[0][k], res[1][k]), (k, slab)
