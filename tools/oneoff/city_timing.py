@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from miniweatherml_amd import modules
 coupler, dycore, hs, ta = modules.make_simple_city(512, 512, 256, 1, 2560., 2560., 1280., "city")
 dt = dycore.compute_time_step(coupler)

@@ -4,7 +4,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from miniweatherml_amd import modules
 coupler, dycore, micro, nudger = modules.make_supercell(400, 400, 100, 1, 2e5, 2e5, 2e4, with_nudger=True)
 def timed(fn, n=10):

@@ -1,5 +1,5 @@
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 order = sys.argv[1] if len(sys.argv) > 1 else "lib_first"
 def maps():
     return sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'hip64' in l or 'hsa-runtime' in l or 'rccl' in l))

@@ -2,7 +2,7 @@
 mode 2 -- bench.py's timed region until then -- 1.5 % of the step, mode 1 5 %; the timed region now runs mode 3.  The step time itself climbs by 10 % over
 the 600 steps of this script: the part throttles.)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from miniweatherml_amd import modules
 c, d, _ = modules.make_supercell(400, 400, 100, 1, 200000., 200000., 20000.)

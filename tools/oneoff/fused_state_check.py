@@ -4,8 +4,8 @@ prints max |difference|, where it sits and how many cells differ (0 everywhere =
 every field first (an indexing error then shows as an O(1) difference; a rounding-level one only on smooth states)."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from miniweatherml_amd import modules
 from util import gpu_fields
 case = sys.argv[1]; nsteps = int(sys.argv[2]); chunk = sys.argv[3] if len(sys.argv) > 3 else None

@@ -1,7 +1,7 @@
 """Where a step of the complete supercell loop goes: dycore | Kessler | sponge | nudger, hipEvent-timed per module over 20 steps, on the
 cloud-free state after 50 steps and on the developed storm (2600 steps)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from miniweatherml_amd import modules
 nx, ny, nz = 400, 400, 100

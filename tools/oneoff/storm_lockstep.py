@@ -1,7 +1,7 @@
 """One-off: the complete supercell loop at the benchmark's size, two handles in lockstep with and without the zero-row maps, every field compared
 every 100 steps (the suite's test_zero_row_maps_through_a_developing_storm does this on 100 x 40 x 40)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from miniweatherml_amd import modules
 names = ("density_dry", "uvel", "vvel", "wvel", "temp", "water_vapor", "cloud_liquid", "precip_liquid")

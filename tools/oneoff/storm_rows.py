@@ -2,7 +2,7 @@
 would leave (a what-if for DESIGN.md; torch arithmetic on the coupler's arrays, no library internals).
     python tools/storm_rows.py [--steps 2600]"""
 import argparse, os, sys, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from miniweatherml_amd import modules
 

@@ -1,6 +1,6 @@
 """One-off: the seeded zero-row-map sweeps of tests/ over many more seeds (not part of the suite)."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import miniweatherml_amd as mw

@@ -14,7 +14,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${tag}_w --
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $R/gpurun_out/prof_${tag}_sq -- python3 $R/bench.py $PARGS > /dev/null 2> $R/gpurun_out/prof_${tag}_sq.err
 cd $R
 # keep only the small CSVs (the counter_collection files are large: aggregate them here)
-python3 tools/summarize_profiles.py r05_${tag} gpurun_out/prof_${tag}_stats gpurun_out/prof_${tag}_f gpurun_out/prof_${tag}_w gpurun_out/prof_${tag}_sq > gpurun_out/prof_${tag}_table.txt 2>&1
-cp profiles/r05_${tag}_summary.json gpurun_out/
+python3 tools/summarize_profiles.py ${MW_ROUND:-r06}_${tag} gpurun_out/prof_${tag}_stats gpurun_out/prof_${tag}_f gpurun_out/prof_${tag}_w gpurun_out/prof_${tag}_sq > gpurun_out/prof_${tag}_table.txt 2>&1
+cp profiles/${MW_ROUND:-r06}_${tag}_summary.json gpurun_out/
 find gpurun_out/prof_${tag}_f gpurun_out/prof_${tag}_w gpurun_out/prof_${tag}_sq -name "*counter_collection.csv" -size +8M -delete
 tail -25 gpurun_out/prof_${tag}_table.txt
