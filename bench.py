@@ -277,6 +277,31 @@ def rows_full_form(dycore):
     return float(((maps[1:4] & 0x6) != 0).mean())
 
 
+def tiles_full_form(dycore, nx, tile=58, halo=4):
+    """The same per 58-cell x tile of a row (round 6: the maps carry x segments, bits 4 .. 29 of a word, L = ceil(nx / 26) cells each): the share of
+    (level, row, tile) iterations of the fused tracer kernel that take the FULL form -- a tile is full when a segment its lanes overlap is set."""
+    import ctypes as C
+    import numpy as np
+    from miniweatherml_amd import capi
+    L = capi.lib()
+    dims = (C.c_int * 2)()
+    n = L.mw_debug_zero_maps(dycore.h, None, 0, dims)
+    if n <= 0:
+        return None
+    buf = np.empty(n, np.uint32)
+    if L.mw_debug_zero_maps(dycore.h, buf.ctypes.data_as(C.c_void_p), n, dims) != n:
+        return None
+    q = buf.reshape(10, dims[0], dims[1])[1:4, :, 9:-9]
+    Ls = (nx + 25) // 26
+    full, tiles = 0.0, 0
+    for t0 in range(0, nx, tile):
+        lo, hi = t0 - halo, t0 + tile + halo - 1
+        segs = set(((x % nx) // Ls) for x in range(lo, hi + 1))
+        m = np.uint32(sum(1 << (4 + sg) for sg in segs))
+        full += float(((q & m) != 0).mean()); tiles += 1
+    return full / tiles
+
+
 def cloud_extent(torch, dm, tile=58):
     """Diagnostics of where cloud / rain are (what a finer map granularity could skip): the share of cells that hold any, and -- after growing that
     set by the 9 cells per direction a sub-cycle can move a tracer -- the share of x rows and of 58-cell x tiles (one wavefront of the marching
@@ -370,6 +395,7 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
     dycore.profile(0)
     res["developed_ms_per_step"] = dev_ms
     res["developed_rows_full_form"] = rows_full_form(dycore)
+    res["developed_tiles_full_form"] = tiles_full_form(dycore, nx)
     res["value_developed"] = ncell / dev_ms * 1e3                # cell-updates/s on the developed state: read it next to "value"
     res["developed_state"] = {"state": "the bench state after the timed region + seeded cloud (2e-3) and rain (4e-4) blobs with sharp rims: "
                                        "FCT multipliers < 1 and a busy y-face correction pass", "cell_updates_per_s": ncell / dev_ms * 1e3,
@@ -411,6 +437,7 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
                         "rain_max": float(f2.get("precip_liquid").max())}
         res["value_storm"] = ncell / storm_ms * 1e3
         res["storm"]["rows_full_form"] = rows_full_form(d2)
+        res["storm"]["tiles_full_form"] = tiles_full_form(d2, nx)
         res["storm"]["extent"] = cloud_extent(torch, f2)
         # the same loop iteration with the nudger's own second pass (the reference's structure), interleaved with the deferred form, at this state
         ab = {"eager": [], "deferred": []}
@@ -434,7 +461,7 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
             res["mature"] = {"state": "after %d steps (%.0f s simulated) of the complete supercell_example loop from the initial state" % (a.mature_steps, a.mature_steps * dt2),
                              "ms_per_step": mature_ms, "cell_updates_per_s": ncell / mature_ms * 1e3,
                              "max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()),
-                             "rain_max": float(f2.get("precip_liquid").max()), "rows_full_form": rows_full_form(d2), "extent": cloud_extent(torch, f2),
+                             "rain_max": float(f2.get("precip_liquid").max()), "rows_full_form": rows_full_form(d2), "tiles_full_form": tiles_full_form(d2, nx), "extent": cloud_extent(torch, f2),
                              "loop_ms_per_step_storm_to_mature": loop2_s / more * 1e3, "loop_cell_updates_per_s_storm_to_mature": ncell * more / loop2_s}
             res["value_mature"] = ncell / mature_ms * 1e3
             res["simulation_loop"]["to_mature"] = {"steps": a.mature_steps - 3, "seconds": loop_s + loop2_s,
@@ -927,23 +954,25 @@ def main():
             # ---- the roofline figure, state by state (the headline state is the best case: cloud and rain identically zero).  frac = SURVEY.md
             # 8(d)'s 32 V B per cell and stage with V = 8; frac_moved = the same with the variables that actually move: the six that are
             # never skipped plus cloud and rain in the share of rows whose tracer iterations take the full form (the zero-row maps)
-            def _state(ms, rows):
+            def _state(ms, rows, tiles=None):
                 if not ms:
                     return None
                 st_s = ms / 3.0 * 1e-3
-                e = {"ms_per_step": ms, "cell_updates_per_s": ncells_local / ms * 1e3, "frac": 32.0 * V * ncells_local / st_s / 8.0e12, "rows_full_form": rows}
-                if rows is not None and V == 8:
-                    e["V_moved"] = 6.0 + 2.0 * rows
-                    e["frac_moved"] = 32.0 * (6.0 + 2.0 * rows) * ncells_local / st_s / 8.0e12
+                e = {"ms_per_step": ms, "cell_updates_per_s": ncells_local / ms * 1e3, "frac": 32.0 * V * ncells_local / st_s / 8.0e12, "rows_full_form": rows,
+                     "tiles_full_form": tiles}
+                share = tiles if tiles is not None else rows          # (the share of the tracer kernel's iterations that move cloud and rain)
+                if share is not None and V == 8:
+                    e["V_moved"] = 6.0 + 2.0 * share
+                    e["frac_moved"] = 32.0 * (6.0 + 2.0 * share) * ncells_local / st_s / 8.0e12
                 return e
             out["roofline"]["frac_by_state"] = {
-                "cloud_free": _state(stage_ms * 3.0, 0.0 if out["config"]["zero_row_maps"] else 1.0),
-                "storm": _state((out.get("storm") or {}).get("ms_per_step"), (out.get("storm") or {}).get("rows_full_form")),
-                "developed": _state(out.get("developed_ms_per_step"), out.get("developed_rows_full_form")),
-                "mature": _state((out.get("mature") or {}).get("ms_per_step"), (out.get("mature") or {}).get("rows_full_form")),
+                "cloud_free": _state(stage_ms * 3.0, 0.0 if out["config"]["zero_row_maps"] else 1.0, 0.0 if out["config"]["zero_row_maps"] else 1.0),
+                "storm": _state((out.get("storm") or {}).get("ms_per_step"), (out.get("storm") or {}).get("rows_full_form"), (out.get("storm") or {}).get("tiles_full_form")),
+                "developed": _state(out.get("developed_ms_per_step"), out.get("developed_rows_full_form"), out.get("developed_tiles_full_form")),
+                "mature": _state((out.get("mature") or {}).get("ms_per_step"), (out.get("mature") or {}).get("rows_full_form"), (out.get("mature") or {}).get("tiles_full_form")),
                 "what": "frac = 32 V B (V = 8) x cells / (ms_per_step / 3) / 8 TB/s per state; rows_full_form = share of (level, row) words of the stage maps in "
-                        "which cloud or rain may be non-zero (the fused tracer kernel's FULL iterations); frac_moved prices only the variables that move: "
-                        "6 + 2 x rows_full_form.  cloud_free = the headline state (this line's roofline.frac); storm = 725 s into the run; developed = a seeded stress "
+                        "which cloud or rain may be non-zero; tiles_full_form = the same per 58-cell x tile (the x segments of the maps: the fused tracer kernel's FULL "
+                        "iterations); frac_moved prices only the variables that move: 6 + 2 x tiles_full_form.  cloud_free = the headline state (this line's roofline.frac); storm = 725 s into the run; developed = a seeded stress "
                         "state with cloud / rain rims everywhere; mature = 3600 s into the run"}
             out["roofline"]["state"] = "cloud_free (headline; see frac_by_state for the storm / developed / mature states)"
         if world == 1 and not a.no_cpu_baseline:

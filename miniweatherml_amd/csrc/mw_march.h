@@ -369,6 +369,33 @@ __global__ __launch_bounds__(256) void k_coupler_to_state_fast(DyP p, CouplerPtr
 // ---------------------------------------------------------------------------------------------------------------
 #define MW_ZR_REACH 3
 #define MW_ZR_HALO (3 * MW_ZR_REACH)                              // rows a tracer can travel in one sub-cycle = halo rows of the maps
+// x SEGMENTS (round 6).  A storm covers a fifth of the x rows but a fourteenth of the 58-cell tiles a marching wave works on (bench.py:
+// storm.extent), so a word also says WHERE in its row something can be:
+//   bits 0 .. 3   tracer v may be non-zero somewhere in the row (as before; the y kernel's store decision, the tests)
+//   bits 4 .. 29  segment s of the row -- cells [s L, (s + 1) L), L = ceil(NXI / 26) -- may hold a non-zero value of a tracer that can vanish.
+//                 Set at SCAN time for every segment within MW_ZR_HALO = 9 cells of a non-zero cell (what a whole sub-cycle can move it in
+//                 x; periodic when one rank owns the direction), so that the row / level growth of k_zero_dilate -- a plain OR of words --
+//                 carries the segments along.  A wave is lean when the segments its lanes (halo lanes and patch cells included) overlap are clear.
+//   bits 30, 31   (the compact copy a block sends to its west / east neighbours only) the grown set touches the block's west / east edge:
+//                 the neighbour then sets the segments of its first / last 9 cells (k_zero_merge).
+// Per cell the invariants are the old ones -- "bit clear => the cell is zero" -- so the zero-store rules hold cell by cell whatever the tiling.
+#define MW_ZR_SEGS 26
+#define MW_ZR_SEG_SHIFT 4
+#define MW_ZR_ROWBITS 0xFu
+#define MW_ZR_TOUCH_W 0x40000000u
+#define MW_ZR_TOUCH_E 0x80000000u
+__host__ __device__ __forceinline__ int zr_seg_len(int NXI) { return (NXI + MW_ZR_SEGS - 1) / MW_ZR_SEGS; }
+// segment bits (in place: shifted) of the cells [a, b], 0 <= a <= b < NXI
+__host__ __device__ __forceinline__ unsigned zr_seg_span(int a, int b, int L) { return ((2u << (b / L)) - (1u << (a / L))) << MW_ZR_SEG_SHIFT; }
+// ... of the cells [lo, hi] of a row of NXI cells (lo may be < 0, hi >= NXI): periodic images when `wrap`, else clamped into the row
+__host__ __device__ __forceinline__ unsigned zr_seg_mask(int lo, int hi, int NXI, bool wrap) {
+  const int L = zr_seg_len(NXI);
+  if (hi - lo + 1 >= NXI) return zr_seg_span(0, NXI - 1, L);
+  if (!wrap) return zr_seg_span(max(lo, 0), min(hi, NXI - 1), L);
+  if (lo < 0) return zr_seg_span(lo + NXI, NXI - 1, L) | zr_seg_span(0, hi, L);
+  if (hi >= NXI) return zr_seg_span(lo, NXI - 1, L) | zr_seg_span(0, hi - NXI, L);
+  return zr_seg_span(lo, hi, L);
+}
 // Map layout: word of (k, j) at [k * zq_ld + j + MW_ZR_HALO], zq_ld = ny + 2 MW_ZR_HALO (j = -9 .. ny+8: the rows beyond the block's
 // south / north edge -- its own rows again when it owns the periodic y direction, the neighbours' rows otherwise).
 // Blocks of a decomposed domain (pipelined schedule): a row's x halo holds the west / east neighbour's cells and its tracer can come
@@ -397,6 +424,8 @@ __global__ __launch_bounds__(256) void k_zero_rows(DyP p, CouplerPtrs c, const d
   }
   const unsigned scan = vmask & ((1u << min(p.nt, 4)) - 1u);
   bool nz[4] = {false, false, false, false};
+  unsigned segb = 0;                                              // this lane's part of the segment bits (+ the edge flags)
+  const bool xwrap = p.wrap_x != 0;
   for (int base = 0; base < NXI; base += 512) {
     double a[4][8];
 #pragma unroll
@@ -405,16 +434,27 @@ __global__ __launch_bounds__(256) void k_zero_rows(DyP p, CouplerPtrs c, const d
 #pragma unroll
       for (int u = 0; u < 8; u++) { const int ie = base + u * 64 + lane; a[v][u] = src[v][min(ie, NXI - 1)]; }
     }
+    bool cellnz[8] = {false, false, false, false, false, false, false, false};
 #pragma unroll
     for (int v = 0; v < 4; v++) {
       if (!((scan >> v) & 1u)) continue;
 #pragma unroll
-      for (int u = 0; u < 8; u++) nz[v] = nz[v] || (a[v][u] != 0.0);
+      for (int u = 0; u < 8; u++) { const bool b = (a[v][u] != 0.0); nz[v] = nz[v] || b; cellnz[u] = cellnz[u] || b; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (!cellnz[u]) continue;
+      const int ie = min(base + u * 64 + lane, NXI - 1);
+      segb |= zr_seg_mask(ie - MW_ZR_HALO, ie + MW_ZR_HALO, NXI, xwrap);
+      if (!xwrap && ie - MW_ZR_HALO < 0) segb |= MW_ZR_TOUCH_W;
+      if (!xwrap && ie + MW_ZR_HALO >= NXI) segb |= MW_ZR_TOUCH_E;
     }
   }
+  for (int off = 32; off > 0; off >>= 1) segb |= (unsigned)__shfl_xor((int)segb, off, 64);
   unsigned word = ((1u << min(p.nt, 4)) - 1u) & ~vmask;           // the tracers that cannot vanish
 #pragma unroll
   for (int v = 0; v < 4; v++) if (((scan >> v) & 1u) && __any(nz[v])) word |= 1u << v;
+  word |= segb;                                                  // (with the two edge flags when x is decomposed: k_zero_merge of the neighbours reads them; nobody else looks at bits 30, 31)
   if (lane == 0) {
     unsigned *o = out + (long long)k * ldo + offo;
     o[j] = word;
@@ -432,7 +472,15 @@ __global__ __launch_bounds__(256) void k_zero_merge(DyP p, const unsigned *__res
   if (t >= (long long)p.nz * p.ny) return;
   const int k = (int)(t / p.ny), j = (int)(t - (long long)k * p.ny);
   unsigned wd = own[t];
-  if (rW) wd |= rW[t] | rE[t];
+  if (rW) {
+    // the neighbours' rows: their row bits as before (coarse, but a superset -- the y kernel's store decision looks at them); of their
+    // segments only what can cross the shared edge within a sub-cycle: a grown set that touches the neighbour's edge reaches my first / last 9 cells
+    const unsigned w = rW[t], e = rE[t];
+    const int NXI = p.nx * p.nens;
+    wd |= (w | e) & MW_ZR_ROWBITS;
+    if (w & MW_ZR_TOUCH_E) wd |= zr_seg_mask(0, MW_ZR_HALO - 1, NXI, false);
+    if (e & MW_ZR_TOUCH_W) wd |= zr_seg_mask(NXI - MW_ZR_HALO, NXI - 1, NXI, false);
+  }
   unsigned *o = M + (long long)k * p.zq_ld + MW_ZR_HALO;
   o[j] = wd;
   if (sS) {
@@ -529,21 +577,28 @@ __global__ __launch_bounds__(256) void k_zero_verify(DyP p, CouplerPtrs c, const
   const int NXI = p.nx * p.nens;
   const unsigned scan = vmask & ((1u << min(p.nt, 4)) - 1u);
   unsigned in_nz = 0, dst_nz = 0, kz_nz = 0;
+  unsigned in_sg = 0, dst_sg = 0, kz_sg = 0;                      // ... and the x segments (exact: no growth) that hold a non-zero cell
   const long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens;
   const long long ci = ((long long)k * p.ny + j) * NXI;
   for (int v = 0; v < 4; v++) {
     if (!((scan >> v) & 1u)) continue;
     bool a = false, b = false, e = false;
     for (int ie = lane; ie < NXI; ie += 64) {
-      if (Sin) a = a || (Sin[(long long)(5 + v) * p.sV + so + ie] != 0.0);
-      if (Sdst && !dst_coupler) b = b || (Sdst[(long long)(5 + v) * p.sV + so + ie] != 0.0);
-      if (dst_coupler) b = b || (c.tr[v][cpl(p, ci + ie)] != 0.0);
-      if (Skz) e = e || (Skz[(long long)(5 + v) * p.sV + so + ie] != 0.0);
+      const unsigned sg = zr_seg_mask(ie, ie, NXI, false);
+      if (Sin && Sin[(long long)(5 + v) * p.sV + so + ie] != 0.0) { a = true; in_sg |= sg; }
+      if (Sdst && !dst_coupler && Sdst[(long long)(5 + v) * p.sV + so + ie] != 0.0) { b = true; dst_sg |= sg; }
+      if (dst_coupler && c.tr[v][cpl(p, ci + ie)] != 0.0) { b = true; dst_sg |= sg; }
+      if (Skz && Skz[(long long)(5 + v) * p.sV + so + ie] != 0.0) { e = true; kz_sg |= sg; }
     }
     if (__any(a)) in_nz |= 1u << v;
     if (__any(b)) dst_nz |= 1u << v;
     if (__any(e)) kz_nz |= 1u << v;
   }
+  for (int off = 32; off > 0; off >>= 1) {
+    in_sg |= (unsigned)__shfl_xor((int)in_sg, off, 64); dst_sg |= (unsigned)__shfl_xor((int)dst_sg, off, 64); kz_sg |= (unsigned)__shfl_xor((int)kz_sg, off, 64);
+  }
+  // (a segment's claim is a claim about its cells: checked with the same rules as the row bits, the segment bits beside them)
+  in_nz |= in_sg; dst_nz |= dst_sg; kz_nz |= kz_sg;
   if (lane != 0) return;
   const long long ld = p.zq_ld;
   if (p.zq && in_nz) {
@@ -1003,6 +1058,9 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
     if (ieA + 63 < 2 * NXI) {
       const unsigned *fnA = p.zq + 3 * (long long)p.nz * p.zq_ld + (long long)kA * p.zq_ld + MW_ZR_HALO;
       const long long nextk = (ieA + 63 >= NXI && kA + 1 < p.nz) ? p.zq_ld : 0;     // the wave's last lanes lie in the next level
+      // the x segments this wave's lanes lie in (the y kernel reads no x neighbour): of level kA, and of the next level when it straddles the row end
+      const unsigned segA = zr_seg_mask(ieA, min(ieA + 63, NXI - 1), NXI, false);
+      const unsigned segB = (ieA + 63 >= NXI) ? zr_seg_mask(0, ieA + 63 - NXI, NXI, false) : 0u;
       const int ji = ja - 1 + (int)(threadIdx.x & 63);
       bool st = (ji > jb);
       if (ji >= 1 && ji - 1 < p.ny) st = st || (((fnA[ji - 1] | fnA[ji - 1 + nextk]) & VANM) != 0u);
@@ -1012,13 +1070,13 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
       const unsigned *qyA = fnA + 3 * (long long)p.nz * p.zq_ld;
       const int jw = wrap_row(p, ji);
       bool ld = true;
-      if (ji <= jb && jw >= 0 && jw < p.ny) ld = ((qyA[jw] | qyA[jw + nextk]) & VANM) != 0u;
+      if (ji <= jb && jw >= 0 && jw < p.ny) ld = ((qyA[jw] & segA) | (qyA[jw + nextk] & segB)) != 0u;
       ym_ld = __ballot(ld) | idle;
       if (CONV && p.zqk != nullptr) {
         const unsigned *kzA = p.zqk + (long long)kA * p.zq_ld + MW_ZR_HALO;
         const int jr = wrap_row(p, min(ji + HS + 1, p.ny + p.HY - 1));       // the row iteration ji converts and stores
         bool ss = true;
-        if (ji <= jb && jr >= 0 && jr < p.ny) ss = ((kzA[jr] | kzA[jr + nextk]) & VANM) != 0u;
+        if (ji <= jb && jr >= 0 && jr < p.ny) ss = ((kzA[jr] & segA) | (kzA[jr + nextk] & segB)) != 0u;
         ym_ss = __ballot(ss) | idle;
       }
     }
@@ -1847,9 +1905,12 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   unsigned long long zq_mask = ~0ull;
   const bool zq_on = (p.zq != nullptr) && p.zero_skip;
   const unsigned *zq_own = p.zq + (MT ? mt_e * mo.zq : 0);       // (members in one workgroup: this wave's member)
+  // (the x segments this wave's lanes, halo lanes and patch cells lie in -- k_zero_rows: a segment bit is set when a tracer that can vanish may be
+  //  non-zero there; the row's other tiles may be busy while this one is lean)
+  const unsigned zseg = zr_seg_mask(tx * U - (hw + 1) * n, tx * U - hw * n + 63 + n, NXI, p.wrap_x != 0);
   auto zq_fetch = [&](int k_first) __attribute__((always_inline)) {
     const unsigned wq = zq_own[(long long)min(k_first + lane, p.nz - 1) * p.zq_ld + j + MW_ZR_HALO];
-    zq_mask = __ballot((wq & ((K == 1) ? ~1u : ~0u)) != 0u) | ~__ballot(true);     // (all 64 lanes are here; a missing one would keep its bit)
+    zq_mask = __ballot((wq & zseg) != 0u) | ~__ballot(true);     // (all 64 lanes are here; a missing one would keep its bit)
   };
   if (zq_on) zq_fetch(kstart);
   // (bit i of zc_mask = "the row that iteration kstart + i stores to may hold something non-zero": the coupler's arrays in MODE 1 -- map MC,
@@ -1860,7 +1921,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   auto zc_fetch = [&](int k_first) __attribute__((always_inline)) {
     const int kq_ = (MODE == 1) ? min(max(k_first + lane - 2, ka), kb - 1) : min(k_first + lane, p.nz - 1);
     const unsigned wc = zc_map[(long long)kq_ * p.zq_ld + j + MW_ZR_HALO];
-    zc_mask = __ballot((wc & ((K == 1) ? ~1u : ~0u)) != 0u) | ~__ballot(true);
+    zc_mask = __ballot((wc & zseg) != 0u) | ~__ballot(true);
   };
   if (zc_on) zc_fetch(kstart);
   bool zc_store = true;

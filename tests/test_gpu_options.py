@@ -300,6 +300,15 @@ def test_zero_row_maps_are_exactly_what_the_design_says(mw):
     dm.get("cloud_liquid").copy_(cl * rho); dm.get("precip_liquid").copy_(pr * rho)
     rows = [torch.ones(nz, ny, dtype=torch.bool), (cl[..., 0] != 0).any(dim=2).cpu(), (pr[..., 0] != 0).any(dim=2).cpu()]
     m0 = sum((r.numpy().astype(np.uint32) << v) for v, r in enumerate(rows))
+    # ... and (round 6) the x segments: bits 4 .. 29 = "a tracer that can vanish may be non-zero in cells [s L, (s + 1) L) of the row", L = ceil(nx / 26),
+    # set for every segment within 9 cells (periodic) of a non-zero cell
+    cellnz = ((cl[..., 0] != 0) | (pr[..., 0] != 0)).cpu().numpy()
+    grown = cellnz.copy()
+    for d in range(1, 10):
+        grown |= np.roll(cellnz, d, axis=2) | np.roll(cellnz, -d, axis=2)
+    Lseg = (nx + 25) // 26
+    for sgm in range((nx + Lseg - 1) // Lseg):
+        m0 |= grown[:, :, sgm * Lseg:(sgm + 1) * Lseg].any(axis=2).astype(np.uint32) << np.uint32(4 + sgm)
     dycore.time_step(coupler, dycore.compute_time_step(coupler))
     L = capi.lib()
     dims = (C.c_int * 2)()
@@ -327,3 +336,7 @@ def test_zero_row_maps_are_exactly_what_the_design_says(mw):
         assert np.array_equal(maps[3 + s], levels_or(b, -3 * s - 6, 3 * s + 2)), ("FN", s)
         assert np.array_equal(maps[6 + s], levels_or(b, -3 * (s - 1), 3 * (s - 1))), ("QY", s)
     assert 0.02 < float((maps[7] & 6 != 0).mean()) < 0.6 and float((maps[1] & 6 != 0).mean()) < 1.0     # (the case has both kinds of row)
+    seg = (maps[1] >> 4) & ((1 << 26) - 1)
+    assert float((seg != 0).mean()) == float((maps[1] & 6 != 0).mean())                              # a row bit set <=> some segment set
+    busy = seg[seg != 0]
+    assert float(np.mean([bin(int(w)).count("1") for w in busy])) < 0.6 * ((nx + Lseg - 1) // Lseg)       # ... and busy rows are busy in part of their segments only
