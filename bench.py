@@ -259,6 +259,70 @@ def calibration(torch, device, stage_cells):
     return out
 
 
+class PowerSampler:
+    """Package power and shader clock of THIS process's card while a region runs (round 6: the stage runs against the board's power cap, and what a
+    state costs is set by the clock the part can hold on it -- profiles/r06_storm_vs_initial.json).  A thread reads the amdgpu hwmon files
+    (power1_average | power1_input in uW, freq1_input in Hz) of the card whose PCI address hipDeviceGetPCIBusId reports, every 10 ms; the step loop
+    spends its time inside ctypes calls, which release the GIL.  All failures are silent: the figures are evidence, not the measurement."""
+
+    def __init__(self, device_index=0, period=0.010):
+        import ctypes
+        import glob
+        import threading
+        self.files, self.rows, self.on, self.period, self.thread = {}, [], False, period, None
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+                return
+            want = buf.value.decode().lower()
+            for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+                if want not in os.path.realpath(os.path.join(h, "..", "..")).lower():
+                    continue
+                for key, names in (("power_uW", ("power1_average", "power1_input")), ("sclk_Hz", ("freq1_input",))):
+                    for n in names:
+                        f = os.path.join(h, n)
+                        if key not in self.files and os.path.exists(f):
+                            try:
+                                float(open(f).read()); self.files[key] = f
+                            except (OSError, ValueError):
+                                pass
+        except Exception:
+            self.files = {}
+        self._threading = threading
+
+    def _run(self):
+        while self.on:
+            r = {}
+            for k, f in self.files.items():
+                try:
+                    r[k] = float(open(f).read())
+                except (OSError, ValueError):
+                    pass
+            self.rows.append(r)
+            time.sleep(self.period)
+
+    def start(self):
+        self.rows = []
+        if self.files:
+            self.on = True
+            self.thread = self._threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+        return self
+
+    def stop(self):
+        if self.thread is not None:
+            self.on = False
+            self.thread.join()
+            self.thread = None
+        out = {"samples": len(self.rows)}
+        for k, scale, name in (("power_uW", 1e-6, "power_W"), ("sclk_Hz", 1e-6, "sclk_MHz")):
+            v = sorted(r[k] * scale for r in self.rows if k in r)
+            if v:
+                out[name] = {"mean": sum(v) / len(v), "min": v[0], "max": v[-1]}
+        return out if len(out) > 1 else None
+
+
 def rows_full_form(dycore):
     """Fraction of (level, row) words of the last sub-cycle's stage maps Q1..Q3 (mw_debug_zero_maps) in which cloud or rain may be non-zero: the
     rows whose iterations of the fused tracer kernel take the FULL form (the others neither load nor compute those two tracers).  None: no maps."""
@@ -429,7 +493,9 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
                                   "simulated_seconds": dt2 * (a.storm_steps - 3), "cell_updates_per_s": ncell * (a.storm_steps - 3) / loop_s}
         res["value_simulation_loop"] = ncell * (a.storm_steps - 3) / loop_s
         res["simulation_loop"]["nudger"] = "deferred (mw_nudge_to_column_deferred: the increments are added by the next time step's conversion; flushed at the end, inside the timed region)"
+        ps = PowerSampler(rho_d.device.index or 0).start()
         storm_ms = timed(lambda: d2.time_step(c2, dt2), 10)
+        res["power_storm"] = ps.stop()
         f2 = c2.get_data_manager_readonly()
         res["storm"] = {"state": "after %d steps of the complete supercell_example loop from the initial state" % a.storm_steps,
                         "ms_per_step": storm_ms, "cell_updates_per_s": ncell / storm_ms * 1e3,
@@ -457,7 +523,9 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
             d2.flush_pending()
             torch.cuda.synchronize()
             loop2_s = time.perf_counter() - t_loop
+            ps = PowerSampler(rho_d.device.index or 0).start()
             mature_ms = timed(lambda: d2.time_step(c2, dt2), 10)
+            res["power_mature"] = ps.stop()
             res["mature"] = {"state": "after %d steps (%.0f s simulated) of the complete supercell_example loop from the initial state" % (a.mature_steps, a.mature_steps * dt2),
                              "ms_per_step": mature_ms, "cell_updates_per_s": ncell / mature_ms * 1e3,
                              "max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()),
@@ -672,12 +740,14 @@ def main():
         step()
     sync()
     progress("warm-up done")
+    power = PowerSampler(local_rank).start()
     dycore.profile(3)                                            # ONE hipEvent pair per time_step on the handle's stream (pairs around every stage and the dominant kernel cost 1.5 % of the step: tools/event_overhead.py)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     sync()
     el = time.perf_counter() - t0
+    power_timed = power.stop()
     progress("timed region done")
     sched = dycore.schedule()                                    # what the timed time_steps ran (mw_dycore_schedule), not re-derived here
     KNAMES = ["xz_state", "tracer_patch", "tracer_update_unfused", "halo", "convert", "y_state", "y_tracers", "tracers_fused"]
@@ -939,6 +1009,8 @@ def main():
                          "calibration": cal,
                          "pipeline": {"alg_bytes_per_cell_update": 64 * V, "achieved": per_gpu * 64 * V / 1e9, "frac": per_gpu * 64 * V / 8.0e12}},
             "multi_gpu": multi,
+            "power": {"timed_region": power_timed, "what": "package power (hwmon power1_*) and shader clock (freq1_input) of this rank's card, sampled every 10 ms "
+                      "during the timed region (and during the storm / mature timings of the micro section); board limit 1400 W"},
             "kernel_ms_per_step": {k: v[0] / 3.0 for k, v in prof.items()},
             "kernel_ms_per_step_exclusive": ({k: v[0] / 3.0 for k, v in prof_excl.items()} if prof_excl else None),
         }
@@ -951,6 +1023,7 @@ def main():
             out["config"]["value_storm"] = out.get("value_storm")
             out["config"]["value_developed"] = out.get("value_developed")
             out["config"]["value_mature"] = out.get("value_mature")
+            out["power"]["storm"], out["power"]["mature"] = out.pop("power_storm", None), out.pop("power_mature", None)
             # ---- the roofline figure, state by state (the headline state is the best case: cloud and rain identically zero).  frac = SURVEY.md
             # 8(d)'s 32 V B per cell and stage with V = 8; frac_moved = the same with the variables that actually move: the six that are
             # never skipped plus cloud and rain in the share of rows whose tracer iterations take the full form (the zero-row maps)
