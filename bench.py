@@ -310,14 +310,19 @@ class PowerSampler:
             self.thread.start()
         return self
 
-    def stop(self):
+    def stop(self, window=None):
+        """window = (first, last) sample indices (negative: from the end) to summarise instead of all samples."""
         if self.thread is not None:
             self.on = False
             self.thread.join()
             self.thread = None
-        out = {"samples": len(self.rows)}
+        return self.stats(window)
+
+    def stats(self, window=None):
+        rows = self.rows if window is None else self.rows[window[0]:window[1]]
+        out = {"samples": len(rows)}
         for k, scale, name in (("power_uW", 1e-6, "power_W"), ("sclk_Hz", 1e-6, "sclk_MHz")):
-            v = sorted(r[k] * scale for r in self.rows if k in r)
+            v = sorted(r[k] * scale for r in rows if k in r)
             if v:
                 out[name] = {"mean": sum(v) / len(v), "min": v[0], "max": v[-1]}
         return out if len(out) > 1 else None
@@ -480,12 +485,17 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
         for _ in range(3):
             modules.supercell_step(c2, d2, m2, n2, dt2, defer_nudge=True)
         torch.cuda.synchronize()
+        ps_loop = PowerSampler(rho_d.device.index or 0, period=0.05).start()      # (20 samples per second: nothing the loop would notice)
         t_loop = time.perf_counter()
         for _ in range(a.storm_steps - 3):
             modules.supercell_step(c2, d2, m2, n2, dt2, defer_nudge=True)
         d2.flush_pending()                                       # (inside the timed region: the loop ends with every field whole)
         torch.cuda.synchronize()
         loop_s = time.perf_counter() - t_loop
+        ps_loop.stop()
+        # (the same loop, the same process: its first seconds run on the cloud-free state, its last on the storm -- 50 ms samples, 2 s windows)
+        res["power_loop"] = {"early_cloud_free": ps_loop.stats((20, 60)), "late_storm": ps_loop.stats((-40, None)),
+                             "what": "50 ms samples: seconds 1-3 and the last 2 s of the simulation loop (and of its continuation to the mature state)"}
         res["simulation_loop"] = {"what": "wall clock of the whole simulation loop the reference's benchmark driver times (community_benchmark/"
                                           "driver.cpp:66-82): %d iterations of dycore.time_step + micro.time_step + sponge_layer + "
                                           "nudge_to_column from the initial state, the storm developing inside it" % (a.storm_steps - 3),
@@ -493,9 +503,7 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
                                   "simulated_seconds": dt2 * (a.storm_steps - 3), "cell_updates_per_s": ncell * (a.storm_steps - 3) / loop_s}
         res["value_simulation_loop"] = ncell * (a.storm_steps - 3) / loop_s
         res["simulation_loop"]["nudger"] = "deferred (mw_nudge_to_column_deferred: the increments are added by the next time step's conversion; flushed at the end, inside the timed region)"
-        ps = PowerSampler(rho_d.device.index or 0).start()
         storm_ms = timed(lambda: d2.time_step(c2, dt2), 10)
-        res["power_storm"] = ps.stop()
         f2 = c2.get_data_manager_readonly()
         res["storm"] = {"state": "after %d steps of the complete supercell_example loop from the initial state" % a.storm_steps,
                         "ms_per_step": storm_ms, "cell_updates_per_s": ncell / storm_ms * 1e3,
@@ -517,15 +525,16 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
         if a.mature_steps > a.storm_steps:
             more = a.mature_steps - a.storm_steps
             torch.cuda.synchronize()
+            ps_loop = PowerSampler(rho_d.device.index or 0, period=0.05).start()
             t_loop = time.perf_counter()
             for _ in range(more):
                 modules.supercell_step(c2, d2, m2, n2, dt2, defer_nudge=True)
             d2.flush_pending()
             torch.cuda.synchronize()
             loop2_s = time.perf_counter() - t_loop
-            ps = PowerSampler(rho_d.device.index or 0).start()
+            ps_loop.stop()
+            res["power_loop"]["late_mature"] = ps_loop.stats((-40, None))
             mature_ms = timed(lambda: d2.time_step(c2, dt2), 10)
-            res["power_mature"] = ps.stop()
             res["mature"] = {"state": "after %d steps (%.0f s simulated) of the complete supercell_example loop from the initial state" % (a.mature_steps, a.mature_steps * dt2),
                              "ms_per_step": mature_ms, "cell_updates_per_s": ncell / mature_ms * 1e3,
                              "max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()),
@@ -1009,8 +1018,9 @@ def main():
                          "calibration": cal,
                          "pipeline": {"alg_bytes_per_cell_update": 64 * V, "achieved": per_gpu * 64 * V / 1e9, "frac": per_gpu * 64 * V / 8.0e12}},
             "multi_gpu": multi,
-            "power": {"timed_region": power_timed, "what": "package power (hwmon power1_*) and shader clock (freq1_input) of this rank's card, sampled every 10 ms "
-                      "during the timed region (and during the storm / mature timings of the micro section); board limit 1400 W"},
+            "power": {"timed_region": power_timed, "what": "package power (hwmon power1_*) and shader clock (freq1_input) of this rank's card, sampled every 10 ms: "
+                      "timed_region = the K timed steps (short: the package-power reading is still ramping up from idle there); simulation_loop = 2 s windows of the whole loop "
+                      "of the micro section, early (cloud-free) against late (storm, mature) -- the steady figures; board limit 1400 W"},
             "kernel_ms_per_step": {k: v[0] / 3.0 for k, v in prof.items()},
             "kernel_ms_per_step_exclusive": ({k: v[0] / 3.0 for k, v in prof_excl.items()} if prof_excl else None),
         }
@@ -1023,7 +1033,7 @@ def main():
             out["config"]["value_storm"] = out.get("value_storm")
             out["config"]["value_developed"] = out.get("value_developed")
             out["config"]["value_mature"] = out.get("value_mature")
-            out["power"]["storm"], out["power"]["mature"] = out.pop("power_storm", None), out.pop("power_mature", None)
+            out["power"]["simulation_loop"] = out.pop("power_loop", None)
             # ---- the roofline figure, state by state (the headline state is the best case: cloud and rain identically zero).  frac = SURVEY.md
             # 8(d)'s 32 V B per cell and stage with V = 8; frac_moved = the same with the variables that actually move: the six that are
             # never skipped plus cloud and rain in the share of rows whose tracer iterations take the full form (the zero-row maps)

@@ -2560,7 +2560,12 @@ static int flush_pending(mw_dycore_s *d) {
   d->pinc_on = false; d->pinc_eager++;
   return 0;
 }
-int mw_dycore_flush_pending(mw_dycore_t d) { if (!d) MW_FAIL("null handle"); fill_params(d); return flush_pending(d); }
+int mw_dycore_flush_pending(mw_dycore_t d) {
+  if (!d) MW_FAIL("null handle");
+  if (!d->pinc_on) return 0;                                    // (the Coupler mirrors call this in front of every field access: nothing parked = nothing done)
+  fill_params(d);
+  return flush_pending(d);
+}
 /* 1: increments are parked; out2 (may be NULL): how often parked increments rode on a conversion / were applied by a pass, since create */
 int mw_dycore_pending(mw_dycore_t d, unsigned long long *out2) {
   if (!d) return 0;

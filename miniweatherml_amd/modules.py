@@ -177,6 +177,7 @@ class Dynamics_Euler_Stratified_WenoFV:
     def time_step(self, coupler, dt_phys):
         with torch.cuda.device(coupler.device):
             check(capi.lib().mw_dycore_time_step(self.h, *[_ptr(t) for t in self._fields], self._tracer_ptrs, float(dt_phys)))
+        self._parked = False                                    # (parked column increments were consumed by the conversion, or applied at entry)
         self.etime += dt_phys
         PATH_LOG.append(self.path())
         if len(PATH_LOG) > 4096:                                # (a long run that nobody drains: keep the distinct entries)
@@ -208,10 +209,14 @@ class Dynamics_Euler_Stratified_WenoFV:
         check(capi.lib().mw_dycore_get_option(self.h, key.encode(), C.byref(v)))
         return v.value
 
+    _parked = False       # column increments may be parked in the handle (set by ColumnNudger.nudge_to_column(defer_to=self), cleared by time_step / flush)
+
     def flush_pending(self):
         """Applies column increments that ColumnNudger.nudge_to_column(..., defer_to=self) parked in this handle (mw_dycore_flush_pending); a
         no-op when there are none.  The coupler's DataManager calls it in front of every field access."""
-        check(capi.lib().mw_dycore_flush_pending(self.h))
+        if self._parked:
+            self._parked = False
+            check(capi.lib().mw_dycore_flush_pending(self.h))
 
     def pending(self):
         """(parked now, [rode on a conversion, applied by a pass]) -- mw_dycore_pending."""
@@ -561,6 +566,7 @@ class ColumnNudger:
                     dm.before_access.append(lambda: ref() is not None and ref().h and ref().flush_pending())
                     defer_to._flush_hook_dm = dm
                 check(capi.lib().mw_nudge_to_column_deferred(defer_to.h, _field_ptr_array(state), _ptr(self.column), float(dt), _ptr(ws), fn, ctx))
+                defer_to._parked = True
             else:
                 check(capi.lib().mw_nudge_to_column(C.byref(coupler.grid), _field_ptr_array(state), _ptr(self.column), float(dt),
                                                     _ptr(ws), fn, ctx, _stream_ptr(coupler.device)))
