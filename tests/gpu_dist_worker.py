@@ -19,7 +19,8 @@ def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     nxg, nyg, nz, nsteps = [int(v) for v in sys.argv[4:8]]
     mode = sys.argv[8] if len(sys.argv) > 8 else "dycore"
-    full = mode in ("full", "rccl_full")                    # the complete driver loop (Kessler, sponge, nudger with all-reduce)
+    full = mode in ("full", "rccl_full", "full_defer")      # the complete driver loop (Kessler, sponge, nudger with all-reduce)
+    defer = mode == "full_defer"                            # ... with the nudger's increments parked in the dycore handle (a decomposed block applies them with a pass at entry)
     rccl = mode.startswith("rccl")                          # one rank per GPU, the built-in RCCL transport (mw_rccl.cpp) over xGMI
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -48,10 +49,13 @@ def main():
     dt = dycore.compute_time_step(coupler)
     for _ in range(nsteps):
         if full:
-            modules.supercell_step(coupler, dycore, micro, nudger, dt)
+            modules.supercell_step(coupler, dycore, micro, nudger, dt, defer_nudge=defer)
         else:
             dycore.time_step(coupler, dt)
     torch.cuda.synchronize()
+    if defer:
+        parked, (rode, passes) = dycore.pending()
+        assert parked and rode == 0 and passes == nsteps - 1, (parked, rode, passes)   # the last call's increments are still parked; gpu_fields applies them
     g = gpu_fields(coupler)
     names = sorted(g)
     mine = np.stack([g[k] for k in names])

@@ -46,6 +46,13 @@ def test_two_processes_full_loop_with_allreduce():
     run_job(2, 24, 32, 12, 3, "full")
 
 
+def test_two_processes_full_loop_with_deferred_nudge():
+    """The same loop with ColumnNudger.nudge_to_column(defer_to=dycore) on every rank: the sums go through the all-reduce as before, the
+    increments are parked; a block of a decomposed domain applies them with a pass at the start of its next time step (its conversion is
+    part of the pipelined exchange), and the DataManager applies the last ones when the fields are read."""
+    run_job(2, 24, 32, 12, 3, "full_defer")
+
+
 def _ngpus():
     import torch
     return torch.cuda.device_count()
