@@ -115,7 +115,7 @@ def cpu_baseline(sample):
                       "(oracle/mw_oracle.cpp, -O2 -ffp-contract=off), %.1f s on 1 of %d host cores" % (nx, ny, nz, el, os.cpu_count())}
 
 
-# what the release build of the dycore kernels is compiled from (mw_fused.h only enters a -DMW_EXPERIMENTS build)
+# what the dycore kernels are compiled from
 KERNEL_SOURCES = ("mw_march.h", "mw_weno.h", "mw_weno79.h", "mw_common.h", "mw_calib.h", "mw_dycore.hip")
 
 

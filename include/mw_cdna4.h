@@ -109,12 +109,12 @@ int  mw_dycore_set_strict(mw_dycore_t h, int strict);
  * claim of the maps is checked against the data in front of the launch that relies on it -- mw_debug_zero_violations).
  * Launch shapes: "chunk_y", "chunk_yt", "chunk_z", "chunk_f" (cells per chunk, 0 = the chunk model), "chunk_model".  Built-in transport
  * (read when mw_dycore_use_rccl / _self installs it): "rccl_lanes" (0 = process default | 1 | 2), "rccl_two_comms" (-1 | 0 | 1), "rccl_prio" (1: side streams at the highest priority), "rccl_inline" (1: the group runs on the caller's stream, no side stream),
- * "xchg_fuzz" (seed of random delays around the sends / receives; a test aid).  Experiments that are not part of the release build:
- * "fused_state", "debug_no_patch" (-DMW_EXPERIMENTS), "sched", "sched_mask" (-DMW_SCHED_LISTS) -- setting them on a build without
- * them is an error.  Unknown keys and out-of-range values are errors. */
+ * "xchg_fuzz" (seed of random delays around the sends / receives; a test aid), "debug_no_patch" (a test aid: the y-face correction pass of the
+ * fused tracer stage is not launched -- the negative control of the FCT tests).  Unknown keys and out-of-range values are errors.  (The
+ * experiment builds of rounds 4-5 -- the fused x-y-z state kernel, the balanced launch lists, the timing hooks -- left the tree in round 6.) */
 int  mw_dycore_set_option(mw_dycore_t h, const char *key, long long value);
 int  mw_dycore_get_option(mw_dycore_t h, const char *key, long long *value);
-/* What this build of the library contains: bit 0 = -DMW_EXPERIMENTS, bit 1 = -DMW_SCHED_LISTS (tools/build_variant.sh); 0 = the release build. */
+/* Optional parts this build of the library contains: always 0 (there are none any more; kept in the ABI). */
 int  mw_build_flags(void);
 /* WENO order, the reference's compile-time -DMW_ORD (dynamics_euler_stratified_wenofv.h:24-29; 3 in build/machines/aws/aws_a100_gpu.env:21):
  * 5 (default), 3, 7 or 9.  Call before mw_dycore_init (the supercell initial data uses `ord` GLL points, :1725-1886).  Orders 3, 7

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmw_cdna4.so")
 SOURCES = ["mw_host.cpp", "mw_dycore.hip", "mw_kessler.hip", "mw_mlp.hip", "mw_column.hip", "mw_output.hip", "mw_netcdf.cpp", "mw_rccl.cpp", "mw_h5.cpp"]
-HEADERS = ["mw_common.h", "mw_weno.h", "mw_weno79.h", "mw_march.h", "mw_fused.h", "mw_calib.h", "mw_glibc_pow.h", "mw_glibc_pow_tables.h", os.path.join("..", "..", "include", "mw_cdna4.h")]
+HEADERS = ["mw_common.h", "mw_weno.h", "mw_weno79.h", "mw_march.h", "mw_calib.h", "mw_glibc_pow.h", "mw_glibc_pow_tables.h", os.path.join("..", "..", "include", "mw_cdna4.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-ffp-contract=on", "-I/opt/rocm/include"]

@@ -663,9 +663,6 @@ __global__ __launch_bounds__(256) void k_update(DyP p, const double *Sstar, cons
 
 } // namespace mw
 #include "mw_march.h"
-#ifdef MW_EXPERIMENTS
-#include "mw_fused.h"      // k_state_xyz: a measured dead end, kept as a tested experiment outside the release build
-#endif
 #include "mw_calib.h"      // calibration kernels: fp64 FMA ceiling, the arithmetic floor of a stage (WENO + Riemann on registers)
 namespace mw {
 
@@ -956,8 +953,7 @@ struct DyOpts {
   int rccl_prio = 1;           // ... its side streams at the highest stream priority (0: default priority; A/B)
   int rccl_inline = 1;         // ... the send / receive group on the caller's stream instead of a side stream of the transport's own
   int xchg_fuzz = 0;           // test aid: seeded random delays (spin kernels) around the built-in transport's sends / receives
-  int fused_state = 0, debug_no_patch = 0;            // -DMW_EXPERIMENTS builds only (mw_fused.h; the negative control of the FCT patch pass)
-  int sched = 0, sched_mask = 7;                      // -DMW_SCHED_LISTS builds only (balanced launch lists)
+  int debug_no_patch = 0;      // test aid: the y-face correction pass of the fused tracer stage is not launched (the negative control of the FCT tests)
 };
 
 struct mw_dycore_s {
@@ -1017,9 +1013,6 @@ struct mw_dycore_s {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[12];      // kernel classes 0..7; 8 = one whole RK stage (all its launches); 9 = one whole time_step; 10 / 11 = the compute stream's waits for the state / tracer strips (pipelined schedule)
   size_t ev_used[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   void (*xchg_free)(void *) = nullptr;       // set when the handle owns xchg_ctx (the built-in RCCL transport, mw_rccl.cpp)
-  // balanced launch lists (pick_sched): per (columns, cells, resident workgroups) the Sched with its device table
-  struct SchedEntry { const mw::Sched *dev; unsigned wgs; };
-  std::map<std::tuple<long long, int, int>, SchedEntry> sched_cache;
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2).  Padding the blocks-per-plane count to a
@@ -1312,84 +1305,11 @@ static int balanced_chunk(const mw_dycore_s *d, int nz, long long base_waves, in
   return (best < 0.97 * cost_of(old_chunk)) ? best_chunk : old_chunk;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The balanced schedule of the marching kernels (Sched, mw_march.h; round 4, an experiment that is kept behind MW_SCHED): a launch whose
-// workgroups are a longest-first list -- whole columns, then equal slices of the remaining columns sized for P = CUs x resident
-// workgroups per CU.  Against equal chunks this halves the ghost iterations (a whole column has none inside) and removes the partly
-// filled last round of workgroups; measured, it does not pay (see pick_sched).  The residency comes from the runtime's occupancy query
-// for the very kernel instantiation (registers, LDS), cached per kernel.
-// ---------------------------------------------------------------------------------------------------------------------
-#ifndef MW_SCHED_DEFAULT_MASK
-#define MW_SCHED_DEFAULT_MASK 7
-#endif
 static int device_cus() {
   static int n = -1;
   if (n < 0) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; else n = 0; }
   return n;
 }
-static int resident_blocks(const void *fn, size_t lds) {
-  static std::mutex mu; static std::map<std::pair<const void *, size_t>, int> cache;
-  std::lock_guard<std::mutex> lk(mu);
-  auto key = std::make_pair(fn, lds);
-  auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
-  int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
-  cache[key] = nb;
-  return nb;
-}
-// -> the schedule of one launch: nullptr = the chunked grid; else the DEVICE list (Sched header + the order of the straddling slices'
-// second parts), and `grid` becomes the list's length.  N columns of `len` cells.  Built once per (N, len, P) and handle.
-static const Sched *pick_sched(mw_dycore_s *d, const void *fn, size_t lds_balanced, long long N, int len, dim3 &grid, int which) {
-  // option "sched": 0 (default) the chunked grid; 1 the balanced lists where a launch has >= 16 cells per workgroup; 2 forced (tests).
-  // Measured (round 4, 400 x 400 x 100, two boxes, three interleaved repetitions each): k_y_all 1.47 -> 1.83 ms per step with the lists
-  // (its chunks keep x-adjacent workgroups on the same row at the same time -- DRAM pages are read out whole; slices start anywhere),
-  // k_xz_state 1.98-2.03 -> 2.01-2.04, k_tracers_fused 1.70 -> 1.65-1.68: -1 % of the step at best with the mask 6, so the default stays 0.
-#ifndef MW_SCHED_LISTS
-  (void)d; (void)fn; (void)lds_balanced; (void)N; (void)len; (void)grid; (void)which;
-  return nullptr;                                               // (the default build has no list code in its kernels, see Sched in mw_march.h)
-#else
-  const int mode = d->o.sched;
-  const int mask = d->o.sched_mask;                             // bit 0: k_y_all, bit 1: k_xz_state, bit 2: k_tracers_fused
-  if (mode == 0 || !((mask >> which) & 1) || d->overlap || N < 1 || N > 0x3fffffff || len < 1) return nullptr;
-  const int cus = device_cus(), occ = cus > 0 ? resident_blocks(fn, lds_balanced) : 0;
-  if (occ < 1) return nullptr;
-  const long long P = (long long)cus * occ;
-  if (mode != 2 && N * len < P * 16) return nullptr;            // small launches: the chunk model of balanced_chunk
-  const auto key = std::make_tuple(N, len, (int)P);
-  auto it = d->sched_cache.find(key);
-  if (it == d->sched_cache.end()) {
-    Sched n = {(int)P, 0, (int)N, len, 0, 0};
-    const long long q = N / P, R = N - q * P;
-    n.W = (int)(q * P);
-    std::vector<int> tab;
-    if (R) {
-      long long piece = (R * len + P - 1) / P;
-      if (piece < 8) piece = std::min<long long>(len, 8);        // (a segment re-primes its pipeline: none shorter than 8 cells)
-      n.piece = (int)piece;
-      n.nsl = (int)((R * len + piece - 1) / piece);
-      std::vector<std::pair<long long, int>> second;            // (cells behind the column boundary inside the slice, slice)
-      for (int sl = 0; sl < n.nsl; sl++) {
-        const long long g0 = sl * piece, g1 = std::min(g0 + piece, R * len), c = g0 / len, rest = g1 - (c + 1) * len;
-        if (rest > 0) second.push_back({rest, sl});
-      }
-      std::sort(second.begin(), second.end(), [](const std::pair<long long, int> &a, const std::pair<long long, int> &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
-      for (auto &pr : second) tab.push_back(pr.second);
-    }
-    std::vector<int> img(sizeof(Sched) / sizeof(int) + tab.size());
-    memcpy(img.data(), &n, sizeof(Sched));
-    if (!tab.empty()) memcpy(img.data() + sizeof(Sched) / sizeof(int), tab.data(), tab.size() * sizeof(int));
-    int *dev = nullptr;
-    if (hipMalloc(&dev, img.size() * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipMemcpy(dev, img.data(), img.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dev); return nullptr; }
-    mw_dycore_s::SchedEntry en; en.dev = (const Sched *)dev; en.wgs = (unsigned)(n.W + n.nsl + (int)tab.size());
-    it = d->sched_cache.emplace(key, en).first;
-  }
-  grid = dim3(it->second.wgs);
-  return it->second.dev;
-#endif
-}
-
 // Which compile-time configuration of the marching kernels (Cf<K>) fits this view of the handle: 1 / 2 = the shipped supercell /
 // simple_city set-ups with their run-time switches folded, 0 = everything at run time.  Option "spec" = 0 forces 0 (A/B timing, tests).
 static int marching_config(const mw_dycore_s *d, const DyP &p) {
@@ -1489,7 +1409,7 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
       row0 = MW_Y_EDGE; row_end = p.ny - MW_Y_EDGE; chunk = (row_end - row0 + n - 1) / n; grid.y = (unsigned)((row_end - row0 + chunk - 1) / chunk);
       fy_skip = 3;
     }
-#define MW_YAM(K_, O_, T_) MW_KLAUNCH((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, st, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, nullptr, pre_lo, pre_hi, fy_skip)
+#define MW_YAM(K_, O_, T_) MW_KLAUNCH((k_y_all<true, K_, O_, T_, true>), grid, dim3(256), 0, st, p, S, d->FY, d->tendY, chunk, *conv, const_cast<double *>(S), mo, row0, chunk, row_end, pre_lo, pre_hi, fy_skip)
 #define MW_YAM_O(K_, T_) { if (d->ord == 3) MW_YAM(K_, 3, T_); else MW_YAM(K_, 5, T_); }
     if (marching_config(d, p) == 1) MW_YAM_O(1, 3) else MW_YAM_O(2, 1)
 #undef MW_YAM_O
@@ -1516,11 +1436,8 @@ static int launch_y_all(mw_dycore_s *d, const double *S, const CouplerPtrs *conv
         if (split) { chunk = MW_Y_EDGE; rstride = p.ny - MW_Y_EDGE; grid.y = 2u; }
       }
     }
-    // (part 0 / 1 = one contiguous row range [row0, row_end): the balanced schedule applies; the two edge strips of part 2 stay chunks)
-#define MW_YA(C_, K_, O_, T_) do { dim3 g_ = grid; const Sched *sc_ = (part == 2) ? nullptr : \
-                                  pick_sched(d, (const void *)&k_y_all<C_, K_, O_, T_>, 0, (long long)grid.x, row_end - row0, g_, 0); \
-                                MW_KLAUNCH((k_y_all<C_, K_, O_, T_>), g_, dim3(256), 0, st, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
-                                                 conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, sc_, pre_lo, pre_hi, fy_skip); } while (0)
+#define MW_YA(C_, K_, O_, T_) MW_KLAUNCH((k_y_all<C_, K_, O_, T_>), grid, dim3(256), 0, st, p, v.S(S), d->FY + e * v.f[1], d->tendY + e * v.tend, chunk, \
+                                         conv ? *conv : CouplerPtrs(), const_cast<double *>(v.S(S)), MemberOff(), row0, rstride, row_end, pre_lo, pre_hi, fy_skip)
 #define MW_YA_O(K_, T_) { if (conv) { if (d->ord == 3) MW_YA(true, K_, 3, T_); else MW_YA(true, K_, 5, T_); } \
                           else      { if (d->ord == 3) MW_YA(false, K_, 3, T_); else MW_YA(false, K_, 5, T_); } }
     const int K = marching_config(d, p);
@@ -1597,7 +1514,7 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
       const size_t lds = (size_t)(chunk + 2) * 64 * 4;
 #define MW_XZ_MT(K_) { if (d->ord == 3) MW_XZ_MTO(K_, 3); else MW_XZ_MTO(K_, 5); }
 #define MW_XZ_MTO(K_, O_) MW_KLAUNCH((k_xz_state<3, true, 1, 1, K_, O_, true>), grid, dim3(256), lds, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
-                                        d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo, nullptr)
+                                        d->UP[par][0], d->UP[par][2], d->tendY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, mo)
       if (marching_config(d, p) == 1) MW_XZ_MT(1) else MW_XZ_MT(0)
 #undef MW_XZ_MT
 #undef MW_XZ_MTO
@@ -1614,11 +1531,8 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
     unsigned char *UX = d->UP[par][0] + e * v.m[0], *UZ = d->UP[par][2] + e * v.m[2];
     // nens == 1 (also: one member of a member-major handle): the per-level background values come through LDS
     // (k_xz_state<.., HPL = 1>; dynamic LDS = the chunk's rows)
-    // (balanced schedule: a segment can be a whole column -- the LDS table then holds nz + 2 rows)
-#define MW_XZ(N1_, HPL_, K_, O_, lds) do { dim3 g_ = grid; const size_t lds_bal_ = (lds) ? (size_t)(p.nz + 2) * 64 : 0; \
-                                        const Sched *sc_ = pick_sched(d, (const void *)&k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>, lds_bal_, (long long)grid.x, p.nz, g_, 1); \
-                                        MW_KLAUNCH((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), g_, dim3(256), sc_ ? lds_bal_ : (lds), d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
-                                                        MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, MemberOff(), sc_); } while (0)
+#define MW_XZ(N1_, HPL_, K_, O_, lds) MW_KLAUNCH((k_xz_state<STAGE, N1_, MODE, HPL_, K_, O_>), grid, dim3(256), (lds), d->stream, p, v.S(S), v.S(Sn), v.S(Sout), \
+                                                 MX, MZ, UX, UZ, tY, dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w, MemberOff())
 #define MW_XZ_K(K_) { if (d->ord == 3) MW_XZ(true, 1, K_, 3, hpl_bytes); else MW_XZ(true, 1, K_, 5, hpl_bytes); }
     const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
     if (p.nens == 1) {
@@ -1631,41 +1545,6 @@ static int launch_xz_state(mw_dycore_s *d, const double *S, const double *Sn, do
   return 0;
 }
 
-#ifdef MW_EXPERIMENTS
-// The state variables' complete stage in one launch (k_state_xyz, mw_fused.h): option "fused_state" (-DMW_EXPERIMENTS builds), folded configurations with periodic y
-// owned by this rank, nens = 1, WENO-5, ny a multiple of 4.  The stage is then k_state_xyz -> k_y_tracers -> k_tracers_fused.
-// (fused_state = 1 | 4: four row-waves per workgroup, two workgroups per CU; 8: eight, one workgroup per CU)
-static int fused_state_rows(const mw_dycore_s *d) {
-  const DyP &p = d->p;
-  const int v = d->o.fused_state, W = v == 8 ? 8 : 4;
-  const bool ok = v != 0 && !d->overlap && !d->pipe && d->fused && (d->ord == 5 || d->ord == 3) && p.nens == 1 && !p.sim2d && p.wrap_y && p.ny % W == 0 &&
-                  p.ny >= 2 * W && marching_config(d, p) != 0;
-  return ok ? W : 0;
-}
-static bool fused_state_ok(const mw_dycore_s *d) { return fused_state_rows(d) != 0; }
-template <int STAGE, int MODE>
-static int launch_state_xyz(mw_dycore_s *d, const double *S, const double *Sn, double *Sout, double dt_stage, double dt_dyn, int par, const CouplerPtrs &c) {
-  ProfScope ps(d, 0);
-  const DyP &p = d->p;
-  dim3 grid; int chunk, tiles_x;
-  if (xz_grid(d, p, grid, chunk, tiles_x)) return 1;
-  const int W = fused_state_rows(d);
-  grid.x = (unsigned)((p.ny / W) * tiles_x);
-  const size_t hpl_bytes = (size_t)(chunk + 2) * 64;
-#define MW_SXYZO(K_, W_, O_) MW_KLAUNCH((k_state_xyz<STAGE, MODE, K_, W_, O_>), grid, dim3(64 * W_), hpl_bytes, d->stream, p, S, Sn, Sout, d->M[par][0], d->M[par][2], \
-                                       d->UP[par][0], d->UP[par][2], d->M[par][1], d->UP[par][1], dt_stage, dt_dyn, chunk, tiles_x, c.u, c.v, c.w)
-#define MW_SXYZ(K_, W_) do { if (d->ord == 3) MW_SXYZO(K_, W_, 3); else MW_SXYZO(K_, W_, 5); } while (0)
-  if (W == 8) { if (marching_config(d, p) == 1) MW_SXYZ(1, 8); else MW_SXYZ(2, 8); }
-  else        { if (marching_config(d, p) == 1) MW_SXYZ(1, 4); else MW_SXYZ(2, 4); }
-#undef MW_SXYZ
-#undef MW_SXYZO
-  MW_LAUNCH_CHECK();
-  return 0;
-}
-
-#else
-static bool fused_state_ok(const mw_dycore_s *) { return false; }
-#endif
 
 template <int T, bool N1>
 static void launch_xz_tracers_t(mw_dycore_s *d, const double *S, dim3 grid, int chunk, int tiles_x, int t0, int par, double dt, int rows4,
@@ -1715,10 +1594,9 @@ template <int STAGE, int MODE, int T, bool N1, int K, int ORD = 5>
 static void launch_tracers_fused_t(mw_dycore_s *d, const View &v, const double *S, const double *Sn, double *Sout, dim3 grid, int chunk, int tiles_x, int par,
                                    double dt, double dt_dyn, const CouplerPtrs &c, int rows4, hipStream_t st) {
   const int e = v.e;
-  const Sched *sc = pick_sched(d, (const void *)&k_tracers_fused<STAGE, MODE, T, N1, K, ORD>, 0, (long long)grid.x, v.p.nz, grid, 2);
   MW_KLAUNCH((k_tracers_fused<STAGE, MODE, T, N1, K, ORD>), grid, dim3(256), 0, st, v.p, v.S(S), v.S(Sn), v.S(Sout), d->FY + e * v.f[1],
                      d->M[par][0] + e * v.m[0], d->M[par][2] + e * v.m[2], d->UP[par][0] + e * v.m[0], d->UP[par][2] + e * v.m[2],
-                     d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4, MemberOff(), sc);
+                     d->FX + e * v.f[0], d->FZ + e * v.f[2], d->flags + e * v.cells, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, rows4, MemberOff());
 }
 // x/z tracer fluxes + FCT + update in one kernel, then the (normally empty) y-face correction
 template <int STAGE, int MODE>
@@ -1739,7 +1617,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
 #define MW_FUSED_MT(TT) case TT: MW_FUSED_MTK(TT, 0) break;
 #define MW_FUSED_MTK(TT, K_) { if (d->ord == 3) MW_FUSED_MTO(TT, K_, 3); else MW_FUSED_MTO(TT, K_, 5); }
 #define MW_FUSED_MTO(TT, K_, O_) MW_KLAUNCH((k_tracers_fused<3, 1, TT, true, K_, O_, true>), grid, dim3(256), 0, st, p, S, Sn, Sout, d->FY, d->M[par][0], d->M[par][2], \
-                                 d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo, nullptr)
+                                 d->UP[par][0], d->UP[par][2], d->FX, d->FZ, d->flags, d->dirty + (d->fused_launches & 1), dt, dt_dyn, c, chunk, tiles_x, 0, mo)
       if (marching_config(d, p) == 1) MW_FUSED_MTK(3, 1)
       else switch (p.nt) { MW_FUSED_MT(1) MW_FUSED_MT(2) MW_FUSED_MT(3) MW_FUSED_MT(4) default: MW_FAIL("fused tracer stage needs 1..4 tracers"); }
 #undef MW_FUSED_MT
@@ -1771,7 +1649,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
     }
   }
   const DyP &p = d->p;
-  if (!p.sim2d && p.pos_mask && !d->o.debug_no_patch) {   // (the switch exists for the negative control in tests/, -DMW_EXPERIMENTS builds)
+  if (!p.sim2d && p.pos_mask && !d->o.debug_no_patch) {   // (the switch exists for the negative control in tests/)
     ProfScope ps(d, 1, st);
     for (int e = 0; e < n_views(d); e++) {
       const View v = view(d, e);
@@ -1844,14 +1722,9 @@ static int rk_stage_march(mw_dycore_s *d, double *Sin, const double *Sn, double 
   d->conv_pending = false;
   // (the converting launch of a member-major handle exists in the members-in-one-workgroup form of the folded configurations only)
   const bool mm_conv_ok = d->mm_direct && d->o.mm_conv && marching_config(d, view(d, 0).p) != 0;
-  const bool fxyz = fused_state_ok(d) && !conv;                 // (round 4 experiment: all three directions of the state variables in one launch)
-  const bool yall = !fxyz && y_all_ok(d) && !(conv && ((d->member_major && !mm_conv_ok) || !d->o.y_all_conv));   // y faces of state variables and tracers in one launch
+  const bool yall = y_all_ok(d) && !(conv && ((d->member_major && !mm_conv_ok) || !d->o.y_all_conv));   // y faces of state variables and tracers in one launch
   if (STAGE == 1) { if (conv) zero_rows_conv(d, Sin, false, ss); else zero_rows_forget(d, Sin); }   // (what is known about the rows of the slab that is about to be written)
   if (STAGE == 3 && MODE == 0) zero_rows_forget(d, Sout);
-#ifdef MW_EXPERIMENTS
-  if (fxyz) { if (launch_state_xyz<STAGE, MODE>(d, Sin, Sn, Sout, dt_stage, dt_dyn, par, c)) return 1; }
-  else
-#endif
   {
   if (conv && zero_rows_verify(d, 1, Sin, nullptr, false, c, ss)) return 1;
   if (yall) { if (halo_fill(d, Sin, 5, T, ts, 1, true) || launch_y_all(d, Sin, conv ? &c : nullptr)) return 1; }
@@ -2005,7 +1878,7 @@ static bool zero_rows_ok(const mw_dycore_s *d) {
   // (nens > 1: the member-major layout on one rank -- every member has its own maps and the per-member launches read them; the launches
   //  that hold all members of a tile in one workgroup run without)
   if (!(d->o.zero_skip && d->o.zero_rows && d->fused && (p.nens == 1 || (d->member_major && !d->xchg)) && p.nt >= 1 && p.nt <= 4 && !p.sim2d &&
-        !fused_state_ok(d) && p.nz >= 2 && p.bc_x == MW_BC_PERIODIC && p.bc_y == MW_BC_PERIODIC)) return false;
+        p.nz >= 2 && p.bc_x == MW_BC_PERIODIC && p.bc_y == MW_BC_PERIODIC)) return false;
   const long long nx_min = d->g.nx_glob / std::max(1, p.nproc_x), ny_min = d->g.ny_glob / std::max(1, p.nproc_y);
   if (ny_min < MW_ZR_HALO || nx_min < 2 * MW_ZR_HALO) return false;   // (a tracer must not cross a whole block in one sub-cycle)
   if (!d->xchg) return !d->overlap && !d->pipe;
@@ -2342,7 +2215,6 @@ void mw_dycore_destroy(mw_dycore_t d) {
   if (d->xchg_free && d->xchg_ctx) d->xchg_free(d->xchg_ctx);
   for (int g = 0; g < 2; g++) for (int b = 0; b < 8; b++) if (d->bufs[g][b]) (void)hipFree(d->bufs[g][b]);
   for (int w = 0; w < 12; w++) for (auto &pr : d->ev[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  for (auto &kv : d->sched_cache) if (kv.second.dev) (void)hipFree(const_cast<mw::Sched *>(kv.second.dev));
   delete d;
 }
 
@@ -2363,7 +2235,7 @@ int mw_dycore_set_strict(mw_dycore_t d, int strict) { if (!d) MW_FAIL("null hand
 
 // ---- run-time options (see DyOpts) ------------------------------------------------------------------------------------
 namespace {
-struct OptDesc { const char *key; int DyOpts::*field; long long lo, hi; int build; };   // build: 0 any, 1 -DMW_EXPERIMENTS, 2 -DMW_SCHED_LISTS
+struct OptDesc { const char *key; int DyOpts::*field; long long lo, hi; int build; };   // build: 0 = every build has it (the experiment builds of rounds 4-5 left the tree in round 6)
 const OptDesc OPTS[] = {
   {"overlap", &DyOpts::overlap, -1, 1, 0}, {"pipe", &DyOpts::pipe, 0, 1, 0}, {"pipe_edge_inline", &DyOpts::pipe_edge_inline, 0, 1, 0},
   {"pipe_convert", &DyOpts::pipe_convert, 0, 1, 0}, {"pipe_split_edges", &DyOpts::pipe_split_edges, 0, 1, 0}, {"spec", &DyOpts::spec, 0, 1, 0}, {"wrap", &DyOpts::wrap, 0, 1, 0},
@@ -2373,17 +2245,9 @@ const OptDesc OPTS[] = {
   {"chunk_z", &DyOpts::chunk_z, 0, 1 << 20, 0}, {"chunk_f", &DyOpts::chunk_f, 0, 1 << 20, 0}, {"chunk_model", &DyOpts::chunk_model, 0, 1, 0},
   {"tf_rows4", &DyOpts::tf_rows4, 0, 1, 0}, {"zero_skip", &DyOpts::zero_skip, 0, 1, 0}, {"zero_rows", &DyOpts::zero_rows, 0, 1, 0}, {"zero_stores", &DyOpts::zero_stores, 0, 1, 0}, {"zero_verify", &DyOpts::zero_verify, 0, 1, 0}, {"pipe_maps_early", &DyOpts::pipe_maps_early, 0, 1, 0}, {"rccl_lanes", &DyOpts::rccl_lanes, 0, 2, 0}, {"rccl_two_comms", &DyOpts::rccl_two_comms, -1, 1, 0},
   {"xchg_fuzz", &DyOpts::xchg_fuzz, 0, 0x7fffffff, 0}, {"rccl_prio", &DyOpts::rccl_prio, 0, 1, 0}, {"rccl_inline", &DyOpts::rccl_inline, 0, 1, 0},
-  {"fused_state", &DyOpts::fused_state, 0, 8, 1}, {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 1},
-  {"sched", &DyOpts::sched, 0, 2, 2}, {"sched_mask", &DyOpts::sched_mask, 0, 7, 2},
+  {"debug_no_patch", &DyOpts::debug_no_patch, 0, 1, 0},
 };
-constexpr int BUILD_FLAGS = 0
-#ifdef MW_EXPERIMENTS
-  | 1
-#endif
-#ifdef MW_SCHED_LISTS
-  | 2
-#endif
-  ;
+constexpr int BUILD_FLAGS = 0;      // (no optional parts any more: mw_build_flags stays in the ABI and says so)
 }
 int mw_build_flags(void) { return BUILD_FLAGS; }
 int mw_dycore_set_option(mw_dycore_t d, const char *key, long long value) {
@@ -2396,8 +2260,6 @@ int mw_dycore_set_option(mw_dycore_t d, const char *key, long long value) {
   }
   for (const OptDesc &od : OPTS) {
     if (strcmp(key, od.key)) continue;
-    if (od.build && !(BUILD_FLAGS & od.build) && value != (long long)(DyOpts().*(od.field)))     // (its default value is accepted: a no-op)
-      MW_FAIL(std::string("option ") + key + " exists in a " + (od.build == 1 ? "-DMW_EXPERIMENTS" : "-DMW_SCHED_LISTS") + " build of libmw_cdna4 only (tools/build_variant.sh)");
     if (value < od.lo || value > od.hi) MW_FAIL(std::string("option ") + key + ": value out of range [" + std::to_string(od.lo) + ", " + std::to_string(od.hi) + "]");
     d->o.*(od.field) = (int)value;
     if (!strncmp(key, "chunk_", 6)) d->chunk_y = d->chunk_yt = d->chunk_z = d->chunk_f = 0;      // (cached chunk sizes: decided again at the next launch)
@@ -2655,11 +2517,10 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
       d->path += " K" + std::to_string(K);
       d->path += p.nens == 1 ? " nens1" : d->mm_direct ? " mm_direct" : d->member_major ? " member_major" : " fused_members";
       d->path += d->pipe ? " pipe" : d->overlap ? " two_stream" : " one_stream";
-      d->path += (y_all_ok(d) && !fused_state_ok(d)) ? " y_all" : " y_split";
+      d->path += y_all_ok(d) ? " y_all" : " y_split";
       d->path += pipe_conv ? " conv_pipe" : d->conv_pending ? " conv_in_y" : " conv_pass";
       d->path += d->fused ? " tracers_fused" : " tracers_unfused";
       d->path += p.sim2d ? " 2d" : " 3d";
-      if (fused_state_ok(d)) d->path += " fused_state";
     } else d->path += p.nens == 1 ? " nens1" : " fused_members";
     if (d->xchg) d->path += " transport"; }
   if (d->pinc_on) {
@@ -2668,7 +2529,7 @@ int mw_dycore_time_step(mw_dycore_t d, double *rho_d, double *u, double *v, doub
     const bool same = c.rho_d == d->pinc_fields[0] && c.u == d->pinc_fields[1] && c.v == d->pinc_fields[2] && c.temp == d->pinc_fields[3] &&
                       p.idWV >= 0 && p.idWV < p.nt && c.tr[p.idWV] == d->pinc_fields[4];
     const bool lazy = same && march && d->conv_pending && !d->pipe && !d->overlap && !d->member_major && p.nens == 1 && marching_config(d, d->p) == 1 &&
-                      y_all_ok(d) && d->o.y_all_conv && !fused_state_ok(d);
+                      y_all_ok(d) && d->o.y_all_conv;
     if (lazy) { d->p.pinc = d->pinc; d->pinc_on = false; d->pinc_lazy++; }
     else if (flush_pending(d)) return 1;
   }
@@ -2937,7 +2798,7 @@ void *dycore_exchange_ctx(mw_dycore_t d, mw_exchange_fn *fn) { if (fn) *fn = d ?
 extern "C" const char *mw_dycore_path(mw_dycore_t d) { return d ? d->path.c_str() : ""; }
 extern "C" int mw_dycore_schedule(mw_dycore_t d) {
   if (!d) return -1;
-  return (d->pipe ? 2 : d->overlap ? 1 : 0) + (d->last_march && y_all_ok(d) && !fused_state_ok(d) ? 4 : 0) + (d->last_march ? 0 : 8);
+  return (d->pipe ? 2 : d->overlap ? 1 : 0) + (d->last_march && y_all_ok(d) ? 4 : 0) + (d->last_march ? 0 : 8);
 }
 
 // ---- init (:1197-1683): host column profiles + device quadrature --------------------------------------

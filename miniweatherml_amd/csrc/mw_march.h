@@ -94,60 +94,13 @@ __device__ __forceinline__ BlockXY xcd_block() {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Which (column, [a, b)) SEGMENT of the marching direction a workgroup processes (round 4).
-//   classic  (P == 0): blockIdx.x = column, blockIdx.y = chunk of `piece` cells.  Every chunk pays its ghost iterations (2 / 4 / 2
-//             for k_xz_state / k_tracers_fused / k_y_all) and the launch ends with a partly filled round of workgroups: 4 x 25
-//             levels on 400 x 400 x 100 are 5.47 rounds of the 512 workgroups the chip holds.
-//   balanced (P > 0 = the workgroups the chip holds at once): a one-dimensional launch whose workgroups are a LIST in dispatch order,
-//             longest items first, so that the hardware's in-order dispatch (next workgroup to the first free slot) is a greedy
-//             longest-first list schedule:
-//               W = q P whole columns                   (no ghost iterations inside a column; all in step from cell 0, so x-adjacent
-//                                                        tiles still meet in L2);
-//               the remaining R = N - W columns laid end to end and cut into `nsl` equal slices of `piece` cells (R len / P each):
-//               the part of a slice up to the first column boundary inside it ...
-//               ... and, for the slices that straddle a boundary, the part behind it: `n2` workgroups ordered by decreasing
-//               length (tab[] = their slices).  A straddling slice's first part is short, ends early, and the slot it frees takes the
-//               longest waiting second part -- its own -- so every slot ends after ~len q + piece cells.
-//   (A persistent form -- one workgroup looping over its segments -- keeps every kernel argument alive across the marching loop:
-//    60-160 SGPR spills in kernels that sit at the register limit.)
-//   MEASURED (round 4): k_y_all +24 %, k_xz_state +1.5 %, k_tracers_fused -2.5 %: no gain.  The balanced form is therefore
-//   only compiled with -DMW_SCHED_LISTS (tools/build_variant.sh lists -DMW_SCHED_LISTS; MW_SCHED=1|2 at run time; MW_TEST_SCHED_LISTS=1
-//   enables its tests); the default build takes the chunked grid unconditionally.
-// ---------------------------------------------------------------------------------------------------------------
-struct Sched { int P, W, N, len, piece, nsl; };   // in DEVICE memory, followed by tab[n2] (ints); a launch on the chunked grid passes nullptr
+// Which (column, [a, b)) SEGMENT of the marching direction a workgroup processes: blockIdx.x = column (XCD-swizzled), blockIdx.y = chunk of
+// `chunk` cells.  Every chunk pays its ghost iterations (2 / 4 / 2 for k_xz_state / k_tracers_fused / k_y_all).  (Round 4 measured a balanced
+// alternative -- one-dimensional launches whose workgroups are a longest-first list of whole columns and equal slices -- at k_y_all +24 %,
+// k_xz_state +1.5 %, k_tracers_fused -2.5 %: no gain; it left the tree in round 6, docs/rounds/DESIGN_rounds1-5.md section 0c.)
 struct Segment { unsigned col; int a, b; };
-__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg) {   // (see xcd_block: blocks b, b + 8, ... share an XCD)
-#if MW_XCD_SWIZZLE
-  const unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-#else
-  return b;
-#endif
-}
-// (the list is one pointer among the kernel arguments: passed by value, its seven words cost the marching kernels 5-13 more SGPR spills
-//  and 16 instructions per level -- they sit at the register limit -- although the default launch never looks at them)
-__device__ __forceinline__ bool sched_segment(const Sched *__restrict__ scp, int chunk, int len, Segment &sg) {
-#ifndef MW_SCHED_LISTS
-  // (the default build: the mere presence of the list branch costs k_xz_state 5 more SGPR spills and 16 instructions per level --
-  //  the segment then arrives as a phi of two paths -- for a schedule that measured no gain; -DMW_SCHED_LISTS builds it in, see Sched)
-  { const BlockXY blk = xcd_block(); sg.col = blk.x; sg.a = (int)blk.y * chunk; sg.b = min(sg.a + chunk, len); return true; }
-#else
-  if (scp == nullptr) { const BlockXY blk = xcd_block(); sg.col = blk.x; sg.a = (int)blk.y * chunk; sg.b = min(sg.a + chunk, len); return true; }
-  const Sched sc = *scp;
-  const int *__restrict__ tab = (const int *)(scp + 1);
-  unsigned b = blockIdx.x;
-  if (b < (unsigned)sc.W) { sg.col = xcd_remap(b, (unsigned)sc.W); sg.a = 0; sg.b = sc.len; return true; }
-  b -= (unsigned)sc.W;                                          // (W is a multiple of 8: the XCD of the block is b % 8 still)
-  const bool second = b >= (unsigned)sc.nsl;
-  const long long sl = second ? tab[b - (unsigned)sc.nsl] : xcd_remap(b, (unsigned)sc.nsl);
-  const long long R = sc.N - sc.W;
-  const long long g0 = sl * sc.piece, g1 = min(g0 + sc.piece, R * sc.len);
-  const int c = (int)(g0 / sc.len);
-  if (!second) { sg.col = (unsigned)(sc.W + c); sg.a = (int)(g0 - (long long)c * sc.len); sg.b = (int)min((long long)sc.len, sg.a + (g1 - g0)); return sg.b > sg.a; }
-  sg.col = (unsigned)(sc.W + c + 1); sg.a = 0; sg.b = (int)(g1 - (long long)(c + 1) * sc.len);   // (piece <= len: one boundary at most)
-  return sg.b > 0;
-#endif
+__device__ __forceinline__ void block_segment(int chunk, int len, Segment &sg) {
+  const BlockXY blk = xcd_block(); sg.col = blk.x; sg.a = (int)blk.y * chunk; sg.b = min(sg.a + chunk, len);
 }
 
 // Periodic direction owned by one rank (DyP::wrap_x / wrap_y): the interior index that a halo index stands for.
@@ -940,7 +893,7 @@ __device__ __forceinline__ double tracer_slab_value(double rho_t, double inv_den
 template <bool CONV, int K, int ORD, int T, bool MT = false>
 __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restrict__ S, double *__restrict__ FY, double *__restrict__ tendY, int chunk,
                                                CouplerPtrs c, double *__restrict__ Sw, MemberOff mo, int row0, int rstride, int row_end,
-                                               const Sched *__restrict__ scp, int pre_lo, int pre_hi, int fy_skip) {
+                                               int pre_lo, int pre_hi, int fy_skip) {
   static_assert(!MT || CONV, "the member-co-located form exists for the converting launch only");
   // (fy_skip: the pipelined multi-rank schedule runs the inner rows and the two edge strips as TWO launches, possibly of two different
   //  instantiations, side by side on two streams; both compute the faces row0 and row_end they share.  The edge launch owns their tracer
@@ -962,12 +915,7 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
     mt_sub = wv >> mo.sh;
     FY += em * mo.fy; tendY += em * mo.tend; Sw += em * mo.slab; S += em * mo.slab; p.hypk += em * mo.per; p.ce = em;
   }
-  // (scp != nullptr: the balanced schedule -- this workgroup's thread column and row segment [ja, jb) come from the launch's list, see Sched)
   unsigned colx; int ja, jb;
-#ifdef MW_SCHED_LISTS
-  if (scp) { Segment sg; if (!sched_segment(scp, 0, 0, sg)) return; colx = sg.col; ja = row0 + sg.a; jb = row0 + sg.b; }   // (the list's len = row_end - row0)
-  else
-#endif
   { colx = blockIdx.x; ja = row0 + (int)blockIdx.y * rstride; jb = min(ja + chunk, row_end); }   // (a launch covers the rows [row0, row_end) in chunks `rstride` rows apart: all of them, the inner ones, or the two edge strips)
   long long t = (long long)colx * 256 + threadIdx.x;             // flattened (k, ie): no idle tail per row
   if (MT) t = ((long long)colx * (4 >> mo.sh) + mt_sub) * 64 + (threadIdx.x & 63);
@@ -979,7 +927,7 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   const double hyr = hp[0], hyt = hp[1], p0 = hp[2], ihyt = hp[3];
   if (pinc_on) {
 #pragma unroll
-    for (int l = 0; l < 5; l++) lds_inc[l][threadIdx.x] = p.pinc[((long long)l * p.nz + k) * p.nens + e];
+    for (int l = 0; l < 5; l++) lds_inc[(CONV && !MT) ? l : 0][threadIdx.x] = p.pinc[((long long)l * p.nz + k) * p.nens + e];   // (the index: the array has one row in the forms that never get here)
   }
   const double *col = S + (long long)(k + p.HZ) * p.sK + (long long)p.HX * p.nens + ie;      // row j at col + (j+HY)*sJ
   double *fy = FY + (long long)k * p.fyK + ie;                                                // tracer v, face j at fy + (5+v)*fyV + j*fyJ
@@ -996,9 +944,10 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   /* the coupler's value + its parked column increment: the addition ColumnNudger's second pass would have stored (rounded once, no contraction) */
 #define MW_ROW_NUDGE(raw)                                                                                             \
   if (pinc_on) {                                                                                                      \
-    raw.rho_d = __dadd_rn(raw.rho_d, lds_inc[0][threadIdx.x]); raw.u = __dadd_rn(raw.u, lds_inc[1][threadIdx.x]);      \
-    raw.v = __dadd_rn(raw.v, lds_inc[2][threadIdx.x]); raw.temp = __dadd_rn(raw.temp, lds_inc[3][threadIdx.x]);        \
-    _Pragma("unroll") for (int tr_ = 0; tr_ < T; tr_++) if (Cf<K>::is_wv(p, tr_)) raw.tr[tr_] = __dadd_rn(raw.tr[tr_], lds_inc[4][threadIdx.x]); \
+    constexpr int LI_ = (CONV && !MT) ? 1 : 0;     /* (the array has one row in the forms that never get here) */           \
+    raw.rho_d = __dadd_rn(raw.rho_d, lds_inc[0][threadIdx.x]); raw.u = __dadd_rn(raw.u, lds_inc[1 * LI_][threadIdx.x]);      \
+    raw.v = __dadd_rn(raw.v, lds_inc[2 * LI_][threadIdx.x]); raw.temp = __dadd_rn(raw.temp, lds_inc[3 * LI_][threadIdx.x]);  \
+    _Pragma("unroll") for (int tr_ = 0; tr_ < T; tr_++) if (Cf<K>::is_wv(p, tr_)) raw.tr[tr_] = __dadd_rn(raw.tr[tr_], lds_inc[4 * LI_][threadIdx.x]); \
   }
   /* (skipv: wave-uniform -- the tracers that can vanish are zero in this row AND the slab row holds zeros already, see ym_ss) */
 #define MW_ROW_FINISH(raw, r, out, skipv)                                                                             \
@@ -1156,14 +1105,10 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
       double fp[5];
 #pragma unroll
       for (int l = 0; l < 5; l++) fp[l] = CONV ? lds_fprev[l][threadIdx.x] : fprev_r[l];
-#ifndef MW_EXP_NO_TENDY                                         // (timing experiment, DESIGN.md 0c: what the y-tendency hand-off costs)
       if (j > ja) {
 #pragma unroll
         for (int l = 0; l < 5; l++) ty[(long long)l * p.nC + (long long)(j - 1) * NXI] = -(f[l] - fp[l]) * p.rdy;
       }
-#else
-      if (j > ja && f[0] == 1.2345e300) ty[(long long)(j - 1) * NXI] = -(f[0] - fp[0]) * p.rdy + f[1] + f[2] + f[3] + f[4] + fp[1] + fp[2] + fp[3] + fp[4];
-#endif
 #pragma unroll
       for (int l = 0; l < 5; l++) { if (CONV) lds_fprev[l][threadIdx.x] = f[l]; else fprev_r[l] = f[l]; }
     }
@@ -1207,7 +1152,6 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
 //   What would close the gap is a member-major layout of the handle's internal arrays (every kernel then runs its nens = 1 path per
 //   member and only the coupler-side accesses are strided) -- not done.)
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool lane_init_xnb(unsigned t) { return (t & 63) < 4; }   // (MW_EXP_LDS_XNB: lanes 0..3 zero the row's four padding cells)
 struct XzGeom {
   int n, lane, NXI, j, q, qq, qa, e, i, qc, ka, kb, kstart;   // qq: index incl. halo (BC logic), qa: the index that is addressed (wrapped)
   int cell_lo, cell_hi, face_hi;                              // lanes [cell_lo, cell_hi) own a cell, [cell_lo, face_hi) a lower x face
@@ -1217,7 +1161,7 @@ struct XzGeom {
 // (nens == 1: hs + 1 halo lanes per side -- hs stencil cells and one more so that the west neighbour's east-edge value is rebuilt in
 //  the wave: 58 cells per wave for WENO-5, 60 for WENO-3)
 __host__ __device__ __forceinline__ int xz_cells_per_wave(int nens, int ord = 5) { return nens == 1 ? 64 - 2 * ((ord - 1) / 2 + 1) : 64 - 2 * nens; }
-// (colx = the workgroup's column of wavefronts, [ka, kb) = the levels it marches: from the launch grid or the balanced schedule, see Sched)
+// (colx = the workgroup's column of wavefronts, [ka, kb) = the levels it marches)
 template <bool N1, int ORD = 5>
 __device__ __forceinline__ XzGeom xz_geom(const DyP &p, unsigned colx, int ka, int kb, int tiles_x, int rows4 = 0, int wslot = -1, int wpb = 4) {
   static_assert(N1 || ORD == 5, "the neighbour-load form (nens > 1 in the fused layout) exists for WENO-5 only");
@@ -1281,7 +1225,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
                                                   unsigned char *__restrict__ UPX, unsigned char *__restrict__ UPZ,
                                                   const double *__restrict__ tendY, double dt_stage, double dt_dyn, int chunk,
                                                   int tiles_x, double *__restrict__ cu, double *__restrict__ cv, double *__restrict__ cw,
-                                                  MemberOff mo, const Sched *__restrict__ scp) {
+                                                  MemberOff mo) {
   static_assert(!MT || (N1 && HPL && MODE == 1), "the member-co-located form is the D13 variant of the nens == 1 kernel");
   constexpr int HS = (ORD - 1) / 2;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1293,13 +1237,9 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   }
   __shared__ double lds_c[8];
   __shared__ double lds_xpart[5][256], lds_fzprev[5][256];
-#ifdef MW_EXP_LDS_XNB
-  __shared__ double lds_xnb[5][4][68];
-  if (lane_init_xnb(threadIdx.x)) { for (int v = 0; v < 5; v++) { lds_xnb[v][threadIdx.x >> 6][(threadIdx.x & 63) < 2 ? (threadIdx.x & 63) : (threadIdx.x & 63) + 64] = 0.0; } }
-#endif
   extern __shared__ double lds_hp_all[];
-  Segment sg;                                                   // (from the launch grid or the balanced schedule's list, see Sched)
-  if (!sched_segment(scp, chunk, p.nz, sg)) return;
+  Segment sg;
+  block_segment(chunk, p.nz, sg);
   const XzGeom g = xz_geom<N1, ORD>(p, sg.col, sg.a, sg.b, tiles_x, 0, MT ? mt_sub : -1, MT ? 4 >> mo.sh : 4);
   const int seg_len = sg.b - sg.a;
   // HPL (nens == 1): the eight background values of every level of this chunk (DyP::hypk rows kstart..kb) are copied to LDS once
@@ -1359,58 +1299,16 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
 #pragma unroll
       for (int l = 0; l < 5; l++) snv[l] = Sn[(long long)l * p.sV + slab0 + (long long)(kfc + p.HZ) * p.sK];
     }
-#ifndef MW_EXP_NO_TENDY
     if (!Cf<K>::sim2d(p)) {
 #pragma unroll
       for (int l = 0; l < 5; l++) tyv[l] = tendY[(long long)l * p.nC + cell0 + (long long)kxc * planeC];
     }
-#endif
     if (Cf<K>::immersed(p)) immv = p.imm[cpl(p, cell0 + (long long)kfc * planeC)];
     double hpl[8];
     if (HPL) {
 #pragma unroll
       for (int f = 0; f < 8; f++) hpl[f] = lds_hp[(k - g.kstart) * 8 + f];
     }
-#ifdef MW_EXP_MOCK_Y
-    // Timing experiment, never a product path: the ARITHMETIC a y direction inside this kernel would add at the very
-    // least -- five reconstructions and one Riemann solve per level, on register data (the window's values in another order, so that
-    // nothing is shared with the z reconstruction) -- without the LDS tile, the barriers, the halo rows or the tile-edge faces a
-    // real fused kernel needs on top.  Together with MW_EXP_NO_TENDY (no y-tendency hand-off) it bounds such a kernel from below.
-    {
-      double ys[5], yn[5];
-#ifdef MW_EXP_MOCK_Y_LDS
-      // ... and the DATA MOVEMENT of an LDS-staged row tile (4 rows = the 4 waves of this workgroup, no halo rows, no tile-edge faces):
-      // every wave publishes its level, waits, takes its four "y neighbours" from the other waves' rows, publishes its north edge
-      // values, waits again and takes its southern neighbour's -- two workgroup barriers per level.
-      __shared__ double lds_tile[5][4][64], lds_edge[5][4][64];
-#pragma unroll
-      for (int v = 0; v < 5; v++) lds_tile[v][wv][lane] = w[v][HS];
-      __syncthreads();
-#pragma unroll
-      for (int v = 0; v < 5; v++) {                             // (one variable at a time: all twenty LDS reads hoisted in front of the arithmetic spill 50-80 VGPRs)
-        MW_SCHED_FENCE();
-        weno5_edges_fast(lds_tile[v][(wv + 2) & 3][lane], lds_tile[v][(wv + 3) & 3][lane], w[v][HS], lds_tile[v][(wv + 1) & 3][lane], lds_tile[v][(wv + 2) & 3][lane ^ 1], ys[v], yn[v]);
-      }
-      MW_SCHED_FENCE();
-#pragma unroll
-      for (int v = 0; v < 5; v++) lds_edge[v][wv][lane] = yn[v];
-      __syncthreads();
-#pragma unroll
-      for (int v = 0; v < 5; v++) yn[v] = lds_edge[v][(wv + 3) & 3][lane];
-#else
-#pragma unroll
-      for (int v = 0; v < 5; v++) weno5_edges_fast(w[v][1], w[v][0], w[v][HS], w[v][ORD - 1], w[v][ORD - 2], ys[v], yn[v]);
-#endif
-      const double *hp = p.hypk + (long long)(k * n + e) * 8;
-      const double hyr = HPL ? hpl[0] : hp[0], hyt = HPL ? hpl[1] : hp[1], p0 = HPL ? hpl[2] : hp[2], ihyt = HPL ? hpl[3] : hp[3];
-      double fn, fT;
-      FaceState fs = riemann_primary<K>(p, yn[idR] + hyr, ys[idR] + hyr, yn[idV], ys[idV], yn[idT], ys[idT], hyt, p0, ihyt, false, fn, fT);
-      const double z0 = lds_c[7];                               // (0 at run time, unknown to the compiler: the mock values are computed and do not disturb the run)
-      tyv[idR] += -(fs.m_upw - ct[idR]) * z0; tyv[idV] += -(fn - ct[idV]) * z0; tyv[idT] += -(fT - ct[idT]) * z0;
-      tyv[idU] += -(fs.m_upw * (fs.ind ? ys[idU] : yn[idU]) - ct[idU]) * z0;
-      tyv[idW] += -(fs.m_upw * (fs.ind ? ys[idW] : yn[idW]) - ct[idW]) * z0;
-    }
-#endif
     // ------------------------------------------------ X direction (cell k = window centre)
     double fxs[5];
     int upx = 0;
@@ -1423,17 +1321,6 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
         double c0 = w[v][HS], m2, m1, p1, p2;
         if (ORD == 3) { m1 = from_west<true>(c0, lane, n); p1 = from_east<true>(c0, lane, n); weno3_edges_fast(m1, c0, p1, we[v], ee[v]); }
         else {
-#ifdef MW_EXP_LDS_XNB
-          // Timing experiment: the four x neighbours through a wave-private LDS row (one write, four reads: LDS
-          // instructions) instead of four DPP wave shifts (eight VALU moves).  The row is padded by two zeros per side.
-          if (N1) {
-            lds_xnb[v][wv][lane + 2] = c0;
-            // (the other lanes' writes must be ordered before this lane's reads: per thread the addresses differ, so the compiler
-            //  would otherwise be free to hoist the reads; the LDS queue itself is in order per wave)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            m2 = lds_xnb[v][wv][lane]; m1 = lds_xnb[v][wv][lane + 1]; p1 = lds_xnb[v][wv][lane + 3]; p2 = lds_xnb[v][wv][lane + 4];
-          } else
-#endif
           x_neighbours<N1>(c0, col + (long long)v * p.sV + (long long)(k + p.HZ) * p.sK, g.om2, g.om1, g.op1, g.op2, lane, n, m2, m1, p1, p2);
           weno5_edges_fast(m2, m1, c0, p1, p2, we[v], ee[v]);
         }
@@ -1795,8 +1682,7 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
                                                        const double *__restrict__ MZ, const unsigned char *__restrict__ UPX,
                                                        const unsigned char *__restrict__ UPZ, double *__restrict__ DS,
                                                        double *__restrict__ DN, unsigned char *__restrict__ flags, unsigned int *__restrict__ dirty,
-                                                       double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4, MemberOff mo,
-                                                       const Sched *__restrict__ scp) {
+                                                       double dt, double dt_dyn, CouplerPtrs c, int chunk, int tiles_x, int rows4, MemberOff mo) {
   static_assert(N1 || ORD == 5, "the neighbour-load form exists for WENO-5 only");
   static_assert(!MT || (N1 && MODE == 1), "the member-co-located form (see MemberOff) is the D13 variant of the nens == 1 kernel");
   constexpr int HS = (ORD - 1) / 2;
@@ -1821,8 +1707,8 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
   const int U = 64 - 2 * hw * n;
   constexpr bool LC = true;
   __shared__ double lds_c[8];
-  Segment sg;                                                   // (from the launch grid or the balanced schedule's list, see Sched)
-  if (!sched_segment(scp, chunk, p.nz, sg)) return;
+  Segment sg;
+  block_segment(chunk, p.nz, sg);
   int j, tx;
   if (MT)         { const int rpb = 4 >> mo.sh, jg = (int)(sg.col / tiles_x); tx = (int)(sg.col - (unsigned)jg * tiles_x); j = jg * rpb + mt_sub; }   // rows of one tile
   else if (rows4) { const int jg = (int)(sg.col / tiles_x); tx = (int)(sg.col - (unsigned)jg * tiles_x); j = jg * 4 + (threadIdx.x >> 6); }

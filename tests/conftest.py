@@ -100,7 +100,7 @@ def pytest_sessionfinish(session, exitstatus):
 _DISPATCHED = {"k_y_all", "k_y_state", "k_y_tracers", "k_xz_state", "k_tracers_fused", "k_tracer_patch", "k_xz_tracers", "k_tracer_update",
                "k_flux", "k_fct", "k_update", "k_coupler_to_state", "k_coupler_to_state_fast", "k_coupler_to_member", "k_member_to_coupler",
                "k_member_to_fused", "k_halo_xyz", "k_pack_xy", "k_unpack_xy", "k_init_cells", "k_perturb_temperature",
-               "k_perturb_temperature_random", "k_state_xyz", "k_zero_rows", "k_zero_merge", "k_zero_halo", "k_zero_dilate"}
+               "k_perturb_temperature_random", "k_zero_rows", "k_zero_merge", "k_zero_halo", "k_zero_dilate"}
 
 
 def _compiled_dycore_kernels(lib_path):
@@ -144,7 +144,7 @@ def _coverage(session, rows):
     all_files = {os.path.basename(f) for f in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_*.py"))}
     ran_files = {os.path.basename(it.nodeid.split("::")[0]) for it in items}
     enforced = ran == len(want) and all_files <= ran_files and session.exitstatus == 0
-    base = lambda p: p.replace(" fused_state", "")                # noqa: E731  (the -DMW_EXPERIMENTS kernel rides on a production path)
+    base = lambda p: p                                            # noqa: E731
     cov = {"enforced": enforced, "paths_compared": dict(sorted(seen.items())), "reachable_paths": len(want),
            "missing_paths": sorted(set(want) - set(seen)), "unknown_paths": sorted(p for p in seen if base(p) not in set(want)),
            "kernels_never_compared": [], "kernels_compiled": None}

@@ -15,9 +15,6 @@ import torch
 from util import compare_fields, gpu_fields, push_fields, set_options
 
 pytestmark = pytest.mark.gpu
-# the balanced launch lists are an experiment that only a -DMW_SCHED_LISTS build contains: MW_TEST_SCHED_LISTS=1 adds their cases
-import os
-SCHEDS = ["0", "2"] if os.environ.get("MW_TEST_SCHED_LISTS") else ["0"]
 
 
 def test_config1_200x200x50_one_step_vs_oracle(mw, oracle):
@@ -111,15 +108,13 @@ def test_config3_surrogate_loop_400x400x100(mw, oracle):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("sched", SCHEDS)
-def test_config4_column_at_production_height_vs_oracle(mw, oracle, monkeypatch, sched):
+def test_config4_column_at_production_height_vs_oracle(mw, oracle, monkeypatch):
     """BASELINE.json configs[3] on a sampled sub-domain at the REAL column height and ensemble size: periodic 32 x 32 x 128 with 4
     members at config 4's spacing (dx = dy = 800 m, zlen 20 km) -- the member-major handle, D1 / D13 with the four members of a tile
     in one workgroup (MemberOff), the folded K = 1 kernels with their (nz + 2)-row LDS tables, z chunks as the production rule cuts
     128 levels.  Members differ (otherwise a member mix-up would go unnoticed).  Two dycore steps against the CPU oracle, tolerance of
-    BASELINE.md section 4 (1e-11 of each field's scale); also with the balanced launch lists forced (option sched = 2)."""
+    BASELINE.md section 4 (1e-11 of each field's scale)"""
     from miniweatherml_amd import modules
-    set_options(monkeypatch, sched=sched)
     nx, ny, nz, nens = 32, 32, 128, 4
     xlen, ylen, zlen = 800.0 * nx, 800.0 * ny, 2.0e4
     coupler, dycore, _ = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, zlen)
@@ -134,21 +129,20 @@ def test_config4_column_at_production_height_vs_oracle(mw, oracle, monkeypatch, 
         odyc.time_step(of, dt)
     sc = dycore.schedule()
     assert sc["y_all"] and not sc["general_kernels"]              # the production kernels ran (not the general path)
-    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "config4 column 32x32x128 nens 4 (sched=%s), 2 steps" % sched)
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "config4 column 32x32x128 nens 4, 2 steps")
     g = gpu_fields(coupler)
     assert not np.array_equal(g["temp"][..., 0], g["temp"][..., 1])
 
 
-@pytest.mark.parametrize("init,nx,ny,sched", [("city", 64, 64, "0"), ("building", 48, 48, "0")] + ([("building", 48, 48, "2")] if "2" in SCHEDS else []))
-def test_config5_column_at_production_height_vs_oracle(mw, oracle, monkeypatch, init, nx, ny, sched):
+@pytest.mark.parametrize("init,nx,ny", [("city", 64, 64), ("building", 48, 48)])
+def test_config5_column_at_production_height_vs_oracle(mw, oracle, monkeypatch, init, nx, ny):
     """BASELINE.json configs[4] on a sampled sub-domain at the REAL column height (256 levels, 5 m spacing, gravity off, water vapour
     only: V = 6, the folded K = 2 kernels with the immersed-boundary term).  `city` at 64 x 64 is the shipped initial state, but the
     reference pads its building blocks with 20 building lengths per side (:1432-1438): below 258 x 294 cells at 5 m there is no
     building -- the immersed term runs with proportion 0 everywhere.  `building` (:1604-1610: one block, 10 % of the domain wide, the
     lowest 20 % of the levels) puts immersed cells into a domain the CPU oracle steps in seconds.  Initial state bit-identical to the
-    oracle's, then two dycore steps at 1e-11; also with the balanced launch lists forced (option sched = 2)."""
+    oracle's, then two dycore steps at 1e-11"""
     from miniweatherml_amd import modules
-    set_options(monkeypatch, sched=sched)
     nz = 256
     xlen, ylen, zlen = 5.0 * nx, 5.0 * ny, 5.0 * nz
     coupler, dycore, _, _ = modules.make_simple_city(nx, ny, nz, 1, xlen, ylen, zlen, init)
@@ -166,7 +160,7 @@ def test_config5_column_at_production_height_vs_oracle(mw, oracle, monkeypatch, 
         odyc.time_step(of, dt)
     sc = dycore.schedule()
     assert sc["y_all"] and not sc["general_kernels"]
-    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "config5 %s column %dx%dx256 (sched=%s), 2 steps" % (init, nx, ny, sched))
+    compare_fields(gpu_fields(coupler), of.as_dict(), 1e-11, "config5 %s column %dx%dx256, 2 steps" % (init, nx, ny))
 
 
 def test_decomposed_block_without_transport_fails_loudly(mw):

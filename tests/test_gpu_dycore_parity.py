@@ -11,7 +11,7 @@ import numpy as np
 import torch
 import pytest
 
-from util import build_has, compare_fields, record_comparison, gpu_fields, oracle_sensitivity, push_fields, sens_allowed, set_options
+from util import compare_fields, record_comparison, gpu_fields, oracle_sensitivity, push_fields, sens_allowed, set_options
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -73,71 +73,6 @@ def test_time_steps_match_oracle(mw, oracle, name, mode):
         odyc.time_step(of, dt)
     compare_fields(gpu_fields(coupler), of.as_dict(), 1e-9, "%s mode %d, 10 steps" % (name, mode), sens[10])
     assert abs(dycore.etime - 10 * dt) < 1e-12
-
-
-@pytest.mark.parametrize("name", sorted(SNAP["cases"]))
-def test_balanced_schedule_bitwise_equal_to_chunked_grid(mw, oracle, name, monkeypatch):
-    """The marching kernels' balanced launch lists (round 4: whole columns first, then equal slices of the remaining columns, the parts
-    of a slice behind a column boundary last; option sched = 2 forces them at any size) only re-partition the marching direction: the
-    production path's results are BITWISE those of the chunked grid (sched = 0), and match the oracle."""
-    if not build_has(2):
-        pytest.skip("the balanced launch lists exist in a -DMW_SCHED_LISTS build only (a measured dead end, DESIGN.md 0c)")
-    res = {}
-    for sched in ("0", "2"):
-        set_options(monkeypatch, sched=sched)
-        coupler, dycore, odyc, of = setup_case(oracle, SNAP["cases"][name])
-        push_fields(coupler, of)
-        dt = dycore.compute_time_step(coupler)
-        for _ in range(3):
-            dycore.time_step(coupler, dt)
-        res[sched] = gpu_fields(coupler)
-    for k in res["0"]:
-        assert np.array_equal(res["0"][k], res["2"][k]), k
-    for _ in range(3):
-        odyc.time_step(of, dt)
-    sens = case_sensitivity(oracle, name, (3,)) if sens_allowed(name) else {3: None}
-    compare_fields(res["2"], of.as_dict(), 1e-10, "%s mode 0 balanced schedule, 3 steps" % name, sens[3])
-
-
-@pytest.mark.parametrize("order", [5, 3])
-@pytest.mark.parametrize("case", ["supercell", "city"])
-def test_fused_state_stage_bitwise_equal_to_production(mw, oracle, case, order, monkeypatch):
-    """Option fused_state (-DMW_EXPERIMENTS builds): the state variables' x, y AND z faces in one z-marching launch (k_state_xyz, mw_fused.h: the y stencil from an
-    LDS tile of the workgroup's four rows, tile-edge faces rebuilt inside the workgroup, three barriers per level) instead of k_y_all's
-    state part + k_xz_state; the tracers' y fluxes then come from k_y_tracers.  Statement by statement the same arithmetic: the
-    coupler's fields after several steps (one of them sub-cycled) are BITWISE those of the production schedule; also against the oracle."""
-    from miniweatherml_amd import modules
-    if not build_has(1):
-        pytest.skip("k_state_xyz (mw_fused.h) is a measured dead end kept outside the release build: -DMW_EXPERIMENTS (tools/build_variant.sh)")
-    res = {}
-    for fused in ("0", "1", "8"):                              # 1: four row-waves per workgroup, 8: eight (one workgroup per CU)
-        set_options(monkeypatch, fused_state=fused, chunk_z=7)  # several z chunks with ghost levels on these small grids
-        if case == "supercell":
-            coupler, dycore, _ = modules.make_supercell(130, 24, 26, 1, 65000., 12000., 20000., ord=order)
-            dm = coupler.get_data_manager_readwrite()
-            dm.get("cloud_liquid").fill_(3.0e-4); dm.get("precip_liquid").fill_(1.0e-4)
-        else:
-            coupler, dycore, _, _ = modules.make_simple_city(96, 48, 16, 1, 480., 240., 80., "building", ord=order)
-        dt = dycore.compute_time_step(coupler)
-        for n in range(3):
-            dycore.time_step(coupler, dt * (2.2 if n == 1 else 1.0))
-        assert dycore.schedule()["code"] & 3 == 0
-        res[fused] = gpu_fields(coupler)
-    for k in res["0"]:
-        if order == 3 and case == "city":
-            # WENO-3 under contract(fast): two instantiations of the same statements may fuse a different multiply-add pair (see
-            # test_folded_configurations_are_bitwise_the_run_time_switches) -- rounding-level agreement is what can be asked of this pair
-            scale = max(float(np.abs(res["0"]["uvel"]).max()), float(np.abs(res["0"][k]).max()))
-            for other in ("1", "8"):
-                d = float(np.abs(res["0"][k] - res[other][k]).max())
-                assert d <= 1e-12 * scale, (k, other, d, scale)
-            continue
-        assert np.array_equal(res["0"][k], res["1"][k]), k
-        assert np.array_equal(res["0"][k], res["8"][k]), k
-    # (the experiment is held to the PRODUCTION path bit for bit, and that path to the oracle elsewhere: credited to the coverage matrix as such)
-    record_comparison("fused state stage (k_state_xyz, -DMW_EXPERIMENTS) bitwise equal to the production path, %s order %d" % (case, order))
-    if case == "supercell":
-        assert float(np.abs(res["1"]["vvel"]).max()) > 0.0     # the y direction is alive
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -379,8 +314,6 @@ def test_fct_limiter_heavy(mw, oracle, fused, shape, monkeypatch, overlap):
 def test_fct_patch_pass_is_exercised(mw, oracle, monkeypatch):
     """Negative control for the test above: with the y-face correction pass switched off the fused path must MISS the
     oracle on the limiter-heavy case (i.e. donors in neighbouring rows really do scale y faces there)."""
-    if not build_has(1):
-        pytest.skip("the no-patch switch of the negative control exists in a -DMW_EXPERIMENTS build only")
     set_options(monkeypatch, debug_no_patch=1)
     with pytest.raises(AssertionError):
         test_fct_limiter_heavy(mw, oracle, "1", (70, 9, 12, 1), monkeypatch, "0")

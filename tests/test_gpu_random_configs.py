@@ -31,9 +31,6 @@ def test_random_configuration(mw, oracle, seed, monkeypatch):
     from miniweatherml_amd import modules
     c = draw(seed)
     set_options(monkeypatch, **c["chunks"])
-    # every other seed: the balanced launch lists (Sched, mw_march.h; only in a -DMW_SCHED_LISTS build, MW_TEST_SCHED_LISTS=1) forced at these small sizes -- whole columns, slices, and the second
-    # parts of slices that straddle a column boundary; the others run the chunked grid with the drawn chunk sizes
-    set_options(monkeypatch, sched=2 if (seed % 2 and os.environ.get("MW_TEST_SCHED_LISTS")) else 0)
     nx, ny, nz, nens, nt = c["nx"], c["ny"], c["nz"], c["nens"], c["nt"]
     xlen, ylen = 500.0 * nx, 500.0 * max(ny, 2)
 

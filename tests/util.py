@@ -29,12 +29,6 @@ def set_options(monkeypatch, **opts):
         monkeypatch.setitem(modules.DEFAULT_OPTIONS, k, int(v))
 
 
-def build_has(bit):
-    """1: a -DMW_EXPERIMENTS build of libmw_cdna4 (mw_fused.h, the no-patch negative control), 2: -DMW_SCHED_LISTS (mw_build_flags)."""
-    from miniweatherml_amd import capi
-    return bool(capi.lib().mw_build_flags() & bit)
-
-
 def launched_kernels(reset=True):
     """Mangled names of the dycore kernels this process has launched since the last reset (mw_debug_launched_kernels)."""
     from miniweatherml_amd import capi

@@ -13,7 +13,7 @@ objs=""
 for s in mw_host.cpp mw_dycore.hip mw_kessler.hip mw_mlp.hip mw_column.hip mw_output.hip mw_netcdf.cpp mw_rccl.cpp mw_h5.cpp; do
   o=/tmp/mwvar_$name/${s%.*}.o
   x=""; case $s in *.hip) x="-x hip";; esac
-  extra=""; case $s in *.hip) extra="$*";; esac      # (the extra flags reach every HIP source: -DMW_EXPERIMENTS, -DMW_KES_SWEEP=1, ...)
+  extra=""; case $s in *.hip) extra="$*";; esac      # (the extra flags reach every HIP source: -DMW_KES_SWEEP=1, -DMW_ZERO_SKIP=0, ...)
   /opt/rocm/bin/hipcc $FLAGS $extra $x -c $C/$s -o $o &
   objs="$objs $o"
 done
