@@ -1656,7 +1656,7 @@ static int launch_tracers_fused(mw_dycore_s *d, const double *S, const double *S
       const DyP &q = v.p;
       // (member-major: every member's launch reads the same `dirty` word; only the last one may clear the next stage's word)
       unsigned int *next = (e == n_views(d) - 1) ? d->dirty + ((d->fused_launches + 1) & 1) : d->dirty + 2;
-      MW_KLAUNCH((k_tracer_patch<STAGE, MODE>), plane_grid((long long)q.ny * q.nx * q.nens, (q.nz + MW_PATCH_LEVELS - 1) / MW_PATCH_LEVELS), dim3(256), 0, st, q,
+      MW_KLAUNCH((k_tracer_patch<STAGE, MODE>), plane_grid((long long)q.ny * ((q.nx * q.nens + MW_PATCH_CELLS - 1) / MW_PATCH_CELLS), q.nz), dim3(256), 0, st, q,
                          v.S(Sout), d->flags + e * v.cells, d->FX + e * v.f[0], d->FZ + e * v.f[2], dt_dyn, c, d->dirty + (d->fused_launches & 1), next);
       MW_LAUNCH_CHECK();
     }

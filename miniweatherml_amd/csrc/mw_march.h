@@ -2048,8 +2048,15 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 }
 
 // Receiver-centred correction for y faces whose donor (the row above or below) scaled them: see k_tracers_fused.
+// Two phases per wavefront (round 6; the byte-per-lane scan of rounds 2-5 took 40-60 us per launch on the mature storm, where one cell in a
+// few hundred is flagged -- the scan was the kernel):
+//   scan    : thread = (level, row, 8 consecutive cells): the flag bytes of the two neighbouring rows come as ONE 8-byte word each (512
+//             contiguous bytes per request); a wavefront whose 2 x 512 bytes are clear leaves at once;
+//   correct : the wavefront's 512 cells in eight passes of 64, lane = cell (the words handed over by ds_bpermute), so that flagged cells that
+//             are neighbours in x -- cloud rims are -- share their requests as they did when a lane was a cell; passes without a flag are
+//             skipped wave-uniformly.
+#define MW_PATCH_CELLS 8
 template <int STAGE, int MODE>
-#define MW_PATCH_LEVELS 8
 __global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const unsigned char *__restrict__ flags,
                                                       const double *__restrict__ DS, const double *__restrict__ DN, double dt_dyn,
                                                       CouplerPtrs c, const unsigned int *__restrict__ dirty, unsigned int *dirty_next) {
@@ -2058,59 +2065,70 @@ __global__ __launch_bounds__(256) void k_tracer_patch(DyP p, double *Sout, const
   // cleared here for the next stage's k_tracers_fused (launches on the tracer stream are serial).
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *dirty_next = 0u;
   if (*dirty == 0u) return;
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int NXI = p.nx * p.nens;
-  if (t >= (long long)p.ny * NXI) return;
-  const int j = (int)(t / NXI), ie = (int)(t - (long long)j * NXI);
-  // Busy case (some y face WAS scaled somewhere: any developed storm): the two flag bytes of all of this thread's levels are
-  // requested together -- one memory latency instead of one per level -- and a thread without a flagged neighbour leaves at once.
-  const int kb0 = blockIdx.y * MW_PATCH_LEVELS, kb1 = min(p.nz, kb0 + MW_PATCH_LEVELS);
-  unsigned fNv[MW_PATCH_LEVELS], fSv[MW_PATCH_LEVELS], anyf = 0u;
-#pragma unroll
-  for (int m = 0; m < MW_PATCH_LEVELS; m++) {
-    const long long cim = ((long long)min(kb0 + m, p.nz - 1) * p.ny + j) * NXI + ie;
-    fNv[m] = (j + 1 < p.ny) ? flags[cim + NXI] : 0u;            // northern neighbour scaled its south face = my north face
-    fSv[m] = (j >= 1) ? flags[cim - NXI] : 0u;                  // southern neighbour scaled its north face = my south face
+  const int G = (NXI + MW_PATCH_CELLS - 1) / MW_PATCH_CELLS;      // groups of 8 cells per row
+  const long long nthr = (long long)p.ny * G;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  // byte m of wN = the northern neighbour's flags (it scaled its south face = cell m's north face), of wS = the southern neighbour's
+  unsigned long long wN = 0ull, wS = 0ull;
+  if (t < nthr) {
+    const int j = (int)(t / G), ie0 = (int)(t - (long long)j * G) * MW_PATCH_CELLS;
+    const long long ci0 = ((long long)k * p.ny + j) * NXI + ie0;
+    if (((NXI & (MW_PATCH_CELLS - 1)) == 0) && ((reinterpret_cast<unsigned long long>(flags) & 7ull) == 0ull)) {
+      if (j + 1 < p.ny) wN = *reinterpret_cast<const unsigned long long *>(flags + ci0 + NXI);
+      if (j >= 1)       wS = *reinterpret_cast<const unsigned long long *>(flags + ci0 - NXI);
+    } else {                                                     // (rows that are not a multiple of 8 cells: byte by byte)
+      for (int m = 0; m < MW_PATCH_CELLS; m++) {
+        if (ie0 + m >= NXI) break;
+        if (j + 1 < p.ny) wN |= (unsigned long long)flags[ci0 + NXI + m] << (8 * m);
+        if (j >= 1)       wS |= (unsigned long long)flags[ci0 - NXI + m] << (8 * m);
+      }
+    }
   }
-#pragma unroll
-  for (int m = 0; m < MW_PATCH_LEVELS; m++) anyf |= (kb0 + m < kb1) ? ((fNv[m] & 0x55u) | (fSv[m] & 0xAAu)) : 0u;
-  if (anyf == 0u) return;
-#pragma unroll
-  for (int m = 0; m < MW_PATCH_LEVELS; m++) {
-  const int k = kb0 + m;
-  if (k >= kb1) break;
-  const long long ci = ((long long)k * p.ny + j) * NXI + ie;
-  const unsigned fN = fNv[m], fS = fSv[m];
-  if (((fN & 0x55u) | (fS & 0xAAu)) == 0u) continue;
-  const int e = ie % p.nens;
-  const long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
-  const double rho_new = Sout[so + idR * p.sV] + p.hyc[k * p.nens + e];
-  const double inv_rho_new = fast_rcp(rho_new);
+  wN &= 0x5555555555555555ull; wS &= 0xAAAAAAAAAAAAAAAAull;        // (the bits a receiver looks at)
+  const unsigned long long busy = __ballot((wN | wS) != 0ull);     // lanes (= 8-cell groups) with a flagged cell
+  if (busy == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const long long t0 = t - lane;                                 // the wavefront's first group
   const double cdt = (STAGE == 1) ? dt_dyn : (STAGE == 2) ? (1.0 / 4.0) * dt_dyn : (2.0 / 3.0) * dt_dyn;
-  for (int v = 0; v < p.nt && v < 4; v++) {
-    double dN = 0, dS = 0;
-    if ((fN >> (2 * v)) & 1u) dN = DS[(long long)(5 + v) * p.fxV + (long long)k * p.fxK + (long long)(j + 1) * p.fxJ + ie];
-    if ((fS >> (2 * v)) & 2u) dS = DN[(long long)(5 + v) * p.fzV + (long long)k * p.fzK + (long long)(j - 1) * p.fzJ + ie];
-    if (dN == 0 && dS == 0) continue;
-    const double corr = cdt * ((dN - dS) * p.rdy);                // tend' = tend - (dN - dS)/dy
-    if (MODE == 0) {
-      const double qp = Sout[so + (5 + v) * p.sV] * rho_new;
-      Sout[so + (5 + v) * p.sV] = fmax(0.0, qp - corr) * inv_rho_new;
-    } else {
-      c.tr[v][cpl(p, ci)] = fmax(0.0, c.tr[v][cpl(p, ci)] - corr);
+#pragma unroll 1
+  for (int s = 0; s < 8; s++) {                                  // pass s: the 64 cells of groups 8 s .. 8 s + 7
+    if (((busy >> (8 * s)) & 0xFFull) == 0ull) continue;
+    const int src = 8 * s + (lane >> 3), sh = 8 * (lane & 7);
+    const unsigned fN = (unsigned)(__shfl(wN, src, 64) >> sh) & 0xFFu, fS = (unsigned)(__shfl(wS, src, 64) >> sh) & 0xFFu;
+    if ((fN | fS) == 0u) continue;
+    const long long ts = t0 + src;                               // the group this lane's cell belongs to (flagged => ts < nthr, ie < NXI)
+    const int j = (int)(ts / G), ie = (int)(ts - (long long)j * G) * MW_PATCH_CELLS + (lane & 7);
+    const long long ci = ((long long)k * p.ny + j) * NXI + ie;
+    const int e = ie % p.nens;
+    const long long so = (long long)(k + p.HZ) * p.sK + (long long)(j + p.HY) * p.sJ + (long long)p.HX * p.nens + ie;
+    const double rho_new = Sout[so + idR * p.sV] + p.hyc[k * p.nens + e];
+    const double inv_rho_new = fast_rcp(rho_new);
+    for (int v = 0; v < p.nt && v < 4; v++) {
+      double dN = 0, dS = 0;
+      if ((fN >> (2 * v)) & 1u) dN = DS[(long long)(5 + v) * p.fxV + (long long)k * p.fxK + (long long)(j + 1) * p.fxJ + ie];
+      if ((fS >> (2 * v)) & 2u) dS = DN[(long long)(5 + v) * p.fzV + (long long)k * p.fzK + (long long)(j - 1) * p.fzJ + ie];
+      if (dN == 0 && dS == 0) continue;
+      const double corr = cdt * ((dN - dS) * p.rdy);                // tend' = tend - (dN - dS)/dy
+      if (MODE == 0) {
+        const double qp = Sout[so + (5 + v) * p.sV] * rho_new;
+        Sout[so + (5 + v) * p.sV] = fmax(0.0, qp - corr) * inv_rho_new;
+      } else {
+        c.tr[v][cpl(p, ci)] = fmax(0.0, c.tr[v][cpl(p, ci)] - corr);
+      }
     }
-  }
-  if (MODE == 1) {
-    double rho_dry = rho_new, rho_v = 0;
-    for (int v = 0; v < p.nt; v++) {
-      const double qv = c.tr[v][cpl(p, ci)];
-      if (v == p.idWV) rho_v = qv;
-      if ((p.mass_mask >> v) & 1u) rho_dry -= qv;
+    if (MODE == 1) {
+      double rho_dry = rho_new, rho_v = 0;
+      for (int v = 0; v < p.nt; v++) {
+        const double qv = c.tr[v][cpl(p, ci)];
+        if (v == p.idWV) rho_v = qv;
+        if ((p.mass_mask >> v) & 1u) rho_dry -= qv;
+      }
+      const double press = Sout[so + idT * p.sV];                   // (k_xz_state<3, ., 1> left D13's pressure in the (rho theta)' slot)
+      c.rho_d[cpl(p, ci)] = rho_dry;
+      c.temp[cpl(p, ci)] = press / (rho_dry * p.R_d + rho_v * p.R_v);
     }
-    const double press = Sout[so + idT * p.sV];                   // (k_xz_state<3, ., 1> left D13's pressure in the (rho theta)' slot)
-    c.rho_d[cpl(p, ci)] = rho_dry;
-    c.temp[cpl(p, ci)] = press / (rho_dry * p.R_d + rho_v * p.R_v);
-  }
   }
 }
 
