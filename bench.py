@@ -27,10 +27,12 @@ roofline: SURVEY.md 8(d)'s flux-stencil figure: 32 V = 256 B per cell and RK sta
           v_fma_f64 issue rate and the clock it held (mw_calib_fma64), the stage's bare arithmetic on registers (mw_calib_stage_arith: the
           time no schedule of this arithmetic can beat), the streaming copy rate -- and roofline.bound says what they imply: the stage is
           co-limited by fp64 VALU issue and HBM traffic, and the arithmetic alone caps the algorithmic HBM fraction below the 0.60 target.
-micro   : after the timed region (the headline is untouched): Kessler (two states) and the surrogate MLP on the same grid, 72 B per
+micro   : after the timed region (the headline is untouched): sustained / value_sustained (round 6: the headline's own step after 1200 back-to-back
+          steps, i.e. at the board's sustained power limit -- the timed region is the first 0.1 s after an idle start, at boost); Kessler (two states) and the surrogate MLP on the same grid, 72 B per
           cell each, and the dycore step on a state with cloud and rain (FCT limiter + y-face correction pass active):
-          developed_ms_per_step (a seeded stress state: rims everywhere) and storm.ms_per_step / value_storm (the real storm after
-          --storm-steps steps of the complete supercell_example loop).  simulation_loop / value_simulation_loop: the wall clock of that whole
+          developed_ms_per_step (a seeded stress state: rims everywhere) and storm.ms_per_step / value_storm, mature.ms_per_step /
+          value_mature (the dycore steps of the complete supercell_example loop's own last 100 iterations in front of --storm-steps and
+          --mature-steps, hipEvents around each: the states the simulation really passes through).  simulation_loop / value_simulation_loop: the wall clock of that whole
           loop -- the reference's own timed region (community_benchmark/driver.cpp:66-82), the storm developing inside it; value_storm and
           value_simulation_loop, not the cloud-free `value`, are the regression metrics.  transport_self_loop: rank 0's block of the
           1 x 2 / 2 x 2 / 4 x 2 decompositions with the built-in RCCL transport in its self-loop form (every peer is this rank on a 1-rank
@@ -77,6 +79,7 @@ def parse():
                     "micro section (0 = skip)")
     ap.add_argument("--mature-steps", type=int, default=12900, help="total steps of the same loop before the 'mature' dycore timing (12900 CFL steps = 3600 s "
                     "simulated on the 400 x 400 x 100 grid; the reference's supercell_example runs 7200 s, input_euler3d.yaml:3); 0 or <= --storm-steps = skip")
+    ap.add_argument("--sustained-steps", type=int, default=1200, help="micro section: back-to-back steps in front of the sustained-power measurement of the headline state (0 = skip)")
     ap.add_argument("--no-micro", action="store_true", help="skip the Kessler / MLP / developed-state section after the timed region")
     ap.add_argument("--no-pmc", action="store_true", help="do not start the rocprofv3 --pmc child processes that count HBM bytes / VALU "
                     "instructions of this very run's kernels (roofline.traffic, fp64_valu); the committed summary is quoted instead")
@@ -487,12 +490,19 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
         torch.cuda.synchronize()
         ps_loop = PowerSampler(rho_d.device.index or 0, period=0.05).start()      # (20 samples per second: nothing the loop would notice)
         t_loop = time.perf_counter()
-        for _ in range(a.storm_steps - 3):
+        tail_n = min(100, max(0, a.storm_steps - 3 - 1))         # the loop's last iterations carry ONE hipEvent pair per dycore step (profile 3)
+        for _ in range(a.storm_steps - 3 - tail_n):
             modules.supercell_step(c2, d2, m2, n2, dt2, defer_nudge=True)
+        d2.profile(3)
+        for _ in range(tail_n):
+            modules.supercell_step(c2, d2, m2, n2, dt2, defer_nudge=True)
+        storm_in = d2.profile_get(9)                             # (total ms, steps): the dycore steps of the loop's last iterations, inside the loop
+        d2.profile(0)
         d2.flush_pending()                                       # (inside the timed region: the loop ends with every field whole)
         torch.cuda.synchronize()
         loop_s = time.perf_counter() - t_loop
         ps_loop.stop()
+        storm_maps = (rows_full_form(d2), tiles_full_form(d2, nx))   # the maps of the loop's last dycore step: the state as the loop left it
         # (the same loop, the same process: its first seconds run on the cloud-free state, its last on the storm -- 50 ms samples, 2 s windows)
         res["power_loop"] = {"early_cloud_free": ps_loop.stats((20, 60)), "late_storm": ps_loop.stats((-40, None)),
                              "what": "50 ms samples: seconds 1-3 and the last 2 s of the simulation loop (and of its continuation to the mature state)"}
@@ -503,16 +513,25 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
                                   "simulated_seconds": dt2 * (a.storm_steps - 3), "cell_updates_per_s": ncell * (a.storm_steps - 3) / loop_s}
         res["value_simulation_loop"] = ncell * (a.storm_steps - 3) / loop_s
         res["simulation_loop"]["nudger"] = "deferred (mw_nudge_to_column_deferred: the increments are added by the next time step's conversion; flushed at the end, inside the timed region)"
-        storm_ms = timed(lambda: d2.time_step(c2, dt2), 10)
         f2 = c2.get_data_manager_readonly()
-        res["storm"] = {"state": "after %d steps of the complete supercell_example loop from the initial state" % a.storm_steps,
+        storm_extent = cloud_extent(torch, f2)
+        storm_fields = {"max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()), "rain_max": float(f2.get("precip_liquid").max())}
+        # Round 6 (late): the dycore step ON THE STORM is the one the loop itself runs there -- hipEvents around every mw_dycore_time_step of the
+        # loop's last iterations.  Rounds 4-6 timed ten back-to-back dycore steps BEHIND the loop instead; without Kessler between them (which
+        # evaporates the tiny amounts of cloud and rain that the advection stencil spreads into clear air, back to exact zeros) the set of non-zero
+        # cells grows by up to 9 cells per step in every direction, the zero-row maps fill up and every further step is slower: that figure is kept as
+        # `isolated_after` -- it measures a state the simulation never visits.
+        storm_iso = timed(lambda: d2.time_step(c2, dt2), 10)
+        storm_ms = (storm_in[0] / storm_in[1]) if storm_in[1] else storm_iso
+        res["storm"] = {"state": "the last %d iterations of the complete supercell_example loop in front of iteration %d from the initial state" % (storm_in[1], a.storm_steps),
                         "ms_per_step": storm_ms, "cell_updates_per_s": ncell / storm_ms * 1e3,
-                        "max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()),
-                        "rain_max": float(f2.get("precip_liquid").max())}
+                        "timing": "hipEvents around each mw_dycore_time_step inside the loop (the step includes the nudger's parked increments riding on its conversion)",
+                        "rows_full_form": storm_maps[0], "tiles_full_form": storm_maps[1], "extent": storm_extent,
+                        "isolated_after": {"ms_per_step": storm_iso, "cell_updates_per_s": ncell / storm_iso * 1e3, "rows_full_form": rows_full_form(d2),
+                                           "tiles_full_form": tiles_full_form(d2, nx),
+                                           "what": "12 back-to-back dycore steps behind the loop (rounds 4-6's figure): no Kessler in between, the non-zero set of cloud and rain spreads"}}
+        res["storm"].update(storm_fields)
         res["value_storm"] = ncell / storm_ms * 1e3
-        res["storm"]["rows_full_form"] = rows_full_form(d2)
-        res["storm"]["tiles_full_form"] = tiles_full_form(d2, nx)
-        res["storm"]["extent"] = cloud_extent(torch, f2)
         # the same loop iteration with the nudger's own second pass (the reference's structure), interleaved with the deferred form, at this state
         ab = {"eager": [], "deferred": []}
         for _ in range(2):
@@ -527,19 +546,32 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
             torch.cuda.synchronize()
             ps_loop = PowerSampler(rho_d.device.index or 0, period=0.05).start()
             t_loop = time.perf_counter()
-            for _ in range(more):
+            tail_n = min(100, more - 1)
+            for _ in range(more - tail_n):
                 modules.supercell_step(c2, d2, m2, n2, dt2, defer_nudge=True)
+            d2.profile(3)
+            for _ in range(tail_n):
+                modules.supercell_step(c2, d2, m2, n2, dt2, defer_nudge=True)
+            mature_in = d2.profile_get(9)
+            d2.profile(0)
             d2.flush_pending()
             torch.cuda.synchronize()
             loop2_s = time.perf_counter() - t_loop
             ps_loop.stop()
+            mature_maps = (rows_full_form(d2), tiles_full_form(d2, nx))
             res["power_loop"]["late_mature"] = ps_loop.stats((-40, None))
-            mature_ms = timed(lambda: d2.time_step(c2, dt2), 10)
-            res["mature"] = {"state": "after %d steps (%.0f s simulated) of the complete supercell_example loop from the initial state" % (a.mature_steps, a.mature_steps * dt2),
+            mature_extent = cloud_extent(torch, f2)
+            mature_fields = {"max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()), "rain_max": float(f2.get("precip_liquid").max())}
+            mature_iso = timed(lambda: d2.time_step(c2, dt2), 10)
+            mature_ms = (mature_in[0] / mature_in[1]) if mature_in[1] else mature_iso
+            res["mature"] = {"state": "the last %d iterations in front of iteration %d (%.0f s simulated) of the complete supercell_example loop from the initial state" % (mature_in[1], a.mature_steps, a.mature_steps * dt2),
                              "ms_per_step": mature_ms, "cell_updates_per_s": ncell / mature_ms * 1e3,
-                             "max_abs_w": float(f2.get("wvel").abs().max()), "cloud_max": float(f2.get("cloud_liquid").max()),
-                             "rain_max": float(f2.get("precip_liquid").max()), "rows_full_form": rows_full_form(d2), "tiles_full_form": tiles_full_form(d2, nx), "extent": cloud_extent(torch, f2),
+                             "timing": "hipEvents around each mw_dycore_time_step inside the loop (see storm)",
+                             "rows_full_form": mature_maps[0], "tiles_full_form": mature_maps[1], "extent": mature_extent,
+                             "isolated_after": {"ms_per_step": mature_iso, "cell_updates_per_s": ncell / mature_iso * 1e3, "rows_full_form": rows_full_form(d2),
+                                                "tiles_full_form": tiles_full_form(d2, nx), "what": "12 back-to-back dycore steps behind the loop (see storm)"},
                              "loop_ms_per_step_storm_to_mature": loop2_s / more * 1e3, "loop_cell_updates_per_s_storm_to_mature": ncell * more / loop2_s}
+            res["mature"].update(mature_fields)
             res["value_mature"] = ncell / mature_ms * 1e3
             res["simulation_loop"]["to_mature"] = {"steps": a.mature_steps - 3, "seconds": loop_s + loop2_s,
                                                    "ms_per_step": (loop_s + loop2_s) / (a.mature_steps - 3) * 1e3,
@@ -577,6 +609,31 @@ def micro_section(torch, modules, coupler, dycore, micro, dt, a):
             res["transport_self_loop"] = emu
         except Exception as e:                                   # evidence, not the measurement
             res["transport_self_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ---- the SUSTAINED step on the headline's own state (round 6, late): the timed region above is the first 0.1 s of GPU work after an idle
+    # start -- the package-power average has not reached the board's 1400 W limit yet and the clock is at its boost.  A run that keeps stepping
+    # settles on the limit within ~1.5 s (tools: --warmup 300 / 1000), and every step of a simulation runs there.  Same cloud-free initial state
+    # on a fresh handle, a.sustained_steps steps back to back, the last 200 timed (cloud and rain stay exactly zero without microphysics).
+    if a.sustained_steps > 0:
+        xlen, ylen = float(coupler.get_xlen()), float(coupler.get_ylen())
+        c4, d4, _m4 = modules.make_supercell(nx, ny, nz, nens, xlen, ylen, 20000.0, "supercell", rho_d.device, ord=a.ord)
+        dt4 = d4.compute_time_step(c4)
+        ps4 = PowerSampler(rho_d.device.index or 0, period=0.05).start()
+        for _ in range(a.sustained_steps):
+            d4.time_step(c4, dt4)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            d4.time_step(c4, dt4)
+        e1.record()
+        torch.cuda.synchronize()
+        ps4.stop()
+        sus_ms = e0.elapsed_time(e1) / 200
+        res["sustained"] = {"what": "the headline's workload and state (cloud-free initial state, dycore only) after %d back-to-back steps: 200 steps timed with the card at "
+                                    "its sustained power limit; `value` is the same step in the first 0.1 s after an idle start" % a.sustained_steps,
+                            "ms_per_step": sus_ms, "cell_updates_per_s": ncell / sus_ms * 1e3, "power_last_second": ps4.stats((-20, None))}
+        res["value_sustained"] = ncell / sus_ms * 1e3
+        del c4, d4, _m4
+        torch.cuda.empty_cache()
     return res
 
 
@@ -1033,6 +1090,7 @@ def main():
             out["config"]["value_storm"] = out.get("value_storm")
             out["config"]["value_developed"] = out.get("value_developed")
             out["config"]["value_mature"] = out.get("value_mature")
+            out["config"]["value_sustained"] = out.get("value_sustained")
             out["power"]["simulation_loop"] = out.pop("power_loop", None)
             # ---- the roofline figure, state by state (the headline state is the best case: cloud and rain identically zero).  frac = SURVEY.md
             # 8(d)'s 32 V B per cell and stage with V = 8; frac_moved = the same with the variables that actually move: the six that are
@@ -1050,13 +1108,17 @@ def main():
                 return e
             out["roofline"]["frac_by_state"] = {
                 "cloud_free": _state(stage_ms * 3.0, 0.0 if out["config"]["zero_row_maps"] else 1.0, 0.0 if out["config"]["zero_row_maps"] else 1.0),
+                "cloud_free_sustained": _state((out.get("sustained") or {}).get("ms_per_step"), 0.0 if out["config"]["zero_row_maps"] else 1.0, 0.0 if out["config"]["zero_row_maps"] else 1.0),
                 "storm": _state((out.get("storm") or {}).get("ms_per_step"), (out.get("storm") or {}).get("rows_full_form"), (out.get("storm") or {}).get("tiles_full_form")),
                 "developed": _state(out.get("developed_ms_per_step"), out.get("developed_rows_full_form"), out.get("developed_tiles_full_form")),
                 "mature": _state((out.get("mature") or {}).get("ms_per_step"), (out.get("mature") or {}).get("rows_full_form"), (out.get("mature") or {}).get("tiles_full_form")),
                 "what": "frac = 32 V B (V = 8) x cells / (ms_per_step / 3) / 8 TB/s per state; rows_full_form = share of (level, row) words of the stage maps in "
                         "which cloud or rain may be non-zero; tiles_full_form = the same per 58-cell x tile (the x segments of the maps: the fused tracer kernel's FULL "
-                        "iterations); frac_moved prices only the variables that move: 6 + 2 x tiles_full_form.  cloud_free = the headline state (this line's roofline.frac); storm = 725 s into the run; developed = a seeded stress "
-                        "state with cloud / rain rims everywhere; mature = 3600 s into the run"}
+                        "iterations); frac_moved prices only the variables that move: 6 + 2 x tiles_full_form.  cloud_free = the headline state (this line's roofline.frac), timed over the first 0.1 s after an idle start; cloud_free_sustained = the same state and step "
+                        "after 1200 back-to-back steps, the card at its 1400 W limit (every state below runs there); storm = 725 s into the run, "
+                        "mature = 3600 s into the run: the dycore steps of the loop's own last 100 iterations in front of those times, hipEvents around each "
+                        "(storm.isolated_after / mature.isolated_after = rounds 4-6's figure, back-to-back dycore steps behind the loop: a state the simulation never visits); "
+                        "developed = a seeded stress state with cloud / rain rims everywhere"}
             out["roofline"]["state"] = "cloud_free (headline; see frac_by_state for the storm / developed / mature states)"
         if world == 1 and not a.no_cpu_baseline:
             progress("cpu baseline ...")
