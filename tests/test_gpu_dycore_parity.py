@@ -271,12 +271,13 @@ def test_unsupported_options_fail_loudly(mw):
 
 @pytest.mark.parametrize("overlap", ["0", "1"])
 @pytest.mark.parametrize("fused", ["1", "0"])
-@pytest.mark.parametrize("shape", [(70, 9, 12, 1), (23, 6, 11, 2), (64, 1, 9, 1)])
+@pytest.mark.parametrize("shape", [(70, 9, 12, 1), (23, 6, 11, 2), (64, 1, 9, 1), (64, 7, 10, 1), (20, 5, 9, 2)])
 def test_fct_limiter_heavy(mw, oracle, fused, shape, monkeypatch, overlap):
     """(overlap: the two-stream schedule -- state | tracer pipelines, the default with a neighbour exchange -- or one stream.)
     Sparse cloud/rain blobs in a strong random wind: the FCT multiplier is < 1 in a large share of the cells, in all three
     directions and across wave (x tile), row and z-chunk edges.  fused=1: k_tracers_fused + k_tracer_patch (y faces scaled
-    by a donor in another row are corrected afterwards); fused=0: k_xz_tracers + k_tracer_update."""
+    by a donor in another row are corrected afterwards); fused=0: k_xz_tracers + k_tracer_update.
+    (Rows of 64 and 2 x 20 = 40 cells: k_tracer_patch reads its flag bytes as 8-byte words; 70 and 46: byte by byte.)"""
     from miniweatherml_amd import modules
     nx, ny, nz, nens = shape
     set_options(monkeypatch, fused_tracers=fused, overlap=overlap, chunk_f=4, chunk_z=4)
@@ -311,12 +312,14 @@ def test_fct_limiter_heavy(mw, oracle, fused, shape, monkeypatch, overlap):
     assert np.max(np.abs(fnof.tracers[1] - of.tracers[1])) > 1e-3 * np.max(np.abs(of.tracers[1]))
 
 
-def test_fct_patch_pass_is_exercised(mw, oracle, monkeypatch):
+@pytest.mark.parametrize("shape", [(70, 9, 12, 1), (64, 7, 10, 1)])
+def test_fct_patch_pass_is_exercised(mw, oracle, monkeypatch, shape):
     """Negative control for the test above: with the y-face correction pass switched off the fused path must MISS the
-    oracle on the limiter-heavy case (i.e. donors in neighbouring rows really do scale y faces there)."""
+    oracle on the limiter-heavy case (i.e. donors in neighbouring rows really do scale y faces there) -- on a row length that
+    k_tracer_patch scans byte by byte and on one it scans in 8-byte words."""
     set_options(monkeypatch, debug_no_patch=1)
     with pytest.raises(AssertionError):
-        test_fct_limiter_heavy(mw, oracle, "1", (70, 9, 12, 1), monkeypatch, "0")
+        test_fct_limiter_heavy(mw, oracle, "1", shape, monkeypatch, "0")
 
 
 def test_large_perturbation_takes_the_pow_fallback(mw, oracle):
