@@ -75,3 +75,30 @@ def test_bench_config4_block_under_the_torchrun_launcher():
     assert r0["ms_per_step"] > 1.0 and r0["one_rank_block_ms_per_step"] > 1.0
     assert 0.5 < m["efficiency_in_run"] < 1.5                   # one rank: the block IS the job
     assert "rccl_ranks_seen" in m and "ms_per_step_max_over_ranks" in m
+
+
+@pytest.mark.gpu
+def test_bench_micro_section_on_a_small_block():
+    """The sections behind the timed region on a grid that takes seconds: the step at the sustained power limit, the storm / mature figures timed
+    INSIDE the loop (hipEvents around the loop's own dycore steps) with the back-to-back figure of rounds 4-6 beside them, the state-qualified
+    roofline, the RCCL self-loop blocks."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--nx", "96", "--ny", "96", "--nz", "40", "--steps", "3", "--warmup", "1", "--storm-steps", "160",
+           "--mature-steps", "330", "--sustained-steps", "40", "--no-pmc", "--no-calib", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["value_sustained"] > 0 and d["sustained"]["ms_per_step"] > 0 and d["config"]["value_sustained"] == d["value_sustained"]
+    for k, total in (("storm", 160), ("mature", 330)):
+        s = d[k]
+        assert s["ms_per_step"] > 0 and "inside the loop" in s["timing"] and ("iteration %d" % total) in s["state"]
+        assert s["isolated_after"]["ms_per_step"] > 0
+        assert 0.0 <= s["tiles_full_form"] <= s["isolated_after"]["tiles_full_form"] <= 1.0      # without Kessler in between the non-zero set only grows
+        assert d["value_" + k] == s["cell_updates_per_s"]
+    f = d["roofline"]["frac_by_state"]
+    for k in ("cloud_free", "cloud_free_sustained", "storm", "mature", "developed"):
+        assert f[k]["frac"] > 0 and f[k]["ms_per_step"] > 0, k
+    assert d["simulation_loop"]["steps"] == 157 and d["simulation_loop"]["to_mature"]["steps"] == 327
+    assert d["value_simulation_loop"] > 0 and d["value_developed"] > 0 and d["kessler"] and d["mlp"]
