@@ -690,6 +690,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a)                                           # does not return
     import threading
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # (before anything initialises the GPU: the host driver only supports dmabuf IPC)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
