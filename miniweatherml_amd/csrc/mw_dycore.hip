@@ -45,13 +45,25 @@ enum { idR = 0, idU = 1, idV = 2, idW = 3, idT = 4 };
 static constexpr int HXc = 3;     // x/y halo: 2 for the stencil + 1 so that the neighbour's edge value is rebuilt locally
 static constexpr int HZc = 2;     // z halo: z faces at the domain boundary use the edge-value BC rule, not ghost cells
 
+// A row / level / variable stride in elements.  It fits 32 bits on any handle that fits the GPU (one variable of a slab with 2^31 doubles is 16 GB,
+// and a handle keeps 4 slabs of >= 6 variables; strides_fit() refuses anything else at create), and every use is a
+// product with a 32-bit index: held as an int that converts to long long, `(long long)idx * stride` is a 32 x 32 -> 64 multiply (s_mul_i32 +
+// s_mul_hi_i32) instead of the 64 x 64 one (7 scalar instructions) -- the marching kernels derive a dozen such offsets from the level index in
+// every iteration (no SGPRs to keep them), and at two waves per SIMD a wave's scalar instructions delay its own vector ones.  No int arithmetic can
+// overflow through it: the only way out is the conversion.
+struct Stride32 {
+  int v;
+  __host__ __device__ __forceinline__ operator long long() const { return (long long)v; }
+  __host__ __device__ __forceinline__ Stride32 &operator=(long long x) { v = (int)x; return *this; }
+};
+
 struct DyP {                      // kernel parameter block (by value)
   int nz, ny, nx, nens, nt, V;
   int HX, HY, HZ;
   int NXE;                        // (nx+2HX)*nens
-  long long sJ, sK, sV;           // strides of the prognostic slabs
-  long long nC;                   // nz*ny*nx*nens
-  long long fxJ, fxK, fxV, fyJ, fyK, fyV, fzJ, fzK, fzV;   // flux strides
+  Stride32 sJ, sK, sV;            // row / level / variable strides of the prognostic slabs
+  Stride32 nC;                    // nz*ny*nx*nens
+  Stride32 fxJ, fxK, fxV, fyJ, fyK, fyV, fzJ, fzK, fzV;   // flux strides
   int sim2d, bc_x, bc_y, bc_z, px, py, nproc_x, nproc_y;
   int v0;                         // halo/pack kernels: index of the first variable of the group being processed
   int cst, ce;                    // coupler-side stride / member offset (1, 0; member-major mode: nens, member) -- see cpl() in mw_march.h
@@ -994,6 +1006,7 @@ struct mw_dycore_s {
   double *pinc = nullptr; bool pinc_on = false; double *pinc_fields[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // parked column increments (mw_nudge_to_column_deferred) and the five arrays they belong to
   unsigned long long pinc_lazy = 0, pinc_eager = 0;             // how often parked increments rode on the conversion / were applied by a pass
   unsigned *zr = nullptr; long long zr_msz = 0; bool zr_on = false;   // zero-row maps (M0 and the six of k_zero_dilate) of the running sub-cycle (mw_march.h: k_zero_rows), zr_msz words each
+  bool strides_ok = true;                  // fill_params: every stride of DyP fits its Stride32
   int fused = 0;                           // 1: fused tracer stage (k_tracers_fused + k_tracer_patch)
   double *hy_dev = nullptr;                  // hyc | hytc | hye | hyte | p0c | ihytc | p0e | ihyte | packed rows (see DyP::hypk)
   double *imm = nullptr;
@@ -1035,6 +1048,9 @@ static void fill_params(mw_dycore_s *d) {
   p.fxJ = (long long)(g.nx + 1) * g.nens; p.fxK = (long long)g.ny * p.fxJ;       p.fxV = (long long)g.nz * p.fxK;
   p.fyJ = (long long)g.nx * g.nens;       p.fyK = (long long)(g.ny + 1) * p.fyJ; p.fyV = (long long)g.nz * p.fyK;
   p.fzJ = (long long)g.nx * g.nens;       p.fzK = (long long)g.ny * p.fzJ;       p.fzV = (long long)(g.nz + 1) * p.fzK;
+  // (Stride32: the largest stride is a slab's variable stride; the products above were formed from converted values, so check it in 64 bits)
+  d->strides_ok = (long long)(g.nz + 2 * p.HZ) * (long long)(g.ny + 2 * p.HY) * (long long)p.NXE <= 2147483647ll &&
+                  (long long)(g.nz + 1) * (long long)(g.ny + 1) * (long long)(g.nx + 1) * g.nens <= 2147483647ll;
   p.v0 = 0; p.wrap_x = 0; p.wrap_y = 0; p.cst = 1; p.ce = 0;
   p.bc_x = g.bc_x; p.bc_y = g.bc_y; p.bc_z = g.bc_z; p.px = g.px; p.py = g.py; p.nproc_x = g.nproc_x; p.nproc_y = g.nproc_y;
   p.enable_gravity = g.enable_gravity; p.use_immersed = g.use_immersed; p.idWV = g.idWV;
@@ -2152,6 +2168,7 @@ int mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tr
   auto fail = [&](void) { mw_dycore_destroy(d); return 1; };
   if (hipMalloc(&d->hy_dev, d->hy_host.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(hy) failed"); return fail(); }
   fill_params(d);
+  if (!d->strides_ok) { set_error("mw_dycore_create: a variable of this block has more than 2^31 - 1 elements (16 GB): too large for one handle"); return fail(); }
   const DyP &p = d->p;
   size_t slab = (size_t)p.V * p.sV * sizeof(double);
   size_t fxb = (size_t)p.V * p.fxV * sizeof(double), fyb = (size_t)p.V * p.fyV * sizeof(double), fzb = (size_t)p.V * p.fzV * sizeof(double);
@@ -2282,6 +2299,7 @@ int mw_dycore_set_order(mw_dycore_t d, int ord) {
   auto rollback = [&]() { d->ord = old_ord; d->hxw = old_hx; d->hzw = old_hz; fill_params(d); return 1; };
   d->ord = ord; d->hxw = hx; d->hzw = hz;
   fill_params(d);
+  if (!d->strides_ok) { set_error("mw_dycore_set_order: with this order's halo a variable of the block has more than 2^31 - 1 elements"); return rollback(); }
   if (check_halo_fit(d)) return rollback();
   if (hx != old_hx || hz != old_hz) {
     MW_HIP(hipStreamSynchronize(d->stream));

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void k_y_state(DyP p, const double *__restr
   // CONV: row r (halo rows wrap) comes from the coupler; the rows ja..jb-1 are this chunk's to store.  The row is REQUESTED at the
   // top of an iteration and converted at its end, when the values have arrived.
   const int hi = k * p.nens + e;
-#define MW_ROW_CI(r) cpl(p, ((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
+#define MW_ROW_CI(r) cpl(p, (long long)(k * p.ny + wrap_row(p, (r))) * NXI + ie)
 #define MW_ROW_FINISH(raw, r, out5)                                                                                   \
   { double inv_den_;                                                                                                  \
     convert_cell_fast<K>(p, raw, hyr, hyt, p0, out5, inv_den_);   /* (the row's background values are in registers already) */ \
@@ -939,7 +939,7 @@ __global__ __launch_bounds__(256, 2) void k_y_all(DyP p, const double *__restric
   const bool pre_on_ = pre_lo < pre_hi;
   const int sja_ = pre_on_ ? max(ja, pre_lo) : ja;
   const int sjb_ = (pre_on_ && (ie < p.HX * p.nens || ie >= NXI - p.HX * p.nens)) ? sja_ : (pre_on_ ? min(jb, pre_hi) : jb);
-#define MW_ROW_CI(r) cpl(p, ((long long)k * p.ny + wrap_row(p, (r))) * NXI + ie)
+#define MW_ROW_CI(r) cpl(p, (long long)(k * p.ny + wrap_row(p, (r))) * NXI + ie)
   constexpr unsigned VANM = (K == 1) ? (((1u << T) - 1u) & ~1u) : ((1u << T) - 1u);        // (= tracer_may_vanish<K>)
   /* the coupler's value + its parked column increment: the addition ColumnNudger's second pass would have stored (rounded once, no contraction) */
 #define MW_ROW_NUDGE(raw)                                                                                             \
@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(256, 2) void k_xz_state(DyP p, const double *__rest
   const double *col = S + (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qa;           // level k at col + (k+HZ)*sK
   const long long cell0 = (long long)j * NXI + g.qc;                                           // + k*ny*NXI
   const long long slab0 = (long long)(j + p.HY) * p.sJ + (long long)p.HX * n + g.qc;           // + (k+HZ)*sK
-  const long long planeC = (long long)p.ny * NXI;
+  const int planeC = p.ny * NXI;                                                                  // (cells of a level: < 2^31, see Stride32 -- every product below is 32 x 32 -> 64)
   // The two per-cell carries that are written once and read once per level (the x+y part of the tendency and the lower z-face
   // flux) live in LDS, one private slot per thread: 20 VGPRs less in a kernel that sits at the 256-register limit (measured:
   // -5 % run time; moving more carries there, or doing the same in k_y_state / k_tracers_fused, was slower).
@@ -1970,14 +1970,14 @@ __global__ __launch_bounds__(256, 2) void k_tracers_fused(DyP p, const double *_
 #pragma unroll
       for (int v = 0; v < T; v++) if (MW_ACT(v)) { landed(nxt[v]); landed(xpn[v]); landed(qn_[v]); }   // in front of the iteration's stores (see landed())
       landed(rho_new); landed(rho_n); landed(st_T);
-      if (rec && do_y) flags[((long long)kp * p.ny + j) * NXI + q] = (unsigned char)fl;     // 2 bits per tracer: (south, north) face scaled
+      if (rec && do_y) flags[(long long)(kp * p.ny + j) * NXI + q] = (unsigned char)fl;     // 2 bits per tracer: (south, north) face scaled
       if (__builtin_expect(fl != 0u, 0)) *dirty = 1u;           // (only set inside `rec`) lets k_tracer_patch return at once when nothing was scaled
     }
     // ------------------------------------------------ S3: cell k-2 -> new value
     {
 #pragma clang fp contract(off)
       const bool st = s3 && upd;
-      const long long ci = ((long long)kuc * p.ny + j) * NXI + qm;
+      const long long ci = (long long)(kuc * p.ny + j) * NXI + qm;                 // (row number and row length are 32-bit: one 32 x 32 -> 64 multiply)
       const double inv_rho_new = fast_rcp(rho_new);
       double rho_dry = rho_new, rho_v = 0;
 #pragma unroll
