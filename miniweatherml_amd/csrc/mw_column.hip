@@ -72,22 +72,39 @@ __global__ __launch_bounds__(256) void k_hsum_finish(const double *__restrict__ 
 }
 
 // sponge_layer.h:66-76
+static constexpr int SPONGE_NPT = 4;
 __global__ __launch_bounds__(256) void k_sponge_apply(FieldPtrs fp, int num_fields, int num_layers, int nz, long long ncell_lev, int nens,
                                                       double zlen, double dz, double time_factor, double nglob,
                                                       const double *__restrict__ havg) {
 #pragma clang fp contract(off)
-  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const int kloc = blockIdx.y, ifld = blockIdx.z;
-  if (t >= ncell_lev * nens) return;
-  const int e = (int)(t % nens);
   const int k = nz - 1 - kloc;
-  double z = (k + 0.5) * dz;
-  double rel_dist = (zlen - z) / (num_layers * dz);
-  double space_factor = (cos_glibc(M_PI * rel_dist) + 1) / 2;
-  double factor = space_factor * time_factor;
-  double *q = fp.f[ifld] + (long long)k * ncell_lev * nens + t;
-  double v = *q;
-  *q = v + (havg[(ifld * num_layers + kloc) * nens + e] / nglob - v) * factor;
+  // the relaxation factor depends on the level alone and the target on (field, level, member): the reference's expressions, evaluated by
+  // the block's first threads once instead of by every cell (a cosine and a division per cell: the pass took twice its bytes' time)
+  __shared__ double sh_factor, sh_target[64];
+  if (threadIdx.x == 0) {
+    double z = (k + 0.5) * dz;
+    double rel_dist = (zlen - z) / (num_layers * dz);
+    double space_factor = (cos_glibc(M_PI * rel_dist) + 1) / 2;
+    sh_factor = space_factor * time_factor;
+  }
+  if ((int)threadIdx.x < min(nens, 64)) sh_target[threadIdx.x] = havg[(ifld * num_layers + kloc) * nens + threadIdx.x] / nglob;
+  __syncthreads();
+  // four cells per thread, 256 apart, their loads issued together (one cell per thread kept one load in flight: 2 TB/s)
+  const double factor = sh_factor;
+  const long long n = ncell_lev * nens, t0 = (long long)blockIdx.x * (256 * SPONGE_NPT) + threadIdx.x;
+  double *base = fp.f[ifld] + (long long)k * n;
+  double v[SPONGE_NPT];
+#pragma unroll
+  for (int i = 0; i < SPONGE_NPT; i++) { const long long ti = t0 + (long long)i * 256; v[i] = (ti < n) ? base[ti] : 0.0; }
+#pragma unroll
+  for (int i = 0; i < SPONGE_NPT; i++) {
+    const long long ti = t0 + (long long)i * 256;
+    if (ti >= n) continue;
+    const int e = (int)(ti % nens);
+    const double target = (e < 64) ? sh_target[e] : havg[(ifld * num_layers + kloc) * nens + e] / nglob;
+    base[ti] = v[i] + (target - v[i]) * factor;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_div_scalar(double *__restrict__ a, long long n, double d) {
@@ -174,7 +191,7 @@ int mw_sponge_layer(const mw_grid_t *g, double *const *fields, int num_fields, d
   double *partial = havg + (long long)num_fields * num_layers * g->nens;
   if (hsum(g, fp, num_fields, num_layers, g->nz - 1, -1, WFLD, havg, partial, allreduce, ctx, st)) return 1;
   const long long ncell_lev = (long long)g->ny * g->nx;
-  dim3 grid((unsigned)((ncell_lev * g->nens + 255) / 256), (unsigned)num_layers, (unsigned)num_fields);
+  dim3 grid((unsigned)((ncell_lev * g->nens + 256 * SPONGE_NPT - 1) / (256 * SPONGE_NPT)), (unsigned)num_layers, (unsigned)num_fields);
   const double dz = g->zlen / g->nz;
   const double nglob = (double)((unsigned long long)g->nx_glob * (unsigned long long)g->ny_glob);      // size_t product (:75)
   hipLaunchKernelGGL(k_sponge_apply, grid, dim3(256), 0, st, fp, num_fields, num_layers, g->nz, ncell_lev, g->nens, g->zlen, dz,
