@@ -269,6 +269,33 @@ def test_unsupported_options_fail_loudly(mw):
         dycore.time_step(coupler, 0.0)
 
 
+def test_a_block_whose_strides_leave_32_bits_is_refused(mw):
+    """The kernels' row / level / variable strides are 32-bit values (Stride32, csrc/mw_dycore.hip): a block with a variable of 2^31 or more
+    elements (16 GB; four slabs of six of them would not fit the GPU) must be refused at create -- before any large allocation -- not
+    wrapped around.  The order change that widens the halo is held to the same rule."""
+    import ctypes as C
+    from miniweatherml_amd import capi, modules
+    from miniweatherml_amd.capi import MWError
+    L = capi.lib()
+    coupler, dycore, _ = modules.make_supercell(8, 8, 8, 1, 4000., 4000., 20000.)
+    g = capi.Grid()
+    capi.check(L.mw_dycore_get_grid(dycore.h, C.byref(g)))
+    g.nz, g.ny, g.ny_glob, g.nx, g.nx_glob = 1500, 1500, 1500, 1000, 1000        # (1504 x 1506 x 1006 = 2.28e9 elements per slab variable)
+    h = C.c_void_p()
+    free0 = torch_free()
+    rc = L.mw_dycore_create(C.byref(h), C.byref(g), bytes([1, 1, 1]), bytes([1, 1, 1]), None)
+    assert rc != 0 and "2^31" in L.mw_last_error().decode()
+    assert free0 - torch_free() < (1 << 30)                                      # nothing of the 18 GB slabs was allocated on the way
+    g.nz, g.ny, g.ny_glob, g.nx, g.nx_glob = 1319, 1276, 1276, 1270, 1270        # 1323 x 1282 x 1276 = 2.164e9 > 2^31 - 1 > 1319 x 1276 x 1270 ... just over
+    assert L.mw_dycore_create(C.byref(h), C.byref(g), bytes([1, 1, 1]), bytes([1, 1, 1]), None) != 0
+
+
+def torch_free():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
 @pytest.mark.parametrize("overlap", ["0", "1"])
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("shape", [(70, 9, 12, 1), (23, 6, 11, 2), (64, 1, 9, 1), (64, 7, 10, 1), (20, 5, 9, 2)])
