@@ -65,7 +65,9 @@ double mw_dycore_compute_time_step(const mw_grid_t *g);
 /* Allocates the device workspace (two halo'd prognostic slabs + six flux arrays, reused across calls --
  * the reference re-allocates them every call/cycle/stage, :97-98,:112-115,:260-265).  `stream` is a
  * hipStream_t (NULL = default stream); all work of this handle is ordered on it.
- * tracer_positive / tracer_adds_mass: host arrays [num_tracers], Coupler::get_tracer_info (:1285-1293). */
+ * tracer_positive / tracer_adds_mass: host arrays [num_tracers], Coupler::get_tracer_info (:1285-1293).
+ * Fails (before any large allocation) when one variable of the block's halo'd slab has 2^31 or more elements (16 GB): the kernels keep
+ * their strides in 32 bits, and four slabs of such variables would not fit the GPU anyway. */
 int  mw_dycore_create(mw_dycore_t *h, const mw_grid_t *g, const unsigned char *tracer_positive,
                       const unsigned char *tracer_adds_mass, void *stream);
 void mw_dycore_destroy(mw_dycore_t h);
